@@ -1,0 +1,301 @@
+/* shimmer_hip.h — C ABI of libshimmer_hip.so: the MI355X (gfx950) wavefront path tracer that drops in
+ * behind Shimmer's `Integrator::render()`.
+ *
+ * The reference has no FFI/plugin interface; its only seam is
+ *     pub trait Integrator { fn render(&mut self, options: &Options); }      (src/integrator.rs:52-54)
+ * constructed by create_integrator(name, params, camera, sampler, aggregate, lights, color_space)
+ * (src/integrator.rs:16-42) and invoked once from render_cpu (src/render.rs:51-54).  A GPU backend is a
+ * new `impl Integrator` whose render() marshals the already-built scene objects (flattened BVH of
+ * src/aggregate.rs:471-481, triangle meshes of src/shape/mesh.rs:9-20, materials, lights, camera, film
+ * sensor) into the flat POD arrays below and calls shm_scene_create + shm_render_wave per spp-wave
+ * (src/integrator.rs:241-320), then reads the film sums back.  INTEGRATION.md shows that Rust shim.
+ *
+ * Conventions: every function returns 0 (SHM_OK) or a negative ShmError; nothing throws, aborts or
+ * unwinds across this boundary (the reference panics; a Rust caller maps codes to Result).  All pointers
+ * are borrowed for the duration of the call only; the library copies what it keeps.  Everything is
+ * little-endian f32/u32/i32 unless stated.  One in-flight render per ShmScene; distinct scenes may be
+ * used from distinct host threads.  No callbacks into the host.
+ */
+#ifndef SHIMMER_HIP_H
+#define SHIMMER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHM_ABI_VERSION 1
+
+typedef enum ShmError {
+    SHM_OK = 0,
+    SHM_ERR_INVALID_ARGUMENT = -1,
+    SHM_ERR_UNSUPPORTED = -2,   /* scene uses a feature outside the contracted path */
+    SHM_ERR_DEVICE = -3,        /* HIP runtime error; see shm_last_error() */
+    SHM_ERR_NO_DEVICE = -4,     /* no gfx950 device visible: there is NO CPU fallback */
+    SHM_ERR_OUT_OF_MEMORY = -5,
+    SHM_ERR_INTERNAL = -6
+} ShmError;
+
+/* ---- geometry -------------------------------------------------------------------------------- */
+
+/* LinearBvhNode (src/aggregate.rs:471-481; 64 B in the reference) narrowed to 32 B.
+ * DFS order: first child of interior node i is i+1; `offset` is second_child_offset (interior) or
+ * primitive_offset into the leaf-ordered primitive list (leaf); n_prims > 0 marks a leaf. */
+typedef struct ShmBvhNode {
+    float bmin[3];
+    float bmax[3];
+    uint32_t offset;
+    uint16_t n_prims;
+    uint8_t axis;
+    uint8_t pad;
+} ShmBvhNode;
+
+/* TriangleMesh (src/shape/mesh.rs:9-20), vertices already in render space (mesh.rs:43-46). */
+typedef struct ShmTriangleMesh {
+    uint32_t n_triangles;
+    uint32_t n_vertices;
+    const uint32_t* vertex_indices; /* 3*n_triangles (the reference's Vec<usize>, narrowed) */
+    const float* p;                 /* 3*n_vertices */
+    const float* n;                 /* 3*n_vertices or NULL */
+    const float* s;                 /* 3*n_vertices or NULL */
+    const float* uv;                /* 2*n_vertices or NULL */
+    uint8_t reverse_orientation;
+    uint8_t transform_swaps_handedness;
+    uint8_t pad[6];
+} ShmTriangleMesh;
+
+/* Sphere (src/shape/sphere.rs:27-38); matrices row-major m[r][c] as SquareMatrix<4>. */
+typedef struct ShmSphere {
+    float radius, z_min, z_max, theta_z_min, theta_z_max, phi_max;
+    float render_from_object[16];
+    float object_from_render[16];
+    uint8_t reverse_orientation;
+    uint8_t transform_swaps_handedness;
+    uint8_t pad[6];
+} ShmSphere;
+
+enum { SHM_SHAPE_TRIANGLE = 0, SHM_SHAPE_SPHERE = 1 };
+
+/* GeometricPrimitive / SimplePrimitive (src/primitive.rs:66-130): shape + material (+ area light).
+ * Listed in the order of BvhAggregate::primitives AFTER the build's reordering (aggregate.rs:270),
+ * i.e. leaf node `offset` indexes this array directly. */
+typedef struct ShmPrimitive {
+    uint32_t shape_kind;   /* SHM_SHAPE_* */
+    uint32_t shape_index;  /* triangle: global triangle index (mesh base + tri_index); sphere: index */
+    uint32_t material;     /* index into materials */
+    int32_t area_light;    /* index into lights, or -1 */
+} ShmPrimitive;
+
+/* ---- spectra, materials, lights -------------------------------------------------------------- */
+
+enum {
+    SHM_SPECTRUM_CONSTANT = 0,         /* ConstantSpectrum          (spectra/spectrum.rs:143-166) */
+    SHM_SPECTRUM_DENSE = 1,            /* DenselySampledSpectrum, lambda_min..=lambda_max, 1 nm (:168-291) */
+    SHM_SPECTRUM_PIECEWISE_LINEAR = 2  /* PiecewiseLinearSpectrum   (:293-428): n lambdas then n values */
+};
+typedef struct ShmSpectrum {
+    uint32_t kind;
+    float c;              /* CONSTANT */
+    uint32_t offset;      /* DENSE / PIECEWISE: first float in ShmSceneDesc::spectrum_data */
+    uint32_t n;           /* DENSE: number of samples; PIECEWISE: number of knots */
+    int32_t lambda_min;   /* DENSE */
+    uint32_t pad[3];
+} ShmSpectrum;
+
+enum {
+    SHM_MATERIAL_DIFFUSE = 0,         /* material.rs:247-332 */
+    SHM_MATERIAL_CONDUCTOR = 1,       /* material.rs:334-516 */
+    SHM_MATERIAL_DIELECTRIC = 2,      /* material.rs:518-650 */
+    SHM_MATERIAL_THIN_DIELECTRIC = 3  /* material.rs:652-768 */
+};
+/* Constant textures only (image textures are a "next" row). */
+typedef struct ShmMaterial {
+    uint32_t kind;
+    uint32_t has_displacement; /* Diffuse: always 1 with a constant-0 texture (material.rs:280, quirk 8) */
+    float displacement;        /* the constant displacement value */
+    uint32_t remap_roughness;
+    float u_roughness, v_roughness;
+    uint32_t pad[2];
+    ShmSpectrum a;  /* Diffuse: reflectance; Conductor: eta; Dielectric/Thin: eta */
+    ShmSpectrum b;  /* Conductor: k */
+} ShmMaterial;
+
+enum {
+    SHM_LIGHT_POINT = 0,            /* light.rs:392-497 */
+    SHM_LIGHT_DIFFUSE_AREA = 1,     /* light.rs:499-690; one per emissive shape (loading/scene.rs:609-624) */
+    SHM_LIGHT_UNIFORM_INFINITE = 2  /* light.rs:692-816 */
+};
+typedef struct ShmLight {
+    uint32_t kind;
+    uint32_t primitive;    /* DIFFUSE_AREA: index into primitives (leaf order) of its shape */
+    float scale;           /* final scale (after /spectrum_to_photometric, power...) */
+    uint32_t two_sided;
+    float position[3];     /* POINT: render_from_light(0,0,0) */
+    float area;            /* DIFFUSE_AREA: shape.area() (light.rs:543) */
+    ShmSpectrum spectrum;  /* DenselySampledSpectrum of I / Lemit (must be DENSE) */
+} ShmLight;
+
+/* ---- camera, film ---------------------------------------------------------------------------- */
+
+/* PerspectiveCamera (camera.rs:866-963) after construction. Matrices row-major. */
+typedef struct ShmCamera {
+    float camera_from_raster[16];
+    float render_from_camera[16];
+    float dx_camera[3];
+    float dy_camera[3];
+    float lens_radius;
+    float focal_distance;
+    float shutter_open, shutter_close;
+} ShmCamera;
+
+/* RgbFilm + PixelSensor (film.rs:470-574, 754-914) + BoxFilter radius (filter.rs:61-105). */
+typedef struct ShmFilm {
+    int32_t pixel_bounds[4];      /* min.x, min.y, max.x, max.y (max exclusive) */
+    int32_t full_resolution[2];
+    float filter_radius[2];
+    float imaging_ratio;
+    float max_component_value;
+    const float* sensor_r_bar;    /* DenselySampledSpectrum 360..=830, 471 floats */
+    const float* sensor_g_bar;
+    const float* sensor_b_bar;
+} ShmFilm;
+
+typedef struct ShmSceneDesc {
+    uint32_t abi_version;         /* SHM_ABI_VERSION */
+    uint32_t n_nodes;
+    const ShmBvhNode* nodes;
+    uint32_t n_primitives;
+    const ShmPrimitive* primitives;
+    uint32_t n_meshes;
+    const ShmTriangleMesh* meshes;
+    uint32_t n_spheres;
+    const ShmSphere* spheres;
+    uint32_t n_materials;
+    const ShmMaterial* materials;
+    uint32_t n_lights;
+    const ShmLight* lights;       /* the integrator's `lights` vector, in order (light_sampler.rs:83-103) */
+    uint32_t n_spectrum_floats;
+    const float* spectrum_data;
+    ShmCamera camera;
+    ShmFilm film;
+} ShmSceneDesc;
+
+/* ---- render parameters ----------------------------------------------------------------------- */
+
+/* options.rs:15-61 (the five flags the path reads) + PathIntegrator params (integrator.rs:188-192)
+ * + sampler params (sampler.rs:95-99). */
+typedef struct ShmRenderParams {
+    uint64_t seed;
+    int32_t samples_per_pixel;    /* total spp (ray-differential scale, integrator.rs:356-359) */
+    int32_t max_depth;            /* "maxdepth", default 5 */
+    uint8_t regularize;
+    uint8_t disable_pixel_jitter;
+    uint8_t disable_wavelength_jitter;
+    uint8_t force_diffuse;        /* must be 0 (unsupported) */
+    uint8_t pad[4];
+} ShmRenderParams;
+
+/* Tile (tile.rs:5-7): Bounds2i, max exclusive. */
+typedef struct ShmTile {
+    int32_t x0, y0, x1, y1;
+} ShmTile;
+
+/* RgbFilmPixel without the unused splat (film.rs:470-479). */
+typedef struct ShmFilmPixel {
+    double rgb_sum[3];
+    double weight_sum;
+} ShmFilmPixel;
+
+typedef struct ShmStats {
+    uint64_t paths;
+    uint64_t rays_closest;     /* camera + extension rays traced by BvhAggregate::intersect */
+    uint64_t rays_any;         /* shadow rays traced by intersect_predicate */
+    uint64_t nodes_closest;    /* BVH nodes visited (bounds tests) */
+    uint64_t tris_closest;     /* primitive tests */
+    uint64_t nodes_any;
+    uint64_t tris_any;
+    double ms_total;           /* HIP-event time of the whole call on the render stream */
+    double ms_trace_closest;   /* summed HIP-event time of K2 launches */
+    double ms_trace_any;       /* summed HIP-event time of K3 launches */
+    double ms_shade;           /* K1 + K5 + K6 */
+    uint32_t launches_closest;
+    uint32_t launches_any;
+} ShmStats;
+
+typedef struct ShmRay {
+    float o[3];
+    float d[3];
+    float t_max;
+    float pad;
+} ShmRay;
+
+/* ShapeIntersection reduced to what identifies it: primitive (leaf-order index), t_hit and the
+ * shape-local hit parameters (triangle: b0,b1,b2; sphere: p_obj.xyz in b0..b2 and phi). */
+typedef struct ShmHit {
+    int32_t prim;   /* -1: miss */
+    float t;
+    float b0, b1, b2;
+    float phi;
+    uint32_t pad[2];
+} ShmHit;
+
+typedef struct ShmScene ShmScene;
+
+/* Scene lifetime.  `device` is the HIP device ordinal (one process per GPU: pass LOCAL_RANK). */
+int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out);
+void shm_scene_destroy(ShmScene* scene);
+
+/* Film accumulation buffer resident in HBM, pixel_bounds-sized, zero-initialised. */
+int shm_film_clear(ShmScene* scene);
+/* Render one spp-wave [sample_begin, sample_end) (integrator.rs:257-260) of the given tiles into the
+ * device film (+=).  Blocking.  stats may be NULL. */
+int shm_render_wave(ShmScene* scene, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles,
+                    int32_t sample_begin, int32_t sample_end, ShmStats* stats);
+/* Copy the device film to a caller-allocated pixel_bounds-sized row-major array. */
+int shm_film_read(ShmScene* scene, ShmFilmPixel* film_out);
+/* Device pointer + byte size of the film (for device-side gathers, e.g. RCCL through torch). */
+int shm_film_device_ptr(ShmScene* scene, void** ptr_out, uint64_t* bytes_out);
+
+/* Whole ImageTileIntegrator::render (integrator.rs:226-322): all waves 1,1,2,4,...,64,64,... over the
+ * given tiles; `film` += on the host. */
+int shm_render(ShmScene* scene, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles,
+               ShmFilmPixel* film, ShmStats* stats);
+
+/* Bring-up / microbenchmark entries for K2/K3 alone (BvhAggregate::intersect / intersect_predicate,
+ * aggregate.rs:71-203).  Host arrays in, host arrays out. */
+int shm_trace_closest(ShmScene* scene, const ShmRay* rays, uint32_t n, ShmHit* hits_out, ShmStats* stats);
+int shm_trace_any(ShmScene* scene, const ShmRay* rays, uint32_t n, uint8_t* occluded_out, ShmStats* stats);
+/* Same, rays already resident in HBM (device pointers); used by bench.py's traversal roofline leg.
+ * `repeat` launches back-to-back; stats->ms_trace_* is the HIP-event total over all of them. */
+int shm_trace_closest_device(ShmScene* scene, const void* rays_dev, uint32_t n, void* hits_dev, int repeat,
+                             ShmStats* stats);
+int shm_trace_any_device(ShmScene* scene, const void* rays_dev, uint32_t n, void* occluded_dev, int repeat,
+                         ShmStats* stats);
+
+const char* shm_last_error(void);   /* thread-local, never NULL */
+int shm_device_count(void);
+
+/* ---- host-side mirror of the reference's scene-construction steps (no GPU needed) ------------- */
+
+/* BvhAggregate::new (aggregate.rs:207-467): recursive build (split_method 0 = middle, 1 = equal counts),
+ * 1-primitive leaves, DFS flatten.  prim_bounds: 6 floats (min xyz, max xyz) per input primitive.
+ * nodes_out capacity 2*n-1; prim_order_out[n] receives, per leaf-order slot, the input primitive index. */
+int shm_bvh_build(const float* prim_bounds, uint32_t n, int split_method, ShmBvhNode* nodes_out,
+                  uint32_t* n_nodes_out, uint32_t* prim_order_out);
+/* Tile::tile (tile.rs:21-104). tiles_out capacity ceil(w/tw)*ceil(h/th); returns the count via n_out. */
+int shm_tile_bounds(const int32_t pixel_bounds[4], int32_t tile_w, int32_t tile_h, ShmTile* tiles_out,
+                    uint32_t* n_out);
+/* PerspectiveCamera::new + CameraTransform (camera.rs:893-963, 507-523, 594-642) for a world_from_camera
+ * matrix, fov (degrees), screen window derived from the aspect ratio (camera.rs:848-864). Rendering
+ * coordinate system: CameraWorld (the reference default, options.rs). */
+int shm_camera_perspective(const float world_from_camera[16], float fov_deg, const int32_t full_resolution[2],
+                           float lens_radius, float focal_distance, ShmCamera* out,
+                           float render_from_world_out[16]);
+/* Image::write_pfm (image.rs:1333-1377): RGB float, bottom-up rows, little-endian (scale -1). */
+int shm_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHIMMER_HIP_H */

@@ -1,0 +1,507 @@
+// oracle/oracle.cpp — CPU restatement of Shimmer's tile-parallel path-integrator loop.
+//
+// *** TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// *** build, load or call this.  The product (libshimmer_hip.so) never links or calls anything here.
+//
+// What is restated here, literally, in the reference's own control structure (scalar, one path at a time):
+//   integrator.rs:226-322   ImageTileIntegrator::render  — spp waves 1,1,2,4,..,64 over 8x8 tiles; worker threads
+//                           pull tiles from a shared queue (the rayon par_iter shape); per-pixel ordered f64 film sums
+//   integrator.rs:326-396   evaluate_pixel_sample
+//   integrator.rs:748-895   PathIntegrator::li
+//   integrator.rs:897-963   PathIntegrator::sample_ld
+//   integrator.rs:100-116   IntegratorBase::{intersect, intersect_predicate, unoccluded}, SHADOW_EPSILON
+//   aggregate.rs:71-203     BvhAggregate::{intersect, intersect_predicate} (64-entry stack, near child first)
+//   film.rs:548-574         RgbFilm::add_sample
+// Leaf arithmetic (vector math, intervals, triangle/sphere intersection, BxDFs, light sampling, camera,
+// sensor) is single-source with the HIP kernels: the headers under shimmer_amd/csrc/shm/ are compiled here
+// by the host compiler with -ffp-contract=off so that CPU and GPU evaluate bit-identical IEEE operations
+// (one ulp of difference flips Russian-roulette / hit decisions and would void a per-pixel tolerance).
+// Those headers are pinned independently: tests/test_oracle_golden.py checks them against the reference's
+// in-source known answers (aggregate.rs:575-702, shape/shape.rs:299-342, bxdf.rs:1839-1903, float.rs:172-211,
+// sampling.rs:801-836) and against float32 numpy re-evaluations of the cited formulas
+// (tests/golden/gen_golden.py).  The reference itself cannot be built here (Rust nightly + crates.io;
+// no toolchain, no network), so there is no oracle/_ref.
+//
+// PARITY PINNING: pinned at function level by the vectors above; the whole-image result is NOT pinned
+// against the Rust binary, because the reference's sample stream is not reproducible (sampler.rs:117-121,
+// integrator.rs:252-255): the deterministic per-pixel stream of shm/sampling.h is used instead.
+#include <atomic>
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../shimmer_amd/csrc/host/flatten.h"
+#include "../shimmer_amd/csrc/shm/path.h"
+
+using namespace shm;
+
+namespace {
+
+struct Counters {
+    uint64_t rays_closest = 0, rays_any = 0, nodes_closest = 0, tris_closest = 0, nodes_any = 0, tris_any = 0, paths = 0;
+    void add(const Counters& o) {
+        rays_closest += o.rays_closest; rays_any += o.rays_any; nodes_closest += o.nodes_closest;
+        tris_closest += o.tris_closest; nodes_any += o.nodes_any; tris_any += o.tris_any; paths += o.paths;
+    }
+};
+
+// aggregate.rs:71-139
+bool bvh_intersect(const SceneView& sv, V3 ro, V3 rd, Float t_max, Hit& hit, Counters& c) {
+    c.rays_closest++;
+    hit.prim = -1;
+    if (sv.n_nodes == 0) return false;
+    V3 inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    int dir_is_neg[3] = {inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f};
+    bool found = false;
+    int to_visit_offset = 0;
+    uint32_t current = 0;
+    uint32_t nodes_to_visit[64];
+    for (;;) {
+        const ShmBvhNode& node = sv.nodes[current];
+        c.nodes_closest++;
+        if (intersect_p_cached(node.bmin, node.bmax, ro, t_max, inv_dir, dir_is_neg)) {
+            if (node.n_prims > 0) {
+                for (uint32_t i = 0; i < node.n_prims; ++i) {
+                    c.tris_closest++;
+                    if (prim_intersect(sv, node.offset + i, ro, rd, t_max, hit)) {
+                        t_max = hit.t;
+                        found = true;
+                    }
+                }
+                if (to_visit_offset == 0) break;
+                current = nodes_to_visit[--to_visit_offset];
+            } else {
+                if (dir_is_neg[node.axis]) {
+                    nodes_to_visit[to_visit_offset++] = current + 1;
+                    current = node.offset;
+                } else {
+                    nodes_to_visit[to_visit_offset++] = node.offset;
+                    current = current + 1;
+                }
+            }
+        } else {
+            if (to_visit_offset == 0) break;
+            current = nodes_to_visit[--to_visit_offset];
+        }
+    }
+    return found;
+}
+
+// aggregate.rs:141-203
+bool bvh_intersect_predicate(const SceneView& sv, V3 ro, V3 rd, Float t_max, Counters& c) {
+    c.rays_any++;
+    if (sv.n_nodes == 0) return false;
+    V3 inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    int dir_is_neg[3] = {inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f};
+    int to_visit_offset = 0;
+    uint32_t current = 0;
+    uint32_t nodes_to_visit[64];
+    for (;;) {
+        const ShmBvhNode& node = sv.nodes[current];
+        c.nodes_any++;
+        if (intersect_p_cached(node.bmin, node.bmax, ro, t_max, inv_dir, dir_is_neg)) {
+            if (node.n_prims > 0) {
+                for (uint32_t i = 0; i < node.n_prims; ++i) {
+                    c.tris_any++;
+                    Hit h;
+                    if (prim_intersect(sv, node.offset + i, ro, rd, t_max, h)) return true;
+                }
+                if (to_visit_offset == 0) break;
+                current = nodes_to_visit[--to_visit_offset];
+            } else {
+                if (dir_is_neg[node.axis]) {
+                    nodes_to_visit[to_visit_offset++] = current + 1;
+                    current = node.offset;
+                } else {
+                    nodes_to_visit[to_visit_offset++] = node.offset;
+                    current = current + 1;
+                }
+            }
+        } else {
+            if (to_visit_offset == 0) break;
+            current = nodes_to_visit[--to_visit_offset];
+        }
+    }
+    return false;
+}
+
+const Float SHADOW_EPSILON = 0.0001f;  // integrator.rs:66
+
+// integrator.rs:897-963
+Spec sample_ld(const SceneView& sv, const SurfaceInteraction& intr, const BSDF& bsdf, const Wavelengths& lambda,
+               Rng& rng, Counters& c) {
+    LightSampleContext ctx = light_ctx_from(intr);
+    uint32_t flags = bsdf_flags(bsdf);
+    if (flags_is_reflective(flags) && !flags_is_transmissive(flags)) ctx.pi = p3i_exact(offset_ray_origin(intr.pi, intr.n, intr.wo));
+    else if (flags_is_transmissive(flags) && !flags_is_reflective(flags)) ctx.pi = p3i_exact(offset_ray_origin(intr.pi, intr.n, -intr.wo));
+    Float u = sampler_get_1d(rng);
+    Float p_sel = 0.0f;
+    int li = light_sampler_sample(sv, u, p_sel);
+    V2 u_light = sampler_get_2d(rng);
+    if (li < 0) return spec_const(0.0f);
+    const ShmLight& light = sv.lights[li];
+    LightLiSample ls;
+    if (!light_sample_li(sv, light, ctx, u_light, lambda, ls)) return spec_const(0.0f);
+    if (is_zero(ls.l) || ls.pdf == 0.0f) return spec_const(0.0f);
+    V3 wo = intr.wo;
+    V3 wi = ls.wi;
+    Spec f = bsdf_f(bsdf, wo, wi) * abs_dot(wi, intr.shading.n);
+    if (is_zero(f)) return spec_const(0.0f);
+    // unoccluded(): !intersect_predicate(p0.spawn_ray_to_interaction(p1), 1 - SHADOW_EPSILON), integrator.rs:114-116
+    Ray sr = spawn_ray_to_both_offset(intr.pi, intr.n, ls.p_light_pi, ls.p_light_n);
+    if (bvh_intersect_predicate(sv, sr.o, sr.d, 1.0f - SHADOW_EPSILON, c)) return spec_const(0.0f);
+    Float p_l = p_sel * ls.pdf;
+    if (light_is_delta(light)) return ls.l * f / p_l;
+    Float p_b = bsdf_pdf(bsdf, wo, wi, REFLTRANS_ALL);
+    Float w_l = power_heuristic(1, p_l, 1, p_b);
+    return w_l * ls.l * f / p_l;
+}
+
+// integrator.rs:748-895
+Spec li(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng, int max_depth, bool regularize, Counters& c) {
+    Spec l = spec_const(0.0f);
+    Spec beta = spec_const(1.0f);
+    int depth = 0;
+    Float p_b = 1.0f;
+    Float eta_scale = 1.0f;
+    bool specular_bounce = false;
+    bool any_non_specular_bounces = false;
+    LightSampleContext prev_intr_ctx;
+    prev_intr_ctx.pi = p3i_exact(v3s(0.0f));
+    prev_intr_ctx.n = v3s(0.0f);
+    prev_intr_ctx.ns = v3s(0.0f);
+    for (;;) {
+        Hit hit;
+        bool found = bvh_intersect(sv, ray.o, ray.d, infinity(), hit, c);
+        if (!found) {
+            for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
+                const ShmLight& light = sv.lights[sv.infinite_lights[k]];
+                Spec le = light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);  // light.rs:795-797
+                if (depth == 0 || specular_bounce) {
+                    l = l + beta * le;
+                } else {
+                    Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, prev_intr_ctx, ray.d);
+                    Float w_b = power_heuristic(1, p_b, 1, p_l);
+                    l = l + beta * w_b * le;
+                }
+            }
+            break;
+        }
+        SurfaceInteraction si = hit_interaction(sv, hit, -ray.d);
+        const ShmPrimitive& prim = sv.primitives[hit.prim];
+        // si.intr.le(-ray.d, lambda), interaction.rs:369-377
+        if (prim.area_light >= 0) {
+            const ShmLight& light = sv.lights[prim.area_light];
+            Spec le = area_light_l(sv, light, si.n, -ray.d, lambda);
+            if (!is_zero(le)) {
+                if (depth == 0 || specular_bounce) {
+                    l = l + beta * le;
+                } else {
+                    Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, prev_intr_ctx, ray.d);
+                    Float w_l = power_heuristic(1, p_b, 1, p_l);
+                    l = l + beta * w_l * le;
+                }
+            }
+        }
+        BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+        if (regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
+        if (depth == max_depth) break;
+        depth += 1;
+        if (flags_is_non_specular(bsdf_flags(bsdf))) {
+            Spec ld = sample_ld(sv, si, bsdf, lambda, rng, c);
+            l = l + beta * ld;
+        }
+        V3 wo = -ray.d;
+        Float u = sampler_get_1d(rng);
+        V2 u2 = sampler_get_2d(rng);
+        BSDFSample bs;
+        if (!bsdf_sample_f(bsdf, wo, u, u2, REFLTRANS_ALL, bs)) break;
+        beta = beta * (bs.f * abs_dot(bs.wi, si.shading.n) / bs.pdf);
+        p_b = bs.pdf_is_proportional ? bsdf_pdf(bsdf, wo, bs.wi, REFLTRANS_ALL) : bs.pdf;
+        specular_bounce = flags_is_specular(bs.flags);
+        any_non_specular_bounces |= !specular_bounce;
+        if (flags_is_transmissive(bs.flags)) eta_scale *= sqr(bs.eta);
+        prev_intr_ctx = light_ctx_from(si);
+        // spawn_ray_with_differentials -> interaction.spawn_ray(wi), interaction.rs:68-75, 441
+        ray.o = offset_ray_origin(si.pi, si.n, bs.wi);
+        ray.d = bs.wi;
+        if (is_finite(eta_scale)) {
+            Spec rr_beta = beta * eta_scale;
+            if (max_component_value(rr_beta) < 1.0f && depth > 1) {
+                Float q = max(0.0f, 1.0f - max_component_value(rr_beta));
+                if (sampler_get_1d(rng) < q) break;
+                beta = beta / (1.0f - q);
+            }
+        }
+    }
+    return l;
+}
+
+struct Oracle {
+    shm_host::FlatScene flat;
+    SceneView sv;
+};
+
+thread_local std::string g_err;
+
+}  // namespace
+
+extern "C" {
+
+struct OrcScene;
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+int orc_scene_create(const ShmSceneDesc* desc, OrcScene** out) {
+    if (!out) return SHM_ERR_INVALID_ARGUMENT;
+    Oracle* o = new Oracle();
+    int rc = shm_host::flatten_scene(desc, o->flat, g_err);
+    if (rc != SHM_OK) { delete o; return rc; }
+    o->sv = o->flat.view();
+    *out = reinterpret_cast<OrcScene*>(o);
+    return SHM_OK;
+}
+void orc_scene_destroy(OrcScene* s) { delete reinterpret_cast<Oracle*>(s); }
+
+int orc_trace_closest(OrcScene* s, const ShmRay* rays, uint32_t n, ShmHit* hits, ShmStats* stats) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    Counters c;
+    for (uint32_t i = 0; i < n; ++i) {
+        Hit h;
+        bvh_intersect(o->sv, v3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), v3(rays[i].d[0], rays[i].d[1], rays[i].d[2]), rays[i].t_max, h, c);
+        memset(&hits[i], 0, sizeof(ShmHit));
+        hits[i].prim = h.prim;
+        if (h.prim >= 0) { hits[i].t = h.t; hits[i].b0 = h.b0; hits[i].b1 = h.b1; hits[i].b2 = h.b2; hits[i].phi = h.phi; }
+    }
+    if (stats) { memset(stats, 0, sizeof(*stats)); stats->rays_closest = c.rays_closest; stats->nodes_closest = c.nodes_closest; stats->tris_closest = c.tris_closest; }
+    return SHM_OK;
+}
+int orc_trace_any(OrcScene* s, const ShmRay* rays, uint32_t n, uint8_t* occluded, ShmStats* stats) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    Counters c;
+    for (uint32_t i = 0; i < n; ++i)
+        occluded[i] = bvh_intersect_predicate(o->sv, v3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), v3(rays[i].d[0], rays[i].d[1], rays[i].d[2]), rays[i].t_max, c) ? 1 : 0;
+    if (stats) { memset(stats, 0, sizeof(*stats)); stats->rays_any = c.rays_any; stats->nodes_any = c.nodes_any; stats->tris_any = c.tris_any; }
+    return SHM_OK;
+}
+
+// One spp-wave over the given tiles, n_threads workers pulling tiles from a shared counter
+// (integrator.rs:242-304).  film: pixel_bounds-sized, += semantics.
+int orc_render_wave(OrcScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles,
+                    int32_t sample_begin, int32_t sample_end, int n_threads, ShmFilmPixel* film, ShmStats* stats) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    if (!params || !tiles || !film || params->force_diffuse) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    const SceneView& sv = o->sv;
+    const int width = sv.pixel_bounds[2] - sv.pixel_bounds[0];
+    if (n_threads < 1) n_threads = 1;
+    std::atomic<uint32_t> next(0);
+    std::vector<Counters> counters(n_threads);
+    auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&](int tid) {
+        Counters c;
+        for (;;) {
+            uint32_t ti = next.fetch_add(1);
+            if (ti >= n_tiles) break;
+            const ShmTile& tile = tiles[ti];
+            for (int x = tile.x0; x < tile.x1; ++x) {
+                for (int y = tile.y0; y < tile.y1; ++y) {
+                    for (int si = sample_begin; si < sample_end; ++si) {
+                        // evaluate_pixel_sample, integrator.rs:326-396
+                        Rng rng = sampler_start_pixel_sample(x, y, si, params->seed);
+                        Wavelengths lambda;
+                        Float weight;
+                        Ray ray = generate_camera_ray(sv, x, y, rng, params->disable_wavelength_jitter != 0,
+                                                      params->disable_pixel_jitter != 0, lambda, weight);
+                        Spec L = spec_const(1.0f) * li(sv, ray, lambda, rng, params->max_depth, params->regularize != 0, c);  // camera_ray.weight * li
+                        c.paths++;
+                        // RgbFilm::add_sample, film.rs:548-574
+                        V3 rgb = film_sample_rgb(sv, L, lambda);
+                        ShmFilmPixel& px = film[(size_t)(y - sv.pixel_bounds[1]) * width + (x - sv.pixel_bounds[0])];
+                        px.rgb_sum[0] += (double)(weight * rgb.x);
+                        px.rgb_sum[1] += (double)(weight * rgb.y);
+                        px.rgb_sum[2] += (double)(weight * rgb.z);
+                        px.weight_sum += (double)weight;
+                    }
+                }
+            }
+        }
+        counters[tid] = c;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : th) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    if (stats) {
+        Counters c;
+        for (auto& k : counters) c.add(k);
+        stats->paths += c.paths; stats->rays_closest += c.rays_closest; stats->rays_any += c.rays_any;
+        stats->nodes_closest += c.nodes_closest; stats->tris_closest += c.tris_closest;
+        stats->nodes_any += c.nodes_any; stats->tris_any += c.tris_any;
+        stats->ms_total += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    }
+    return SHM_OK;
+}
+
+// ImageTileIntegrator::render: all waves (integrator.rs:231-233, 306-308).
+int orc_render(OrcScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles, int n_threads,
+               ShmFilmPixel* film, ShmStats* stats) {
+    if (!params) return SHM_ERR_INVALID_ARGUMENT;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    int spp = params->samples_per_pixel;
+    int wave_start = 0, wave_end = 1, next_wave_size = 1;
+    while (wave_start < spp) {
+        int rc = orc_render_wave(s, params, tiles, n_tiles, wave_start, wave_end, n_threads, film, stats);
+        if (rc != SHM_OK) return rc;
+        wave_start = wave_end;
+        wave_end = std::min(spp, wave_end + next_wave_size);
+        next_wave_size = std::min(2 * next_wave_size, 64);
+    }
+    return SHM_OK;
+}
+
+// ---- unit-function entry points for the golden-vector tests (tests/test_oracle_golden.py) ----
+float orc_fn_next_float_up(float v) { return next_float_up(v); }
+float orc_fn_next_float_down(float v) { return next_float_down(v); }
+float orc_fn_gamma(int n) { return gamma(n); }
+float orc_fn_difference_of_products(float a, float b, float c, float d) { return difference_of_products(a, b, c, d); }
+float orc_fn_sin(float x) { return shm::sin(x); }
+float orc_fn_cos(float x) { return shm::cos(x); }
+float orc_fn_asin(float x) { return shm::asin(x); }
+float orc_fn_acos(float x) { return shm::acos(x); }
+float orc_fn_atan2(float y, float x) { return shm::atan2(y, x); }
+float orc_fn_exp(float x) { return shm::exp(x); }
+float orc_fn_log(float x) { return shm::log(x); }
+float orc_fn_atanh(float x) { return shm::atanh(x); }
+float orc_fn_cosh(float x) { return shm::cosh(x); }
+float orc_fn_hypot(float x, float y) { return shm::hypot(x, y); }
+float orc_fn_round(float x) { return shm::round(x); }
+float orc_fn_sample_visible_wavelengths(float u) { return sample_visible_wavelengths(u); }
+float orc_fn_visible_wavelengths_pdf(float l) { return visible_wavelengths_pdf(l); }
+float orc_fn_dot(const float* a, const float* b) { return dot(ld3(a), ld3(b)); }
+void orc_fn_cross(const float* a, const float* b, float* out) { V3 r = cross(ld3(a), ld3(b)); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void orc_fn_coordinate_system(const float* v, float* out6) {
+    V3 a, b;
+    coordinate_system(ld3(v), a, b);
+    out6[0] = a.x; out6[1] = a.y; out6[2] = a.z; out6[3] = b.x; out6[4] = b.y; out6[5] = b.z;
+}
+int orc_fn_intersect_p_cached(const float* bmin, const float* bmax, const float* o, const float* d, float t_max) {
+    V3 rd = ld3(d);
+    V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    int neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
+    return intersect_p_cached(bmin, bmax, ld3(o), t_max, inv, neg) ? 1 : 0;
+}
+int orc_fn_intersect_triangle(const float* o, const float* d, float t_max, const float* p0, const float* p1, const float* p2, float* out4) {
+    TriangleIntersection ti;
+    if (!intersect_triangle(ld3(o), ld3(d), t_max, ld3(p0), ld3(p1), ld3(p2), ti)) return 0;
+    out4[0] = ti.b0; out4[1] = ti.b1; out4[2] = ti.b2; out4[3] = ti.t;
+    return 1;
+}
+float orc_fn_tr_d(float ax, float ay, const float* wm) { return trowbridge_reitz_new(ax, ay).d(ld3(wm)); }
+float orc_fn_tr_g(float ax, float ay, const float* wo, const float* wi) { return trowbridge_reitz_new(ax, ay).g(ld3(wo), ld3(wi)); }
+float orc_fn_tr_lambda(float ax, float ay, const float* w) { return trowbridge_reitz_new(ax, ay).lambda(ld3(w)); }
+void orc_fn_tr_sample_wm(float ax, float ay, const float* w, const float* u, float* out) {
+    V3 r = trowbridge_reitz_new(ax, ay).sample_wm(ld3(w), v2(u[0], u[1]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+float orc_fn_fresnel_dielectric(float c, float eta) { return fresnel_dielectric(c, eta); }
+float orc_fn_fresnel_complex(float c, float eta, float k) { return fresnel_complex(c, cx(eta, k)); }
+// BxDF::sample_f in the local frame. out: f[4], wi[3], pdf, flags, eta (10 floats). Returns 1 if Some.
+int orc_fn_bxdf_sample_f(int kind, const float* r4, const float* k4, float eta, float ax, float ay, const float* wo,
+                         float uc, const float* u, float* out10) {
+    BxDF b;
+    b.kind = (uint32_t)kind;
+    for (int i = 0; i < 4; ++i) { b.r.v[i] = r4[i]; b.k.v[i] = k4[i]; }
+    b.eta = eta;
+    b.mf = trowbridge_reitz_new(ax, ay);
+    BSDFSample bs;
+    if (!bxdf_sample_f(b, ld3(wo), uc, v2(u[0], u[1]), REFLTRANS_ALL, bs)) return 0;
+    for (int i = 0; i < 4; ++i) out10[i] = bs.f.v[i];
+    out10[4] = bs.wi.x; out10[5] = bs.wi.y; out10[6] = bs.wi.z; out10[7] = bs.pdf; out10[8] = (float)bs.flags; out10[9] = bs.eta;
+    return 1;
+}
+void orc_fn_bxdf_f_pdf(int kind, const float* r4, const float* k4, float eta, float ax, float ay, const float* wo,
+                       const float* wi, float* out5) {
+    BxDF b;
+    b.kind = (uint32_t)kind;
+    for (int i = 0; i < 4; ++i) { b.r.v[i] = r4[i]; b.k.v[i] = k4[i]; }
+    b.eta = eta;
+    b.mf = trowbridge_reitz_new(ax, ay);
+    Spec f = bxdf_f(b, ld3(wo), ld3(wi));
+    for (int i = 0; i < 4; ++i) out5[i] = f.v[i];
+    out5[4] = bxdf_pdf(b, ld3(wo), ld3(wi), REFLTRANS_ALL);
+}
+void orc_fn_sample_cosine_hemisphere(const float* u, float* out3) { V3 r = sample_cosine_hemisphere(v2(u[0], u[1])); out3[0] = r.x; out3[1] = r.y; out3[2] = r.z; }
+float orc_fn_power_heuristic(float f, float g) { return power_heuristic(1, f, 1, g); }
+float orc_fn_sampler_stream(int px, int py, int sample_index, uint64_t seed, int n, float* out) {
+    Rng r = sampler_start_pixel_sample(px, py, sample_index, seed);
+    for (int i = 0; i < n; ++i) out[i] = sampler_get_1d(r);
+    return n > 0 ? out[0] : 0.0f;
+}
+void orc_fn_offset_ray_origin(const float* p, const float* err, const float* n, const float* w, float* out3) {
+    V3 r = offset_ray_origin(p3i_from_value_and_error(ld3(p), ld3(err)), ld3(n), ld3(w));
+    out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
+// Triangle light sampling from a reference point: out = p[3], n[3], pdf ; returns 1 if Some
+int orc_fn_triangle_sample_with_context(const float* p0, const float* p1, const float* p2, const float* ctx_p, const float* ctx_n,
+                                        const float* ctx_ns, const float* u, float* out7) {
+    TriangleData tr;
+    memset(&tr, 0, sizeof(tr));
+    tr.p0 = ld3(p0); tr.p1 = ld3(p1); tr.p2 = ld3(p2);
+    ShapeSampleContext c;
+    c.pi = p3i_exact(ld3(ctx_p)); c.n = ld3(ctx_n); c.ns = ld3(ctx_ns);
+    ShapeSample ss;
+    if (!triangle_sample_with_context(tr, c, v2(u[0], u[1]), ss)) return 0;
+    V3 p = ss.pi.mid();
+    out7[0] = p.x; out7[1] = p.y; out7[2] = p.z; out7[3] = ss.n.x; out7[4] = ss.n.y; out7[5] = ss.n.z; out7[6] = ss.pdf;
+    return 1;
+}
+float orc_fn_triangle_pdf_with_context(const float* p0, const float* p1, const float* p2, const float* ctx_p, const float* ctx_n,
+                                       const float* ctx_ns, const float* wi) {
+    TriangleData tr;
+    memset(&tr, 0, sizeof(tr));
+    tr.p0 = ld3(p0); tr.p1 = ld3(p1); tr.p2 = ld3(p2);
+    ShapeSampleContext c;
+    c.pi = p3i_exact(ld3(ctx_p)); c.n = ld3(ctx_n); c.ns = ld3(ctx_ns);
+    return triangle_pdf_with_context(tr, c, ld3(wi));
+}
+// Full interaction at a hit of the scene: out = p[3], n[3], ns[3], dpdu_s[3] (12 floats)
+int orc_fn_hit_interaction(OrcScene* s, const ShmRay* ray, float* out12, ShmHit* hit_out) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    Counters c;
+    Hit h;
+    V3 ro = v3(ray->o[0], ray->o[1], ray->o[2]), rd = v3(ray->d[0], ray->d[1], ray->d[2]);
+    if (!bvh_intersect(o->sv, ro, rd, ray->t_max, h, c)) return 0;
+    SurfaceInteraction si = hit_interaction(o->sv, h, -rd);
+    V3 p = si.p();
+    out12[0] = p.x; out12[1] = p.y; out12[2] = p.z;
+    out12[3] = si.n.x; out12[4] = si.n.y; out12[5] = si.n.z;
+    out12[6] = si.shading.n.x; out12[7] = si.shading.n.y; out12[8] = si.shading.n.z;
+    out12[9] = si.shading.dpdu.x; out12[10] = si.shading.dpdu.y; out12[11] = si.shading.dpdu.z;
+    if (hit_out) { memset(hit_out, 0, sizeof(*hit_out)); hit_out->prim = h.prim; hit_out->t = h.t; hit_out->b0 = h.b0; hit_out->b1 = h.b1; hit_out->b2 = h.b2; hit_out->phi = h.phi; }
+    return 1;
+}
+void orc_fn_camera_ray(OrcScene* s, int px, int py, int sample_index, uint64_t seed, float* out14) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    Rng rng = sampler_start_pixel_sample(px, py, sample_index, seed);
+    Wavelengths lambda;
+    Float w;
+    Ray r = generate_camera_ray(o->sv, px, py, rng, false, false, lambda, w);
+    out14[0] = r.o.x; out14[1] = r.o.y; out14[2] = r.o.z; out14[3] = r.d.x; out14[4] = r.d.y; out14[5] = r.d.z;
+    for (int i = 0; i < 4; ++i) { out14[6 + i] = lambda.lambda[i]; out14[10 + i] = lambda.pdf[i]; }
+}
+void orc_fn_film_sample_rgb(OrcScene* s, const float* L4, const float* lambda4, const float* pdf4, float* out3) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    Spec L;
+    Wavelengths w;
+    for (int i = 0; i < 4; ++i) { L.v[i] = L4[i]; w.lambda[i] = lambda4[i]; w.pdf[i] = pdf4[i]; }
+    V3 r = film_sample_rgb(o->sv, L, w);
+    out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
+float orc_fn_spectrum_get(OrcScene* s, const ShmSpectrum* sp, float lambda) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    return spectrum_get(*sp, o->sv.spectrum_data, lambda);
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+"""ctypes mirror of include/shimmer_hip.h (the C ABI of libshimmer_hip.so).
+
+Plumbing only: struct layouts, library loading and argument marshalling. No arithmetic of the hot path
+lives in Python; if the HIP library is missing this module raises — there is no CPU fallback.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+LIB_PATH = ROOT / "csrc" / "libshimmer_hip.so"
+
+SHM_ABI_VERSION = 1
+SHM_OK = 0
+SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE = 0, 1
+SHM_SPECTRUM_CONSTANT, SHM_SPECTRUM_DENSE, SHM_SPECTRUM_PIECEWISE_LINEAR = 0, 1, 2
+SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATERIAL_THIN_DIELECTRIC = 0, 1, 2, 3
+SHM_LIGHT_POINT, SHM_LIGHT_DIFFUSE_AREA, SHM_LIGHT_UNIFORM_INFINITE = 0, 1, 2
+
+c_float_p = C.POINTER(C.c_float)
+c_u32_p = C.POINTER(C.c_uint32)
+
+
+class ShmBvhNode(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("offset", C.c_uint32), ("n_prims", C.c_uint16),
+                ("axis", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class ShmTriangleMesh(C.Structure):
+    _fields_ = [("n_triangles", C.c_uint32), ("n_vertices", C.c_uint32), ("vertex_indices", c_u32_p), ("p", c_float_p),
+                ("n", c_float_p), ("s", c_float_p), ("uv", c_float_p), ("reverse_orientation", C.c_uint8),
+                ("transform_swaps_handedness", C.c_uint8), ("pad", C.c_uint8 * 6)]
+
+
+class ShmSphere(C.Structure):
+    _fields_ = [("radius", C.c_float), ("z_min", C.c_float), ("z_max", C.c_float), ("theta_z_min", C.c_float),
+                ("theta_z_max", C.c_float), ("phi_max", C.c_float), ("render_from_object", C.c_float * 16),
+                ("object_from_render", C.c_float * 16), ("reverse_orientation", C.c_uint8),
+                ("transform_swaps_handedness", C.c_uint8), ("pad", C.c_uint8 * 6)]
+
+
+class ShmPrimitive(C.Structure):
+    _fields_ = [("shape_kind", C.c_uint32), ("shape_index", C.c_uint32), ("material", C.c_uint32), ("area_light", C.c_int32)]
+
+
+class ShmSpectrum(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("c", C.c_float), ("offset", C.c_uint32), ("n", C.c_uint32),
+                ("lambda_min", C.c_int32), ("pad", C.c_uint32 * 3)]
+
+
+class ShmMaterial(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("has_displacement", C.c_uint32), ("displacement", C.c_float),
+                ("remap_roughness", C.c_uint32), ("u_roughness", C.c_float), ("v_roughness", C.c_float),
+                ("pad", C.c_uint32 * 2), ("a", ShmSpectrum), ("b", ShmSpectrum)]
+
+
+class ShmLight(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("primitive", C.c_uint32), ("scale", C.c_float), ("two_sided", C.c_uint32),
+                ("position", C.c_float * 3), ("area", C.c_float), ("spectrum", ShmSpectrum)]
+
+
+class ShmCamera(C.Structure):
+    _fields_ = [("camera_from_raster", C.c_float * 16), ("render_from_camera", C.c_float * 16), ("dx_camera", C.c_float * 3),
+                ("dy_camera", C.c_float * 3), ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+                ("shutter_open", C.c_float), ("shutter_close", C.c_float)]
+
+
+class ShmFilm(C.Structure):
+    _fields_ = [("pixel_bounds", C.c_int32 * 4), ("full_resolution", C.c_int32 * 2), ("filter_radius", C.c_float * 2),
+                ("imaging_ratio", C.c_float), ("max_component_value", C.c_float), ("sensor_r_bar", c_float_p),
+                ("sensor_g_bar", c_float_p), ("sensor_b_bar", c_float_p)]
+
+
+class ShmSceneDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("n_nodes", C.c_uint32), ("nodes", C.POINTER(ShmBvhNode)),
+                ("n_primitives", C.c_uint32), ("primitives", C.POINTER(ShmPrimitive)), ("n_meshes", C.c_uint32),
+                ("meshes", C.POINTER(ShmTriangleMesh)), ("n_spheres", C.c_uint32), ("spheres", C.POINTER(ShmSphere)),
+                ("n_materials", C.c_uint32), ("materials", C.POINTER(ShmMaterial)), ("n_lights", C.c_uint32),
+                ("lights", C.POINTER(ShmLight)), ("n_spectrum_floats", C.c_uint32), ("spectrum_data", c_float_p),
+                ("camera", ShmCamera), ("film", ShmFilm)]
+
+
+class ShmRenderParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32), ("regularize", C.c_uint8),
+                ("disable_pixel_jitter", C.c_uint8), ("disable_wavelength_jitter", C.c_uint8), ("force_diffuse", C.c_uint8),
+                ("pad", C.c_uint8 * 4)]
+
+
+class ShmTile(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32)]
+
+
+class ShmFilmPixel(C.Structure):
+    _fields_ = [("rgb_sum", C.c_double * 3), ("weight_sum", C.c_double)]
+
+
+class ShmStats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("nodes_closest", C.c_uint64),
+                ("tris_closest", C.c_uint64), ("nodes_any", C.c_uint64), ("tris_any", C.c_uint64), ("ms_total", C.c_double),
+                ("ms_trace_closest", C.c_double), ("ms_trace_any", C.c_double), ("ms_shade", C.c_double),
+                ("launches_closest", C.c_uint32), ("launches_any", C.c_uint32)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class ShmRay(C.Structure):
+    _fields_ = [("o", C.c_float * 3), ("d", C.c_float * 3), ("t_max", C.c_float), ("pad", C.c_float)]
+
+
+class ShmHit(C.Structure):
+    _fields_ = [("prim", C.c_int32), ("t", C.c_float), ("b0", C.c_float), ("b1", C.c_float), ("b2", C.c_float),
+                ("phi", C.c_float), ("pad", C.c_uint32 * 2)]
+
+
+assert C.sizeof(ShmBvhNode) == 32 and C.sizeof(ShmRay) == 32 and C.sizeof(ShmHit) == 32 and C.sizeof(ShmFilmPixel) == 32
+
+# Every symbol include/shimmer_hip.h declares, with its signature (tests check the .so exports all of them).
+EXPORTS = {
+    "shm_scene_create": (C.c_int, [C.POINTER(ShmSceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "shm_scene_destroy": (None, [C.c_void_p]),
+    "shm_film_clear": (C.c_int, [C.c_void_p]),
+    "shm_render_wave": (C.c_int, [C.c_void_p, C.POINTER(ShmRenderParams), C.POINTER(ShmTile), C.c_uint32, C.c_int32, C.c_int32,
+                                  C.POINTER(ShmStats)]),
+    "shm_film_read": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "shm_film_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "shm_render": (C.c_int, [C.c_void_p, C.POINTER(ShmRenderParams), C.POINTER(ShmTile), C.c_uint32, C.c_void_p, C.POINTER(ShmStats)]),
+    "shm_trace_closest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(ShmStats)]),
+    "shm_trace_any": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(ShmStats)]),
+    "shm_trace_closest_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(ShmStats)]),
+    "shm_trace_any_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(ShmStats)]),
+    "shm_last_error": (C.c_char_p, []),
+    "shm_device_count": (C.c_int, []),
+    "shm_bvh_build": (C.c_int, [c_float_p, C.c_uint32, C.c_int, C.POINTER(ShmBvhNode), c_u32_p, c_u32_p]),
+    "shm_tile_bounds": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(ShmTile), c_u32_p]),
+    "shm_camera_perspective": (C.c_int, [c_float_p, C.c_float, C.POINTER(C.c_int32), C.c_float, C.c_float, C.POINTER(ShmCamera), c_float_p]),
+    "shm_write_pfm": (C.c_int, [C.c_char_p, c_float_p, C.c_int32, C.c_int32]),
+}
+
+_lib = None
+
+
+class ShimmerHipError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """Load libshimmer_hip.so (built in-tree by __graft_entry__.build()). Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise ShimmerHipError(f"{p} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback for the render path.")
+    lib = C.CDLL(str(p), mode=getattr(os, "RTLD_NOW", 2))
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib, rc, what):
+    if rc != SHM_OK:
+        msg = lib.shm_last_error()
+        raise ShimmerHipError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,221 @@
+// host/flatten.h — validate a ShmSceneDesc and marshal it into the flat arrays of shm::SceneView
+// (host memory). libshimmer_hip uploads these arrays to HBM; the CPU oracle reads them in place.
+// This is data marshalling only: no arithmetic of the hot path lives here.
+#pragma once
+#include <algorithm>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../shm/scene.h"
+
+namespace shm_host {
+
+struct FlatScene {
+    std::vector<ShmBvhNode> nodes;
+    std::vector<shm::PrimRec> prim_recs;
+    std::vector<ShmPrimitive> primitives;
+    std::vector<uint32_t> mesh_flags;
+    std::vector<uint32_t> vi;
+    std::vector<float> vn, vs, vuv;
+    std::vector<ShmSphere> spheres;
+    std::vector<ShmMaterial> materials;
+    std::vector<ShmLight> lights;
+    std::vector<uint32_t> infinite_lights;
+    std::vector<float> spectrum_data;
+    std::vector<float> sensor_r, sensor_g, sensor_b;
+    ShmCamera camera;
+    ShmFilm film;
+    uint32_t max_leaf_depth = 0;  // deepest leaf (root = 0); bounds the traversal stack
+    bool has_spheres = false;
+
+    shm::SceneView view() const {
+        shm::SceneView v;
+        v.nodes = nodes.data();
+        v.n_nodes = (uint32_t)nodes.size();
+        v.prim_recs = prim_recs.data();
+        v.primitives = primitives.data();
+        v.n_primitives = (uint32_t)primitives.size();
+        v.mesh_flags = mesh_flags.data();
+        v.vi = vi.data();
+        v.vn = vn.data();
+        v.vs = vs.data();
+        v.vuv = vuv.data();
+        v.spheres = spheres.data();
+        v.materials = materials.data();
+        v.lights = lights.data();
+        v.n_lights = (uint32_t)lights.size();
+        v.infinite_lights = infinite_lights.data();
+        v.n_infinite_lights = (uint32_t)infinite_lights.size();
+        v.spectrum_data = spectrum_data.data();
+        v.camera = camera;
+        for (int i = 0; i < 4; ++i) v.pixel_bounds[i] = film.pixel_bounds[i];
+        v.filter_radius[0] = film.filter_radius[0];
+        v.filter_radius[1] = film.filter_radius[1];
+        v.imaging_ratio = film.imaging_ratio;
+        v.max_component_value = film.max_component_value;
+        v.sensor_r_bar = sensor_r.data();
+        v.sensor_g_bar = sensor_g.data();
+        v.sensor_b_bar = sensor_b.data();
+        return v;
+    }
+};
+
+inline bool check_spectrum(const ShmSpectrum& s, uint32_t n_floats, std::string& err) {
+    if (s.kind == SHM_SPECTRUM_CONSTANT) return true;
+    if (s.kind == SHM_SPECTRUM_DENSE) {
+        if ((uint64_t)s.offset + s.n > n_floats) { err = "dense spectrum out of range"; return false; }
+        return true;
+    }
+    if (s.kind == SHM_SPECTRUM_PIECEWISE_LINEAR) {
+        if (s.n < 2 || (uint64_t)s.offset + 2ull * s.n > n_floats) { err = "piecewise spectrum out of range"; return false; }
+        return true;
+    }
+    err = "unknown spectrum kind";
+    return false;
+}
+
+// Returns 0 or a negative ShmError; err receives a message.
+inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err) {
+    if (!d) { err = "null scene description"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (d->abi_version != SHM_ABI_VERSION) { err = "abi_version mismatch"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (d->n_nodes == 0 || !d->nodes) { err = "scene has no BVH nodes"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (d->n_primitives == 0 || !d->primitives) { err = "scene has no primitives"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (d->n_materials == 0 || !d->materials) { err = "scene has no materials"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (!d->film.sensor_r_bar || !d->film.sensor_g_bar || !d->film.sensor_b_bar) { err = "film sensor tables missing"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (d->film.pixel_bounds[2] <= d->film.pixel_bounds[0] || d->film.pixel_bounds[3] <= d->film.pixel_bounds[1]) { err = "empty pixel bounds"; return SHM_ERR_INVALID_ARGUMENT; }
+
+    out.nodes.assign(d->nodes, d->nodes + d->n_nodes);
+    out.primitives.assign(d->primitives, d->primitives + d->n_primitives);
+    out.spheres.assign(d->spheres, d->spheres + (d->spheres ? d->n_spheres : 0));
+    out.materials.assign(d->materials, d->materials + d->n_materials);
+    out.lights.assign(d->lights, d->lights + (d->lights ? d->n_lights : 0));
+    out.spectrum_data.assign(d->spectrum_data, d->spectrum_data + (d->spectrum_data ? d->n_spectrum_floats : 0));
+    if (out.spectrum_data.empty()) out.spectrum_data.push_back(0.0f);
+    out.sensor_r.assign(d->film.sensor_r_bar, d->film.sensor_r_bar + 471);
+    out.sensor_g.assign(d->film.sensor_g_bar, d->film.sensor_g_bar + 471);
+    out.sensor_b.assign(d->film.sensor_b_bar, d->film.sensor_b_bar + 471);
+    out.camera = d->camera;
+    out.film = d->film;
+    out.film.sensor_r_bar = out.film.sensor_g_bar = out.film.sensor_b_bar = nullptr;
+
+    // meshes -> global arrays
+    std::vector<uint32_t> tri_base(d->n_meshes + 1, 0), vert_base(d->n_meshes + 1, 0);
+    for (uint32_t m = 0; m < d->n_meshes; ++m) {
+        const ShmTriangleMesh& mesh = d->meshes[m];
+        if (!mesh.vertex_indices || !mesh.p) { err = "mesh without indices/positions"; return SHM_ERR_INVALID_ARGUMENT; }
+        tri_base[m + 1] = tri_base[m] + mesh.n_triangles;
+        vert_base[m + 1] = vert_base[m] + mesh.n_vertices;
+    }
+    uint32_t n_tris = tri_base[d->n_meshes], n_verts = vert_base[d->n_meshes];
+    bool any_attr = false;
+    out.mesh_flags.resize(d->n_meshes ? d->n_meshes : 1, 0);
+    for (uint32_t m = 0; m < d->n_meshes; ++m) {
+        const ShmTriangleMesh& mesh = d->meshes[m];
+        uint32_t f = 0;
+        if (mesh.n) f |= shm::MESH_HAS_N;
+        if (mesh.s) f |= shm::MESH_HAS_S;
+        if (mesh.uv) f |= shm::MESH_HAS_UV;
+        if ((mesh.reverse_orientation != 0) ^ (mesh.transform_swaps_handedness != 0)) f |= shm::MESH_FLIP;
+        out.mesh_flags[m] = f;
+        if (f & (shm::MESH_HAS_N | shm::MESH_HAS_S | shm::MESH_HAS_UV)) any_attr = true;
+    }
+    if (any_attr) {
+        out.vi.resize(3ull * n_tris);
+        out.vn.assign(3ull * n_verts, 0.0f);
+        out.vs.assign(3ull * n_verts, 0.0f);
+        out.vuv.assign(2ull * n_verts, 0.0f);
+        for (uint32_t m = 0; m < d->n_meshes; ++m) {
+            const ShmTriangleMesh& mesh = d->meshes[m];
+            for (uint64_t i = 0; i < 3ull * mesh.n_triangles; ++i)
+                out.vi[3ull * tri_base[m] + i] = mesh.vertex_indices[i] + vert_base[m];
+            if (mesh.n) std::copy(mesh.n, mesh.n + 3ull * mesh.n_vertices, out.vn.begin() + 3ull * vert_base[m]);
+            if (mesh.s) std::copy(mesh.s, mesh.s + 3ull * mesh.n_vertices, out.vs.begin() + 3ull * vert_base[m]);
+            if (mesh.uv) std::copy(mesh.uv, mesh.uv + 2ull * mesh.n_vertices, out.vuv.begin() + 2ull * vert_base[m]);
+        }
+    } else {
+        out.vi.assign(3, 0);
+        out.vn.assign(3, 0.0f);
+        out.vs.assign(3, 0.0f);
+        out.vuv.assign(2, 0.0f);
+    }
+
+    // 48-B leaf-order records
+    out.prim_recs.resize(d->n_primitives);
+    for (uint32_t s = 0; s < d->n_primitives; ++s) {
+        const ShmPrimitive& pr = d->primitives[s];
+        shm::PrimRec rec;
+        memset(&rec, 0, sizeof(rec));
+        if (pr.material >= d->n_materials) { err = "primitive material out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+        if (pr.area_light >= (int32_t)d->n_lights) { err = "primitive area light out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+        if (pr.shape_kind == SHM_SHAPE_SPHERE) {
+            if (pr.shape_index >= d->n_spheres) { err = "sphere index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            rec.kind_index = shm::PRIM_SPHERE_BIT | pr.shape_index;
+            out.has_spheres = true;
+        } else if (pr.shape_kind == SHM_SHAPE_TRIANGLE) {
+            if (pr.shape_index >= n_tris) { err = "triangle index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            uint32_t m = (uint32_t)(std::upper_bound(tri_base.begin(), tri_base.end(), pr.shape_index) - tri_base.begin()) - 1;
+            const ShmTriangleMesh& mesh = d->meshes[m];
+            uint32_t local = pr.shape_index - tri_base[m];
+            for (int k = 0; k < 3; ++k) {
+                uint32_t vidx = mesh.vertex_indices[3ull * local + k];
+                if (vidx >= mesh.n_vertices) { err = "vertex index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+                float* dst = (k == 0) ? rec.p0 : (k == 1 ? rec.p1 : rec.p2);
+                dst[0] = mesh.p[3ull * vidx];
+                dst[1] = mesh.p[3ull * vidx + 1];
+                dst[2] = mesh.p[3ull * vidx + 2];
+            }
+            rec.kind_index = 0;
+            rec.mesh = m;
+            rec.tri = pr.shape_index;
+        } else {
+            err = "unsupported shape kind (bilinear patches / instances are SURVEY §8f rows)";
+            return SHM_ERR_UNSUPPORTED;
+        }
+        out.prim_recs[s] = rec;
+    }
+
+    // materials / lights
+    uint32_t nsf = (uint32_t)out.spectrum_data.size();
+    for (const ShmMaterial& m : out.materials) {
+        if (m.kind > SHM_MATERIAL_THIN_DIELECTRIC) { err = "unsupported material kind (LayeredBxDF / Mix are SURVEY §8f rows)"; return SHM_ERR_UNSUPPORTED; }
+        if (!check_spectrum(m.a, nsf, err)) return SHM_ERR_INVALID_ARGUMENT;
+        if (m.kind == SHM_MATERIAL_CONDUCTOR && !check_spectrum(m.b, nsf, err)) return SHM_ERR_INVALID_ARGUMENT;
+    }
+    for (uint32_t i = 0; i < out.lights.size(); ++i) {
+        const ShmLight& l = out.lights[i];
+        if (l.kind > SHM_LIGHT_UNIFORM_INFINITE) { err = "unsupported light kind (ImageInfinite is a SURVEY §8f row)"; return SHM_ERR_UNSUPPORTED; }
+        if (l.spectrum.kind != SHM_SPECTRUM_DENSE) { err = "light spectrum must be densely sampled (light.rs:404,551,717)"; return SHM_ERR_INVALID_ARGUMENT; }
+        if (!check_spectrum(l.spectrum, nsf, err)) return SHM_ERR_INVALID_ARGUMENT;
+        if (l.kind == SHM_LIGHT_DIFFUSE_AREA && l.primitive >= d->n_primitives) { err = "area light primitive out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+        if (l.kind == SHM_LIGHT_UNIFORM_INFINITE) out.infinite_lights.push_back(i);
+    }
+
+    // BVH validation + depth (explicit stack; DFS order means child0 = i+1)
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> st;
+        st.push_back({0u, 0u});
+        uint64_t visited = 0;
+        while (!st.empty()) {
+            auto [i, depth] = st.back();
+            st.pop_back();
+            if (i >= d->n_nodes) { err = "BVH child index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            if (++visited > d->n_nodes) { err = "BVH is not a tree"; return SHM_ERR_INVALID_ARGUMENT; }
+            const ShmBvhNode& n = d->nodes[i];
+            if (n.n_prims > 0) {
+                if ((uint64_t)n.offset + n.n_prims > d->n_primitives) { err = "BVH leaf range out of bounds"; return SHM_ERR_INVALID_ARGUMENT; }
+                if (depth > out.max_leaf_depth) out.max_leaf_depth = depth;
+            } else {
+                if (n.axis > 2) { err = "BVH axis out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+                if (n.offset <= i) { err = "BVH second child must follow its parent"; return SHM_ERR_INVALID_ARGUMENT; }
+                st.push_back({n.offset, depth + 1});
+                st.push_back({i + 1, depth + 1});
+            }
+        }
+    }
+    // The reference's traversal stack is [usize; 64] (aggregate.rs:90); deeper trees would index out of bounds there.
+    if (out.max_leaf_depth >= 64) { err = "BVH deeper than the reference's 64-entry traversal stack"; return SHM_ERR_UNSUPPORTED; }
+    return SHM_OK;
+}
+
+}  // namespace shm_host

@@ -1,0 +1,354 @@
+// host/host_mirror.cpp — C++ mirror of the reference's host-side scene-construction steps that sit
+// directly either side of the hot path (the reference is compiled Rust; no Rust toolchain exists here,
+// so the host side above the C ABI is C++; see INTEGRATION.md for the Rust shim a maintainer would add).
+//
+// Restates (paths relative to /root/reference/src):
+//   aggregate.rs:207-467        BvhAggregate::new / build_recursive / flatten_bvh
+//   bounding_box.rs:284-415     Bounds3::union, union_point, surface_area, max_dimension, Default
+//   tile.rs:21-104              Tile::tile
+//   camera.rs:507-523,594-642,893-963   CameraTransform::new, ProjectiveCameraBase::new, PerspectiveCamera::new
+//   transform.rs:263-316        Transform::inverse / look_at / perspective / scale / translate
+//   image.rs:1333-1377          Image::write_pfm
+//
+// Third-party pieces the reference pulls in here, restated from their published behaviour (unpinned):
+//   itertools 0.11 `partition` (aggregate.rs:362) and pdqselect 0.1.1 `select_by` (aggregate.rs:371,386);
+//   both only decide the ORDER of primitives inside a partition, i.e. tie-breaking of BVH topology.
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../../include/shimmer_hip.h"
+
+namespace {
+
+struct B3 {
+    float mn[3], mx[3];
+};
+inline B3 b3_default() {  // bounding_box.rs:568-581: min = MAX, max = MIN (f32::MIN is the most negative float)
+    B3 b;
+    for (int i = 0; i < 3; ++i) { b.mn[i] = 3.40282346638528859812e+38f; b.mx[i] = -3.40282346638528859812e+38f; }
+    return b;
+}
+inline float fmin_rs(float a, float b) { return (b != b) ? a : ((a != a) ? b : (a < b ? a : b)); }
+inline float fmax_rs(float a, float b) { return (b != b) ? a : ((a != a) ? b : (a > b ? a : b)); }
+inline B3 b3_union(const B3& a, const B3& b) {
+    B3 r;
+    for (int i = 0; i < 3; ++i) { r.mn[i] = fmin_rs(a.mn[i], b.mn[i]); r.mx[i] = fmax_rs(a.mx[i], b.mx[i]); }
+    return r;
+}
+inline B3 b3_union_point(const B3& a, const float p[3]) {
+    B3 r;
+    for (int i = 0; i < 3; ++i) { r.mn[i] = fmin_rs(a.mn[i], p[i]); r.mx[i] = fmax_rs(a.mx[i], p[i]); }
+    return r;
+}
+inline float b3_surface_area(const B3& b) {  // bounding_box.rs:394-397
+    float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    return 2.0f * (dx * dy + dx * dz + dy * dz);
+}
+inline int b3_max_dimension(const B3& b) {  // bounding_box.rs:404-415
+    float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    if (dx > dy && dx > dz) return 0;
+    return (dy > dz) ? 1 : 2;
+}
+
+struct BvhPrimitive {  // aggregate.rs:484-493
+    uint32_t primitive_index;
+    B3 bounds;
+    float centroid(int dim) const {  // 0.5 * min + (max * 0.5)
+        return 0.5f * bounds.mn[dim] + bounds.mx[dim] * 0.5f;
+    }
+};
+
+struct BuildNode {  // aggregate.rs:498-510
+    B3 bounds;
+    int left = -1, right = -1;
+    uint8_t split_axis = 0;
+    uint32_t first_prim_offset = 0;
+    uint32_t n_primitives = 0;
+};
+
+struct Builder {
+    std::vector<BvhPrimitive> prims;
+    std::vector<BuildNode> build_nodes;
+    uint32_t* ordered;
+    uint32_t ordered_offset = 0;
+    int split_method;
+
+    // itertools::partition: elements for which pred is true are moved to the front (unstable, two-ended).
+    template <typename Pred>
+    static size_t partition(BvhPrimitive* a, size_t n, Pred pred) {
+        size_t split_index = 0;
+        size_t front = 0, back = n;
+        while (front < back) {
+            if (!pred(a[front])) {
+                bool swapped = false;
+                while (back > front + 1) {
+                    --back;
+                    if (pred(a[back])) {
+                        std::swap(a[front], a[back]);
+                        swapped = true;
+                        break;
+                    }
+                }
+                if (!swapped) break;
+            }
+            ++split_index;
+            ++front;
+        }
+        return split_index;
+    }
+
+    int make_leaf(int node_idx, size_t begin, size_t end, const B3& bounds) {  // aggregate.rs:326-337, 348-358
+        BuildNode& node = build_nodes[node_idx];
+        uint32_t first = ordered_offset;
+        ordered_offset += (uint32_t)(end - begin);
+        for (size_t i = begin; i < end; ++i) ordered[first + (i - begin)] = prims[i].primitive_index;
+        node.bounds = bounds;
+        node.first_prim_offset = first;
+        node.n_primitives = (uint32_t)(end - begin);
+        return node_idx;
+    }
+
+    // aggregate.rs:304-419, recursion made explicit where it is a tail (right child) to bound host stack depth.
+    int build(size_t begin, size_t end) {
+        int node_idx = (int)build_nodes.size();
+        build_nodes.emplace_back();
+        B3 bounds = b3_default();
+        for (size_t i = begin; i < end; ++i) bounds = b3_union(bounds, prims[i].bounds);
+        if (b3_surface_area(bounds) == 0.0f || end - begin == 1) return make_leaf(node_idx, begin, end, bounds);
+        B3 cb = b3_default();
+        for (size_t i = begin; i < end; ++i) {
+            float c[3] = {prims[i].centroid(0), prims[i].centroid(1), prims[i].centroid(2)};
+            cb = b3_union_point(cb, c);
+        }
+        int dim = b3_max_dimension(cb);
+        if (cb.mx[dim] == cb.mn[dim]) return make_leaf(node_idx, begin, end, bounds);
+        size_t n = end - begin;
+        size_t split_index;
+        auto median_split = [&]() {
+            size_t mid = n / 2;
+            std::nth_element(prims.begin() + begin, prims.begin() + begin + mid, prims.begin() + end,
+                             [dim](const BvhPrimitive& a, const BvhPrimitive& b) { return a.centroid(dim) < b.centroid(dim); });
+            return mid;
+        };
+        if (split_method == 0) {
+            float pmid = (cb.mn[dim] + cb.mx[dim]) / 2.0f;
+            split_index = partition(prims.data() + begin, n, [dim, pmid](const BvhPrimitive& p) { return p.centroid(dim) < pmid; });
+            if (split_index == 0 || split_index == n) split_index = median_split();
+        } else {
+            split_index = median_split();
+        }
+        int left = build(begin, begin + split_index);
+        int right = build(begin + split_index, end);
+        BuildNode& node = build_nodes[node_idx];
+        node.bounds = b3_union(build_nodes[left].bounds, build_nodes[right].bounds);  // init_interior, aggregate.rs:540-557
+        node.left = left;
+        node.right = right;
+        node.split_axis = (uint8_t)dim;
+        return node_idx;
+    }
+};
+
+thread_local std::string g_host_err;
+
+// ---- 4x4 helpers (row-major), host precision is free: the results are INPUTS to oracle and GPU alike ----
+struct M4 {
+    double m[4][4];
+};
+M4 m4_identity() {
+    M4 r;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i][j] = (i == j) ? 1.0 : 0.0;
+    return r;
+}
+M4 m4_mul(const M4& a, const M4& b) {
+    M4 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += a.m[i][k] * b.m[k][j];
+            r.m[i][j] = s;
+        }
+    return r;
+}
+bool m4_inverse(const M4& a, M4& out) {  // Gauss-Jordan with partial pivoting
+    double aug[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { aug[i][j] = a.m[i][j]; aug[i][j + 4] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r) if (std::fabs(aug[r][c]) > std::fabs(aug[piv][c])) piv = r;
+        if (aug[piv][c] == 0.0) return false;
+        if (piv != c) for (int j = 0; j < 8; ++j) std::swap(aug[c][j], aug[piv][j]);
+        double inv = 1.0 / aug[c][c];
+        for (int j = 0; j < 8; ++j) aug[c][j] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            double f = aug[r][c];
+            if (f != 0.0) for (int j = 0; j < 8; ++j) aug[r][j] -= f * aug[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out.m[i][j] = aug[i][j + 4];
+    return true;
+}
+M4 m4_scale(double x, double y, double z) { M4 r = m4_identity(); r.m[0][0] = x; r.m[1][1] = y; r.m[2][2] = z; return r; }
+M4 m4_translate(double x, double y, double z) { M4 r = m4_identity(); r.m[0][3] = x; r.m[1][3] = y; r.m[2][3] = z; return r; }
+void m4_to_f32(const M4& a, float* out) { for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i * 4 + j] = (float)a.m[i][j]; }
+void m4_point(const M4& a, const double p[3], double out[3]) {
+    double r[4];
+    for (int i = 0; i < 4; ++i) r[i] = a.m[i][0] * p[0] + a.m[i][1] * p[1] + a.m[i][2] * p[2] + a.m[i][3];
+    for (int i = 0; i < 3; ++i) out[i] = (r[3] == 1.0) ? r[i] : r[i] / r[3];
+}
+
+}  // namespace
+
+extern "C" {
+
+int shm_bvh_build(const float* prim_bounds, uint32_t n, int split_method, ShmBvhNode* nodes_out,
+                  uint32_t* n_nodes_out, uint32_t* prim_order_out) {
+    if (!prim_bounds || n == 0 || !nodes_out || !n_nodes_out || !prim_order_out || split_method < 0 || split_method > 1)
+        return SHM_ERR_INVALID_ARGUMENT;
+    Builder b;
+    b.prims.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        b.prims[i].primitive_index = i;
+        for (int k = 0; k < 3; ++k) {
+            b.prims[i].bounds.mn[k] = prim_bounds[6ull * i + k];
+            b.prims[i].bounds.mx[k] = prim_bounds[6ull * i + 3 + k];
+            if (prim_bounds[6ull * i + k] != prim_bounds[6ull * i + k]) return SHM_ERR_INVALID_ARGUMENT;  // "Unexpected NaN"
+        }
+    }
+    b.build_nodes.reserve(2ull * n);
+    b.ordered = prim_order_out;
+    b.split_method = split_method;
+    int root = b.build(0, n);
+    if (b.ordered_offset != n) return SHM_ERR_INTERNAL;
+    // flatten_bvh, aggregate.rs:425-467: DFS, first child right after the parent. Our build order IS DFS
+    // pre-order (node created before its left subtree, right subtree after it), so indices carry over.
+    uint32_t total = (uint32_t)b.build_nodes.size();
+    (void)root;
+    for (uint32_t i = 0; i < total; ++i) {
+        const BuildNode& bn = b.build_nodes[i];
+        ShmBvhNode ln;
+        memset(&ln, 0, sizeof(ln));
+        for (int k = 0; k < 3; ++k) { ln.bmin[k] = bn.bounds.mn[k]; ln.bmax[k] = bn.bounds.mx[k]; }
+        if (bn.n_primitives > 0) {
+            if (bn.n_primitives >= 65536) return SHM_ERR_UNSUPPORTED;  // aggregate.rs:441 debug_assert
+            ln.offset = bn.first_prim_offset;
+            ln.n_prims = (uint16_t)bn.n_primitives;
+            ln.axis = 0;
+        } else {
+            ln.offset = (uint32_t)bn.right;  // second_child_offset
+            ln.n_prims = 0;
+            ln.axis = bn.split_axis;
+        }
+        nodes_out[i] = ln;
+    }
+    *n_nodes_out = total;
+    return SHM_OK;
+}
+
+int shm_tile_bounds(const int32_t pb[4], int32_t tile_w, int32_t tile_h, ShmTile* tiles_out, uint32_t* n_out) {
+    if (!pb || !tiles_out || !n_out || tile_w <= 0 || tile_h <= 0) return SHM_ERR_INVALID_ARGUMENT;
+    // tile.rs:21-104
+    int32_t image_width = pb[2] - pb[0];
+    int32_t image_height = pb[3] - pb[1];
+    int32_t nh = image_width / tile_w, rh = image_width % tile_w;
+    int32_t nv = image_height / tile_h, rv = image_height % tile_h;
+    uint32_t k = 0;
+    for (int32_t ty = 0; ty < nv; ++ty) {
+        for (int32_t tx = 0; tx < nh; ++tx) {
+            int32_t sx = pb[0] + tx * tile_w, sy = pb[1] + ty * tile_h;
+            tiles_out[k++] = ShmTile{sx, sy, sx + tile_w, sy + tile_h};
+        }
+        if (rh > 0) {
+            int32_t sx = pb[0] + nh * tile_w, sy = pb[1] + ty * tile_h;
+            tiles_out[k++] = ShmTile{sx, sy, sx + rh, sy + tile_h};
+        }
+    }
+    if (rv > 0) {
+        for (int32_t tx = 0; tx < nh; ++tx) {
+            int32_t sx = pb[0] + tx * tile_w, sy = pb[1] + nv * tile_h;
+            tiles_out[k++] = ShmTile{sx, sy, sx + tile_w, sy + rv};
+        }
+    }
+    if (rh > 0 && rv > 0) {
+        int32_t sx = pb[0] + nh * tile_w, sy = pb[1] + nv * tile_h;
+        tiles_out[k++] = ShmTile{sx, sy, sx + rh, sy + rv};
+    }
+    *n_out = k;
+    return SHM_OK;
+}
+
+int shm_camera_perspective(const float world_from_camera[16], float fov_deg, const int32_t full_resolution[2],
+                           float lens_radius, float focal_distance, ShmCamera* out, float render_from_world_out[16]) {
+    if (!world_from_camera || !full_resolution || !out || full_resolution[0] <= 0 || full_resolution[1] <= 0)
+        return SHM_ERR_INVALID_ARGUMENT;
+    M4 wfc;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) wfc.m[i][j] = world_from_camera[i * 4 + j];
+    // CameraTransform::new, RenderingCoordinateSystem::CameraWorld (camera.rs:507-523; main.rs:66 default)
+    double origin[3] = {0, 0, 0}, p_camera[3];
+    m4_point(wfc, origin, p_camera);
+    M4 world_from_render = m4_translate(p_camera[0], p_camera[1], p_camera[2]);
+    M4 render_from_world;
+    if (!m4_inverse(world_from_render, render_from_world)) return SHM_ERR_INVALID_ARGUMENT;
+    M4 render_from_camera = m4_mul(render_from_world, wfc);
+    // Transform::perspective(fov, 1e-2, 1000) (transform.rs:305-316)
+    double n = 1e-2, f = 1000.0;
+    M4 persp = m4_identity();
+    persp.m[2][2] = f / (f - n);
+    persp.m[2][3] = -f * n / (f - n);
+    persp.m[3][2] = 1.0;
+    persp.m[3][3] = 0.0;
+    double inv_tan = 1.0 / std::tan((3.14159265358979323846 / 180.0) * fov_deg / 2.0);
+    M4 screen_from_camera = m4_mul(m4_scale(inv_tan, inv_tan, 1.0), persp);
+    // screen window from the aspect ratio (camera.rs:848-864)
+    double frame = (double)full_resolution[0] / (double)full_resolution[1];
+    double sw[4];  // min.x, min.y, max.x, max.y
+    if (frame > 1.0) { sw[0] = -frame; sw[1] = -1.0; sw[2] = frame; sw[3] = 1.0; }
+    else { sw[0] = -1.0; sw[1] = -1.0 / frame; sw[2] = 1.0; sw[3] = 1.0 / frame; }
+    // ProjectiveCameraBase::new (camera.rs:612-634)
+    M4 ndc_from_screen = m4_mul(m4_scale(1.0 / (sw[2] - sw[0]), 1.0 / (sw[3] - sw[1]), 1.0), m4_translate(-sw[0], -sw[3], 0.0));
+    M4 raster_from_ndc = m4_scale((double)full_resolution[0], -(double)full_resolution[1], 1.0);
+    M4 raster_from_screen = m4_mul(raster_from_ndc, ndc_from_screen);
+    M4 screen_from_raster, camera_from_screen;
+    if (!m4_inverse(raster_from_screen, screen_from_raster) || !m4_inverse(screen_from_camera, camera_from_screen))
+        return SHM_ERR_INVALID_ARGUMENT;
+    M4 camera_from_raster = m4_mul(camera_from_screen, screen_from_raster);
+    memset(out, 0, sizeof(*out));
+    m4_to_f32(camera_from_raster, out->camera_from_raster);
+    m4_to_f32(render_from_camera, out->render_from_camera);
+    // dx_camera / dy_camera (camera.rs:907-910)
+    double px[3] = {1, 0, 0}, py[3] = {0, 1, 0}, p0[3] = {0, 0, 0}, a[3], b[3], c[3];
+    m4_point(camera_from_raster, px, a);
+    m4_point(camera_from_raster, py, b);
+    m4_point(camera_from_raster, p0, c);
+    for (int i = 0; i < 3; ++i) { out->dx_camera[i] = (float)(a[i] - c[i]); out->dy_camera[i] = (float)(b[i] - c[i]); }
+    out->lens_radius = lens_radius;
+    out->focal_distance = focal_distance;
+    out->shutter_open = 0.0f;
+    out->shutter_close = 1.0f;
+    if (render_from_world_out) m4_to_f32(render_from_world, render_from_world_out);
+    return SHM_OK;
+}
+
+int shm_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height) {
+    if (!path || !rgb || width <= 0 || height <= 0) return SHM_ERR_INVALID_ARGUMENT;
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return SHM_ERR_INVALID_ARGUMENT;
+    // image.rs:1333-1377: "PF\n<w> <h>\n-1.0\n" then rows bottom-to-top, little-endian f32 RGB
+    fprintf(fp, "PF\n%d %d\n-1.0\n", width, height);
+    for (int y = height - 1; y >= 0; --y) {
+        if (fwrite(rgb + 3ull * (size_t)y * (size_t)width, sizeof(float), 3ull * (size_t)width, fp) != 3ull * (size_t)width) {
+            fclose(fp);
+            return SHM_ERR_INTERNAL;
+        }
+    }
+    fclose(fp);
+    return SHM_OK;
+}
+
+}  // extern "C"

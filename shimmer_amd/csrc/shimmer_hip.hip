@@ -1,0 +1,924 @@
+// shimmer_hip.hip — the MI355X (gfx950, wave64) wavefront path tracer behind include/shimmer_hip.h.
+//
+// Replaces the tile-parallel loop of the reference (paths relative to /root/reference/src):
+//   integrator.rs:226-322  ImageTileIntegrator::render      -> shm_render / shm_render_wave (host loop below)
+//   integrator.rs:326-396  evaluate_pixel_sample            -> K1 k_generate
+//   aggregate.rs:71-139    BvhAggregate::intersect          -> K2 k_trace<false,...> (persistent waves, LDS stack)
+//   aggregate.rs:141-203   BvhAggregate::intersect_predicate-> K3 k_trace<true,...>
+//   integrator.rs:772-892  PathIntegrator::li loop body     -> K4+K5 k_shade (one path vertex per launch)
+//   integrator.rs:897-963  PathIntegrator::sample_ld        -> inside k_shade (shadow ray deferred to K3)
+//   film.rs:548-574        RgbFilm::add_sample              -> K6 k_film (per-pixel ordered f64 sums)
+// Leaf arithmetic is the single-source header library csrc/shm/*.h (compiled with -ffp-contract=off).
+//
+// Execution model: one (pixel, sample) per lane; paths live in SoA arrays in HBM; each bounce is
+// trace_closest -> shade -> trace_any over index queues compacted with wave-aggregated atomics; queue
+// sizes stay on the device (persistent / grid-stride kernels read them), so a whole spp-wave is enqueued
+// on one HIP stream without host round trips. There is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "host/flatten.h"
+#include "shm/path.h"
+
+using namespace shm;
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(_e);                           \
+            return SHM_ERR_DEVICE;                                                               \
+        }                                                                                        \
+    } while (0)
+
+constexpr int WAVE = 64;
+constexpr int TRACE_BLOCK = 256;  // 4 waves per workgroup
+constexpr int SHADE_BLOCK = 128;
+
+struct DeviceCounters {
+    unsigned long long rays_closest, rays_any, nodes_closest, tris_closest, nodes_any, tris_any, paths;
+};
+
+// Queue bookkeeping that lives in HBM so that no launch needs a host round trip.
+struct QueueState {
+    uint32_t n_active[2];   // entries in q_active[0/1]
+    uint32_t n_shadow;      // entries in q_shadow
+    uint32_t head_closest;  // persistent-wave work pointers
+    uint32_t head_any;
+    uint32_t pad[3];
+};
+
+// Path state, structure of arrays (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
+struct PathArrays {
+    ShmRay* ray;            // 32 B: o, d, t_max — input of K2
+    ShmHit* hit;            // 32 B: output of K2
+    ShmRay* shadow_ray;     // 32 B: input of K3
+    float4* shadow_contrib; // beta * Ld, added to L by K3 when unoccluded
+    float4* L;
+    float4* beta;
+    float4* lambda;
+    float4* lambda_pdf;
+    float4* ctx0;           // prev_intr_ctx: pi.low.xyz, pi.high.x
+    float4* ctx1;           //                pi.high.yz, n.xy
+    float4* ctx2;           //                n.z, ns.xyz
+    float2* pb_eta;         // p_b, eta_scale
+    uint2* rng;             // PCG32 state (inc is re-derived from pixel+seed)
+    uint32_t* pixel;        // x | y << 16 (absolute pixel coordinates, < 65536)
+    uint32_t* flags;        // depth | specular_bounce << 8 | any_non_specular << 9
+};
+
+__device__ __forceinline__ uint32_t wave_lane() { return __lane_id(); }
+
+// Wave-aggregated append: one atomic per wave, lanes get consecutive slots.
+__device__ __forceinline__ uint32_t queue_push_slot(uint32_t* counter, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    uint32_t lane = wave_lane();
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    return base + rank;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0: expand the tile list into a pixel list (reference loop order inside a tile: x outer, y inner;
+// integrator.rs:257-258).  One thread per tile; tiny.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_expand_tiles(const ShmTile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t* pixels) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    ShmTile tl = tiles[t];
+    uint32_t k = tile_offset[t];
+    for (int x = tl.x0; x < tl.x1; ++x)
+        for (int y = tl.y0; y < tl.y1; ++y) pixels[k++] = (uint32_t)x | ((uint32_t)y << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: camera rays for one batch: slot = s_local * n_pix + p_local.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArrays pa, const uint32_t* pixels, uint32_t n_pix,
+                                                        int sample_begin, int n_samples, ShmRenderParams params,
+                                                        uint32_t* q_active, QueueState* qs) {
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t total = n_pix * (uint32_t)n_samples;
+    if (slot >= total) return;
+    uint32_t p_local = slot % n_pix;
+    uint32_t s_local = slot / n_pix;
+    uint32_t pix = pixels[p_local];
+    int px = (int)(pix & 0xffffu), py = (int)(pix >> 16);
+    Rng rng = sampler_start_pixel_sample(px, py, sample_begin + (int)s_local, params.seed);
+    Wavelengths lambda;
+    Float weight;
+    Ray r = generate_camera_ray(sv, px, py, rng, params.disable_wavelength_jitter != 0, params.disable_pixel_jitter != 0,
+                                lambda, weight);
+    ShmRay ray;
+    ray.o[0] = r.o.x; ray.o[1] = r.o.y; ray.o[2] = r.o.z;
+    ray.d[0] = r.d.x; ray.d[1] = r.d.y; ray.d[2] = r.d.z;
+    ray.t_max = infinity();
+    ray.pad = 0.0f;
+    pa.ray[slot] = ray;
+    pa.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    pa.lambda[slot] = make_float4(lambda.lambda[0], lambda.lambda[1], lambda.lambda[2], lambda.lambda[3]);
+    pa.lambda_pdf[slot] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
+    pa.ctx0[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    pa.ctx1[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    pa.ctx2[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    pa.pb_eta[slot] = make_float2(1.0f, 1.0f);
+    pa.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+    pa.pixel[slot] = pix;
+    pa.flags[slot] = 0u;
+    q_active[slot] = slot;  // first bounce: identity queue
+    if (slot == 0) {
+        qs->n_active[0] = total;
+        qs->n_active[1] = 0;
+        qs->n_shadow = 0;
+        qs->head_closest = 0;
+        qs->head_any = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 / K3: BVH traversal.  Persistent waves: the grid is sized to fill the chip once; each wave pulls
+// 64 queue entries at a time with one atomic.  The per-lane node stack lives in LDS, laid out
+// [level][lane] so that a wave's push/pop touches 64 consecutive dwords (bank-conflict free for the two
+// 32-lane halves ds_read_b32/ds_write_b32 are serviced in).  Node (32 B) and primitive (48 B) records
+// are fetched as 16-B vector loads.
+//   ANY          intersect_predicate (early out, no hit record) vs intersect (closest hit)
+//   HAS_SPHERES  compile the quadric path only for scenes that contain spheres
+// ---------------------------------------------------------------------------------------------
+struct NodeRaw {
+    float4 a, b;  // a = bmin.xyz, bmax.x ; b = bmax.yz, offset(bits), n_prims|axis<<16 (bits)
+};
+
+template <bool ANY, bool HAS_SPHERES>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace(SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
+                                                      uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
+                                                      ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
+                                                      float4* __restrict__ L, const float4* __restrict__ contrib,
+                                                      DeviceCounters* counters, int stack_entries) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave_in_block = threadIdx.x / WAVE;
+    uint32_t* stack = lds_stack + (size_t)wave_in_block * (size_t)stack_entries * WAVE + lane;
+    const uint32_t n = n_ptr ? *n_ptr : n_direct;
+    unsigned long long c_nodes = 0, c_prims = 0, c_rays = 0;
+    const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sv.nodes);
+
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(head, (uint32_t)WAVE);
+        base = __shfl(base, 0);
+        if (base >= n) break;
+        uint32_t qi = base + lane;
+        bool active = qi < n;
+        uint32_t path = 0;
+        V3 ro = v3s(0.0f), rd = v3(0.0f, 0.0f, 1.0f);
+        Float t_max = 0.0f;
+        if (active) {
+            path = queue ? queue[qi] : qi;
+            const float4* rp = reinterpret_cast<const float4*>(rays + path);
+            float4 r0 = rp[0], r1 = rp[1];
+            ro = v3(r0.x, r0.y, r0.z);
+            rd = v3(r0.w, r1.x, r1.y);
+            t_max = r1.z;
+            c_rays++;
+        }
+        Hit hit;
+        hit.prim = -1; hit.t = 0.0f; hit.b0 = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f; hit.phi = 0.0f;
+        bool found_any = false;
+        if (active) {
+            // aggregate.rs:76-81
+            V3 inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+            int dir_is_neg[3] = {inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f};
+            int sp = 0;
+            uint32_t current = 0;
+            for (;;) {
+                float4 na = nodes4[2 * current], nb = nodes4[2 * current + 1];
+                c_nodes++;
+                Float bmin[3] = {na.x, na.y, na.z};
+                Float bmax[3] = {na.w, nb.x, nb.y};
+                uint32_t offset = __float_as_uint(nb.z);
+                uint32_t meta = __float_as_uint(nb.w);
+                uint32_t n_prims = meta & 0xffffu;
+                uint32_t axis = (meta >> 16) & 0xffu;
+                bool pop = true;
+                if (intersect_p_cached(bmin, bmax, ro, t_max, inv_dir, dir_is_neg)) {
+                    if (n_prims > 0) {
+                        for (uint32_t i = 0; i < n_prims; ++i) {
+                            uint32_t slot = offset + i;
+                            c_prims++;
+                            bool got;
+                            if (HAS_SPHERES) {
+                                got = prim_intersect(sv, slot, ro, rd, t_max, hit);
+                            } else {
+                                const float4* pr = reinterpret_cast<const float4*>(sv.prim_recs + slot);
+                                float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+                                TriangleIntersection ti;
+                                got = intersect_triangle(ro, rd, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y),
+                                                         v3(q1.z, q1.w, q2.x), ti);
+                                if (got) { hit.prim = (int32_t)slot; hit.t = ti.t; hit.b0 = ti.b0; hit.b1 = ti.b1; hit.b2 = ti.b2; }
+                            }
+                            if (got) {
+                                if (ANY) { found_any = true; break; }
+                                t_max = hit.t;  // aggregate.rs:105-109
+                            }
+                        }
+                        if (ANY && found_any) break;
+                    } else {
+                        // interior: push far child, descend into near child (aggregate.rs:119-127)
+                        if (dir_is_neg[axis]) {
+                            stack[(size_t)sp * WAVE] = current + 1;
+                            current = offset;
+                        } else {
+                            stack[(size_t)sp * WAVE] = offset;
+                            current = current + 1;
+                        }
+                        sp++;
+                        pop = false;
+                    }
+                }
+                if (pop) {
+                    if (sp == 0) break;
+                    sp--;
+                    current = stack[(size_t)sp * WAVE];
+                }
+            }
+        }
+        if (active) {
+            if (ANY) {
+                if (occluded_out) occluded_out[path] = found_any ? 1 : 0;
+                if (L && !found_any) {
+                    float4 l = L[path], c = contrib[path];
+                    l.x += c.x; l.y += c.y; l.z += c.z; l.w += c.w;
+                    L[path] = l;
+                }
+            } else {
+                float4* hp = reinterpret_cast<float4*>(hits + path);
+                hp[0] = make_float4(__int_as_float(hit.prim), hit.t, hit.b0, hit.b1);
+                hp[1] = make_float4(hit.b2, hit.phi, 0.0f, 0.0f);
+            }
+        }
+    }
+    // one set of atomics per wave per launch
+    for (int off = 32; off > 0; off >>= 1) {
+        c_nodes += __shfl_down(c_nodes, off);
+        c_prims += __shfl_down(c_prims, off);
+        c_rays += __shfl_down(c_rays, off);
+    }
+    if (lane == 0 && c_rays) {
+        if (ANY) {
+            atomicAdd(&counters->rays_any, c_rays);
+            atomicAdd(&counters->nodes_any, c_nodes);
+            atomicAdd(&counters->tris_any, c_prims);
+        } else {
+            atomicAdd(&counters->rays_closest, c_rays);
+            atomicAdd(&counters->nodes_closest, c_nodes);
+            atomicAdd(&counters->tris_closest, c_prims);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4+K5: one path vertex (integrator.rs:772-892 for the vertex found by K2).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ Spec ld_spec(const float4& f) { Spec s; s.v[0] = f.x; s.v[1] = f.y; s.v[2] = f.z; s.v[3] = f.w; return s; }
+__device__ __forceinline__ float4 st_spec(const Spec& s) { return make_float4(s.v[0], s.v[1], s.v[2], s.v[3]); }
+
+__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
+                                                     uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
+                                                     DeviceCounters* counters) {
+    const uint32_t n = qs->n_active[cur];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // Uniform trip count per wave so that the wave-aggregated pushes see all lanes.
+    const uint32_t n_round = (n + WAVE - 1) / WAVE * WAVE;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        bool active = i < n;
+        bool push_next = false, push_shadow = false;
+        uint32_t path = 0;
+        if (active) {
+            path = q_cur[i];
+            const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
+            float4 h0 = hp[0], h1 = hp[1];
+            Hit hit;
+            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y;
+            const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
+            float4 r0 = rp[0], r1 = rp[1];
+            V3 ray_d = v3(r0.w, r1.x, r1.y);
+            Spec l = ld_spec(pa.L[path]);
+            Spec beta = ld_spec(pa.beta[path]);
+            Wavelengths lambda;
+            {
+                float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
+                lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
+            }
+            uint32_t fl = pa.flags[path];
+            int depth = (int)(fl & 0xffu);
+            bool specular_bounce = (fl >> 8) & 1u;
+            bool any_non_specular_bounces = (fl >> 9) & 1u;
+            float2 pe = pa.pb_eta[path];
+            Float p_b = pe.x, eta_scale = pe.y;
+            LightSampleContext prev_ctx;
+            {
+                float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path];
+                prev_ctx.pi.x = iv2(c0.x, c0.w);
+                prev_ctx.pi.y = iv2(c0.y, c1.x);
+                prev_ctx.pi.z = iv2(c0.z, c1.y);
+                prev_ctx.n = v3(c1.z, c1.w, c2.x);
+                prev_ctx.ns = v3(c2.y, c2.z, c2.w);
+            }
+            if (hit.prim < 0) {
+                // integrator.rs:776-794: escaped ray, infinite lights
+                for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
+                    const ShmLight& light = sv.lights[sv.infinite_lights[k]];
+                    Spec le = light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
+                    if (depth == 0 || specular_bounce) {
+                        l = l + beta * le;
+                    } else {
+                        Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, prev_ctx, ray_d);
+                        Float w_b = power_heuristic(1, p_b, 1, p_l);
+                        l = l + beta * w_b * le;
+                    }
+                }
+                pa.L[path] = st_spec(l);
+            } else {
+                SurfaceInteraction si = hit_interaction(sv, hit, -ray_d);
+                const ShmPrimitive prim = sv.primitives[hit.prim];
+                // integrator.rs:798-813: emission at the hit
+                if (prim.area_light >= 0) {
+                    const ShmLight& light = sv.lights[prim.area_light];
+                    Spec le = area_light_l(sv, light, si.n, -ray_d, lambda);
+                    if (!is_zero(le)) {
+                        if (depth == 0 || specular_bounce) {
+                            l = l + beta * le;
+                        } else {
+                            Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, prev_ctx, ray_d);
+                            Float w_l = power_heuristic(1, p_b, 1, p_l);
+                            l = l + beta * w_l * le;
+                        }
+                    }
+                }
+                BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+                if (params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
+                bool alive = (depth != params.max_depth);  // integrator.rs:830-834
+                Rng rng;
+                if (alive) {
+                    depth += 1;
+                    uint32_t pix = pa.pixel[path];
+                    uint2 rs = pa.rng[path];
+                    rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+                    // inc is a pure function of (pixel, seed): re-derive instead of storing 8 more bytes per path
+                    {
+                        uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
+                        h = mix_bits(h ^ (params.seed + 0x9e3779b97f4a7c15ULL));
+                        rng.inc = (h << 1u) | 1u;
+                    }
+                    // integrator.rs:837-841 + 897-963: next-event estimation; the visibility test is deferred to K3
+                    if (flags_is_non_specular(bsdf_flags(bsdf))) {
+                        LightSampleContext ctx = light_ctx_from(si);
+                        uint32_t bf = bsdf_flags(bsdf);
+                        if (flags_is_reflective(bf) && !flags_is_transmissive(bf)) ctx.pi = p3i_exact(offset_ray_origin(si.pi, si.n, si.wo));
+                        else if (flags_is_transmissive(bf) && !flags_is_reflective(bf)) ctx.pi = p3i_exact(offset_ray_origin(si.pi, si.n, -si.wo));
+                        Float u = sampler_get_1d(rng);
+                        Float p_sel = 0.0f;
+                        int li = light_sampler_sample(sv, u, p_sel);
+                        V2 u_light = sampler_get_2d(rng);
+                        if (li >= 0) {
+                            const ShmLight& light = sv.lights[li];
+                            LightLiSample ls;
+                            if (light_sample_li(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
+                                V3 wo = si.wo;
+                                V3 wi = ls.wi;
+                                Spec f = bsdf_f(bsdf, wo, wi) * abs_dot(wi, si.shading.n);
+                                if (!is_zero(f)) {
+                                    Ray sr = spawn_ray_to_both_offset(si.pi, si.n, ls.p_light_pi, ls.p_light_n);
+                                    Float p_l = p_sel * ls.pdf;
+                                    Spec ld;
+                                    if (light_is_delta(light)) {
+                                        ld = ls.l * f / p_l;
+                                    } else {
+                                        Float pb2 = bsdf_pdf(bsdf, wo, wi, REFLTRANS_ALL);
+                                        Float w_l = power_heuristic(1, p_l, 1, pb2);
+                                        ld = w_l * ls.l * f / p_l;
+                                    }
+                                    ShmRay s;
+                                    s.o[0] = sr.o.x; s.o[1] = sr.o.y; s.o[2] = sr.o.z;
+                                    s.d[0] = sr.d.x; s.d[1] = sr.d.y; s.d[2] = sr.d.z;
+                                    s.t_max = 1.0f - 0.0001f;  // 1 - SHADOW_EPSILON, integrator.rs:66,115
+                                    s.pad = 0.0f;
+                                    pa.shadow_ray[path] = s;
+                                    pa.shadow_contrib[path] = st_spec(beta * ld);
+                                    push_shadow = true;
+                                }
+                            }
+                        }
+                    }
+                    // integrator.rs:843-857: sample the BSDF
+                    V3 wo = -ray_d;
+                    Float u = sampler_get_1d(rng);
+                    V2 u2 = sampler_get_2d(rng);
+                    BSDFSample bs;
+                    if (!bsdf_sample_f(bsdf, wo, u, u2, REFLTRANS_ALL, bs)) {
+                        alive = false;
+                    } else {
+                        // integrator.rs:859-872
+                        beta = beta * (bs.f * abs_dot(bs.wi, si.shading.n) / bs.pdf);
+                        p_b = bs.pdf_is_proportional ? bsdf_pdf(bsdf, wo, bs.wi, REFLTRANS_ALL) : bs.pdf;
+                        specular_bounce = flags_is_specular(bs.flags);
+                        any_non_specular_bounces |= !specular_bounce;
+                        if (flags_is_transmissive(bs.flags)) eta_scale *= sqr(bs.eta);
+                        LightSampleContext nctx = light_ctx_from(si);
+                        V3 no = offset_ray_origin(si.pi, si.n, bs.wi);  // integrator.rs:875 -> interaction.rs:68-75
+                        // integrator.rs:878-891: Russian roulette
+                        if (is_finite(eta_scale)) {
+                            Spec rr_beta = beta * eta_scale;
+                            if (max_component_value(rr_beta) < 1.0f && depth > 1) {
+                                Float q = max(0.0f, 1.0f - max_component_value(rr_beta));
+                                if (sampler_get_1d(rng) < q) alive = false;
+                                else beta = beta / (1.0f - q);
+                            }
+                        }
+                        if (alive) {
+                            ShmRay nr;
+                            nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z;
+                            nr.d[0] = bs.wi.x; nr.d[1] = bs.wi.y; nr.d[2] = bs.wi.z;
+                            nr.t_max = infinity();
+                            nr.pad = 0.0f;
+                            pa.ray[path] = nr;
+                            pa.beta[path] = st_spec(beta);
+                            pa.pb_eta[path] = make_float2(p_b, eta_scale);
+                            pa.ctx0[path] = make_float4(nctx.pi.x.low, nctx.pi.y.low, nctx.pi.z.low, nctx.pi.x.high);
+                            pa.ctx1[path] = make_float4(nctx.pi.y.high, nctx.pi.z.high, nctx.n.x, nctx.n.y);
+                            pa.ctx2[path] = make_float4(nctx.n.z, nctx.ns.x, nctx.ns.y, nctx.ns.z);
+                            pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                            pa.flags[path] = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9);
+                            push_next = true;
+                        }
+                    }
+                }
+                pa.L[path] = st_spec(l);
+                // terminate_secondary may have changed the pdfs (material.rs:609-619)
+                pa.lambda_pdf[path] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
+            }
+        }
+        uint32_t s1 = queue_push_slot(&qs->n_active[cur ^ 1], push_next);
+        if (push_next) q_next[s1] = path;
+        uint32_t s2 = queue_push_slot(&qs->n_shadow, push_shadow);
+        if (push_shadow) q_shadow[s2] = path;
+    }
+    (void)counters;
+}
+
+// Between bounces: recycle the counters (1 thread).
+__global__ void k_next_bounce(QueueState* qs, int cur) {
+    qs->n_active[cur] = 0;
+    qs->n_shadow = 0;
+    qs->head_closest = 0;
+    qs->head_any = 0;
+}
+__global__ void k_reset_head(uint32_t* head) { *head = 0; }
+
+// ---------------------------------------------------------------------------------------------
+// K6: RgbFilm::add_sample for every sample of the batch, per pixel in sample order (f64 sums are
+// order dependent; the reference adds samples of a pixel in increasing sample_index).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SHADE_BLOCK) k_film(SceneView sv, PathArrays pa, const uint32_t* pixels, uint32_t n_pix, int n_samples,
+                                                    ShmFilmPixel* film, DeviceCounters* counters) {
+    uint32_t p_local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p_local >= n_pix) return;
+    uint32_t pix = pixels[p_local];
+    int px = (int)(pix & 0xffffu), py = (int)(pix >> 16);
+    int width = sv.pixel_bounds[2] - sv.pixel_bounds[0];
+    ShmFilmPixel* fp = film + (size_t)(py - sv.pixel_bounds[1]) * (size_t)width + (size_t)(px - sv.pixel_bounds[0]);
+    double r = fp->rgb_sum[0], g = fp->rgb_sum[1], b = fp->rgb_sum[2], w = fp->weight_sum;
+    for (int s = 0; s < n_samples; ++s) {
+        uint32_t slot = (uint32_t)s * n_pix + p_local;
+        Spec L = ld_spec(pa.L[slot]);
+        Wavelengths lambda;
+        float4 a = pa.lambda[slot], c = pa.lambda_pdf[slot];
+        lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
+        lambda.pdf[0] = c.x; lambda.pdf[1] = c.y; lambda.pdf[2] = c.z; lambda.pdf[3] = c.w;
+        V3 rgb = film_sample_rgb(sv, L, lambda);
+        const Float weight = 1.0f;  // BoxFilter::sample weight (filter.rs:104)
+        r += (double)(weight * rgb.x);
+        g += (double)(weight * rgb.y);
+        b += (double)(weight * rgb.z);
+        w += (double)weight;
+    }
+    fp->rgb_sum[0] = r; fp->rgb_sum[1] = g; fp->rgb_sum[2] = b; fp->weight_sum = w;
+    if (p_local == 0) atomicAdd(&counters->paths, (unsigned long long)n_pix * (unsigned long long)n_samples);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+struct ShmScene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    shm_host::FlatScene flat;
+    SceneView dsv;                 // device pointers
+    std::vector<void*> allocs;
+    ShmFilmPixel* d_film = nullptr;
+    size_t n_film_pixels = 0;
+    // path workspace
+    uint32_t capacity = 0;
+    PathArrays pa;
+    uint32_t* d_q_active[2] = {nullptr, nullptr};
+    uint32_t* d_q_shadow = nullptr;
+    QueueState* d_qs = nullptr;
+    DeviceCounters* d_counters = nullptr;
+    uint32_t* d_pixels = nullptr;
+    size_t pixels_capacity = 0;
+    ShmTile* d_tiles = nullptr;
+    uint32_t* d_tile_offset = nullptr;
+    size_t tiles_capacity = 0;
+    uint32_t* d_head = nullptr;    // for the standalone trace entry points
+    int n_cu = 256;
+    int stack_entries = 64;
+    int trace_blocks = 0;
+    std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+template <typename T>
+int dev_upload(ShmScene* s, const std::vector<T>& v, const T** out) {
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    s->allocs.push_back(d);
+    if (!v.empty()) HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const T*>(d);
+    return SHM_OK;
+}
+template <typename T>
+int dev_alloc(ShmScene* s, size_t n, T** out) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)));
+    s->allocs.push_back(d);
+    *out = reinterpret_cast<T*>(d);
+    return SHM_OK;
+}
+
+int ensure_workspace(ShmScene* s) {
+    if (s->capacity) return SHM_OK;
+    uint32_t cap = 1u << 22;  // 4 Mi paths per batch (~1 GB of path state); SHM_BATCH_PATHS overrides
+    if (const char* e = getenv("SHM_BATCH_PATHS")) {
+        long v = atol(e);
+        if (v >= 4096) cap = (uint32_t)v;
+    }
+    cap = (cap + 4095u) & ~4095u;
+    int rc;
+#define WS(field, type) if ((rc = dev_alloc<type>(s, cap, &s->pa.field)) != SHM_OK) return rc
+    WS(ray, ShmRay); WS(hit, ShmHit); WS(shadow_ray, ShmRay); WS(shadow_contrib, float4); WS(L, float4); WS(beta, float4);
+    WS(lambda, float4); WS(lambda_pdf, float4); WS(ctx0, float4); WS(ctx1, float4); WS(ctx2, float4); WS(pb_eta, float2);
+    WS(rng, uint2); WS(pixel, uint32_t); WS(flags, uint32_t);
+#undef WS
+    if ((rc = dev_alloc<uint32_t>(s, cap, &s->d_q_active[0])) != SHM_OK) return rc;
+    if ((rc = dev_alloc<uint32_t>(s, cap, &s->d_q_active[1])) != SHM_OK) return rc;
+    if ((rc = dev_alloc<uint32_t>(s, cap, &s->d_q_shadow)) != SHM_OK) return rc;
+    s->capacity = cap;
+    return SHM_OK;
+}
+
+size_t trace_lds_bytes(const ShmScene* s) { return (size_t)(TRACE_BLOCK / WAVE) * (size_t)s->stack_entries * WAVE * sizeof(uint32_t); }
+
+template <bool ANY>
+void launch_trace(ShmScene* s, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, uint32_t* head, const ShmRay* rays,
+                  ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib) {
+    dim3 grid(s->trace_blocks), block(TRACE_BLOCK);
+    size_t lds = trace_lds_bytes(s);
+    if (s->flat.has_spheres)
+        hipLaunchKernelGGL((k_trace<ANY, true>), grid, block, lds, s->stream, s->dsv, queue, n_ptr, n_direct, head, rays, hits, occluded, L,
+                           contrib, s->d_counters, s->stack_entries);
+    else
+        hipLaunchKernelGGL((k_trace<ANY, false>), grid, block, lds, s->stream, s->dsv, queue, n_ptr, n_direct, head, rays, hits, occluded, L,
+                           contrib, s->d_counters, s->stack_entries);
+}
+
+struct EventPool {
+    ShmScene* s;
+    size_t used = 0;
+    hipEvent_t get() {
+        if (used == s->events.size()) {
+            hipEvent_t e;
+            hipEventCreate(&e);
+            s->events.push_back(e);
+        }
+        return s->events[used++];
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* shm_last_error(void) { return g_err.c_str(); }
+
+int shm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void shm_scene_destroy(ShmScene* s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    for (void* p : s->allocs) hipFree(p);
+    for (hipEvent_t e : s->events) hipEventDestroy(e);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
+    if (!out) { g_err = "out is null"; return SHM_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    ShmScene* s = new ShmScene();
+    int rc = shm_host::flatten_scene(desc, s->flat, g_err);
+    if (rc != SHM_OK) { delete s; return rc; }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+        g_err = "no HIP device visible (libshimmer_hip has no CPU fallback)";
+        delete s;
+        return SHM_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n_dev) { g_err = "device ordinal out of range"; delete s; return SHM_ERR_INVALID_ARGUMENT; }
+    s->device = device;
+    auto fail = [&](int code) { shm_scene_destroy(s); return code; };
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return fail(SHM_ERR_DEVICE); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreate(&s->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; return fail(SHM_ERR_DEVICE); }
+
+    const shm_host::FlatScene& f = s->flat;
+    SceneView v = f.view();  // scalars + host pointers; pointers replaced below
+    if ((rc = dev_upload(s, f.nodes, &v.nodes)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.prim_recs, &v.prim_recs)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.primitives, &v.primitives)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.mesh_flags, &v.mesh_flags)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.vi, &v.vi)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.vn, &v.vn)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.vs, &v.vs)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.vuv, &v.vuv)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.spheres, &v.spheres)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.materials, &v.materials)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.lights, &v.lights)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.infinite_lights, &v.infinite_lights)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.spectrum_data, &v.spectrum_data)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.sensor_r, &v.sensor_r_bar)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.sensor_g, &v.sensor_g_bar)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.sensor_b, &v.sensor_b_bar)) != SHM_OK) return fail(rc);
+    s->dsv = v;
+
+    size_t w = (size_t)(f.film.pixel_bounds[2] - f.film.pixel_bounds[0]);
+    size_t h = (size_t)(f.film.pixel_bounds[3] - f.film.pixel_bounds[1]);
+    s->n_film_pixels = w * h;
+    if ((rc = dev_alloc<ShmFilmPixel>(s, s->n_film_pixels, &s->d_film)) != SHM_OK) return fail(rc);
+    if (hipMemset(s->d_film, 0, s->n_film_pixels * sizeof(ShmFilmPixel)) != hipSuccess) { g_err = "hipMemset film"; return fail(SHM_ERR_DEVICE); }
+    if ((rc = dev_alloc<QueueState>(s, 1, &s->d_qs)) != SHM_OK) return fail(rc);
+    if ((rc = dev_alloc<DeviceCounters>(s, 1, &s->d_counters)) != SHM_OK) return fail(rc);
+    if ((rc = dev_alloc<uint32_t>(s, 1, &s->d_head)) != SHM_OK) return fail(rc);
+    hipMemset(s->d_qs, 0, sizeof(QueueState));
+    hipMemset(s->d_counters, 0, sizeof(DeviceCounters));
+
+    // Traversal stack: the deepest leaf bounds the number of simultaneously pending far children.
+    s->stack_entries = (int)std::min<uint32_t>(64u, std::max<uint32_t>(f.max_leaf_depth + 1u, 2u));
+    if (const char* e = getenv("SHM_STACK_ENTRIES")) { int v2 = atoi(e); if (v2 >= (int)f.max_leaf_depth + 1 && v2 <= 64) s->stack_entries = v2; }
+    // Persistent grid: as many 256-thread workgroups per CU as LDS (160 KiB) and the 32-wave cap admit.
+    size_t lds = trace_lds_bytes(s);
+    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+    per_cu = std::max(1, std::min(per_cu, 8));
+    if (const char* e = getenv("SHM_TRACE_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) per_cu = v2; }
+    s->trace_blocks = s->n_cu * per_cu;
+    *out = s;
+    return SHM_OK;
+}
+
+int shm_film_clear(ShmScene* s) {
+    if (!s) return SHM_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemsetAsync(s->d_film, 0, s->n_film_pixels * sizeof(ShmFilmPixel), s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SHM_OK;
+}
+
+int shm_film_read(ShmScene* s, ShmFilmPixel* film_out) {
+    if (!s || !film_out) return SHM_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(film_out, s->d_film, s->n_film_pixels * sizeof(ShmFilmPixel), hipMemcpyDeviceToHost));
+    return SHM_OK;
+}
+
+int shm_film_device_ptr(ShmScene* s, void** ptr_out, uint64_t* bytes_out) {
+    if (!s || !ptr_out || !bytes_out) return SHM_ERR_INVALID_ARGUMENT;
+    *ptr_out = s->d_film;
+    *bytes_out = (uint64_t)(s->n_film_pixels * sizeof(ShmFilmPixel));
+    return SHM_OK;
+}
+
+int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles, int32_t sample_begin,
+                    int32_t sample_end, ShmStats* stats) {
+    if (!s || !params || !tiles || n_tiles == 0 || sample_end <= sample_begin) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (params->force_diffuse) { g_err = "force_diffuse is not supported"; return SHM_ERR_UNSUPPORTED; }
+    if (params->max_depth < 0 || params->max_depth > 254) { g_err = "max_depth out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_workspace(s);
+    if (rc != SHM_OK) return rc;
+    const int32_t* pb = s->flat.film.pixel_bounds;
+    // pixel list for these tiles
+    std::vector<uint32_t> tile_offset(n_tiles);
+    uint64_t n_pixels = 0;
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        const ShmTile& tl = tiles[t];
+        if (tl.x0 < pb[0] || tl.y0 < pb[1] || tl.x1 > pb[2] || tl.y1 > pb[3] || tl.x1 <= tl.x0 || tl.y1 <= tl.y0 || tl.x1 > 65535 || tl.y1 > 65535 ||
+            tl.x0 < 0 || tl.y0 < 0) {
+            g_err = "tile outside pixel bounds";
+            return SHM_ERR_INVALID_ARGUMENT;
+        }
+        tile_offset[t] = (uint32_t)n_pixels;
+        n_pixels += (uint64_t)(tl.x1 - tl.x0) * (uint64_t)(tl.y1 - tl.y0);
+    }
+    if (n_pixels > 0xffffffffull) { g_err = "too many pixels"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (s->tiles_capacity < n_tiles) {
+        if ((rc = dev_alloc<ShmTile>(s, n_tiles, &s->d_tiles)) != SHM_OK) return rc;
+        if ((rc = dev_alloc<uint32_t>(s, n_tiles, &s->d_tile_offset)) != SHM_OK) return rc;
+        s->tiles_capacity = n_tiles;
+    }
+    if (s->pixels_capacity < n_pixels) {
+        if ((rc = dev_alloc<uint32_t>(s, n_pixels, &s->d_pixels)) != SHM_OK) return rc;
+        s->pixels_capacity = n_pixels;
+    }
+    HIP_TRY(hipMemcpyAsync(s->d_tiles, tiles, n_tiles * sizeof(ShmTile), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_tile_offset, tile_offset.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), s->stream));
+    hipLaunchKernelGGL(k_expand_tiles, dim3((n_tiles + 255) / 256), dim3(256), 0, s->stream, s->d_tiles, s->d_tile_offset, n_tiles, s->d_pixels);
+
+    const int n_samples = sample_end - sample_begin;
+    uint32_t pix_per_batch = s->capacity / (uint32_t)n_samples;
+    if (pix_per_batch == 0) { g_err = "spp-wave larger than the path workspace"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (pix_per_batch > 64) pix_per_batch &= ~63u;  // whole 8x8 tiles per wavefront
+    EventPool ev{s};
+    hipEvent_t e_begin = ev.get(), e_end = ev.get();
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_any;
+    HIP_TRY(hipEventRecord(e_begin, s->stream));
+    const int shade_blocks = s->n_cu * 8;
+    for (uint64_t p0 = 0; p0 < n_pixels; p0 += pix_per_batch) {
+        uint32_t n_pix = (uint32_t)std::min<uint64_t>(pix_per_batch, n_pixels - p0);
+        uint32_t total = n_pix * (uint32_t)n_samples;
+        const uint32_t* pixels = s->d_pixels + p0;
+        hipLaunchKernelGGL(k_generate, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
+                           sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs);
+        int cur = 0;
+        for (int bounce = 0; bounce <= params->max_depth; ++bounce) {
+            hipEvent_t a = ev.get(), b = ev.get();
+            hipEventRecord(a, s->stream);
+            launch_trace<false>(s, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, &s->d_qs->head_closest, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr);
+            hipEventRecord(b, s->stream);
+            ev_closest.push_back({a, b});
+            hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur], s->d_q_active[cur ^ 1],
+                               s->d_q_shadow, s->d_qs, cur, *params, s->d_counters);
+            if (bounce < params->max_depth) {
+                hipEvent_t c = ev.get(), d = ev.get();
+                hipEventRecord(c, s->stream);
+                launch_trace<true>(s, s->d_q_shadow, &s->d_qs->n_shadow, 0, &s->d_qs->head_any, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib);
+                hipEventRecord(d, s->stream);
+                ev_any.push_back({c, d});
+            }
+            hipLaunchKernelGGL(k_next_bounce, dim3(1), dim3(1), 0, s->stream, s->d_qs, cur);
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL(k_film, dim3((n_pix + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix, n_samples,
+                           s->d_film, s->d_counters);
+    }
+    HIP_TRY(hipEventRecord(e_end, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        DeviceCounters c;
+        HIP_TRY(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+        stats->paths += c.paths;
+        stats->rays_closest += c.rays_closest;
+        stats->rays_any += c.rays_any;
+        stats->nodes_closest += c.nodes_closest;
+        stats->tris_closest += c.tris_closest;
+        stats->nodes_any += c.nodes_any;
+        stats->tris_any += c.tris_any;
+        float ms = 0.0f;
+        hipEventElapsedTime(&ms, e_begin, e_end);
+        stats->ms_total += ms;
+        double mc = 0.0, ma = 0.0;
+        for (auto& p : ev_closest) { hipEventElapsedTime(&ms, p.first, p.second); mc += ms; }
+        for (auto& p : ev_any) { hipEventElapsedTime(&ms, p.first, p.second); ma += ms; }
+        stats->ms_trace_closest += mc;
+        stats->ms_trace_any += ma;
+        float tot = 0.0f;
+        hipEventElapsedTime(&tot, e_begin, e_end);
+        stats->ms_shade += (double)tot - mc - ma;
+        stats->launches_closest += (uint32_t)ev_closest.size();
+        stats->launches_any += (uint32_t)ev_any.size();
+    }
+    return SHM_OK;
+}
+
+int shm_render(ShmScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles, ShmFilmPixel* film, ShmStats* stats) {
+    if (!s || !params || !film) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (stats) memset(stats, 0, sizeof(*stats));
+    int rc = shm_film_clear(s);
+    if (rc != SHM_OK) return rc;
+    // integrator.rs:231-233, 306-308
+    int spp = params->samples_per_pixel;
+    int wave_start = 0, wave_end = 1, next_wave_size = 1;
+    while (wave_start < spp) {
+        rc = shm_render_wave(s, params, tiles, n_tiles, wave_start, wave_end, stats);
+        if (rc != SHM_OK) return rc;
+        wave_start = wave_end;
+        wave_end = std::min(spp, wave_end + next_wave_size);
+        next_wave_size = std::min(2 * next_wave_size, 64);
+    }
+    std::vector<ShmFilmPixel> tmp(s->n_film_pixels);
+    rc = shm_film_read(s, tmp.data());
+    if (rc != SHM_OK) return rc;
+    for (size_t i = 0; i < tmp.size(); ++i) {
+        film[i].rgb_sum[0] += tmp[i].rgb_sum[0];
+        film[i].rgb_sum[1] += tmp[i].rgb_sum[1];
+        film[i].rgb_sum[2] += tmp[i].rgb_sum[2];
+        film[i].weight_sum += tmp[i].weight_sum;
+    }
+    return SHM_OK;
+}
+
+static int trace_device_impl(ShmScene* s, bool any, const void* rays_dev, uint32_t n, void* out_dev, int repeat, ShmStats* stats) {
+    if (!s || !rays_dev || !out_dev || n == 0 || repeat < 1) { g_err = "invalid trace arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), s->stream));
+    EventPool ev{s};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    for (int r = 0; r < repeat; ++r) {
+        hipLaunchKernelGGL(k_reset_head, dim3(1), dim3(1), 0, s->stream, s->d_head);
+        hipEvent_t a = ev.get(), b = ev.get();
+        hipEventRecord(a, s->stream);
+        if (any) launch_trace<true>(s, nullptr, nullptr, n, s->d_head, (const ShmRay*)rays_dev, nullptr, (uint8_t*)out_dev, nullptr, nullptr);
+        else launch_trace<false>(s, nullptr, nullptr, n, s->d_head, (const ShmRay*)rays_dev, (ShmHit*)out_dev, nullptr, nullptr, nullptr);
+        hipEventRecord(b, s->stream);
+        evs.push_back({a, b});
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        DeviceCounters c;
+        HIP_TRY(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+        stats->rays_closest = c.rays_closest; stats->rays_any = c.rays_any;
+        stats->nodes_closest = c.nodes_closest; stats->tris_closest = c.tris_closest;
+        stats->nodes_any = c.nodes_any; stats->tris_any = c.tris_any;
+        double tot = 0.0;
+        for (auto& p : evs) { float ms = 0.0f; hipEventElapsedTime(&ms, p.first, p.second); tot += ms; }
+        if (any) { stats->ms_trace_any = tot; stats->launches_any = (uint32_t)repeat; }
+        else { stats->ms_trace_closest = tot; stats->launches_closest = (uint32_t)repeat; }
+        stats->ms_total = tot;
+    }
+    return SHM_OK;
+}
+
+int shm_trace_closest_device(ShmScene* s, const void* rays_dev, uint32_t n, void* hits_dev, int repeat, ShmStats* stats) {
+    return trace_device_impl(s, false, rays_dev, n, hits_dev, repeat, stats);
+}
+int shm_trace_any_device(ShmScene* s, const void* rays_dev, uint32_t n, void* occluded_dev, int repeat, ShmStats* stats) {
+    return trace_device_impl(s, true, rays_dev, n, occluded_dev, repeat, stats);
+}
+
+static int trace_host_impl(ShmScene* s, bool any, const ShmRay* rays, uint32_t n, void* out, ShmStats* stats) {
+    if (!s || !rays || !out || n == 0) { g_err = "invalid trace arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(s->device));
+    void *d_rays = nullptr, *d_out = nullptr;
+    size_t out_bytes = any ? (size_t)n : (size_t)n * sizeof(ShmHit);
+    HIP_TRY(hipMalloc(&d_rays, (size_t)n * sizeof(ShmRay)));
+    if (hipMalloc(&d_out, out_bytes) != hipSuccess) { hipFree(d_rays); g_err = "hipMalloc"; return SHM_ERR_OUT_OF_MEMORY; }
+    int rc = SHM_OK;
+    if (hipMemcpy(d_rays, rays, (size_t)n * sizeof(ShmRay), hipMemcpyHostToDevice) != hipSuccess) { g_err = "hipMemcpy rays"; rc = SHM_ERR_DEVICE; }
+    if (rc == SHM_OK) rc = trace_device_impl(s, any, d_rays, n, d_out, 1, stats);
+    if (rc == SHM_OK && hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) { g_err = "hipMemcpy out"; rc = SHM_ERR_DEVICE; }
+    hipFree(d_rays);
+    hipFree(d_out);
+    return rc;
+}
+int shm_trace_closest(ShmScene* s, const ShmRay* rays, uint32_t n, ShmHit* hits_out, ShmStats* stats) { return trace_host_impl(s, false, rays, n, hits_out, stats); }
+int shm_trace_any(ShmScene* s, const ShmRay* rays, uint32_t n, uint8_t* occluded_out, ShmStats* stats) { return trace_host_impl(s, true, rays, n, occluded_out, stats); }
+
+}  // extern "C"

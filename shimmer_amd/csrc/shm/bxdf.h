@@ -1,0 +1,481 @@
+// shm/bxdf.h — scattering helpers, Trowbridge–Reitz, the four contracted BxDFs and the BSDF wrapper.
+//
+// Restates (paths relative to /root/reference/src):
+//   vecmath/spherical.rs:28-92   cos_theta, cos2_theta, abs_cos_theta, sin2_theta, sin_theta, tan2_theta,
+//                                cos_phi, sin_phi, same_hemisphere
+//   scattering.rs:12-43          reflect, refract
+//   scattering.rs:49-104         fresnel_dielectric, fresnel_complex (num-complex 0.4.4 arithmetic
+//                                restated from its published definitions: parity unpinned), _spectral
+//   scattering.rs:107-220        TrowbridgeReitzDistribution::{new,effectively_smooth,d,g1,lambda,g,d_w,pdf,
+//                                sample_wm,roughness_to_alpha,regularize}
+//   bxdf.rs:184-267              DiffuseBxDF
+//   bxdf.rs:328-458              ConductorBxDF
+//   bxdf.rs:518-795              DielectricBxDF
+//   bxdf.rs:797-881              ThinDielectricBxDF
+//   bxdf.rs:1702-1829            BSDFSample, BxDFReflTransFlags, BxDFFLags
+//   bsdf.rs:22-111               BSDF::{new,f,sample_f,pdf,flags,regularize}
+#pragma once
+#include "sampling.h"
+#include "spectrum.h"
+
+namespace shm {
+
+// spherical.rs
+SHM_HD Float cos_theta(V3 w) { return w.z; }
+SHM_HD Float cos2_theta(V3 w) { return w.z * w.z; }
+SHM_HD Float abs_cos_theta(V3 w) { return abs(w.z); }
+SHM_HD Float sin2_theta(V3 w) { return max(0.0f, 1.0f - cos2_theta(w)); }
+SHM_HD Float sin_theta(V3 w) { return sqrt(sin2_theta(w)); }
+SHM_HD Float tan2_theta(V3 w) { return sin2_theta(w) / cos2_theta(w); }
+SHM_HD Float cos_phi(V3 w) {
+    Float st = sin_theta(w);
+    return (st == 0.0f) ? 1.0f : clamp(w.x / st, -1.0f, 1.0f);
+}
+SHM_HD Float sin_phi(V3 w) {
+    Float st = sin_theta(w);
+    return (st == 0.0f) ? 1.0f : clamp(w.y / st, -1.0f, 1.0f);  // spherical.rs:71-78 returns 1.0 here too
+}
+SHM_HD bool same_hemisphere(V3 w, V3 wp) { return w.z * wp.z > 0.0f; }
+
+// scattering.rs:12-14
+SHM_HD V3 reflect(V3 wo, V3 n) { return -wo + 2.0f * dot(wo, n) * n; }
+// scattering.rs:21-43
+SHM_HD bool refract(V3 wi, V3 n, Float eta, V3& wt, Float& etap) {
+    Float cos_theta_i = dot(n, wi);
+    if (cos_theta_i < 0.0f) {
+        eta = 1.0f / eta;
+        cos_theta_i = -cos_theta_i;
+        n = -n;
+    }
+    Float sin2_theta_i = max(0.0f, 1.0f - sqr(cos_theta_i));
+    Float sin2_theta_t = sin2_theta_i / sqr(eta);
+    if (sin2_theta_t >= 1.0f) return false;
+    Float cos_theta_t = sqrt(1.0f - sin2_theta_t);
+    wt = -wi / eta + (cos_theta_i / eta - cos_theta_t) * n;
+    etap = eta;
+    return true;
+}
+// scattering.rs:49-70
+SHM_HD Float fresnel_dielectric(Float cos_theta_i, Float eta) {
+    cos_theta_i = clamp(cos_theta_i, -1.0f, 1.0f);
+    if (cos_theta_i < 0.0f) {
+        eta = 1.0f / eta;
+        cos_theta_i = -cos_theta_i;
+    }
+    Float sin2_theta_i = 1.0f - cos_theta_i * cos_theta_i;
+    Float sin2_theta_t = sin2_theta_i / (eta * eta);
+    if (sin2_theta_t >= 1.0f) return 1.0f;
+    Float cos_theta_t = safe_sqrt(1.0f - sin2_theta_t);
+    Float r_parl = (eta * cos_theta_i - cos_theta_t) / (eta * cos_theta_i + cos_theta_t);
+    Float r_perp = (cos_theta_i - eta * cos_theta_t) / (cos_theta_i + eta * cos_theta_t);
+    return 0.5f * (r_parl * r_parl + r_perp * r_perp);
+}
+
+// num-complex 0.4.4 Complex<f32> (Cargo.lock; not vendored) — operations as that crate defines them.
+struct Cx { Float re, im; };
+SHM_HD Cx cx(Float re, Float im) { Cx c; c.re = re; c.im = im; return c; }
+SHM_HD Cx cx_mul(Cx a, Cx b) { return cx(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+SHM_HD Float cx_norm_sqr(Cx a) { return a.re * a.re + a.im * a.im; }
+SHM_HD Cx cx_div(Cx a, Cx b) {
+    Float ns = cx_norm_sqr(b);
+    Float re = a.re * b.re + a.im * b.im;
+    Float im = a.im * b.re - a.re * b.im;
+    return cx(re / ns, im / ns);
+}
+SHM_HD Cx real_div_cx(Float a, Cx b) {  // impl Div<Complex<T>> for T
+    Float ns = cx_norm_sqr(b);
+    return cx(a * b.re / ns, -a * b.im / ns);
+}
+SHM_HD Cx cx_sqrt(Cx z) {  // Complex::sqrt, num-complex 0.4.4
+    bool im_zero = (z.im == 0.0f);
+    bool re_zero = (z.re == 0.0f);
+    if (im_zero) {
+        bool re_pos = (float_to_bits(z.re) >> 31) == 0;
+        if (re_pos) return cx(sqrt(z.re), z.im);
+        Float im = sqrt(-z.re);
+        bool im_pos = (float_to_bits(z.im) >> 31) == 0;
+        return im_pos ? cx(0.0f, im) : cx(0.0f, -im);
+    } else if (re_zero) {
+        Float x = sqrt(abs(z.im) / 2.0f);
+        bool im_pos = (float_to_bits(z.im) >> 31) == 0;
+        return im_pos ? cx(x, x) : cx(x, -x);
+    } else {
+        Float r = hypot(z.re, z.im);
+        Float theta = atan2(z.im, z.re);
+        Float sr = sqrt(r);
+        Float ht = theta / 2.0f;
+        return cx(sr * cos(ht), sr * sin(ht));
+    }
+}
+// scattering.rs:78-89
+SHM_HD Float fresnel_complex(Float cos_theta_i, Cx eta) {
+    cos_theta_i = clamp(cos_theta_i, 0.0f, 1.0f);
+    Float sin2_theta_i = 1.0f - sqr(cos_theta_i);
+    Cx sin2_theta_t = real_div_cx(sin2_theta_i, cx_mul(eta, eta));
+    Cx cos_theta_t = cx_sqrt(cx(1.0f - sin2_theta_t.re, 0.0f - sin2_theta_t.im));
+    Cx eci = cx(eta.re * cos_theta_i, eta.im * cos_theta_i);          // eta * cos_theta_i
+    Cx r_parl = cx_div(cx(eci.re - cos_theta_t.re, eci.im - cos_theta_t.im),
+                       cx(eci.re + cos_theta_t.re, eci.im + cos_theta_t.im));
+    Cx ect = cx_mul(eta, cos_theta_t);                                // eta * cos_theta_t
+    Cx r_perp = cx_div(cx(cos_theta_i - ect.re, 0.0f - ect.im), cx(cos_theta_i + ect.re, ect.im));
+    return (cx_norm_sqr(r_parl) + cx_norm_sqr(r_perp)) / 2.0f;
+}
+// scattering.rs:92-104
+SHM_HD Spec fresnel_complex_spectral(Float cos_theta_i, const Spec& eta, const Spec& k) {
+    Spec s;
+    for (int i = 0; i < NSPEC; ++i) s.v[i] = fresnel_complex(cos_theta_i, cx(eta.v[i], k.v[i]));
+    return s;
+}
+
+// scattering.rs:107-220
+struct TrowbridgeReitz {
+    Float alpha_x, alpha_y;
+    SHM_HD bool effectively_smooth() const { return alpha_x < 1e-3f && alpha_y < 1e-3f; }
+    SHM_HD Float d(V3 wm) const {
+        Float t2 = tan2_theta(wm);
+        if (is_inf(t2)) return 0.0f;
+        Float cos4_theta = sqr(cos2_theta(wm));
+        if (cos4_theta < 1e-16f) return 0.0f;
+        Float e = t2 * (sqr(cos_phi(wm) / alpha_x) + sqr(sin_phi(wm) / alpha_y));
+        return 1.0f / (PI_F * alpha_x * alpha_y * cos4_theta * sqr(1.0f + e));
+    }
+    SHM_HD Float lambda(V3 w) const {
+        Float t2 = tan2_theta(w);
+        if (is_inf(t2)) return 0.0f;
+        Float alpha2 = sqr(cos_phi(w) * alpha_x) + sqr(sin_phi(w) * alpha_y);
+        return (-1.0f + sqrt(1.0f + alpha2 * t2)) / 2.0f;
+    }
+    SHM_HD Float g1(V3 w) const { return 1.0f / (1.0f + lambda(w)); }
+    SHM_HD Float g(V3 wo, V3 wi) const { return 1.0f / (1.0f + lambda(wo) + lambda(wi)); }
+    SHM_HD Float d_w(V3 w, V3 wm) const { return g1(w) / abs_cos_theta(w) * d(wm) * abs_dot(w, wm); }
+    SHM_HD Float pdf(V3 w, V3 wm) const { return d_w(w, wm); }
+    SHM_HD V3 sample_wm(V3 w, V2 u) const {
+        V3 wh = normalize(v3(alpha_x * w.x, alpha_y * w.y, w.z));
+        if (wh.z < 0.0f) wh = -wh;
+        V3 t1 = (wh.z < 0.99999f) ? normalize(cross(v3(0.0f, 0.0f, 1.0f), wh)) : v3(1.0f, 0.0f, 0.0f);
+        V3 t2 = cross(wh, t1);
+        V2 p = sample_uniform_disk_polar(u);
+        Float h = sqrt(1.0f - sqr(p.x));
+        p.y = lerp((1.0f + wh.z) / 2.0f, h, p.y);
+        Float pz = sqrt(max(0.0f, 1.0f - length_squared(p)));
+        V3 nh = p.x * t1 + p.y * t2 + pz * wh;
+        return normalize(v3(alpha_x * nh.x, alpha_y * nh.y, max(1e-6f, nh.z)));
+    }
+    SHM_HD void regularize() {
+        if (alpha_x < 0.3f) alpha_x = clamp(2.0f * alpha_x, 0.1f, 0.3f);
+        if (alpha_y < 0.3f) alpha_y = clamp(2.0f * alpha_y, 0.1f, 0.3f);
+    }
+};
+SHM_HD TrowbridgeReitz trowbridge_reitz_new(Float ax, Float ay) {  // scattering.rs:113-126
+    TrowbridgeReitz d;
+    d.alpha_x = ax;
+    d.alpha_y = ay;
+    if (!d.effectively_smooth()) {
+        d.alpha_x = max(d.alpha_x, 1e-4f);
+        d.alpha_y = max(d.alpha_y, 1e-4f);
+    }
+    return d;
+}
+SHM_HD Float roughness_to_alpha(Float roughness) { return sqrt(roughness); }  // scattering.rs:208-210
+
+// bxdf.rs:1773-1829
+enum : uint32_t {
+    BXDF_UNSET = 0,
+    BXDF_REFLECTION = 1 << 0,
+    BXDF_TRANSMISSION = 1 << 1,
+    BXDF_DIFFUSE = 1 << 2,
+    BXDF_GLOSSY = 1 << 3,
+    BXDF_SPECULAR = 1 << 4,
+    BXDF_DIFFUSE_REFLECTION = BXDF_DIFFUSE | BXDF_REFLECTION,
+    BXDF_GLOSSY_REFLECTION = BXDF_GLOSSY | BXDF_REFLECTION,
+    BXDF_GLOSSY_TRANSMISSION = BXDF_GLOSSY | BXDF_TRANSMISSION,
+    BXDF_SPECULAR_REFLECTION = BXDF_SPECULAR | BXDF_REFLECTION,
+    BXDF_SPECULAR_TRANSMISSION = BXDF_SPECULAR | BXDF_TRANSMISSION,
+};
+enum : uint32_t { REFLTRANS_REFLECTION = 1, REFLTRANS_TRANSMISSION = 2, REFLTRANS_ALL = 3 };
+SHM_HD bool flags_is_reflective(uint32_t f) { return (f & BXDF_REFLECTION) != 0; }
+SHM_HD bool flags_is_transmissive(uint32_t f) { return (f & BXDF_TRANSMISSION) != 0; }
+SHM_HD bool flags_is_specular(uint32_t f) { return (f & BXDF_SPECULAR) != 0; }
+SHM_HD bool flags_is_non_specular(uint32_t f) { return (f & (BXDF_DIFFUSE | BXDF_GLOSSY)) != 0; }
+
+// bxdf.rs:1702-1742
+struct BSDFSample {
+    Spec f;
+    V3 wi;
+    Float pdf;
+    uint32_t flags;
+    Float eta;
+    bool pdf_is_proportional;
+};
+SHM_HD BSDFSample bsdf_sample(const Spec& f, V3 wi, Float pdf, uint32_t flags, Float eta = 1.0f) {
+    BSDFSample s;
+    s.f = f; s.wi = wi; s.pdf = pdf; s.flags = flags; s.eta = eta; s.pdf_is_proportional = false;
+    return s;
+}
+
+// One tagged struct for the four BxDFs (the reference's `enum BxDF`, bxdf.rs:96-103, minus Coated*).
+struct BxDF {
+    uint32_t kind;       // SHM_MATERIAL_*
+    Spec r;              // Diffuse: R ; Conductor: eta
+    Spec k;              // Conductor: k
+    Float eta;           // Dielectric / ThinDielectric
+    TrowbridgeReitz mf;  // Conductor / Dielectric
+};
+
+// ---- DiffuseBxDF, bxdf.rs:184-267 ----
+SHM_HD Spec diffuse_f(const BxDF& b, V3 wo, V3 wi) {
+    if (!same_hemisphere(wo, wi)) return spec_const(0.0f);
+    return b.r * INV_PI;
+}
+SHM_HD bool diffuse_sample_f(const BxDF& b, V3 wo, V2 u, uint32_t sample_flags, BSDFSample& out) {
+    if ((sample_flags & REFLTRANS_REFLECTION) == 0) return false;
+    V3 wi = sample_cosine_hemisphere(u);
+    if (wo.z < 0.0f) wi.z *= -1.0f;
+    Float pdf = cosine_hemisphere_pdf(abs_cos_theta(wi));
+    out = bsdf_sample(b.r * INV_PI, wi, pdf, BXDF_DIFFUSE_REFLECTION);
+    return true;
+}
+SHM_HD Float diffuse_pdf(const BxDF&, V3 wo, V3 wi, uint32_t sample_flags) {
+    if ((sample_flags & REFLTRANS_REFLECTION) == 0 || !same_hemisphere(wo, wi)) return 0.0f;
+    return cosine_hemisphere_pdf(abs_cos_theta(wi));
+}
+
+// ---- ConductorBxDF, bxdf.rs:328-458 ----
+SHM_HD Spec conductor_f(const BxDF& b, V3 wo, V3 wi) {
+    if (!same_hemisphere(wo, wi)) return spec_const(0.0f);
+    if (b.mf.effectively_smooth()) return spec_const(0.0f);
+    Float cos_theta_o = abs_cos_theta(wo);
+    Float cos_theta_i = abs_cos_theta(wi);
+    if (cos_theta_i == 0.0f || cos_theta_o == 0.0f) return spec_const(0.0f);
+    V3 wm = wi + wo;
+    if (length_squared(wm) == 0.0f) return spec_const(0.0f);
+    wm = normalize(wm);
+    Spec f = fresnel_complex_spectral(abs_dot(wo, wm), b.r, b.k);
+    return b.mf.d(wm) * f * b.mf.g(wo, wi) / (4.0f * cos_theta_o * cos_theta_i);
+}
+SHM_HD bool conductor_sample_f(const BxDF& b, V3 wo, V2 u, uint32_t sample_flags, BSDFSample& out) {
+    if ((sample_flags & REFLTRANS_REFLECTION) == 0) return false;
+    if (b.mf.effectively_smooth()) {
+        V3 wi = v3(-wo.x, -wo.y, wo.z);
+        Spec f = fresnel_complex_spectral(abs_cos_theta(wi), b.r, b.k) / abs_cos_theta(wi);
+        out = bsdf_sample(f, wi, 1.0f, BXDF_SPECULAR_REFLECTION);
+        return true;
+    }
+    if (wo.z == 0.0f) return false;
+    V3 wm = b.mf.sample_wm(wo, u);
+    V3 wi = reflect(wo, wm);
+    if (!same_hemisphere(wo, wi)) return false;
+    Float pdf = b.mf.pdf(wo, wm) / (4.0f * abs_dot(wo, wm));
+    Float cos_theta_o = abs_cos_theta(wo);
+    Float cos_theta_i = abs_cos_theta(wi);
+    if (cos_theta_i == 0.0f || cos_theta_o == 0.0f) return false;
+    Spec fr = fresnel_complex_spectral(abs_dot(wo, wm), b.r, b.k);
+    Spec f = b.mf.d(wm) * fr * b.mf.g(wo, wi) / (4.0f * cos_theta_o * cos_theta_i);
+    out = bsdf_sample(f, wi, pdf, BXDF_GLOSSY_REFLECTION);
+    return true;
+}
+SHM_HD Float conductor_pdf(const BxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
+    if ((sample_flags & REFLTRANS_REFLECTION) == 0 || !same_hemisphere(wo, wi) || b.mf.effectively_smooth())
+        return 0.0f;
+    V3 wm = wo + wi;
+    if (length_squared(wm) == 0.0f) return 0.0f;
+    wm = face_forward(normalize(wm), v3(0.0f, 0.0f, 1.0f));
+    return b.mf.pdf(wo, wm) / (4.0f * abs_dot(wo, wm));
+}
+
+// ---- DielectricBxDF, bxdf.rs:518-795 (TransportMode::Radiance only: the path never uses Importance) ----
+SHM_HD Spec dielectric_f(const BxDF& b, V3 wo, V3 wi) {
+    if (b.eta == 1.0f || b.mf.effectively_smooth()) return spec_const(0.0f);
+    Float cos_theta_o = cos_theta(wo);
+    Float cos_theta_i = cos_theta(wi);
+    bool reflect_ = cos_theta_i * cos_theta_o > 0.0f;
+    Float etap = 1.0f;
+    if (!reflect_) etap = (cos_theta_o > 0.0f) ? b.eta : (1.0f / b.eta);
+    V3 wm = wi * etap + wo;
+    if (cos_theta_i == 0.0f || cos_theta_o == 0.0f || length_squared(wm) == 0.0f) return spec_const(0.0f);
+    wm = face_forward(normalize(wm), v3(0.0f, 0.0f, 1.0f));
+    if (dot(wm, wi) * cos_theta_i < 0.0f || dot(wm, wo) * cos_theta_o < 0.0f) return spec_const(0.0f);
+    Float f = fresnel_dielectric(dot(wo, wm), b.eta);
+    if (reflect_) {
+        return spec_const(b.mf.d(wm) * b.mf.g(wo, wi) * f / abs(4.0f * cos_theta_i * cos_theta_o));
+    } else {
+        Float denom = sqr(dot(wi, wm) + dot(wo, wm) / etap) * cos_theta_i * cos_theta_o;
+        Float ft = b.mf.d(wm) * (1.0f - f) * b.mf.g(wo, wi) * abs(dot(wi, wm) * dot(wo, wm) / denom);
+        ft /= sqr(etap);  // TransportMode::Radiance
+        return spec_const(ft);
+    }
+}
+SHM_HD bool dielectric_sample_f(const BxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out) {
+    if (b.eta == 1.0f || b.mf.effectively_smooth()) {
+        Float r = fresnel_dielectric(cos_theta(wo), b.eta);
+        Float t = 1.0f - r;
+        Float pr = r, pt = t;
+        if ((sample_flags & REFLTRANS_REFLECTION) == 0) pr = 0.0f;
+        if ((sample_flags & REFLTRANS_TRANSMISSION) == 0) pt = 0.0f;
+        if (pr == 0.0f && pt == 0.0f) return false;
+        if (uc < pr / (pr + pt)) {
+            V3 wi = v3(-wo.x, -wo.y, wo.z);
+            Spec fr = spec_const(r / abs_cos_theta(wi));
+            out = bsdf_sample(fr, wi, pr / (pr + pt), BXDF_SPECULAR_REFLECTION);
+            return true;
+        } else {
+            V3 wi; Float etap;
+            if (!refract(wo, v3(0.0f, 0.0f, 1.0f), b.eta, wi, etap)) return false;
+            Spec ft = spec_const(t / abs_cos_theta(wi));
+            ft = ft / sqr(etap);  // Radiance
+            out = bsdf_sample(ft, wi, pt / (pr + pt), BXDF_SPECULAR_TRANSMISSION, etap);
+            return true;
+        }
+    } else {
+        V3 wm = b.mf.sample_wm(wo, u);
+        Float r = fresnel_dielectric(dot(wo, wm), b.eta);
+        Float t = 1.0f - r;
+        Float pr = r, pt = t;
+        if ((sample_flags & REFLTRANS_REFLECTION) == 0) pr = 0.0f;
+        if ((sample_flags & REFLTRANS_TRANSMISSION) == 0) pt = 0.0f;
+        if (pr == 0.0f && pt == 0.0f) return false;
+        if (uc < pr / (pr + pt)) {
+            V3 wi = reflect(wo, wm);
+            if (!same_hemisphere(wo, wi)) return false;
+            Float pdf = b.mf.pdf(wo, wm) / (4.0f * abs_dot(wo, wm)) * pr / (pr + pt);
+            Spec f = spec_const(b.mf.d(wm) * b.mf.g(wo, wi) * r / (4.0f * cos_theta(wi) * cos_theta(wo)));
+            out = bsdf_sample(f, wi, pdf, BXDF_GLOSSY_REFLECTION);
+            return true;
+        } else {
+            V3 wi; Float etap;
+            if (!refract(wo, wm, b.eta, wi, etap)) return false;
+            if (same_hemisphere(wo, wi) || wi.z == 0.0f) return false;
+            Float denom = sqr(dot(wi, wm) + dot(wo, wm) / etap);
+            Float dwm_dwi = abs_dot(wi, wm) / denom;
+            Float pdf = b.mf.pdf(wo, wm) * dwm_dwi * pt / (pr + pt);
+            Spec ft = spec_const(t * b.mf.d(wm) * b.mf.g(wo, wi)
+                                 * abs(dot(wi, wm) * dot(wo, wm) / (cos_theta(wi) * cos_theta(wo) * denom)));
+            ft = ft / sqr(etap);  // Radiance
+            out = bsdf_sample(ft, wi, pdf, BXDF_GLOSSY_TRANSMISSION, etap);
+            return true;
+        }
+    }
+}
+SHM_HD Float dielectric_pdf(const BxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
+    if (b.eta == 1.0f || b.mf.effectively_smooth()) return 0.0f;
+    Float cos_theta_o = cos_theta(wo);
+    Float cos_theta_i = cos_theta(wi);
+    bool reflect_ = cos_theta_i * cos_theta_o > 0.0f;
+    Float etap = 1.0f;
+    if (!reflect_) etap = (cos_theta_o > 0.0f) ? b.eta : (1.0f / b.eta);
+    V3 wm = wi * etap + wo;
+    if (cos_theta_i == 0.0f || cos_theta_o == 0.0f || length_squared(wm) == 0.0f) return 0.0f;
+    wm = face_forward(normalize(wm), v3(0.0f, 0.0f, 1.0f));
+    if (dot(wm, wi) * cos_theta_i < 0.0f || dot(wm, wo) * cos_theta_o < 0.0f) return 0.0f;
+    Float r = fresnel_dielectric(dot(wo, wm), b.eta);
+    Float t = 1.0f - r;
+    Float pr = r, pt = t;
+    if ((sample_flags & REFLTRANS_REFLECTION) == 0) pr = 0.0f;
+    if ((sample_flags & REFLTRANS_TRANSMISSION) == 0) pt = 0.0f;
+    if (pr == 0.0f && pt == 0.0f) return 0.0f;
+    if (reflect_) {
+        return b.mf.pdf(wo, wm) / (4.0f * abs_dot(wo, wm)) * pr / (pr + pt);
+    } else {
+        Float denom = sqr(dot(wi, wm) + dot(wo, wm) / etap);
+        Float dwm_dwi = abs_dot(wi, wm) / denom;
+        return b.mf.pdf(wo, wm) * dwm_dwi * pt / (pr + pt);
+    }
+}
+SHM_HD uint32_t dielectric_flags(const BxDF& b) {
+    uint32_t flags = (b.eta == 1.0f) ? BXDF_TRANSMISSION : (BXDF_REFLECTION | BXDF_TRANSMISSION);
+    return flags | (b.mf.effectively_smooth() ? BXDF_SPECULAR : BXDF_GLOSSY);
+}
+
+// ---- ThinDielectricBxDF, bxdf.rs:797-881 ----
+SHM_HD bool thin_dielectric_sample_f(const BxDF& b, V3 wo, Float uc, uint32_t sample_flags, BSDFSample& out) {
+    Float r = fresnel_dielectric(abs_cos_theta(wo), b.eta);
+    Float t = 1.0f - r;
+    if (r < 1.0f) {
+        r += sqr(t) * r / (1.0f - sqr(r));
+        t = 1.0f - r;
+    }
+    Float pr = r, pt = t;
+    if ((sample_flags & REFLTRANS_REFLECTION) == 0) pr = 0.0f;
+    if ((sample_flags & REFLTRANS_TRANSMISSION) == 0) pt = 0.0f;
+    if (pr == 0.0f && pt == 0.0f) return false;
+    if (uc < pr / (pr + pt)) {
+        V3 wi = v3(-wo.x, -wo.y, wo.z);
+        out = bsdf_sample(spec_const(r / abs_cos_theta(wi)), wi, pr / (pr + pt), BXDF_SPECULAR_REFLECTION);
+    } else {
+        V3 wi = -wo;
+        out = bsdf_sample(spec_const(t / abs_cos_theta(wi)), wi, pt / (pr + pt), BXDF_SPECULAR_TRANSMISSION);
+    }
+    return true;
+}
+
+// ---- enum dispatch, bxdf.rs:105-182 ----
+SHM_HD uint32_t bxdf_flags(const BxDF& b) {
+    switch (b.kind) {
+        case SHM_MATERIAL_DIFFUSE: return is_zero(b.r) ? BXDF_UNSET : BXDF_DIFFUSE_REFLECTION;
+        case SHM_MATERIAL_CONDUCTOR: return b.mf.effectively_smooth() ? BXDF_SPECULAR_REFLECTION : BXDF_GLOSSY_REFLECTION;
+        case SHM_MATERIAL_DIELECTRIC: return dielectric_flags(b);
+        default: return BXDF_REFLECTION | BXDF_TRANSMISSION | BXDF_SPECULAR;
+    }
+}
+SHM_HD Spec bxdf_f(const BxDF& b, V3 wo, V3 wi) {
+    switch (b.kind) {
+        case SHM_MATERIAL_DIFFUSE: return diffuse_f(b, wo, wi);
+        case SHM_MATERIAL_CONDUCTOR: return conductor_f(b, wo, wi);
+        case SHM_MATERIAL_DIELECTRIC: return dielectric_f(b, wo, wi);
+        default: return spec_const(0.0f);
+    }
+}
+SHM_HD bool bxdf_sample_f(const BxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out) {
+    switch (b.kind) {
+        case SHM_MATERIAL_DIFFUSE: return diffuse_sample_f(b, wo, u, sample_flags, out);
+        case SHM_MATERIAL_CONDUCTOR: return conductor_sample_f(b, wo, u, sample_flags, out);
+        case SHM_MATERIAL_DIELECTRIC: return dielectric_sample_f(b, wo, uc, u, sample_flags, out);
+        default: return thin_dielectric_sample_f(b, wo, uc, sample_flags, out);
+    }
+}
+SHM_HD Float bxdf_pdf(const BxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
+    switch (b.kind) {
+        case SHM_MATERIAL_DIFFUSE: return diffuse_pdf(b, wo, wi, sample_flags);
+        case SHM_MATERIAL_CONDUCTOR: return conductor_pdf(b, wo, wi, sample_flags);
+        case SHM_MATERIAL_DIELECTRIC: return dielectric_pdf(b, wo, wi, sample_flags);
+        default: return 0.0f;
+    }
+}
+SHM_HD void bxdf_regularize(BxDF& b) {
+    if (b.kind == SHM_MATERIAL_CONDUCTOR || b.kind == SHM_MATERIAL_DIELECTRIC) b.mf.regularize();
+}
+
+// ---- BSDF, bsdf.rs:9-111 ----
+struct BSDF {
+    BxDF bxdf;
+    Frame shading_frame;
+};
+SHM_HD BSDF bsdf_new(V3 ns, V3 dpdus, const BxDF& bxdf) {  // bsdf.rs:22-28
+    BSDF b;
+    b.bxdf = bxdf;
+    b.shading_frame = frame_from_xz(normalize(dpdus), ns);
+    return b;
+}
+SHM_HD uint32_t bsdf_flags(const BSDF& b) { return bxdf_flags(b.bxdf); }
+SHM_HD Spec bsdf_f(const BSDF& b, V3 wo_render, V3 wi_render) {  // bsdf.rs:44-58
+    V3 wi = b.shading_frame.to_local(wi_render);
+    V3 wo = b.shading_frame.to_local(wo_render);
+    if (wo.z == 0.0f) return spec_const(0.0f);
+    return bxdf_f(b.bxdf, wo, wi);
+}
+SHM_HD bool bsdf_sample_f(const BSDF& b, V3 wo_render, Float u, V2 u2, uint32_t sample_flags, BSDFSample& bs) {  // bsdf.rs:60-82
+    V3 wo = b.shading_frame.to_local(wo_render);
+    if (wo.z == 0.0f || !((bxdf_flags(b.bxdf) & sample_flags) != 0)) return false;
+    if (!bxdf_sample_f(b.bxdf, wo, u, u2, sample_flags, bs)) return false;
+    if (is_zero(bs.f) || bs.pdf == 0.0f || bs.wi.z == 0.0f) return false;
+    bs.wi = b.shading_frame.from_local(bs.wi);
+    return true;
+}
+SHM_HD Float bsdf_pdf(const BSDF& b, V3 wo_render, V3 wi_render, uint32_t sample_flags) {  // bsdf.rs:84-97
+    V3 wo = b.shading_frame.to_local(wo_render);
+    V3 wi = b.shading_frame.to_local(wi_render);
+    if (wo.z == 0.0f) return 0.0f;
+    return bxdf_pdf(b.bxdf, wo, wi, sample_flags);
+}
+
+}  // namespace shm

@@ -1,0 +1,190 @@
+// shm/path.h — per-vertex building blocks of PathIntegrator::li: lights, material -> BSDF, camera rays, film.
+//
+// Restates (paths relative to /root/reference/src):
+//   light.rs:984-1043             LightSampleContext
+//   light.rs:392-497              PointLight::{sample_li,pdf_li}
+//   light.rs:632-684              DiffuseAreaLight::{sample_li,pdf_li,l}
+//   light.rs:747-803              UniformInfiniteLight::{sample_li,pdf_li,le}
+//   light_sampler.rs:83-111       UniformLightSampler::{sample_light,pmf_light}
+//   interaction.rs:187-278        SurfaceInteraction::get_bsdf (constant textures: ray differentials are dead
+//                                 values and are not carried; bump_map with a constant displacement is executed
+//                                 literally so that signed zeros match, material.rs:1477-1508)
+//   material.rs:301-311,456-499,603-635,723-742   get_bxdf for Diffuse/Conductor/Dielectric/ThinDielectric
+//   sampling.rs:347-371, filter.rs:99-105         get_camera_sample, BoxFilter::sample
+//   camera.rs:1003-1079           PerspectiveCamera::generate_ray_differential (main ray only)
+//   film.rs:548-574, 907-914      RgbFilm::add_sample, PixelSensor::to_sensor_rgb
+#pragma once
+#include "bxdf.h"
+#include "scene.h"
+
+namespace shm {
+
+struct LightSampleContext {  // light.rs:984-999
+    P3i pi;
+    V3 n, ns;
+    SHM_HD V3 p() const { return pi.mid(); }
+};
+SHM_HD LightSampleContext light_ctx_from(const SurfaceInteraction& si) {  // light.rs:1001-1009
+    LightSampleContext c;
+    c.pi = si.pi; c.n = si.n; c.ns = si.shading.n;
+    return c;
+}
+struct LightLiSample {  // light.rs:1045-1065
+    Spec l;
+    V3 wi;
+    Float pdf;
+    P3i p_light_pi;  // p_light: Interaction {pi, n}
+    V3 p_light_n;
+};
+
+SHM_HD bool light_is_delta(const ShmLight& l) { return l.kind == SHM_LIGHT_POINT; }  // light.rs:1098-1102
+
+// DiffuseAreaLight::l, light.rs:668-684
+SHM_HD Spec area_light_l(const SceneView& sv, const ShmLight& light, V3 n, V3 w, const Wavelengths& lambda) {
+    if (!light.two_sided && dot(n, w) < 0.0f) return spec_const(0.0f);
+    return light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
+}
+
+// Light::sample_li with allow_incomplete_pdf = true (the only way PathIntegrator calls it, integrator.rs:927)
+SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const LightSampleContext& ctx, V2 u,
+                            const Wavelengths& lambda, LightLiSample& out) {
+    if (light.kind == SHM_LIGHT_POINT) {  // light.rs:452-468
+        V3 p = ld3(light.position);
+        V3 wi = normalize(p - ctx.p());
+        Spec li = light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda) / distance_squared(p, ctx.p());
+        out.l = li; out.wi = wi; out.pdf = 1.0f;
+        out.p_light_pi = p3i_exact(p);
+        out.p_light_n = v3s(0.0f);
+        return true;
+    }
+    if (light.kind == SHM_LIGHT_UNIFORM_INFINITE) return false;  // light.rs:747-749 (allow_incomplete_pdf)
+    // DiffuseAreaLight::sample_li, light.rs:632-661
+    ShapeSampleContext sctx;
+    sctx.pi = ctx.pi; sctx.n = ctx.n; sctx.ns = ctx.ns;
+    ShapeSample ss;
+    const PrimRec& pr = sv.prim_recs[light.primitive];
+    bool ok;
+    if (pr.kind_index & PRIM_SPHERE_BIT) ok = sphere_sample_with_context(sv.spheres[pr.kind_index & ~PRIM_SPHERE_BIT], sctx, u, ss);
+    else ok = triangle_sample_with_context(load_triangle(sv, light.primitive), sctx, u, ss);
+    if (!ok) return false;
+    if (ss.pdf == 0.0f || length_squared(ss.pi.mid() - ctx.p()) == 0.0f) return false;
+    V3 wi = normalize(ss.pi.mid() - ctx.p());
+    Spec le = area_light_l(sv, light, ss.n, -wi, lambda);
+    if (is_zero(le)) return false;
+    out.l = le; out.wi = wi; out.pdf = ss.pdf;
+    out.p_light_pi = ss.pi;
+    out.p_light_n = ss.n;
+    return true;
+}
+// Light::pdf_li with allow_incomplete_pdf = true
+SHM_HD Float light_pdf_li(const SceneView& sv, const ShmLight& light, const LightSampleContext& ctx, V3 wi) {
+    if (light.kind != SHM_LIGHT_DIFFUSE_AREA) return 0.0f;  // light.rs:470-477, 774-775
+    ShapeSampleContext sctx;
+    sctx.pi = ctx.pi; sctx.n = ctx.n; sctx.ns = ctx.ns;
+    const PrimRec& pr = sv.prim_recs[light.primitive];
+    if (pr.kind_index & PRIM_SPHERE_BIT) return sphere_pdf_with_context(sv.spheres[pr.kind_index & ~PRIM_SPHERE_BIT], sctx, wi);
+    return triangle_pdf_with_context(load_triangle(sv, light.primitive), sctx, wi);
+}
+// UniformLightSampler, light_sampler.rs:91-111. Returns light index or -1; p = 1/n.
+SHM_HD int light_sampler_sample(const SceneView& sv, Float u, Float& p) {
+    if (sv.n_lights == 0) return -1;
+    uint32_t idx = (uint32_t)(u * (Float)sv.n_lights);
+    if (idx > sv.n_lights - 1) idx = sv.n_lights - 1;
+    p = 1.0f / (Float)sv.n_lights;
+    return (int)idx;
+}
+SHM_HD Float light_sampler_pmf(const SceneView& sv) { return sv.n_lights == 0 ? 0.0f : 1.0f / (Float)sv.n_lights; }
+
+// SurfaceInteraction::get_bsdf (interaction.rs:187-278) for Single materials with constant textures.
+// lambda is mutable: DielectricMaterial terminates secondary wavelengths for dispersive eta.
+SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMaterial& m, Wavelengths& lambda) {
+    if (m.has_displacement) {
+        // bump_map, material.rs:1477-1508, with FloatConstantTexture: u_displace == v_displace == displace.
+        // du, dv are finite and > 0 (interaction.rs:316-339 clamps; 0 -> 0.0005), so (x - x) / du == +0.
+        Float displace = m.displacement;
+        Float du = 0.0005f, dv = 0.0005f;
+        V3 dpdu = si.shading.dpdu + (displace - displace) / du * si.shading.n + displace * si.shading.dndu;
+        V3 dpdv = si.shading.dpdv + (displace - displace) / dv * si.shading.n + displace * si.shading.dndv;
+        V3 ns = normalize(cross(dpdu, dpdv));
+        set_shading_geometry(si, ns, dpdu, dpdv, si.shading.dndu, si.shading.dndv, false);
+    }
+    BxDF b;
+    b.kind = m.kind;
+    b.r = spec_const(0.0f);
+    b.k = spec_const(0.0f);
+    b.eta = 1.0f;
+    b.mf.alpha_x = 0.0f;
+    b.mf.alpha_y = 0.0f;
+    if (m.kind == SHM_MATERIAL_DIFFUSE) {
+        b.r = clamp(spectrum_sample(m.a, sv.spectrum_data, lambda), 0.0f, 1.0f);  // material.rs:301-311
+    } else if (m.kind == SHM_MATERIAL_CONDUCTOR) {  // material.rs:456-499
+        Float ur = m.u_roughness, vr = m.v_roughness;
+        if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+        b.r = spectrum_sample(m.a, sv.spectrum_data, lambda);
+        b.k = spectrum_sample(m.b, sv.spectrum_data, lambda);
+        b.mf = trowbridge_reitz_new(ur, vr);
+    } else if (m.kind == SHM_MATERIAL_DIELECTRIC) {  // material.rs:603-635
+        Float sampled_eta = spectrum_get(m.a, sv.spectrum_data, lambda.lambda[0]);
+        if (m.a.kind != SHM_SPECTRUM_CONSTANT) terminate_secondary(lambda);
+        if (sampled_eta == 0.0f) sampled_eta = 1.0f;
+        Float ur = m.u_roughness, vr = m.v_roughness;
+        if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+        b.eta = sampled_eta;
+        b.mf = trowbridge_reitz_new(ur, vr);
+    } else {  // ThinDielectric, material.rs:723-742
+        Float sampled_eta = spectrum_get(m.a, sv.spectrum_data, lambda.lambda[0]);
+        if (m.a.kind != SHM_SPECTRUM_CONSTANT) terminate_secondary(lambda);
+        if (sampled_eta == 0.0f) sampled_eta = 1.0f;
+        b.eta = sampled_eta;
+    }
+    return bsdf_new(si.shading.n, si.shading.dpdu, b);
+}
+
+// evaluate_pixel_sample head (integrator.rs:338-362): wavelength sample, camera sample, camera ray.
+// The sampler dimension order (1d lambda | 2d filter | 2d lens | 1d time) is the reference's.
+SHM_HD Ray generate_camera_ray(const SceneView& sv, int px, int py, Rng& rng, bool disable_wavelength_jitter,
+                               bool disable_pixel_jitter, Wavelengths& lambda, Float& filter_weight) {
+    Float lu = disable_wavelength_jitter ? 0.5f : sampler_get_1d(rng);
+    lambda = sample_visible(lu);
+    // get_camera_sample, sampling.rs:347-371 (filter.sample(get_pixel_2d()) is drawn in both branches)
+    V2 uf = sampler_get_2d(rng);
+    V2 fp = v2(lerp(uf.x, -sv.filter_radius[0], sv.filter_radius[0]), lerp(uf.y, -sv.filter_radius[1], sv.filter_radius[1]));
+    V2 p_film, p_lens;
+    if (disable_pixel_jitter) {
+        p_film = v2((Float)px, (Float)py) + v2(0.5f, 0.5f);
+        p_lens = v2(0.5f, 0.5f);
+    } else {
+        p_film = v2((Float)px, (Float)py) + fp + v2(0.5f, 0.5f);
+        p_lens = sampler_get_2d(rng);
+        (void)sampler_get_1d(rng);  // time
+    }
+    filter_weight = 1.0f;
+    // PerspectiveCamera::generate_ray_differential, camera.rs:1003-1028 (main ray)
+    const ShmCamera& cam = sv.camera;
+    V3 p_camera = xf_point(cam.camera_from_raster, v3(p_film.x, p_film.y, 0.0f));
+    Ray base;
+    base.o = v3s(0.0f);
+    base.d = normalize(p_camera);
+    if (cam.lens_radius > 0.0f) {
+        V2 pl = cam.lens_radius * sample_uniform_disk_concentric(p_lens);
+        Float ft = cam.focal_distance / base.d.z;
+        V3 p_focus = base.o + base.d * ft;
+        base.o = v3(pl.x, pl.y, 0.0f);
+        base.d = normalize(p_focus - base.o);
+    }
+    return xf_ray(cam.render_from_camera, base);
+}
+
+// PixelSensor::to_sensor_rgb + the clamp of RgbFilm::add_sample (film.rs:907-914, 556-565).
+SHM_HD V3 film_sample_rgb(const SceneView& sv, const Spec& l_in, const Wavelengths& lambda) {
+    Spec l = safe_div(l_in, pdf_spec(lambda));
+    V3 rgb = v3(average(dense_table_sample(sv.sensor_r_bar, lambda) * l),
+                average(dense_table_sample(sv.sensor_g_bar, lambda) * l),
+                average(dense_table_sample(sv.sensor_b_bar, lambda) * l))
+             * sv.imaging_ratio;
+    Float m = max(max(rgb.x, rgb.y), rgb.z);
+    if (m > sv.max_component_value) rgb = rgb * sv.max_component_value / m;
+    return rgb;
+}
+
+}  // namespace shm

@@ -1,0 +1,127 @@
+// shm/scene.h — flat, pointer-based view of a scene as the kernels (and the CPU oracle) read it.
+//
+// Data layout in HBM (DESIGN.md §"Data layout"):
+//   nodes[]      32-B LinearBvhNode records, DFS order (aggregate.rs:425-481 narrowed from 64 B)
+//   prim_recs[]  48-B records in BVH LEAF ORDER: the three triangle vertices pre-gathered (the reference
+//                chases Vec<Arc<Primitive>> -> Arc<Shape> -> Arc<TriangleMesh> -> Vec<usize> -> Vec<Point3f>,
+//                shape/triangle.rs:148-160) + kind/shape index + mesh id + global triangle id.
+//                A leaf's primitive_offset indexes this array directly: one 48-B read per candidate.
+//   primitives[] material / area-light ids per leaf-order slot (primitive.rs:66-130), read once per path vertex
+//   vi/vn/vs/vuv global per-vertex shading arrays (only read when a mesh has N/S/uv)
+#pragma once
+#include "shapes.h"
+#include "spectrum.h"
+
+namespace shm {
+
+struct PrimRec {
+    Float p0[3], p1[3], p2[3];
+    uint32_t kind_index;  // bit 31: sphere; low bits: sphere index (sphere) or unused (triangle)
+    uint32_t mesh;        // triangle: mesh id
+    uint32_t tri;         // triangle: global triangle index
+};
+static_assert(sizeof(PrimRec) == 48, "PrimRec must be 48 bytes");
+constexpr uint32_t PRIM_SPHERE_BIT = 0x80000000u;
+
+enum : uint32_t { MESH_HAS_N = 1, MESH_HAS_S = 2, MESH_HAS_UV = 4, MESH_FLIP = 8 };
+
+struct SceneView {
+    const ShmBvhNode* nodes;
+    uint32_t n_nodes;
+    const PrimRec* prim_recs;
+    const ShmPrimitive* primitives;
+    uint32_t n_primitives;
+    const uint32_t* mesh_flags;
+    const uint32_t* vi;   // 3 per triangle, global vertex ids
+    const Float* vn;      // 3 per vertex
+    const Float* vs;      // 3 per vertex
+    const Float* vuv;     // 2 per vertex
+    const ShmSphere* spheres;
+    const ShmMaterial* materials;
+    const ShmLight* lights;
+    uint32_t n_lights;
+    const uint32_t* infinite_lights;  // indices into lights (integrator.rs:86-92)
+    uint32_t n_infinite_lights;
+    const Float* spectrum_data;
+    ShmCamera camera;
+    int32_t pixel_bounds[4];
+    Float filter_radius[2];
+    Float imaging_ratio;
+    Float max_component_value;
+    const Float* sensor_r_bar;
+    const Float* sensor_g_bar;
+    const Float* sensor_b_bar;
+};
+
+SHM_HD V3 ld3(const Float* p) { return v3(p[0], p[1], p[2]); }
+
+// Triangle::get_points + mesh attribute fetch (shape/triangle.rs:148-160, 311-320)
+SHM_HD TriangleData load_triangle(const SceneView& sv, uint32_t slot) {
+    const PrimRec& pr = sv.prim_recs[slot];
+    TriangleData t;
+    t.p0 = ld3(pr.p0);
+    t.p1 = ld3(pr.p1);
+    t.p2 = ld3(pr.p2);
+    uint32_t f = sv.mesh_flags[pr.mesh];
+    t.has_n = (f & MESH_HAS_N) != 0;
+    t.has_s = (f & MESH_HAS_S) != 0;
+    t.has_uv = (f & MESH_HAS_UV) != 0;
+    t.flip = (f & MESH_FLIP) != 0;
+    t.uv0 = t.uv1 = t.uv2 = v2(0.0f, 0.0f);
+    t.n0 = t.n1 = t.n2 = v3s(0.0f);
+    t.s0 = t.s1 = t.s2 = v3s(0.0f);
+    if (f & (MESH_HAS_N | MESH_HAS_S | MESH_HAS_UV)) {
+        uint32_t i0 = sv.vi[3 * pr.tri], i1 = sv.vi[3 * pr.tri + 1], i2 = sv.vi[3 * pr.tri + 2];
+        if (t.has_n) { t.n0 = ld3(sv.vn + 3 * i0); t.n1 = ld3(sv.vn + 3 * i1); t.n2 = ld3(sv.vn + 3 * i2); }
+        if (t.has_s) { t.s0 = ld3(sv.vs + 3 * i0); t.s1 = ld3(sv.vs + 3 * i1); t.s2 = ld3(sv.vs + 3 * i2); }
+        if (t.has_uv) {
+            t.uv0 = v2(sv.vuv[2 * i0], sv.vuv[2 * i0 + 1]);
+            t.uv1 = v2(sv.vuv[2 * i1], sv.vuv[2 * i1 + 1]);
+            t.uv2 = v2(sv.vuv[2 * i2], sv.vuv[2 * i2 + 1]);
+        }
+    }
+    return t;
+}
+
+// Result of BvhAggregate::intersect reduced to identifying data (see ShmHit).
+struct Hit {
+    int32_t prim;  // leaf-order slot, -1 = miss
+    Float t;
+    Float b0, b1, b2;  // triangle barycentrics | sphere p_obj
+    Float phi;         // sphere
+};
+
+// Shape::intersect's interaction for the CLOSEST hit only (the reference builds it per accepted
+// candidate, triangle.rs:529-535; the result for the surviving candidate is identical).
+SHM_HD SurfaceInteraction hit_interaction(const SceneView& sv, const Hit& h, V3 wo) {
+    const PrimRec& pr = sv.prim_recs[h.prim];
+    if (pr.kind_index & PRIM_SPHERE_BIT) {
+        QuadricIntersection qi;
+        qi.t_hit = h.t;
+        qi.p_obj = v3(h.b0, h.b1, h.b2);
+        qi.phi = h.phi;
+        return sphere_interaction(sv.spheres[pr.kind_index & ~PRIM_SPHERE_BIT], qi, wo);
+    }
+    TriangleData tr = load_triangle(sv, (uint32_t)h.prim);
+    TriangleIntersection ti;
+    ti.b0 = h.b0; ti.b1 = h.b1; ti.b2 = h.b2; ti.t = h.t;
+    return triangle_interaction(tr, ti, wo);
+}
+
+// Primitive::intersect for one leaf-order slot (primitive.rs:95-103 -> shape/shape.rs:164-170).
+// Updates hit/t_max on acceptance exactly as aggregate.rs:101-110 does.
+SHM_HD bool prim_intersect(const SceneView& sv, uint32_t slot, V3 ro, V3 rd, Float t_max, Hit& h) {
+    const PrimRec& pr = sv.prim_recs[slot];
+    if (pr.kind_index & PRIM_SPHERE_BIT) {
+        QuadricIntersection qi;
+        if (!sphere_basic_intersect(sv.spheres[pr.kind_index & ~PRIM_SPHERE_BIT], ro, rd, t_max, qi)) return false;
+        h.prim = (int32_t)slot; h.t = qi.t_hit; h.b0 = qi.p_obj.x; h.b1 = qi.p_obj.y; h.b2 = qi.p_obj.z; h.phi = qi.phi;
+        return true;
+    }
+    TriangleIntersection ti;
+    if (!intersect_triangle(ro, rd, t_max, ld3(pr.p0), ld3(pr.p1), ld3(pr.p2), ti)) return false;
+    h.prim = (int32_t)slot; h.t = ti.t; h.b0 = ti.b0; h.b1 = ti.b1; h.b2 = ti.b2; h.phi = 0.0f;
+    return true;
+}
+
+}  // namespace shm

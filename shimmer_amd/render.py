@@ -1,0 +1,144 @@
+"""Python mirror of the reference's render driver for the GPU path (src/render.rs:8-55 ->
+ImageTileIntegrator::render, src/integrator.rs:226-322): spp-wave schedule over 8x8 tiles, film read-back,
+RgbFilm::get_pixel_rgb (film.rs:720-738).  Multi-GPU: tiles are sharded across ranks (one process per GPU,
+no data-path collective while rendering); the per-rank film slabs are gathered with RCCL through
+torch.distributed (plumbing only — all arithmetic happens inside libshimmer_hip.so).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .scene import tiles_for, wave_schedule
+
+FILM_DTYPE = np.dtype([("rgb_sum", "<f8", (3,)), ("weight_sum", "<f8")])
+
+
+def make_params(seed=0, spp=4, max_depth=5, regularize=False, disable_pixel_jitter=False, disable_wavelength_jitter=False):
+    p = abi.ShmRenderParams()
+    p.seed, p.samples_per_pixel, p.max_depth = seed, spp, max_depth
+    p.regularize, p.disable_pixel_jitter, p.disable_wavelength_jitter = int(regularize), int(disable_pixel_jitter), int(disable_wavelength_jitter)
+    return p
+
+
+def film_to_rgb(film):
+    """RgbFilm::get_pixel_rgb without the output colour matrix: rgb_sum / weight_sum as f32 (film.rs:720-731)."""
+    rgb = film["rgb_sum"].astype(np.float32)
+    w = film["weight_sum"].astype(np.float32)
+    out = rgb.copy()
+    nz = w != 0
+    out[nz] = rgb[nz] / w[nz][..., None]
+    return out
+
+
+def shard_tiles(n_tiles, tiles_per_row, rank, world_size, rows_per_block=16):
+    """Static interleaved sharding: blocks of `rows_per_block` tile rows, block b -> rank b % world."""
+    idx = np.arange(n_tiles)
+    block = (idx // tiles_per_row) // rows_per_block
+    return idx[(block % world_size) == rank]
+
+
+class Renderer:
+    """Owns a ShmScene on one GPU. Raises if the library or a device is missing: no CPU fallback."""
+
+    def __init__(self, lib, desc, device=0):
+        self.lib = lib
+        self.desc = desc
+        self.handle = C.c_void_p()
+        abi.check(lib, lib.shm_scene_create(C.byref(desc), device, C.byref(self.handle)), "shm_scene_create")
+        pb = desc.film.pixel_bounds
+        self.pixel_bounds = (pb[0], pb[1], pb[2], pb[3])
+        self.width, self.height = pb[2] - pb[0], pb[3] - pb[1]
+        self.tiles, self.n_tiles = tiles_for(lib, self.pixel_bounds)
+        self.tiles_per_row = (self.width + 7) // 8
+
+    def close(self):
+        if self.handle:
+            self.lib.shm_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def _tile_subset(self, tile_indices):
+        if tile_indices is None:
+            return self.tiles, self.n_tiles
+        sub = (abi.ShmTile * max(1, len(tile_indices)))()
+        for k, i in enumerate(tile_indices):
+            sub[k] = self.tiles[int(i)]
+        return sub, len(tile_indices)
+
+    def clear(self):
+        abi.check(self.lib, self.lib.shm_film_clear(self.handle), "shm_film_clear")
+
+    def render_waves(self, params, tile_indices=None, waves=None):
+        """Enqueue all spp-waves into the device film; returns accumulated stats dict."""
+        tiles, n = self._tile_subset(tile_indices)
+        stats = abi.ShmStats()
+        if n == 0:
+            return stats.as_dict()
+        for (ws, we) in (waves if waves is not None else wave_schedule(params.samples_per_pixel)):
+            abi.check(self.lib, self.lib.shm_render_wave(self.handle, C.byref(params), tiles, n, ws, we, C.byref(stats)), "shm_render_wave")
+        return stats.as_dict()
+
+    def read_film(self):
+        film = np.zeros((self.height, self.width), dtype=FILM_DTYPE)
+        abi.check(self.lib, self.lib.shm_film_read(self.handle, film.ctypes.data_as(C.c_void_p)), "shm_film_read")
+        return film
+
+    def film_device_ptr(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        abi.check(self.lib, self.lib.shm_film_device_ptr(self.handle, C.byref(p), C.byref(n)), "shm_film_device_ptr")
+        return p.value, n.value
+
+    def render(self, params, tile_indices=None):
+        """ImageTileIntegrator::render: clear, all waves, read back. Returns (film structured array, stats)."""
+        self.clear()
+        stats = self.render_waves(params, tile_indices)
+        return self.read_film(), stats
+
+    def trace(self, rays, any_hit=False):
+        """Bring-up entry: rays = structured/float32 array (n, 8) [o,d,t_max,pad]. Returns hits (n,8 view) or occluded bytes."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        stats = abi.ShmStats()
+        if any_hit:
+            out = np.zeros(n, np.uint8)
+            abi.check(self.lib, self.lib.shm_trace_any(self.handle, rays.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p), C.byref(stats)), "shm_trace_any")
+        else:
+            out = np.zeros(n, dtype=HIT_DTYPE)
+            abi.check(self.lib, self.lib.shm_trace_closest(self.handle, rays.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p), C.byref(stats)), "shm_trace_closest")
+        return out, stats.as_dict()
+
+
+HIT_DTYPE = np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"), ("phi", "<f4"), ("pad", "<u4", (2,))])
+
+
+def film_tensor(renderer, device=None):
+    """The renderer's film as a flat float64 torch tensor: zero-copy view of the HBM buffer when `device` is given."""
+    import torch
+
+    if device is not None:
+        ptr, nbytes = renderer.film_device_ptr()
+
+        class _Holder:
+            pass
+
+        h = _Holder()
+        h.__cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+        return torch.as_tensor(h, device=device)
+    return torch.from_numpy(renderer.read_film().view(np.float64).reshape(-1).copy())
+
+
+def gather_film(local, rank, world_size, height, width):
+    """C1 of SURVEY §2.1: gather the per-rank film slabs (flat float64 tensors) to rank 0 over RCCL (backend
+    'nccl' on ROCm; 'gloo' in the CPU tests).  Pixel ownership is exclusive (tiles are disjoint) and untouched
+    pixels are exactly 0.0, so adding the slabs reproduces the single-process film bit for bit."""
+    import torch
+    import torch.distributed as dist
+
+    gathered = [torch.empty_like(local) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(local, gathered, dst=0)
+    if rank != 0:
+        return None
+    total = gathered[0].clone()
+    for g in gathered[1:]:
+        total += g
+    return total.cpu().numpy().view(FILM_DTYPE).reshape(height, width)

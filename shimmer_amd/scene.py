@@ -1,0 +1,405 @@
+"""Host-side scene assembly: the marshalling a Rust `impl Integrator` would do before calling the C ABI.
+
+Mirrors (paths relative to /root/reference/src) the pieces of scene construction that sit directly before
+the hot path: primitive bounds (shape/triangle.rs:507-510, shape/sphere.rs:275-280), BvhAggregate::new via
+shm_bvh_build (aggregate.rs:207-467), one DiffuseAreaLight per emissive shape (loading/scene.rs:609-624),
+DenselySampledSpectrum::new (spectra/spectrum.rs:179-196), BlackbodySpectrum (:430-489),
+PiecewiseLinearSpectrum::from_interleaved (:313-352), spectrum_to_photometric (:617-631).
+Everything computed here is INPUT data handed identically to the HIP library and to the CPU oracle.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import abi
+
+_TABLES = None
+
+
+def tables():
+    global _TABLES
+    if _TABLES is None:
+        _TABLES = dict(np.load(Path(__file__).resolve().parent / "data" / "spectral_tables.npz"))
+    return _TABLES
+
+
+f32 = np.float32
+
+
+def blackbody_dense(temperature):
+    """DenselySampledSpectrum::new(BlackbodySpectrum::new(T)) at 360..830 nm (f32 arithmetic as the reference)."""
+    t = f32(temperature)
+
+    def bb(lam_nm):
+        c = f32(299792458.0)
+        h = f32(6.62606957e-34)
+        kb = f32(1.3806488e-23)
+        l = (lam_nm * f32(1e-9)).astype(np.float32)
+        l5 = (l * l * l * l * l).astype(np.float32)
+        e = np.exp(((h * c) / (l * kb * t)).astype(np.float32)).astype(np.float32)
+        return ((f32(2.0) * h * c * c) / (l5 * (e - f32(1.0)))).astype(np.float32)
+
+    lambda_max = f32(2.8977721e-3) / t
+    norm = f32(1.0) / bb(np.asarray([lambda_max * f32(1e9)], dtype=np.float32))[0]
+    lam = np.arange(360, 831, dtype=np.float32)
+    return (bb(lam) * norm).astype(np.float32)
+
+
+def piecewise_from_interleaved(samples, normalize=False):
+    """PiecewiseLinearSpectrum::from_interleaved -> (lambdas, values)."""
+    s = np.asarray(samples, dtype=np.float32)
+    lam, val = list(s[0::2]), list(s[1::2])
+    if lam[0] > 360.0:
+        lam.insert(0, f32(359.0))
+        val.insert(0, val[0])
+    if lam[-1] < 830.0:
+        lam.append(f32(831.0))
+        val.append(val[-1])
+    lam, val = np.asarray(lam, np.float32), np.asarray(val, np.float32)
+    if normalize:
+        dense = piecewise_to_dense(lam, val)
+        y = tables()["CIE_Y"]
+        integral = f32(0.0)
+        for a, b in zip(dense, y):
+            integral = f32(integral + f32(a * b))
+        val = (val * f32(tables()["CIE_Y_INTEGRAL"] / integral)).astype(np.float32)
+    return lam, val
+
+
+def piecewise_get(lam, val, x):
+    """PiecewiseLinearSpectrum::get for scalar x (f32)."""
+    x = f32(x)
+    if x < lam[0] or x > lam[-1]:
+        return f32(0.0)
+    o = int(np.clip(np.searchsorted(lam, x, side="right") - 1, 0, len(lam) - 2))
+    t = f32((x - lam[o]) / (lam[o + 1] - lam[o]))
+    return f32(val[o] * f32(f32(1.0) - t) + f32(val[o + 1] * t))
+
+
+def piecewise_to_dense(lam, val):
+    return np.asarray([piecewise_get(lam, val, float(l)) for l in range(360, 831)], dtype=np.float32)
+
+
+def spectrum_to_photometric(dense):
+    """spectrum_to_photometric over a 360..830 dense table (f32 running sum, as the reference)."""
+    y = tables()["CIE_Y"]
+    acc = f32(0.0)
+    for a, b in zip(y, dense):
+        acc = f32(acc + f32(a * b))
+    return acc
+
+
+def _as_f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _fptr(a):
+    return a.ctypes.data_as(abi.c_float_p)
+
+
+IDENTITY = np.eye(4, dtype=np.float32)
+
+
+class SceneBuilder:
+    """Accumulates shapes/materials/lights in input order, builds the BVH with the host-side mirror of
+    BvhAggregate::new and emits a ShmSceneDesc (keeping every backing array alive)."""
+
+    def __init__(self):
+        self.meshes = []       # dict(p, vi, n, s, uv, reverse, swaps)
+        self.spheres = []      # abi.ShmSphere
+        self.prims = []        # chunks of (N,4) int64: shape_kind, shape_index, material, area_light
+        self._n_prims = 0
+        self.materials = []    # abi.ShmMaterial
+        self.lights = []       # abi.ShmLight (primitive = INPUT prim index until build())
+        self.spec = []         # list of float32 arrays (spectrum pool)
+        self.spec_len = 0
+        self.camera = None
+        self.film = None
+        self._keep = []
+        self._tri_count = 0
+        self._emission_cache = {}
+
+    # ---- spectra ----
+    def spectrum_constant(self, c):
+        s = abi.ShmSpectrum()
+        s.kind, s.c = abi.SHM_SPECTRUM_CONSTANT, float(c)
+        return s
+
+    def _pool(self, arr):
+        off = self.spec_len
+        arr = _as_f32(arr).ravel()
+        self.spec.append(arr)
+        self.spec_len += arr.size
+        return off
+
+    def spectrum_dense(self, values471):
+        v = _as_f32(values471)
+        assert v.size == 471
+        s = abi.ShmSpectrum()
+        s.kind, s.offset, s.n, s.lambda_min = abi.SHM_SPECTRUM_DENSE, self._pool(v), 471, 360
+        return s
+
+    def spectrum_piecewise(self, lam, val):
+        lam, val = _as_f32(lam), _as_f32(val)
+        assert lam.size == val.size and lam.size >= 2
+        s = abi.ShmSpectrum()
+        s.kind, s.offset, s.n = abi.SHM_SPECTRUM_PIECEWISE_LINEAR, self._pool(np.concatenate([lam, val])), lam.size
+        return s
+
+    def spectrum_named(self, name):
+        """NamedSpectrum (spectra/named_spectrum.rs:13-27): metals / glasses as PiecewiseLinear."""
+        key = {"glass-BK7": "GLASS_BK7_ETA_SAMPLES", "glass-BAF10": "GLASS_BAF10_ETA_SAMPLES", "glass-F11": "GLASS_F11_ETA_SAMPLES",
+               "metal-Cu-eta": "CU_ETA_SAMPLES", "metal-Cu-k": "CU_K_SAMPLES", "metal-Au-eta": "AU_ETA_SAMPLES",
+               "metal-Au-k": "AU_K_SAMPLES", "metal-Ag-eta": "AG_ETA_SAMPLES", "metal-Ag-k": "AG_K_SAMPLES",
+               "metal-Al-eta": "AL_ETA_SAMPLES", "metal-Al-k": "AL_K_SAMPLES"}[name]
+        lam, val = piecewise_from_interleaved(tables()[key], False)
+        return self.spectrum_piecewise(lam, val)
+
+    # ---- materials ----
+    def material_diffuse(self, reflectance):
+        m = abi.ShmMaterial()
+        m.kind = abi.SHM_MATERIAL_DIFFUSE
+        m.has_displacement, m.displacement = 1, 0.0  # material.rs:280 always installs a constant-0 displacement
+        m.a = reflectance if isinstance(reflectance, abi.ShmSpectrum) else self.spectrum_constant(reflectance)
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def material_conductor(self, eta, k, roughness=0.0, remap=True):
+        m = abi.ShmMaterial()
+        m.kind = abi.SHM_MATERIAL_CONDUCTOR
+        m.remap_roughness, m.u_roughness, m.v_roughness = int(remap), float(roughness), float(roughness)
+        m.a, m.b = eta, k
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def material_dielectric(self, eta, roughness=0.0, remap=True, thin=False):
+        m = abi.ShmMaterial()
+        m.kind = abi.SHM_MATERIAL_THIN_DIELECTRIC if thin else abi.SHM_MATERIAL_DIELECTRIC
+        m.remap_roughness, m.u_roughness, m.v_roughness = int(remap), float(roughness), float(roughness)
+        m.a = eta if isinstance(eta, abi.ShmSpectrum) else self.spectrum_constant(eta)
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    # ---- lights ----
+    def _area_light(self, prim_index, area, dense_emission, scale, two_sided):
+        """DiffuseAreaLight::create: scale /= spectrum_to_photometric(L) (light.rs:598)."""
+        l = abi.ShmLight()
+        l.kind, l.primitive, l.two_sided, l.area = abi.SHM_LIGHT_DIFFUSE_AREA, prim_index, int(two_sided), float(area)
+        key = id(dense_emission)
+        if key not in self._emission_cache:  # one pooled table + photometric integral per distinct emission spectrum
+            self._emission_cache[key] = (self.spectrum_dense(dense_emission), spectrum_to_photometric(dense_emission), dense_emission)
+        spec, photometric, _ = self._emission_cache[key]
+        l.scale = float(f32(scale) / photometric)
+        l.spectrum = spec
+        self.lights.append(l)
+        return len(self.lights) - 1
+
+    def light_point(self, position, dense_intensity, scale=1.0):
+        l = abi.ShmLight()
+        l.kind = abi.SHM_LIGHT_POINT
+        l.scale = float(f32(scale) / spectrum_to_photometric(dense_intensity))
+        l.position[:] = [float(x) for x in position]
+        l.spectrum = self.spectrum_dense(dense_intensity)
+        self.lights.append(l)
+        return len(self.lights) - 1
+
+    def light_uniform_infinite(self, dense_emission, scale=1.0):
+        l = abi.ShmLight()
+        l.kind = abi.SHM_LIGHT_UNIFORM_INFINITE
+        l.scale = float(f32(scale) / spectrum_to_photometric(dense_emission))
+        l.spectrum = self.spectrum_dense(dense_emission)
+        self.lights.append(l)
+        return len(self.lights) - 1
+
+    # ---- shapes ----
+    def add_mesh(self, p, vi, material, n=None, s=None, uv=None, reverse_orientation=False, swaps_handedness=False,
+                 emission=None, emission_scale=1.0, two_sided=False):
+        """trianglemesh: vertices already in render space. emission = dense 471 table -> one area light per triangle."""
+        p = _as_f32(p, (-1, 3))
+        vi = np.ascontiguousarray(vi, dtype=np.uint32).reshape(-1, 3)
+        mesh = dict(p=p, vi=vi, n=None if n is None else _as_f32(n, (-1, 3)), s=None if s is None else _as_f32(s, (-1, 3)),
+                    uv=None if uv is None else _as_f32(uv, (-1, 2)), reverse=bool(reverse_orientation), swaps=bool(swaps_handedness))
+        self.meshes.append(mesh)
+        base = self._tri_count
+        ntri = vi.shape[0]
+        self._tri_count += ntri
+        first_prim = self._n_prims
+        chunk = np.empty((ntri, 4), np.int64)
+        chunk[:, 0], chunk[:, 1], chunk[:, 2], chunk[:, 3] = abi.SHM_SHAPE_TRIANGLE, base + np.arange(ntri), material, -1
+        if emission is not None:
+            p0, p1, p2 = p[vi[:, 0]], p[vi[:, 1]], p[vi[:, 2]]
+            for t in range(ntri):
+                # Triangle::area = 0.5 * |(p1-p0) x (p2-p0)| — only the light's `area` field (phi(); unused by the path)
+                area = 0.5 * float(np.linalg.norm(np.cross((p1[t] - p0[t]).astype(np.float64), (p2[t] - p0[t]).astype(np.float64))))
+                chunk[t, 3] = self._area_light(first_prim + t, area, emission, emission_scale, two_sided)
+        self.prims.append(chunk)
+        self._n_prims += ntri
+        return first_prim
+
+    def add_sphere(self, radius, material, render_from_object=None, reverse_orientation=False, z_min=None, z_max=None,
+                   phi_max=360.0, emission=None, emission_scale=1.0, two_sided=False):
+        rfo = IDENTITY if render_from_object is None else _as_f32(render_from_object, (4, 4))
+        ofr = np.linalg.inv(rfo.astype(np.float64)).astype(np.float32)
+        s = abi.ShmSphere()
+        r = f32(radius)
+        zmin = -r if z_min is None else f32(z_min)
+        zmax = r if z_max is None else f32(z_max)
+        s.radius = r
+        s.z_min = float(np.clip(min(zmin, zmax), -r, r))
+        s.z_max = float(np.clip(max(zmin, zmax), -r, r))
+        s.theta_z_min = float(np.arccos(np.clip(f32(min(zmin, zmax) / r), -1, 1), dtype=np.float32))
+        s.theta_z_max = float(np.arccos(np.clip(f32(max(zmin, zmax) / r), -1, 1), dtype=np.float32))
+        s.phi_max = float(f32(np.pi / 180.0) * f32(np.clip(phi_max, 0, 360)))
+        s.render_from_object[:] = [float(x) for x in rfo.ravel()]
+        s.object_from_render[:] = [float(x) for x in ofr.ravel()]
+        s.reverse_orientation = int(reverse_orientation)
+        s.transform_swaps_handedness = int(np.linalg.det(rfo[:3, :3].astype(np.float64)) < 0)
+        self.spheres.append(s)
+        prim_index = self._n_prims
+        li = -1
+        if emission is not None:
+            area = float(s.phi_max * s.radius * (s.z_max - s.z_min))
+            li = self._area_light(prim_index, area, emission, emission_scale, two_sided)
+        self.prims.append(np.array([[abi.SHM_SHAPE_SPHERE, len(self.spheres) - 1, material, li]], np.int64))
+        self._n_prims += 1
+        return prim_index
+
+    # ---- camera / film ----
+    def set_film(self, width, height, pixel_bounds=None, filter_radius=(0.5, 0.5), imaging_ratio=1.0, max_component_value=np.inf):
+        t = tables()
+        self._sensor = [_as_f32(t["CIE_X"]), _as_f32(t["CIE_Y"]), _as_f32(t["CIE_Z"])]  # PixelSensor::new cie1931 (film.rs:823-837)
+        f = abi.ShmFilm()
+        pb = pixel_bounds if pixel_bounds is not None else (0, 0, width, height)
+        f.pixel_bounds[:] = pb
+        f.full_resolution[:] = (width, height)
+        f.filter_radius[:] = filter_radius
+        f.imaging_ratio = imaging_ratio
+        f.max_component_value = max_component_value
+        f.sensor_r_bar, f.sensor_g_bar, f.sensor_b_bar = (_fptr(a) for a in self._sensor)
+        self.film = f
+
+    def set_camera_look_at(self, lib, pos, look_at, up, fov, lens_radius=0.0, focal_distance=1e6):
+        """Transform::look_at (transform.rs:270-303) -> world_from_camera, then shm_camera_perspective.
+        Returns render_from_world (4x4 f32) so that callers can move world-space geometry into render space."""
+        pos, look_at, up = (np.asarray(v, np.float64) for v in (pos, look_at, up))
+        d = look_at - pos
+        d /= np.linalg.norm(d)
+        right = np.cross(up / np.linalg.norm(up), d)
+        right /= np.linalg.norm(right)
+        new_up = np.cross(d, right)
+        wfc = np.eye(4)
+        wfc[:3, 0], wfc[:3, 1], wfc[:3, 2], wfc[:3, 3] = right, new_up, d, pos
+        wfc32 = _as_f32(wfc)
+        cam = abi.ShmCamera()
+        rfw = np.zeros(16, np.float32)
+        res = (C.c_int32 * 2)(*self.film.full_resolution)
+        abi.check(lib, lib.shm_camera_perspective(_fptr(wfc32), float(fov), res, float(lens_radius), float(focal_distance),
+                                                  C.byref(cam), _fptr(rfw)), "shm_camera_perspective")
+        self.camera = cam
+        return rfw.reshape(4, 4)
+
+    # ---- finalize ----
+    def prim_bounds(self):
+        """Per-primitive Bounds3f in input order (triangle.rs:507-510; sphere.rs:275-280 + transform.rs:537-549)."""
+        n = self._n_prims
+        out = np.empty((n, 6), np.float32)
+        src = np.concatenate(self.prims, axis=0)
+        kinds, sidx = src[:, 0], src[:, 1]
+        tri_mask = kinds == abi.SHM_SHAPE_TRIANGLE
+        if tri_mask.any():
+            allp = []
+            for m in self.meshes:
+                allp.append(m["p"][m["vi"].astype(np.int64)])  # (T,3,3)
+            tri_p = np.concatenate(allp, axis=0)
+            tp = tri_p[sidx[tri_mask]]
+            out[tri_mask, :3] = tp.min(axis=1)
+            out[tri_mask, 3:] = tp.max(axis=1)
+        for i in np.nonzero(~tri_mask)[0]:
+            s = self.spheres[sidx[i]]
+            m = np.asarray(list(s.render_from_object), np.float32).reshape(4, 4)
+            r = f32(s.radius)
+            lo, hi = np.array([-r, -r, s.z_min], np.float32), np.array([r, r, s.z_max], np.float32)
+            pts = []
+            for c in range(8):
+                q = np.array([hi[0] if c & 1 else lo[0], hi[1] if c & 2 else lo[1], hi[2] if c & 4 else lo[2]], np.float32)
+                xp = f32(f32(f32(m[0, 0] * q[0]) + f32(m[0, 1] * q[1])) + f32(m[0, 2] * q[2])) + m[0, 3]
+                yp = f32(f32(f32(m[1, 0] * q[0]) + f32(m[1, 1] * q[1])) + f32(m[1, 2] * q[2])) + m[1, 3]
+                zp = f32(f32(f32(m[2, 0] * q[0]) + f32(m[2, 1] * q[1])) + f32(m[2, 2] * q[2])) + m[2, 3]
+                pts.append([f32(xp), f32(yp), f32(zp)])
+            pts = np.asarray(pts, np.float32)
+            out[i, :3], out[i, 3:] = pts.min(axis=0), pts.max(axis=0)
+        return out
+
+    def build(self, lib, split_method=0):
+        """BvhAggregate::new + marshal. Returns (ShmSceneDesc, info dict). Keeps all arrays alive on self."""
+        assert self.camera is not None and self.film is not None
+        n = self._n_prims
+        bounds = np.ascontiguousarray(self.prim_bounds())
+        nodes = (abi.ShmBvhNode * (2 * n))()
+        order = np.zeros(n, np.uint32)
+        n_nodes = C.c_uint32(0)
+        abi.check(lib, lib.shm_bvh_build(_fptr(bounds), n, split_method, nodes, C.byref(n_nodes), order.ctypes.data_as(abi.c_u32_p)),
+                  "shm_bvh_build")
+        slot_of_input = np.empty(n, np.uint32)
+        slot_of_input[order] = np.arange(n, dtype=np.uint32)
+        prim_arr = (abi.ShmPrimitive * n)()
+        pa = np.frombuffer(prim_arr, dtype=np.dtype([("k", "<u4"), ("i", "<u4"), ("m", "<u4"), ("l", "<i4")]))
+        src = np.concatenate(self.prims, axis=0)
+        pa["k"], pa["i"], pa["m"], pa["l"] = src[order, 0], src[order, 1], src[order, 2], src[order, 3]
+        lights = (abi.ShmLight * max(1, len(self.lights)))()
+        for i, l in enumerate(self.lights):
+            lights[i] = l
+            if l.kind == abi.SHM_LIGHT_DIFFUSE_AREA:
+                lights[i].primitive = int(slot_of_input[l.primitive])
+        meshes = (abi.ShmTriangleMesh * max(1, len(self.meshes)))()
+        for i, m in enumerate(self.meshes):
+            mm = meshes[i]
+            mm.n_triangles, mm.n_vertices = m["vi"].shape[0], m["p"].shape[0]
+            mm.vertex_indices = m["vi"].ctypes.data_as(abi.c_u32_p)
+            mm.p = _fptr(m["p"])
+            mm.n = _fptr(m["n"]) if m["n"] is not None else None
+            mm.s = _fptr(m["s"]) if m["s"] is not None else None
+            mm.uv = _fptr(m["uv"]) if m["uv"] is not None else None
+            mm.reverse_orientation, mm.transform_swaps_handedness = int(m["reverse"]), int(m["swaps"])
+        spheres = (abi.ShmSphere * max(1, len(self.spheres)))(*self.spheres)
+        materials = (abi.ShmMaterial * len(self.materials))(*self.materials)
+        spec = np.concatenate(self.spec).astype(np.float32) if self.spec else np.zeros(1, np.float32)
+        d = abi.ShmSceneDesc()
+        d.abi_version = abi.SHM_ABI_VERSION
+        d.n_nodes, d.nodes = n_nodes.value, nodes
+        d.n_primitives, d.primitives = n, prim_arr
+        d.n_meshes, d.meshes = len(self.meshes), meshes
+        d.n_spheres, d.spheres = len(self.spheres), spheres
+        d.n_materials, d.materials = len(self.materials), materials
+        d.n_lights, d.lights = len(self.lights), lights
+        d.n_spectrum_floats, d.spectrum_data = spec.size, _fptr(spec)
+        d.camera, d.film = self.camera, self.film
+        self._keep = [nodes, prim_arr, lights, meshes, spheres, materials, spec, bounds, order]
+        info = dict(n_nodes=n_nodes.value, n_primitives=n, order=order, slot_of_input=slot_of_input, bounds=bounds)
+        return d, info
+
+
+def tiles_for(lib, pixel_bounds, tile=8):
+    """Tile::tile(pixel_bounds, 8, 8) through the host mirror."""
+    pb = (C.c_int32 * 4)(*pixel_bounds)
+    w, h = pixel_bounds[2] - pixel_bounds[0], pixel_bounds[3] - pixel_bounds[1]
+    cap = ((w + tile - 1) // tile) * ((h + tile - 1) // tile)
+    tiles = (abi.ShmTile * cap)()
+    n = C.c_uint32(0)
+    abi.check(lib, lib.shm_tile_bounds(pb, tile, tile, tiles, C.byref(n)), "shm_tile_bounds")
+    return tiles, n.value
+
+
+def wave_schedule(spp):
+    """integrator.rs:231-233, 306-308: (start, end) of each spp-wave: sizes 1,1,2,4,...,64,64,..."""
+    waves, ws, we, nxt = [], 0, 1, 1
+    while ws < spp:
+        waves.append((ws, we))
+        ws = we
+        we = min(spp, we + nxt)
+        nxt = min(2 * nxt, 64)
+    return waves

@@ -1,0 +1,295 @@
+"""Seeded synthetic scenes for the BASELINE.json configs (the reference's own scenes live in an external repo
+and are not available offline; SURVEY §8d defines these stand-ins).
+
+  S1 sphere_light   unit diffuse sphere + one-sided quad area light            (C1, 128x128x4)
+  S2 cornell_box    Cornell-style box, 32 triangles                            (C2, 512x512x64)
+  S3 ganesha_proxy  displaced cube-sphere, 4 305 612 tris + room (16 tris)     (C3/C5, 1024x1024x256 / 4K)
+  S4 crown_proxy    dispersive dielectric icospheres + rough gold + floor      (C4, maxdepth 32)
+  three_spheres     the reference's own BVH known-answer scene (aggregate.rs:631-702)
+
+All geometry is generated in world space and moved to render space with the camera-world translation
+(camera.rs:507-523), as TriangleMesh::new does at load time (shape/mesh.rs:43-46).
+"""
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import abi
+from .scene import SceneBuilder, blackbody_dense, f32
+
+
+def _to_render(p, rfw):
+    """render_from_world is a pure translation here: apply_point_helper in f32 (transform.rs:742-752)."""
+    p = np.asarray(p, np.float32)
+    t = rfw[:3, 3].astype(np.float32)
+    return (p + t[None, :]).astype(np.float32)
+
+
+def _quad(p0, p1, p2, p3):
+    """Two triangles (p0,p1,p2), (p0,p2,p3)."""
+    return np.array([p0, p1, p2, p3], np.float32), np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+
+
+def _merge(parts):
+    ps, vis, base = [], [], 0
+    for p, vi in parts:
+        ps.append(p)
+        vis.append(vi + base)
+        base += p.shape[0]
+    return np.concatenate(ps).astype(np.float32), np.concatenate(vis).astype(np.uint32)
+
+
+def _box(lo, hi, faces="xXyYzZ"):
+    """Axis-aligned box faces with outward normals (counter-clockwise seen from outside)."""
+    x0, y0, z0 = lo
+    x1, y1, z1 = hi
+    f = {
+        "x": [(x0, y0, z0), (x0, y0, z1), (x0, y1, z1), (x0, y1, z0)],
+        "X": [(x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (x1, y0, z1)],
+        "y": [(x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1)],
+        "Y": [(x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0)],
+        "z": [(x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0)],
+        "Z": [(x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)],
+    }
+    return _merge([_quad(*f[c]) for c in faces])
+
+
+def _finish(b, lib, **extra):
+    desc, info = b.build(lib)
+    return SimpleNamespace(desc=desc, builder=b, info=info, **extra)
+
+
+def sphere_light(lib, width=128, height=128):
+    """S1 (config C1)."""
+    b = SceneBuilder()
+    b.set_film(width, height)
+    rfw = b.set_camera_look_at(lib, (0, 1, 5), (0, 0, 0), (0, 1, 0), 40.0)
+    grey = b.material_diffuse(0.5)
+    black = b.material_diffuse(0.0)
+    rfo = np.eye(4, dtype=np.float32)
+    rfo[:3, 3] = rfw[:3, 3]
+    b.add_sphere(1.0, grey, render_from_object=rfo)
+    # 2x2 quad at y=3 facing -y (one-sided): winding chosen so that normalize(dp02 x dp12) points down
+    p, vi = _quad((-1, 3, -1), (1, 3, -1), (1, 3, 1), (-1, 3, 1))
+    b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=10.0)
+    # a floor so that paths do more than one bounce
+    pf, vif = _quad((-4, -1, -4), (-4, -1, 4), (4, -1, 4), (4, -1, -4))
+    b.add_mesh(_to_render(pf, rfw), vif, grey)
+    return _finish(b, lib, name="S1 sphere+area light")
+
+
+def _two_point_spectrum(b, lo, hi):
+    """Red/green walls as 2-knot piecewise-linear reflectances."""
+    return b.spectrum_piecewise(np.array([359.0, 831.0], np.float32), np.array([lo, hi], np.float32))
+
+
+def cornell_box(lib, width=512, height=512):
+    """S2 (config C2): 5 walls x 2 + 2 boxes x 5 faces x 2 + light 2 = 32 triangles."""
+    b = SceneBuilder()
+    b.set_film(width, height)
+    rfw = b.set_camera_look_at(lib, (0, 1, 3.4), (0, 1, 0), (0, 1, 0), 39.0)
+    white = b.material_diffuse(0.75)
+    red = b.material_diffuse(_two_point_spectrum(b, 0.05, 0.75))
+    green = b.material_diffuse(_two_point_spectrum(b, 0.6, 0.08))
+    black = b.material_diffuse(0.0)
+    # room [-1,1] x [0,2] x [-1,1], open towards +z (camera side); inward-facing windings via reversed quads
+    def inward(q):
+        p, vi = q
+        return p, vi[:, ::-1].copy()
+    floor = inward(_quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1)))
+    ceil_ = _quad((-1, 2, -1), (1, 2, -1), (1, 2, 1), (-1, 2, 1))
+    back = _quad((-1, 0, -1), (-1, 2, -1), (1, 2, -1), (1, 0, -1))
+    left = _quad((-1, 0, -1), (-1, 0, 1), (-1, 2, 1), (-1, 2, -1))
+    right = inward(_quad((1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1)))
+    p, vi = _merge([floor, ceil_, back])
+    b.add_mesh(_to_render(p, rfw), vi, white)
+    p, vi = left
+    b.add_mesh(_to_render(p, rfw), vi, red)
+    p, vi = right
+    b.add_mesh(_to_render(p, rfw), vi, green)
+    # two boxes, 5 faces each (no bottom), the tall one rotated about y
+    def rot_y(p, deg, centre):
+        a = np.deg2rad(deg)
+        c, s = np.cos(a), np.sin(a)
+        q = p - centre
+        out = np.stack([c * q[:, 0] + s * q[:, 2], q[:, 1], -s * q[:, 0] + c * q[:, 2]], axis=1)
+        return (out + centre).astype(np.float32)
+    p, vi = _box((-0.75, 0.0, -0.65), (-0.15, 1.2, -0.05), faces="xXYzZ")
+    b.add_mesh(_to_render(rot_y(p, 18.0, np.array([-0.45, 0, -0.35], np.float32)), rfw), vi, white)
+    p, vi = _box((0.1, 0.0, 0.0), (0.7, 0.6, 0.6), faces="xXYzZ")
+    b.add_mesh(_to_render(rot_y(p, -17.0, np.array([0.4, 0, 0.3], np.float32)), rfw), vi, white)
+    # ceiling light, facing down
+    p, vi = _quad((-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (0.3, 1.98, 0.3), (-0.3, 1.98, 0.3))
+    b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=20.0)
+    return _finish(b, lib, name="S2 cornell box")
+
+
+def _hash3(ix, iy, iz, seed):
+    """Integer lattice hash -> [0,1) float64 (vectorised, wraps like uint64)."""
+    with np.errstate(over="ignore"):
+        h = (ix.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (iy.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)) ^ (
+            iz.astype(np.uint64) * np.uint64(0x165667B19E3779F9)) ^ np.uint64(seed)
+        h ^= h >> np.uint64(29)
+        h *= np.uint64(0xBF58476D1CE4E5B9)
+        h ^= h >> np.uint64(32)
+    return (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+
+
+def _value_noise(p, seed, octaves=3):
+    """Seeded value noise on R^3 (trilinear, smoothstep), summed over octaves."""
+    total = np.zeros(p.shape[0], np.float64)
+    amp, freq = 1.0, 3.0
+    for o in range(octaves):
+        q = p.astype(np.float64) * freq + 100.0
+        i = np.floor(q).astype(np.int64)
+        f = q - i
+        f = f * f * (3.0 - 2.0 * f)
+        acc = 0.0
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    w = (f[:, 0] if dx else 1 - f[:, 0]) * (f[:, 1] if dy else 1 - f[:, 1]) * (f[:, 2] if dz else 1 - f[:, 2])
+                    acc = acc + w * _hash3(i[:, 0] + dx, i[:, 1] + dy, i[:, 2] + dz, seed + o)
+        total += amp * (acc - 0.5)
+        amp *= 0.5
+        freq *= 2.0
+    return total
+
+
+def cube_sphere(n, seed=1234, amplitude=0.15, shuffle_seed=99):
+    """Closed genus-0 cube-sphere: 6 faces x n x n quads x 2 triangles with shared vertices (6 n^2 + 2), unit radius,
+    radially displaced by value noise; triangle order randomised (seeded Fisher-Yates / permutation)."""
+    m = n + 1
+    # unique lattice points on the cube surface, indexed through a dict-free scheme: generate all 6 faces then unify
+    g = np.arange(m, dtype=np.int64)
+    u, v = np.meshgrid(g, g, indexing="ij")
+    u, v = u.ravel(), v.ravel()
+    faces = []
+    zeros, full = np.zeros_like(u), np.full_like(u, n)
+    faces.append(np.stack([full, u, v], 1))    # +x
+    faces.append(np.stack([zeros, v, u], 1))   # -x
+    faces.append(np.stack([v, full, u], 1))    # +y
+    faces.append(np.stack([u, zeros, v], 1))   # -y
+    faces.append(np.stack([u, v, full], 1))    # +z
+    faces.append(np.stack([v, u, zeros], 1))   # -z
+    allp = np.concatenate(faces)               # integer lattice coords in [0,n]^3 on the surface
+    key = (allp[:, 0] * (m * m) + allp[:, 1] * m + allp[:, 2])
+    uniq, inverse = np.unique(key, return_inverse=True)
+    coords = np.stack([uniq // (m * m), (uniq // m) % m, uniq % m], 1).astype(np.float64)
+    cube = coords / n * 2.0 - 1.0
+    # tangent-warp for more uniform cells, then normalise to the sphere
+    cube = np.tan(cube * (np.pi / 4.0))
+    sph = cube / np.linalg.norm(cube, axis=1, keepdims=True)
+    r = 1.0 + amplitude * _value_noise(sph, seed) * 2.0
+    verts = (sph * r[:, None]).astype(np.float32)
+    tris = []
+    cell_i, cell_j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    cell_i, cell_j = cell_i.ravel(), cell_j.ravel()
+    for fi in range(6):
+        idx = inverse[fi * m * m:(fi + 1) * m * m].reshape(m, m)
+        a, b_, c, d = idx[cell_i, cell_j], idx[cell_i + 1, cell_j], idx[cell_i + 1, cell_j + 1], idx[cell_i, cell_j + 1]
+        tris.append(np.stack([a, b_, c], 1))
+        tris.append(np.stack([a, c, d], 1))
+    tris = np.concatenate(tris).astype(np.uint32)
+    rng = np.random.Generator(np.random.PCG64(shuffle_seed))
+    tris = tris[rng.permutation(tris.shape[0])]
+    return verts, tris
+
+
+def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True):
+    """S3 (configs C3/C5): n=599 gives 6*599^2*2 = 4 305 612 triangles and 2 152 808 vertices."""
+    b = SceneBuilder()
+    b.set_film(width, height)
+    rfw = b.set_camera_look_at(lib, (0.0, 0.6, 4.2), (0.0, 0.0, 0.0), (0, 1, 0), 38.0)
+    obj = b.material_diffuse(0.4)
+    wall = b.material_diffuse(0.6)
+    black = b.material_diffuse(0.0)
+    verts, tris = cube_sphere(n)
+    b.add_mesh(_to_render(verts, rfw), tris, obj)
+    if with_room:
+        # ground (2) + open room (10: back, left, right, ceiling, front-top strip) + window emitter (2)
+        p, vi = _quad((-4, -1.25, -4), (-4, -1.25, 6), (4, -1.25, 6), (4, -1.25, -4))
+        b.add_mesh(_to_render(p, rfw), vi, wall)
+        room = _merge([
+            _quad((-4, -1.25, -4), (4, -1.25, -4), (4, 4, -4), (-4, 4, -4)),      # back
+            _quad((-4, -1.25, -4), (-4, 4, -4), (-4, 4, 6), (-4, -1.25, 6)),      # left
+            _quad((4, -1.25, -4), (4, -1.25, 6), (4, 4, 6), (4, 4, -4)),          # right
+            _quad((-4, 4, -4), (4, 4, -4), (4, 4, 6), (-4, 4, 6)),                # ceiling
+            _quad((-4, -1.25, 6), (-4, 4, 6), (4, 4, 6), (4, -1.25, 6)),          # behind camera
+        ])
+        b.add_mesh(_to_render(room[0], rfw), room[1], wall)
+        # window emitter high on the left, facing +x/-y into the room (one-sided)
+        p, vi = _quad((-3.9, 1.0, -1.5), (-3.9, 3.0, -1.5), (-3.9, 3.0, 1.5), (-3.9, 1.0, 1.5))
+        b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=40.0)
+    return _finish(b, lib, name=f"S3 ganesha-proxy n={n}")
+
+
+def icosphere(level):
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6],
+                  [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10],
+                  [8, 6, 7], [9, 8, 1]], np.int64)
+    for _ in range(level):
+        edges = {}
+        verts = list(v)
+
+        def mid(a, b_):
+            k = (min(a, b_), max(a, b_))
+            if k not in edges:
+                m = verts[a] + verts[b_]
+                verts.append(m / np.linalg.norm(m))
+                edges[k] = len(verts) - 1
+            return edges[k]
+
+        nf = []
+        for a, b_, c in f:
+            ab, bc, ca = mid(a, b_), mid(b_, c), mid(c, a)
+            nf += [[a, ab, ca], [b_, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        v, f = np.array(verts), np.array(nf, np.int64)
+    return v.astype(np.float32), f.astype(np.uint32)
+
+
+def crown_proxy(lib, width=1000, height=1400, level=4, n_glass=64, n_gold=16, seed=4242):
+    """S4 (config C4): dispersive smooth dielectric icospheres (BK7 eta table -> terminate_secondary), rough gold
+    conductors, diffuse floor, one quad emitter; render with max_depth=32."""
+    b = SceneBuilder()
+    b.set_film(width, height)
+    rfw = b.set_camera_look_at(lib, (0.0, 2.2, 7.5), (0.0, 1.2, 0.0), (0, 1, 0), 32.0)
+    glass = b.material_dielectric(b.spectrum_named("glass-BK7"))
+    gold = b.material_conductor(b.spectrum_named("metal-Au-eta"), b.spectrum_named("metal-Au-k"), roughness=0.01)  # alpha = sqrt(0.01) = 0.1
+    floor = b.material_diffuse(0.5)
+    black = b.material_diffuse(0.0)
+    sv, sf = icosphere(level)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    k = n_glass + n_gold
+    ring = np.arange(k)
+    ang = ring * (2 * np.pi / 16.0) + (ring // 16) * 0.2
+    rad = 1.0 + 0.35 * (ring // 16)
+    centres = np.stack([rad * np.cos(ang), 0.35 + 0.55 * (ring // 16) + 0.1 * rng.random(k), rad * np.sin(ang)], 1)
+    radii = 0.18 + 0.1 * rng.random(k)
+    order = rng.permutation(k)
+    for j, idx in enumerate(order):
+        verts = sv * f32(radii[idx]) + centres[idx].astype(np.float32)[None, :]
+        b.add_mesh(_to_render(verts, rfw), sf, glass if j < n_glass else gold)
+    p, vi = _quad((-6, 0, -6), (-6, 0, 8), (6, 0, 8), (6, 0, -6))
+    b.add_mesh(_to_render(p, rfw), vi, floor)
+    p, vi = _quad((-2, 5, -2), (2, 5, -2), (2, 5, 2), (-2, 5, 2))
+    b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=30.0)
+    return _finish(b, lib, name="S4 crown-proxy")
+
+
+def three_spheres(lib, width=32, height=32, offsets=(-3.5, 0.0, 5.0)):
+    """The reference's set_of_spheres BVH test scene (aggregate.rs:631-702): unit spheres at x = -3.5, 0, 5
+    (world == render space here: the camera sits at the origin)."""
+    b = SceneBuilder()
+    b.set_film(width, height)
+    b.set_camera_look_at(lib, (0, 0, 0), (0, 0, -1), (0, 1, 0), 60.0)
+    m = b.material_diffuse(0.5)
+    for x in offsets:
+        rfo = np.eye(4, dtype=np.float32)
+        rfo[0, 3] = x
+        b.add_sphere(1.0, m, render_from_object=rfo)
+    return _finish(b, lib, name="three spheres")
