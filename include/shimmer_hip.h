@@ -27,6 +27,13 @@ extern "C" {
 
 #define SHM_ABI_VERSION 1
 
+/* The library is built with -fvisibility=hidden; only these entry points are exported. */
+#if defined(__GNUC__)
+#define SHM_API __attribute__((visibility("default")))
+#else
+#define SHM_API
+#endif
+
 typedef enum ShmError {
     SHM_OK = 0,
     SHM_ERR_INVALID_ARGUMENT = -1,
@@ -243,57 +250,57 @@ typedef struct ShmHit {
 typedef struct ShmScene ShmScene;
 
 /* Scene lifetime.  `device` is the HIP device ordinal (one process per GPU: pass LOCAL_RANK). */
-int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out);
-void shm_scene_destroy(ShmScene* scene);
+SHM_API int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out);
+SHM_API void shm_scene_destroy(ShmScene* scene);
 
 /* Film accumulation buffer resident in HBM, pixel_bounds-sized, zero-initialised. */
-int shm_film_clear(ShmScene* scene);
+SHM_API int shm_film_clear(ShmScene* scene);
 /* Render one spp-wave [sample_begin, sample_end) (integrator.rs:257-260) of the given tiles into the
  * device film (+=).  Blocking.  stats may be NULL. */
-int shm_render_wave(ShmScene* scene, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles,
+SHM_API int shm_render_wave(ShmScene* scene, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles,
                     int32_t sample_begin, int32_t sample_end, ShmStats* stats);
 /* Copy the device film to a caller-allocated pixel_bounds-sized row-major array. */
-int shm_film_read(ShmScene* scene, ShmFilmPixel* film_out);
+SHM_API int shm_film_read(ShmScene* scene, ShmFilmPixel* film_out);
 /* Device pointer + byte size of the film (for device-side gathers, e.g. RCCL through torch). */
-int shm_film_device_ptr(ShmScene* scene, void** ptr_out, uint64_t* bytes_out);
+SHM_API int shm_film_device_ptr(ShmScene* scene, void** ptr_out, uint64_t* bytes_out);
 
 /* Whole ImageTileIntegrator::render (integrator.rs:226-322): all waves 1,1,2,4,...,64,64,... over the
  * given tiles; `film` += on the host. */
-int shm_render(ShmScene* scene, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles,
+SHM_API int shm_render(ShmScene* scene, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles,
                ShmFilmPixel* film, ShmStats* stats);
 
 /* Bring-up / microbenchmark entries for K2/K3 alone (BvhAggregate::intersect / intersect_predicate,
  * aggregate.rs:71-203).  Host arrays in, host arrays out. */
-int shm_trace_closest(ShmScene* scene, const ShmRay* rays, uint32_t n, ShmHit* hits_out, ShmStats* stats);
-int shm_trace_any(ShmScene* scene, const ShmRay* rays, uint32_t n, uint8_t* occluded_out, ShmStats* stats);
+SHM_API int shm_trace_closest(ShmScene* scene, const ShmRay* rays, uint32_t n, ShmHit* hits_out, ShmStats* stats);
+SHM_API int shm_trace_any(ShmScene* scene, const ShmRay* rays, uint32_t n, uint8_t* occluded_out, ShmStats* stats);
 /* Same, rays already resident in HBM (device pointers); used by bench.py's traversal roofline leg.
  * `repeat` launches back-to-back; stats->ms_trace_* is the HIP-event total over all of them. */
-int shm_trace_closest_device(ShmScene* scene, const void* rays_dev, uint32_t n, void* hits_dev, int repeat,
+SHM_API int shm_trace_closest_device(ShmScene* scene, const void* rays_dev, uint32_t n, void* hits_dev, int repeat,
                              ShmStats* stats);
-int shm_trace_any_device(ShmScene* scene, const void* rays_dev, uint32_t n, void* occluded_dev, int repeat,
+SHM_API int shm_trace_any_device(ShmScene* scene, const void* rays_dev, uint32_t n, void* occluded_dev, int repeat,
                          ShmStats* stats);
 
-const char* shm_last_error(void);   /* thread-local, never NULL */
-int shm_device_count(void);
+SHM_API const char* shm_last_error(void);   /* thread-local, never NULL */
+SHM_API int shm_device_count(void);
 
 /* ---- host-side mirror of the reference's scene-construction steps (no GPU needed) ------------- */
 
 /* BvhAggregate::new (aggregate.rs:207-467): recursive build (split_method 0 = middle, 1 = equal counts),
  * 1-primitive leaves, DFS flatten.  prim_bounds: 6 floats (min xyz, max xyz) per input primitive.
  * nodes_out capacity 2*n-1; prim_order_out[n] receives, per leaf-order slot, the input primitive index. */
-int shm_bvh_build(const float* prim_bounds, uint32_t n, int split_method, ShmBvhNode* nodes_out,
+SHM_API int shm_bvh_build(const float* prim_bounds, uint32_t n, int split_method, ShmBvhNode* nodes_out,
                   uint32_t* n_nodes_out, uint32_t* prim_order_out);
 /* Tile::tile (tile.rs:21-104). tiles_out capacity ceil(w/tw)*ceil(h/th); returns the count via n_out. */
-int shm_tile_bounds(const int32_t pixel_bounds[4], int32_t tile_w, int32_t tile_h, ShmTile* tiles_out,
+SHM_API int shm_tile_bounds(const int32_t pixel_bounds[4], int32_t tile_w, int32_t tile_h, ShmTile* tiles_out,
                     uint32_t* n_out);
 /* PerspectiveCamera::new + CameraTransform (camera.rs:893-963, 507-523, 594-642) for a world_from_camera
  * matrix, fov (degrees), screen window derived from the aspect ratio (camera.rs:848-864). Rendering
  * coordinate system: CameraWorld (the reference default, options.rs). */
-int shm_camera_perspective(const float world_from_camera[16], float fov_deg, const int32_t full_resolution[2],
+SHM_API int shm_camera_perspective(const float world_from_camera[16], float fov_deg, const int32_t full_resolution[2],
                            float lens_radius, float focal_distance, ShmCamera* out,
                            float render_from_world_out[16]);
 /* Image::write_pfm (image.rs:1333-1377): RGB float, bottom-up rows, little-endian (scale -1). */
-int shm_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height);
+SHM_API int shm_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height);
 
 #ifdef __cplusplus
 }

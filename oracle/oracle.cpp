@@ -247,6 +247,7 @@ thread_local std::string g_err;
 
 }  // namespace
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 struct OrcScene;
@@ -505,3 +506,4 @@ float orc_fn_spectrum_get(OrcScene* s, const ShmSpectrum* sp, float lambda) {
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

@@ -41,6 +41,9 @@ thread_local std::string g_err;
         }                                                                                        \
     } while (0)
 
+static bool dbg_on() { static int v = -1; if (v < 0) v = getenv("SHM_DEBUG") ? 1 : 0; return v == 1; }
+#define DBG(...) do { if (dbg_on()) { fprintf(stderr, "[shm] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
+
 constexpr int WAVE = 64;
 constexpr int TRACE_BLOCK = 256;  // 4 waves per workgroup
 constexpr int SHADE_BLOCK = 128;
@@ -866,19 +869,26 @@ int shm_render(ShmScene* s, const ShmRenderParams* params, const ShmTile* tiles,
 static int trace_device_impl(ShmScene* s, bool any, const void* rays_dev, uint32_t n, void* out_dev, int repeat, ShmStats* stats) {
     if (!s || !rays_dev || !out_dev || n == 0 || repeat < 1) { g_err = "invalid trace arguments"; return SHM_ERR_INVALID_ARGUMENT; }
     HIP_TRY(hipSetDevice(s->device));
+    DBG("trace_device_impl n=%u any=%d blocks=%d lds=%zu stack=%d", n, (int)any, s->trace_blocks, trace_lds_bytes(s), s->stack_entries);
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), s->stream));
+    DBG("memset ok");
     EventPool ev{s};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
     for (int r = 0; r < repeat; ++r) {
         hipLaunchKernelGGL(k_reset_head, dim3(1), dim3(1), 0, s->stream, s->d_head);
+        DBG("reset_head launched: %s", hipGetErrorString(hipGetLastError()));
         hipEvent_t a = ev.get(), b = ev.get();
+        DBG("events %p %p", (void*)a, (void*)b);
         hipEventRecord(a, s->stream);
+        DBG("event recorded");
         if (any) launch_trace<true>(s, nullptr, nullptr, n, s->d_head, (const ShmRay*)rays_dev, nullptr, (uint8_t*)out_dev, nullptr, nullptr);
         else launch_trace<false>(s, nullptr, nullptr, n, s->d_head, (const ShmRay*)rays_dev, (ShmHit*)out_dev, nullptr, nullptr, nullptr);
+        DBG("trace launched: %s", hipGetErrorString(hipGetLastError()));
         hipEventRecord(b, s->stream);
         evs.push_back({a, b});
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
+    DBG("synchronized");
     HIP_TRY(hipGetLastError());
     if (stats) {
         memset(stats, 0, sizeof(*stats));

@@ -1,0 +1,333 @@
+"""The oracle (and with it the shared leaf-arithmetic headers) against (1) the reference's own in-source
+known answers and (2) independent float32 numpy re-evaluations (tests/golden/gen_golden.py)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_py
+from oracle_py import fa
+from shimmer_amd import abi, scenes, scene as scn
+
+f32 = np.float32
+
+
+def bits(x):
+    return np.float32(x).view(np.uint32)
+
+
+def same_f32(a, b):
+    a, b = np.float32(a), np.float32(b)
+    return bits(a) == bits(b) or (a == b)  # +0/-0 compare equal
+
+
+def ulp_diff(a, b):
+    a, b = np.float32(a), np.float32(b)
+    ia, ib = np.int64(a.view(np.int32)), np.int64(b.view(np.int32))
+    ia = ia if ia >= 0 else np.int64(-2**31) - ia
+    ib = ib if ib >= 0 else np.int64(-2**31) - ib
+    return abs(int(ia) - int(ib))
+
+
+# ---------------------------------------------------------------- reference known answers
+def ray8(r, tmax=np.inf):
+    return np.array([[*r, tmax, 0]], np.float32)
+
+
+def test_aggregate_single_sphere(lib, golden):
+    """aggregate.rs:601-628."""
+    ka = golden["reference_known_answers"]["aggregate_single_sphere"]
+    sc = scenes.three_spheres(lib, offsets=(0.0,))
+    o = oracle_py.Oracle(sc.desc)
+    hit, _ = o.trace(ray8(ka["ray"]))
+    assert hit["prim"][0] == 0
+    assert abs(hit["t"][0] - ka["t"]) < 1e-6 * 4  # assert_approx_eq default epsilon is f32::EPSILON-scaled
+    out = (C.c_float * 12)()
+    ray = abi.ShmRay()
+    ray.o[:], ray.d[:], ray.t_max = ka["ray"][:3], ka["ray"][3:], float("inf")
+    assert o.lib.orc_fn_hit_interaction(o.handle, C.byref(ray), out, None) == 1
+    assert abs(out[0] - ka["p_x"]) < ka["eps_p"] and abs(out[1]) < 1e-6 and abs(out[2]) < 1e-6
+    ns_dot = -out[6]  # shading.n . (-1,0,0)
+    assert abs(ns_dot - ka["n_dot_negx"]) < 1e-6
+    o.close()
+
+
+def test_aggregate_three_spheres(lib, golden):
+    """aggregate.rs:631-702: closest hit at t = 5.5, predicate true; offset ray misses both ways."""
+    ka = golden["reference_known_answers"]["aggregate_three_spheres"]
+    sc = scenes.three_spheres(lib, offsets=tuple(ka["offsets"]))
+    o = oracle_py.Oracle(sc.desc)
+    hit, _ = o.trace(ray8(ka["ray"]))
+    assert hit["prim"][0] >= 0 and abs(hit["t"][0] - ka["t"]) < ka["eps_t"]
+    occ, _ = o.trace(ray8(ka["ray"]), any_hit=True)
+    assert occ[0] == 1
+    out = (C.c_float * 12)()
+    ray = abi.ShmRay()
+    ray.o[:], ray.d[:], ray.t_max = ka["ray"][:3], ka["ray"][3:], float("inf")
+    assert o.lib.orc_fn_hit_interaction(o.handle, C.byref(ray), out, None) == 1
+    assert abs(out[0] - ka["p_x"]) < 1e-5
+    miss, _ = o.trace(ray8(ka["miss_ray"]))
+    assert miss["prim"][0] == -1
+    occ, _ = o.trace(ray8(ka["miss_ray"]), any_hit=True)
+    assert occ[0] == 0
+    o.close()
+
+
+@pytest.mark.parametrize("which,zmin,zmax", [("full", None, None), ("partial_z_pm_half", -0.5, 0.5)])
+def test_sphere_predicates(lib, golden, which, zmin, zmax):
+    """shape/shape.rs:299-342."""
+    b = scn.SceneBuilder()
+    b.set_film(8, 8)
+    b.set_camera_look_at(lib, (0, 0, 0), (0, 0, -1), (0, 1, 0), 60.0)
+    b.add_sphere(1.0, b.material_diffuse(0.5), z_min=zmin, z_max=zmax)
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    for case in golden["reference_known_answers"]["sphere_predicates"][which]:
+        occ, _ = o.trace(ray8(case["ray"]), any_hit=True)
+        assert bool(occ[0]) == case["hit"], case
+    o.close()
+
+
+def test_tr_d_reference_value(orc, golden):
+    """bxdf.rs:1839-1856 (the D value; the G constant there is stale — SURVEY §4)."""
+    ka = golden["reference_known_answers"]["tr_d"]
+    d = orc.orc_fn_tr_d(ka["alpha"], ka["alpha"], fa(*ka["wm"]))
+    assert abs(d - ka["d"]) / ka["d"] < ka["rel"]
+
+
+def test_dielectric_sample_f_reference_vector(orc, golden):
+    """bxdf.rs:1871-1903."""
+    ka = golden["reference_known_answers"]["dielectric_sample_f"]
+    out = (C.c_float * 10)()
+    z4 = fa(0, 0, 0, 0)
+    ok = orc.orc_fn_bxdf_sample_f(abi.SHM_MATERIAL_DIELECTRIC, z4, z4, ka["eta"], 0.0, 0.0, fa(*ka["wo"]), ka["uc"], fa(*ka["u"]), out)
+    assert ok == 1
+    assert int(out[8]) == ka["flags"]  # SPECULAR | TRANSMISSION
+    rel = ka["rel"]
+    assert abs(out[7] - ka["pdf"]) <= rel * ka["pdf"]
+    assert abs(out[9] - ka["eta_out"]) <= rel
+    for i in range(4):
+        assert abs(out[i] - ka["f"]) <= rel * ka["f"]
+    for i in range(3):
+        assert abs(out[4 + i] - ka["wi"][i]) <= 2e-7
+
+
+def test_visible_wavelengths_pdf_bounds(orc, golden):
+    """sampling.rs:801-812."""
+    for lam in golden["reference_known_answers"]["visible_wavelengths_pdf_zero"]:
+        assert orc.orc_fn_visible_wavelengths_pdf(lam) == 0.0
+    assert orc.orc_fn_visible_wavelengths_pdf(550.0) > 0.0
+
+
+def test_cie_y_integral_monte_carlo(orc):
+    """spectra/spectrum.rs:860-889: MC estimate of CIE_Y_INTEGRAL through sample_visible_wavelengths (eps 0.2 there for
+    a random stream; a stratified stream is used here)."""
+    y = scn.tables()["CIE_Y"]
+    n = 20000
+    acc = 0.0
+    for i in range(n):
+        u = (i + 0.5) / n
+        lam = orc.orc_fn_sample_visible_wavelengths(u)
+        pdf = orc.orc_fn_visible_wavelengths_pdf(lam)
+        if pdf > 0:
+            acc += y[int(round(lam)) - 360] / pdf
+    assert abs(acc / n - 106.856895) < 0.2
+
+
+def test_blackbody_known_answers(golden):
+    """spectra/spectrum.rs:654-680 against the host-side restatement used for light spectra (f32 arithmetic)."""
+    for lam, t, expect in golden["reference_known_answers"]["blackbody"]:
+        c, h, kb = f32(299792458.0), f32(6.62606957e-34), f32(1.3806488e-23)
+        l = f32(lam) * f32(1e-9)
+        le = (f32(2.0) * h * c * c) / (l ** 5 * (np.exp((h * c) / (l * kb * f32(t)), dtype=np.float32) - f32(1.0)))
+        assert abs(le - expect) / expect < 1e-3
+    d = scn.blackbody_dense(6500.0)
+    assert d.shape == (471,) and abs(d.max() - 1.0) < 2e-3  # normalised at Wien's peak (446 nm)
+
+
+def test_next_float(orc, golden):
+    """float.rs:172-211."""
+    assert orc.orc_fn_next_float_up(-0.0) > 0.0
+    assert orc.orc_fn_next_float_down(0.0) < 0.0
+    inf = float("inf")
+    assert orc.orc_fn_next_float_up(inf) == inf and orc.orc_fn_next_float_down(inf) < inf
+    assert orc.orc_fn_next_float_down(-inf) == -inf and orc.orc_fn_next_float_up(-inf) > -inf
+    rng = np.random.default_rng(1)
+    for x in (rng.random(2000).astype(np.float32) * 2000 - 1000):
+        assert orc.orc_fn_next_float_up(float(x)) == float(np.nextafter(x, f32(np.inf)))
+        assert orc.orc_fn_next_float_down(float(x)) == float(np.nextafter(x, f32(-np.inf)))
+    for x, up, down in golden["numpy_f32"]["next_float"]:
+        assert orc.orc_fn_next_float_up(x) == up and orc.orc_fn_next_float_down(x) == down
+
+
+# ---------------------------------------------------------------- independent numpy float32 goldens (bit-exact)
+def test_gamma(orc, golden):
+    for n, g in golden["numpy_f32"]["gamma"]:
+        assert same_f32(orc.orc_fn_gamma(n), g)
+
+
+def test_difference_of_products(orc, golden):
+    for a, b, c, d, r in golden["numpy_f32"]["difference_of_products"]:
+        assert same_f32(orc.orc_fn_difference_of_products(a, b, c, d), r)
+
+
+def test_dot_cross(orc, golden):
+    for row in golden["numpy_f32"]["dot"]:
+        assert same_f32(orc.orc_fn_dot(fa(*row[:3]), fa(*row[3:6])), row[6])
+    out = (C.c_float * 3)()
+    for row in golden["numpy_f32"]["cross"]:
+        orc.orc_fn_cross(fa(*row[:3]), fa(*row[3:6]), out)
+        assert all(same_f32(out[i], row[6 + i]) for i in range(3))
+
+
+def test_coordinate_system(orc, golden):
+    out = (C.c_float * 6)()
+    for row in golden["numpy_f32"]["coordinate_system"]:
+        orc.orc_fn_coordinate_system(fa(*row[:3]), out)
+        assert all(same_f32(out[i], row[3 + i]) for i in range(6))
+
+
+def test_intersect_p_cached(orc, golden):
+    n_hit = 0
+    for c in golden["numpy_f32"]["intersect_p_cached"]:
+        got = orc.orc_fn_intersect_p_cached(fa(*c["bmin"]), fa(*c["bmax"]), fa(*c["o"]), fa(*c["d"]), c["t_max"])
+        assert bool(got) == c["hit"], c
+        n_hit += got
+    assert 5 < n_hit < 62  # both outcomes are exercised
+
+
+def test_intersect_triangle(orc, golden):
+    out = (C.c_float * 4)()
+    n_hit = 0
+    for c in golden["numpy_f32"]["intersect_triangle"]:
+        got = orc.orc_fn_intersect_triangle(fa(*c["o"]), fa(*c["d"]), c["t_max"], fa(*c["p0"]), fa(*c["p1"]), fa(*c["p2"]), out)
+        assert bool(got) == (c["hit"] is not None), c
+        if got:
+            n_hit += 1
+            assert all(same_f32(out[i], c["hit"][i]) for i in range(4)), (list(out), c)
+    assert n_hit > 15
+
+
+def test_trowbridge_reitz(orc, golden):
+    g = golden["numpy_f32"]
+    for ax, ay, x, y, z, d in g["tr_d"]:
+        assert same_f32(orc.orc_fn_tr_d(ax, ay, fa(x, y, z)), d)
+    for ax, ay, x, y, z, lam in g["tr_lambda"]:
+        assert same_f32(orc.orc_fn_tr_lambda(ax, ay, fa(x, y, z)), lam)
+    for row in g["tr_g"]:
+        assert same_f32(orc.orc_fn_tr_g(row[0], row[1], fa(*row[2:5]), fa(*row[5:8])), row[8])
+    tv = g["tr_g_bxdf_test_vector"]
+    got = orc.orc_fn_tr_g(tv["alpha"], tv["alpha"], fa(*tv["w1"]), fa(*tv["w2"]))
+    assert same_f32(got, tv["g"]) and abs(got - 0.97391653) < 1e-6  # not the stale 0.954060972 of bxdf.rs:1851
+
+
+def test_fresnel_dielectric(orc, golden):
+    for c, eta, r in golden["numpy_f32"]["fresnel_dielectric"]:
+        assert same_f32(orc.orc_fn_fresnel_dielectric(c, eta), r)
+
+
+def test_offset_ray_origin(orc, golden):
+    out = (C.c_float * 3)()
+    for c in golden["numpy_f32"]["offset_ray_origin"]:
+        orc.orc_fn_offset_ray_origin(fa(*c["p"]), fa(*c["err"]), fa(*c["n"]), fa(*c["w"]), out)
+        assert all(same_f32(out[i], c["out"][i]) for i in range(3)), c
+
+
+# ---------------------------------------------------------------- transcendentals vs float64 numpy (<= 2 ulp)
+@pytest.mark.parametrize("name,ref,lo,hi,tol", [
+    ("sin", np.sin, -10.0, 10.0, 2), ("cos", np.cos, -10.0, 10.0, 2), ("asin", np.arcsin, -1.0, 1.0, 2),
+    ("acos", np.arccos, -1.0, 1.0, 3), ("exp", np.exp, -20.0, 20.0, 2), ("log", np.log, 1e-6, 1e6, 2),
+    ("cosh", np.cosh, -3.0, 3.0, 3), ("atanh", None, -0.98, 0.9, 2)])
+def test_transcendentals(orc, name, ref, lo, hi, tol):
+    fn = getattr(orc, "orc_fn_" + name)
+    if name == "atanh":
+        # Rust std's f32::atanh is 0.5 * ln_1p(2x / (1 - x)) with the quotient rounded to f32 (ill-conditioned near -1 by
+        # construction); the restatement must match THAT formula, evaluated here with an exact log1p.
+        def ref(x):
+            x = np.float32(x)
+            return 0.5 * np.log1p(np.float64(np.float32(np.float32(2.0) * x) / np.float32(np.float32(1.0) - x)))
+    xs = np.linspace(lo, hi, 4001).astype(np.float32)
+    worst = 0
+    for x in xs:
+        want = np.float32(ref(np.float64(x)))
+        got = fn(float(x))
+        if abs(want) < 1e-30:
+            assert abs(got) < 1e-6
+            continue
+        if name in ("sin", "cos") and abs(want) < 1e-3:
+            assert abs(got - want) < 1e-7  # near zeros of sin/cos the absolute error is what matters
+            continue
+        worst = max(worst, ulp_diff(got, want))
+    assert worst <= tol, worst
+
+
+def test_atan2_hypot_round(orc):
+    rng = np.random.default_rng(5)
+    worst = 0
+    for y, x in rng.normal(size=(4000, 2)).astype(np.float32):
+        want = np.float32(np.arctan2(np.float64(y), np.float64(x)))
+        worst = max(worst, ulp_diff(orc.orc_fn_atan2(float(y), float(x)), want))
+        assert same_f32(orc.orc_fn_hypot(float(x), float(y)), np.float32(np.hypot(np.float64(x), np.float64(y))))
+    assert worst <= 4, worst  # quotient rounding + Cephes-class atan kernel
+    assert orc.orc_fn_atan2(0.0, -1.0) == np.float32(np.pi) and orc.orc_fn_atan2(-0.0, -1.0) == -np.float32(np.pi)
+    assert orc.orc_fn_atan2(1.0, 0.0) == np.float32(np.pi / 2)
+    for x in [0.5, 1.5, 2.5, -0.5, -2.5, 359.5, 360.49, 829.5, 0.49999997]:
+        assert orc.orc_fn_round(x) == math.copysign(math.floor(abs(float(np.float32(x))) + 0.5), x)  # half away from zero
+
+
+def test_fresnel_complex_against_complex128(orc):
+    """scattering.rs:78-89 through num-complex's operation order, against numpy complex128 (tolerance 1e-5)."""
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        c, eta, k = rng.random(), 0.1 + 3 * rng.random(), 4 * rng.random()
+        e = complex(eta, k)
+        s2 = (1 - c * c) / (e * e)
+        ct = np.sqrt(1 - s2)
+        rp = (e * c - ct) / (e * c + ct)
+        rs = (c - e * ct) / (c + e * ct)
+        want = (abs(rp) ** 2 + abs(rs) ** 2) / 2
+        assert abs(orc.orc_fn_fresnel_complex(c, eta, k) - want) < 2e-5
+
+
+def test_sampler_stream_properties(orc):
+    """The defined per-pixel PCG32 stream (shm/sampling.h): deterministic, in [0,1), distinct per pixel/sample/seed,
+    uniform to first order."""
+    n = 4096
+    a, b = (C.c_float * n)(), (C.c_float * n)()
+    orc.orc_fn_sampler_stream(3, 7, 0, 0, n, a)
+    orc.orc_fn_sampler_stream(3, 7, 0, 0, n, b)
+    a = np.array(a)
+    assert np.array_equal(a, np.array(b)) and a.min() >= 0.0 and a.max() < 1.0
+    assert abs(a.mean() - 0.5) < 0.02 and abs(np.mean(a * a) - 1 / 3) < 0.02
+    for args in [(4, 7, 0, 0), (3, 8, 0, 0), (3, 7, 1, 0), (3, 7, 0, 1)]:
+        orc.orc_fn_sampler_stream(*args, n, b)
+        assert not np.array_equal(a[:16], np.array(b)[:16])
+    # sample_index s starts 65536*s draws into the pixel's sequence: the first draw differs from the continuation
+    assert len(set(np.round(a[:64], 7))) > 60
+
+
+def test_triangle_light_sampling_consistency(orc):
+    """triangle.rs:595-745: a sample produced by sample_with_context has pdf_with_context equal to the sampled pdf
+    (the solid-angle branch is exact up to rounding; the area branch recomputes through an intersection)."""
+    rng = np.random.default_rng(11)
+    p0, p1, p2 = fa(-1, 3, -1), fa(1, 3, -1), fa(1, 3, 1)
+    out = (C.c_float * 7)()
+    checked = 0
+    for _ in range(200):
+        ctx_p = (rng.random(3) * np.array([4, 2, 4]) - np.array([2, 0, 2])).astype(np.float32)
+        ns = fa(0, 1, 0)
+        u = rng.random(2).astype(np.float32)
+        if not orc.orc_fn_triangle_sample_with_context(p0, p1, p2, fa(*ctx_p), fa(0, 1, 0), ns, fa(*u), out):
+            continue
+        p = np.array(out[:3])
+        wi = p - ctx_p
+        wi = (wi / np.linalg.norm(wi)).astype(np.float32)
+        pdf = orc.orc_fn_triangle_pdf_with_context(p0, p1, p2, fa(*ctx_p), fa(0, 1, 0), ns, fa(*wi))
+        assert out[6] > 0 and pdf > 0
+        assert abs(out[3]) < 1e-6 and abs(out[4] + 1) < 1e-6 and abs(out[5]) < 1e-6  # normal of this winding: -y
+        checked += 1
+        # NB: the reference samples with the UNWARPED u but reports the warped pdf (triangle.rs:639-641), so the
+        # two pdfs agree only up to the bilinear warp density ratio; both must be finite and of the same scale.
+        assert 0.05 < pdf / out[6] < 20
+    assert checked > 100
