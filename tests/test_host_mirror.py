@@ -1,0 +1,212 @@
+"""Host-side mirror of the reference's scene-construction steps + C-ABI surface (no GPU needed)."""
+import ctypes as C
+import re
+import struct
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from shimmer_amd import abi, scene as scn, scenes
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_library_exports_every_declared_symbol(lib):
+    """Every function include/shimmer_hip.h declares is exported by libshimmer_hip.so, and nothing the header
+    declares is missing from the ctypes table (no compute calls here)."""
+    header = (ROOT / "include" / "shimmer_hip.h").read_text()
+    declared = set(re.findall(r"SHM_API\s+[\w\s\*]+?\b(shm_[a-z_]+)\s*\(", header))
+    assert declared == set(abi.EXPORTS), declared ^ set(abi.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.shm_last_error() is not None
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(abi.ShmBvhNode) == 32 and C.sizeof(abi.ShmPrimitive) == 16 and C.sizeof(abi.ShmSpectrum) == 32
+    assert C.sizeof(abi.ShmRay) == 32 and C.sizeof(abi.ShmHit) == 32 and C.sizeof(abi.ShmFilmPixel) == 32 and C.sizeof(abi.ShmTile) == 16
+    assert C.sizeof(abi.ShmMaterial) == 32 + 64 and C.sizeof(abi.ShmLight) == 32 + 32 and C.sizeof(abi.ShmRenderParams) == 24
+
+
+def test_no_device_is_a_loud_error_not_a_fallback(lib):
+    """On a machine without a GPU the render entry points must fail with SHM_ERR_NO_DEVICE."""
+    if lib.shm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    sc = scenes.cornell_box(lib, 16, 16)
+    h = C.c_void_p()
+    rc = lib.shm_scene_create(C.byref(sc.desc), 0, C.byref(h))
+    assert rc == -4 and not h.value and b"no CPU fallback" in lib.shm_last_error()
+
+
+def py_tiles(pb, tw=8, th=8):
+    """Tile::tile restated literally (tile.rs:21-104)."""
+    w, h = pb[2] - pb[0], pb[3] - pb[1]
+    nh, rh, nv, rv = w // tw, w % tw, h // th, h % th
+    out = []
+    for ty in range(nv):
+        for tx in range(nh):
+            out.append((pb[0] + tx * tw, pb[1] + ty * th, pb[0] + tx * tw + tw, pb[1] + ty * th + th))
+        if rh > 0:
+            out.append((pb[0] + nh * tw, pb[1] + ty * th, pb[0] + nh * tw + rh, pb[1] + ty * th + th))
+    if rv > 0:
+        for tx in range(nh):
+            out.append((pb[0] + tx * tw, pb[1] + nv * th, pb[0] + tx * tw + tw, pb[1] + nv * th + rv))
+    if rh > 0 and rv > 0:
+        out.append((pb[0] + nh * tw, pb[1] + nv * th, pb[0] + nh * tw + rh, pb[1] + nv * th + rv))
+    return out
+
+
+@pytest.mark.parametrize("pb", [(0, 0, 128, 128), (0, 0, 13, 7), (3, 5, 36, 22), (0, 0, 8, 8), (0, 0, 3, 3), (10, 10, 1034, 1034)])
+def test_tile_bounds(lib, pb):
+    tiles, n = scn.tiles_for(lib, pb)
+    got = [(t.x0, t.y0, t.x1, t.y1) for t in tiles[:n]]
+    assert got == py_tiles(pb)
+    cover = np.zeros((pb[3] - pb[1], pb[2] - pb[0]), np.int32)
+    for x0, y0, x1, y1 in got:
+        cover[y0 - pb[1]:y1 - pb[1], x0 - pb[0]:x1 - pb[0]] += 1
+    assert (cover == 1).all()  # exclusive ownership: the film-write argument of integrator.rs:277-286
+
+
+def test_wave_schedule():
+    """integrator.rs:231-233, 306-308."""
+    assert scn.wave_schedule(1) == [(0, 1)]
+    assert scn.wave_schedule(4) == [(0, 1), (1, 2), (2, 4)]
+    sizes = [e - s for s, e in scn.wave_schedule(256)]
+    assert sizes == [1, 1, 2, 4, 8, 16, 32, 64, 64, 64] and sum(sizes) == 256
+    assert sum(e - s for s, e in scn.wave_schedule(1024)) == 1024 and len(scn.wave_schedule(1024)) == 22
+
+
+def check_bvh(desc, info):
+    nodes = np.frombuffer(C.string_at(desc.nodes, desc.n_nodes * 32), dtype=np.dtype(
+        [("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<u4"), ("n_prims", "<u2"), ("axis", "u1"), ("pad", "u1")]))
+    n = desc.n_primitives
+    pb = info["bounds"][info["order"]]  # leaf-order primitive bounds
+    seen = np.zeros(n, np.int32)
+    stack = [0]
+    visited = 0
+    depth_max = 0
+    depth = {0: 0}
+    while stack:
+        i = stack.pop()
+        visited += 1
+        nd = nodes[i]
+        if nd["n_prims"] > 0:
+            sl = slice(int(nd["offset"]), int(nd["offset"]) + int(nd["n_prims"]))
+            seen[sl] += 1
+            assert (pb[sl, :3] >= nd["bmin"]).all() and (pb[sl, 3:] <= nd["bmax"]).all()
+            assert np.array_equal(pb[sl, :3].min(0), nd["bmin"]) and np.array_equal(pb[sl, 3:].max(0), nd["bmax"])
+            depth_max = max(depth_max, depth[i])
+        else:
+            a, b = i + 1, int(nd["offset"])
+            assert b > a and nd["axis"] <= 2
+            for c in (a, b):
+                assert (nodes[c]["bmin"] >= nd["bmin"]).all() and (nodes[c]["bmax"] <= nd["bmax"]).all()
+                depth[c] = depth[i] + 1
+            assert np.array_equal(np.minimum(nodes[a]["bmin"], nodes[b]["bmin"]), nd["bmin"])
+            assert np.array_equal(np.maximum(nodes[a]["bmax"], nodes[b]["bmax"]), nd["bmax"])
+            stack += [b, a]
+    assert visited == desc.n_nodes and (seen == 1).all()
+    assert sorted(info["order"].tolist()) == list(range(n))
+    return nodes, depth_max
+
+
+def test_bvh_build_structure(lib):
+    """BvhAggregate::new (aggregate.rs:207-467): every primitive in exactly one leaf, DFS order (first child = i+1),
+    parent bounds = union of children, leaves only for single prims or degenerate centroid bounds."""
+    sc = scenes.ganesha_proxy(lib, 32, 32, n=12)
+    nodes, depth = check_bvh(sc.desc, sc.info)
+    assert depth < 64
+    multi = nodes[nodes["n_prims"] > 1]
+    # multi-primitive leaves only arise from coincident centroids (the room's quads): aggregate.rs:345
+    assert len(multi) <= 16
+    sc2 = scenes.cornell_box(lib, 16, 16)
+    check_bvh(sc2.desc, sc2.info)
+    assert sc2.desc.n_primitives == 32
+
+
+def test_bvh_single_primitive_bounds(lib):
+    """aggregate.rs:575-598 single_primitive_bvh: the BVH bounds equal the primitive's bounds."""
+    sc = scenes.three_spheres(lib, offsets=(0.0,))
+    assert sc.desc.n_nodes == 1
+    nd = sc.desc.nodes[0]
+    assert list(nd.bmin) == [-1.0, -1.0, -1.0] and list(nd.bmax) == [1.0, 1.0, 1.0] and nd.n_prims == 1
+
+
+def test_bvh_equal_counts_and_errors(lib):
+    rng = np.random.default_rng(3)
+    lo = rng.random((257, 3)).astype(np.float32)
+    bounds = np.ascontiguousarray(np.concatenate([lo, lo + 0.01], axis=1).astype(np.float32))
+    nodes = (abi.ShmBvhNode * (2 * 257))()
+    order = np.zeros(257, np.uint32)
+    nn = C.c_uint32()
+    for method in (0, 1):
+        assert lib.shm_bvh_build(bounds.ctypes.data_as(abi.c_float_p), 257, method, nodes, C.byref(nn), order.ctypes.data_as(abi.c_u32_p)) == 0
+        assert nn.value == 2 * 257 - 1 and sorted(order.tolist()) == list(range(257))
+    assert lib.shm_bvh_build(bounds.ctypes.data_as(abi.c_float_p), 0, 0, nodes, C.byref(nn), order.ctypes.data_as(abi.c_u32_p)) == -1
+    assert lib.shm_bvh_build(bounds.ctypes.data_as(abi.c_float_p), 257, 7, nodes, C.byref(nn), order.ctypes.data_as(abi.c_u32_p)) == -1
+    bad = bounds.copy()
+    bad[5, 1] = np.nan  # the reference panics "Unexpected NaN" (aggregate.rs:373)
+    assert lib.shm_bvh_build(bad.ctypes.data_as(abi.c_float_p), 257, 0, nodes, C.byref(nn), order.ctypes.data_as(abi.c_u32_p)) == -1
+
+
+def test_camera_perspective(lib):
+    """PerspectiveCamera::new: the centre of the raster maps to the optical axis, corners to +-tan(fov/2) on the short
+    side (camera.rs:848-963), camera-world rendering space (camera.rs:507-523)."""
+    b = scn.SceneBuilder()
+    b.set_film(200, 100)
+    rfw = b.set_camera_look_at(lib, (1, 2, 3), (1, 2, 2), (0, 1, 0), 60.0)
+    cam = b.camera
+    m = np.array(list(cam.camera_from_raster), np.float64).reshape(4, 4)
+
+    def xf(p):
+        q = m @ np.array([*p, 1.0])
+        return q[:3] / q[3]
+
+    c = xf((100, 50, 0))
+    assert abs(c[0]) < 1e-6 and abs(c[1]) < 1e-6
+    t = np.tan(np.deg2rad(30.0))
+    top = xf((100, 0, 0))
+    left = xf((0, 50, 0))
+    assert abs(top[1] / top[2] - t) < 1e-5 and abs(left[0] / left[2] + 2 * t) < 1e-5
+    assert np.allclose(rfw[:3, 3], [-1, -2, -3]) and np.allclose(rfw[:3, :3], np.eye(3))
+    rfc = np.array(list(cam.render_from_camera), np.float64).reshape(4, 4)
+    assert np.allclose(rfc[:3, 3], 0, atol=1e-6)  # camera at the render-space origin
+    assert np.allclose(rfc[:3, 2], [0, 0, -1], atol=1e-6)  # looking down -z in world = +z in camera space
+    dx = np.array(list(cam.dx_camera))
+    assert dx[0] > 0 and abs(dx[1]) < 1e-9
+
+
+def test_write_pfm_roundtrip(lib, tmp_path):
+    """Image::write_pfm (image.rs:1333-1377): 'PF', dims, scale -1 (little endian), rows bottom-up."""
+    img = np.arange(5 * 3 * 3, dtype=np.float32).reshape(3, 5, 3)
+    path = tmp_path / "x.pfm"
+    assert lib.shm_write_pfm(str(path).encode(), img.ctypes.data_as(abi.c_float_p), 5, 3) == 0
+    raw = path.read_bytes()
+    header, body = raw[:raw.index(b"-1.0\n") + 5], raw[raw.index(b"-1.0\n") + 5:]
+    assert header == b"PF\n5 3\n-1.0\n" and len(body) == 5 * 3 * 3 * 4
+    back = np.frombuffer(body, "<f4").reshape(3, 5, 3)[::-1]
+    assert np.array_equal(back, img)
+
+
+def test_scene_validation_errors(orc, lib):
+    """flatten_scene rejects malformed descriptions with codes instead of panicking (the reference panics)."""
+    import oracle_py
+    sc = scenes.cornell_box(lib, 16, 16)
+    d = sc.desc
+    h = C.c_void_p()
+    for field, bad in (("abi_version", 99), ("n_nodes", 0), ("n_primitives", 0), ("n_materials", 0)):
+        keep = getattr(d, field)
+        setattr(d, field, bad)
+        assert orc.orc_scene_create(C.byref(d), C.byref(h)) == -1
+        setattr(d, field, keep)
+    keep = d.materials[0].kind
+    d.materials[0].kind = 9  # e.g. a coated material: SURVEY §8f row, not in the contract
+    assert orc.orc_scene_create(C.byref(d), C.byref(h)) == -2
+    d.materials[0].kind = keep
+    keep = d.nodes[0].offset
+    d.nodes[0].offset = 10 ** 6
+    assert orc.orc_scene_create(C.byref(d), C.byref(h)) == -1
+    d.nodes[0].offset = keep
+    o = oracle_py.Oracle(d)  # intact again
+    o.close()
