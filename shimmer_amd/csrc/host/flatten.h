@@ -2,6 +2,9 @@
 // (host memory). libshimmer_hip uploads these arrays to HBM; the CPU oracle reads them in place.
 // This is data marshalling only: no arithmetic of the hot path lives here.
 #pragma once
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
 #include <string>
 #include <utility>
@@ -214,6 +217,7 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         }
     }
     // The reference's traversal stack is [usize; 64] (aggregate.rs:90); deeper trees would index out of bounds there.
+    if (getenv("SHM_DEBUG")) fprintf(stderr, "[shm] flatten: %u nodes, %u prims, max leaf depth %u\n", d->n_nodes, d->n_primitives, out.max_leaf_depth);
     if (out.max_leaf_depth >= 64) { err = "BVH deeper than the reference's 64-entry traversal stack"; return SHM_ERR_UNSUPPORTED; }
     return SHM_OK;
 }

@@ -47,22 +47,36 @@ struct TriangleIntersection {
     Float b0, b1, b2, t;
 };
 
-// shape/triangle.rs:173-302
-SHM_HD bool intersect_triangle(V3 ro, V3 rd, Float t_max, V3 p0, V3 p1, V3 p2, TriangleIntersection& out) {
+// shape/triangle.rs:197-219: the permutation and shear depend on the ray only ("it may be worth caching those with
+// the ray", triangle.rs:221-222) — hoisted so that a traversal computes the three divisions once per ray. Same
+// operations, same order: bit-identical to evaluating them per triangle.
+struct RayShear {
+    int kx, ky, kz;
+    V3 d;  // permuted direction
+    Float sx, sy, sz;
+};
+SHM_HD RayShear ray_shear(V3 rd) {
+    RayShear r;
+    r.kz = max_component_index(abs3(rd));
+    r.kx = r.kz + 1;
+    if (r.kx == 3) r.kx = 0;
+    r.ky = r.kx + 1;
+    if (r.ky == 3) r.ky = 0;
+    r.d = permute(rd, r.kx, r.ky, r.kz);
+    r.sx = -r.d.x / r.d.z;
+    r.sy = -r.d.y / r.d.z;
+    r.sz = 1.0f / r.d.z;
+    return r;
+}
+
+// shape/triangle.rs:173-302 with the ray constants precomputed.
+SHM_HD bool intersect_triangle_pre(V3 ro, const RayShear& rs, Float t_max, V3 p0, V3 p1, V3 p2, TriangleIntersection& out) {
     if (length_squared(cross(p2 - p0, p1 - p0)) == 0.0f) return false;
     V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
-    int kz = max_component_index(abs3(rd));
-    int kx = kz + 1;
-    if (kx == 3) kx = 0;
-    int ky = kx + 1;
-    if (ky == 3) ky = 0;
-    V3 d = permute(rd, kx, ky, kz);
-    p0t = permute(p0t, kx, ky, kz);
-    p1t = permute(p1t, kx, ky, kz);
-    p2t = permute(p2t, kx, ky, kz);
-    Float sx = -d.x / d.z;
-    Float sy = -d.y / d.z;
-    Float sz = 1.0f / d.z;
+    p0t = permute(p0t, rs.kx, rs.ky, rs.kz);
+    p1t = permute(p1t, rs.kx, rs.ky, rs.kz);
+    p2t = permute(p2t, rs.kx, rs.ky, rs.kz);
+    const Float sx = rs.sx, sy = rs.sy, sz = rs.sz;
     p0t.x += sx * p0t.z;
     p0t.y += sy * p0t.z;
     p1t.x += sx * p1t.z;
@@ -109,6 +123,9 @@ SHM_HD bool intersect_triangle(V3 ro, V3 rd, Float t_max, V3 p0, V3 p1, V3 p2, T
     if (t <= delta_t) return false;
     out.b0 = b0; out.b1 = b1; out.b2 = b2; out.t = t;
     return true;
+}
+SHM_HD bool intersect_triangle(V3 ro, V3 rd, Float t_max, V3 p0, V3 p1, V3 p2, TriangleIntersection& out) {
+    return intersect_triangle_pre(ro, ray_shear(rd), t_max, p0, p1, p2, out);
 }
 
 // interaction.rs:24-31 + 87-98

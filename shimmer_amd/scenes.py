@@ -281,15 +281,21 @@ def crown_proxy(lib, width=1000, height=1400, level=4, n_glass=64, n_gold=16, se
     return _finish(b, lib, name="S4 crown-proxy")
 
 
-def three_spheres(lib, width=32, height=32, offsets=(-3.5, 0.0, 5.0)):
-    """The reference's set_of_spheres BVH test scene (aggregate.rs:631-702): unit spheres at x = -3.5, 0, 5
-    (world == render space here: the camera sits at the origin)."""
+def three_spheres(lib, width=32, height=32, offsets=(-3.5, 0.0, 5.0), camera=(0.0, 0.0, 0.0)):
+    """The reference's set_of_spheres BVH test scene (aggregate.rs:631-702): unit spheres at x = -3.5, 0, 5.
+    With the default camera at the origin world == render space, as the reference's unit tests assume (rays are given
+    in render space); pass a camera position outside the spheres to render it."""
     b = SceneBuilder()
     b.set_film(width, height)
-    b.set_camera_look_at(lib, (0, 0, 0), (0, 0, -1), (0, 1, 0), 60.0)
+    cam = np.asarray(camera, np.float64)
+    rfw = b.set_camera_look_at(lib, cam, cam + np.array([0.0, 0.0, -1.0]), (0, 1, 0), 60.0)
     m = b.material_diffuse(0.5)
     for x in offsets:
         rfo = np.eye(4, dtype=np.float32)
-        rfo[0, 3] = x
+        rfo[:3, 3] = rfw[:3, 3]
+        rfo[0, 3] += np.float32(x)
         b.add_sphere(1.0, m, render_from_object=rfo)
+    # a uniform environment (UniformInfiniteLight, light.rs:692-816): exercises the escaped-ray branch of
+    # PathIntegrator::li (integrator.rs:776-794)
+    b.light_uniform_infinite(np.ones(471, np.float32), scale=1.0)
     return _finish(b, lib, name="three spheres")

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_gpu.sh output directory (rocprofv3 rocpd .db files): per-kernel time from the kernel-trace
+pass and per-kernel PMC sums from each counter pass.  FETCH_SIZE on gfx950 reports half the bytes of a wide coalesced
+read (MI355X_MICROARCH.md §HBM): raw and x2 figures are both printed; the access pattern here is 16-B gathers, for which
+the guide says the absolute value is uncalibrated, so ratios between variants are what to read."""
+import glob
+import os
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(name):
+    m = re.search(r"k_(trace|shade\w*|generate|film|expand_tiles|next_bounce|reset_head)", name)
+    if not m:
+        return name[:48]
+    k = m.group(0)
+    if k == "k_trace":
+        t = re.search(r"k_trace<(\w+), (\w+)>", name)
+        if t:
+            k += "<any>" if t.group(1) == "true" else "<closest>"
+            k += "+sph" if t.group(2) == "true" else ""
+    return k
+
+
+print(f"# {out}")
+print("== kernel-trace --stats ==")
+for f in glob.glob(os.path.join(out, "stats", "*.db")):
+    cur = sqlite3.connect(f).cursor()
+    for name, calls, total, avg, pct in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+        print(f"{short(name):24s} calls={calls:5d} total_ms={total/1e3:10.3f} avg_us={avg:10.2f} pct={pct:6.2f}")
+    r = cur.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, workgroup_x, grid_x from kernels group by name").fetchall()
+    for name, v, a, s, lds, wg, grid in r:
+        if "k_" in name:
+            print(f"   {short(name):22s} vgpr={v} agpr={a} sgpr={s} lds={lds} wg={wg} grid={grid}")
+print("== PMC (sum over dispatches, per kernel) ==")
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    for f in glob.glob(os.path.join(d, "*.db")):
+        cur = sqlite3.connect(f).cursor()
+        acc = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(set)
+        dur = defaultdict(float)
+        for name, counter, value, disp, duration in cur.execute("select kernel_name, counter_name, value, dispatch_id, duration from counters_collection"):
+            k = short(name)
+            acc[k][counter] += value
+            if disp not in cnt[k]:
+                dur[k] += duration
+            cnt[k].add(disp)
+        for k in sorted(acc):
+            if not k.startswith("k_"):
+                continue
+            for c, v in sorted(acc[k].items()):
+                n = len(cnt[k])
+                extra = ""
+                if c == "FETCH_SIZE":
+                    extra = f"  = {v*1024/1e9:8.3f} GB raw, {2*v*1024/1e9:8.3f} GB x2; {v*1024/n/1e6:8.2f} MB/dispatch raw; {v*1024/(dur[k]):7.1f} GB/s raw over profiled time"
+                elif c == "WRITE_SIZE":
+                    extra = f"  = {v*1024/1e9:8.3f} GB; {v*1024/n/1e6:8.2f} MB/dispatch"
+                print(f"{k:24s} {c:22s} {v:20.1f}  ({n} dispatches, {dur[k]/1e6:9.3f} ms){extra}")
