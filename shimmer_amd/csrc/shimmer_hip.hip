@@ -504,6 +504,231 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace2(SceneView sv, const uint
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2 / K3, third variant: the reference's traversal (aggregate.rs:71-203: test the current node, push the far child
+// untested, enter the near child; pop on a miss or after a leaf) executed as UNIFORM steps, because the profile of the
+// first two variants (profiles/r01_*) shows ~10 of 64 lanes active per VALU instruction: the kernels are issue-bound by
+// divergence, not by HBM (FETCH_SIZE is 3-6x below the algorithmic bytes).
+//  * every loop iteration is one identical step for every lane that has a node to test: [pop if requested] -> fetch the
+//    32-B record -> slab test -> push far / enter near, or mark the leaf pending, or request a pop.  No nested loops;
+//  * leaf (triangle) tests are POSTPONED: a lane that reached a leaf waits until at least `leaf_min` lanes of its wave
+//    have a pending leaf (or no lane can take a node step), then the watertight test runs for all of them at once;
+//  * finished lanes are refilled from the queue (one wave-aggregated atomic) once `refill_min` lanes are idle;
+//  * stack levels [LOW, LOW + LDS_N) live in LDS as [level][lane]; the few bottom levels (pushed once near the root,
+//    popped once at the very end) and any level above the LDS window go to a per-lane HBM region laid out the same way.
+// Node and primitive visit counts equal the reference's in both modes (it is the same algorithm, node for node).
+// ---------------------------------------------------------------------------------------------
+constexpr int K3_LOW = 6;      // stack levels [0, K3_LOW) -> HBM spill
+constexpr int K3_LDS_N = 26;   // stack levels [K3_LOW, K3_LOW + K3_LDS_N) -> LDS (6.5 KiB per wave)
+enum : uint32_t { ST_IDLE = 0, ST_NODE = 1, ST_LEAF = 2, ST_DONE = 3 };
+
+template <bool ANY>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
+                                                       uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
+                                                       ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
+                                                       float4* __restrict__ L, const float4* __restrict__ contrib,
+                                                       DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
+                                                       int refill_min, int leaf_min) {
+    __shared__ uint32_t lds_stack[(TRACE_BLOCK / WAVE) * K3_LDS_N * WAVE];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave_in_block = threadIdx.x / WAVE;
+    uint32_t* const st_lds = lds_stack + wave_in_block * K3_LDS_N * WAVE + lane;
+    uint32_t* const st_spill = spill + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE + lane;
+    const uint32_t n = n_ptr ? *n_ptr : n_direct;
+    const char* __restrict__ node_base = reinterpret_cast<const char*>(sv.nodes);
+    const char* __restrict__ prim_base = reinterpret_cast<const char*>(sv.prim_recs);
+    uint32_t c_nodes = 0, c_prims = 0, c_rays = 0;
+
+    uint32_t state = ST_IDLE;
+    bool exhausted = false;  // wave-uniform
+    uint32_t w_next = 0, w_end = 0;  // wave-uniform private range of the queue
+    // chunk size: large enough that the single head word sees few atomics (it saturates near 88 dequeues/us,
+    // MI355X_MICROARCH.md "dequeue"), small enough that the last chunks balance across the resident waves
+    const uint32_t n_waves = gridDim.x * (TRACE_BLOCK / WAVE);
+    uint32_t chunk = n / (n_waves * 8u);
+    chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
+    chunk = (chunk + 63u) & ~63u;
+    bool want_pop = false;
+    uint32_t path = 0;
+    V3 ro = v3s(0.0f), inv_dir = v3s(0.0f);
+    bool negx = false, negy = false, negz = false;
+    RayShear rs;
+    rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
+    Float t_max = 0.0f;
+    int32_t hit_prim = -1;
+    Float hit_t = 0.0f, hit_b0 = 0.0f, hit_b1 = 0.0f, hit_b2 = 0.0f;
+    int sp = 0;
+    uint32_t cur = 0;
+    uint32_t leaf_off = 0, leaf_n = 0;
+
+    auto stack_slot = [&](int level) -> uint32_t* {
+        int l = level - K3_LOW;
+        if (l >= 0 && l < K3_LDS_N) return st_lds + l * WAVE;
+        return st_spill + (size_t)(level < K3_LOW ? level : level - K3_LDS_N) * WAVE;
+    };
+
+    for (;;) {
+        // ---- refill idle lanes from the wave-private chunk [w_next, w_end); one atomic per `chunk` rays ----
+        unsigned long long idle = __ballot(state == ST_IDLE);
+        if (idle != 0ull) {
+            int n_idle = __popcll(idle);
+            if (!exhausted && (n_idle >= refill_min || idle == ~0ull)) {
+                if (w_next >= w_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(head, chunk);
+                    base = __shfl(base, 0);
+                    w_next = base;
+                    w_end = (base < n) ? ((n - base < chunk) ? n : base + chunk) : base;
+                    if (base >= n) exhausted = true;
+                }
+                if (!exhausted) {
+                    uint32_t take = min((uint32_t)n_idle, w_end - w_next);
+                    if (state == ST_IDLE) {
+                        uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                        if (rank < take) {
+                            uint32_t qi = w_next + rank;
+                            path = queue ? queue[qi] : qi;
+                            const float4* rp = reinterpret_cast<const float4*>(rays + path);
+                            float4 r0 = rp[0], r1 = rp[1];
+                            ro = v3(r0.x, r0.y, r0.z);
+                            V3 rd = v3(r0.w, r1.x, r1.y);
+                            t_max = r1.z;
+                            inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);  // aggregate.rs:76-81
+                            negx = inv_dir.x < 0.0f;
+                            negy = inv_dir.y < 0.0f;
+                            negz = inv_dir.z < 0.0f;
+                            rs = ray_shear(rd);
+                            hit_prim = -1;
+                            sp = 0;
+                            cur = 0;
+                            want_pop = false;
+                            state = ST_NODE;
+                            c_rays++;
+                        }
+                    }
+                    w_next += take;
+                }
+            }
+            if (__ballot(state != ST_IDLE) == 0ull) {
+                if (exhausted) break;
+                continue;  // private chunk was empty: fetch the next one
+            }
+        }
+        // ---- one uniform node step ----
+        if (state == ST_NODE) {
+            bool go = true;
+            if (want_pop) {
+                want_pop = false;
+                if (sp == 0) { state = ST_DONE; go = false; }
+                else { sp--; cur = *stack_slot(sp); }
+            }
+            if (go) {
+                const float4* np = reinterpret_cast<const float4*>(node_base + ((size_t)cur << 5));
+                float4 na = np[0], nb = np[1];
+                c_nodes++;
+                // Bounds3f::intersect_p_cached (bounding_box.rs:520-563), signs held as lane masks
+                const Float g = 1.0f + 2.0f * gamma(3);
+                Float t0 = ((negx ? na.w : na.x) - ro.x) * inv_dir.x;
+                Float t1 = ((negx ? na.x : na.w) - ro.x) * inv_dir.x;
+                Float ty0 = ((negy ? nb.x : na.y) - ro.y) * inv_dir.y;
+                Float ty1 = ((negy ? na.y : nb.x) - ro.y) * inv_dir.y;
+                t1 *= g;
+                ty1 *= g;
+                bool hit_box = !(t0 > ty1 || ty0 > t1);
+                if (ty0 > t0) t0 = ty0;
+                if (ty1 < t1) t1 = ty1;
+                Float tz0 = ((negz ? nb.y : na.z) - ro.z) * inv_dir.z;
+                Float tz1 = ((negz ? na.z : nb.y) - ro.z) * inv_dir.z;
+                tz1 *= g;
+                hit_box = hit_box && !(t0 > tz1 || tz0 > t1);
+                if (tz0 > t0) t0 = tz0;
+                if (tz1 < t1) t1 = tz1;
+                hit_box = hit_box && (t0 < t_max) && (t1 > 0.0f);
+                uint32_t offset = __float_as_uint(nb.z);
+                uint32_t meta = __float_as_uint(nb.w);
+                uint32_t n_prims = meta & 0xffffu;
+                if (!hit_box) {
+                    want_pop = true;
+                } else if (n_prims > 0) {
+                    leaf_off = offset;
+                    leaf_n = n_prims;
+                    state = ST_LEAF;
+                } else {
+                    uint32_t axis = (meta >> 16) & 0xffu;
+                    bool neg = (axis == 0) ? negx : ((axis == 1) ? negy : negz);
+                    uint32_t far_child = neg ? cur + 1 : offset;   // aggregate.rs:119-127
+                    uint32_t near_child = neg ? offset : cur + 1;
+                    *stack_slot(sp) = far_child;
+                    sp++;
+                    cur = near_child;
+                }
+            }
+        }
+        // ---- postponed leaf phase ----
+        unsigned long long leaf_mask = __ballot(state == ST_LEAF);
+        if (leaf_mask != 0ull) {
+            unsigned long long node_mask = __ballot(state == ST_NODE);
+            if (__popcll(leaf_mask) >= leaf_min || node_mask == 0ull) {
+                if (state == ST_LEAF) {
+                    bool found_any = false;
+                    for (uint32_t i = 0; i < leaf_n; ++i) {
+                        uint32_t slot = leaf_off + i;
+                        c_prims++;
+                        const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * 48u);
+                        float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+                        TriangleIntersection ti;
+                        if (intersect_triangle_pre(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti)) {
+                            hit_prim = (int32_t)slot; hit_t = ti.t; hit_b0 = ti.b0; hit_b1 = ti.b1; hit_b2 = ti.b2;
+                            if (ANY) { found_any = true; break; }
+                            t_max = ti.t;  // aggregate.rs:105-109
+                        }
+                    }
+                    if (ANY && found_any) {
+                        state = ST_DONE;
+                    } else {
+                        state = ST_NODE;
+                        want_pop = true;
+                    }
+                }
+            }
+        }
+        // ---- retire finished rays ----
+        if (state == ST_DONE) {
+            if (ANY) {
+                bool occl = hit_prim >= 0;
+                if (occluded_out) occluded_out[path] = occl ? 1 : 0;
+                if (L && !occl) {
+                    float4 l = L[path], c = contrib[path];
+                    l.x += c.x; l.y += c.y; l.z += c.z; l.w += c.w;
+                    L[path] = l;
+                }
+            } else {
+                float4* hp = reinterpret_cast<float4*>(hits + path);
+                hp[0] = make_float4(__int_as_float(hit_prim), hit_t, hit_b0, hit_b1);
+                hp[1] = make_float4(hit_b2, 0.0f, 0.0f, 0.0f);
+            }
+            state = ST_IDLE;
+        }
+    }
+    unsigned long long w_nodes = c_nodes, w_prims = c_prims, w_rays = c_rays;
+    for (int off = 32; off > 0; off >>= 1) {
+        w_nodes += __shfl_down(w_nodes, off);
+        w_prims += __shfl_down(w_prims, off);
+        w_rays += __shfl_down(w_rays, off);
+    }
+    if (lane == 0 && w_rays) {
+        if (ANY) {
+            atomicAdd(&counters->rays_any, w_rays);
+            atomicAdd(&counters->nodes_any, w_nodes);
+            atomicAdd(&counters->tris_any, w_prims);
+        } else {
+            atomicAdd(&counters->rays_closest, w_rays);
+            atomicAdd(&counters->nodes_closest, w_nodes);
+            atomicAdd(&counters->tris_closest, w_prims);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4+K5: one path vertex (integrator.rs:772-892 for the vertex found by K2).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ Spec ld_spec(const float4& f) { Spec s; s.v[0] = f.x; s.v[1] = f.y; s.v[2] = f.z; s.v[3] = f.w; return s; }
@@ -745,6 +970,7 @@ struct ShmScene {
     shm_host::FlatScene flat;
     SceneView dsv;                 // device pointers
     std::vector<void*> allocs;
+    std::vector<void*> ws_allocs;  // path workspace (regrown on demand)
     ShmFilmPixel* d_film = nullptr;
     size_t n_film_pixels = 0;
     // path workspace
@@ -764,7 +990,11 @@ struct ShmScene {
     int stack_entries = 64;
     int trace_blocks = 0;
     // tuned traversal (k_trace2)
-    int trace_kernel = 2;          // 1: reference-shaped kernel (k_trace), 2: k_trace2 (triangle-only scenes)
+    int trace_kernel = 3;          // 1: k_trace (generic, spheres), 2: k_trace2, 3: k_trace3 (triangle-only scenes)
+    int trace3_blocks = 0;
+    int spill3_levels = 1;
+    int leaf_min = 8;
+    uint32_t* d_spill3 = nullptr;
     int trace2_blocks = 0;
     int spill_levels = 1;
     int refill_min = 16;
@@ -793,24 +1023,41 @@ int dev_alloc(ShmScene* s, size_t n, T** out) {
     return SHM_OK;
 }
 
-int ensure_workspace(ShmScene* s) {
-    if (s->capacity) return SHM_OK;
-    uint32_t cap = 1u << 22;  // 4 Mi paths per batch (~1 GB of path state); SHM_BATCH_PATHS overrides
+// Path workspace sized to the work: up to SHM_BATCH_PATHS (default 64 Mi paths = 17 GB of the 288 GB) so that one spp-wave
+// of the 1024^2 frame is ONE batch. Small batches starve the persistent traversal kernels: with ~400 K resident lanes a
+// 1 M-ray launch gives each lane ~3 rays and the launch time is set by the longest ray, not by throughput (profiles/r01_*).
+int ensure_workspace(ShmScene* s, uint64_t needed_paths) {
+    uint64_t max_cap = 1ull << 26;
     if (const char* e = getenv("SHM_BATCH_PATHS")) {
-        long v = atol(e);
-        if (v >= 4096) cap = (uint32_t)v;
+        long long v = atoll(e);
+        if (v >= 4096) max_cap = (uint64_t)v;
     }
-    cap = (cap + 4095u) & ~4095u;
+    uint64_t want = std::min<uint64_t>(std::max<uint64_t>(needed_paths, 4096), max_cap);
+    want = (want + 4095ull) & ~4095ull;
+    if (want > 0xfffff000ull) want = 0xfffff000ull;
+    if (s->capacity >= want) return SHM_OK;
+    for (void* p : s->ws_allocs) hipFree(p);
+    s->ws_allocs.clear();
+    s->capacity = 0;
+    uint32_t cap = (uint32_t)want;
+    auto ws_alloc = [&](size_t bytes, void** out) -> int {
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess) { g_err = "hipMalloc of the path workspace failed"; return SHM_ERR_OUT_OF_MEMORY; }
+        s->ws_allocs.push_back(d);
+        *out = d;
+        return SHM_OK;
+    };
     int rc;
-#define WS(field, type) if ((rc = dev_alloc<type>(s, cap, &s->pa.field)) != SHM_OK) return rc
+#define WS(field, type) if ((rc = ws_alloc((size_t)cap * sizeof(type), (void**)&s->pa.field)) != SHM_OK) return rc
     WS(ray, ShmRay); WS(hit, ShmHit); WS(shadow_ray, ShmRay); WS(shadow_contrib, float4); WS(L, float4); WS(beta, float4);
     WS(lambda, float4); WS(lambda_pdf, float4); WS(ctx0, float4); WS(ctx1, float4); WS(ctx2, float4); WS(pb_eta, float2);
     WS(rng, uint2); WS(pixel, uint32_t); WS(flags, uint32_t);
 #undef WS
-    if ((rc = dev_alloc<uint32_t>(s, cap, &s->d_q_active[0])) != SHM_OK) return rc;
-    if ((rc = dev_alloc<uint32_t>(s, cap, &s->d_q_active[1])) != SHM_OK) return rc;
-    if ((rc = dev_alloc<uint32_t>(s, cap, &s->d_q_shadow)) != SHM_OK) return rc;
+    if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_active[0])) != SHM_OK) return rc;
+    if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_active[1])) != SHM_OK) return rc;
+    if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_shadow)) != SHM_OK) return rc;
     s->capacity = cap;
+    DBG("workspace: %u paths (%.2f GB)", cap, (double)cap * 276.0 / 1e9);
     return SHM_OK;
 }
 
@@ -819,6 +1066,11 @@ size_t trace_lds_bytes(const ShmScene* s) { return (size_t)(TRACE_BLOCK / WAVE) 
 template <bool ANY>
 void launch_trace(ShmScene* s, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, uint32_t* head, const ShmRay* rays,
                   ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib) {
+    if (!s->flat.has_spheres && s->trace_kernel == 3) {
+        hipLaunchKernelGGL((k_trace3<ANY>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, head, rays, hits,
+                           occluded, L, contrib, s->d_counters, s->d_spill3, s->spill3_levels, s->refill_min, s->leaf_min);
+        return;
+    }
     if (!s->flat.has_spheres && s->trace_kernel == 2) {
         hipLaunchKernelGGL((k_trace2<ANY>), dim3(s->trace2_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, head, rays, hits,
                            occluded, L, contrib, s->d_counters, s->d_spill, s->spill_levels, s->refill_min);
@@ -863,6 +1115,7 @@ void shm_scene_destroy(ShmScene* s) {
     if (!s) return;
     hipSetDevice(s->device);
     for (void* p : s->allocs) hipFree(p);
+    for (void* p : s->ws_allocs) hipFree(p);
     for (hipEvent_t e : s->events) hipEventDestroy(e);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
@@ -929,7 +1182,15 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_TRACE_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) per_cu = v2; }
     s->trace_blocks = s->n_cu * per_cu;
     // k_trace2: 16 KiB of LDS per workgroup -> 8 workgroups (32 waves) per CU; deeper stack levels spill to HBM
-    if (const char* e = getenv("SHM_TRACE_KERNEL")) { int v2 = atoi(e); if (v2 == 1 || v2 == 2) s->trace_kernel = v2; }
+    if (const char* e = getenv("SHM_TRACE_KERNEL")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 3) s->trace_kernel = v2; }
+    {
+        int per_cu3 = 6;  // 26 KiB of LDS per workgroup
+        if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 6) per_cu3 = v2; }
+        if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
+        s->trace3_blocks = s->n_cu * per_cu3;
+        s->spill3_levels = K3_LOW + std::max(0, (int)f.max_leaf_depth + 1 - K3_LOW - K3_LDS_N) + 1;
+        if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3)) != SHM_OK) return fail(rc);
+    }
     int per_cu2 = 8;
     if (const char* e = getenv("SHM_TRACE2_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) per_cu2 = v2; }
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = v2; }
@@ -971,8 +1232,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     if (params->force_diffuse) { g_err = "force_diffuse is not supported"; return SHM_ERR_UNSUPPORTED; }
     if (params->max_depth < 0 || params->max_depth > 254) { g_err = "max_depth out of range"; return SHM_ERR_INVALID_ARGUMENT; }
     HIP_TRY(hipSetDevice(s->device));
-    int rc = ensure_workspace(s);
-    if (rc != SHM_OK) return rc;
+    int rc;
     const int32_t* pb = s->flat.film.pixel_bounds;
     // pixel list for these tiles
     std::vector<uint32_t> tile_offset(n_tiles);
@@ -1003,6 +1263,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     hipLaunchKernelGGL(k_expand_tiles, dim3((n_tiles + 255) / 256), dim3(256), 0, s->stream, s->d_tiles, s->d_tile_offset, n_tiles, s->d_pixels);
 
     const int n_samples = sample_end - sample_begin;
+    if ((rc = ensure_workspace(s, n_pixels * (uint64_t)n_samples)) != SHM_OK) return rc;
     uint32_t pix_per_batch = s->capacity / (uint32_t)n_samples;
     if (pix_per_batch == 0) { g_err = "spp-wave larger than the path workspace"; return SHM_ERR_INVALID_ARGUMENT; }
     if (pix_per_batch > 64) pix_per_batch &= ~63u;  // whole 8x8 tiles per wavefront
