@@ -27,6 +27,19 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(args):
+    """HBM traffic of the K2 kernel per launch from the committed rocprofv3 PMC passes of THIS configuration
+    (tools/profile_gpu.sh -> profiles/*.traffic.json): 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md
+    section HBM) + WRITE_SIZE, in bytes. None when no profile of this configuration is committed."""
+    f = ROOT / "profiles" / f"traffic_res{args.res}_spp{args.spp}_n{args.n}_depth{args.max_depth}.json"
+    if not f.exists():
+        return None
+    t = json.loads(f.read_text()).get("k_trace3<closest>")
+    if not t:
+        return None
+    return 2.0 * t.get("FETCH_SIZE_bytes_per_dispatch_raw", 0.0) + t.get("WRITE_SIZE_bytes_per_dispatch_raw", 0.0)
+
+
 def cpu_baseline(sc, params_full, host_lib, budget_s=15.0):
     """The CPU oracle (kind "port": a C++ restatement of the reference loop, oracle/oracle.cpp) timed on this box's host
     cores on a bounded sample of the same workload: a centred crop of the frame at a reduced spp."""
@@ -167,7 +180,7 @@ def main():
                        "rays_per_step": rays / args.steps, "paths_per_step": tot["paths"] / args.steps,
                        "film_gather": "RCCL gather to rank 0 (inside the timed region)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_trace<closest> (BvhAggregate::intersect)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args) if world == 1 else None,
                          "bytes_per_launch": bytes_alg / launches, "avg_launch_ms": ms / launches, "launches": launches,
                          "nodes_per_ray": acc["nodes_closest"] / max(1, acc["rays_closest"]),
                          "prims_per_ray": acc["tris_closest"] / max(1, acc["rays_closest"]),

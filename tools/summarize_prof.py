@@ -14,12 +14,12 @@ out = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"k_(trace|shade\w*|generate|film|expand_tiles|next_bounce|reset_head)", name)
+    m = re.search(r"k_(trace\d?|shade\w*|generate|film|expand_tiles|next_bounce|reset_head)", name)
     if not m:
         return name[:48]
     k = m.group(0)
-    if k == "k_trace":
-        t = re.search(r"k_trace<(\w+), (\w+)>", name)
+    if k.startswith("k_trace"):
+        t = re.search(r"k_trace\d?<(\w+)(?:, (\w+))?>", name)
         if t:
             k += "<any>" if t.group(1) == "true" else "<closest>"
             k += "+sph" if t.group(2) == "true" else ""
@@ -36,6 +36,7 @@ for f in glob.glob(os.path.join(out, "stats", "*.db")):
     for name, v, a, s, lds, wg, grid in r:
         if "k_" in name:
             print(f"   {short(name):22s} vgpr={v} agpr={a} sgpr={s} lds={lds} wg={wg} grid={grid}")
+traffic = {}
 print("== PMC (sum over dispatches, per kernel) ==")
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     for f in glob.glob(os.path.join(d, "*.db")):
@@ -60,3 +61,8 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
                 elif c == "WRITE_SIZE":
                     extra = f"  = {v*1024/1e9:8.3f} GB; {v*1024/n/1e6:8.2f} MB/dispatch"
                 print(f"{k:24s} {c:22s} {v:20.1f}  ({n} dispatches, {dur[k]/1e6:9.3f} ms){extra}")
+                if c in ("FETCH_SIZE", "WRITE_SIZE"):
+                    traffic.setdefault(k, {})[c + "_bytes_per_dispatch_raw"] = v * 1024 / n
+                    traffic[k]["dispatches"] = n
+import json
+json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
