@@ -131,7 +131,7 @@ def main():
 
     def step():
         r.clear()
-        st = r.render_waves(params, my_tiles)
+        st = r.render_device(params, my_tiles)
         film = None
         if world > 1:
             film = render.gather_film(render.film_tensor(r, device), rank, world, r.height, r.width)

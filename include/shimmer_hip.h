@@ -264,7 +264,12 @@ SHM_API int shm_film_read(ShmScene* scene, ShmFilmPixel* film_out);
 /* Device pointer + byte size of the film (for device-side gathers, e.g. RCCL through torch). */
 SHM_API int shm_film_device_ptr(ShmScene* scene, void** ptr_out, uint64_t* bytes_out);
 
-/* Whole ImageTileIntegrator::render (integrator.rs:226-322): all waves 1,1,2,4,...,64,64,... over the
+/* Whole ImageTileIntegrator::render (integrator.rs:226-322) into the DEVICE film (+=, no clear, no read-back): all
+ * spp-waves over the given tiles. Consecutive waves of the reference's schedule are fused into launches of up to 64 spp
+ * (identical film sums: a pixel's samples are always added in increasing sample_index). */
+SHM_API int shm_render_device(ShmScene* scene, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles,
+                              ShmStats* stats);
+/* The same with clear + read-back: whole ImageTileIntegrator::render (integrator.rs:226-322): all waves 1,1,2,4,...,64,64,... over the
  * given tiles; `film` += on the host. */
 SHM_API int shm_render(ShmScene* scene, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles,
                ShmFilmPixel* film, ShmStats* stats);

@@ -124,6 +124,7 @@ EXPORTS = {
                                   C.POINTER(ShmStats)]),
     "shm_film_read": (C.c_int, [C.c_void_p, C.c_void_p]),
     "shm_film_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "shm_render_device": (C.c_int, [C.c_void_p, C.POINTER(ShmRenderParams), C.POINTER(ShmTile), C.c_uint32, C.POINTER(ShmStats)]),
     "shm_render": (C.c_int, [C.c_void_p, C.POINTER(ShmRenderParams), C.POINTER(ShmTile), C.c_uint32, C.c_void_p, C.POINTER(ShmStats)]),
     "shm_trace_closest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(ShmStats)]),
     "shm_trace_any": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(ShmStats)]),

@@ -734,14 +734,20 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
 __device__ __forceinline__ Spec ld_spec(const float4& f) { Spec s; s.v[0] = f.x; s.v[1] = f.y; s.v[2] = f.z; s.v[3] = f.w; return s; }
 __device__ __forceinline__ float4 st_spec(const Spec& s) { return make_float4(s.v[0], s.v[1], s.v[2], s.v[3]); }
 
-__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
+constexpr int SHADE2_BLOCK = 256;
+constexpr int SHADE_CHUNK = 2048;  // queue entries per workgroup chunk: ONE global atomic per queue per chunk (a single
+                                   // counter word saturates near 88 atomics/us: MI355X_MICROARCH.md "dequeue")
+__global__ void __launch_bounds__(SHADE2_BLOCK) k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters) {
     const uint32_t n = qs->n_active[cur];
-    const uint32_t stride = gridDim.x * blockDim.x;
-    // Uniform trip count per wave so that the wave-aggregated pushes see all lanes.
-    const uint32_t n_round = (n + WAVE - 1) / WAVE * WAVE;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
+    __shared__ uint32_t s_cnt[2], s_base[2];
+    for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
+      if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+      __syncthreads();
+      for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+        const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
         bool active = i < n;
         bool push_next = false, push_shadow = false;
         uint32_t path = 0;
@@ -911,10 +917,21 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(SceneView sv, PathArrays 
                 pa.lambda_pdf[path] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
             }
         }
-        uint32_t s1 = queue_push_slot(&qs->n_active[cur ^ 1], push_next);
-        if (push_next) q_next[s1] = path;
-        uint32_t s2 = queue_push_slot(&qs->n_shadow, push_shadow);
-        if (push_shadow) q_shadow[s2] = path;
+        // stage the queue entries of this chunk in LDS (wave-aggregated LDS atomics)
+        uint32_t s1 = queue_push_slot(&s_cnt[0], push_next);
+        if (push_next) s_next[s1] = path;
+        uint32_t s2 = queue_push_slot(&s_cnt[1], push_shadow);
+        if (push_shadow) s_shadow[s2] = path;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+          s_base[0] = s_cnt[0] ? atomicAdd(&qs->n_active[cur ^ 1], s_cnt[0]) : 0u;
+          s_base[1] = s_cnt[1] ? atomicAdd(&qs->n_shadow, s_cnt[1]) : 0u;
+      }
+      __syncthreads();
+      for (uint32_t j = threadIdx.x; j < s_cnt[0]; j += SHADE2_BLOCK) q_next[s_base[0] + j] = s_next[j];
+      for (uint32_t j = threadIdx.x; j < s_cnt[1]; j += SHADE2_BLOCK) q_shadow[s_base[1] + j] = s_shadow[j];
+      __syncthreads();
     }
     (void)counters;
 }
@@ -1271,7 +1288,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     hipEvent_t e_begin = ev.get(), e_end = ev.get();
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_any;
     HIP_TRY(hipEventRecord(e_begin, s->stream));
-    const int shade_blocks = s->n_cu * 8;
+    const int shade_blocks = s->n_cu * 4;
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += pix_per_batch) {
         uint32_t n_pix = (uint32_t)std::min<uint64_t>(pix_per_batch, n_pixels - p0);
         uint32_t total = n_pix * (uint32_t)n_samples;
@@ -1285,7 +1302,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
             launch_trace<false>(s, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, &s->d_qs->head_closest, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr);
             hipEventRecord(b, s->stream);
             ev_closest.push_back({a, b});
-            hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur], s->d_q_active[cur ^ 1],
+            hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur], s->d_q_active[cur ^ 1],
                                s->d_q_shadow, s->d_qs, cur, *params, s->d_counters);
             if (bounce < params->max_depth) {
                 hipEvent_t c = ev.get(), d = ev.get();
@@ -1330,21 +1347,41 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     return SHM_OK;
 }
 
+int shm_render_device(ShmScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles, ShmStats* stats) {
+    if (!s || !params) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    // ImageTileIntegrator::render's wave schedule (integrator.rs:231-233, 306-308: 1,1,2,4,...,64,64,...). The waves only
+    // exist there to show progress / write intermediate images (TODO at :311); a pixel's samples are added to the film in
+    // increasing sample_index whatever the grouping, so consecutive waves are fused into launches of up to 64 spp (the
+    // reference's own maximum wave size) without changing a single film sum. SHM_FUSE_WAVES=0 keeps one launch per wave.
+    bool fuse = true;
+    if (const char* e = getenv("SHM_FUSE_WAVES")) fuse = atoi(e) != 0;
+    int spp = params->samples_per_pixel;
+    int wave_start = 0, wave_end = 1, next_wave_size = 1;
+    int pend_begin = 0, pend_end = 0;
+    while (wave_start < spp) {
+        if (pend_end == pend_begin) pend_begin = wave_start;
+        pend_end = wave_end;
+        int nws = wave_end;  // advance the reference's schedule
+        wave_start = wave_end;
+        wave_end = std::min(spp, nws + next_wave_size);
+        next_wave_size = std::min(2 * next_wave_size, 64);
+        bool flush = !fuse || wave_start >= spp || (wave_end - pend_begin) > 64;
+        if (flush) {
+            int rc = shm_render_wave(s, params, tiles, n_tiles, pend_begin, pend_end, stats);
+            if (rc != SHM_OK) return rc;
+            pend_begin = pend_end;
+        }
+    }
+    return SHM_OK;
+}
+
 int shm_render(ShmScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles, ShmFilmPixel* film, ShmStats* stats) {
     if (!s || !params || !film) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
     if (stats) memset(stats, 0, sizeof(*stats));
     int rc = shm_film_clear(s);
     if (rc != SHM_OK) return rc;
-    // integrator.rs:231-233, 306-308
-    int spp = params->samples_per_pixel;
-    int wave_start = 0, wave_end = 1, next_wave_size = 1;
-    while (wave_start < spp) {
-        rc = shm_render_wave(s, params, tiles, n_tiles, wave_start, wave_end, stats);
-        if (rc != SHM_OK) return rc;
-        wave_start = wave_end;
-        wave_end = std::min(spp, wave_end + next_wave_size);
-        next_wave_size = std::min(2 * next_wave_size, 64);
-    }
+    rc = shm_render_device(s, params, tiles, n_tiles, stats);
+    if (rc != SHM_OK) return rc;
     std::vector<ShmFilmPixel> tmp(s->n_film_pixels);
     rc = shm_film_read(s, tmp.data());
     if (rc != SHM_OK) return rc;

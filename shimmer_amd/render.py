@@ -78,6 +78,14 @@ class Renderer:
             abi.check(self.lib, self.lib.shm_render_wave(self.handle, C.byref(params), tiles, n, ws, we, C.byref(stats)), "shm_render_wave")
         return stats.as_dict()
 
+    def render_device(self, params, tile_indices=None):
+        """Whole render (all spp-waves, fused into <= 64-spp launches) into the device film; returns the stats dict."""
+        tiles, n = self._tile_subset(tile_indices)
+        stats = abi.ShmStats()
+        if n:
+            abi.check(self.lib, self.lib.shm_render_device(self.handle, C.byref(params), tiles, n, C.byref(stats)), "shm_render_device")
+        return stats.as_dict()
+
     def read_film(self):
         film = np.zeros((self.height, self.width), dtype=FILM_DTYPE)
         abi.check(self.lib, self.lib.shm_film_read(self.handle, film.ctypes.data_as(C.c_void_p)), "shm_film_read")

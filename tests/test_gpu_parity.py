@@ -168,6 +168,9 @@ def test_render_decomposition_invariance(env, monkeypatch):
         gpu.render_waves(p, tile_indices=idx[idx % 3 != 0], waves=[(ws, we)])
         gpu.render_waves(p, tile_indices=idx[idx % 3 == 0], waves=[(ws, we)])
     assert np.array_equal(gpu.read_film(), f1)
+    gpu.clear()
+    gpu.render_device(p)  # shm_render_device fuses the 1,1,2,4,4-sample waves into one launch: same film
+    assert np.array_equal(gpu.read_film(), f1)
     gpu.close()
     monkeypatch.setenv("SHM_BATCH_PATHS", "8192")  # forces many small batches per wave
     gpu_small = render.Renderer(lib, sc.desc, 0)
