@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL init + film gather path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,7 +111,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     t0 = time.perf_counter()
@@ -125,7 +129,7 @@ def main():
     my_tiles = None if world == 1 else render.shard_tiles(r.n_tiles, r.tiles_per_row, rank, world)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -133,7 +137,7 @@ def main():
         r.clear()
         st = r.render_device(params, my_tiles)
         film = None
-        if world > 1:
+        if use_dist:
             film = render.gather_film(render.film_tensor(r, device), rank, world, r.height, r.width)
         return st, film
 
@@ -148,7 +152,7 @@ def main():
             acc[k] = acc.get(k, 0) + v
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -176,7 +180,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S3 ganesha-proxy ({sc.info['n_primitives']} prims, {sc.info['n_nodes']} BVH nodes), "
                                    f"{args.res}x{args.res}, {args.spp} spp, maxdepth {args.max_depth}, path integrator",
-                       "tiles": "8x8, sharded across ranks in 16-tile-row blocks" if world > 1 else "8x8",
+                       "tiles": "8x8, sharded across ranks in interleaved blocks of tile rows (~8 blocks per rank)" if world > 1 else "8x8",
                        "rays_per_step": rays / args.steps, "paths_per_step": tot["paths"] / args.steps,
                        "film_gather": "RCCL gather to rank 0 (inside the timed region)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_trace<closest> (BvhAggregate::intersect)", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -194,8 +198,12 @@ def main():
             except Exception as e:  # the baseline is reporting only; never let it hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
+    if use_dist and rank == 0 and film is not None:
+        # the gathered film must equal what this rank's library holds when it is the only rank (self-check of the gather)
+        if world == 1 and not np.array_equal(film, r.read_film()):
+            raise SystemExit("film gather mismatch")
     r.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

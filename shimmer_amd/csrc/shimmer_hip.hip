@@ -295,219 +295,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace(SceneView sv, const uint3
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2 / K3, tuned variant for triangle-only scenes (every BASELINE bench scene).  Same results and the same
-// order of leaf tests as aggregate.rs:71-203, restructured for gfx950:
-//  * both children of an interior node are fetched together (4 independent 16-B loads in flight per lane) and
-//    their boxes tested at the parent; the near child is entered with its record already in registers; a far
-//    child is pushed only if its box is hit (it is re-tested with the then-current t_max when popped, which is the
-//    reference's test; a box that misses now can only miss later because t_max never grows);
-//  * persistent waves with per-lane replacement: a lane whose ray has finished pulls the next queue entry, so the
-//    64 lanes stay busy despite the very uneven node counts per ray;
-//  * "while-while" structure: lanes walk interior nodes until each has reached a leaf, then the triangle tests
-//    (the ALU-heavy part) run with the wave converged;
-//  * the ray-only part of the watertight test (permutation, shear: three IEEE divisions) is hoisted per ray;
-//  * node stack: levels [0, LDS_LEVELS) in LDS as [level][lane]; deeper levels (rare: only hit far children are
-//    pushed) spill to a per-lane HBM region laid out the same way.  4 KiB of LDS per wave -> 32 waves per CU.
-// Node visits are counted exactly as the reference makes them in closest-hit mode (root + two per processed interior
-// node); in any-hit mode far children are counted when tested, which can exceed the reference's count (it stops early).
-// ---------------------------------------------------------------------------------------------
-constexpr int LDS_LEVELS = 16;
-constexpr uint32_t NODE_NONE = 0xffffffffu;
-
-template <bool ANY>
-__global__ void __launch_bounds__(TRACE_BLOCK) k_trace2(SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
-                                                       uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
-                                                       ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
-                                                       float4* __restrict__ L, const float4* __restrict__ contrib,
-                                                       DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
-                                                       int refill_min) {
-    __shared__ uint32_t lds_stack[(TRACE_BLOCK / WAVE) * LDS_LEVELS * WAVE];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wave_in_block = threadIdx.x / WAVE;
-    uint32_t* const st_lds = lds_stack + wave_in_block * LDS_LEVELS * WAVE + lane;
-    uint32_t* const st_spill = spill + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE + lane;
-    const uint32_t n = n_ptr ? *n_ptr : n_direct;
-    const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sv.nodes);
-    unsigned long long c_nodes = 0, c_prims = 0, c_rays = 0;
-
-    bool has_ray = false;
-    bool exhausted = false;  // wave-uniform
-    uint32_t path = 0;
-    V3 ro = v3s(0.0f), inv_dir = v3s(0.0f);
-    RayShear rs;
-    rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
-    uint32_t neg_bits = 0;
-    Float t_max = 0.0f;
-    Hit hit;
-    hit.prim = -1; hit.t = 0.0f; hit.b0 = hit.b1 = hit.b2 = hit.phi = 0.0f;
-    int sp = 0;
-    uint32_t cur = NODE_NONE;
-    bool need_load = false;
-    float4 na = make_float4(0, 0, 0, 0), nb = na;
-
-    auto stack_push = [&](uint32_t v) {
-        if (sp < LDS_LEVELS) st_lds[sp * WAVE] = v;
-        else st_spill[(size_t)(sp - LDS_LEVELS) * WAVE] = v;
-        sp++;
-    };
-    auto stack_pop = [&]() -> uint32_t {
-        if (sp == 0) return NODE_NONE;
-        sp--;
-        return (sp < LDS_LEVELS) ? st_lds[sp * WAVE] : st_spill[(size_t)(sp - LDS_LEVELS) * WAVE];
-    };
-    auto box_hit = [&](const float4& a, const float4& b) -> bool {
-        Float bmin[3] = {a.x, a.y, a.z};
-        Float bmax[3] = {a.w, b.x, b.y};
-        int dn[3] = {(int)(neg_bits & 1u), (int)((neg_bits >> 1) & 1u), (int)((neg_bits >> 2) & 1u)};
-        return intersect_p_cached(bmin, bmax, ro, t_max, inv_dir, dn);
-    };
-
-    for (;;) {
-        // ---- per-lane replacement of finished rays ----
-        unsigned long long idle = __ballot(!has_ray);
-        if (idle != 0ull) {
-            int n_idle = __popcll(idle);
-            if (!exhausted && (n_idle >= refill_min || idle == ~0ull)) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(head, (uint32_t)n_idle);
-                base = __shfl(base, 0);
-                if (!has_ray) {
-                    uint32_t qi = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                    if (qi < n) {
-                        path = queue ? queue[qi] : qi;
-                        const float4* rp = reinterpret_cast<const float4*>(rays + path);
-                        float4 r0 = rp[0], r1 = rp[1];
-                        ro = v3(r0.x, r0.y, r0.z);
-                        V3 rd = v3(r0.w, r1.x, r1.y);
-                        t_max = r1.z;
-                        inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);  // aggregate.rs:76-81
-                        neg_bits = (inv_dir.x < 0.0f ? 1u : 0u) | (inv_dir.y < 0.0f ? 2u : 0u) | (inv_dir.z < 0.0f ? 4u : 0u);
-                        rs = ray_shear(rd);
-                        hit.prim = -1;
-                        sp = 0;
-                        cur = 0;
-                        need_load = true;
-                        has_ray = true;
-                        c_rays++;
-                        c_nodes++;  // the root is visited
-                    }
-                }
-                if (base + (uint32_t)n_idle >= n) exhausted = true;
-            }
-            if (__ballot(has_ray) == 0ull) break;
-        }
-        // ---- interior-node phase: run until this lane has a leaf to test or has emptied its stack ----
-        uint32_t leaf_off = 0, leaf_n = 0;
-        while (has_ray && cur != NODE_NONE) {
-            if (need_load) {  // popped (or root) node: fetch its record and apply the reference's box test with the current t_max
-                na = nodes4[2 * (size_t)cur];
-                nb = nodes4[2 * (size_t)cur + 1];
-                need_load = false;
-                if (!box_hit(na, nb)) {
-                    cur = stack_pop();
-                    need_load = true;
-                    continue;
-                }
-            }
-            uint32_t offset = __float_as_uint(nb.z);
-            uint32_t meta = __float_as_uint(nb.w);
-            uint32_t n_prims = meta & 0xffffu;
-            if (n_prims > 0) {
-                leaf_off = offset;
-                leaf_n = n_prims;
-                break;
-            }
-            uint32_t axis = (meta >> 16) & 0xffu;
-            uint32_t c0 = cur + 1, c1 = offset;
-            float4 a0 = nodes4[2 * (size_t)c0], b0 = nodes4[2 * (size_t)c0 + 1];
-            float4 a1 = nodes4[2 * (size_t)c1], b1 = nodes4[2 * (size_t)c1 + 1];
-            c_nodes += 2;
-            bool h0 = box_hit(a0, b0);
-            bool h1 = box_hit(a1, b1);
-            bool near_is_1 = ((neg_bits >> axis) & 1u) != 0;  // aggregate.rs:119-127
-            bool h_near = near_is_1 ? h1 : h0;
-            bool h_far = near_is_1 ? h0 : h1;
-            uint32_t c_near = near_is_1 ? c1 : c0;
-            uint32_t c_far = near_is_1 ? c0 : c1;
-            if (h_near) {
-                if (h_far) stack_push(c_far);
-                cur = c_near;
-                na = near_is_1 ? a1 : a0;
-                nb = near_is_1 ? b1 : b0;
-            } else if (h_far) {
-                cur = c_far;
-                na = near_is_1 ? a0 : a1;
-                nb = near_is_1 ? b0 : b1;
-            } else {
-                cur = stack_pop();
-                need_load = true;
-            }
-        }
-        // ---- leaf phase (wave reconverged) ----
-        bool done = has_ray && cur == NODE_NONE;
-        if (has_ray && leaf_n) {
-            bool found_any = false;
-            for (uint32_t i = 0; i < leaf_n; ++i) {
-                uint32_t slot = leaf_off + i;
-                c_prims++;
-                const float4* pr = reinterpret_cast<const float4*>(sv.prim_recs + slot);
-                float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
-                TriangleIntersection ti;
-                if (intersect_triangle_pre(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti)) {
-                    hit.prim = (int32_t)slot; hit.t = ti.t; hit.b0 = ti.b0; hit.b1 = ti.b1; hit.b2 = ti.b2;
-                    if (ANY) { found_any = true; break; }
-                    t_max = ti.t;  // aggregate.rs:105-109
-                }
-            }
-            if (ANY && found_any) {
-                done = true;
-            } else {
-                cur = stack_pop();
-                need_load = true;
-                done = (cur == NODE_NONE);
-            }
-        }
-        if (done) {
-            if (ANY) {
-                bool occl = hit.prim >= 0;
-                if (occluded_out) occluded_out[path] = occl ? 1 : 0;
-                if (L && !occl) {
-                    float4 l = L[path], c = contrib[path];
-                    l.x += c.x; l.y += c.y; l.z += c.z; l.w += c.w;
-                    L[path] = l;
-                }
-            } else {
-                float4* hp = reinterpret_cast<float4*>(hits + path);
-                hp[0] = make_float4(__int_as_float(hit.prim), hit.t, hit.b0, hit.b1);
-                hp[1] = make_float4(hit.b2, 0.0f, 0.0f, 0.0f);
-            }
-            has_ray = false;
-            cur = NODE_NONE;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        c_nodes += __shfl_down(c_nodes, off);
-        c_prims += __shfl_down(c_prims, off);
-        c_rays += __shfl_down(c_rays, off);
-    }
-    if (lane == 0 && c_rays) {
-        if (ANY) {
-            atomicAdd(&counters->rays_any, c_rays);
-            atomicAdd(&counters->nodes_any, c_nodes);
-            atomicAdd(&counters->tris_any, c_prims);
-        } else {
-            atomicAdd(&counters->rays_closest, c_rays);
-            atomicAdd(&counters->nodes_closest, c_nodes);
-            atomicAdd(&counters->tris_closest, c_prims);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K2 / K3, third variant: the reference's traversal (aggregate.rs:71-203: test the current node, push the far child
+// K2 / K3, tuned variant for triangle-only scenes: the reference's traversal (aggregate.rs:71-203: test the current node, push the far child
 // untested, enter the near child; pop on a miss or after a leaf) executed as UNIFORM steps, because the profile of the
 // first two variants (profiles/r01_*) shows ~10 of 64 lanes active per VALU instruction: the kernels are issue-bound by
-// divergence, not by HBM (FETCH_SIZE is 3-6x below the algorithmic bytes).
+// divergence, not by HBM (FETCH_SIZE is 3-6x below the algorithmic bytes).  (A variant that fetched and tested both
+// children at the parent was measured and dropped: same results, more loads, no gain — DESIGN.md §6.)
 //  * every loop iteration is one identical step for every lane that has a node to test: [pop if requested] -> fetch the
 //    32-B record -> slab test -> push far / enter near, or mark the leaf pending, or request a pop.  No nested loops;
 //  * leaf (triangle) tests are POSTPONED: a lane that reached a leaf waits until at least `leaf_min` lanes of its wave
@@ -1006,16 +798,13 @@ struct ShmScene {
     int n_cu = 256;
     int stack_entries = 64;
     int trace_blocks = 0;
-    // tuned traversal (k_trace2)
-    int trace_kernel = 3;          // 1: k_trace (generic, spheres), 2: k_trace2, 3: k_trace3 (triangle-only scenes)
+    // tuned traversal (k_trace3)
+    int trace_kernel = 3;          // 1: k_trace (generic: spheres), 3: k_trace3 (triangle-only scenes)
     int trace3_blocks = 0;
     int spill3_levels = 1;
     int leaf_min = 8;
     uint32_t* d_spill3 = nullptr;
-    int trace2_blocks = 0;
-    int spill_levels = 1;
     int refill_min = 16;
-    uint32_t* d_spill = nullptr;
     std::vector<hipEvent_t> events;
 };
 
@@ -1086,11 +875,6 @@ void launch_trace(ShmScene* s, const uint32_t* queue, const uint32_t* n_ptr, uin
     if (!s->flat.has_spheres && s->trace_kernel == 3) {
         hipLaunchKernelGGL((k_trace3<ANY>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, head, rays, hits,
                            occluded, L, contrib, s->d_counters, s->d_spill3, s->spill3_levels, s->refill_min, s->leaf_min);
-        return;
-    }
-    if (!s->flat.has_spheres && s->trace_kernel == 2) {
-        hipLaunchKernelGGL((k_trace2<ANY>), dim3(s->trace2_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, head, rays, hits,
-                           occluded, L, contrib, s->d_counters, s->d_spill, s->spill_levels, s->refill_min);
         return;
     }
     dim3 grid(s->trace_blocks), block(TRACE_BLOCK);
@@ -1198,8 +982,8 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     per_cu = std::max(1, std::min(per_cu, 8));
     if (const char* e = getenv("SHM_TRACE_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) per_cu = v2; }
     s->trace_blocks = s->n_cu * per_cu;
-    // k_trace2: 16 KiB of LDS per workgroup -> 8 workgroups (32 waves) per CU; deeper stack levels spill to HBM
-    if (const char* e = getenv("SHM_TRACE_KERNEL")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 3) s->trace_kernel = v2; }
+    if (const char* e = getenv("SHM_TRACE_KERNEL")) { int v2 = atoi(e); if (v2 == 1 || v2 == 3) s->trace_kernel = v2; }
+    if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = v2; }
     {
         int per_cu3 = 6;  // 26 KiB of LDS per workgroup
         if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 6) per_cu3 = v2; }
@@ -1208,14 +992,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
         s->spill3_levels = K3_LOW + std::max(0, (int)f.max_leaf_depth + 1 - K3_LOW - K3_LDS_N) + 1;
         if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3)) != SHM_OK) return fail(rc);
     }
-    int per_cu2 = 8;
-    if (const char* e = getenv("SHM_TRACE2_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) per_cu2 = v2; }
-    if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = v2; }
-    s->trace2_blocks = s->n_cu * per_cu2;
-    s->spill_levels = std::max(1, (int)f.max_leaf_depth + 1 - LDS_LEVELS);
-    if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace2_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill_levels * WAVE, &s->d_spill)) != SHM_OK) return fail(rc);
-    DBG("scene: %u nodes, depth %u, stack_entries %d, trace_blocks %d, trace2_blocks %d, spill_levels %d", (unsigned)f.nodes.size(), f.max_leaf_depth,
-        s->stack_entries, s->trace_blocks, s->trace2_blocks, s->spill_levels);
+    DBG("scene: %u nodes, depth %u, stack_entries %d, trace_blocks %d, trace3_blocks %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->stack_entries, s->trace_blocks, s->trace3_blocks);
     *out = s;
     return SHM_OK;
 }

@@ -31,8 +31,13 @@ def film_to_rgb(film):
     return out
 
 
-def shard_tiles(n_tiles, tiles_per_row, rank, world_size, rows_per_block=16):
-    """Static interleaved sharding: blocks of `rows_per_block` tile rows, block b -> rank b % world."""
+def shard_tiles(n_tiles, tiles_per_row, rank, world_size, rows_per_block=None):
+    """Static interleaved sharding: blocks of `rows_per_block` tile rows, block b -> rank b % world.
+    Default block height: about 8 blocks per rank, so that expensive image regions (the object) and cheap ones (walls)
+    are spread over all ranks."""
+    if rows_per_block is None:
+        tile_rows = (n_tiles + tiles_per_row - 1) // tiles_per_row
+        rows_per_block = max(1, tile_rows // (world_size * 8))
     idx = np.arange(n_tiles)
     block = (idx // tiles_per_row) // rows_per_block
     return idx[(block % world_size) == rank]
