@@ -55,6 +55,15 @@ struct RayShear {
     V3 d;  // permuted direction
     Float sx, sy, sz;
 };
+// permute((kx, ky, kz)) for the three cyclic cases kz = 0, 1, 2 -> (y,z,x), (z,x,y), (x,y,z): written as selects so
+// that the GPU build uses v_cndmask instead of a branchy index switch (values are identical to V3::operator[]).
+SHM_HD V3 permute_cyclic(V3 p, int kz) {
+    const bool k0 = (kz == 0), k1 = (kz == 1);
+    return v3(k0 ? p.y : (k1 ? p.z : p.x), k0 ? p.z : (k1 ? p.x : p.y), k0 ? p.x : (k1 ? p.y : p.z));
+}
+// max of three values that are |.| results (non-negative or NaN): IEEE maxNum, the semantics of Rust's f32::max that
+// max_component_value uses (math.rs:112-117); the sign-of-zero ambiguity of maxNum cannot arise for |.| inputs.
+SHM_HD Float max_abs3(Float a, Float b, Float c) { return __builtin_fmaxf(a, __builtin_fmaxf(b, c)); }
 SHM_HD RayShear ray_shear(V3 rd) {
     RayShear r;
     r.kz = max_component_index(abs3(rd));
@@ -62,7 +71,7 @@ SHM_HD RayShear ray_shear(V3 rd) {
     if (r.kx == 3) r.kx = 0;
     r.ky = r.kx + 1;
     if (r.ky == 3) r.ky = 0;
-    r.d = permute(rd, r.kx, r.ky, r.kz);
+    r.d = permute_cyclic(rd, r.kz);
     r.sx = -r.d.x / r.d.z;
     r.sy = -r.d.y / r.d.z;
     r.sz = 1.0f / r.d.z;
@@ -73,9 +82,9 @@ SHM_HD RayShear ray_shear(V3 rd) {
 SHM_HD bool intersect_triangle_pre(V3 ro, const RayShear& rs, Float t_max, V3 p0, V3 p1, V3 p2, TriangleIntersection& out) {
     if (length_squared(cross(p2 - p0, p1 - p0)) == 0.0f) return false;
     V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
-    p0t = permute(p0t, rs.kx, rs.ky, rs.kz);
-    p1t = permute(p1t, rs.kx, rs.ky, rs.kz);
-    p2t = permute(p2t, rs.kx, rs.ky, rs.kz);
+    p0t = permute_cyclic(p0t, rs.kz);
+    p1t = permute_cyclic(p1t, rs.kz);
+    p2t = permute_cyclic(p2t, rs.kz);
     const Float sx = rs.sx, sy = rs.sy, sz = rs.sz;
     p0t.x += sx * p0t.z;
     p0t.y += sy * p0t.z;
@@ -111,14 +120,14 @@ SHM_HD bool intersect_triangle_pre(V3 ro, const RayShear& rs, Float t_max, V3 p0
     Float b1 = e1 * inv_det;
     Float b2 = e2 * inv_det;
     Float t = t_scaled * inv_det;
-    Float max_zt = max_component_value(abs3(v3(p0t.z, p1t.z, p2t.z)));
+    Float max_zt = max_abs3(abs(p0t.z), abs(p1t.z), abs(p2t.z));
     Float delta_z = gamma(3) * max_zt;
-    Float max_xt = max_component_value(abs3(v3(p0t.x, p1t.x, p2t.x)));
-    Float max_yt = max_component_value(abs3(v3(p0t.y, p1t.y, p2t.y)));
+    Float max_xt = max_abs3(abs(p0t.x), abs(p1t.x), abs(p2t.x));
+    Float max_yt = max_abs3(abs(p0t.y), abs(p1t.y), abs(p2t.y));
     Float delta_x = gamma(5) * (max_xt + max_zt);
     Float delta_y = gamma(5) * (max_yt + max_zt);
     Float delta_e = 2.0f * (gamma(2) * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
-    Float max_e = max_component_value(abs3(v3(e0, e1, e2)));
+    Float max_e = max_abs3(abs(e0), abs(e1), abs(e2));
     Float delta_t = 3.0f * (gamma(3) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * abs(inv_det);
     if (t <= delta_t) return false;
     out.b0 = b0; out.b1 = b1; out.b2 = b2; out.t = t;
