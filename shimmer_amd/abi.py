@@ -150,6 +150,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    if path is None and os.environ.get("SHM_LIB"):  # development hook: A/B a differently compiled build of the same source
+        path = os.environ["SHM_LIB"]
     p = Path(path) if path else LIB_PATH
     if not p.exists():
         raise ShimmerHipError(f"{p} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -109,16 +109,30 @@ __global__ void k_expand_tiles(const ShmTile* tiles, const uint32_t* tile_offset
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1: camera rays for one batch: slot = s_local * n_pix + p_local.
+// K1: camera rays for one batch. Path slots are ordered [pixel group][sample][pixel in group] with groups of `pix_group`
+// consecutive pixels of the tile-ordered pixel list (pix_group >= n_pix is the plain sample-major order
+// slot = s_local * n_pix + p_local; pix_group = 64 keeps all samples of one 8x8 tile adjacent in the queues, so that a
+// wave's private queue range, and an XCD's queue partition, is a compact image region).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t slot_of(uint32_t p_local, uint32_t s_local, uint32_t n_pix, uint32_t n_samples, uint32_t pix_group) {
+    uint32_t g = p_local / pix_group;
+    uint32_t g0 = g * pix_group;
+    uint32_t pg = min(pix_group, n_pix - g0);
+    return g0 * n_samples + s_local * pg + (p_local - g0);
+}
+
 __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArrays pa, const uint32_t* pixels, uint32_t n_pix,
                                                         int sample_begin, int n_samples, ShmRenderParams params,
-                                                        uint32_t* q_active, QueueState* qs) {
+                                                        uint32_t* q_active, QueueState* qs, uint32_t pix_group) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t total = n_pix * (uint32_t)n_samples;
     if (slot >= total) return;
-    uint32_t p_local = slot % n_pix;
-    uint32_t s_local = slot / n_pix;
+    uint32_t g = slot / (pix_group * (uint32_t)n_samples);
+    uint32_t g0 = g * pix_group;
+    uint32_t pg = min(pix_group, n_pix - g0);
+    uint32_t rem = slot - g0 * (uint32_t)n_samples;
+    uint32_t s_local = rem / pg;
+    uint32_t p_local = g0 + (rem - s_local * pg);
     uint32_t pix = pixels[p_local];
     int px = (int)(pix & 0xffffu), py = (int)(pix >> 16);
     Rng rng = sampler_start_pixel_sample(px, py, sample_begin + (int)s_local, params.seed);
@@ -309,6 +323,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace(SceneView sv, const uint3
 //    popped once at the very end) and any level above the LDS window go to a per-lane HBM region laid out the same way.
 // Node and primitive visit counts equal the reference's in both modes (it is the same algorithm, node for node).
 // ---------------------------------------------------------------------------------------------
+#ifndef K3_CHUNK_MAX
+#define K3_CHUNK_MAX 1024
+#endif
 constexpr int K3_LOW = 6;      // stack levels [0, K3_LOW) -> HBM spill
 constexpr int K3_LDS_N = 26;   // stack levels [K3_LOW, K3_LOW + K3_LDS_N) -> LDS (6.5 KiB per wave)
 enum : uint32_t { ST_IDLE = 0, ST_NODE = 1, ST_LEAF = 2, ST_DONE = 3 };
@@ -319,7 +336,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                                                        ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
                                                        float4* __restrict__ L, const float4* __restrict__ contrib,
                                                        DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
-                                                       int refill_min, int leaf_min) {
+                                                       int refill_min, int leaf_min, int queue_parts) {
     __shared__ uint32_t lds_stack[(TRACE_BLOCK / WAVE) * K3_LDS_N * WAVE];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave_in_block = threadIdx.x / WAVE;
@@ -337,7 +354,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
     // MI355X_MICROARCH.md "dequeue"), small enough that the last chunks balance across the resident waves
     const uint32_t n_waves = gridDim.x * (TRACE_BLOCK / WAVE);
     uint32_t chunk = n / (n_waves * 8u);
-    chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
+    chunk = chunk < 64u ? 64u : (chunk > (uint32_t)K3_CHUNK_MAX ? (uint32_t)K3_CHUNK_MAX : chunk);
     chunk = (chunk + 63u) & ~63u;
     bool want_pop = false;
     uint32_t path = 0;
@@ -352,25 +369,45 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
     uint32_t cur = 0;
     uint32_t leaf_off = 0, leaf_n = 0;
 
-    auto stack_slot = [&](int level) -> uint32_t* {
+    // explicit LDS / HBM branches (a single generic pointer compiles to flat_load/flat_store, which wait on both counters)
+    auto stack_load = [&](int level) -> uint32_t {
         int l = level - K3_LOW;
-        if (l >= 0 && l < K3_LDS_N) return st_lds + l * WAVE;
-        return st_spill + (size_t)(level < K3_LOW ? level : level - K3_LDS_N) * WAVE;
+        if ((unsigned)l < (unsigned)K3_LDS_N) return st_lds[l * WAVE];
+        return st_spill[(size_t)(level < K3_LOW ? level : level - K3_LDS_N) * WAVE];
+    };
+    auto stack_store = [&](int level, uint32_t v) {
+        int l = level - K3_LOW;
+        if ((unsigned)l < (unsigned)K3_LDS_N) st_lds[l * WAVE] = v;
+        else st_spill[(size_t)(level < K3_LOW ? level : level - K3_LDS_N) * WAVE] = v;
     };
 
+    // Queue partitions: the queue is cut into `queue_parts` contiguous ranges, each with its own head word (own 128-B
+    // line). A wave starts in the partition of the XCD it runs on — queue order is image order (pix_group), so one XCD's L2
+    // serves one image region's part of the BVH, and 8 head words see 1/8 of the atomics each (one word saturates near
+    // 88 dequeues/us: MI355X_MICROARCH.md "dequeue") — and moves on to the next partition when its own has run dry.
+    const uint32_t n_parts = (uint32_t)queue_parts;
+    const uint32_t part_size = ((n + n_parts * 64u - 1u) / (n_parts * 64u)) * 64u;
+    uint32_t part = (n_parts > 1u) ? (__builtin_amdgcn_s_getreg(6164 /* HW_REG_XCC_ID, bits [3:0] */) & (n_parts - 1u)) : 0u;
+    uint32_t parts_left = n_parts;
     for (;;) {
         // ---- refill idle lanes from the wave-private chunk [w_next, w_end); one atomic per `chunk` rays ----
         unsigned long long idle = __ballot(state == ST_IDLE);
         if (idle != 0ull) {
             int n_idle = __popcll(idle);
             if (!exhausted && (n_idle >= refill_min || idle == ~0ull)) {
-                if (w_next >= w_end) {
+                while (w_next >= w_end && !exhausted) {
+                    const uint32_t p_begin = part * part_size;
+                    const uint32_t p_end = (p_begin < n) ? ((n - p_begin < part_size) ? n : p_begin + part_size) : p_begin;
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(head, chunk);
+                    if (lane == 0) base = atomicAdd(head + part * 32u, chunk);
                     base = __shfl(base, 0);
-                    w_next = base;
-                    w_end = (base < n) ? ((n - base < chunk) ? n : base + chunk) : base;
-                    if (base >= n) exhausted = true;
+                    if (base < p_end - p_begin) {
+                        w_next = p_begin + base;
+                        w_end = (p_end - w_next < chunk) ? p_end : w_next + chunk;
+                    } else {
+                        part = (part + 1u == n_parts) ? 0u : part + 1u;
+                        if (--parts_left == 0u) exhausted = true;
+                    }
                 }
                 if (!exhausted) {
                     uint32_t take = min((uint32_t)n_idle, w_end - w_next);
@@ -411,7 +448,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
             if (want_pop) {
                 want_pop = false;
                 if (sp == 0) { state = ST_DONE; go = false; }
-                else { sp--; cur = *stack_slot(sp); }
+                else { sp--; cur = stack_load(sp); }
             }
             if (go) {
                 const float4* np = reinterpret_cast<const float4*>(node_base + ((size_t)cur << 5));
@@ -449,7 +486,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                     bool neg = (axis == 0) ? negx : ((axis == 1) ? negy : negz);
                     uint32_t far_child = neg ? cur + 1 : offset;   // aggregate.rs:119-127
                     uint32_t near_child = neg ? offset : cur + 1;
-                    *stack_slot(sp) = far_child;
+                    stack_store(sp, far_child);
                     sp++;
                     cur = near_child;
                 }
@@ -529,7 +566,12 @@ __device__ __forceinline__ float4 st_spec(const Spec& s) { return make_float4(s.
 constexpr int SHADE2_BLOCK = 256;
 constexpr int SHADE_CHUNK = 2048;  // queue entries per workgroup chunk: ONE global atomic per queue per chunk (a single
                                    // counter word saturates near 88 atomics/us: MI355X_MICROARCH.md "dequeue")
-__global__ void __launch_bounds__(SHADE2_BLOCK) k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
+#ifndef K_SHADE_WAVES
+#define K_SHADE_ATTR
+#else
+#define K_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(K_SHADE_WAVES, K_SHADE_WAVES)))
+#endif
+__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters) {
     const uint32_t n = qs->n_active[cur];
@@ -736,13 +778,14 @@ __global__ void k_next_bounce(QueueState* qs, int cur) {
     qs->head_any = 0;
 }
 __global__ void k_reset_head(uint32_t* head) { *head = 0; }
+__global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x; i < 8 * 32; i += blockDim.x) heads[i] = 0; }
 
 // ---------------------------------------------------------------------------------------------
 // K6: RgbFilm::add_sample for every sample of the batch, per pixel in sample order (f64 sums are
 // order dependent; the reference adds samples of a pixel in increasing sample_index).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SHADE_BLOCK) k_film(SceneView sv, PathArrays pa, const uint32_t* pixels, uint32_t n_pix, int n_samples,
-                                                    ShmFilmPixel* film, DeviceCounters* counters) {
+                                                    ShmFilmPixel* film, DeviceCounters* counters, uint32_t pix_group) {
     uint32_t p_local = blockIdx.x * blockDim.x + threadIdx.x;
     if (p_local >= n_pix) return;
     uint32_t pix = pixels[p_local];
@@ -751,7 +794,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_film(SceneView sv, PathArrays p
     ShmFilmPixel* fp = film + (size_t)(py - sv.pixel_bounds[1]) * (size_t)width + (size_t)(px - sv.pixel_bounds[0]);
     double r = fp->rgb_sum[0], g = fp->rgb_sum[1], b = fp->rgb_sum[2], w = fp->weight_sum;
     for (int s = 0; s < n_samples; ++s) {
-        uint32_t slot = (uint32_t)s * n_pix + p_local;
+        uint32_t slot = slot_of(p_local, (uint32_t)s, n_pix, (uint32_t)n_samples, pix_group);
         Spec L = ld_spec(pa.L[slot]);
         Wavelengths lambda;
         float4 a = pa.lambda[slot], c = pa.lambda_pdf[slot];
@@ -805,6 +848,9 @@ struct ShmScene {
     int leaf_min = 8;
     uint32_t* d_spill3 = nullptr;
     int refill_min = 16;
+    uint32_t pix_group = 1024;      // path-slot order [tile][sample][pixel in tile] (SHM_PIX_GROUP; >= n_pix: sample-major)
+    int queue_parts = 8;           // k_trace3 queue partitions, one per XCD with stealing (SHM_QUEUE_PARTS: 1 or 8)
+    uint32_t* d_heads3 = nullptr;  // [2 (closest, any)][8 partitions][32 dwords: one 128-B line per head word]
     std::vector<hipEvent_t> events;
 };
 
@@ -829,15 +875,20 @@ int dev_alloc(ShmScene* s, size_t n, T** out) {
     return SHM_OK;
 }
 
-// Path workspace sized to the work: up to SHM_BATCH_PATHS (default 64 Mi paths = 17 GB of the 288 GB) so that one spp-wave
-// of the 1024^2 frame is ONE batch. Small batches starve the persistent traversal kernels: with ~400 K resident lanes a
+// Path workspace sized to the work: up to SHM_BATCH_PATHS (default 256 Mi paths = 71 GB of the 288 GB) so that all 256 spp
+// of the 1024^2 frame are ONE batch (6 closest + 5 any launches for the whole frame). Small batches starve the persistent traversal kernels: with ~400 K resident lanes a
 // 1 M-ray launch gives each lane ~3 rays and the launch time is set by the longest ray, not by throughput (profiles/r01_*).
-int ensure_workspace(ShmScene* s, uint64_t needed_paths) {
-    uint64_t max_cap = 1ull << 26;
+static uint64_t max_batch_paths() {
+    uint64_t max_cap = 1ull << 28;
     if (const char* e = getenv("SHM_BATCH_PATHS")) {
         long long v = atoll(e);
         if (v >= 4096) max_cap = (uint64_t)v;
     }
+    return max_cap;
+}
+
+int ensure_workspace(ShmScene* s, uint64_t needed_paths) {
+    uint64_t max_cap = max_batch_paths();
     uint64_t want = std::min<uint64_t>(std::max<uint64_t>(needed_paths, 4096), max_cap);
     want = (want + 4095ull) & ~4095ull;
     if (want > 0xfffff000ull) want = 0xfffff000ull;
@@ -873,8 +924,10 @@ template <bool ANY>
 void launch_trace(ShmScene* s, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, uint32_t* head, const ShmRay* rays,
                   ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib) {
     if (!s->flat.has_spheres && s->trace_kernel == 3) {
-        hipLaunchKernelGGL((k_trace3<ANY>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, head, rays, hits,
-                           occluded, L, contrib, s->d_counters, s->d_spill3, s->spill3_levels, s->refill_min, s->leaf_min);
+        uint32_t* heads = s->d_heads3 + (ANY ? 8 * 32 : 0);
+        hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, s->stream, heads);
+        hipLaunchKernelGGL((k_trace3<ANY>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, heads, rays, hits,
+                           occluded, L, contrib, s->d_counters, s->d_spill3, s->spill3_levels, s->refill_min, s->leaf_min, s->queue_parts);
         return;
     }
     dim3 grid(s->trace_blocks), block(TRACE_BLOCK);
@@ -970,6 +1023,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if ((rc = dev_alloc<QueueState>(s, 1, &s->d_qs)) != SHM_OK) return fail(rc);
     if ((rc = dev_alloc<DeviceCounters>(s, 1, &s->d_counters)) != SHM_OK) return fail(rc);
     if ((rc = dev_alloc<uint32_t>(s, 1, &s->d_head)) != SHM_OK) return fail(rc);
+    if ((rc = dev_alloc<uint32_t>(s, 2 * 8 * 32, &s->d_heads3)) != SHM_OK) return fail(rc);
     hipMemset(s->d_qs, 0, sizeof(QueueState));
     hipMemset(s->d_counters, 0, sizeof(DeviceCounters));
 
@@ -983,6 +1037,8 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_TRACE_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) per_cu = v2; }
     s->trace_blocks = s->n_cu * per_cu;
     if (const char* e = getenv("SHM_TRACE_KERNEL")) { int v2 = atoi(e); if (v2 == 1 || v2 == 3) s->trace_kernel = v2; }
+    if (const char* e = getenv("SHM_PIX_GROUP")) { long long v2 = atoll(e); if (v2 >= 1) s->pix_group = (uint32_t)std::min<long long>(v2, 0x7fffffffll); }
+    if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = v2; }
     {
         int per_cu3 = 6;  // 26 KiB of LDS per workgroup
@@ -1071,7 +1127,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         uint32_t total = n_pix * (uint32_t)n_samples;
         const uint32_t* pixels = s->d_pixels + p0;
         hipLaunchKernelGGL(k_generate, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
-                           sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs);
+                           sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs, s->pix_group);
         int cur = 0;
         for (int bounce = 0; bounce <= params->max_depth; ++bounce) {
             hipEvent_t a = ev.get(), b = ev.get();
@@ -1092,7 +1148,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
             cur ^= 1;
         }
         hipLaunchKernelGGL(k_film, dim3((n_pix + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix, n_samples,
-                           s->d_film, s->d_counters);
+                           s->d_film, s->d_counters, s->pix_group);
     }
     HIP_TRY(hipEventRecord(e_end, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1128,11 +1184,16 @@ int shm_render_device(ShmScene* s, const ShmRenderParams* params, const ShmTile*
     if (!s || !params) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
     // ImageTileIntegrator::render's wave schedule (integrator.rs:231-233, 306-308: 1,1,2,4,...,64,64,...). The waves only
     // exist there to show progress / write intermediate images (TODO at :311); a pixel's samples are added to the film in
-    // increasing sample_index whatever the grouping, so consecutive waves are fused into launches of up to 64 spp (the
-    // reference's own maximum wave size) without changing a single film sum. SHM_FUSE_WAVES=0 keeps one launch per wave.
+    // increasing sample_index whatever the grouping, so consecutive waves are fused into launches of at least 64 spp (the
+    // reference's own maximum wave size) and as many more as fit the path workspace in one batch (a rank that owns 1/8 of
+    // the tiles takes all 256 spp at once), without changing a single film sum. SHM_FUSE_WAVES=0 keeps one launch per wave.
     bool fuse = true;
     if (const char* e = getenv("SHM_FUSE_WAVES")) fuse = atoi(e) != 0;
     int spp = params->samples_per_pixel;
+    uint64_t n_pixels = 0;
+    for (uint32_t t = 0; tiles && t < n_tiles; ++t)
+        n_pixels += (uint64_t)std::max(0, tiles[t].x1 - tiles[t].x0) * (uint64_t)std::max(0, tiles[t].y1 - tiles[t].y0);
+    const int max_fuse = (int)std::min<uint64_t>(std::max<uint64_t>(64, n_pixels ? max_batch_paths() / n_pixels : 64), 1u << 20);
     int wave_start = 0, wave_end = 1, next_wave_size = 1;
     int pend_begin = 0, pend_end = 0;
     while (wave_start < spp) {
@@ -1142,7 +1203,7 @@ int shm_render_device(ShmScene* s, const ShmRenderParams* params, const ShmTile*
         wave_start = wave_end;
         wave_end = std::min(spp, nws + next_wave_size);
         next_wave_size = std::min(2 * next_wave_size, 64);
-        bool flush = !fuse || wave_start >= spp || (wave_end - pend_begin) > 64;
+        bool flush = !fuse || wave_start >= spp || (wave_end - pend_begin) > max_fuse;
         if (flush) {
             int rc = shm_render_wave(s, params, tiles, n_tiles, pend_begin, pend_end, stats);
             if (rc != SHM_OK) return rc;
