@@ -319,15 +319,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace(SceneView sv, const uint3
 //  * leaf (triangle) tests are POSTPONED: a lane that reached a leaf waits until at least `leaf_min` lanes of its wave
 //    have a pending leaf (or no lane can take a node step), then the watertight test runs for all of them at once;
 //  * finished lanes are refilled from the queue (one wave-aggregated atomic) once `refill_min` lanes are idle;
-//  * stack levels [LOW, LOW + LDS_N) live in LDS as [level][lane]; the few bottom levels (pushed once near the root,
-//    popped once at the very end) and any level above the LDS window go to a per-lane HBM region laid out the same way.
+//  * stack levels [0, LDS_N) live in LDS as [level][lane]; any deeper level goes to a per-lane HBM region laid out the
+//    same way.
 // Node and primitive visit counts equal the reference's in both modes (it is the same algorithm, node for node).
 // ---------------------------------------------------------------------------------------------
 #ifndef K3_CHUNK_MAX
 #define K3_CHUNK_MAX 1024
 #endif
-constexpr int K3_LOW = 6;      // stack levels [0, K3_LOW) -> HBM spill
-constexpr int K3_LDS_N = 26;   // stack levels [K3_LOW, K3_LOW + K3_LDS_N) -> LDS (6.5 KiB per wave)
+constexpr int K3_LDS_N = 26;   // stack levels [0, K3_LDS_N) -> LDS (6.5 KiB per wave), deeper levels -> HBM spill
 enum : uint32_t { ST_IDLE = 0, ST_NODE = 1, ST_LEAF = 2, ST_DONE = 3 };
 
 template <bool ANY>
@@ -369,18 +368,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
     uint32_t cur = 0;
     uint32_t leaf_off = 0, leaf_n = 0;
 
-    // explicit LDS / HBM branches (a single generic pointer compiles to flat_load/flat_store, which wait on both counters)
-    auto stack_load = [&](int level) -> uint32_t {
-        int l = level - K3_LOW;
-        if ((unsigned)l < (unsigned)K3_LDS_N) return st_lds[l * WAVE];
-        return st_spill[(size_t)(level < K3_LOW ? level : level - K3_LDS_N) * WAVE];
-    };
-    auto stack_store = [&](int level, uint32_t v) {
-        int l = level - K3_LOW;
-        if ((unsigned)l < (unsigned)K3_LDS_N) st_lds[l * WAVE] = v;
-        else st_spill[(size_t)(level < K3_LOW ? level : level - K3_LDS_N) * WAVE] = v;
-    };
-
+    // Stack storage by level: [0, K3_LDS_N) in LDS, anything deeper in the per-lane HBM spill. (The first version kept
+    // the LDS window at levels 6..31 and spilled the bottom levels: those are written at the start of every ray and again
+    // whenever the traversal comes back near the root, and as HBM stores they made WRITE_SIZE 7x the algorithmic hit writes
+    // — profiles/r01_v4. Holding them in registers through select chains was measured too: slower than LDS.)
     // Queue partitions: the queue is cut into `queue_parts` contiguous ranges, each with its own head word (own 128-B
     // line). A wave starts in the partition of the XCD it runs on — queue order is image order (pix_group), so one XCD's L2
     // serves one image region's part of the BVH, and 8 head words see 1/8 of the atomics each (one word saturates near
@@ -448,7 +439,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
             if (want_pop) {
                 want_pop = false;
                 if (sp == 0) { state = ST_DONE; go = false; }
-                else { sp--; cur = stack_load(sp); }
+                else {
+                    sp--;
+                    cur = (sp < K3_LDS_N) ? st_lds[sp * WAVE] : st_spill[(size_t)(sp - K3_LDS_N) * WAVE];
+                }
             }
             if (go) {
                 const float4* np = reinterpret_cast<const float4*>(node_base + ((size_t)cur << 5));
@@ -486,7 +480,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                     bool neg = (axis == 0) ? negx : ((axis == 1) ? negy : negz);
                     uint32_t far_child = neg ? cur + 1 : offset;   // aggregate.rs:119-127
                     uint32_t near_child = neg ? offset : cur + 1;
-                    stack_store(sp, far_child);
+                    if (sp < K3_LDS_N) st_lds[sp * WAVE] = far_child;
+                    else st_spill[(size_t)(sp - K3_LDS_N) * WAVE] = far_child;
                     sp++;
                     cur = near_child;
                 }
@@ -845,7 +840,8 @@ struct ShmScene {
     int trace_kernel = 3;          // 1: k_trace (generic: spheres), 3: k_trace3 (triangle-only scenes)
     int trace3_blocks = 0;
     int spill3_levels = 1;
-    int leaf_min = 8;
+    int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
+    int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
     uint32_t* d_spill3 = nullptr;
     int refill_min = 16;
     uint32_t pix_group = 1024;      // path-slot order [tile][sample][pixel in tile] (SHM_PIX_GROUP; >= n_pix: sample-major)
@@ -927,7 +923,7 @@ void launch_trace(ShmScene* s, const uint32_t* queue, const uint32_t* n_ptr, uin
         uint32_t* heads = s->d_heads3 + (ANY ? 8 * 32 : 0);
         hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, s->stream, heads);
         hipLaunchKernelGGL((k_trace3<ANY>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, heads, rays, hits,
-                           occluded, L, contrib, s->d_counters, s->d_spill3, s->spill3_levels, s->refill_min, s->leaf_min, s->queue_parts);
+                           occluded, L, contrib, s->d_counters, s->d_spill3, s->spill3_levels, s->refill_min, ANY ? s->leaf_min_any : s->leaf_min, s->queue_parts);
         return;
     }
     dim3 grid(s->trace_blocks), block(TRACE_BLOCK);
@@ -1044,8 +1040,9 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
         int per_cu3 = 6;  // 26 KiB of LDS per workgroup
         if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 6) per_cu3 = v2; }
         if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
+        if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
         s->trace3_blocks = s->n_cu * per_cu3;
-        s->spill3_levels = K3_LOW + std::max(0, (int)f.max_leaf_depth + 1 - K3_LOW - K3_LDS_N) + 1;
+        s->spill3_levels = std::max(0, (int)f.max_leaf_depth + 1 - K3_LDS_N) + 1;
         if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3)) != SHM_OK) return fail(rc);
     }
     DBG("scene: %u nodes, depth %u, stack_entries %d, trace_blocks %d, trace3_blocks %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->stack_entries, s->trace_blocks, s->trace3_blocks);
@@ -1167,8 +1164,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         hipEventElapsedTime(&ms, e_begin, e_end);
         stats->ms_total += ms;
         double mc = 0.0, ma = 0.0;
-        for (auto& p : ev_closest) { hipEventElapsedTime(&ms, p.first, p.second); mc += ms; }
-        for (auto& p : ev_any) { hipEventElapsedTime(&ms, p.first, p.second); ma += ms; }
+        for (auto& p : ev_closest) { hipEventElapsedTime(&ms, p.first, p.second); mc += ms; DBG("closest launch %.3f ms", ms); }
+        for (auto& p : ev_any) { hipEventElapsedTime(&ms, p.first, p.second); ma += ms; DBG("any launch %.3f ms", ms); }
         stats->ms_trace_closest += mc;
         stats->ms_trace_any += ma;
         float tot = 0.0f;
