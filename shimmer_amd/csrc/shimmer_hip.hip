@@ -150,9 +150,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
     pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     pa.lambda[slot] = make_float4(lambda.lambda[0], lambda.lambda[1], lambda.lambda[2], lambda.lambda[3]);
     pa.lambda_pdf[slot] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
-    pa.ctx0[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    pa.ctx1[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    pa.ctx2[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // (ctx0..2, the previous vertex's LightSampleContext, are first read at depth >= 1, after k_shade has written them)
     pa.pb_eta[slot] = make_float2(1.0f, 1.0f);
     pa.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
     pa.pixel[slot] = pix;
@@ -589,11 +587,14 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
             const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
             float4 r0 = rp[0], r1 = rp[1];
             V3 ray_d = v3(r0.w, r1.x, r1.y);
-            Spec l = ld_spec(pa.L[path]);
+            // L is only touched by a vertex that adds emission (most do not): loaded and stored inside add_l
+            auto add_l = [&](const Spec& c) { pa.L[path] = st_spec(ld_spec(pa.L[path]) + c); };
             Spec beta = ld_spec(pa.beta[path]);
             Wavelengths lambda;
+            float4 pdf_in;
             {
                 float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                pdf_in = b;
                 lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
                 lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
             }
@@ -603,29 +604,30 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
             bool any_non_specular_bounces = (fl >> 9) & 1u;
             float2 pe = pa.pb_eta[path];
             Float p_b = pe.x, eta_scale = pe.y;
-            LightSampleContext prev_ctx;
-            {
+            // the previous vertex's context is only needed for the MIS weight of an emitter that was hit
+            auto load_prev_ctx = [&]() {
+                LightSampleContext c;
                 float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path];
-                prev_ctx.pi.x = iv2(c0.x, c0.w);
-                prev_ctx.pi.y = iv2(c0.y, c1.x);
-                prev_ctx.pi.z = iv2(c0.z, c1.y);
-                prev_ctx.n = v3(c1.z, c1.w, c2.x);
-                prev_ctx.ns = v3(c2.y, c2.z, c2.w);
-            }
+                c.pi.x = iv2(c0.x, c0.w);
+                c.pi.y = iv2(c0.y, c1.x);
+                c.pi.z = iv2(c0.z, c1.y);
+                c.n = v3(c1.z, c1.w, c2.x);
+                c.ns = v3(c2.y, c2.z, c2.w);
+                return c;
+            };
             if (hit.prim < 0) {
                 // integrator.rs:776-794: escaped ray, infinite lights
                 for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
                     const ShmLight& light = sv.lights[sv.infinite_lights[k]];
                     Spec le = light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
                     if (depth == 0 || specular_bounce) {
-                        l = l + beta * le;
+                        add_l(beta * le);
                     } else {
-                        Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, prev_ctx, ray_d);
+                        Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, load_prev_ctx(), ray_d);
                         Float w_b = power_heuristic(1, p_b, 1, p_l);
-                        l = l + beta * w_b * le;
+                        add_l(beta * w_b * le);
                     }
                 }
-                pa.L[path] = st_spec(l);
             } else {
                 SurfaceInteraction si = hit_interaction(sv, hit, -ray_d);
                 const ShmPrimitive prim = sv.primitives[hit.prim];
@@ -635,11 +637,11 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                     Spec le = area_light_l(sv, light, si.n, -ray_d, lambda);
                     if (!is_zero(le)) {
                         if (depth == 0 || specular_bounce) {
-                            l = l + beta * le;
+                            add_l(beta * le);
                         } else {
-                            Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, prev_ctx, ray_d);
+                            Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, load_prev_ctx(), ray_d);
                             Float w_l = power_heuristic(1, p_b, 1, p_l);
-                            l = l + beta * w_l * le;
+                            add_l(beta * w_l * le);
                         }
                     }
                 }
@@ -741,9 +743,9 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                         }
                     }
                 }
-                pa.L[path] = st_spec(l);
-                // terminate_secondary may have changed the pdfs (material.rs:609-619)
-                pa.lambda_pdf[path] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
+                // terminate_secondary may have changed the pdfs (material.rs:609-619): written back only then
+                if (lambda.pdf[1] != pdf_in.y || lambda.pdf[2] != pdf_in.z || lambda.pdf[3] != pdf_in.w || lambda.pdf[0] != pdf_in.x)
+                    pa.lambda_pdf[path] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
             }
         }
         // stage the queue entries of this chunk in LDS (wave-aggregated LDS atomics)
@@ -1141,6 +1143,12 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 hipEventRecord(d, s->stream);
                 ev_any.push_back({c, d});
             }
+            if (dbg_on()) {  // queue sizes per bounce (costs a sync: debug only)
+                QueueState q;
+                hipStreamSynchronize(s->stream);
+                hipMemcpy(&q, s->d_qs, sizeof(q), hipMemcpyDeviceToHost);
+                DBG("bounce %d: traced %u, next %u, shadow %u", bounce, q.n_active[cur], q.n_active[cur ^ 1], q.n_shadow);
+            }
             hipLaunchKernelGGL(k_next_bounce, dim3(1), dim3(1), 0, s->stream, s->d_qs, cur);
             cur ^= 1;
         }
@@ -1166,6 +1174,11 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         double mc = 0.0, ma = 0.0;
         for (auto& p : ev_closest) { hipEventElapsedTime(&ms, p.first, p.second); mc += ms; DBG("closest launch %.3f ms", ms); }
         for (auto& p : ev_any) { hipEventElapsedTime(&ms, p.first, p.second); ma += ms; DBG("any launch %.3f ms", ms); }
+        if (dbg_on())
+            for (size_t i = 0; i < ev_any.size() && i < ev_closest.size(); ++i) {
+                hipEventElapsedTime(&ms, ev_closest[i].second, ev_any[i].first);
+                DBG("shade launch %.3f ms", ms);
+            }
         stats->ms_trace_closest += mc;
         stats->ms_trace_any += ma;
         float tot = 0.0f;
