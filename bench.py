@@ -51,20 +51,29 @@ def cpu_baseline(sc, params_full, host_lib, budget_s=15.0):
     orc = oracle_py.Oracle(sc.desc)
     pb = orc.pixel_bounds
     w, h = pb[2] - pb[0], pb[3] - pb[1]
-    cw, ch = min(w, 256), min(h, 256)
-    crop = (pb[0] + (w - cw) // 2, pb[1] + (h - ch) // 2, pb[0] + (w - cw) // 2 + cw, pb[1] + (h - ch) // 2 + ch)
-    tiles, n_tiles = scn.tiles_for(host_lib, crop)
-    p = render.make_params(seed=params_full.seed, spp=1, max_depth=params_full.max_depth)
-    t0 = time.perf_counter()
-    _, st = orc.render(p, n_threads=cores, tiles=tiles, n_tiles=n_tiles)
-    t1 = time.perf_counter() - t0
-    rays1 = st["rays_closest"] + st["rays_any"]
-    spp = int(max(1, min(params_full.samples_per_pixel, budget_s / max(t1, 1e-3))))
-    p = render.make_params(seed=params_full.seed, spp=spp, max_depth=params_full.max_depth)
-    t0 = time.perf_counter()
-    _, st = orc.render(p, n_threads=cores, tiles=tiles, n_tiles=n_tiles)
-    dt = time.perf_counter() - t0
-    rays = st["rays_closest"] + st["rays_any"]
+
+    def crop_tiles(side):
+        cw, ch = min(w, side), min(h, side)
+        x0, y0 = pb[0] + (w - cw) // 2, pb[1] + (h - ch) // 2
+        return (cw, ch) + scn.tiles_for(host_lib, (x0, y0, x0 + cw, y0 + ch))
+
+    def run(side, spp):
+        cw, ch, tiles, n_tiles = crop_tiles(side)
+        p = render.make_params(seed=params_full.seed, spp=spp, max_depth=params_full.max_depth)
+        t0 = time.perf_counter()
+        _, st = orc.render(p, n_threads=cores, tiles=tiles, n_tiles=n_tiles)
+        return cw, ch, st["rays_closest"] + st["rays_any"], time.perf_counter() - t0
+
+    # probe (1 and 5 spp on the 256^2 crop) to size the sample to ~budget_s seconds of wall time on all host cores
+    run(256, 1)  # thread start-up, page faults
+    _, _, _, t0 = run(256, 1)
+    _, _, rays1, t1 = run(256, 5)
+    full = params_full.samples_per_pixel
+    want = budget_s / max((t1 - t0) / 4.0, 1e-4)  # spp the 256^2 crop could take (fixed per-call cost cancels)
+    side, spp = 256, int(max(1, min(full, want)))
+    if want > full:
+        side, spp = 512, int(max(1, min(full, want / 4.0)))
+    cw, ch, rays, dt = run(side, spp)
     orc.close()
     model = ""
     try:
@@ -76,7 +85,7 @@ def cpu_baseline(sc, params_full, host_lib, budget_s=15.0):
         pass
     return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
             "sample": f"oracle/oracle.cpp, {cores} threads over 8x8 tiles, centred {cw}x{ch} crop of the same frame at {spp} spp "
-                      f"({rays} rays in {dt:.1f} s; probe {rays1} rays in {t1:.1f} s); cpu: {model}"}
+                      f"({rays} rays in {dt:.1f} s; probe {rays1} rays in {t1:.2f} s); cpu: {model}"}
 
 
 def main():
@@ -183,7 +192,7 @@ def main():
                        "tiles": "8x8, sharded across ranks in interleaved blocks of tile rows (~8 blocks per rank)" if world > 1 else "8x8",
                        "rays_per_step": rays / args.steps, "paths_per_step": tot["paths"] / args.steps,
                        "film_gather": "RCCL gather to rank 0 (inside the timed region)" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "k_trace<closest> (BvhAggregate::intersect)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_trace3<closest> (BvhAggregate::intersect)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args) if world == 1 else None,
                          "bytes_per_launch": bytes_alg / launches, "avg_launch_ms": ms / launches, "launches": launches,
                          "nodes_per_ray": acc["nodes_closest"] / max(1, acc["rays_closest"]),
