@@ -439,7 +439,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                 if (sp == 0) { state = ST_DONE; go = false; }
                 else {
                     sp--;
-                    cur = (sp < K3_LDS_N) ? st_lds[sp * WAVE] : st_spill[(size_t)(sp - K3_LDS_N) * WAVE];
+                    // two different load flavours, so that the compiler cannot merge them into one flat_load of a selected
+                    // pointer (which waits on both the LDS and the vector-memory counter)
+                    if (sp < K3_LDS_N) cur = st_lds[sp * WAVE];
+                    else cur = __builtin_nontemporal_load(st_spill + (size_t)(sp - K3_LDS_N) * WAVE);
                 }
             }
             if (go) {
