@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--coated", action="store_true", help="S3 with a CoatedDiffuse object (LayeredBxDF, SURVEY 8f-1) instead of the "
+                    "headline diffuse one: a side measurement, not the BASELINE config")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL init + film gather path even with one rank")
     args = ap.parse_args()
 
@@ -127,7 +129,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     t0 = time.perf_counter()
-    sc = scenes.ganesha_proxy(lib, args.res, args.res, n=args.n)
+    sc = scenes.ganesha_proxy(lib, args.res, args.res, n=args.n, coated=args.coated)
     t_scene = time.perf_counter() - t0
     t0 = time.perf_counter()
     r = render.Renderer(lib, sc.desc, device=local_rank)
@@ -187,7 +189,7 @@ def main():
             "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"S3 ganesha-proxy ({sc.info['n_primitives']} prims, {sc.info['n_nodes']} BVH nodes), "
+            "config": {"workload": f"{'S3c coated ' if args.coated else 'S3 '}ganesha-proxy ({sc.info['n_primitives']} prims, {sc.info['n_nodes']} BVH nodes), "
                                    f"{args.res}x{args.res}, {args.spp} spp, maxdepth {args.max_depth}, path integrator",
                        "tiles": "8x8, sharded across ranks in interleaved blocks of tile rows (~8 blocks per rank)" if world > 1 else "8x8",
                        "rays_per_step": rays / args.steps, "paths_per_step": tot["paths"] / args.steps,

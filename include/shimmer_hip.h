@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SHM_ABI_VERSION 1
+#define SHM_ABI_VERSION 2
 
 /* The library is built with -fvisibility=hidden; only these entry points are exported. */
 #if defined(__GNUC__)
@@ -114,7 +114,9 @@ enum {
     SHM_MATERIAL_DIFFUSE = 0,         /* material.rs:247-332 */
     SHM_MATERIAL_CONDUCTOR = 1,       /* material.rs:334-516 */
     SHM_MATERIAL_DIELECTRIC = 2,      /* material.rs:518-650 */
-    SHM_MATERIAL_THIN_DIELECTRIC = 3  /* material.rs:652-768 */
+    SHM_MATERIAL_THIN_DIELECTRIC = 3, /* material.rs:652-768 */
+    SHM_MATERIAL_COATED_DIFFUSE = 4,  /* material.rs:772-1005: LayeredBxDF<Dielectric, Diffuse, two-sided> (bxdf.rs:269-290, 883-1620) */
+    SHM_MATERIAL_COATED_CONDUCTOR = 5 /* material.rs:1007-1286: LayeredBxDF<Dielectric, Conductor, two-sided> (bxdf.rs:460-480) */
 };
 /* Constant textures only (image textures are a "next" row). */
 typedef struct ShmMaterial {
@@ -122,10 +124,17 @@ typedef struct ShmMaterial {
     uint32_t has_displacement; /* Diffuse: always 1 with a constant-0 texture (material.rs:280, quirk 8) */
     float displacement;        /* the constant displacement value */
     uint32_t remap_roughness;
-    float u_roughness, v_roughness;
-    uint32_t pad[2];
-    ShmSpectrum a;  /* Diffuse: reflectance; Conductor: eta; Dielectric/Thin: eta */
-    ShmSpectrum b;  /* Conductor: k */
+    float u_roughness, v_roughness; /* Conductor / Dielectric; Coated*: the dielectric interface */
+    float u2_roughness, v2_roughness; /* CoatedConductor: the conductor (material.rs:1237-1244 derives it from the interface
+                                         roughness when remap_roughness is set: reference behaviour, done in get_bsdf) */
+    float thickness, g;               /* Coated*: layer thickness, HG asymmetry of the medium between the interfaces */
+    int32_t max_depth, n_samples;     /* Coated*: random-walk depth and walks per evaluation (defaults 10, 1) */
+    uint32_t conductor_from_reflectance; /* CoatedConductor: `a` is a reflectance (material.rs:1224-1231), not eta */
+    uint32_t pad[3];
+    ShmSpectrum a;  /* Diffuse / CoatedDiffuse: reflectance; Conductor / CoatedConductor: eta (or reflectance); Dielectric/Thin: eta */
+    ShmSpectrum b;  /* Conductor / CoatedConductor: k */
+    ShmSpectrum c;  /* Coated*: albedo of the medium */
+    ShmSpectrum d;  /* Coated*: eta of the dielectric interface */
 } ShmMaterial;
 
 enum {

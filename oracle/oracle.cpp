@@ -433,6 +433,44 @@ void orc_fn_bxdf_f_pdf(int kind, const float* r4, const float* k4, float eta, fl
     for (int i = 0; i < 4; ++i) out5[i] = f.v[i];
     out5[4] = bxdf_pdf(b, ld3(wo), ld3(wi), REFLTRANS_ALL);
 }
+// LayeredBxDF (CoatedDiffuse kind 4 / CoatedConductor kind 5) in the local frame. p: r[4], k[4], albedo[4], eta, ax, ay,
+// ax2, ay2, thickness, g (19 floats); ip: max_depth, n_samples.
+static BxDF make_layered(int kind, const float* p, const int* ip) {
+    BxDF b;
+    b.kind = (uint32_t)kind;
+    for (int i = 0; i < 4; ++i) { b.r.v[i] = p[i]; b.k.v[i] = p[4 + i]; b.albedo.v[i] = p[8 + i]; }
+    b.eta = p[12];
+    b.mf = trowbridge_reitz_new(p[13], p[14]);
+    b.mf2 = trowbridge_reitz_new(p[15], p[16]);
+    b.thickness = p[17];
+    b.g = p[18];
+    b.max_depth = ip[0];
+    b.n_samples = ip[1];
+    return b;
+}
+void orc_fn_layered_f_pdf(int kind, const float* p, const int* ip, const float* wo, const float* wi, float* out6) {
+    BxDF b = make_layered(kind, p, ip);
+    Spec f = bxdf_f(b, ld3(wo), ld3(wi));
+    for (int i = 0; i < 4; ++i) out6[i] = f.v[i];
+    out6[4] = bxdf_pdf(b, ld3(wo), ld3(wi), REFLTRANS_ALL);
+    out6[5] = (float)bxdf_flags(b);
+}
+int orc_fn_layered_sample_f(int kind, const float* p, const int* ip, const float* wo, float uc, const float* u, float* out10) {
+    BxDF b = make_layered(kind, p, ip);
+    BSDFSample bs;
+    if (!bxdf_sample_f(b, ld3(wo), uc, v2(u[0], u[1]), REFLTRANS_ALL, bs)) return 0;
+    for (int i = 0; i < 4; ++i) out10[i] = bs.f.v[i];
+    out10[4] = bs.wi.x; out10[5] = bs.wi.y; out10[6] = bs.wi.z; out10[7] = bs.pdf; out10[8] = (float)bs.flags;
+    out10[9] = bs.pdf_is_proportional ? 1.0f : 0.0f;
+    return 1;
+}
+float orc_fn_henyey_greenstein(float cos_theta, float g) { return henyey_greenstein(cos_theta, g); }
+void orc_fn_sample_henyey_greenstein(const float* wo, float g, const float* u, float* out4) {
+    Float pdf;
+    V3 wi = sample_henyey_greenstein(ld3(wo), g, v2(u[0], u[1]), pdf);
+    out4[0] = wi.x; out4[1] = wi.y; out4[2] = wi.z; out4[3] = pdf;
+}
+float orc_fn_sample_exponential(float x, float a) { return sample_exponential(x, a); }
 void orc_fn_sample_cosine_hemisphere(const float* u, float* out3) { V3 r = sample_cosine_hemisphere(v2(u[0], u[1])); out3[0] = r.x; out3[1] = r.y; out3[2] = r.z; }
 float orc_fn_power_heuristic(float f, float g) { return power_heuristic(1, f, 1, g); }
 float orc_fn_sampler_stream(int px, int py, int sample_index, uint64_t seed, int n, float* out) {

@@ -62,6 +62,12 @@ def load():
     lib.orc_fn_bxdf_sample_f.restype = C.c_int
     lib.orc_fn_bxdf_sample_f.argtypes = [C.c_int, FP, FP, F, F, F, FP, F, FP, FP]
     lib.orc_fn_bxdf_f_pdf.restype, lib.orc_fn_bxdf_f_pdf.argtypes = None, [C.c_int, FP, FP, F, F, F, FP, FP, FP]
+    IP = C.POINTER(C.c_int)
+    lib.orc_fn_layered_f_pdf.restype, lib.orc_fn_layered_f_pdf.argtypes = None, [C.c_int, FP, IP, FP, FP, FP]
+    lib.orc_fn_layered_sample_f.restype, lib.orc_fn_layered_sample_f.argtypes = C.c_int, [C.c_int, FP, IP, FP, F, FP, FP]
+    lib.orc_fn_henyey_greenstein.restype, lib.orc_fn_henyey_greenstein.argtypes = F, [F, F]
+    lib.orc_fn_sample_henyey_greenstein.restype, lib.orc_fn_sample_henyey_greenstein.argtypes = None, [FP, F, FP, FP]
+    lib.orc_fn_sample_exponential.restype, lib.orc_fn_sample_exponential.argtypes = F, [F, F]
     lib.orc_fn_sample_cosine_hemisphere.restype, lib.orc_fn_sample_cosine_hemisphere.argtypes = None, [FP, FP]
     lib.orc_fn_sampler_stream.restype, lib.orc_fn_sampler_stream.argtypes = F, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, FP]
     lib.orc_fn_offset_ray_origin.restype, lib.orc_fn_offset_ray_origin.argtypes = None, [FP, FP, FP, FP, FP]

@@ -10,11 +10,12 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 LIB_PATH = ROOT / "csrc" / "libshimmer_hip.so"
 
-SHM_ABI_VERSION = 1
+SHM_ABI_VERSION = 2
 SHM_OK = 0
 SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE = 0, 1
 SHM_SPECTRUM_CONSTANT, SHM_SPECTRUM_DENSE, SHM_SPECTRUM_PIECEWISE_LINEAR = 0, 1, 2
 SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATERIAL_THIN_DIELECTRIC = 0, 1, 2, 3
+SHM_MATERIAL_COATED_DIFFUSE, SHM_MATERIAL_COATED_CONDUCTOR = 4, 5
 SHM_LIGHT_POINT, SHM_LIGHT_DIFFUSE_AREA, SHM_LIGHT_UNIFORM_INFINITE = 0, 1, 2
 
 c_float_p = C.POINTER(C.c_float)
@@ -51,7 +52,9 @@ class ShmSpectrum(C.Structure):
 class ShmMaterial(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("has_displacement", C.c_uint32), ("displacement", C.c_float),
                 ("remap_roughness", C.c_uint32), ("u_roughness", C.c_float), ("v_roughness", C.c_float),
-                ("pad", C.c_uint32 * 2), ("a", ShmSpectrum), ("b", ShmSpectrum)]
+                ("u2_roughness", C.c_float), ("v2_roughness", C.c_float), ("thickness", C.c_float), ("g", C.c_float),
+                ("max_depth", C.c_int32), ("n_samples", C.c_int32), ("conductor_from_reflectance", C.c_uint32),
+                ("pad", C.c_uint32 * 3), ("a", ShmSpectrum), ("b", ShmSpectrum), ("c", ShmSpectrum), ("d", ShmSpectrum)]
 
 
 class ShmLight(C.Structure):
@@ -113,7 +116,7 @@ class ShmHit(C.Structure):
                 ("phi", C.c_float), ("pad", C.c_uint32 * 2)]
 
 
-assert C.sizeof(ShmBvhNode) == 32 and C.sizeof(ShmRay) == 32 and C.sizeof(ShmHit) == 32 and C.sizeof(ShmFilmPixel) == 32
+assert C.sizeof(ShmMaterial) == 64 + 4 * 32 and C.sizeof(ShmBvhNode) == 32 and C.sizeof(ShmRay) == 32 and C.sizeof(ShmHit) == 32 and C.sizeof(ShmFilmPixel) == 32
 
 # Every symbol include/shimmer_hip.h declares, with its signature (tests check the .so exports all of them).
 EXPORTS = {

@@ -12,6 +12,8 @@
 
 #include "../shm/scene.h"
 
+static_assert(sizeof(ShmMaterial) == 192 && sizeof(ShmSpectrum) == 32 && sizeof(ShmBvhNode) == 32 && sizeof(ShmPrimitive) == 16,
+              "POD layouts of include/shimmer_hip.h (mirrored by shimmer_amd/abi.py)");
 namespace shm_host {
 
 struct FlatScene {
@@ -31,6 +33,7 @@ struct FlatScene {
     ShmFilm film;
     uint32_t max_leaf_depth = 0;  // deepest leaf (root = 0); bounds the traversal stack
     bool has_spheres = false;
+    bool has_layered = false;  // any Coated* material: selects the k_shade instantiation that carries LayeredBxDF
 
     shm::SceneView view() const {
         shm::SceneView v;
@@ -181,9 +184,17 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
     // materials / lights
     uint32_t nsf = (uint32_t)out.spectrum_data.size();
     for (const ShmMaterial& m : out.materials) {
-        if (m.kind > SHM_MATERIAL_THIN_DIELECTRIC) { err = "unsupported material kind (LayeredBxDF / Mix are SURVEY §8f rows)"; return SHM_ERR_UNSUPPORTED; }
+        if (m.kind > SHM_MATERIAL_COATED_CONDUCTOR) { err = "unsupported material kind (MixMaterial is a SURVEY §8f row)"; return SHM_ERR_UNSUPPORTED; }
         if (!check_spectrum(m.a, nsf, err)) return SHM_ERR_INVALID_ARGUMENT;
-        if (m.kind == SHM_MATERIAL_CONDUCTOR && !check_spectrum(m.b, nsf, err)) return SHM_ERR_INVALID_ARGUMENT;
+        const bool coated = m.kind == SHM_MATERIAL_COATED_DIFFUSE || m.kind == SHM_MATERIAL_COATED_CONDUCTOR;
+        if ((m.kind == SHM_MATERIAL_CONDUCTOR || (m.kind == SHM_MATERIAL_COATED_CONDUCTOR && !m.conductor_from_reflectance)) &&
+            !check_spectrum(m.b, nsf, err))
+            return SHM_ERR_INVALID_ARGUMENT;
+        if (coated) {
+            if (!check_spectrum(m.c, nsf, err) || !check_spectrum(m.d, nsf, err)) return SHM_ERR_INVALID_ARGUMENT;
+            if (m.max_depth < 0 || m.max_depth > 1024 || m.n_samples < 1 || m.n_samples > 1024) { err = "coated material: max_depth / n_samples out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            out.has_layered = true;
+        }
     }
     for (uint32_t i = 0; i < out.lights.size(); ++i) {
         const ShmLight& l = out.lights[i];

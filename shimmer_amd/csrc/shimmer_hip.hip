@@ -567,6 +567,9 @@ constexpr int SHADE_CHUNK = 2048;  // queue entries per workgroup chunk: ONE glo
 #else
 #define K_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(K_SHADE_WAVES, K_SHADE_WAVES)))
 #endif
+// HAS_LAYERED = false is the instantiation for scenes without Coated* materials: the LayeredBxDF random walks (three per
+// vertex: f and pdf for NEE, sample_f) are compiled out of it.
+template <bool HAS_LAYERED>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters) {
@@ -649,6 +652,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                     }
                 }
                 BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+                if (!HAS_LAYERED) __builtin_assume(bsdf.bxdf.kind <= SHM_MATERIAL_THIN_DIELECTRIC);
                 if (params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
                 bool alive = (depth != params.max_depth);  // integrator.rs:830-834
                 Rng rng;
@@ -1137,8 +1141,12 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
             launch_trace<false>(s, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, &s->d_qs->head_closest, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr);
             hipEventRecord(b, s->stream);
             ev_closest.push_back({a, b});
-            hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur], s->d_q_active[cur ^ 1],
-                               s->d_q_shadow, s->d_qs, cur, *params, s->d_counters);
+            if (s->flat.has_layered)
+                hipLaunchKernelGGL(k_shade<true>, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
+                                   s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, s->d_counters);
+            else
+                hipLaunchKernelGGL(k_shade<false>, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
+                                   s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, s->d_counters);
             if (bounce < params->max_depth) {
                 hipEvent_t c = ev.get(), d = ev.get();
                 hipEventRecord(c, s->stream);

@@ -213,21 +213,30 @@ SHM_HD BSDFSample bsdf_sample(const Spec& f, V3 wi, Float pdf, uint32_t flags, F
     return s;
 }
 
-// One tagged struct for the four BxDFs (the reference's `enum BxDF`, bxdf.rs:96-103, minus Coated*).
-struct BxDF {
-    uint32_t kind;       // SHM_MATERIAL_*
+// One tagged struct for the four single-layer BxDFs (the reference's `enum BxDF`, bxdf.rs:96-103) ...
+struct BaseBxDF {
+    uint32_t kind;       // SHM_MATERIAL_DIFFUSE / CONDUCTOR / DIELECTRIC / THIN_DIELECTRIC
     Spec r;              // Diffuse: R ; Conductor: eta
     Spec k;              // Conductor: k
     Float eta;           // Dielectric / ThinDielectric
     TrowbridgeReitz mf;  // Conductor / Dielectric
 };
+// ... and the two coated ones, LayeredBxDF<Dielectric, Diffuse|Conductor, TWO_SIDED = true> (bxdf.rs:269-290, 460-480, 883-1620):
+// for kind == SHM_MATERIAL_COATED_*, {eta, mf} are the top dielectric interface and {r, k, mf2} the bottom layer.
+struct BxDF : BaseBxDF {
+    TrowbridgeReitz mf2;  // CoatedConductor: the conductor's distribution
+    Float thickness, g;
+    Spec albedo;
+    int max_depth, n_samples;
+};
+enum : int { MODE_RADIANCE = 0, MODE_IMPORTANCE = 1 };  // TransportMode
 
 // ---- DiffuseBxDF, bxdf.rs:184-267 ----
-SHM_HD Spec diffuse_f(const BxDF& b, V3 wo, V3 wi) {
+SHM_HD Spec diffuse_f(const BaseBxDF& b, V3 wo, V3 wi) {
     if (!same_hemisphere(wo, wi)) return spec_const(0.0f);
     return b.r * INV_PI;
 }
-SHM_HD bool diffuse_sample_f(const BxDF& b, V3 wo, V2 u, uint32_t sample_flags, BSDFSample& out) {
+SHM_HD bool diffuse_sample_f(const BaseBxDF& b, V3 wo, V2 u, uint32_t sample_flags, BSDFSample& out) {
     if ((sample_flags & REFLTRANS_REFLECTION) == 0) return false;
     V3 wi = sample_cosine_hemisphere(u);
     if (wo.z < 0.0f) wi.z *= -1.0f;
@@ -235,13 +244,13 @@ SHM_HD bool diffuse_sample_f(const BxDF& b, V3 wo, V2 u, uint32_t sample_flags, 
     out = bsdf_sample(b.r * INV_PI, wi, pdf, BXDF_DIFFUSE_REFLECTION);
     return true;
 }
-SHM_HD Float diffuse_pdf(const BxDF&, V3 wo, V3 wi, uint32_t sample_flags) {
+SHM_HD Float diffuse_pdf(const BaseBxDF&, V3 wo, V3 wi, uint32_t sample_flags) {
     if ((sample_flags & REFLTRANS_REFLECTION) == 0 || !same_hemisphere(wo, wi)) return 0.0f;
     return cosine_hemisphere_pdf(abs_cos_theta(wi));
 }
 
 // ---- ConductorBxDF, bxdf.rs:328-458 ----
-SHM_HD Spec conductor_f(const BxDF& b, V3 wo, V3 wi) {
+SHM_HD Spec conductor_f(const BaseBxDF& b, V3 wo, V3 wi) {
     if (!same_hemisphere(wo, wi)) return spec_const(0.0f);
     if (b.mf.effectively_smooth()) return spec_const(0.0f);
     Float cos_theta_o = abs_cos_theta(wo);
@@ -253,7 +262,7 @@ SHM_HD Spec conductor_f(const BxDF& b, V3 wo, V3 wi) {
     Spec f = fresnel_complex_spectral(abs_dot(wo, wm), b.r, b.k);
     return b.mf.d(wm) * f * b.mf.g(wo, wi) / (4.0f * cos_theta_o * cos_theta_i);
 }
-SHM_HD bool conductor_sample_f(const BxDF& b, V3 wo, V2 u, uint32_t sample_flags, BSDFSample& out) {
+SHM_HD bool conductor_sample_f(const BaseBxDF& b, V3 wo, V2 u, uint32_t sample_flags, BSDFSample& out) {
     if ((sample_flags & REFLTRANS_REFLECTION) == 0) return false;
     if (b.mf.effectively_smooth()) {
         V3 wi = v3(-wo.x, -wo.y, wo.z);
@@ -274,7 +283,7 @@ SHM_HD bool conductor_sample_f(const BxDF& b, V3 wo, V2 u, uint32_t sample_flags
     out = bsdf_sample(f, wi, pdf, BXDF_GLOSSY_REFLECTION);
     return true;
 }
-SHM_HD Float conductor_pdf(const BxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
+SHM_HD Float conductor_pdf(const BaseBxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
     if ((sample_flags & REFLTRANS_REFLECTION) == 0 || !same_hemisphere(wo, wi) || b.mf.effectively_smooth())
         return 0.0f;
     V3 wm = wo + wi;
@@ -283,8 +292,8 @@ SHM_HD Float conductor_pdf(const BxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
     return b.mf.pdf(wo, wm) / (4.0f * abs_dot(wo, wm));
 }
 
-// ---- DielectricBxDF, bxdf.rs:518-795 (TransportMode::Radiance only: the path never uses Importance) ----
-SHM_HD Spec dielectric_f(const BxDF& b, V3 wo, V3 wi) {
+// ---- DielectricBxDF, bxdf.rs:518-795 (mode: the path itself only uses Radiance; LayeredBxDF samples wis in the other mode) ----
+SHM_HD Spec dielectric_f(const BaseBxDF& b, V3 wo, V3 wi, int mode = MODE_RADIANCE) {
     if (b.eta == 1.0f || b.mf.effectively_smooth()) return spec_const(0.0f);
     Float cos_theta_o = cos_theta(wo);
     Float cos_theta_i = cos_theta(wi);
@@ -301,11 +310,11 @@ SHM_HD Spec dielectric_f(const BxDF& b, V3 wo, V3 wi) {
     } else {
         Float denom = sqr(dot(wi, wm) + dot(wo, wm) / etap) * cos_theta_i * cos_theta_o;
         Float ft = b.mf.d(wm) * (1.0f - f) * b.mf.g(wo, wi) * abs(dot(wi, wm) * dot(wo, wm) / denom);
-        ft /= sqr(etap);  // TransportMode::Radiance
+        if (mode == MODE_RADIANCE) ft /= sqr(etap);
         return spec_const(ft);
     }
 }
-SHM_HD bool dielectric_sample_f(const BxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out) {
+SHM_HD bool dielectric_sample_f(const BaseBxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out, int mode = MODE_RADIANCE) {
     if (b.eta == 1.0f || b.mf.effectively_smooth()) {
         Float r = fresnel_dielectric(cos_theta(wo), b.eta);
         Float t = 1.0f - r;
@@ -322,7 +331,7 @@ SHM_HD bool dielectric_sample_f(const BxDF& b, V3 wo, Float uc, V2 u, uint32_t s
             V3 wi; Float etap;
             if (!refract(wo, v3(0.0f, 0.0f, 1.0f), b.eta, wi, etap)) return false;
             Spec ft = spec_const(t / abs_cos_theta(wi));
-            ft = ft / sqr(etap);  // Radiance
+            if (mode == MODE_RADIANCE) ft = ft / sqr(etap);
             out = bsdf_sample(ft, wi, pt / (pr + pt), BXDF_SPECULAR_TRANSMISSION, etap);
             return true;
         }
@@ -350,13 +359,13 @@ SHM_HD bool dielectric_sample_f(const BxDF& b, V3 wo, Float uc, V2 u, uint32_t s
             Float pdf = b.mf.pdf(wo, wm) * dwm_dwi * pt / (pr + pt);
             Spec ft = spec_const(t * b.mf.d(wm) * b.mf.g(wo, wi)
                                  * abs(dot(wi, wm) * dot(wo, wm) / (cos_theta(wi) * cos_theta(wo) * denom)));
-            ft = ft / sqr(etap);  // Radiance
+            if (mode == MODE_RADIANCE) ft = ft / sqr(etap);
             out = bsdf_sample(ft, wi, pdf, BXDF_GLOSSY_TRANSMISSION, etap);
             return true;
         }
     }
 }
-SHM_HD Float dielectric_pdf(const BxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
+SHM_HD Float dielectric_pdf(const BaseBxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
     if (b.eta == 1.0f || b.mf.effectively_smooth()) return 0.0f;
     Float cos_theta_o = cos_theta(wo);
     Float cos_theta_i = cos_theta(wi);
@@ -381,13 +390,13 @@ SHM_HD Float dielectric_pdf(const BxDF& b, V3 wo, V3 wi, uint32_t sample_flags) 
         return b.mf.pdf(wo, wm) * dwm_dwi * pt / (pr + pt);
     }
 }
-SHM_HD uint32_t dielectric_flags(const BxDF& b) {
+SHM_HD uint32_t dielectric_flags(const BaseBxDF& b) {
     uint32_t flags = (b.eta == 1.0f) ? BXDF_TRANSMISSION : (BXDF_REFLECTION | BXDF_TRANSMISSION);
     return flags | (b.mf.effectively_smooth() ? BXDF_SPECULAR : BXDF_GLOSSY);
 }
 
 // ---- ThinDielectricBxDF, bxdf.rs:797-881 ----
-SHM_HD bool thin_dielectric_sample_f(const BxDF& b, V3 wo, Float uc, uint32_t sample_flags, BSDFSample& out) {
+SHM_HD bool thin_dielectric_sample_f(const BaseBxDF& b, V3 wo, Float uc, uint32_t sample_flags, BSDFSample& out) {
     Float r = fresnel_dielectric(abs_cos_theta(wo), b.eta);
     Float t = 1.0f - r;
     if (r < 1.0f) {
@@ -408,8 +417,8 @@ SHM_HD bool thin_dielectric_sample_f(const BxDF& b, V3 wo, Float uc, uint32_t sa
     return true;
 }
 
-// ---- enum dispatch, bxdf.rs:105-182 ----
-SHM_HD uint32_t bxdf_flags(const BxDF& b) {
+// ---- enum dispatch over the single-layer BxDFs, bxdf.rs:105-182 ----
+SHM_HD uint32_t base_flags(const BaseBxDF& b) {
     switch (b.kind) {
         case SHM_MATERIAL_DIFFUSE: return is_zero(b.r) ? BXDF_UNSET : BXDF_DIFFUSE_REFLECTION;
         case SHM_MATERIAL_CONDUCTOR: return b.mf.effectively_smooth() ? BXDF_SPECULAR_REFLECTION : BXDF_GLOSSY_REFLECTION;
@@ -417,23 +426,23 @@ SHM_HD uint32_t bxdf_flags(const BxDF& b) {
         default: return BXDF_REFLECTION | BXDF_TRANSMISSION | BXDF_SPECULAR;
     }
 }
-SHM_HD Spec bxdf_f(const BxDF& b, V3 wo, V3 wi) {
+SHM_HD Spec base_f(const BaseBxDF& b, V3 wo, V3 wi, int mode = MODE_RADIANCE) {
     switch (b.kind) {
         case SHM_MATERIAL_DIFFUSE: return diffuse_f(b, wo, wi);
         case SHM_MATERIAL_CONDUCTOR: return conductor_f(b, wo, wi);
-        case SHM_MATERIAL_DIELECTRIC: return dielectric_f(b, wo, wi);
+        case SHM_MATERIAL_DIELECTRIC: return dielectric_f(b, wo, wi, mode);
         default: return spec_const(0.0f);
     }
 }
-SHM_HD bool bxdf_sample_f(const BxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out) {
+SHM_HD bool base_sample_f(const BaseBxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out, int mode = MODE_RADIANCE) {
     switch (b.kind) {
         case SHM_MATERIAL_DIFFUSE: return diffuse_sample_f(b, wo, u, sample_flags, out);
         case SHM_MATERIAL_CONDUCTOR: return conductor_sample_f(b, wo, u, sample_flags, out);
-        case SHM_MATERIAL_DIELECTRIC: return dielectric_sample_f(b, wo, uc, u, sample_flags, out);
+        case SHM_MATERIAL_DIELECTRIC: return dielectric_sample_f(b, wo, uc, u, sample_flags, out, mode);
         default: return thin_dielectric_sample_f(b, wo, uc, sample_flags, out);
     }
 }
-SHM_HD Float bxdf_pdf(const BxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
+SHM_HD Float base_pdf(const BaseBxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
     switch (b.kind) {
         case SHM_MATERIAL_DIFFUSE: return diffuse_pdf(b, wo, wi, sample_flags);
         case SHM_MATERIAL_CONDUCTOR: return conductor_pdf(b, wo, wi, sample_flags);
@@ -441,8 +450,328 @@ SHM_HD Float bxdf_pdf(const BxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
         default: return 0.0f;
     }
 }
+
+// ---- Henyey-Greenstein, scattering.rs:231-260; HGPhaseFunction, media.rs:8-40 (p == pdf) ----
+SHM_HD Float henyey_greenstein(Float cos_theta, Float g) {
+    g = clamp(g, -0.99f, 0.99f);
+    Float denom = 1.0f + sqr(g) + 2.0f * g * cos_theta;
+    return INV_4PI * (1.0f - sqr(g)) / (denom * safe_sqrt(denom));
+}
+SHM_HD Float hg_p(Float g, V3 wo, V3 wi) { return henyey_greenstein(dot(wo, wi), g); }
+SHM_HD V3 sample_henyey_greenstein(V3 wo, Float g, V2 u, Float& pdf) {
+    g = clamp(g, -0.99f, 0.99f);
+    Float cos_t;
+    if (abs(g) < 1e-3f) cos_t = 1.0f - 2.0f * u.x;
+    else cos_t = -1.0f / (2.0f * g) * (1.0f + sqr(g) - sqr((1.0f - sqr(g)) / (1.0f + g - 2.0f * g * u.x)));
+    Float sin_t = safe_sqrt(1.0f - sqr(cos_t));
+    Float phi = 2.0f * PI_F * u.y;
+    Frame w_frame = frame_from_z(wo);
+    V3 wi = w_frame.from_local(spherical_direction(sin_t, cos_t, phi));
+    pdf = henyey_greenstein(cos_t, g);
+    return wi;
+}
+// sampling.rs:789-792 (returns the exponential density at x, not a sample: reference behaviour preserved)
+SHM_HD Float sample_exponential(Float x, Float a) { return a * exp(-a * x); }
+
+// ---- LayeredBxDF<DielectricBxDF, DiffuseBxDF | ConductorBxDF, TWO_SIDED = true>, bxdf.rs:883-1620 ----
+// The reference draws the inner random walk from SmallRng::from_entropy() (bxdf.rs:1014, 1292, 1426: "TODO Use a seed for
+// this"), so its coated materials are not reproducible run to run. Defined here instead, the way PBRT-v4 does: a PCG32
+// stream seeded from a hash of the arguments of the call (parity at this boundary is unpinned: no reference value exists).
+SHM_HD uint64_t hash_f32(uint64_t h, Float x) { return mix_bits(h ^ ((uint64_t)float_to_bits(x) + 0x9e3779b97f4a7c15ULL)); }
+SHM_HD uint64_t hash_v3(uint64_t h, V3 v) { return hash_f32(hash_f32(hash_f32(h, v.x), v.y), v.z); }
+SHM_HD Rng layered_rng(uint64_t sequence, uint64_t seed) {
+    Rng r;
+    rng_set_sequence(r, sequence, seed);
+    return r;
+}
+SHM_HD Float layered_r(Rng& rng) { return min(sampler_get_1d(rng), ONE_MINUS_EPSILON); }  // the closure `r` of bxdf.rs:1015-1020
+SHM_HD V2 layered_r2(Rng& rng) { Float a = layered_r(rng); Float b = layered_r(rng); return v2(a, b); }
+
+SHM_HD BaseBxDF layered_top(const BxDF& l) {
+    BaseBxDF t;
+    t.kind = SHM_MATERIAL_DIELECTRIC; t.r = spec_const(0.0f); t.k = spec_const(0.0f); t.eta = l.eta; t.mf = l.mf;
+    return t;
+}
+SHM_HD BaseBxDF layered_bottom(const BxDF& l) {
+    BaseBxDF b;
+    b.kind = (l.kind == SHM_MATERIAL_COATED_DIFFUSE) ? (uint32_t)SHM_MATERIAL_DIFFUSE : (uint32_t)SHM_MATERIAL_CONDUCTOR;
+    b.r = l.r; b.k = l.k; b.eta = 1.0f; b.mf = l.mf2;
+    return b;
+}
+// LayeredBxDF::tr, bxdf.rs:925-933. `Float::MIN` is the most negative finite f32 there, so the early-out never fires.
+SHM_HD Float layered_tr(Float dz, V3 w) {
+    if (abs(dz) <= -3.40282347e+38f) return 1.0f;
+    return exp(-abs(dz / w.z));
+}
+SHM_HD bool sample_unusable(const BSDFSample& s) { return is_zero(s.f) || s.pdf == 0.0f || s.wi.z == 0.0f; }
+
+// LayeredBxDF::f, bxdf.rs:941-1218
+SHM_HD Spec layered_f(const BxDF& l, V3 wo, V3 wi, int mode) {
+    Spec f = spec_const(0.0f);
+    if (wo.z < 0.0f) { wo = -wo; wi = -wi; }  // TWO_SIDED
+    const bool entered_top = true;            // TWO_SIDED || wo.z > 0
+    const BaseBxDF top = layered_top(l), bottom = layered_bottom(l);
+    const BaseBxDF& enter_i = entered_top ? top : bottom;
+    const bool exit_is_bottom = same_hemisphere(wo, wi) ^ entered_top;
+    const BaseBxDF& exit_i = exit_is_bottom ? bottom : top;
+    const BaseBxDF& non_exit_i = exit_is_bottom ? top : bottom;
+    const Float exit_z = exit_is_bottom ? 0.0f : l.thickness;
+    const uint32_t exit_flags = base_flags(exit_i), non_exit_flags = base_flags(non_exit_i);
+    const Float n_samples_f = (Float)l.n_samples;
+    if (same_hemisphere(wo, wi)) f = base_f(enter_i, wo, wi, mode) * n_samples_f;
+    Rng rng = layered_rng(hash_v3(0x5eed0001ULL, wi), hash_v3(0ULL, wo));
+    const int wis_mode = (mode == MODE_RADIANCE) ? MODE_IMPORTANCE : MODE_RADIANCE;
+    for (int s = 0; s < l.n_samples; ++s) {
+        Float uc = layered_r(rng);
+        V2 u = layered_r2(rng);
+        BSDFSample wos;
+        if (!base_sample_f(enter_i, wo, uc, u, REFLTRANS_TRANSMISSION, wos, mode)) continue;
+        if (sample_unusable(wos)) continue;
+        uc = layered_r(rng);
+        u = layered_r2(rng);
+        BSDFSample wis;
+        if (!base_sample_f(exit_i, wi, uc, u, REFLTRANS_TRANSMISSION, wis, wis_mode)) continue;
+        if (sample_unusable(wis)) continue;
+        Spec beta = wos.f * abs_cos_theta(wos.wi) / wos.pdf;
+        Float z = entered_top ? l.thickness : 0.0f;
+        V3 w = wos.wi;
+        for (int depth = 0; depth < l.max_depth; ++depth) {
+            if (depth > 3 && max_component_value(beta) < 0.25f) {
+                Float q = max(0.0f, 1.0f - max_component_value(beta));
+                if (layered_r(rng) < q) break;
+                beta = beta / (1.0f - q);
+            }
+            if (is_zero(l.albedo)) {
+                z = (z == l.thickness) ? 0.0f : l.thickness;
+                beta = beta * layered_tr(l.thickness, w);
+            } else {
+                const Float sigma_t = 1.0f;
+                Float dz = sample_exponential(layered_r(rng), sigma_t / abs(w.z));
+                Float zp = (w.z > 0.0f) ? (z + dz) : (z - dz);
+                if (z == zp) continue;
+                if (0.0f < zp && zp < l.thickness) {
+                    Float wt = 1.0f;
+                    if (!flags_is_specular(exit_flags)) wt = power_heuristic(1, wis.pdf, 1, hg_p(l.g, -w, -wis.wi));
+                    f = f + beta * l.albedo * hg_p(l.g, -w, -wis.wi) * wt * layered_tr(zp - exit_z, wis.wi) * wis.f / wis.pdf;
+                    V2 up = layered_r2(rng);
+                    Float ps_pdf;
+                    V3 ps_wi = sample_henyey_greenstein(-w, l.g, up, ps_pdf);
+                    if (ps_pdf == 0.0f || ps_wi.z == 0.0f) continue;
+                    beta = beta * (l.albedo * ps_pdf / ps_pdf);
+                    w = ps_wi;
+                    z = zp;
+                    if (((z < exit_z && w.z > 0.0f) || (z > exit_z && w.z < 0.0f)) && !flags_is_specular(exit_flags)) {
+                        Spec f_exit = base_f(exit_i, -w, wi, mode);
+                        if (!is_zero(f_exit)) {
+                            Float exit_pdf = base_pdf(exit_i, -w, wi, REFLTRANS_TRANSMISSION);
+                            Float wt2 = power_heuristic(1, ps_pdf, 1, exit_pdf);
+                            f = f + beta * layered_tr(zp - exit_z, ps_wi) * f_exit * wt2;
+                        }
+                    }
+                    continue;
+                }
+                z = clamp(zp, 0.0f, l.thickness);
+            }
+            if (z == exit_z) {
+                Float uc2 = layered_r(rng);
+                V2 u2 = layered_r2(rng);
+                BSDFSample bs;
+                if (!base_sample_f(exit_i, -w, uc2, u2, REFLTRANS_REFLECTION, bs, mode)) break;
+                if (sample_unusable(bs)) break;
+                beta = beta * (bs.f * abs_cos_theta(bs.wi) / bs.pdf);
+                w = bs.wi;
+            } else {
+                if (!flags_is_specular(non_exit_flags)) {
+                    Float wt = 1.0f;
+                    if (!flags_is_specular(exit_flags)) wt = power_heuristic(1, wis.pdf, 1, base_pdf(non_exit_i, -w, -wis.wi, REFLTRANS_ALL));
+                    f = f + beta * base_f(non_exit_i, -w, -wis.wi, mode) * abs_cos_theta(wis.wi) * wt * layered_tr(l.thickness, wis.wi) * wis.f / wis.pdf;
+                }
+                Float uc2 = layered_r(rng);
+                V2 u2 = layered_r2(rng);
+                BSDFSample bs;
+                if (!base_sample_f(non_exit_i, -w, uc2, u2, REFLTRANS_REFLECTION, bs, mode)) break;
+                if (sample_unusable(bs)) break;
+                beta = beta * (bs.f * abs_cos_theta(bs.wi) / bs.pdf);
+                w = bs.wi;
+                if (!flags_is_specular(exit_flags)) {
+                    Spec f_exit = base_f(exit_i, -w, wi, mode);
+                    if (!is_zero(f_exit)) {
+                        Float wt = 1.0f;
+                        if (!flags_is_specular(non_exit_flags)) {
+                            Float exit_pdf = base_pdf(exit_i, -w, wi, REFLTRANS_TRANSMISSION);
+                            wt = power_heuristic(1, bs.pdf, 1, exit_pdf);
+                        }
+                        f = f + beta * layered_tr(l.thickness, bs.wi) * f_exit * wt;
+                    }
+                }
+            }
+        }
+    }
+    return f / n_samples_f;
+}
+
+// LayeredBxDF::sample_f, bxdf.rs:1220-1404 (sample_flags must be ALL there: assert)
+SHM_HD bool layered_sample_f(const BxDF& l, V3 wo, Float uc, V2 u, int mode, BSDFSample& out) {
+    bool flip_wi = false;
+    if (wo.z < 0.0f) { wo = -wo; flip_wi = true; }  // TWO_SIDED
+    const bool entered_top = true;
+    const BaseBxDF top = layered_top(l), bottom = layered_bottom(l);
+    BSDFSample bs;
+    if (!base_sample_f(entered_top ? top : bottom, wo, uc, u, REFLTRANS_ALL, bs, mode)) return false;
+    if (sample_unusable(bs)) return false;
+    if (flags_is_reflective(bs.flags)) {
+        if (flip_wi) bs.wi = -bs.wi;
+        bs.pdf_is_proportional = true;
+        out = bs;
+        return true;
+    }
+    V3 w = bs.wi;
+    bool specular_path = flags_is_specular(bs.flags);
+    Rng rng = layered_rng(hash_f32(hash_f32(hash_f32(0x5eed0002ULL, uc), u.x), u.y), hash_v3(0ULL, wo));
+    Spec f = bs.f * abs_cos_theta(bs.wi);
+    Float pdf = bs.pdf;
+    Float z = entered_top ? l.thickness : 0.0f;
+    for (int depth = 0; depth < l.max_depth; ++depth) {
+        Float rr_beta = max_component_value(f) / pdf;
+        if (depth > 3 && rr_beta < 0.25f) {
+            Float q = max(0.0f, 1.0f - rr_beta);
+            if (layered_r(rng) < q) return false;
+            pdf *= 1.0f - q;
+        }
+        if (w.z == 0.0f) return false;
+        if (!is_zero(l.albedo)) {
+            const Float sigma_t = 1.0f;
+            Float dz = sample_exponential(layered_r(rng), sigma_t / abs_cos_theta(w));
+            Float zp = (w.z > 0.0f) ? (z + dz) : (z - dz);
+            if (zp == z) return false;
+            if (0.0f < zp && zp < l.thickness) {
+                V2 up = layered_r2(rng);
+                Float ps_pdf;
+                V3 ps_wi = sample_henyey_greenstein(-w, l.g, up, ps_pdf);
+                if (ps_pdf == 0.0f || ps_wi.z == 0.0f) return false;
+                f = f * (l.albedo * ps_pdf);
+                pdf *= ps_pdf;
+                specular_path = false;
+                w = ps_wi;
+                z = zp;
+                continue;
+            }
+            z = clamp(zp, 0.0f, l.thickness);
+        } else {
+            z = (z == l.thickness) ? 0.0f : l.thickness;
+            f = f * layered_tr(l.thickness, w);
+        }
+        const BaseBxDF& iface = (z == 0.0f) ? bottom : top;
+        Float uc2 = layered_r(rng);
+        V2 u2 = layered_r2(rng);
+        BSDFSample s2;
+        if (!base_sample_f(iface, -w, uc2, u2, REFLTRANS_ALL, s2, mode)) return false;
+        if (sample_unusable(s2)) return false;
+        f = f * s2.f;
+        pdf *= s2.pdf;
+        specular_path = specular_path && flags_is_specular(s2.flags);
+        w = s2.wi;
+        if (flags_is_transmissive(s2.flags)) {
+            uint32_t flags = same_hemisphere(wo, w) ? BXDF_REFLECTION : BXDF_TRANSMISSION;
+            flags |= specular_path ? BXDF_SPECULAR : BXDF_GLOSSY;
+            if (flip_wi) w = -w;
+            out = bsdf_sample(f, w, pdf, flags, 1.0f);
+            out.pdf_is_proportional = true;
+            return true;
+        }
+        f = f * abs_cos_theta(s2.wi);
+    }
+    return false;
+}
+
+// LayeredBxDF::pdf, bxdf.rs:1406-1575 (sample_flags must be ALL there: assert)
+SHM_HD Float layered_pdf(const BxDF& l, V3 wo, V3 wi, int mode) {
+    if (wo.z < 0.0f) { wo = -wo; wi = -wi; }  // TWO_SIDED
+    Rng rng = layered_rng(hash_v3(0x5eed0003ULL, wo), hash_v3(0ULL, wi));
+    const bool entered_top = true;
+    const BaseBxDF top = layered_top(l), bottom = layered_bottom(l);
+    const Float n_samples_f = (Float)l.n_samples;
+    const int wis_mode = (mode == MODE_RADIANCE) ? MODE_IMPORTANCE : MODE_RADIANCE;
+    Float pdf_sum = 0.0f;
+    if (same_hemisphere(wo, wi)) pdf_sum += n_samples_f * base_pdf(entered_top ? top : bottom, wo, wi, REFLTRANS_REFLECTION);
+    for (int s = 0; s < l.n_samples; ++s) {
+        if (same_hemisphere(wo, wi)) {
+            const BaseBxDF& r_i = entered_top ? bottom : top;
+            const BaseBxDF& t_i = entered_top ? top : bottom;
+            const uint32_t r_flags = base_flags(r_i), t_flags = base_flags(t_i);
+            Float uc = layered_r(rng);
+            V2 u = layered_r2(rng);
+            BSDFSample wos, wis;
+            bool have_wos = base_sample_f(t_i, wo, uc, u, REFLTRANS_TRANSMISSION, wos, mode);
+            uc = layered_r(rng);
+            u = layered_r2(rng);
+            bool have_wis = base_sample_f(t_i, wi, uc, u, REFLTRANS_TRANSMISSION, wis, wis_mode);
+            if (have_wos && have_wis && !is_zero(wos.f) && wos.pdf > 0.0f && !is_zero(wis.f) && wis.pdf > 0.0f) {
+                if (!flags_is_non_specular(t_flags)) {
+                    pdf_sum += base_pdf(r_i, -wos.wi, -wis.wi, REFLTRANS_ALL);
+                } else {
+                    uc = layered_r(rng);
+                    u = layered_r2(rng);
+                    BSDFSample rs;
+                    if (base_sample_f(r_i, -wos.wi, uc, u, REFLTRANS_ALL, rs, mode)) {
+                        if (!flags_is_non_specular(r_flags)) {
+                            pdf_sum += base_pdf(t_i, -rs.wi, wi, REFLTRANS_ALL);
+                        } else {
+                            Float r_pdf = base_pdf(r_i, -wos.wi, -wis.wi, REFLTRANS_ALL);
+                            Float wt = power_heuristic(1, wis.pdf, 1, r_pdf);
+                            pdf_sum += wt * r_pdf;
+                            Float t_pdf = base_pdf(t_i, -rs.wi, wi, REFLTRANS_ALL);
+                            wt = power_heuristic(1, rs.pdf, 1, t_pdf);
+                            pdf_sum += wt * t_pdf;
+                        }
+                    }
+                }
+            }
+        } else {
+            const BaseBxDF& to_i = entered_top ? top : bottom;
+            const BaseBxDF& ti_i = entered_top ? bottom : top;
+            Float uc = layered_r(rng);
+            V2 u = layered_r2(rng);
+            BSDFSample wos;
+            if (!base_sample_f(to_i, wo, uc, u, REFLTRANS_ALL, wos, mode)) continue;
+            if (sample_unusable(wos) || flags_is_reflective(wos.flags)) continue;
+            uc = layered_r(rng);
+            u = layered_r2(rng);
+            BSDFSample wis;
+            if (!base_sample_f(ti_i, wi, uc, u, REFLTRANS_ALL, wis, wis_mode)) continue;
+            if (sample_unusable(wis) || flags_is_reflective(wis.flags)) continue;
+            if (flags_is_specular(base_flags(to_i))) pdf_sum += base_pdf(ti_i, -wos.wi, wi, REFLTRANS_ALL);
+            else if (flags_is_specular(base_flags(ti_i))) pdf_sum += base_pdf(to_i, wo, -wis.wi, REFLTRANS_ALL);
+            else pdf_sum += (base_pdf(to_i, wo, -wis.wi, REFLTRANS_ALL) + base_pdf(ti_i, -wos.wi, wi, REFLTRANS_ALL)) / 2.0f;
+        }
+    }
+    return lerp(0.9f, 1.0f / (4.0f * PI_F), pdf_sum / n_samples_f);
+}
+// LayeredBxDF::flags, bxdf.rs:1577-1606
+SHM_HD uint32_t layered_flags(const BxDF& l) {
+    uint32_t tf = base_flags(layered_top(l)), bf = base_flags(layered_bottom(l));
+    uint32_t flags = BXDF_REFLECTION;
+    if (flags_is_specular(tf)) flags |= BXDF_SPECULAR;
+    if ((tf & BXDF_DIFFUSE) || (bf & BXDF_DIFFUSE) || !is_zero(l.albedo)) flags |= BXDF_DIFFUSE;
+    else if ((tf & BXDF_GLOSSY) || (bf & BXDF_GLOSSY)) flags |= BXDF_GLOSSY;
+    if (flags_is_transmissive(tf) && flags_is_transmissive(bf)) flags |= BXDF_TRANSMISSION;
+    return flags;
+}
+
+// ---- enum dispatch with the coated BxDFs, bxdf.rs:105-182 ----
+SHM_HD bool bxdf_is_layered(const BxDF& b) { return b.kind == SHM_MATERIAL_COATED_DIFFUSE || b.kind == SHM_MATERIAL_COATED_CONDUCTOR; }
+SHM_HD uint32_t bxdf_flags(const BxDF& b) { return bxdf_is_layered(b) ? layered_flags(b) : base_flags(b); }
+SHM_HD Spec bxdf_f(const BxDF& b, V3 wo, V3 wi) { return bxdf_is_layered(b) ? layered_f(b, wo, wi, MODE_RADIANCE) : base_f(b, wo, wi); }
+SHM_HD bool bxdf_sample_f(const BxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out) {
+    if (bxdf_is_layered(b)) return layered_sample_f(b, wo, uc, u, MODE_RADIANCE, out);
+    return base_sample_f(b, wo, uc, u, sample_flags, out);
+}
+SHM_HD Float bxdf_pdf(const BxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
+    return bxdf_is_layered(b) ? layered_pdf(b, wo, wi, MODE_RADIANCE) : base_pdf(b, wo, wi, sample_flags);
+}
 SHM_HD void bxdf_regularize(BxDF& b) {
-    if (b.kind == SHM_MATERIAL_CONDUCTOR || b.kind == SHM_MATERIAL_DIELECTRIC) b.mf.regularize();
+    if (b.kind == SHM_MATERIAL_CONDUCTOR || b.kind == SHM_MATERIAL_DIELECTRIC || bxdf_is_layered(b)) b.mf.regularize();
+    if (b.kind == SHM_MATERIAL_COATED_CONDUCTOR) b.mf2.regularize();
 }
 
 // ---- BSDF, bsdf.rs:9-111 ----

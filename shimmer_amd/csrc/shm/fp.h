@@ -38,6 +38,7 @@ constexpr Float PI_F = 3.14159265358979323846f;          // float.rs:14 (std::f3
 constexpr Float INV_PI = 0.31830988618379067154f;        // math.rs:13
 constexpr Float INV_2PI = 0.15915494309189533577f;       // math.rs:14
 constexpr Float INV_4PI = 0.07957747154594766788f;       // math.rs:15
+constexpr Float ONE_MINUS_EPSILON = 0.99999994f;         // next_float_down(1.0) = 0x3f7fffff (bxdf.rs:1019)
 constexpr Float PI_OVER_4 = 0.78539816339744830961f;     // math.rs:16
 constexpr Float PI_OVER_2 = 1.57079632679489661923f;     // math.rs:17
 constexpr Float MACHINE_EPSILON = 1.1920928955078125e-7f * 0.5f;  // float.rs:19 (f32::EPSILON * 0.5)

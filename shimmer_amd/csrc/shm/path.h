@@ -115,6 +115,13 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
     b.eta = 1.0f;
     b.mf.alpha_x = 0.0f;
     b.mf.alpha_y = 0.0f;
+    b.mf2.alpha_x = 0.0f;
+    b.mf2.alpha_y = 0.0f;
+    b.thickness = 0.0f;
+    b.g = 0.0f;
+    b.albedo = spec_const(0.0f);
+    b.max_depth = 0;
+    b.n_samples = 1;
     if (m.kind == SHM_MATERIAL_DIFFUSE) {
         b.r = clamp(spectrum_sample(m.a, sv.spectrum_data, lambda), 0.0f, 1.0f);  // material.rs:301-311
     } else if (m.kind == SHM_MATERIAL_CONDUCTOR) {  // material.rs:456-499
@@ -131,11 +138,56 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
         if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
         b.eta = sampled_eta;
         b.mf = trowbridge_reitz_new(ur, vr);
-    } else {  // ThinDielectric, material.rs:723-742
+    } else if (m.kind == SHM_MATERIAL_THIN_DIELECTRIC) {  // material.rs:723-742
         Float sampled_eta = spectrum_get(m.a, sv.spectrum_data, lambda.lambda[0]);
         if (m.a.kind != SHM_SPECTRUM_CONSTANT) terminate_secondary(lambda);
         if (sampled_eta == 0.0f) sampled_eta = 1.0f;
         b.eta = sampled_eta;
+    } else if (m.kind == SHM_MATERIAL_COATED_DIFFUSE) {  // material.rs:917-963
+        b.r = clamp(spectrum_sample(m.a, sv.spectrum_data, lambda), 0.0f, 1.0f);
+        Float ur = m.u_roughness, vr = m.v_roughness;
+        if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+        b.mf = trowbridge_reitz_new(ur, vr);
+        b.thickness = m.thickness;
+        Float sampled_eta = spectrum_get(m.d, sv.spectrum_data, lambda.lambda[0]);
+        if (m.d.kind != SHM_SPECTRUM_CONSTANT) terminate_secondary(lambda);
+        if (sampled_eta == 0.0f) sampled_eta = 1.0f;
+        b.eta = sampled_eta;
+        b.albedo = clamp(spectrum_sample(m.c, sv.spectrum_data, lambda), 0.0f, 1.0f);
+        b.g = clamp(m.g, -1.0f, 1.0f);
+        b.max_depth = m.max_depth;
+        b.n_samples = m.n_samples;
+    } else {  // CoatedConductor, material.rs:1189-1256
+        Float iur = m.u_roughness, ivr = m.v_roughness;
+        if (m.remap_roughness) { iur = roughness_to_alpha(iur); ivr = roughness_to_alpha(ivr); }
+        b.mf = trowbridge_reitz_new(iur, ivr);
+        b.thickness = m.thickness;
+        Float ieta = spectrum_get(m.d, sv.spectrum_data, lambda.lambda[0]);
+        if (m.d.kind != SHM_SPECTRUM_CONSTANT) terminate_secondary(lambda);
+        if (ieta == 0.0f) ieta = 1.0f;
+        Spec ce, ck;
+        if (!m.conductor_from_reflectance) {
+            ce = spectrum_sample(m.a, sv.spectrum_data, lambda);
+            ck = spectrum_sample(m.b, sv.spectrum_data, lambda);
+        } else {
+            Spec r = clamp(spectrum_sample(m.a, sv.spectrum_data, lambda), 0.0f, 0.9999f);  // "avoid r == 1 NaN case"
+            ce = spec_const(1.0f);
+            ck = 2.0f * spec_sqrt(r) / spec_sqrt(clamp_zero(spec_const(1.0f) - r));
+        }
+        ce = ce / ieta;
+        ck = ck / ieta;
+        Float cur = m.u2_roughness, cvr = m.v2_roughness;
+        // material.rs:1239-1243: with remap_roughness the conductor's alphas are derived from the (already remapped)
+        // INTERFACE roughness, not from its own: reference behaviour preserved
+        if (m.remap_roughness) { cur = roughness_to_alpha(iur); cvr = roughness_to_alpha(ivr); }
+        b.mf2 = trowbridge_reitz_new(cur, cvr);
+        b.r = ce;
+        b.k = ck;
+        b.eta = ieta;
+        b.albedo = clamp(spectrum_sample(m.c, sv.spectrum_data, lambda), 0.0f, 1.0f);
+        b.g = clamp(m.g, -1.0f, 1.0f);
+        b.max_depth = m.max_depth;
+        b.n_samples = m.n_samples;
     }
     return bsdf_new(si.shading.n, si.shading.dpdu, b);
 }

@@ -41,6 +41,8 @@ SHM_HD Spec safe_div(const Spec& a, const Spec& b) {
     for (int i = 0; i < NSPEC; ++i) r.v[i] = (b.v[i] != 0.0f) ? a.v[i] / b.v[i] : 0.0f;
     return r;
 }
+SHM_HD Spec clamp_zero(const Spec& a) { Spec r; for (int i = 0; i < NSPEC; ++i) r.v[i] = max(0.0f, a.v[i]); return r; }  // sampled_spectrum.rs:61-68
+SHM_HD Spec spec_sqrt(const Spec& a) { Spec r; for (int i = 0; i < NSPEC; ++i) r.v[i] = sqrt(a.v[i]); return r; }          // sampled_spectrum.rs:312-319
 SHM_HD Spec clamp(const Spec& a, Float lo, Float hi) { Spec r; for (int i = 0; i < NSPEC; ++i) r.v[i] = clamp(a.v[i], lo, hi); return r; }
 // sampled_spectrum.rs:102-104: iter().sum() / len
 SHM_HD Float average(const Spec& a) {

@@ -184,6 +184,40 @@ class SceneBuilder:
         self.materials.append(m)
         return len(self.materials) - 1
 
+    def _spec(self, v):
+        return v if isinstance(v, abi.ShmSpectrum) else self.spectrum_constant(v)
+
+    def material_coated_diffuse(self, reflectance=0.5, roughness=0.0, thickness=0.01, eta=1.5, g=0.0, albedo=0.0, max_depth=10,
+                                n_samples=1, remap=True):
+        """CoatedDiffuseMaterial::create defaults (material.rs:826-911): no displacement texture unless given."""
+        m = abi.ShmMaterial()
+        m.kind = abi.SHM_MATERIAL_COATED_DIFFUSE
+        m.remap_roughness, m.u_roughness, m.v_roughness = int(remap), float(roughness), float(roughness)
+        m.thickness, m.g, m.max_depth, m.n_samples = float(thickness), float(g), int(max_depth), int(n_samples)
+        m.a, m.c, m.d = self._spec(reflectance), self._spec(albedo), self._spec(eta)
+        m.b = self.spectrum_constant(0.0)
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def material_coated_conductor(self, conductor_eta=None, k=None, reflectance=None, interface_roughness=0.0, conductor_roughness=0.0,
+                                  thickness=0.01, interface_eta=1.5, g=0.0, albedo=0.0, max_depth=10, n_samples=1, remap=True):
+        """CoatedConductorMaterial::create (material.rs:1052-1180): conductor given by (eta, k) spectra — default
+        metal-Cu — or by a reflectance."""
+        m = abi.ShmMaterial()
+        m.kind = abi.SHM_MATERIAL_COATED_CONDUCTOR
+        m.remap_roughness, m.u_roughness, m.v_roughness = int(remap), float(interface_roughness), float(interface_roughness)
+        m.u2_roughness, m.v2_roughness = float(conductor_roughness), float(conductor_roughness)
+        m.thickness, m.g, m.max_depth, m.n_samples = float(thickness), float(g), int(max_depth), int(n_samples)
+        if reflectance is not None:
+            m.conductor_from_reflectance = 1
+            m.a, m.b = self._spec(reflectance), self.spectrum_constant(0.0)
+        else:
+            m.a = conductor_eta if conductor_eta is not None else self.spectrum_named("metal-Cu-eta")
+            m.b = k if k is not None else self.spectrum_named("metal-Cu-k")
+        m.c, m.d = self._spec(albedo), self._spec(interface_eta)
+        self.materials.append(m)
+        return len(self.materials) - 1
+
     # ---- lights ----
     def _area_light(self, prim_index, area, dense_emission, scale, two_sided):
         """DiffuseAreaLight::create: scale /= spectrum_to_photometric(L) (light.rs:598)."""

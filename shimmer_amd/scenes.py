@@ -83,8 +83,10 @@ def _two_point_spectrum(b, lo, hi):
     return b.spectrum_piecewise(np.array([359.0, 831.0], np.float32), np.array([lo, hi], np.float32))
 
 
-def cornell_box(lib, width=512, height=512):
-    """S2 (config C2): 5 walls x 2 + 2 boxes x 5 faces x 2 + light 2 = 32 triangles."""
+def cornell_box(lib, width=512, height=512, coated=False):
+    """S2 (config C2): 5 walls x 2 + 2 boxes x 5 faces x 2 + light 2 = 32 triangles.
+    coated=True: the tall box becomes CoatedConductor (rough interface, Cu), the short one CoatedDiffuse with a scattering
+    medium between the interfaces, the floor CoatedDiffuse with a smooth interface (SURVEY §8f-1 materials)."""
     b = SceneBuilder()
     b.set_film(width, height)
     rfw = b.set_camera_look_at(lib, (0, 1, 3.4), (0, 1, 0), (0, 1, 0), 39.0)
@@ -92,6 +94,11 @@ def cornell_box(lib, width=512, height=512):
     red = b.material_diffuse(_two_point_spectrum(b, 0.05, 0.75))
     green = b.material_diffuse(_two_point_spectrum(b, 0.6, 0.08))
     black = b.material_diffuse(0.0)
+    tall_m = short_m = floor_m = white
+    if coated:
+        tall_m = b.material_coated_conductor(interface_roughness=0.05, conductor_roughness=0.2, thickness=0.02)
+        short_m = b.material_coated_diffuse(reflectance=_two_point_spectrum(b, 0.1, 0.7), roughness=0.1, thickness=0.05, albedo=0.6, g=0.3)
+        floor_m = b.material_coated_diffuse(reflectance=0.6, roughness=0.0, eta=b.spectrum_named("glass-BK7"))
     # room [-1,1] x [0,2] x [-1,1], open towards +z (camera side); inward-facing windings via reversed quads
     def inward(q):
         p, vi = q
@@ -101,8 +108,9 @@ def cornell_box(lib, width=512, height=512):
     back = _quad((-1, 0, -1), (-1, 2, -1), (1, 2, -1), (1, 0, -1))
     left = _quad((-1, 0, -1), (-1, 0, 1), (-1, 2, 1), (-1, 2, -1))
     right = inward(_quad((1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1)))
-    p, vi = _merge([floor, ceil_, back])
+    p, vi = _merge([ceil_, back])
     b.add_mesh(_to_render(p, rfw), vi, white)
+    b.add_mesh(_to_render(floor[0], rfw), floor[1], floor_m)
     p, vi = left
     b.add_mesh(_to_render(p, rfw), vi, red)
     p, vi = right
@@ -115,13 +123,13 @@ def cornell_box(lib, width=512, height=512):
         out = np.stack([c * q[:, 0] + s * q[:, 2], q[:, 1], -s * q[:, 0] + c * q[:, 2]], axis=1)
         return (out + centre).astype(np.float32)
     p, vi = _box((-0.75, 0.0, -0.65), (-0.15, 1.2, -0.05), faces="xXYzZ")
-    b.add_mesh(_to_render(rot_y(p, 18.0, np.array([-0.45, 0, -0.35], np.float32)), rfw), vi, white)
+    b.add_mesh(_to_render(rot_y(p, 18.0, np.array([-0.45, 0, -0.35], np.float32)), rfw), vi, tall_m)
     p, vi = _box((0.1, 0.0, 0.0), (0.7, 0.6, 0.6), faces="xXYzZ")
-    b.add_mesh(_to_render(rot_y(p, -17.0, np.array([0.4, 0, 0.3], np.float32)), rfw), vi, white)
+    b.add_mesh(_to_render(rot_y(p, -17.0, np.array([0.4, 0, 0.3], np.float32)), rfw), vi, short_m)
     # ceiling light, facing down
     p, vi = _quad((-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (0.3, 1.98, 0.3), (-0.3, 1.98, 0.3))
     b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=20.0)
-    return _finish(b, lib, name="S2 cornell box")
+    return _finish(b, lib, name="S2 cornell box" + (" (coated)" if coated else ""))
 
 
 def _hash3(ix, iy, iz, seed):
@@ -196,12 +204,13 @@ def cube_sphere(n, seed=1234, amplitude=0.15, shuffle_seed=99):
     return verts, tris
 
 
-def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True):
-    """S3 (configs C3/C5): n=599 gives 6*599^2*2 = 4 305 612 triangles and 2 152 808 vertices."""
+def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=False):
+    """S3 (configs C3/C5): n=599 gives 6*599^2*2 = 4 305 612 triangles and 2 152 808 vertices.
+    coated=True: the object is CoatedDiffuse (the material of the reference's Ganesha render, images/shimmer-ganesha-1.png)."""
     b = SceneBuilder()
     b.set_film(width, height)
     rfw = b.set_camera_look_at(lib, (0.0, 0.6, 4.2), (0.0, 0.0, 0.0), (0, 1, 0), 38.0)
-    obj = b.material_diffuse(0.4)
+    obj = b.material_coated_diffuse(reflectance=0.4, roughness=0.05, thickness=0.01) if coated else b.material_diffuse(0.4)
     wall = b.material_diffuse(0.6)
     black = b.material_diffuse(0.0)
     verts, tris = cube_sphere(n)
@@ -221,7 +230,7 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True):
         # window emitter high on the left, facing +x/-y into the room (one-sided)
         p, vi = _quad((-3.9, 1.0, -1.5), (-3.9, 3.0, -1.5), (-3.9, 3.0, 1.5), (-3.9, 1.0, 1.5))
         b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=40.0)
-    return _finish(b, lib, name=f"S3 ganesha-proxy n={n}")
+    return _finish(b, lib, name=f"S3 ganesha-proxy n={n}" + (" (coated)" if coated else ""))
 
 
 def icosphere(level):

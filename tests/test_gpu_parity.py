@@ -42,6 +42,9 @@ SCENES = {
     "S3_small": lambda scenes, lib: (scenes.ganesha_proxy(lib, 96, 96, n=48), 8, 5),
     "S4_small_depth32": lambda scenes, lib: (scenes.crown_proxy(lib, 60, 84, level=2, n_glass=12, n_gold=4), 8, 32),
     "three_spheres": lambda scenes, lib: (scenes.three_spheres(lib, 48, 32, camera=(0.75, 0.5, 9.0)), 4, 5),
+    # LayeredBxDF materials (CoatedDiffuse with and without a scattering medium, CoatedConductor)
+    "S2_cornell_coated": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, coated=True), 8, 5),
+    "S3_small_coated": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, coated=True), 4, 5),
 }
 
 

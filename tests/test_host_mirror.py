@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_struct_layouts_match_header():
     assert C.sizeof(abi.ShmBvhNode) == 32 and C.sizeof(abi.ShmPrimitive) == 16 and C.sizeof(abi.ShmSpectrum) == 32
     assert C.sizeof(abi.ShmRay) == 32 and C.sizeof(abi.ShmHit) == 32 and C.sizeof(abi.ShmFilmPixel) == 32 and C.sizeof(abi.ShmTile) == 16
-    assert C.sizeof(abi.ShmMaterial) == 32 + 64 and C.sizeof(abi.ShmLight) == 32 + 32 and C.sizeof(abi.ShmRenderParams) == 24
+    assert C.sizeof(abi.ShmMaterial) == 64 + 4 * 32 and C.sizeof(abi.ShmLight) == 32 + 32 and C.sizeof(abi.ShmRenderParams) == 24
 
 
 def test_no_device_is_a_loud_error_not_a_fallback(lib):
