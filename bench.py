@@ -149,7 +149,7 @@ def main():
         st = r.render_device(params, my_tiles)
         film = None
         if use_dist:
-            film = render.gather_film(render.film_tensor(r, device), rank, world, r.height, r.width)
+            film = render.gather_film(render.film_tensor(r, device), rank, world, r.height, r.width, to_host=False)
         return st, film
 
     for _ in range(args.warmup):
@@ -208,15 +208,24 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(sc, params, lib)
             except Exception as e:  # the baseline is reporting only; never let it hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
     if use_dist and rank == 0 and film is not None:
         # the gathered film must equal what this rank's library holds when it is the only rank (self-check of the gather)
-        if world == 1 and not np.array_equal(film, r.read_film()):
+        host = film.cpu().numpy().view(render.FILM_DTYPE).reshape(r.height, r.width)
+        if world == 1 and not np.array_equal(host, r.read_film()):
             raise SystemExit("film gather mismatch")
+        if not (host["weight_sum"] == float(args.spp)).all():  # every pixel of the frame received all its samples, from some rank
+            raise SystemExit("gathered film is incomplete")
     r.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which is flushed at exit: flush it now so that the JSON line is the
+        # last thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -140,10 +140,12 @@ def film_tensor(renderer, device=None):
     return torch.from_numpy(renderer.read_film().view(np.float64).reshape(-1).copy())
 
 
-def gather_film(local, rank, world_size, height, width):
+def gather_film(local, rank, world_size, height, width, to_host=True):
     """C1 of SURVEY §2.1: gather the per-rank film slabs (flat float64 tensors) to rank 0 over RCCL (backend
     'nccl' on ROCm; 'gloo' in the CPU tests).  Pixel ownership is exclusive (tiles are disjoint) and untouched
-    pixels are exactly 0.0, so adding the slabs reproduces the single-process film bit for bit."""
+    pixels are exactly 0.0, so adding the slabs reproduces the single-process film bit for bit.
+    to_host=False leaves the summed film on rank 0's device (a flat float64 tensor): the read-back is the caller's business
+    (the reference writes its image once at the end, integrator.rs:311-321) and stays out of a timed region."""
     import torch
     import torch.distributed as dist
 
@@ -154,4 +156,6 @@ def gather_film(local, rank, world_size, height, width):
     total = gathered[0].clone()
     for g in gathered[1:]:
         total += g
+    if not to_host:
+        return total
     return total.cpu().numpy().view(FILM_DTYPE).reshape(height, width)
