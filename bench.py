@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--coated", action="store_true", help="S3 with a CoatedDiffuse object (LayeredBxDF, SURVEY 8f-1) instead of the "
                     "headline diffuse one: a side measurement, not the BASELINE config")
+    ap.add_argument("--shard-of", type=int, default=0, help="development: render only the tiles rank 0 of N would own (no gather), "
+                    "to estimate the per-rank time of an N-GPU run on one GPU")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL init + film gather path even with one rank")
     args = ap.parse_args()
 
@@ -138,6 +140,8 @@ def main():
         log(f"[bench] scene {sc.name}: {sc.info['n_primitives']} prims, {sc.info['n_nodes']} nodes; build {t_scene:.1f}s, upload {t_upload:.2f}s")
     params = render.make_params(seed=args.seed, spp=args.spp, max_depth=args.max_depth)
     my_tiles = None if world == 1 else render.shard_tiles(r.n_tiles, r.tiles_per_row, rank, world)
+    if world == 1 and args.shard_of > 1:
+        my_tiles = render.shard_tiles(r.n_tiles, r.tiles_per_row, 0, args.shard_of)
 
     def barrier():
         if use_dist:
