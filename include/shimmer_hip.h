@@ -116,7 +116,10 @@ enum {
     SHM_MATERIAL_DIELECTRIC = 2,      /* material.rs:518-650 */
     SHM_MATERIAL_THIN_DIELECTRIC = 3, /* material.rs:652-768 */
     SHM_MATERIAL_COATED_DIFFUSE = 4,  /* material.rs:772-1005: LayeredBxDF<Dielectric, Diffuse, two-sided> (bxdf.rs:269-290, 883-1620) */
-    SHM_MATERIAL_COATED_CONDUCTOR = 5 /* material.rs:1007-1286: LayeredBxDF<Dielectric, Conductor, two-sided> (bxdf.rs:460-480) */
+    SHM_MATERIAL_COATED_CONDUCTOR = 5,/* material.rs:1007-1286: LayeredBxDF<Dielectric, Conductor, two-sided> (bxdf.rs:460-480) */
+    SHM_MATERIAL_MIX = 6              /* material.rs:1288-1330: MixMaterial, resolved per hit in get_bsdf (interaction.rs:205-220).
+                                         The reference draws the choice from the tile's entropy-seeded SmallRng (integrator.rs:255);
+                                         here it is a hash of (wo, p), the way PBRT-v4 defines it: reproducible, parity unpinned. */
 };
 /* Constant textures only (image textures are a "next" row). */
 typedef struct ShmMaterial {
@@ -130,7 +133,8 @@ typedef struct ShmMaterial {
     float thickness, g;               /* Coated*: layer thickness, HG asymmetry of the medium between the interfaces */
     int32_t max_depth, n_samples;     /* Coated*: random-walk depth and walks per evaluation (defaults 10, 1) */
     uint32_t conductor_from_reflectance; /* CoatedConductor: `a` is a reflectance (material.rs:1224-1231), not eta */
-    uint32_t pad[3];
+    uint32_t mix_material[2];         /* Mix: indices into the material table (may themselves be Mix; no cycles) */
+    float mix_amount;                 /* Mix: constant `amount` texture (default 0.5): <= 0 -> [0], >= 1 -> [1], else [amount < u ? 0 : 1] */
     ShmSpectrum a;  /* Diffuse / CoatedDiffuse: reflectance; Conductor / CoatedConductor: eta (or reflectance); Dielectric/Thin: eta */
     ShmSpectrum b;  /* Conductor / CoatedConductor: k */
     ShmSpectrum c;  /* Coated*: albedo of the medium */

@@ -15,7 +15,7 @@ SHM_OK = 0
 SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE = 0, 1
 SHM_SPECTRUM_CONSTANT, SHM_SPECTRUM_DENSE, SHM_SPECTRUM_PIECEWISE_LINEAR = 0, 1, 2
 SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATERIAL_THIN_DIELECTRIC = 0, 1, 2, 3
-SHM_MATERIAL_COATED_DIFFUSE, SHM_MATERIAL_COATED_CONDUCTOR = 4, 5
+SHM_MATERIAL_COATED_DIFFUSE, SHM_MATERIAL_COATED_CONDUCTOR, SHM_MATERIAL_MIX = 4, 5, 6
 SHM_LIGHT_POINT, SHM_LIGHT_DIFFUSE_AREA, SHM_LIGHT_UNIFORM_INFINITE = 0, 1, 2
 
 c_float_p = C.POINTER(C.c_float)
@@ -54,7 +54,7 @@ class ShmMaterial(C.Structure):
                 ("remap_roughness", C.c_uint32), ("u_roughness", C.c_float), ("v_roughness", C.c_float),
                 ("u2_roughness", C.c_float), ("v2_roughness", C.c_float), ("thickness", C.c_float), ("g", C.c_float),
                 ("max_depth", C.c_int32), ("n_samples", C.c_int32), ("conductor_from_reflectance", C.c_uint32),
-                ("pad", C.c_uint32 * 3), ("a", ShmSpectrum), ("b", ShmSpectrum), ("c", ShmSpectrum), ("d", ShmSpectrum)]
+                ("mix_material", C.c_uint32 * 2), ("mix_amount", C.c_float), ("a", ShmSpectrum), ("b", ShmSpectrum), ("c", ShmSpectrum), ("d", ShmSpectrum)]
 
 
 class ShmLight(C.Structure):

@@ -184,7 +184,24 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
     // materials / lights
     uint32_t nsf = (uint32_t)out.spectrum_data.size();
     for (const ShmMaterial& m : out.materials) {
-        if (m.kind > SHM_MATERIAL_COATED_CONDUCTOR) { err = "unsupported material kind (MixMaterial is a SURVEY §8f row)"; return SHM_ERR_UNSUPPORTED; }
+        if (m.kind > SHM_MATERIAL_MIX) { err = "unsupported material kind"; return SHM_ERR_UNSUPPORTED; }
+        if (m.kind == SHM_MATERIAL_MIX) {
+            // both branches must reach a single material: follow every path with a step bound (a cycle never terminates)
+            if (m.mix_material[0] >= d->n_materials || m.mix_material[1] >= d->n_materials) { err = "mix material index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            std::vector<std::pair<uint32_t, int>> todo{{m.mix_material[0], 1}, {m.mix_material[1], 1}};
+            size_t steps = 0;
+            while (!todo.empty()) {
+                auto [j, depth] = todo.back();
+                todo.pop_back();
+                const ShmMaterial& c = out.materials[j];
+                if (c.kind != SHM_MATERIAL_MIX) continue;
+                if (depth >= 16 || ++steps > 65536) { err = "mix materials form a cycle or nest deeper than 16 levels"; return SHM_ERR_INVALID_ARGUMENT; }
+                if (c.mix_material[0] >= d->n_materials || c.mix_material[1] >= d->n_materials) { err = "mix material index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+                todo.push_back({c.mix_material[0], depth + 1});
+                todo.push_back({c.mix_material[1], depth + 1});
+            }
+            continue;
+        }
         if (!check_spectrum(m.a, nsf, err)) return SHM_ERR_INVALID_ARGUMENT;
         const bool coated = m.kind == SHM_MATERIAL_COATED_DIFFUSE || m.kind == SHM_MATERIAL_COATED_CONDUCTOR;
         if ((m.kind == SHM_MATERIAL_CONDUCTOR || (m.kind == SHM_MATERIAL_COATED_CONDUCTOR && !m.conductor_from_reflectance)) &&

@@ -892,8 +892,22 @@ static uint64_t max_batch_paths() {
     return max_cap;
 }
 
+// The batch limit on THIS device right now: SHM_BATCH_PATHS, bounded by 80 % of the memory that is free (plus what the
+// current workspace already holds), so that a GPU shared with other allocations degrades to more batches, not to an error.
+static uint64_t workspace_cap(const ShmScene* s) {
+    constexpr uint64_t BYTES_PER_PATH = 264 + 3 * 4;  // path state + three queues
+    uint64_t cap = max_batch_paths();
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        uint64_t avail = (uint64_t)free_b + (uint64_t)s->capacity * BYTES_PER_PATH;
+        uint64_t by_mem = (uint64_t)((double)avail * 0.8) / BYTES_PER_PATH;
+        if (by_mem < cap) cap = by_mem;
+    }
+    return std::max<uint64_t>(cap, 4096);
+}
+
 int ensure_workspace(ShmScene* s, uint64_t needed_paths) {
-    uint64_t max_cap = max_batch_paths();
+    uint64_t max_cap = workspace_cap(s);
     uint64_t want = std::min<uint64_t>(std::max<uint64_t>(needed_paths, 4096), max_cap);
     want = (want + 4095ull) & ~4095ull;
     if (want > 0xfffff000ull) want = 0xfffff000ull;
@@ -1214,7 +1228,8 @@ int shm_render_device(ShmScene* s, const ShmRenderParams* params, const ShmTile*
     uint64_t n_pixels = 0;
     for (uint32_t t = 0; tiles && t < n_tiles; ++t)
         n_pixels += (uint64_t)std::max(0, tiles[t].x1 - tiles[t].x0) * (uint64_t)std::max(0, tiles[t].y1 - tiles[t].y0);
-    const int max_fuse = (int)std::min<uint64_t>(std::max<uint64_t>(64, n_pixels ? max_batch_paths() / n_pixels : 64), 1u << 20);
+    HIP_TRY(hipSetDevice(s->device));
+    const int max_fuse = (int)std::min<uint64_t>(std::max<uint64_t>(64, n_pixels ? workspace_cap(s) / n_pixels : 64), 1u << 20);
     int wave_start = 0, wave_end = 1, next_wave_size = 1;
     int pend_begin = 0, pend_end = 0;
     while (wave_start < spp) {

@@ -97,7 +97,23 @@ SHM_HD Float light_sampler_pmf(const SceneView& sv) { return sv.n_lights == 0 ? 
 
 // SurfaceInteraction::get_bsdf (interaction.rs:187-278) for Single materials with constant textures.
 // lambda is mutable: DielectricMaterial terminates secondary wavelengths for dispersive eta.
-SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMaterial& m, Wavelengths& lambda) {
+SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMaterial& m_in, Wavelengths& lambda) {
+    // Resolve mixed materials (interaction.rs:205-220, MixMaterial::choose_material material.rs:1308-1329). The reference takes
+    // u from the tile's entropy-seeded rng; defined here as a hash of (wo, p, nesting level): reproducible, parity unpinned.
+    const ShmMaterial* mp = &m_in;
+    for (int level = 0; mp->kind == SHM_MATERIAL_MIX && level < 16; ++level) {
+        Float amt = mp->mix_amount;
+        uint32_t pick;
+        if (amt <= 0.0f) pick = 0;
+        else if (amt >= 1.0f) pick = 1;
+        else {
+            uint64_t h = hash_v3(hash_v3(0x4d495800ULL + (uint64_t)level, si.wo), si.p());
+            Float u = (Float)(uint32_t)(h >> 40) * 5.9604644775390625e-8f;  // 24 bits -> [0, 1)
+            pick = (amt < u) ? 0u : 1u;
+        }
+        mp = &sv.materials[mp->mix_material[pick]];
+    }
+    const ShmMaterial& m = *mp;
     if (m.has_displacement) {
         // bump_map, material.rs:1477-1508, with FloatConstantTexture: u_displace == v_displace == displace.
         // du, dv are finite and > 0 (interaction.rs:316-339 clamps; 0 -> 0.0005), so (x - x) / du == +0.

@@ -218,6 +218,16 @@ class SceneBuilder:
         self.materials.append(m)
         return len(self.materials) - 1
 
+    def material_mix(self, m0, m1, amount=0.5):
+        """MixMaterial::create (material.rs:1296-1306): two material indices (either may be a mix) and a constant amount."""
+        m = abi.ShmMaterial()
+        m.kind = abi.SHM_MATERIAL_MIX
+        m.mix_material[0], m.mix_material[1], m.mix_amount = int(m0), int(m1), float(amount)
+        z = self.spectrum_constant(0.0)
+        m.a, m.b, m.c, m.d = z, z, z, z
+        self.materials.append(m)
+        return len(self.materials) - 1
+
     # ---- lights ----
     def _area_light(self, prim_index, area, dense_emission, scale, two_sided):
         """DiffuseAreaLight::create: scale /= spectrum_to_photometric(L) (light.rs:598)."""

@@ -83,7 +83,7 @@ def _two_point_spectrum(b, lo, hi):
     return b.spectrum_piecewise(np.array([359.0, 831.0], np.float32), np.array([lo, hi], np.float32))
 
 
-def cornell_box(lib, width=512, height=512, coated=False):
+def cornell_box(lib, width=512, height=512, coated=False, mix=False):
     """S2 (config C2): 5 walls x 2 + 2 boxes x 5 faces x 2 + light 2 = 32 triangles.
     coated=True: the tall box becomes CoatedConductor (rough interface, Cu), the short one CoatedDiffuse with a scattering
     medium between the interfaces, the floor CoatedDiffuse with a smooth interface (SURVEY §8f-1 materials)."""
@@ -99,6 +99,11 @@ def cornell_box(lib, width=512, height=512, coated=False):
         tall_m = b.material_coated_conductor(interface_roughness=0.05, conductor_roughness=0.2, thickness=0.02)
         short_m = b.material_coated_diffuse(reflectance=_two_point_spectrum(b, 0.1, 0.7), roughness=0.1, thickness=0.05, albedo=0.6, g=0.3)
         floor_m = b.material_coated_diffuse(reflectance=0.6, roughness=0.0, eta=b.spectrum_named("glass-BK7"))
+    if mix:  # MixMaterial (material.rs:1288-1330): a plain two-way mix, and a nested one whose leaves include a coated material
+        gold = b.material_conductor(b.spectrum_named("metal-Au-eta"), b.spectrum_named("metal-Au-k"), roughness=0.3)
+        short_m = b.material_mix(white, gold, 0.5)
+        tall_m = b.material_mix(b.material_mix(red, green, 0.3), b.material_coated_diffuse(reflectance=0.7, roughness=0.1), 0.6)
+        floor_m = b.material_mix(white, black, 0.0)  # amount <= 0: always the first
     # room [-1,1] x [0,2] x [-1,1], open towards +z (camera side); inward-facing windings via reversed quads
     def inward(q):
         p, vi = q
@@ -129,7 +134,7 @@ def cornell_box(lib, width=512, height=512, coated=False):
     # ceiling light, facing down
     p, vi = _quad((-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (0.3, 1.98, 0.3), (-0.3, 1.98, 0.3))
     b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=20.0)
-    return _finish(b, lib, name="S2 cornell box" + (" (coated)" if coated else ""))
+    return _finish(b, lib, name="S2 cornell box" + (" (coated)" if coated else "") + (" (mix)" if mix else ""))
 
 
 def _hash3(ix, iy, iz, seed):

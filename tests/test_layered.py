@@ -206,8 +206,51 @@ def test_coated_scene_renders_deterministically(lib):
 
 
 def test_unsupported_material_is_rejected(lib):
-    """Kinds beyond CoatedConductor (e.g. Mix) fail loudly at scene creation: SHM_ERR_UNSUPPORTED, never a substitute."""
+    """Kinds beyond Mix fail loudly at scene creation: SHM_ERR_UNSUPPORTED, never a substitute."""
     sc = scenes.cornell_box(lib, 16, 16)
-    sc.desc.materials[0].kind = 6
+    sc.desc.materials[0].kind = 7
+    with pytest.raises(Exception):
+        oracle_py.Oracle(sc.desc)
+
+
+def test_mix_material(lib):
+    """MixMaterial (material.rs:1288-1330, resolved in get_bsdf, interaction.rs:205-220). amount <= 0 always takes the
+    first material and amount >= 1 the second (bit-identical films to the unmixed scenes); in between the render is
+    deterministic (the defined hash replaces the reference's entropy) and differs from both; cycles and bad indices are
+    rejected at scene creation."""
+    p = render.make_params(seed=4, spp=4, max_depth=5)
+
+    base = scenes.cornell_box(lib, 32, 32)
+    f_base, _ = oracle_py.Oracle(base.desc).render(p, n_threads=4)
+
+    sc = scenes.cornell_box(lib, 32, 32, mix=True)
+    o = oracle_py.Oracle(sc.desc)
+    f1, s1 = o.render(p, n_threads=1)
+    f2, s2 = o.render(p, n_threads=4)
+    assert np.array_equal(f1, f2) and s1["rays_closest"] == s2["rays_closest"]
+    rgb = render.film_to_rgb(f1)
+    assert np.isfinite(rgb).all() and rgb.mean() > 0.05 and not np.array_equal(f1, f_base)
+    o.close()
+    # amount 0 / 1 select a branch exactly: the floor of the mix scene is mix(white, black, 0.0) == white
+    mats = sc.desc.materials
+    idx = [i for i in range(sc.desc.n_materials) if mats[i].kind == abi.SHM_MATERIAL_MIX]
+    assert len(idx) == 4
+    # turn every mix into "always first" and compare with a scene whose primitives point at the first leaves directly
+    saved = [(mats[i].mix_amount, mats[i].mix_material[0], mats[i].mix_material[1]) for i in idx]
+    for i in idx:
+        mats[i].mix_amount = -1.0
+    fa0, _ = oracle_py.Oracle(sc.desc).render(p, n_threads=4)
+    for i in idx:
+        mats[i].mix_amount = 2.0
+        mats[i].mix_material[0], mats[i].mix_material[1] = mats[i].mix_material[1], mats[i].mix_material[0]
+    fa1, _ = oracle_py.Oracle(sc.desc).render(p, n_threads=4)
+    assert np.array_equal(fa0, fa1)  # "always first" == "always second" with the children swapped
+    for i, (a, m0, m1) in zip(idx, saved):
+        mats[i].mix_amount, mats[i].mix_material[0], mats[i].mix_material[1] = a, m0, m1
+    # a cycle and an out-of-range index are errors
+    mats[idx[0]].mix_material[0] = idx[0]
+    with pytest.raises(Exception):
+        oracle_py.Oracle(sc.desc)
+    mats[idx[0]].mix_material[0] = 10 ** 6
     with pytest.raises(Exception):
         oracle_py.Oracle(sc.desc)
