@@ -204,6 +204,12 @@ def main():
                          "nodes_per_ray": acc["nodes_closest"] / max(1, acc["rays_closest"]),
                          "prims_per_ray": acc["tris_closest"] / max(1, acc["rays_closest"]),
                          "closest_Mray_s_in_kernel": acc["rays_closest"] / (ms * 1e-3) / 1e6 if ms > 0 else 0.0},
+            # the second traversal kernel, same accounting (informational; `roofline` above is the dominant kernel)
+            "roofline_any_hit": {"kernel": "k_trace3<any> (BvhAggregate::intersect_predicate)",
+                                 "achieved": ((32.0 * acc["nodes_any"] + 48.0 * acc["tris_any"] + 48.0 * acc["rays_any"]) / (acc["ms_trace_any"] * 1e-3) / 1e9)
+                                 if acc["ms_trace_any"] > 0 else 0.0, "unit": "GB/s",
+                                 "nodes_per_ray": acc["nodes_any"] / max(1, acc["rays_any"]), "prims_per_ray": acc["tris_any"] / max(1, acc["rays_any"]),
+                                 "any_Mray_s_in_kernel": acc["rays_any"] / (acc["ms_trace_any"] * 1e-3) / 1e6 if acc["ms_trace_any"] > 0 else 0.0},
             "breakdown_ms_per_step": {"trace_closest": acc["ms_trace_closest"] / args.steps, "trace_any": acc["ms_trace_any"] / args.steps,
                                       "shade_generate_film": acc["ms_shade"] / args.steps, "gpu_total": acc["ms_total"] / args.steps},
         }
