@@ -226,6 +226,11 @@ def main():
             raise SystemExit("film gather mismatch")
         if not (host["weight_sum"] == float(args.spp)).all():  # every pixel of the frame received all its samples, from some rank
             raise SystemExit("gathered film is incomplete")
+    if rank == 0 and world == 1 and not args.shard_of:
+        # self-check outside the timed region: every pixel received all its samples, all sums finite
+        host = r.read_film()
+        if not (host["weight_sum"] == float(args.spp)).all() or not np.isfinite(host["rgb_sum"]).all():
+            raise SystemExit("film is incomplete or not finite")
     r.close()
     if use_dist:
         dist.barrier()
