@@ -56,9 +56,7 @@ struct DeviceCounters {
 struct QueueState {
     uint32_t n_active[2];   // entries in q_active[0/1]
     uint32_t n_shadow;      // entries in q_shadow
-    uint32_t head_closest;  // persistent-wave work pointers
-    uint32_t head_any;
-    uint32_t pad[3];
+    uint32_t pad[5];
 };
 
 // Path state, structure of arrays (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
@@ -160,158 +158,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
         qs->n_active[0] = total;
         qs->n_active[1] = 0;
         qs->n_shadow = 0;
-        qs->head_closest = 0;
-        qs->head_any = 0;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2 / K3: BVH traversal.  Persistent waves: the grid is sized to fill the chip once; each wave pulls
-// 64 queue entries at a time with one atomic.  The per-lane node stack lives in LDS, laid out
-// [level][lane] so that a wave's push/pop touches 64 consecutive dwords (bank-conflict free for the two
-// 32-lane halves ds_read_b32/ds_write_b32 are serviced in).  Node (32 B) and primitive (48 B) records
-// are fetched as 16-B vector loads.
-//   ANY          intersect_predicate (early out, no hit record) vs intersect (closest hit)
-//   HAS_SPHERES  compile the quadric path only for scenes that contain spheres
-// ---------------------------------------------------------------------------------------------
-struct NodeRaw {
-    float4 a, b;  // a = bmin.xyz, bmax.x ; b = bmax.yz, offset(bits), n_prims|axis<<16 (bits)
-};
-
-template <bool ANY, bool HAS_SPHERES>
-__global__ void __launch_bounds__(TRACE_BLOCK) k_trace(SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
-                                                      uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
-                                                      ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
-                                                      float4* __restrict__ L, const float4* __restrict__ contrib,
-                                                      DeviceCounters* counters, int stack_entries) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wave_in_block = threadIdx.x / WAVE;
-    uint32_t* stack = lds_stack + (size_t)wave_in_block * (size_t)stack_entries * WAVE + lane;
-    const uint32_t n = n_ptr ? *n_ptr : n_direct;
-    unsigned long long c_nodes = 0, c_prims = 0, c_rays = 0;
-    const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sv.nodes);
-
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(head, (uint32_t)WAVE);
-        base = __shfl(base, 0);
-        if (base >= n) break;
-        uint32_t qi = base + lane;
-        bool active = qi < n;
-        uint32_t path = 0;
-        V3 ro = v3s(0.0f), rd = v3(0.0f, 0.0f, 1.0f);
-        Float t_max = 0.0f;
-        if (active) {
-            path = queue ? queue[qi] : qi;
-            const float4* rp = reinterpret_cast<const float4*>(rays + path);
-            float4 r0 = rp[0], r1 = rp[1];
-            ro = v3(r0.x, r0.y, r0.z);
-            rd = v3(r0.w, r1.x, r1.y);
-            t_max = r1.z;
-            c_rays++;
-        }
-        Hit hit;
-        hit.prim = -1; hit.t = 0.0f; hit.b0 = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f; hit.phi = 0.0f;
-        bool found_any = false;
-        if (active) {
-            // aggregate.rs:76-81
-            V3 inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-            int dir_is_neg[3] = {inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f};
-            int sp = 0;
-            uint32_t current = 0;
-            for (;;) {
-                float4 na = nodes4[2 * current], nb = nodes4[2 * current + 1];
-                c_nodes++;
-                Float bmin[3] = {na.x, na.y, na.z};
-                Float bmax[3] = {na.w, nb.x, nb.y};
-                uint32_t offset = __float_as_uint(nb.z);
-                uint32_t meta = __float_as_uint(nb.w);
-                uint32_t n_prims = meta & 0xffffu;
-                uint32_t axis = (meta >> 16) & 0xffu;
-                bool pop = true;
-                if (intersect_p_cached(bmin, bmax, ro, t_max, inv_dir, dir_is_neg)) {
-                    if (n_prims > 0) {
-                        for (uint32_t i = 0; i < n_prims; ++i) {
-                            uint32_t slot = offset + i;
-                            c_prims++;
-                            bool got;
-                            if (HAS_SPHERES) {
-                                got = prim_intersect(sv, slot, ro, rd, t_max, hit);
-                            } else {
-                                const float4* pr = reinterpret_cast<const float4*>(sv.prim_recs + slot);
-                                float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
-                                TriangleIntersection ti;
-                                got = intersect_triangle(ro, rd, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y),
-                                                         v3(q1.z, q1.w, q2.x), ti);
-                                if (got) { hit.prim = (int32_t)slot; hit.t = ti.t; hit.b0 = ti.b0; hit.b1 = ti.b1; hit.b2 = ti.b2; }
-                            }
-                            if (got) {
-                                if (ANY) { found_any = true; break; }
-                                t_max = hit.t;  // aggregate.rs:105-109
-                            }
-                        }
-                        if (ANY && found_any) break;
-                    } else {
-                        // interior: push far child, descend into near child (aggregate.rs:119-127)
-                        if (dir_is_neg[axis]) {
-                            stack[(size_t)sp * WAVE] = current + 1;
-                            current = offset;
-                        } else {
-                            stack[(size_t)sp * WAVE] = offset;
-                            current = current + 1;
-                        }
-                        sp++;
-                        pop = false;
-                    }
-                }
-                if (pop) {
-                    if (sp == 0) break;
-                    sp--;
-                    current = stack[(size_t)sp * WAVE];
-                }
-            }
-        }
-        if (active) {
-            if (ANY) {
-                if (occluded_out) occluded_out[path] = found_any ? 1 : 0;
-                if (L && !found_any) {
-                    float4 l = L[path], c = contrib[path];
-                    l.x += c.x; l.y += c.y; l.z += c.z; l.w += c.w;
-                    L[path] = l;
-                }
-            } else {
-                float4* hp = reinterpret_cast<float4*>(hits + path);
-                hp[0] = make_float4(__int_as_float(hit.prim), hit.t, hit.b0, hit.b1);
-                hp[1] = make_float4(hit.b2, hit.phi, 0.0f, 0.0f);
-            }
-        }
-    }
-    // one set of atomics per wave per launch
-    for (int off = 32; off > 0; off >>= 1) {
-        c_nodes += __shfl_down(c_nodes, off);
-        c_prims += __shfl_down(c_prims, off);
-        c_rays += __shfl_down(c_rays, off);
-    }
-    if (lane == 0 && c_rays) {
-        if (ANY) {
-            atomicAdd(&counters->rays_any, c_rays);
-            atomicAdd(&counters->nodes_any, c_nodes);
-            atomicAdd(&counters->tris_any, c_prims);
-        } else {
-            atomicAdd(&counters->rays_closest, c_rays);
-            atomicAdd(&counters->nodes_closest, c_nodes);
-            atomicAdd(&counters->tris_closest, c_prims);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K2 / K3, tuned variant for triangle-only scenes: the reference's traversal (aggregate.rs:71-203: test the current node, push the far child
+// K2 / K3: BVH traversal. The reference's traversal (aggregate.rs:71-203: test the current node, push the far child
 // untested, enter the near child; pop on a miss or after a leaf) executed as UNIFORM steps, because the profile of the
-// first two variants (profiles/r01_*) shows ~10 of 64 lanes active per VALU instruction: the kernels are issue-bound by
-// divergence, not by HBM (FETCH_SIZE is 3-6x below the algorithmic bytes).  (A variant that fetched and tested both
-// children at the parent was measured and dropped: same results, more loads, no gain — DESIGN.md §6.)
+// first, reference-shaped kernel (one ray per lane from root to done; profiles/r01_v1) showed ~10 of 64 lanes active per
+// VALU instruction: issue-bound by divergence, not by HBM (FETCH_SIZE is 3-6x below the algorithmic bytes).  (A variant
+// that fetched and tested both children at the parent was measured and dropped: same results, more loads, no gain.)
+//   ANY       intersect_predicate (early out, no hit record) vs intersect (closest hit)
+//   TRI_ONLY  scenes made of triangles only; otherwise the leaf phase also carries Sphere::intersect (sphere.rs:95-196)
 //  * every loop iteration is one identical step for every lane that has a node to test: [pop if requested] -> fetch the
 //    32-B record -> slab test -> push far / enter near, or mark the leaf pending, or request a pop.  No nested loops;
 //  * leaf (triangle) tests are POSTPONED: a lane that reached a leaf waits until at least `leaf_min` lanes of its wave
@@ -327,7 +184,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace(SceneView sv, const uint3
 constexpr int K3_LDS_N = 26;   // stack levels [0, K3_LDS_N) -> LDS (6.5 KiB per wave), deeper levels -> HBM spill
 enum : uint32_t { ST_IDLE = 0, ST_NODE = 1, ST_LEAF = 2, ST_DONE = 3 };
 
-template <bool ANY>
+template <bool ANY, bool TRI_ONLY>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
                                                        uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
                                                        ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
@@ -356,12 +213,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
     bool want_pop = false;
     uint32_t path = 0;
     V3 ro = v3s(0.0f), inv_dir = v3s(0.0f);
+    V3 rd_full = v3s(0.0f);  // the direction itself is only kept for non-triangle shapes (TRI_ONLY = false)
     bool negx = false, negy = false, negz = false;
     RayShear rs;
     rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
     Float t_max = 0.0f;
     int32_t hit_prim = -1;
-    Float hit_t = 0.0f, hit_b0 = 0.0f, hit_b1 = 0.0f, hit_b2 = 0.0f;
+    Float hit_t = 0.0f, hit_b0 = 0.0f, hit_b1 = 0.0f, hit_b2 = 0.0f, hit_phi = 0.0f;
     int sp = 0;
     uint32_t cur = 0;
     uint32_t leaf_off = 0, leaf_n = 0;
@@ -415,6 +273,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                             negy = inv_dir.y < 0.0f;
                             negz = inv_dir.z < 0.0f;
                             rs = ray_shear(rd);
+                            if (!TRI_ONLY) rd_full = rd;
                             hit_prim = -1;
                             sp = 0;
                             cur = 0;
@@ -500,11 +359,20 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                         c_prims++;
                         const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * 48u);
                         float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
-                        TriangleIntersection ti;
-                        if (intersect_triangle_pre(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti)) {
-                            hit_prim = (int32_t)slot; hit_t = ti.t; hit_b0 = ti.b0; hit_b1 = ti.b1; hit_b2 = ti.b2;
+                        bool got;
+                        if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_SPHERE_BIT)) {
+                            // Sphere::intersect (sphere.rs:95-196) through the same leaf phase; the hit record carries p_obj and phi
+                            QuadricIntersection qi;
+                            got = sphere_basic_intersect(sv.spheres[__float_as_uint(q2.y) & ~PRIM_SPHERE_BIT], ro, rd_full, t_max, qi);
+                            if (got) { hit_prim = (int32_t)slot; hit_t = qi.t_hit; hit_b0 = qi.p_obj.x; hit_b1 = qi.p_obj.y; hit_b2 = qi.p_obj.z; hit_phi = qi.phi; }
+                        } else {
+                            TriangleIntersection ti;
+                            got = intersect_triangle_pre(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
+                            if (got) { hit_prim = (int32_t)slot; hit_t = ti.t; hit_b0 = ti.b0; hit_b1 = ti.b1; hit_b2 = ti.b2; hit_phi = 0.0f; }
+                        }
+                        if (got) {
                             if (ANY) { found_any = true; break; }
-                            t_max = ti.t;  // aggregate.rs:105-109
+                            t_max = hit_t;  // aggregate.rs:105-109
                         }
                     }
                     if (ANY && found_any) {
@@ -529,7 +397,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
             } else {
                 float4* hp = reinterpret_cast<float4*>(hits + path);
                 hp[0] = make_float4(__int_as_float(hit_prim), hit_t, hit_b0, hit_b1);
-                hp[1] = make_float4(hit_b2, 0.0f, 0.0f, 0.0f);
+                hp[1] = make_float4(hit_b2, TRI_ONLY ? 0.0f : hit_phi, 0.0f, 0.0f);
             }
             state = ST_IDLE;
         }
@@ -778,10 +646,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
 __global__ void k_next_bounce(QueueState* qs, int cur) {
     qs->n_active[cur] = 0;
     qs->n_shadow = 0;
-    qs->head_closest = 0;
-    qs->head_any = 0;
 }
-__global__ void k_reset_head(uint32_t* head) { *head = 0; }
 __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x; i < 8 * 32; i += blockDim.x) heads[i] = 0; }
 
 // ---------------------------------------------------------------------------------------------
@@ -841,12 +706,8 @@ struct ShmScene {
     ShmTile* d_tiles = nullptr;
     uint32_t* d_tile_offset = nullptr;
     size_t tiles_capacity = 0;
-    uint32_t* d_head = nullptr;    // for the standalone trace entry points
     int n_cu = 256;
-    int stack_entries = 64;
-    int trace_blocks = 0;
     // tuned traversal (k_trace3)
-    int trace_kernel = 3;          // 1: k_trace (generic: spheres), 3: k_trace3 (triangle-only scenes)
     int trace3_blocks = 0;
     int spill3_levels = 1;
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
@@ -937,26 +798,18 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths) {
     return SHM_OK;
 }
 
-size_t trace_lds_bytes(const ShmScene* s) { return (size_t)(TRACE_BLOCK / WAVE) * (size_t)s->stack_entries * WAVE * sizeof(uint32_t); }
-
 template <bool ANY>
-void launch_trace(ShmScene* s, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, uint32_t* head, const ShmRay* rays,
-                  ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib) {
-    if (!s->flat.has_spheres && s->trace_kernel == 3) {
-        uint32_t* heads = s->d_heads3 + (ANY ? 8 * 32 : 0);
-        hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, s->stream, heads);
-        hipLaunchKernelGGL((k_trace3<ANY>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, heads, rays, hits,
-                           occluded, L, contrib, s->d_counters, s->d_spill3, s->spill3_levels, s->refill_min, ANY ? s->leaf_min_any : s->leaf_min, s->queue_parts);
-        return;
-    }
-    dim3 grid(s->trace_blocks), block(TRACE_BLOCK);
-    size_t lds = trace_lds_bytes(s);
+void launch_trace(ShmScene* s, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, const ShmRay* rays, ShmHit* hits,
+                  uint8_t* occluded, float4* L, const float4* contrib) {
+    uint32_t* heads = s->d_heads3 + (ANY ? 8 * 32 : 0);
+    hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, s->stream, heads);
+    const int leaf_min = ANY ? s->leaf_min_any : s->leaf_min;
     if (s->flat.has_spheres)
-        hipLaunchKernelGGL((k_trace<ANY, true>), grid, block, lds, s->stream, s->dsv, queue, n_ptr, n_direct, head, rays, hits, occluded, L,
-                           contrib, s->d_counters, s->stack_entries);
+        hipLaunchKernelGGL((k_trace3<ANY, false>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, heads, rays,
+                           hits, occluded, L, contrib, s->d_counters, s->d_spill3, s->spill3_levels, s->refill_min, leaf_min, s->queue_parts);
     else
-        hipLaunchKernelGGL((k_trace<ANY, false>), grid, block, lds, s->stream, s->dsv, queue, n_ptr, n_direct, head, rays, hits, occluded, L,
-                           contrib, s->d_counters, s->stack_entries);
+        hipLaunchKernelGGL((k_trace3<ANY, true>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, heads, rays,
+                           hits, occluded, L, contrib, s->d_counters, s->d_spill3, s->spill3_levels, s->refill_min, leaf_min, s->queue_parts);
 }
 
 struct EventPool {
@@ -1041,26 +894,16 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (hipMemset(s->d_film, 0, s->n_film_pixels * sizeof(ShmFilmPixel)) != hipSuccess) { g_err = "hipMemset film"; return fail(SHM_ERR_DEVICE); }
     if ((rc = dev_alloc<QueueState>(s, 1, &s->d_qs)) != SHM_OK) return fail(rc);
     if ((rc = dev_alloc<DeviceCounters>(s, 1, &s->d_counters)) != SHM_OK) return fail(rc);
-    if ((rc = dev_alloc<uint32_t>(s, 1, &s->d_head)) != SHM_OK) return fail(rc);
     if ((rc = dev_alloc<uint32_t>(s, 2 * 8 * 32, &s->d_heads3)) != SHM_OK) return fail(rc);
     hipMemset(s->d_qs, 0, sizeof(QueueState));
     hipMemset(s->d_counters, 0, sizeof(DeviceCounters));
 
-    // Traversal stack: the deepest leaf bounds the number of simultaneously pending far children.
-    s->stack_entries = (int)std::min<uint32_t>(64u, std::max<uint32_t>(f.max_leaf_depth + 1u, 2u));
-    if (const char* e = getenv("SHM_STACK_ENTRIES")) { int v2 = atoi(e); if (v2 >= (int)f.max_leaf_depth + 1 && v2 <= 64) s->stack_entries = v2; }
-    // Persistent grid: as many 256-thread workgroups per CU as LDS (160 KiB) and the 32-wave cap admit.
-    size_t lds = trace_lds_bytes(s);
-    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
-    per_cu = std::max(1, std::min(per_cu, 8));
-    if (const char* e = getenv("SHM_TRACE_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) per_cu = v2; }
-    s->trace_blocks = s->n_cu * per_cu;
-    if (const char* e = getenv("SHM_TRACE_KERNEL")) { int v2 = atoi(e); if (v2 == 1 || v2 == 3) s->trace_kernel = v2; }
+    // Tuning knobs (development): defaults are the measured optimum on S3
     if (const char* e = getenv("SHM_PIX_GROUP")) { long long v2 = atoll(e); if (v2 >= 1) s->pix_group = (uint32_t)std::min<long long>(v2, 0x7fffffffll); }
     if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = v2; }
     {
-        int per_cu3 = 6;  // 26 KiB of LDS per workgroup
+        int per_cu3 = 6;  // persistent grid: 26 KiB of LDS per 256-thread workgroup -> 6 workgroups (24 waves) per CU
         if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 6) per_cu3 = v2; }
         if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
         if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
@@ -1068,7 +911,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
         s->spill3_levels = std::max(0, (int)f.max_leaf_depth + 1 - K3_LDS_N) + 1;
         if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3)) != SHM_OK) return fail(rc);
     }
-    DBG("scene: %u nodes, depth %u, stack_entries %d, trace_blocks %d, trace3_blocks %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->stack_entries, s->trace_blocks, s->trace3_blocks);
+    DBG("scene: %u nodes, depth %u, trace blocks %d, spill levels %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->trace3_blocks, s->spill3_levels);
     *out = s;
     return SHM_OK;
 }
@@ -1152,7 +995,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         for (int bounce = 0; bounce <= params->max_depth; ++bounce) {
             hipEvent_t a = ev.get(), b = ev.get();
             hipEventRecord(a, s->stream);
-            launch_trace<false>(s, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, &s->d_qs->head_closest, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr);
+            launch_trace<false>(s, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr);
             hipEventRecord(b, s->stream);
             ev_closest.push_back({a, b});
             if (s->flat.has_layered)
@@ -1164,7 +1007,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
             if (bounce < params->max_depth) {
                 hipEvent_t c = ev.get(), d = ev.get();
                 hipEventRecord(c, s->stream);
-                launch_trace<true>(s, s->d_q_shadow, &s->d_qs->n_shadow, 0, &s->d_qs->head_any, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib);
+                launch_trace<true>(s, s->d_q_shadow, &s->d_qs->n_shadow, 0, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib);
                 hipEventRecord(d, s->stream);
                 ev_any.push_back({c, d});
             }
@@ -1271,26 +1114,18 @@ int shm_render(ShmScene* s, const ShmRenderParams* params, const ShmTile* tiles,
 static int trace_device_impl(ShmScene* s, bool any, const void* rays_dev, uint32_t n, void* out_dev, int repeat, ShmStats* stats) {
     if (!s || !rays_dev || !out_dev || n == 0 || repeat < 1) { g_err = "invalid trace arguments"; return SHM_ERR_INVALID_ARGUMENT; }
     HIP_TRY(hipSetDevice(s->device));
-    DBG("trace_device_impl n=%u any=%d blocks=%d lds=%zu stack=%d", n, (int)any, s->trace_blocks, trace_lds_bytes(s), s->stack_entries);
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), s->stream));
-    DBG("memset ok");
     EventPool ev{s};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
     for (int r = 0; r < repeat; ++r) {
-        hipLaunchKernelGGL(k_reset_head, dim3(1), dim3(1), 0, s->stream, s->d_head);
-        DBG("reset_head launched: %s", hipGetErrorString(hipGetLastError()));
         hipEvent_t a = ev.get(), b = ev.get();
-        DBG("events %p %p", (void*)a, (void*)b);
         hipEventRecord(a, s->stream);
-        DBG("event recorded");
-        if (any) launch_trace<true>(s, nullptr, nullptr, n, s->d_head, (const ShmRay*)rays_dev, nullptr, (uint8_t*)out_dev, nullptr, nullptr);
-        else launch_trace<false>(s, nullptr, nullptr, n, s->d_head, (const ShmRay*)rays_dev, (ShmHit*)out_dev, nullptr, nullptr, nullptr);
-        DBG("trace launched: %s", hipGetErrorString(hipGetLastError()));
+        if (any) launch_trace<true>(s, nullptr, nullptr, n, (const ShmRay*)rays_dev, nullptr, (uint8_t*)out_dev, nullptr, nullptr);
+        else launch_trace<false>(s, nullptr, nullptr, n, (const ShmRay*)rays_dev, (ShmHit*)out_dev, nullptr, nullptr, nullptr);
         hipEventRecord(b, s->stream);
         evs.push_back({a, b});
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
-    DBG("synchronized");
     HIP_TRY(hipGetLastError());
     if (stats) {
         memset(stats, 0, sizeof(*stats));

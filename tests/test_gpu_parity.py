@@ -68,7 +68,7 @@ def test_trace_bitwise_parity(env, name):
         ao, s3 = orc.trace(rays, any_hit=True)
         # any-hit: identical occlusion flags and primitive tests; the tuned kernel tests both children at the parent, so it
         # may count node visits the reference never makes after its early exit
-        assert np.array_equal(ag, ao) and s2["nodes_any"] >= s3["nodes_any"] and s2["tris_any"] == s3["tris_any"]
+        assert np.array_equal(ag, ao) and s2["nodes_any"] == s3["nodes_any"] and s2["tris_any"] == s3["tris_any"]
     gpu.close()
     orc.close()
 
@@ -114,9 +114,8 @@ def test_render_parity(env, name):
     assert np.isfinite(a).all() and a.max() > 0
     assert float(np.max(np.abs(a - b))) < L_INF_TOL
     assert np.array_equal(fg, fo)  # bit-exact f64 sums
-    for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "tris_any"):
+    for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
         assert sg[k] == so[k], k
-    assert sg["nodes_any"] >= so["nodes_any"]
     gpu.close()
     orc.close()
 

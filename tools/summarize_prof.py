@@ -14,7 +14,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"k_(trace\d?|shade\w*|generate|film|expand_tiles|next_bounce|reset_head)", name)
+    m = re.search(r"k_(trace\d?|shade\w*|generate|film|expand_tiles|next_bounce|reset_heads3)", name)
     if not m:
         return name[:48]
     k = m.group(0)
@@ -22,7 +22,7 @@ def short(name):
         t = re.search(r"k_trace\d?<(\w+)(?:, (\w+))?>", name)
         if t:
             k += "<any>" if t.group(1) == "true" else "<closest>"
-            k += "+sph" if t.group(2) == "true" else ""
+            k += "+sph" if t.group(2) == "false" else ""  # second template argument is TRI_ONLY
     return k
 
 

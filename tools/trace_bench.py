@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """K2 microbenchmark on S3: device-resident ray batches through shm_trace_closest_device.
 Ray sets: camera (coherent), diffuse-bounce rays off the object (incoherent), the same sorted by a Morton key.
-Prints Mray/s, nodes/ray, algorithmic GB/s. Env knobs (SHM_TRACE_KERNEL, SHM_TRACE2_BLOCKS_PER_CU, SHM_REFILL_MIN)
+Prints Mray/s, nodes/ray, algorithmic GB/s. Env knobs (SHM_REFILL_MIN, SHM_LEAF_MIN, SHM_TRACE3_BLOCKS_PER_CU)
 are read at scene creation, so each configuration is a separate process invocation."""
 import ctypes as C
 import os, sys, time
@@ -81,7 +81,7 @@ def report(name, rays, repeat=5):
     gb = (32 * nodes + 48 * tris + 48 * n) / 1e9
     print(f"{name:28s} n={n:8d} {ms:8.3f} ms  {n/ms/1e3:8.1f} Mray/s  nodes/ray {nodes/n:6.1f} prims/ray {tris/n:5.2f}  alg {gb/ms*1e3:7.0f} GB/s ({gb/ms*1e3/80:5.1f}% of 8 TB/s)  hit {float((hits['prim']>=0).mean()):.2f}", flush=True)
 
-cfg = {k: os.environ.get(k) for k in ("SHM_TRACE_KERNEL", "SHM_TRACE2_BLOCKS_PER_CU", "SHM_REFILL_MIN", "SHM_TRACE_BLOCKS_PER_CU")}
+cfg = {k: os.environ.get(k) for k in ("SHM_REFILL_MIN", "SHM_LEAF_MIN", "SHM_TRACE3_BLOCKS_PER_CU")}
 print("config:", cfg, flush=True)
 cam = camera_rays()
 report("camera (tile order)", cam)
