@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SHM_ABI_VERSION 2
+#define SHM_ABI_VERSION 3
 
 /* The library is built with -fvisibility=hidden; only these entry points are exported. */
 #if defined(__GNUC__)
@@ -72,6 +72,20 @@ typedef struct ShmTriangleMesh {
     uint8_t pad[6];
 } ShmTriangleMesh;
 
+/* BilinearPatchMesh (src/shape/mesh.rs:289-376) for BilinearPatch (src/shape/bilinear_patch.rs), vertices in render space.
+ * This ABI version takes meshes WITHOUT per-vertex n / uv arrays (both pointers must be NULL: SHM_ERR_UNSUPPORTED otherwise). */
+typedef struct ShmBilinearPatchMesh {
+    uint32_t n_patches;
+    uint32_t n_vertices;
+    const uint32_t* vertex_indices; /* 4*n_patches: p00, p10, p01, p11 (bilinear_patch.rs:87-98) */
+    const float* p;                 /* 3*n_vertices */
+    const float* n;                 /* must be NULL */
+    const float* uv;                /* must be NULL */
+    uint8_t reverse_orientation;
+    uint8_t transform_swaps_handedness;
+    uint8_t pad[6];
+} ShmBilinearPatchMesh;
+
 /* Sphere (src/shape/sphere.rs:27-38); matrices row-major m[r][c] as SquareMatrix<4>. */
 typedef struct ShmSphere {
     float radius, z_min, z_max, theta_z_min, theta_z_max, phi_max;
@@ -82,14 +96,15 @@ typedef struct ShmSphere {
     uint8_t pad[6];
 } ShmSphere;
 
-enum { SHM_SHAPE_TRIANGLE = 0, SHM_SHAPE_SPHERE = 1 };
+enum { SHM_SHAPE_TRIANGLE = 0, SHM_SHAPE_SPHERE = 1, SHM_SHAPE_BILINEAR_PATCH = 2 };
 
 /* GeometricPrimitive / SimplePrimitive (src/primitive.rs:66-130): shape + material (+ area light).
  * Listed in the order of BvhAggregate::primitives AFTER the build's reordering (aggregate.rs:270),
  * i.e. leaf node `offset` indexes this array directly. */
 typedef struct ShmPrimitive {
     uint32_t shape_kind;   /* SHM_SHAPE_* */
-    uint32_t shape_index;  /* triangle: global triangle index (mesh base + tri_index); sphere: index */
+    uint32_t shape_index;  /* triangle: global triangle index (mesh base + tri_index); sphere: index;
+                              bilinear patch: global patch index (patch-mesh base + blp_index) */
     uint32_t material;     /* index into materials */
     int32_t area_light;    /* index into lights, or -1 */
 } ShmPrimitive;
@@ -199,6 +214,9 @@ typedef struct ShmSceneDesc {
     const float* spectrum_data;
     ShmCamera camera;
     ShmFilm film;
+    uint32_t n_patch_meshes;      /* ABI v3 */
+    uint32_t pad;
+    const ShmBilinearPatchMesh* patch_meshes;
 } ShmSceneDesc;
 
 /* ---- render parameters ----------------------------------------------------------------------- */

@@ -505,6 +505,70 @@ float orc_fn_triangle_pdf_with_context(const float* p0, const float* p1, const f
     c.pi = p3i_exact(ld3(ctx_p)); c.n = ld3(ctx_n); c.ns = ld3(ctx_ns);
     return triangle_pdf_with_context(tr, c, ld3(wi));
 }
+// ---- BilinearPatch (shape/bilinear_patch.rs) unit entry points. pts = p00, p10, p01, p11 (12 floats) ----
+static PatchData make_patch(const float* pts, int flip) {
+    PatchData pd;
+    pd.p00 = ld3(pts); pd.p10 = ld3(pts + 3); pd.p01 = ld3(pts + 6); pd.p11 = ld3(pts + 9);
+    pd.flip = flip != 0;
+    pd.is_rect = blp_is_rectangle(pd.p00, pd.p10, pd.p01, pd.p11);
+    pd.area = blp_area(pd.p00, pd.p10, pd.p01, pd.p11, pd.is_rect);
+    return pd;
+}
+void orc_fn_blp_info(const float* pts, float* out2) {
+    PatchData pd = make_patch(pts, 0);
+    out2[0] = pd.is_rect ? 1.0f : 0.0f;
+    out2[1] = pd.area;
+}
+// out = u, v, t ; returns 1 on a hit
+int orc_fn_blp_intersect(const float* pts, const float* o, const float* d, float t_max, float* out3) {
+    BilinearIntersection bi;
+    if (!blp_intersect(ld3(o), ld3(d), t_max, ld3(pts), ld3(pts + 3), ld3(pts + 6), ld3(pts + 9), bi)) return 0;
+    out3[0] = bi.u; out3[1] = bi.v; out3[2] = bi.t;
+    return 1;
+}
+// out = p[3], n[3], dpdu[3], dpdv[3], dndu[3], dndv[3], p_error[3] (21 floats)
+void orc_fn_blp_interaction(const float* pts, int flip, float u, float v, const float* wo, float* out21) {
+    SurfaceInteraction si = blp_interaction(make_patch(pts, flip), u, v, ld3(wo));
+    V3 p = si.p();
+    V3 err = v3(0.5f * (si.pi.x.high - si.pi.x.low), 0.5f * (si.pi.y.high - si.pi.y.low), 0.5f * (si.pi.z.high - si.pi.z.low));
+    const V3 vs[7] = {p, si.n, si.dpdu, si.dpdv, si.dndu, si.dndv, err};
+    for (int i = 0; i < 7; ++i) { out21[3 * i] = vs[i].x; out21[3 * i + 1] = vs[i].y; out21[3 * i + 2] = vs[i].z; }
+}
+int orc_fn_blp_sample_with_context(const float* pts, int flip, const float* ctx_p, const float* ctx_n, const float* ctx_ns,
+                                   const float* u, float* out7) {
+    ShapeSampleContext c;
+    c.pi = p3i_exact(ld3(ctx_p)); c.n = ld3(ctx_n); c.ns = ld3(ctx_ns);
+    ShapeSample ss;
+    if (!blp_sample_with_context(make_patch(pts, flip), c, v2(u[0], u[1]), ss)) return 0;
+    V3 p = ss.pi.mid();
+    out7[0] = p.x; out7[1] = p.y; out7[2] = p.z; out7[3] = ss.n.x; out7[4] = ss.n.y; out7[5] = ss.n.z; out7[6] = ss.pdf;
+    return 1;
+}
+float orc_fn_blp_pdf_with_context(const float* pts, int flip, const float* ctx_p, const float* ctx_n, const float* ctx_ns, const float* wi) {
+    ShapeSampleContext c;
+    c.pi = p3i_exact(ld3(ctx_p)); c.n = ld3(ctx_n); c.ns = ld3(ctx_ns);
+    return blp_pdf_with_context(make_patch(pts, flip), c, ld3(wi));
+}
+float orc_fn_spherical_quad_area(const float* a, const float* b, const float* c, const float* d) {
+    return spherical_quad_area(ld3(a), ld3(b), ld3(c), ld3(d));
+}
+// out = p[3], pdf
+void orc_fn_sample_spherical_rectangle(const float* p_ref, const float* s, const float* ex, const float* ey, const float* u, float* out4) {
+    Float pdf = 0.0f;
+    V3 p = sample_spherical_rectangle(ld3(p_ref), ld3(s), ld3(ex), ld3(ey), v2(u[0], u[1]), pdf);
+    out4[0] = p.x; out4[1] = p.y; out4[2] = p.z; out4[3] = pdf;
+}
+void orc_fn_invert_spherical_rectangle_sample(const float* p_ref, const float* s, const float* ex, const float* ey, const float* p_rect,
+                                              float* out2) {
+    V2 u = invert_spherical_rectangle_sample(ld3(p_ref), ld3(s), ld3(ex), ld3(ey), ld3(p_rect));
+    out2[0] = u.x; out2[1] = u.y;
+}
+int orc_fn_quadratic(float a, float b, float c, float* out2) {
+    Float t0, t1;
+    if (!quadratic(a, b, c, t0, t1)) return 0;
+    out2[0] = t0; out2[1] = t1;
+    return 1;
+}
 // Full interaction at a hit of the scene: out = p[3], n[3], ns[3], dpdu_s[3] (12 floats)
 int orc_fn_hit_interaction(OrcScene* s, const ShmRay* ray, float* out12, ShmHit* hit_out) {
     Oracle* o = reinterpret_cast<Oracle*>(s);

@@ -68,6 +68,15 @@ def load():
     lib.orc_fn_henyey_greenstein.restype, lib.orc_fn_henyey_greenstein.argtypes = F, [F, F]
     lib.orc_fn_sample_henyey_greenstein.restype, lib.orc_fn_sample_henyey_greenstein.argtypes = None, [FP, F, FP, FP]
     lib.orc_fn_sample_exponential.restype, lib.orc_fn_sample_exponential.argtypes = F, [F, F]
+    lib.orc_fn_blp_info.restype, lib.orc_fn_blp_info.argtypes = None, [FP, FP]
+    lib.orc_fn_blp_intersect.restype, lib.orc_fn_blp_intersect.argtypes = C.c_int, [FP, FP, FP, F, FP]
+    lib.orc_fn_blp_interaction.restype, lib.orc_fn_blp_interaction.argtypes = None, [FP, C.c_int, F, F, FP, FP]
+    lib.orc_fn_blp_sample_with_context.restype, lib.orc_fn_blp_sample_with_context.argtypes = C.c_int, [FP, C.c_int, FP, FP, FP, FP, FP]
+    lib.orc_fn_blp_pdf_with_context.restype, lib.orc_fn_blp_pdf_with_context.argtypes = F, [FP, C.c_int, FP, FP, FP, FP]
+    lib.orc_fn_spherical_quad_area.restype, lib.orc_fn_spherical_quad_area.argtypes = F, [FP, FP, FP, FP]
+    lib.orc_fn_sample_spherical_rectangle.restype, lib.orc_fn_sample_spherical_rectangle.argtypes = None, [FP, FP, FP, FP, FP, FP]
+    lib.orc_fn_invert_spherical_rectangle_sample.restype, lib.orc_fn_invert_spherical_rectangle_sample.argtypes = None, [FP, FP, FP, FP, FP, FP]
+    lib.orc_fn_quadratic.restype, lib.orc_fn_quadratic.argtypes = C.c_int, [F, F, F, FP]
     lib.orc_fn_sample_cosine_hemisphere.restype, lib.orc_fn_sample_cosine_hemisphere.argtypes = None, [FP, FP]
     lib.orc_fn_sampler_stream.restype, lib.orc_fn_sampler_stream.argtypes = F, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, FP]
     lib.orc_fn_offset_ray_origin.restype, lib.orc_fn_offset_ray_origin.argtypes = None, [FP, FP, FP, FP, FP]

@@ -10,9 +10,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 LIB_PATH = ROOT / "csrc" / "libshimmer_hip.so"
 
-SHM_ABI_VERSION = 2
+SHM_ABI_VERSION = 3
 SHM_OK = 0
-SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE = 0, 1
+SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE, SHM_SHAPE_BILINEAR_PATCH = 0, 1, 2
 SHM_SPECTRUM_CONSTANT, SHM_SPECTRUM_DENSE, SHM_SPECTRUM_PIECEWISE_LINEAR = 0, 1, 2
 SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATERIAL_THIN_DIELECTRIC = 0, 1, 2, 3
 SHM_MATERIAL_COATED_DIFFUSE, SHM_MATERIAL_COATED_CONDUCTOR, SHM_MATERIAL_MIX = 4, 5, 6
@@ -30,6 +30,12 @@ class ShmBvhNode(C.Structure):
 class ShmTriangleMesh(C.Structure):
     _fields_ = [("n_triangles", C.c_uint32), ("n_vertices", C.c_uint32), ("vertex_indices", c_u32_p), ("p", c_float_p),
                 ("n", c_float_p), ("s", c_float_p), ("uv", c_float_p), ("reverse_orientation", C.c_uint8),
+                ("transform_swaps_handedness", C.c_uint8), ("pad", C.c_uint8 * 6)]
+
+
+class ShmBilinearPatchMesh(C.Structure):
+    _fields_ = [("n_patches", C.c_uint32), ("n_vertices", C.c_uint32), ("vertex_indices", c_u32_p), ("p", c_float_p),
+                ("n", c_float_p), ("uv", c_float_p), ("reverse_orientation", C.c_uint8),
                 ("transform_swaps_handedness", C.c_uint8), ("pad", C.c_uint8 * 6)]
 
 
@@ -80,7 +86,8 @@ class ShmSceneDesc(C.Structure):
                 ("meshes", C.POINTER(ShmTriangleMesh)), ("n_spheres", C.c_uint32), ("spheres", C.POINTER(ShmSphere)),
                 ("n_materials", C.c_uint32), ("materials", C.POINTER(ShmMaterial)), ("n_lights", C.c_uint32),
                 ("lights", C.POINTER(ShmLight)), ("n_spectrum_floats", C.c_uint32), ("spectrum_data", c_float_p),
-                ("camera", ShmCamera), ("film", ShmFilm)]
+                ("camera", ShmCamera), ("film", ShmFilm), ("n_patch_meshes", C.c_uint32), ("pad", C.c_uint32),
+                ("patch_meshes", C.POINTER(ShmBilinearPatchMesh))]
 
 
 class ShmRenderParams(C.Structure):

@@ -24,6 +24,7 @@ struct FlatScene {
     std::vector<uint32_t> vi;
     std::vector<float> vn, vs, vuv;
     std::vector<ShmSphere> spheres;
+    std::vector<shm::PatchExtra> patches;
     std::vector<ShmMaterial> materials;
     std::vector<ShmLight> lights;
     std::vector<uint32_t> infinite_lights;
@@ -32,7 +33,7 @@ struct FlatScene {
     ShmCamera camera;
     ShmFilm film;
     uint32_t max_leaf_depth = 0;  // deepest leaf (root = 0); bounds the traversal stack
-    bool has_spheres = false;
+    bool has_spheres = false;  // any non-triangle shape (sphere or bilinear patch): selects k_trace3<.., TRI_ONLY = false>
     bool has_layered = false;  // any Coated* material: selects the k_shade instantiation that carries LayeredBxDF
 
     shm::SceneView view() const {
@@ -48,6 +49,7 @@ struct FlatScene {
         v.vs = vs.data();
         v.vuv = vuv.data();
         v.spheres = spheres.data();
+        v.patches = patches.data();
         v.materials = materials.data();
         v.lights = lights.data();
         v.n_lights = (uint32_t)lights.size();
@@ -146,6 +148,19 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         out.vuv.assign(2, 0.0f);
     }
 
+    // bilinear patch meshes
+    const uint32_t n_pm = d->patch_meshes ? d->n_patch_meshes : 0;
+    std::vector<uint32_t> patch_base(n_pm + 1, 0);
+    for (uint32_t m = 0; m < n_pm; ++m) {
+        const ShmBilinearPatchMesh& mesh = d->patch_meshes[m];
+        if (!mesh.vertex_indices || !mesh.p) { err = "patch mesh without indices/positions"; return SHM_ERR_INVALID_ARGUMENT; }
+        if (mesh.n || mesh.uv) { err = "bilinear patch meshes with per-vertex n / uv are not supported by this ABI version"; return SHM_ERR_UNSUPPORTED; }
+        patch_base[m + 1] = patch_base[m] + mesh.n_patches;
+    }
+    const uint32_t n_patches = patch_base[n_pm];
+    if (n_patches > shm::PRIM_INDEX_MASK) { err = "too many bilinear patches"; return SHM_ERR_INVALID_ARGUMENT; }
+    out.patches.assign(std::max<uint32_t>(n_patches, 1), shm::PatchExtra{});
+
     // 48-B leaf-order records
     out.prim_recs.resize(d->n_primitives);
     for (uint32_t s = 0; s < d->n_primitives; ++s) {
@@ -174,8 +189,30 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
             rec.kind_index = 0;
             rec.mesh = m;
             rec.tri = pr.shape_index;
+        } else if (pr.shape_kind == SHM_SHAPE_BILINEAR_PATCH) {
+            if (pr.shape_index >= n_patches) { err = "bilinear patch index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            uint32_t m = (uint32_t)(std::upper_bound(patch_base.begin(), patch_base.end(), pr.shape_index) - patch_base.begin()) - 1;
+            const ShmBilinearPatchMesh& mesh = d->patch_meshes[m];
+            uint32_t local = pr.shape_index - patch_base[m];
+            shm::V3 c[4];
+            for (int k = 0; k < 4; ++k) {
+                uint32_t vidx = mesh.vertex_indices[4ull * local + k];
+                if (vidx >= mesh.n_vertices) { err = "vertex index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+                c[k] = shm::v3(mesh.p[3ull * vidx], mesh.p[3ull * vidx + 1], mesh.p[3ull * vidx + 2]);
+            }
+            rec.p0[0] = c[0].x; rec.p0[1] = c[0].y; rec.p0[2] = c[0].z;  // p00
+            rec.p1[0] = c[1].x; rec.p1[1] = c[1].y; rec.p1[2] = c[1].z;  // p10
+            rec.p2[0] = c[2].x; rec.p2[1] = c[2].y; rec.p2[2] = c[2].z;  // p01
+            shm::PatchExtra& px = out.patches[pr.shape_index];
+            px.p11[0] = c[3].x; px.p11[1] = c[3].y; px.p11[2] = c[3].z;
+            // BilinearPatch::new / is_rectangle (bilinear_patch.rs:40-69, 108-142), evaluated once, with the shared arithmetic
+            bool is_rect = shm::blp_is_rectangle(c[0], c[1], c[2], c[3]);
+            px.area = shm::blp_area(c[0], c[1], c[2], c[3], is_rect);
+            px.flags = (is_rect ? 1u : 0u) | ((((mesh.reverse_orientation != 0) ^ (mesh.transform_swaps_handedness != 0)) ? 2u : 0u));
+            rec.kind_index = shm::PRIM_PATCH_BIT | pr.shape_index;
+            out.has_spheres = true;
         } else {
-            err = "unsupported shape kind (bilinear patches / instances are SURVEY §8f rows)";
+            err = "unsupported shape kind (instances are a SURVEY §8f row)";
             return SHM_ERR_UNSUPPORTED;
         }
         out.prim_recs[s] = rec;

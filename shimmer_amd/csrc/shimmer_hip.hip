@@ -363,8 +363,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                         if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_SPHERE_BIT)) {
                             // Sphere::intersect (sphere.rs:95-196) through the same leaf phase; the hit record carries p_obj and phi
                             QuadricIntersection qi;
-                            got = sphere_basic_intersect(sv.spheres[__float_as_uint(q2.y) & ~PRIM_SPHERE_BIT], ro, rd_full, t_max, qi);
+                            got = sphere_basic_intersect(sv.spheres[__float_as_uint(q2.y) & PRIM_INDEX_MASK], ro, rd_full, t_max, qi);
                             if (got) { hit_prim = (int32_t)slot; hit_t = qi.t_hit; hit_b0 = qi.p_obj.x; hit_b1 = qi.p_obj.y; hit_b2 = qi.p_obj.z; hit_phi = qi.phi; }
+                        } else if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_PATCH_BIT)) {
+                            // BilinearPatch::intersect (bilinear_patch.rs:144-236): the record holds p00, p10, p01; (u, v) go in b0, b1
+                            BilinearIntersection bi;
+                            got = blp_intersect(ro, rd_full, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x),
+                                                ld3(sv.patches[__float_as_uint(q2.y) & PRIM_INDEX_MASK].p11), bi);
+                            if (got) { hit_prim = (int32_t)slot; hit_t = bi.t; hit_b0 = bi.u; hit_b1 = bi.v; hit_b2 = 0.0f; hit_phi = 0.0f; }
                         } else {
                             TriangleIntersection ti;
                             got = intersect_triangle_pre(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
@@ -437,7 +443,9 @@ constexpr int SHADE_CHUNK = 2048;  // queue entries per workgroup chunk: ONE glo
 #endif
 // HAS_LAYERED = false is the instantiation for scenes without Coated* materials: the LayeredBxDF random walks (three per
 // vertex: f and pdf for NEE, sample_f) are compiled out of it.
-template <bool HAS_LAYERED>
+//   TRI_ONLY = true is the instantiation for scenes made of triangles only: no quadric / bilinear-patch interaction and light
+//   sampling code (with it the kernel needs 264 VGPRs, one wave per SIMD; without it 243, two waves).
+template <bool HAS_LAYERED, bool TRI_ONLY>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters) {
@@ -497,13 +505,13 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                     if (depth == 0 || specular_bounce) {
                         add_l(beta * le);
                     } else {
-                        Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, load_prev_ctx(), ray_d);
+                        Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY>(sv, light, load_prev_ctx(), ray_d);
                         Float w_b = power_heuristic(1, p_b, 1, p_l);
                         add_l(beta * w_b * le);
                     }
                 }
             } else {
-                SurfaceInteraction si = hit_interaction(sv, hit, -ray_d);
+                SurfaceInteraction si = hit_interaction<TRI_ONLY>(sv, hit, -ray_d);
                 const ShmPrimitive prim = sv.primitives[hit.prim];
                 // integrator.rs:798-813: emission at the hit
                 if (prim.area_light >= 0) {
@@ -513,7 +521,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                         if (depth == 0 || specular_bounce) {
                             add_l(beta * le);
                         } else {
-                            Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, load_prev_ctx(), ray_d);
+                            Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY>(sv, light, load_prev_ctx(), ray_d);
                             Float w_l = power_heuristic(1, p_b, 1, p_l);
                             add_l(beta * w_l * le);
                         }
@@ -548,7 +556,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                         if (li >= 0) {
                             const ShmLight& light = sv.lights[li];
                             LightLiSample ls;
-                            if (light_sample_li(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
+                            if (light_sample_li<TRI_ONLY>(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
                                 V3 wo = si.wo;
                                 V3 wi = ls.wi;
                                 Spec f = bsdf_f(bsdf, wo, wi) * abs_dot(wi, si.shading.n);
@@ -878,6 +886,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if ((rc = dev_upload(s, f.vs, &v.vs)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.vuv, &v.vuv)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.spheres, &v.spheres)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.patches, &v.patches)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.materials, &v.materials)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.lights, &v.lights)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.infinite_lights, &v.infinite_lights)) != SHM_OK) return fail(rc);
@@ -998,12 +1007,15 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
             launch_trace<false>(s, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr);
             hipEventRecord(b, s->stream);
             ev_closest.push_back({a, b});
-            if (s->flat.has_layered)
-                hipLaunchKernelGGL(k_shade<true>, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
-                                   s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, s->d_counters);
-            else
-                hipLaunchKernelGGL(k_shade<false>, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
-                                   s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, s->d_counters);
+            {
+                auto launch_shade = [&](auto kernel) {
+                    hipLaunchKernelGGL(kernel, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
+                                       s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, s->d_counters);
+                };
+                const bool tri_only = !s->flat.has_spheres;
+                if (s->flat.has_layered) { if (tri_only) launch_shade(k_shade<true, true>); else launch_shade(k_shade<true, false>); }
+                else { if (tri_only) launch_shade(k_shade<false, true>); else launch_shade(k_shade<false, false>); }
+            }
             if (bounce < params->max_depth) {
                 hipEvent_t c = ev.get(), d = ev.get();
                 hipEventRecord(c, s->stream);

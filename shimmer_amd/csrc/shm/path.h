@@ -46,6 +46,7 @@ SHM_HD Spec area_light_l(const SceneView& sv, const ShmLight& light, V3 n, V3 w,
 }
 
 // Light::sample_li with allow_incomplete_pdf = true (the only way PathIntegrator calls it, integrator.rs:927)
+template <bool TRI_ONLY = false>
 SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const LightSampleContext& ctx, V2 u,
                             const Wavelengths& lambda, LightLiSample& out) {
     if (light.kind == SHM_LIGHT_POINT) {  // light.rs:452-468
@@ -64,7 +65,8 @@ SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const Li
     ShapeSample ss;
     const PrimRec& pr = sv.prim_recs[light.primitive];
     bool ok;
-    if (pr.kind_index & PRIM_SPHERE_BIT) ok = sphere_sample_with_context(sv.spheres[pr.kind_index & ~PRIM_SPHERE_BIT], sctx, u, ss);
+    if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) ok = sphere_sample_with_context(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], sctx, u, ss);
+    else if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) ok = blp_sample_with_context(load_patch(sv, light.primitive), sctx, u, ss);
     else ok = triangle_sample_with_context(load_triangle(sv, light.primitive), sctx, u, ss);
     if (!ok) return false;
     if (ss.pdf == 0.0f || length_squared(ss.pi.mid() - ctx.p()) == 0.0f) return false;
@@ -77,12 +79,14 @@ SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const Li
     return true;
 }
 // Light::pdf_li with allow_incomplete_pdf = true
+template <bool TRI_ONLY = false>
 SHM_HD Float light_pdf_li(const SceneView& sv, const ShmLight& light, const LightSampleContext& ctx, V3 wi) {
     if (light.kind != SHM_LIGHT_DIFFUSE_AREA) return 0.0f;  // light.rs:470-477, 774-775
     ShapeSampleContext sctx;
     sctx.pi = ctx.pi; sctx.n = ctx.n; sctx.ns = ctx.ns;
     const PrimRec& pr = sv.prim_recs[light.primitive];
-    if (pr.kind_index & PRIM_SPHERE_BIT) return sphere_pdf_with_context(sv.spheres[pr.kind_index & ~PRIM_SPHERE_BIT], sctx, wi);
+    if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) return sphere_pdf_with_context(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], sctx, wi);
+    if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) return blp_pdf_with_context(load_patch(sv, light.primitive), sctx, wi);
     return triangle_pdf_with_context(load_triangle(sv, light.primitive), sctx, wi);
 }
 // UniformLightSampler, light_sampler.rs:91-111. Returns light index or -1; p = 1/n.

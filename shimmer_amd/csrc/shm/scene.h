@@ -10,16 +10,27 @@
 //   vi/vn/vs/vuv global per-vertex shading arrays (only read when a mesh has N/S/uv)
 #pragma once
 #include "shapes.h"
+#include "patch.h"
 #include "spectrum.h"
 
 namespace shm {
 
 struct PrimRec {
     Float p0[3], p1[3], p2[3];
-    uint32_t kind_index;  // bit 31: sphere; low bits: sphere index (sphere) or unused (triangle)
+    uint32_t kind_index;  // bit 31: sphere, bit 30: bilinear patch; low bits: sphere / patch index (0 for a triangle)
     uint32_t mesh;        // triangle: mesh id
     uint32_t tri;         // triangle: global triangle index
 };
+// A bilinear patch keeps p00, p10, p01 in {p0, p1, p2}; its fourth corner and the per-patch constants live here.
+struct PatchExtra {
+    Float p11[3];
+    Float area;      // BilinearPatch::new (bilinear_patch.rs:40-69)
+    uint32_t flags;  // bit 0: is_rectangle (:108-142), bit 1: reverse_orientation ^ transform_swaps_handedness
+    uint32_t pad[3];
+};
+static_assert(sizeof(PatchExtra) == 32, "PatchExtra must be 32 bytes");
+constexpr uint32_t PRIM_PATCH_BIT = 0x40000000u;
+constexpr uint32_t PRIM_INDEX_MASK = 0x3fffffffu;
 static_assert(sizeof(PrimRec) == 48, "PrimRec must be 48 bytes");
 constexpr uint32_t PRIM_SPHERE_BIT = 0x80000000u;
 
@@ -37,6 +48,7 @@ struct SceneView {
     const Float* vs;      // 3 per vertex
     const Float* vuv;     // 2 per vertex
     const ShmSphere* spheres;
+    const PatchExtra* patches;
     const ShmMaterial* materials;
     const ShmLight* lights;
     uint32_t n_lights;
@@ -83,25 +95,41 @@ SHM_HD TriangleData load_triangle(const SceneView& sv, uint32_t slot) {
     return t;
 }
 
+// BilinearPatch::get_points (bilinear_patch.rs:87-98) + the constants fixed at scene creation
+SHM_HD PatchData load_patch(const SceneView& sv, uint32_t slot) {
+    const PrimRec& pr = sv.prim_recs[slot];
+    const PatchExtra& px = sv.patches[pr.kind_index & PRIM_INDEX_MASK];
+    PatchData pd;
+    pd.p00 = ld3(pr.p0); pd.p10 = ld3(pr.p1); pd.p01 = ld3(pr.p2); pd.p11 = ld3(px.p11);
+    pd.is_rect = (px.flags & 1u) != 0;
+    pd.flip = (px.flags & 2u) != 0;
+    pd.area = px.area;
+    return pd;
+}
+
 // Result of BvhAggregate::intersect reduced to identifying data (see ShmHit).
 struct Hit {
     int32_t prim;  // leaf-order slot, -1 = miss
     Float t;
-    Float b0, b1, b2;  // triangle barycentrics | sphere p_obj
+    Float b0, b1, b2;  // triangle barycentrics | sphere p_obj | bilinear patch (u, v, -)
     Float phi;         // sphere
 };
 
 // Shape::intersect's interaction for the CLOSEST hit only (the reference builds it per accepted
 // candidate, triangle.rs:529-535; the result for the surviving candidate is identical).
+// TRI_ONLY: the caller knows the scene holds triangles only (the GPU shade kernel is instantiated per scene class so that the
+// quadric / patch code does not cost registers where it cannot run); the general form is the default.
+template <bool TRI_ONLY = false>
 SHM_HD SurfaceInteraction hit_interaction(const SceneView& sv, const Hit& h, V3 wo) {
     const PrimRec& pr = sv.prim_recs[h.prim];
-    if (pr.kind_index & PRIM_SPHERE_BIT) {
+    if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) {
         QuadricIntersection qi;
         qi.t_hit = h.t;
         qi.p_obj = v3(h.b0, h.b1, h.b2);
         qi.phi = h.phi;
-        return sphere_interaction(sv.spheres[pr.kind_index & ~PRIM_SPHERE_BIT], qi, wo);
+        return sphere_interaction(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], qi, wo);
     }
+    if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) return blp_interaction(load_patch(sv, (uint32_t)h.prim), h.b0, h.b1, wo);
     TriangleData tr = load_triangle(sv, (uint32_t)h.prim);
     TriangleIntersection ti;
     ti.b0 = h.b0; ti.b1 = h.b1; ti.b2 = h.b2; ti.t = h.t;
@@ -114,8 +142,14 @@ SHM_HD bool prim_intersect(const SceneView& sv, uint32_t slot, V3 ro, V3 rd, Flo
     const PrimRec& pr = sv.prim_recs[slot];
     if (pr.kind_index & PRIM_SPHERE_BIT) {
         QuadricIntersection qi;
-        if (!sphere_basic_intersect(sv.spheres[pr.kind_index & ~PRIM_SPHERE_BIT], ro, rd, t_max, qi)) return false;
+        if (!sphere_basic_intersect(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], ro, rd, t_max, qi)) return false;
         h.prim = (int32_t)slot; h.t = qi.t_hit; h.b0 = qi.p_obj.x; h.b1 = qi.p_obj.y; h.b2 = qi.p_obj.z; h.phi = qi.phi;
+        return true;
+    }
+    if (pr.kind_index & PRIM_PATCH_BIT) {
+        BilinearIntersection bi;
+        if (!blp_intersect(ro, rd, t_max, ld3(pr.p0), ld3(pr.p1), ld3(pr.p2), ld3(sv.patches[pr.kind_index & PRIM_INDEX_MASK].p11), bi)) return false;
+        h.prim = (int32_t)slot; h.t = bi.t; h.b0 = bi.u; h.b1 = bi.v; h.b2 = 0.0f; h.phi = 0.0f;
         return true;
     }
     TriangleIntersection ti;

@@ -111,6 +111,8 @@ class SceneBuilder:
     def __init__(self):
         self.meshes = []       # dict(p, vi, n, s, uv, reverse, swaps)
         self.spheres = []      # abi.ShmSphere
+        self.patch_meshes = [] # dict(p, vi (N,4), reverse, swaps)
+        self._patch_count = 0
         self.prims = []        # chunks of (N,4) int64: shape_kind, shape_index, material, area_light
         self._n_prims = 0
         self.materials = []    # abi.ShmMaterial
@@ -284,6 +286,27 @@ class SceneBuilder:
         self._n_prims += ntri
         return first_prim
 
+    def add_patch_mesh(self, p, vi, material, reverse_orientation=False, swaps_handedness=False, emission=None, emission_scale=1.0,
+                       two_sided=False):
+        """bilinearmesh (shape/mesh.rs:289-376): vertices in render space, 4 indices per patch in the order p00, p10, p01, p11
+        (bilinear_patch.rs:87-98). emission -> one DiffuseAreaLight per patch."""
+        p = _as_f32(p, (-1, 3))
+        vi = np.ascontiguousarray(vi, dtype=np.uint32).reshape(-1, 4)
+        self.patch_meshes.append(dict(p=p, vi=vi, reverse=bool(reverse_orientation), swaps=bool(swaps_handedness)))
+        base, n = self._patch_count, vi.shape[0]
+        self._patch_count += n
+        first_prim = self._n_prims
+        chunk = np.empty((n, 4), np.int64)
+        chunk[:, 0], chunk[:, 1], chunk[:, 2], chunk[:, 3] = abi.SHM_SHAPE_BILINEAR_PATCH, base + np.arange(n), material, -1
+        if emission is not None:
+            for t in range(n):
+                q = p[vi[t]].astype(np.float64)  # the light's `area` field feeds phi() only (unused by the path): float64 estimate
+                area = 0.5 * (np.linalg.norm(np.cross(q[1] - q[0], q[2] - q[0])) + np.linalg.norm(np.cross(q[1] - q[3], q[2] - q[3])))
+                chunk[t, 3] = self._area_light(first_prim + t, float(area), emission, emission_scale, two_sided)
+        self.prims.append(chunk)
+        self._n_prims += n
+        return first_prim
+
     def add_sphere(self, radius, material, render_from_object=None, reverse_orientation=False, z_min=None, z_max=None,
                    phi_max=360.0, emission=None, emission_scale=1.0, two_sided=False):
         rfo = IDENTITY if render_from_object is None else _as_f32(render_from_object, (4, 4))
@@ -362,7 +385,12 @@ class SceneBuilder:
             tp = tri_p[sidx[tri_mask]]
             out[tri_mask, :3] = tp.min(axis=1)
             out[tri_mask, 3:] = tp.max(axis=1)
-        for i in np.nonzero(~tri_mask)[0]:
+        patch_mask = kinds == abi.SHM_SHAPE_BILINEAR_PATCH
+        if patch_mask.any():  # bilinear_patch.rs:430-433: union of the four corners
+            pp = np.concatenate([m["p"][m["vi"].astype(np.int64)] for m in self.patch_meshes], axis=0)[sidx[patch_mask]]  # (N,4,3)
+            out[patch_mask, :3] = pp.min(axis=1)
+            out[patch_mask, 3:] = pp.max(axis=1)
+        for i in np.nonzero(kinds == abi.SHM_SHAPE_SPHERE)[0]:
             s = self.spheres[sidx[i]]
             m = np.asarray(list(s.render_from_object), np.float32).reshape(4, 4)
             r = f32(s.radius)
@@ -410,6 +438,13 @@ class SceneBuilder:
             mm.uv = _fptr(m["uv"]) if m["uv"] is not None else None
             mm.reverse_orientation, mm.transform_swaps_handedness = int(m["reverse"]), int(m["swaps"])
         spheres = (abi.ShmSphere * max(1, len(self.spheres)))(*self.spheres)
+        patch_meshes = (abi.ShmBilinearPatchMesh * max(1, len(self.patch_meshes)))()
+        for i, m in enumerate(self.patch_meshes):
+            pm = patch_meshes[i]
+            pm.n_patches, pm.n_vertices = m["vi"].shape[0], m["p"].shape[0]
+            pm.vertex_indices = m["vi"].ctypes.data_as(abi.c_u32_p)
+            pm.p = _fptr(m["p"])
+            pm.reverse_orientation, pm.transform_swaps_handedness = int(m["reverse"]), int(m["swaps"])
         materials = (abi.ShmMaterial * len(self.materials))(*self.materials)
         spec = np.concatenate(self.spec).astype(np.float32) if self.spec else np.zeros(1, np.float32)
         d = abi.ShmSceneDesc()
@@ -422,7 +457,8 @@ class SceneBuilder:
         d.n_lights, d.lights = len(self.lights), lights
         d.n_spectrum_floats, d.spectrum_data = spec.size, _fptr(spec)
         d.camera, d.film = self.camera, self.film
-        self._keep = [nodes, prim_arr, lights, meshes, spheres, materials, spec, bounds, order]
+        d.n_patch_meshes, d.patch_meshes = len(self.patch_meshes), patch_meshes
+        self._keep = [nodes, prim_arr, lights, meshes, spheres, materials, spec, bounds, order, patch_meshes]
         info = dict(n_nodes=n_nodes.value, n_primitives=n, order=order, slot_of_input=slot_of_input, bounds=bounds)
         return d, info
 

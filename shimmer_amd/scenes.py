@@ -83,7 +83,7 @@ def _two_point_spectrum(b, lo, hi):
     return b.spectrum_piecewise(np.array([359.0, 831.0], np.float32), np.array([lo, hi], np.float32))
 
 
-def cornell_box(lib, width=512, height=512, coated=False, mix=False):
+def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=False, patch_skew=0.0):
     """S2 (config C2): 5 walls x 2 + 2 boxes x 5 faces x 2 + light 2 = 32 triangles.
     coated=True: the tall box becomes CoatedConductor (rough interface, Cu), the short one CoatedDiffuse with a scattering
     medium between the interfaces, the floor CoatedDiffuse with a smooth interface (SURVEY §8f-1 materials)."""
@@ -132,9 +132,18 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False):
     p, vi = _box((0.1, 0.0, 0.0), (0.7, 0.6, 0.6), faces="xXYzZ")
     b.add_mesh(_to_render(rot_y(p, -17.0, np.array([0.4, 0, 0.3], np.float32)), rfw), vi, short_m)
     # ceiling light, facing down
-    p, vi = _quad((-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (0.3, 1.98, 0.3), (-0.3, 1.98, 0.3))
-    b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=20.0)
-    return _finish(b, lib, name="S2 cornell box" + (" (coated)" if coated else "") + (" (mix)" if mix else ""))
+    if patches:
+        # the light is ONE rectangular bilinear patch (spherical-rectangle sampling, bilinear_patch.rs:681-737), and
+        # a curved (non-planar) diffuse patch leans against the back wall (area sampling, quadratic intersection)
+        # (patch_skew lifts p11 out of the plane: is_rectangle fails and the same emitter is sampled by area instead)
+        q = np.array([(-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (-0.3, 1.98, 0.3), (0.3, 1.98 - patch_skew, 0.3)], np.float32)  # p00 p10 p01 p11
+        b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], black, emission=blackbody_dense(6500.0), emission_scale=20.0)
+        q = np.array([(-0.9, 0.9, -0.95), (-0.2, 1.1, -0.7), (-0.9, 1.7, -0.95), (-0.2, 1.6, -0.95)], np.float32)
+        b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], green, reverse_orientation=True)
+    else:
+        p, vi = _quad((-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (0.3, 1.98, 0.3), (-0.3, 1.98, 0.3))
+        b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=20.0)
+    return _finish(b, lib, name="S2 cornell box" + (" (coated)" if coated else "") + (" (mix)" if mix else "") + (" (patches)" if patches else ""))
 
 
 def _hash3(ix, iy, iz, seed):

@@ -45,6 +45,8 @@ SCENES = {
     # LayeredBxDF materials (CoatedDiffuse with and without a scattering medium, CoatedConductor)
     "S2_cornell_coated": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, coated=True), 8, 5),
     "S3_small_coated": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, coated=True), 4, 5),
+    "S2_cornell_patches": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, patches=True), 8, 5),  # BilinearPatch: rectangle light + curved patch
+    "S2_cornell_patches_skewed": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, patches=True, patch_skew=2e-3), 4, 5),  # area-sampled patch light
     "S2_cornell_mix": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, mix=True), 8, 5),  # MixMaterial, nested, with a coated leaf
 }
 
