@@ -322,3 +322,97 @@ def three_spheres(lib, width=32, height=32, offsets=(-3.5, 0.0, 5.0), camera=(0.
     # PathIntegrator::li (integrator.rs:776-794)
     b.light_uniform_infinite(np.ones(471, np.float32), scale=1.0)
     return _finish(b, lib, name="three spheres")
+
+
+def random_scene(lib, seed, width=40, height=32):
+    """A seeded random scene for parity fuzzing: every shape kind (triangle meshes with and without per-vertex N / S / uv,
+    full and partial transformed spheres, flat and curved bilinear patches), every material kind (including nested mixes
+    and both coated ones), area lights on every shape kind, a point light, optionally a uniform infinite light, and a
+    thin-lens camera for odd seeds. Nothing here is tuned to look good; it is tuned to reach code."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    b = SceneBuilder()
+    b.set_film(width, height)
+    lens = 0.05 if seed % 2 else 0.0
+    rfw = b.set_camera_look_at(lib, (0.0, 1.2, 6.0), (0.0, 0.8, 0.0), (0, 1, 0), 42.0, lens_radius=lens, focal_distance=6.0)
+
+    def spec():
+        k = rng.integers(0, 3)
+        if k == 0:
+            return float(rng.uniform(0.1, 0.9))
+        return _two_point_spectrum(b, float(rng.uniform(0.05, 0.9)), float(rng.uniform(0.05, 0.9)))
+
+    singles = [
+        b.material_diffuse(spec()),
+        b.material_diffuse(spec()),
+        b.material_conductor(b.spectrum_named("metal-Cu-eta"), b.spectrum_named("metal-Cu-k"), roughness=float(rng.uniform(0.0, 0.4))),
+        b.material_conductor(b.spectrum_named("metal-Ag-eta"), b.spectrum_named("metal-Ag-k"), roughness=0.0),
+        b.material_dielectric(1.5, roughness=float(rng.uniform(0.0, 0.3))),
+        b.material_dielectric(b.spectrum_named("glass-F11"), roughness=0.0),
+        b.material_dielectric(1.33, thin=True),
+        b.material_coated_diffuse(reflectance=spec(), roughness=float(rng.uniform(0.0, 0.3)), thickness=float(rng.uniform(0.005, 0.1)),
+                                  albedo=float(rng.choice([0.0, 0.5])), g=float(rng.uniform(-0.5, 0.5))),
+        b.material_coated_conductor(interface_roughness=float(rng.uniform(0.0, 0.2)), conductor_roughness=float(rng.uniform(0.0, 0.3)),
+                                    reflectance=(0.8 if rng.random() < 0.5 else None)),
+    ]
+    mixes = [b.material_mix(int(rng.choice(singles)), int(rng.choice(singles)), float(rng.uniform(0.2, 0.8)))]
+    mixes.append(b.material_mix(mixes[0], int(rng.choice(singles)), float(rng.uniform(0.2, 0.8))))
+    mats = singles + mixes
+    black = b.material_diffuse(0.0)
+    emit = blackbody_dense(float(rng.uniform(3000.0, 7000.0)))
+
+    def pick():
+        return int(rng.choice(mats))
+
+    # a floor and a back wall so that paths bounce
+    p, vi = _quad((-5, 0, -5), (-5, 0, 7), (5, 0, 7), (5, 0, -5))
+    b.add_mesh(_to_render(p, rfw), vi, singles[0])
+    p, vi = _quad((-5, 0, -3), (5, 0, -3), (5, 5, -3), (-5, 5, -3))
+    b.add_mesh(_to_render(p, rfw), vi, singles[1])
+    # random triangle meshes: icospheres (with per-vertex normals / tangents / uv in some) and a triangle soup
+    for k in range(3):
+        sv, sf = icosphere(int(rng.integers(0, 3)))
+        c = np.array([rng.uniform(-2.5, 2.5), rng.uniform(0.4, 2.0), rng.uniform(-1.5, 2.0)], np.float32)
+        r = f32(rng.uniform(0.3, 0.8))
+        verts = sv * r + c[None]
+        kw = {}
+        if k != 1:
+            kw["n"] = sv / np.linalg.norm(sv, axis=1, keepdims=True)
+        if k == 2:
+            t = np.cross(sv, np.array([0.0, 1.0, 0.0], np.float32)) + np.float32(1e-3)
+            kw["s"] = (t / np.linalg.norm(t, axis=1, keepdims=True)).astype(np.float32)
+            kw["uv"] = np.stack([np.arctan2(sv[:, 2], sv[:, 0]) / (2 * np.pi) + 0.5, np.arccos(np.clip(sv[:, 1], -1, 1)) / np.pi], 1).astype(np.float32)
+        b.add_mesh(_to_render(verts, rfw), sf, pick(), reverse_orientation=bool(k == 1), **kw)
+    soup = rng.uniform(-1.0, 1.0, size=(24, 3)).astype(np.float32) * np.array([2.5, 1.0, 1.5], np.float32) + np.array([0.0, 1.5, 0.5], np.float32)
+    b.add_mesh(_to_render(soup, rfw), np.arange(24).reshape(8, 3), pick())
+    # spheres: full, partial (z clip + phi), scaled / rotated
+    for k in range(3):
+        ang = rng.uniform(0, 2 * np.pi)
+        rot = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+        rfo = np.eye(4, dtype=np.float32)
+        rfo[:3, :3] = rot * (np.float32(rng.uniform(0.7, 1.3)) if k == 2 else np.float32(1.0))
+        rfo[:3, 3] = np.array([rng.uniform(-3, 3), rng.uniform(0.6, 2.2), rng.uniform(-1, 2.5)], np.float32)
+        rfo = (rfw @ rfo).astype(np.float32)
+        kw = dict(z_min=-0.3, z_max=0.45, phi_max=float(rng.uniform(120, 300))) if k == 1 else {}
+        b.add_sphere(0.5, pick(), render_from_object=rfo, reverse_orientation=bool(k == 2), **kw)
+    # bilinear patches: a flat skewed quad and a saddle
+    q = np.array([(-3.0, 0.2, 2.0), (-1.8, 0.2, 2.2), (-3.1, 1.4, 1.6), (-1.7, 1.6, 2.1)], np.float32) + rng.uniform(-0.1, 0.1, (4, 3)).astype(np.float32)
+    b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], pick(), reverse_orientation=bool(seed % 3 == 0))
+    q = np.array([(1.5, 0.1, 2.5), (3.0, 0.1, 2.5), (1.5, 0.1, 3.6), (3.0, 0.1, 3.6)], np.float32)
+    q[:, 1] += rng.uniform(0.0, 0.6, 4).astype(np.float32)
+    b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], pick())
+    # lights: a triangle pair, a sphere, a rectangular patch and a skewed patch, a point light, sometimes the sky
+    p, vi = _quad((-1, 4.5, -1), (1, 4.5, -1), (1, 4.5, 1), (-1, 4.5, 1))
+    b.add_mesh(_to_render(p, rfw), vi, black, emission=emit, emission_scale=float(rng.uniform(5, 20)), two_sided=bool(seed % 2))
+    rfo = np.eye(4, dtype=np.float32)
+    rfo[:3, 3] = np.array([2.5, 3.0, 1.0], np.float32)
+    b.add_sphere(0.25, black, render_from_object=(rfw @ rfo).astype(np.float32), emission=emit, emission_scale=8.0)
+    q = np.array([(-3.5, 3.0, 0.0), (-2.5, 3.0, 0.0), (-3.5, 3.0, 1.0), (-2.5, 3.0, 1.0)], np.float32)  # faces down
+    b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], black, emission=emit, emission_scale=10.0)
+    q = q + np.array([5.5, 0.3, 0.5], np.float32)
+    q[3, 1] -= np.float32(0.05)
+    b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], black, emission=emit, emission_scale=10.0, two_sided=True)
+    pos = (rfw @ np.array([0.0, 3.5, 3.0, 1.0], np.float32))[:3]
+    b.light_point(pos, emit, scale=float(rng.uniform(2, 10)))
+    if seed % 3 == 1:
+        b.light_uniform_infinite(blackbody_dense(6500.0), scale=0.3)
+    return _finish(b, lib, name=f"random scene {seed}")
