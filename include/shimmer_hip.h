@@ -335,6 +335,12 @@ SHM_API int shm_tile_bounds(const int32_t pixel_bounds[4], int32_t tile_w, int32
 SHM_API int shm_camera_perspective(const float world_from_camera[16], float fov_deg, const int32_t full_resolution[2],
                            float lens_radius, float focal_distance, ShmCamera* out,
                            float render_from_world_out[16]);
+/* RgbFilm::get_image / get_pixel_rgb (film.rs:647-707, 720-738) over a read-back film: rgb = sum / weight_sum (when the
+ * weight is non-zero), plus the (here always zero) splat term, times output_rgb_from_sensor_rgb (film.rs:524; row-major 3x3,
+ * passed by the caller, who owns the colour space), with the reference's f16 clamp when write_fp16 is set (film.rs:676-690,
+ * including its `rgb.g > max -> rgb.r = max` assignment). rgb_out: 3 floats per pixel, same order as `film`. */
+SHM_API int shm_film_get_image(const ShmFilmPixel* film, uint64_t n_pixels, const float output_rgb_from_sensor_rgb[9], int write_fp16,
+                       float* rgb_out);
 /* Image::write_pfm (image.rs:1333-1377): RGB float, bottom-up rows, little-endian (scale -1). */
 SHM_API int shm_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height);
 

@@ -335,6 +335,38 @@ int shm_camera_perspective(const float world_from_camera[16], float fov_deg, con
     return SHM_OK;
 }
 
+int shm_film_get_image(const ShmFilmPixel* film, uint64_t n_pixels, const float m[9], int write_fp16, float* rgb_out) {
+    if (!film || !m || !rgb_out) return SHM_ERR_INVALID_ARGUMENT;
+    const float max_f16 = 65504.0f;
+    for (uint64_t i = 0; i < n_pixels; ++i) {
+        // get_pixel_rgb, film.rs:720-738
+        float rgb[3] = {(float)film[i].rgb_sum[0], (float)film[i].rgb_sum[1], (float)film[i].rgb_sum[2]};
+        const double weight_sum = film[i].weight_sum;
+        if (weight_sum != 0.0) {
+            const float w = (float)weight_sum;
+            rgb[0] /= w; rgb[1] /= w; rgb[2] /= w;
+        }
+        for (int c = 0; c < 3; ++c) rgb[c] += 0.0f;  // splat_scale * rgb_splat / filter_integral: nothing splats on this path
+        float out[3];
+        for (int r = 0; r < 3; ++r) {  // mul_mat_vec, square_matrix.rs:474-491: out[i] starts at 0 and accumulates in j order
+            float acc = 0.0f;
+            for (int c = 0; c < 3; ++c) acc += m[3 * r + c] * rgb[c];
+            out[r] = acc;
+        }
+        if (write_fp16) {  // film.rs:676-690, as written there
+            float mx = -INFINITY;
+            for (int c = 0; c < 3; ++c) mx = (out[c] > mx || mx != mx) ? out[c] : mx;
+            if (mx > max_f16) {
+                if (out[0] > max_f16) out[0] = max_f16;
+                if (out[1] > max_f16) out[0] = max_f16;  // (sic) the reference assigns r here
+                if (out[2] > max_f16) out[2] = max_f16;
+            }
+        }
+        rgb_out[3 * i] = out[0]; rgb_out[3 * i + 1] = out[1]; rgb_out[3 * i + 2] = out[2];
+    }
+    return SHM_OK;
+}
+
 int shm_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height) {
     if (!path || !rgb || width <= 0 || height <= 0) return SHM_ERR_INVALID_ARGUMENT;
     FILE* fp = fopen(path, "wb");

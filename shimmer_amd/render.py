@@ -21,6 +21,21 @@ def make_params(seed=0, spp=4, max_depth=5, regularize=False, disable_pixel_jitt
     return p
 
 
+# XYZ -> linear sRGB (IEC 61966-2-1), the output_rgb_from_sensor_rgb of an sRGB film behind an XYZ sensor (film.rs:524):
+# used by the examples and tests; a host that owns an RGBColorSpace passes its own matrix.
+SRGB_FROM_XYZ = np.array([[3.2404542, -1.5371385, -0.4985314], [-0.9692660, 1.8760108, 0.0415560], [0.0556434, -0.2040259, 1.0572252]], np.float32)
+
+
+def film_get_image(lib, film, matrix=None, write_fp16=False):
+    """RgbFilm::get_image through the host mirror (shm_film_get_image): (H, W, 3) float32."""
+    m = np.ascontiguousarray(np.eye(3, dtype=np.float32) if matrix is None else matrix, dtype=np.float32)
+    film = np.ascontiguousarray(film)
+    out = np.empty(film.shape + (3,), np.float32)
+    abi.check(lib, lib.shm_film_get_image(film.ctypes.data_as(C.c_void_p), film.size, m.ctypes.data_as(abi.c_float_p), int(write_fp16),
+                                          out.ctypes.data_as(abi.c_float_p)), "shm_film_get_image")
+    return out
+
+
 def film_to_rgb(film):
     """RgbFilm::get_pixel_rgb without the output colour matrix: rgb_sum / weight_sum as f32 (film.rs:720-731)."""
     rgb = film["rgb_sum"].astype(np.float32)

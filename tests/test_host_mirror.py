@@ -7,7 +7,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from shimmer_amd import abi, scene as scn, scenes
+from shimmer_amd import abi, render, scene as scn, scenes
 
 ROOT = Path(__file__).resolve().parents[1]
 
@@ -210,3 +210,42 @@ def test_scene_validation_errors(orc, lib):
     d.nodes[0].offset = keep
     o = oracle_py.Oracle(d)  # intact again
     o.close()
+
+
+def test_film_get_image(lib, tmp_path):
+    """RgbFilm::get_pixel_rgb / get_image (film.rs:647-707, 720-738) and write_pfm: sum / weight in f32, zero-weight pixels
+    untouched, the 3x3 output matrix applied as mul_mat_vec does (accumulating from 0 in column order), the f16 clamp as
+    the reference writes it, and the PFM file read back row-flipped."""
+    rng = np.random.default_rng(2)
+    film = np.zeros((5, 7), dtype=render.FILM_DTYPE)
+    film["rgb_sum"] = rng.uniform(0, 50, (5, 7, 3))
+    film["weight_sum"] = rng.integers(1, 9, (5, 7)).astype(np.float64)
+    film["weight_sum"][0, 0] = 0.0
+    film["rgb_sum"][1, 1] = (1e6, 3e6, 2.0)   # r and g above the f16 range
+    film["rgb_sum"][1, 2] = (1.0, 3e6, 2.0)   # only g above it
+    film["weight_sum"][1, 1] = film["weight_sum"][1, 2] = 1.0
+    m = render.SRGB_FROM_XYZ
+    img = render.film_get_image(lib, film, m)
+    rgb = film["rgb_sum"].astype(np.float32)
+    w = film["weight_sum"].astype(np.float32)
+    nz = w != 0
+    rgb[nz] = rgb[nz] / w[nz][:, None]
+    want = np.zeros_like(rgb)
+    for r in range(3):
+        acc = np.zeros(rgb.shape[:2], np.float32)
+        for c in range(3):
+            acc = (acc + m[r, c] * rgb[..., c]).astype(np.float32)
+        want[..., r] = acc
+    assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
+    ident = render.film_get_image(lib, film)
+    assert np.array_equal(ident, render.film_to_rgb(film))
+    half = render.film_get_image(lib, film, None, write_fp16=True)
+    assert half[1, 1, 0] == 65504.0 and half[1, 1, 1] == 3e6  # (sic) g > max clamps r, g itself is left alone
+    assert half[1, 2, 0] == 65504.0 and half[1, 2, 1] == 3e6 and half[1, 2, 2] == 2.0
+    path = tmp_path / "out.pfm"
+    abi.check(lib, lib.shm_write_pfm(str(path).encode(), img.ctypes.data_as(abi.c_float_p), 7, 5), "shm_write_pfm")
+    raw = path.read_bytes()
+    header, body = raw[:raw.index(b"-1.0\n") + 5], raw[raw.index(b"-1.0\n") + 5:]
+    assert header == b"PF\n7 5\n-1.0\n"
+    back = np.frombuffer(body, "<f4").reshape(5, 7, 3)[::-1]
+    assert np.array_equal(back, img)
