@@ -154,6 +154,7 @@ def main():
         film = None
         if use_dist:
             film = render.gather_film(render.film_tensor(r, device), rank, world, r.height, r.width, to_host=False)
+            torch.cuda.synchronize(device)  # the send must have read this rank's film before the next step clears it
         return st, film
 
     for _ in range(args.warmup):
