@@ -1,19 +1,19 @@
 // shimmer_hip.hip — the MI355X (gfx950, wave64) wavefront path tracer behind include/shimmer_hip.h.
 //
 // Replaces the tile-parallel loop of the reference (paths relative to /root/reference/src):
-//   integrator.rs:226-322  ImageTileIntegrator::render      -> shm_render / shm_render_wave (host loop below)
+//   integrator.rs:226-322  ImageTileIntegrator::render      -> shm_render / shm_render_device / shm_render_wave (host loop below)
 //   integrator.rs:326-396  evaluate_pixel_sample            -> K1 k_generate
-//   aggregate.rs:71-139    BvhAggregate::intersect          -> K2 k_trace<false,...> (persistent waves, LDS stack)
-//   aggregate.rs:141-203   BvhAggregate::intersect_predicate-> K3 k_trace<true,...>
-//   integrator.rs:772-892  PathIntegrator::li loop body     -> K4+K5 k_shade (one path vertex per launch)
+//   aggregate.rs:71-139    BvhAggregate::intersect          -> K2 k_trace3<false, TRI_ONLY> (persistent waves, LDS stack)
+//   aggregate.rs:141-203   BvhAggregate::intersect_predicate-> K3 k_trace3<true, TRI_ONLY>
+//   integrator.rs:772-892  PathIntegrator::li loop body     -> K4+K5 k_shade<HAS_LAYERED, TRI_ONLY> (one path vertex per launch)
 //   integrator.rs:897-963  PathIntegrator::sample_ld        -> inside k_shade (shadow ray deferred to K3)
 //   film.rs:548-574        RgbFilm::add_sample              -> K6 k_film (per-pixel ordered f64 sums)
 // Leaf arithmetic is the single-source header library csrc/shm/*.h (compiled with -ffp-contract=off).
 //
 // Execution model: one (pixel, sample) per lane; paths live in SoA arrays in HBM; each bounce is
 // trace_closest -> shade -> trace_any over index queues compacted with wave-aggregated atomics; queue
-// sizes stay on the device (persistent / grid-stride kernels read them), so a whole spp-wave is enqueued
-// on one HIP stream without host round trips. There is no CPU fallback anywhere in this file.
+// sizes stay on the device (persistent / grid-stride kernels read them), so a whole render (all fused spp-waves)
+// is enqueued on one HIP stream without host round trips. There is no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
