@@ -335,6 +335,13 @@ SHM_API int shm_tile_bounds(const int32_t pixel_bounds[4], int32_t tile_w, int32
 SHM_API int shm_camera_perspective(const float world_from_camera[16], float fov_deg, const int32_t full_resolution[2],
                            float lens_radius, float focal_distance, ShmCamera* out,
                            float render_from_world_out[16]);
+/* C entry to the C++ host mirror of the reference's integrator interface (shimmer_amd/csrc/host/integrator.hpp):
+ * create_integrator(name, {maxdepth, regularize, lightsampler "uniform", spp}, scene)->render(options), integrator.rs:16-42,
+ * 52-54, 180-210, 226-322. `name` other than "path" fails the way the reference panics ("Unknown integrator ..."); the message
+ * is available through shm_last_error(). film_out: pixel_bounds-sized, overwritten; n_waves_out: spp-waves rendered. */
+SHM_API int shm_integrator_render(const char* name, const ShmSceneDesc* scene, int device, int32_t max_depth, int regularize,
+                          int32_t samples_per_pixel, int32_t seed, int disable_pixel_jitter, int disable_wavelength_jitter,
+                          ShmFilmPixel* film_out, ShmStats* stats_out, int32_t* n_waves_out);
 /* RgbFilm::get_image / get_pixel_rgb (film.rs:647-707, 720-738) over a read-back film: rgb = sum / weight_sum (when the
  * weight is non-zero), plus the (here always zero) splat term, times output_rgb_from_sensor_rgb (film.rs:524; row-major 3x3,
  * passed by the caller, who owns the colour space), with the reference's f16 clamp when write_fp16 is set (film.rs:676-690,

@@ -145,6 +145,8 @@ EXPORTS = {
     "shm_bvh_build": (C.c_int, [c_float_p, C.c_uint32, C.c_int, C.POINTER(ShmBvhNode), c_u32_p, c_u32_p]),
     "shm_tile_bounds": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(ShmTile), c_u32_p]),
     "shm_camera_perspective": (C.c_int, [c_float_p, C.c_float, C.POINTER(C.c_int32), C.c_float, C.c_float, C.POINTER(ShmCamera), c_float_p]),
+    "shm_integrator_render": (C.c_int, [C.c_char_p, C.POINTER(ShmSceneDesc), C.c_int, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_int,
+                                        C.c_void_p, C.POINTER(ShmStats), C.POINTER(C.c_int32)]),
     "shm_film_get_image": (C.c_int, [C.c_void_p, C.c_uint64, c_float_p, C.c_int, c_float_p]),
     "shm_write_pfm": (C.c_int, [C.c_char_p, c_float_p, C.c_int32, C.c_int32]),
 }

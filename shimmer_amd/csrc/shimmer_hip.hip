@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "host/flatten.h"
+#include "host/integrator.hpp"
 #include "shm/path.h"
 
 using namespace shm;
@@ -1153,6 +1154,35 @@ static int trace_device_impl(ShmScene* s, bool any, const void* rays_dev, uint32
         stats->ms_total = tot;
     }
     return SHM_OK;
+}
+
+int shm_integrator_render(const char* name, const ShmSceneDesc* scene, int device, int32_t max_depth, int regularize,
+                          int32_t samples_per_pixel, int32_t seed, int disable_pixel_jitter, int disable_wavelength_jitter,
+                          ShmFilmPixel* film_out, ShmStats* stats_out, int32_t* n_waves_out) {
+    if (!name || !scene || !film_out) { g_err = "invalid integrator arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    try {
+        shimmer::PathIntegratorParameters p;
+        p.max_depth = max_depth;
+        p.regularize = regularize != 0;
+        p.samples_per_pixel = samples_per_pixel;
+        std::unique_ptr<shimmer::Integrator> integrator = shimmer::create_integrator(name, p, *scene, device);
+        shimmer::Options options;
+        options.seed = seed;
+        options.disable_pixel_jitter = disable_pixel_jitter != 0;
+        options.disable_wavelength_jitter = disable_wavelength_jitter != 0;
+        integrator->render(options);
+        auto* w = static_cast<shimmer::WavefrontPathIntegrator*>(integrator.get());
+        std::copy(w->film().begin(), w->film().end(), film_out);
+        if (stats_out) *stats_out = w->stats();
+        if (n_waves_out) *n_waves_out = w->waves();
+        return SHM_OK;
+    } catch (const shimmer::IntegratorError& e) {
+        g_err = e.what();
+        return SHM_ERR_UNSUPPORTED;
+    } catch (const std::exception& e) {  // nothing unwinds across the ABI
+        g_err = e.what();
+        return SHM_ERR_INTERNAL;
+    }
 }
 
 int shm_trace_closest_device(ShmScene* s, const void* rays_dev, uint32_t n, void* hits_dev, int repeat, ShmStats* stats) {

@@ -222,3 +222,27 @@ def test_no_silent_fallback(env):
     ptr, nbytes = gpu.film_device_ptr()
     assert ptr and nbytes == 16 * 16 * 32
     gpu.close()
+
+
+def test_integrator_mirror_parity(env):
+    """The C++ host mirror of the reference's interface (create_integrator("path", ...)->render(options), integrator.hpp):
+    the reference's own spp-wave loop (1, 1, 2, 4, 8, ... over all 8x8 tiles) driving shm_render_wave gives the oracle's film
+    bit for bit, the same counters, and the wave count of integrator.rs:231-233."""
+    import ctypes as C
+    from shimmer_amd import abi
+    lib, oracle_py, render, scenes = env
+    sc = scenes.cornell_box(lib, 72, 56)
+    spp, depth, seed = 21, 5, 6
+    film = np.zeros((56, 72), dtype=render.FILM_DTYPE)
+    st, waves = abi.ShmStats(), C.c_int32(0)
+    abi.check(lib, lib.shm_integrator_render(b"path", C.byref(sc.desc), 0, depth, 0, spp, seed, 0, 0, film.ctypes.data_as(C.c_void_p),
+                                             C.byref(st), C.byref(waves)), "shm_integrator_render")
+    fo, so = oracle_py.Oracle(sc.desc).render(render.make_params(seed=seed, spp=spp, max_depth=depth), n_threads=os.cpu_count() or 1)
+    assert np.array_equal(film, fo)
+    assert st.rays_closest == so["rays_closest"] and st.rays_any == so["rays_any"] and st.nodes_closest == so["nodes_closest"]
+    assert waves.value == len(scn_wave_schedule(spp)) == 6  # [0,1) [1,2) [2,4) [4,8) [8,16) [16,21)
+
+
+def scn_wave_schedule(spp):
+    from shimmer_amd.scene import wave_schedule
+    return wave_schedule(spp)

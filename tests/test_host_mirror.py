@@ -249,3 +249,16 @@ def test_film_get_image(lib, tmp_path):
     assert header == b"PF\n7 5\n-1.0\n"
     back = np.frombuffer(body, "<f4").reshape(5, 7, 3)[::-1]
     assert np.array_equal(back, img)
+
+
+def test_integrator_mirror_errors(lib):
+    """create_integrator (integrator.rs:16-42) through the C++ host mirror: an unknown name is the reference's
+    "Unknown integrator" panic turned into an error code + message; the other two reference integrators are named as not
+    provided; without a GPU "path" fails with the no-device error instead of falling back."""
+    sc = scenes.cornell_box(lib, 16, 16)
+    film = np.zeros((16, 16), dtype=render.FILM_DTYPE)
+    args = (C.byref(sc.desc), 0, 5, 0, 2, 0, 0, 0, film.ctypes.data_as(C.c_void_p), None, None)
+    assert lib.shm_integrator_render(b"bdpt", *args) == -2 and b"Unknown integrator bdpt" in lib.shm_last_error()
+    assert lib.shm_integrator_render(b"randomwalk", *args) == -2 and b"not provided" in lib.shm_last_error()
+    if lib.shm_device_count() == 0:
+        assert lib.shm_integrator_render(b"path", *args) == -2 and b"no CPU fallback" in lib.shm_last_error()
