@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Throughput of the BASELINE.json side configurations on one GPU (informational; bench.py measures the headline one):
+C1 sphere + area light 128^2 x 4, C2 Cornell 512^2 x 64, C4 crown-proxy 1000x1400 x 256 maxdepth 32, and the coated S3."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from shimmer_amd import abi, scenes, render
+
+lib = abi.load_library()
+CONFIGS = [
+    ("C1 sphere+light 128x128x4", lambda: scenes.sphere_light(lib, 128, 128), 4, 5),
+    ("C2 cornell 512x512x64", lambda: scenes.cornell_box(lib, 512, 512), 64, 5),
+    ("C2p cornell+patches 512x512x64", lambda: scenes.cornell_box(lib, 512, 512, patches=True), 64, 5),
+    ("C4 crown-proxy 1000x1400x256 d32", lambda: scenes.crown_proxy(lib, 1000, 1400), 256, 32),
+    ("S3c coated ganesha 1024x1024x64", lambda: scenes.ganesha_proxy(lib, 1024, 1024, coated=True), 64, 5),
+]
+only = sys.argv[1:] 
+for name, make, spp, depth in CONFIGS:
+    if only and not any(o in name for o in only):
+        continue
+    sc = make()
+    r = render.Renderer(lib, sc.desc, 0)
+    p = render.make_params(seed=0, spp=spp, max_depth=depth)
+    r.clear(); r.render_device(p)  # warm-up (workspace allocation)
+    r.clear()
+    t0 = time.perf_counter()
+    st = r.render_device(p)
+    dt = time.perf_counter() - t0
+    rays = st["rays_closest"] + st["rays_any"]
+    print(f"{name:36s} prims {sc.info['n_primitives']:8d}  {rays/1e6:9.1f} Mrays in {dt*1e3:8.1f} ms = {rays/dt/1e6:8.1f} Mray/s | closest {st['ms_trace_closest']:7.1f} any {st['ms_trace_any']:7.1f} "
+          f"shade {st['ms_shade']:7.1f} ms | nodes/ray {st['nodes_closest']/max(1,st['rays_closest']):5.1f}", flush=True)
+    r.close()
