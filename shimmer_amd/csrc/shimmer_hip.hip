@@ -437,11 +437,13 @@ __device__ __forceinline__ float4 st_spec(const Spec& s) { return make_float4(s.
 constexpr int SHADE2_BLOCK = 256;
 constexpr int SHADE_CHUNK = 2048;  // queue entries per workgroup chunk: ONE global atomic per queue per chunk (a single
                                    // counter word saturates near 88 atomics/us: MI355X_MICROARCH.md "dequeue")
+// Two waves per SIMD for every instantiation: the lean one needs 236 VGPRs anyway; the ones with the quadric / patch or the
+// LayeredBxDF code want 264 / 460 and are better off spilling a little than running one wave per SIMD (measured: patch scene
+// shade 16.6 -> 10.9 ms, coated S3 187 -> 177 ms; 3 or 4 waves lose to spills).
 #ifndef K_SHADE_WAVES
-#define K_SHADE_ATTR
-#else
-#define K_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(K_SHADE_WAVES, K_SHADE_WAVES)))
+#define K_SHADE_WAVES 2
 #endif
+#define K_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(K_SHADE_WAVES, K_SHADE_WAVES)))
 // HAS_LAYERED = false is the instantiation for scenes without Coated* materials: the LayeredBxDF random walks (three per
 // vertex: f and pdf for NEE, sample_f) are compiled out of it.
 //   TRI_ONLY = true is the instantiation for scenes made of triangles only: no quadric / bilinear-patch interaction and light
