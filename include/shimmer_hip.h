@@ -114,7 +114,13 @@ typedef struct ShmPrimitive {
 enum {
     SHM_SPECTRUM_CONSTANT = 0,         /* ConstantSpectrum          (spectra/spectrum.rs:143-166) */
     SHM_SPECTRUM_DENSE = 1,            /* DenselySampledSpectrum, lambda_min..=lambda_max, 1 nm (:168-291) */
-    SHM_SPECTRUM_PIECEWISE_LINEAR = 2  /* PiecewiseLinearSpectrum   (:293-428): n lambdas then n values */
+    SHM_SPECTRUM_PIECEWISE_LINEAR = 2, /* PiecewiseLinearSpectrum   (:293-428): n lambdas then n values */
+    /* RGB-derived spectra: the host looks the sigmoid coefficients up (RgbColorSpace::to_rgb_coeffs, colorspace.rs:95) and
+     * hands them over; the device evaluates RgbSigmoidPolynomial::get = s(c0 l^2 + c1 l + c2) (color.rs:333-383). */
+    SHM_SPECTRUM_RGB_ALBEDO = 3,       /* RgbAlbedoSpectrum     (:498-528) */
+    SHM_SPECTRUM_RGB_UNBOUNDED = 4,    /* RgbUnboundedSpectrum  (:531-565): c = scale (2 max(r,g,b)) */
+    SHM_SPECTRUM_RGB_ILLUMINANT = 5    /* RgbIlluminantSpectrum (:568-607): c = scale; offset / n / lambda_min: the colour space's
+                                          illuminant as a densely sampled table */
 };
 typedef struct ShmSpectrum {
     uint32_t kind;
@@ -122,7 +128,7 @@ typedef struct ShmSpectrum {
     uint32_t offset;      /* DENSE / PIECEWISE: first float in ShmSceneDesc::spectrum_data */
     uint32_t n;           /* DENSE: number of samples; PIECEWISE: number of knots */
     int32_t lambda_min;   /* DENSE */
-    uint32_t pad[3];
+    float rgb_c[3];       /* RGB_*: c0, c1, c2 of the sigmoid polynomial */
 } ShmSpectrum;
 
 enum {

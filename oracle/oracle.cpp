@@ -606,6 +606,14 @@ float orc_fn_spectrum_get(OrcScene* s, const ShmSpectrum* sp, float lambda) {
     Oracle* o = reinterpret_cast<Oracle*>(s);
     return spectrum_get(*sp, o->sv.spectrum_data, lambda);
 }
+// Spectrum::sample at four wavelengths
+void orc_fn_spectrum_sample(OrcScene* s, const ShmSpectrum* sp, const float* lambda4, float* out4) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    Wavelengths w;
+    for (int i = 0; i < 4; ++i) { w.lambda[i] = lambda4[i]; w.pdf[i] = 1.0f; }
+    Spec r = spectrum_sample(*sp, o->sv.spectrum_data, w);
+    for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
+}
 
 }  // extern "C"
 #pragma GCC visibility pop

@@ -88,6 +88,7 @@ def load():
     lib.orc_fn_camera_ray.restype, lib.orc_fn_camera_ray.argtypes = None, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, FP]
     lib.orc_fn_film_sample_rgb.restype, lib.orc_fn_film_sample_rgb.argtypes = None, [C.c_void_p, FP, FP, FP, FP]
     lib.orc_fn_spectrum_get.restype, lib.orc_fn_spectrum_get.argtypes = F, [C.c_void_p, C.POINTER(abi.ShmSpectrum), F]
+    lib.orc_fn_spectrum_sample.restype, lib.orc_fn_spectrum_sample.argtypes = None, [C.c_void_p, C.POINTER(abi.ShmSpectrum), FP, FP]
     _lib = lib
     return lib
 

@@ -14,6 +14,7 @@ SHM_ABI_VERSION = 3
 SHM_OK = 0
 SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE, SHM_SHAPE_BILINEAR_PATCH = 0, 1, 2
 SHM_SPECTRUM_CONSTANT, SHM_SPECTRUM_DENSE, SHM_SPECTRUM_PIECEWISE_LINEAR = 0, 1, 2
+SHM_SPECTRUM_RGB_ALBEDO, SHM_SPECTRUM_RGB_UNBOUNDED, SHM_SPECTRUM_RGB_ILLUMINANT = 3, 4, 5
 SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATERIAL_THIN_DIELECTRIC = 0, 1, 2, 3
 SHM_MATERIAL_COATED_DIFFUSE, SHM_MATERIAL_COATED_CONDUCTOR, SHM_MATERIAL_MIX = 4, 5, 6
 SHM_LIGHT_POINT, SHM_LIGHT_DIFFUSE_AREA, SHM_LIGHT_UNIFORM_INFINITE = 0, 1, 2
@@ -52,7 +53,7 @@ class ShmPrimitive(C.Structure):
 
 class ShmSpectrum(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("c", C.c_float), ("offset", C.c_uint32), ("n", C.c_uint32),
-                ("lambda_min", C.c_int32), ("pad", C.c_uint32 * 3)]
+                ("lambda_min", C.c_int32), ("rgb_c", C.c_float * 3)]
 
 
 class ShmMaterial(C.Structure):

@@ -70,8 +70,8 @@ struct FlatScene {
 };
 
 inline bool check_spectrum(const ShmSpectrum& s, uint32_t n_floats, std::string& err) {
-    if (s.kind == SHM_SPECTRUM_CONSTANT) return true;
-    if (s.kind == SHM_SPECTRUM_DENSE) {
+    if (s.kind == SHM_SPECTRUM_CONSTANT || s.kind == SHM_SPECTRUM_RGB_ALBEDO || s.kind == SHM_SPECTRUM_RGB_UNBOUNDED) return true;
+    if (s.kind == SHM_SPECTRUM_DENSE || s.kind == SHM_SPECTRUM_RGB_ILLUMINANT) {
         if ((uint64_t)s.offset + s.n > n_floats) { err = "dense spectrum out of range"; return false; }
         return true;
     }

@@ -111,9 +111,26 @@ SHM_HD int find_interval(int size, Pred pred) {
     return r;
 }
 
-// Spectrum::get(lambda) for the three supported kinds.
+// RgbSigmoidPolynomial::get, color.rs:353-383: s(poly(lambda, [c2, c1, c0])). `poly` is the fast_polynomial 0.1.0 crate (source
+// not vendored: parity unpinned at that boundary); a three-coefficient Estrin / Horner evaluation with FMAs is
+// fma(x^2, c0, fma(x, c1, c2)), which is what is done here.
+SHM_HD Float rgb_sigmoid(const Float c[3], Float lambda) {
+    Float x = fma(lambda * lambda, c[0], fma(lambda, c[1], c[2]));
+    if (is_inf(x)) return x > 0.0f ? 1.0f : 0.0f;
+    return 0.5f + x / (2.0f * sqrt(1.0f + x * x));
+}
+SHM_HD Float dense_get(const ShmSpectrum& s, const Float* data, Float lambda) {  // spectrum.rs:265-271
+    int offset = (int)lambda - s.lambda_min;
+    if (offset < 0 || offset >= (int)s.n) return 0.0f;
+    return data[s.offset + offset];
+}
+
+// Spectrum::get(lambda)
 SHM_HD Float spectrum_get(const ShmSpectrum& s, const Float* data, Float lambda) {
     if (s.kind == SHM_SPECTRUM_CONSTANT) return s.c;
+    if (s.kind == SHM_SPECTRUM_RGB_ALBEDO) return rgb_sigmoid(s.rgb_c, lambda);                                   // spectrum.rs:513-515
+    if (s.kind == SHM_SPECTRUM_RGB_UNBOUNDED) return s.c * rgb_sigmoid(s.rgb_c, lambda);                           // :550-552
+    if (s.kind == SHM_SPECTRUM_RGB_ILLUMINANT) return s.c * rgb_sigmoid(s.rgb_c, lambda) * dense_get(s, data, lambda);  // :592-594
     if (s.kind == SHM_SPECTRUM_DENSE) {
         // spectrum.rs:265-271: `lambda as i32` truncates toward zero (saturating)
         int offset = (int)lambda - s.lambda_min;
@@ -131,13 +148,17 @@ SHM_HD Float spectrum_get(const ShmSpectrum& s, const Float* data, Float lambda)
 // Spectrum::sample(lambda)
 SHM_HD Spec spectrum_sample(const ShmSpectrum& s, const Float* data, const Wavelengths& w) {
     Spec r;
-    if (s.kind == SHM_SPECTRUM_DENSE) {
+    if (s.kind == SHM_SPECTRUM_DENSE || s.kind == SHM_SPECTRUM_RGB_ILLUMINANT) {
         // spectrum.rs:280-291: nearest-nm lookup through round() (reference quirk 11)
         for (int i = 0; i < NSPEC; ++i) {
             int offset = (int)round(w.lambda[i]) - s.lambda_min;
             r.v[i] = (offset < 0 || offset >= (int)s.n) ? 0.0f : data[s.offset + offset];
         }
-        return r;
+        if (s.kind == SHM_SPECTRUM_DENSE) return r;
+        // RgbIlluminantSpectrum::sample, spectrum.rs:600-606: (scale * rsp) per wavelength, times the illuminant's sample
+        Spec q;
+        for (int i = 0; i < NSPEC; ++i) q.v[i] = s.c * rgb_sigmoid(s.rgb_c, w.lambda[i]);
+        return q * r;
     }
     for (int i = 0; i < NSPEC; ++i) r.v[i] = spectrum_get(s, data, w.lambda[i]);
     return r;

@@ -152,6 +152,20 @@ class SceneBuilder:
         s.kind, s.offset, s.n = abi.SHM_SPECTRUM_PIECEWISE_LINEAR, self._pool(np.concatenate([lam, val])), lam.size
         return s
 
+    def spectrum_rgb(self, coeffs, scale=None, illuminant=None):
+        """RGB-derived spectra from sigmoid coefficients (c0, c1, c2) the host looked up with RgbColorSpace::to_rgb_coeffs:
+        RgbAlbedoSpectrum (no scale), RgbUnboundedSpectrum (scale), RgbIlluminantSpectrum (scale + dense illuminant table)."""
+        s = abi.ShmSpectrum()
+        s.rgb_c[:] = [float(f32(c)) for c in coeffs]
+        if illuminant is not None:
+            d = self.spectrum_dense(illuminant)
+            s.kind, s.c, s.offset, s.n, s.lambda_min = abi.SHM_SPECTRUM_RGB_ILLUMINANT, float(scale), d.offset, d.n, d.lambda_min
+        elif scale is not None:
+            s.kind, s.c = abi.SHM_SPECTRUM_RGB_UNBOUNDED, float(scale)
+        else:
+            s.kind = abi.SHM_SPECTRUM_RGB_ALBEDO
+        return s
+
     def spectrum_named(self, name):
         """NamedSpectrum (spectra/named_spectrum.rs:13-27): metals / glasses as PiecewiseLinear."""
         key = {"glass-BK7": "GLASS_BK7_ETA_SAMPLES", "glass-BAF10": "GLASS_BAF10_ETA_SAMPLES", "glass-F11": "GLASS_F11_ETA_SAMPLES",

@@ -336,9 +336,12 @@ def random_scene(lib, seed, width=40, height=32):
     rfw = b.set_camera_look_at(lib, (0.0, 1.2, 6.0), (0.0, 0.8, 0.0), (0, 1, 0), 42.0, lens_radius=lens, focal_distance=6.0)
 
     def spec():
-        k = rng.integers(0, 3)
+        k = rng.integers(0, 4)
         if k == 0:
             return float(rng.uniform(0.1, 0.9))
+        if k == 3:  # RgbAlbedoSpectrum from sigmoid coefficients: x = c0 l^2 + c1 l + c2 stays within a few units over 360..830 nm
+            c0 = float(rng.uniform(-2e-5, 2e-5))
+            return b.spectrum_rgb((c0, float(rng.uniform(-6e-3, 6e-3)) - 1190.0 * c0, float(rng.uniform(-1.5, 1.5))))
         return _two_point_spectrum(b, float(rng.uniform(0.05, 0.9)), float(rng.uniform(0.05, 0.9)))
 
     singles = [
