@@ -10,7 +10,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 LIB_PATH = ROOT / "csrc" / "libshimmer_hip.so"
 
-SHM_ABI_VERSION = 3
+SHM_ABI_VERSION = 4
 SHM_OK = 0
 SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE, SHM_SHAPE_BILINEAR_PATCH = 0, 1, 2
 SHM_SPECTRUM_CONSTANT, SHM_SPECTRUM_DENSE, SHM_SPECTRUM_PIECEWISE_LINEAR = 0, 1, 2
@@ -18,6 +18,7 @@ SHM_SPECTRUM_RGB_ALBEDO, SHM_SPECTRUM_RGB_UNBOUNDED, SHM_SPECTRUM_RGB_ILLUMINANT
 SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATERIAL_THIN_DIELECTRIC = 0, 1, 2, 3
 SHM_MATERIAL_COATED_DIFFUSE, SHM_MATERIAL_COATED_CONDUCTOR, SHM_MATERIAL_MIX = 4, 5, 6
 SHM_LIGHT_POINT, SHM_LIGHT_DIFFUSE_AREA, SHM_LIGHT_UNIFORM_INFINITE = 0, 1, 2
+SHM_CAMERA_PERSPECTIVE, SHM_CAMERA_ORTHOGRAPHIC = 0, 1
 
 c_float_p = C.POINTER(C.c_float)
 c_u32_p = C.POINTER(C.c_uint32)
@@ -72,7 +73,7 @@ class ShmLight(C.Structure):
 class ShmCamera(C.Structure):
     _fields_ = [("camera_from_raster", C.c_float * 16), ("render_from_camera", C.c_float * 16), ("dx_camera", C.c_float * 3),
                 ("dy_camera", C.c_float * 3), ("lens_radius", C.c_float), ("focal_distance", C.c_float),
-                ("shutter_open", C.c_float), ("shutter_close", C.c_float)]
+                ("shutter_open", C.c_float), ("shutter_close", C.c_float), ("kind", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class ShmFilm(C.Structure):
@@ -148,6 +149,7 @@ EXPORTS = {
     "shm_camera_perspective": (C.c_int, [c_float_p, C.c_float, C.POINTER(C.c_int32), C.c_float, C.c_float, C.POINTER(ShmCamera), c_float_p]),
     "shm_integrator_render": (C.c_int, [C.c_char_p, C.POINTER(ShmSceneDesc), C.c_int, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_int,
                                         C.c_void_p, C.POINTER(ShmStats), C.POINTER(C.c_int32)]),
+    "shm_camera_orthographic": (C.c_int, [c_float_p, C.POINTER(C.c_int32), C.c_float, C.c_float, C.POINTER(ShmCamera), c_float_p]),
     "shm_film_get_image": (C.c_int, [C.c_void_p, C.c_uint64, c_float_p, C.c_int, c_float_p]),
     "shm_write_pfm": (C.c_int, [C.c_char_p, c_float_p, C.c_int32, C.c_int32]),
 }

@@ -283,8 +283,9 @@ int shm_tile_bounds(const int32_t pb[4], int32_t tile_w, int32_t tile_h, ShmTile
     return SHM_OK;
 }
 
-int shm_camera_perspective(const float world_from_camera[16], float fov_deg, const int32_t full_resolution[2],
-                           float lens_radius, float focal_distance, ShmCamera* out, float render_from_world_out[16]) {
+// ProjectiveCameraBase::new for either projection (camera.rs:594-642); fov_deg < 0 selects Transform::orthographic(0, 1)
+static int projective_camera(const float world_from_camera[16], float fov_deg, const int32_t full_resolution[2],
+                             float lens_radius, float focal_distance, ShmCamera* out, float render_from_world_out[16]) {
     if (!world_from_camera || !full_resolution || !out || full_resolution[0] <= 0 || full_resolution[1] <= 0)
         return SHM_ERR_INVALID_ARGUMENT;
     M4 wfc;
@@ -305,6 +306,8 @@ int shm_camera_perspective(const float world_from_camera[16], float fov_deg, con
     persp.m[3][3] = 0.0;
     double inv_tan = 1.0 / std::tan((3.14159265358979323846 / 180.0) * fov_deg / 2.0);
     M4 screen_from_camera = m4_mul(m4_scale(inv_tan, inv_tan, 1.0), persp);
+    const bool ortho = fov_deg < 0.0f;
+    if (ortho) screen_from_camera = m4_identity();  // Transform::orthographic(0, 1) = scale(1, 1, 1 / (1 - 0)) * translate(0, 0, -0) (transform.rs:293-303)
     // screen window from the aspect ratio (camera.rs:848-864)
     double frame = (double)full_resolution[0] / (double)full_resolution[1];
     double sw[4];  // min.x, min.y, max.x, max.y
@@ -331,8 +334,19 @@ int shm_camera_perspective(const float world_from_camera[16], float fov_deg, con
     out->focal_distance = focal_distance;
     out->shutter_open = 0.0f;
     out->shutter_close = 1.0f;
+    out->kind = ortho ? SHM_CAMERA_ORTHOGRAPHIC : SHM_CAMERA_PERSPECTIVE;
     if (render_from_world_out) m4_to_f32(render_from_world, render_from_world_out);
     return SHM_OK;
+}
+
+int shm_camera_perspective(const float world_from_camera[16], float fov_deg, const int32_t full_resolution[2],
+                           float lens_radius, float focal_distance, ShmCamera* out, float render_from_world_out[16]) {
+    if (!(fov_deg > 0.0f)) return SHM_ERR_INVALID_ARGUMENT;
+    return projective_camera(world_from_camera, fov_deg, full_resolution, lens_radius, focal_distance, out, render_from_world_out);
+}
+int shm_camera_orthographic(const float world_from_camera[16], const int32_t full_resolution[2], float lens_radius,
+                            float focal_distance, ShmCamera* out, float render_from_world_out[16]) {
+    return projective_camera(world_from_camera, -1.0f, full_resolution, lens_radius, focal_distance, out, render_from_world_out);
 }
 
 int shm_film_get_image(const ShmFilmPixel* film, uint64_t n_pixels, const float m[9], int write_fp16, float* rgb_out) {

@@ -235,6 +235,11 @@ SHM_HD Ray generate_camera_ray(const SceneView& sv, int px, int py, Rng& rng, bo
     const ShmCamera& cam = sv.camera;
     V3 p_camera = xf_point(cam.camera_from_raster, v3(p_film.x, p_film.y, 0.0f));
     Ray base;
+    if (cam.kind == SHM_CAMERA_ORTHOGRAPHIC) {  // OrthographicCamera::generate_ray_differential, camera.rs:769-792 (no depth of field there)
+        base.o = p_camera;
+        base.d = v3(0.0f, 0.0f, 1.0f);
+        return xf_ray(cam.render_from_camera, base);
+    }
     base.o = v3s(0.0f);
     base.d = normalize(p_camera);
     if (cam.lens_radius > 0.0f) {

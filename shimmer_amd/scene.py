@@ -363,7 +363,7 @@ class SceneBuilder:
         f.sensor_r_bar, f.sensor_g_bar, f.sensor_b_bar = (_fptr(a) for a in self._sensor)
         self.film = f
 
-    def set_camera_look_at(self, lib, pos, look_at, up, fov, lens_radius=0.0, focal_distance=1e6):
+    def set_camera_look_at(self, lib, pos, look_at, up, fov, lens_radius=0.0, focal_distance=1e6, orthographic=False):
         """Transform::look_at (transform.rs:270-303) -> world_from_camera, then shm_camera_perspective.
         Returns render_from_world (4x4 f32) so that callers can move world-space geometry into render space."""
         pos, look_at, up = (np.asarray(v, np.float64) for v in (pos, look_at, up))
@@ -378,8 +378,12 @@ class SceneBuilder:
         cam = abi.ShmCamera()
         rfw = np.zeros(16, np.float32)
         res = (C.c_int32 * 2)(*self.film.full_resolution)
-        abi.check(lib, lib.shm_camera_perspective(_fptr(wfc32), float(fov), res, float(lens_radius), float(focal_distance),
-                                                  C.byref(cam), _fptr(rfw)), "shm_camera_perspective")
+        if orthographic:  # OrthographicCamera (camera.rs:658-840): `fov` is ignored, the screen window is [-aspect, aspect] x [-1, 1]
+            abi.check(lib, lib.shm_camera_orthographic(_fptr(wfc32), res, float(lens_radius), float(focal_distance), C.byref(cam),
+                                                       _fptr(rfw)), "shm_camera_orthographic")
+        else:
+            abi.check(lib, lib.shm_camera_perspective(_fptr(wfc32), float(fov), res, float(lens_radius), float(focal_distance),
+                                                      C.byref(cam), _fptr(rfw)), "shm_camera_perspective")
         self.camera = cam
         return rfw.reshape(4, 4)
 

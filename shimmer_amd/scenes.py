@@ -333,7 +333,10 @@ def random_scene(lib, seed, width=40, height=32):
     b = SceneBuilder()
     b.set_film(width, height)
     lens = 0.05 if seed % 2 else 0.0
-    rfw = b.set_camera_look_at(lib, (0.0, 1.2, 6.0), (0.0, 0.8, 0.0), (0, 1, 0), 42.0, lens_radius=lens, focal_distance=6.0)
+    # every fourth seed looks through an OrthographicCamera (camera.rs:658-840; its screen window spans [-aspect, aspect] x [-1, 1]
+    # world units, so it sees the middle of the scene)
+    rfw = b.set_camera_look_at(lib, (0.0, 1.2, 6.0), (0.0, 0.8, 0.0), (0, 1, 0), 42.0, lens_radius=lens, focal_distance=6.0,
+                               orthographic=bool(seed % 4 == 2))
 
     def spec():
         k = rng.integers(0, 4)

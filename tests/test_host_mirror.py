@@ -262,3 +262,37 @@ def test_integrator_mirror_errors(lib):
     assert lib.shm_integrator_render(b"randomwalk", *args) == -2 and b"not provided" in lib.shm_last_error()
     if lib.shm_device_count() == 0:
         assert lib.shm_integrator_render(b"path", *args) == -2 and b"no CPU fallback" in lib.shm_last_error()
+
+
+def test_orthographic_camera(lib):
+    """OrthographicCamera (camera.rs:658-840) through the host mirror + the oracle's camera-ray generator: every ray runs along
+    the view direction, origins span the screen window ([-aspect, aspect] x [-1, 1] around the camera position, y down in
+    raster space), one pixel apart by dx_camera / dy_camera."""
+    import oracle_py
+    from oracle_py import fa  # noqa: F401
+    b = scn.SceneBuilder()
+    b.set_film(64, 32)
+    rfw = b.set_camera_look_at(lib, (1.0, 2.0, 5.0), (1.0, 2.0, 0.0), (0, 1, 0), 30.0, orthographic=True)
+    assert b.camera.kind == abi.SHM_CAMERA_ORTHOGRAPHIC
+    m = b.material_diffuse(0.5)
+    p = np.array([(-9, -9, -1), (9, -9, -1), (0, 9, -1)], np.float32)
+    pr = (np.c_[p, np.ones(3, np.float32)] @ rfw.T)[:, :3]
+    b.add_mesh(pr, [[0, 1, 2]], m)
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    rays = {}
+    for (px, py) in ((0, 0), (63, 0), (0, 31), (32, 16), (33, 16), (32, 17)):
+        out = (C.c_float * 14)()
+        o.lib.orc_fn_camera_ray(o.handle, px, py, 0, 0, out)
+        rays[(px, py)] = np.array(out[:6], np.float64)
+    for r in rays.values():
+        assert np.allclose(r[3:], (0, 0, -1), atol=1e-6)  # looking down -z in world == render orientation (CameraWorld translates only)
+    # render space = world translated by -camera position: the film centre is the origin, x spans [-2, 2], y [-1, 1]; look_at's
+    # camera x axis is up x dir = -x_world here (transform.rs:270-303), so raster x = 0 is world x = +2
+    assert abs(rays[(0, 0)][0] - 2.0) < 0.08 and abs(rays[(63, 0)][0] + 2.0) < 0.08
+    assert rays[(0, 0)][1] > 0.9 and rays[(0, 31)][1] < -0.9  # raster y grows downwards
+    dx = rays[(33, 16)][:3] - rays[(32, 16)][:3]
+    dy = rays[(32, 17)][:3] - rays[(32, 16)][:3]
+    assert np.allclose(np.abs(dx), np.abs(np.array(list(b.camera.dx_camera))), atol=0.08)  # jittered samples: one pixel +- the jitter
+    assert abs(abs(dy[1]) - abs(b.camera.dy_camera[1])) < 0.08
+    o.close()
