@@ -73,14 +73,14 @@ typedef struct ShmTriangleMesh {
 } ShmTriangleMesh;
 
 /* BilinearPatchMesh (src/shape/mesh.rs:289-376) for BilinearPatch (src/shape/bilinear_patch.rs), vertices in render space.
- * This ABI version takes meshes WITHOUT per-vertex n / uv arrays (both pointers must be NULL: SHM_ERR_UNSUPPORTED otherwise). */
+ * (Image-valued emission on a patch light is not carried: `uv` only drives the (s, t) parameterisation of the interaction.) */
 typedef struct ShmBilinearPatchMesh {
     uint32_t n_patches;
     uint32_t n_vertices;
     const uint32_t* vertex_indices; /* 4*n_patches: p00, p10, p01, p11 (bilinear_patch.rs:87-98) */
     const float* p;                 /* 3*n_vertices */
-    const float* n;                 /* must be NULL */
-    const float* uv;                /* must be NULL */
+    const float* n;                 /* 3*n_vertices or NULL */
+    const float* uv;                /* 2*n_vertices or NULL */
     uint8_t reverse_orientation;
     uint8_t transform_swaps_handedness;
     uint8_t pad[6];

@@ -512,7 +512,32 @@ static PatchData make_patch(const float* pts, int flip) {
     pd.flip = flip != 0;
     pd.is_rect = blp_is_rectangle(pd.p00, pd.p10, pd.p01, pd.p11);
     pd.area = blp_area(pd.p00, pd.p10, pd.p01, pd.p11, pd.is_rect);
+    pd.has_n = pd.has_uv = false;
+    pd.n00 = pd.n10 = pd.n01 = pd.n11 = v3s(0.0f);
+    pd.uv00 = pd.uv10 = pd.uv01 = pd.uv11 = v2(0.0f, 0.0f);
     return pd;
+}
+// with per-vertex attributes: normals (12 floats, p00 p10 p01 p11 order) and / or uv (8 floats); NULL = absent
+static PatchData make_patch_attr(const float* pts, int flip, const float* n12, const float* uv8) {
+    PatchData pd = make_patch(pts, flip);
+    if (n12) { pd.has_n = true; pd.n00 = ld3(n12); pd.n10 = ld3(n12 + 3); pd.n01 = ld3(n12 + 6); pd.n11 = ld3(n12 + 9); }
+    if (uv8) { pd.has_uv = true; pd.uv00 = v2(uv8[0], uv8[1]); pd.uv10 = v2(uv8[2], uv8[3]); pd.uv01 = v2(uv8[4], uv8[5]); pd.uv11 = v2(uv8[6], uv8[7]); }
+    return pd;
+}
+// out = p[3], n[3], dpdu[3], dpdv[3], ns[3], dpdu_s[3], dpdv_s[3], uv[2] (23 floats)
+void orc_fn_blp_interaction_attr(const float* pts, int flip, const float* n12, const float* uv8, float u, float v, const float* wo, float* out23) {
+    SurfaceInteraction si = blp_interaction(make_patch_attr(pts, flip, n12, uv8), u, v, ld3(wo));
+    const V3 vs[7] = {si.p(), si.n, si.dpdu, si.dpdv, si.shading.n, si.shading.dpdu, si.shading.dpdv};
+    for (int i = 0; i < 7; ++i) { out23[3 * i] = vs[i].x; out23[3 * i + 1] = vs[i].y; out23[3 * i + 2] = vs[i].z; }
+    out23[21] = si.uv.x; out23[22] = si.uv.y;
+}
+void orc_fn_invert_bilinear(const float* p2, const float* v8, float* out2) {
+    V2 r = invert_bilinear(v2(p2[0], p2[1]), v2(v8[0], v8[1]), v2(v8[2], v8[3]), v2(v8[4], v8[5]), v2(v8[6], v8[7]));
+    out2[0] = r.x; out2[1] = r.y;
+}
+void orc_fn_rotate_from_to(const float* from, const float* to, const float* v, float* out3) {
+    V3 r = rot3_apply(rotate_from_to(ld3(from), ld3(to)), ld3(v));
+    out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
 }
 void orc_fn_blp_info(const float* pts, float* out2) {
     PatchData pd = make_patch(pts, 0);

@@ -69,6 +69,9 @@ def load():
     lib.orc_fn_sample_henyey_greenstein.restype, lib.orc_fn_sample_henyey_greenstein.argtypes = None, [FP, F, FP, FP]
     lib.orc_fn_sample_exponential.restype, lib.orc_fn_sample_exponential.argtypes = F, [F, F]
     lib.orc_fn_blp_info.restype, lib.orc_fn_blp_info.argtypes = None, [FP, FP]
+    lib.orc_fn_blp_interaction_attr.restype, lib.orc_fn_blp_interaction_attr.argtypes = None, [FP, C.c_int, FP, FP, F, F, FP, FP]
+    lib.orc_fn_invert_bilinear.restype, lib.orc_fn_invert_bilinear.argtypes = None, [FP, FP, FP]
+    lib.orc_fn_rotate_from_to.restype, lib.orc_fn_rotate_from_to.argtypes = None, [FP, FP, FP, FP]
     lib.orc_fn_blp_intersect.restype, lib.orc_fn_blp_intersect.argtypes = C.c_int, [FP, FP, FP, F, FP]
     lib.orc_fn_blp_interaction.restype, lib.orc_fn_blp_interaction.argtypes = None, [FP, C.c_int, F, F, FP, FP]
     lib.orc_fn_blp_sample_with_context.restype, lib.orc_fn_blp_sample_with_context.argtypes = C.c_int, [FP, C.c_int, FP, FP, FP, FP, FP]

@@ -25,6 +25,8 @@ struct FlatScene {
     std::vector<float> vn, vs, vuv;
     std::vector<ShmSphere> spheres;
     std::vector<shm::PatchExtra> patches;
+    std::vector<uint32_t> patch_vi;
+    std::vector<float> patch_vn, patch_vuv;
     std::vector<ShmMaterial> materials;
     std::vector<ShmLight> lights;
     std::vector<uint32_t> infinite_lights;
@@ -50,6 +52,9 @@ struct FlatScene {
         v.vuv = vuv.data();
         v.spheres = spheres.data();
         v.patches = patches.data();
+        v.patch_vi = patch_vi.data();
+        v.patch_vn = patch_vn.data();
+        v.patch_vuv = patch_vuv.data();
         v.materials = materials.data();
         v.lights = lights.data();
         v.n_lights = (uint32_t)lights.size();
@@ -148,18 +153,38 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         out.vuv.assign(2, 0.0f);
     }
 
-    // bilinear patch meshes
+    // bilinear patch meshes (per-vertex n / uv into global arrays, like the triangle meshes' vi / vn / vuv)
     const uint32_t n_pm = d->patch_meshes ? d->n_patch_meshes : 0;
-    std::vector<uint32_t> patch_base(n_pm + 1, 0);
+    std::vector<uint32_t> patch_base(n_pm + 1, 0), patch_vert_base(n_pm + 1, 0);
+    bool any_patch_attr = false;
     for (uint32_t m = 0; m < n_pm; ++m) {
         const ShmBilinearPatchMesh& mesh = d->patch_meshes[m];
         if (!mesh.vertex_indices || !mesh.p) { err = "patch mesh without indices/positions"; return SHM_ERR_INVALID_ARGUMENT; }
-        if (mesh.n || mesh.uv) { err = "bilinear patch meshes with per-vertex n / uv are not supported by this ABI version"; return SHM_ERR_UNSUPPORTED; }
         patch_base[m + 1] = patch_base[m] + mesh.n_patches;
+        patch_vert_base[m + 1] = patch_vert_base[m] + mesh.n_vertices;
+        if (mesh.n || mesh.uv) any_patch_attr = true;
     }
     const uint32_t n_patches = patch_base[n_pm];
     if (n_patches > shm::PRIM_INDEX_MASK) { err = "too many bilinear patches"; return SHM_ERR_INVALID_ARGUMENT; }
     out.patches.assign(std::max<uint32_t>(n_patches, 1), shm::PatchExtra{});
+    if (any_patch_attr) {
+        out.patch_vi.assign(4ull * n_patches, 0);
+        out.patch_vn.assign(3ull * patch_vert_base[n_pm], 0.0f);
+        out.patch_vuv.assign(2ull * patch_vert_base[n_pm], 0.0f);
+        for (uint32_t m = 0; m < n_pm; ++m) {
+            const ShmBilinearPatchMesh& mesh = d->patch_meshes[m];
+            for (uint64_t i = 0; i < 4ull * mesh.n_patches; ++i) {
+                if (mesh.vertex_indices[i] >= mesh.n_vertices) { err = "vertex index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+                out.patch_vi[4ull * patch_base[m] + i] = mesh.vertex_indices[i] + patch_vert_base[m];
+            }
+            if (mesh.n) std::copy(mesh.n, mesh.n + 3ull * mesh.n_vertices, out.patch_vn.begin() + 3ull * patch_vert_base[m]);
+            if (mesh.uv) std::copy(mesh.uv, mesh.uv + 2ull * mesh.n_vertices, out.patch_vuv.begin() + 2ull * patch_vert_base[m]);
+        }
+    } else {
+        out.patch_vi.assign(4, 0);
+        out.patch_vn.assign(3, 0.0f);
+        out.patch_vuv.assign(2, 0.0f);
+    }
 
     // 48-B leaf-order records
     out.prim_recs.resize(d->n_primitives);
@@ -208,7 +233,8 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
             // BilinearPatch::new / is_rectangle (bilinear_patch.rs:40-69, 108-142), evaluated once, with the shared arithmetic
             bool is_rect = shm::blp_is_rectangle(c[0], c[1], c[2], c[3]);
             px.area = shm::blp_area(c[0], c[1], c[2], c[3], is_rect);
-            px.flags = (is_rect ? 1u : 0u) | ((((mesh.reverse_orientation != 0) ^ (mesh.transform_swaps_handedness != 0)) ? 2u : 0u));
+            px.flags = (is_rect ? 1u : 0u) | ((((mesh.reverse_orientation != 0) ^ (mesh.transform_swaps_handedness != 0)) ? 2u : 0u)) |
+                       (mesh.n ? 4u : 0u) | (mesh.uv ? 8u : 0u);
             rec.kind_index = shm::PRIM_PATCH_BIT | pr.shape_index;
             out.has_spheres = true;
         } else {

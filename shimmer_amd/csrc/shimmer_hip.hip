@@ -890,6 +890,9 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if ((rc = dev_upload(s, f.vuv, &v.vuv)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.spheres, &v.spheres)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.patches, &v.patches)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.patch_vi, &v.patch_vi)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.patch_vn, &v.patch_vn)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.patch_vuv, &v.patch_vuv)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.materials, &v.materials)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.lights, &v.lights)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.infinite_lights, &v.infinite_lights)) != SHM_OK) return fail(rc);

@@ -10,9 +10,11 @@
 //   square_matrix.rs:281-292         determinant of a 3x3 matrix
 //   vecmath/mod.rs:118-140           spherical_quad_area
 //   sampling.rs:501-579, 645-787     sample_spherical_rectangle, invert_spherical_rectangle_sample
-// Scope of this cut: patch meshes WITHOUT per-vertex `uv` and `n` arrays (the (s,t) re-parameterisation of
-// bilinear_patch.rs:258-318 and the shading-normal rotation of :399-424 are not restated; shm_scene_create rejects such
-// meshes with SHM_ERR_UNSUPPORTED instead of rendering something else).
+//   transform.rs:227-253             Transform::rotate_from_to (shading frame of a patch with per-vertex normals)
+//   vecmath/mod.rs:70-116            invert_bilinear
+// Per-vertex `uv` (the (s,t) re-parameterisation, :258-318) and `n` (shading normals, :399-424; normal flipping in the
+// samplers) are both carried. What is NOT: image-valued emission on a patch light (the `st` of a sample is therefore not
+// produced: nothing on the path reads it).
 // Reference behaviour kept as written: sample() interpolates pu0 / pu1 along different parameters (:549-553), pdf() uses
 // uv[1] for both edge points (:627-628); both differ from PBRT-v4 and both are what the reference computes.
 #pragma once
@@ -25,7 +27,13 @@ struct PatchData {
     bool flip;     // reverse_orientation ^ transform_swaps_handedness
     bool is_rect;  // is_rectangle(), evaluated once at scene creation with blp_is_rectangle
     Float area;    // BilinearPatch::new
+    bool has_n, has_uv;
+    V3 n00, n10, n01, n11;
+    V2 uv00, uv10, uv01, uv11;
 };
+SHM_HD V2 lerp2(Float t, V2 a, V2 b) { return a * (1.0f - t) + b * t; }
+// the interpolated per-vertex normal lerp(u, lerp(v, n00, n01), lerp(v, n10, n11)) of :407, :576, :714
+SHM_HD V3 blp_interp_normal(const PatchData& pd, Float u, Float v);
 struct BilinearIntersection {
     Float u, v, t;
 };
@@ -130,12 +138,52 @@ SHM_HD bool blp_intersect(V3 ro, V3 rd, Float t_max, V3 p00, V3 p10, V3 p01, V3 
     return true;
 }
 
-// bilinear_patch.rs:238-428 for a mesh without uv / n arrays (duds = 1, dudt = 0, dvds = 0, dvdt = 1)
+SHM_HD V3 blp_interp_normal(const PatchData& pd, Float u, Float v) { return lerp3(u, lerp3(v, pd.n00, pd.n01), lerp3(v, pd.n10, pd.n11)); }
+
+// transform.rs:227-253, the 3x3 part (row-major); applied to vectors as Transform::apply does (transform.rs:420-431)
+struct Rot3 { Float m[3][3]; };
+SHM_HD Rot3 rotate_from_to(V3 from, V3 to) {
+    V3 ref1 = (abs(from.x) < 0.72f && abs(to.x) < 0.72f) ? v3(1.0f, 0.0f, 0.0f)
+              : ((abs(from.y) < 0.72f && abs(to.y) < 0.72f) ? v3(0.0f, 1.0f, 0.0f) : v3(0.0f, 0.0f, 1.0f));
+    V3 u = ref1 - from, v = ref1 - to;
+    const Float ua[3] = {u.x, u.y, u.z}, va[3] = {v.x, v.y, v.z};
+    Rot3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Float kronecker = (i == j) ? 1.0f : 0.0f;
+            r.m[i][j] = kronecker - 2.0f / dot(u, u) * ua[i] * ua[j] - 2.0f / dot(v, v) * va[i] * va[j]
+                        + 4.0f * dot(u, v) / (dot(u, u) * dot(v, v)) * va[i] * ua[j];
+        }
+    return r;
+}
+SHM_HD V3 rot3_apply(const Rot3& r, V3 a) {
+    return v3(r.m[0][0] * a.x + r.m[0][1] * a.y + r.m[0][2] * a.z, r.m[1][0] * a.x + r.m[1][1] * a.y + r.m[1][2] * a.z,
+              r.m[2][0] * a.x + r.m[2][1] * a.y + r.m[2][2] * a.z);
+}
+
+// bilinear_patch.rs:238-428
 SHM_HD SurfaceInteraction blp_interaction(const PatchData& pd, Float u, Float v, V3 wo) {
     V3 p = lerp3(u, lerp3(v, pd.p00, pd.p01), lerp3(v, pd.p10, pd.p11));
     V3 dpdu = lerp3(v, pd.p10, pd.p11) - lerp3(v, pd.p00, pd.p01);
     V3 dpdv = lerp3(u, pd.p01, pd.p11) - lerp3(u, pd.p00, pd.p10);
-    const Float duds = 1.0f, dudt = 0.0f, dvds = 0.0f, dvdt = 1.0f;
+    V2 st = v2(u, v);
+    Float duds = 1.0f, dudt = 0.0f, dvds = 0.0f, dvdt = 1.0f;
+    if (pd.has_uv) {
+        st = lerp2(u, lerp2(v, pd.uv00, pd.uv01), lerp2(v, pd.uv10, pd.uv11));
+        V2 dstdu = lerp2(v, pd.uv10, pd.uv11) - lerp2(v, pd.uv00, pd.uv01);
+        V2 dstdv = lerp2(u, pd.uv01, pd.uv11) - lerp2(u, pd.uv00, pd.uv10);
+        duds = (abs(dstdu.x) < 1e-8f) ? 0.0f : 1.0f / dstdu.x;
+        dvds = (abs(dstdv.x) < 1e-8f) ? 0.0f : 1.0f / dstdv.x;
+        dudt = (abs(dstdu.y) < 1e-8f) ? 0.0f : 1.0f / dstdu.y;
+        dvdt = (abs(dstdv.y) < 1e-8f) ? 0.0f : 1.0f / dstdv.y;
+        V3 dpds = dpdu * duds + dpdv * dvds;
+        V3 dpdt = dpdu * dudt + dpdv * dvdt;
+        if (cross(dpds, dpdt) != v3s(0.0f)) {
+            if (dot(cross(dpdu, dpdv), cross(dpds, dpdt)) < 0.0f) dpdt = -dpdt;
+            dpdu = dpds;
+            dpdv = dpdt;
+        }
+    }
     V3 d2pduu = v3s(0.0f), d2pdvv = v3s(0.0f);
     V3 d2pduv = (pd.p00 - pd.p01) + (pd.p11 - pd.p10);
     Float e1 = dot(dpdu, dpdu), f1 = dot(dpdu, dpdv), g1 = dot(dpdv, dpdv);
@@ -151,7 +199,39 @@ SHM_HD SurfaceInteraction blp_interaction(const PatchData& pd, Float u, Float v,
     dndv = dndt;
     V3 p_abs_sum = abs3(pd.p00) + abs3(pd.p01) + abs3(pd.p10) + abs3(pd.p11);
     V3 p_error = gamma(6) * p_abs_sum;
-    return surface_interaction_new(p3i_from_value_and_error(p, p_error), v2(u, v), wo, dpdu, dpdv, dndu, dndv, pd.flip);
+    SurfaceInteraction isect = surface_interaction_new(p3i_from_value_and_error(p, p_error), st, wo, dpdu, dpdv, dndu, dndv, pd.flip);
+    if (pd.has_n) {  // :399-424
+        V3 ns = blp_interp_normal(pd, u, v);
+        if (length_squared(ns) > 0.0f) {
+            ns = normalize(ns);
+            V3 dndu_s = lerp3(v, pd.n10, pd.n11) - lerp3(v, pd.n00, pd.n01);
+            V3 dndv_s = lerp3(u, pd.n01, pd.n11) - lerp3(u, pd.n00, pd.n10);
+            V3 dnds_s = dndu_s * duds + dndv_s * dvds;
+            V3 dndt_s = dndu_s * dudt + dndv_s * dvdt;
+            Rot3 r = rotate_from_to(isect.n, ns);
+            set_shading_geometry(isect, ns, rot3_apply(r, dpdu), rot3_apply(r, dpdv), dnds_s, dndt_s, true);
+        }
+    }
+    return isect;
+}
+
+// vecmath/mod.rs:70-116
+SHM_HD Float cross2d(V2 a, V2 b) { return difference_of_products(a.x, b.y, a.y, b.x); }
+SHM_HD V2 invert_bilinear(V2 p, V2 v0, V2 v1, V2 v2_, V2 v3_) {
+    V2 a = v0, b = v1, c = v3_, d = v2_;
+    V2 e = b - a, f = d - a, g = (a - b) + (c - d), h = p - a;
+    Float k2 = cross2d(g, f);
+    Float k1 = cross2d(e, f) + cross2d(h, g);
+    Float k0 = cross2d(h, e);
+    if (abs(k2) < 0.001f) {
+        if (abs(e.x * k1 - g.x * k0) < 1e-5f) return v2((h.y * k1 + f.y * k0) / (e.y * k1 - g.y * k0), -k0 / k1);
+        return v2((h.x * k1 + f.x * k0) / (e.x * k1 - g.x * k0), -k0 / k1);
+    }
+    Float r0, r1;
+    if (!quadratic(k2, k1, k0, r0, r1)) return v2(0.0f, 0.0f);
+    Float u = (h.x - f.x * r0) / (e.x + g.x * r0);
+    if (u < 0.0f || u > 1.0f || r0 < 0.0f || r0 > 1.0f) return v2((h.x - f.x * r1) / (e.x + g.x * r1), r1);
+    return v2(u, r0);
 }
 
 // vecmath/mod.rs:118-140
@@ -260,7 +340,7 @@ SHM_HD V2 invert_spherical_rectangle_sample(V3 p_ref, V3 s, V3 ex, V3 ey, V3 p_r
     return v2(clamp(u0, 0.0f, 1.0f), u1b);
 }
 
-// bilinear_patch.rs:521-600 (meshes without uv / n)
+// bilinear_patch.rs:521-600 (the sample's st is not produced: see the header)
 SHM_HD bool blp_sample(const PatchData& pd, V2 u, ShapeSample& out) {
     V2 uv;
     Float pdf;
@@ -280,7 +360,8 @@ SHM_HD bool blp_sample(const PatchData& pd, V2 u, ShapeSample& out) {
     V3 dpdv = lerp3(uv.x, pd.p01, pd.p11) - lerp3(uv.x, pd.p00, pd.p10);
     if (length_squared(dpdu) == 0.0f || length_squared(dpdv) == 0.0f) return false;
     V3 n = normalize(cross(dpdu, dpdv));
-    if (pd.flip) n = -n;
+    if (pd.has_n) n = face_forward(n, blp_interp_normal(pd, uv.x, uv.y));  // :570-577
+    else if (pd.flip) n = -n;
     V3 p_abs_sum = abs3(pd.p00) + abs3(pd.p01) + abs3(pd.p10) + abs3(pd.p11);
     V3 p_error = gamma(6) * p_abs_sum;
     out.pi = p3i_from_value_and_error(p, p_error);
@@ -288,8 +369,9 @@ SHM_HD bool blp_sample(const PatchData& pd, V2 u, ShapeSample& out) {
     out.pdf = pdf / length(cross(dpdu, dpdv));
     return true;
 }
-// bilinear_patch.rs:602-636: interaction.uv is the patch (u, v) (no uv array)
+// bilinear_patch.rs:602-636: `uv` is Interaction::uv, i.e. (s, t) when the mesh has a uv array (inverted first, :607-614)
 SHM_HD Float blp_pdf(const PatchData& pd, V2 uv) {
+    if (pd.has_uv) uv = invert_bilinear(uv, pd.uv00, pd.uv10, pd.uv01, pd.uv11);
     Float pdf = 1.0f;
     if (!pd.is_rect) {
         Float w[4] = {length(cross(pd.p10 - pd.p00, pd.p01 - pd.p00)), length(cross(pd.p10 - pd.p00, pd.p11 - pd.p10)),
@@ -330,8 +412,10 @@ SHM_HD bool blp_sample_with_context(const PatchData& pd, const ShapeSampleContex
     Float quad_pdf = 0.0f;
     V3 p = sample_spherical_rectangle(rp, pd.p00, eu, ev, u, quad_pdf);
     pdf *= quad_pdf;
+    V2 uv = v2(dot(p - pd.p00, eu) / distance_squared(pd.p10, pd.p00), dot(p - pd.p00, ev) / distance_squared(pd.p01, pd.p00));  // :698-701
     V3 n = normalize(cross(eu, ev));
-    if (pd.flip) n = -n;
+    if (pd.has_n) n = face_forward(n, blp_interp_normal(pd, uv.x, uv.y));  // :706-716
+    else if (pd.flip) n = -n;
     out.pi = p3i_exact(p);
     out.n = n;
     out.pdf = pdf;

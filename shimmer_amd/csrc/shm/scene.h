@@ -25,7 +25,8 @@ struct PrimRec {
 struct PatchExtra {
     Float p11[3];
     Float area;      // BilinearPatch::new (bilinear_patch.rs:40-69)
-    uint32_t flags;  // bit 0: is_rectangle (:108-142), bit 1: reverse_orientation ^ transform_swaps_handedness
+    uint32_t flags;  // bit 0: is_rectangle (:108-142), bit 1: reverse_orientation ^ transform_swaps_handedness,
+                     // bit 2: the mesh has per-vertex normals, bit 3: per-vertex uv (attributes through SceneView::patch_vi)
     uint32_t pad[3];
 };
 static_assert(sizeof(PatchExtra) == 32, "PatchExtra must be 32 bytes");
@@ -49,6 +50,9 @@ struct SceneView {
     const Float* vuv;     // 2 per vertex
     const ShmSphere* spheres;
     const PatchExtra* patches;
+    const uint32_t* patch_vi;  // 4 per patch: global ids into patch_vn / patch_vuv (only read for patches with attributes)
+    const Float* patch_vn;     // 3 per patch-mesh vertex
+    const Float* patch_vuv;    // 2 per patch-mesh vertex
     const ShmMaterial* materials;
     const ShmLight* lights;
     uint32_t n_lights;
@@ -104,6 +108,20 @@ SHM_HD PatchData load_patch(const SceneView& sv, uint32_t slot) {
     pd.is_rect = (px.flags & 1u) != 0;
     pd.flip = (px.flags & 2u) != 0;
     pd.area = px.area;
+    pd.has_n = (px.flags & 4u) != 0;
+    pd.has_uv = (px.flags & 8u) != 0;
+    pd.n00 = pd.n10 = pd.n01 = pd.n11 = v3s(0.0f);
+    pd.uv00 = pd.uv10 = pd.uv01 = pd.uv11 = v2(0.0f, 0.0f);
+    if (px.flags & 12u) {
+        const uint32_t* vi = sv.patch_vi + 4u * (pr.kind_index & PRIM_INDEX_MASK);
+        if (pd.has_n) { pd.n00 = ld3(sv.patch_vn + 3 * vi[0]); pd.n10 = ld3(sv.patch_vn + 3 * vi[1]); pd.n01 = ld3(sv.patch_vn + 3 * vi[2]); pd.n11 = ld3(sv.patch_vn + 3 * vi[3]); }
+        if (pd.has_uv) {
+            pd.uv00 = v2(sv.patch_vuv[2 * vi[0]], sv.patch_vuv[2 * vi[0] + 1]);
+            pd.uv10 = v2(sv.patch_vuv[2 * vi[1]], sv.patch_vuv[2 * vi[1] + 1]);
+            pd.uv01 = v2(sv.patch_vuv[2 * vi[2]], sv.patch_vuv[2 * vi[2] + 1]);
+            pd.uv11 = v2(sv.patch_vuv[2 * vi[3]], sv.patch_vuv[2 * vi[3] + 1]);
+        }
+    }
     return pd;
 }
 

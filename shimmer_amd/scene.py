@@ -300,13 +300,14 @@ class SceneBuilder:
         self._n_prims += ntri
         return first_prim
 
-    def add_patch_mesh(self, p, vi, material, reverse_orientation=False, swaps_handedness=False, emission=None, emission_scale=1.0,
-                       two_sided=False):
+    def add_patch_mesh(self, p, vi, material, n=None, uv=None, reverse_orientation=False, swaps_handedness=False, emission=None,
+                       emission_scale=1.0, two_sided=False):
         """bilinearmesh (shape/mesh.rs:289-376): vertices in render space, 4 indices per patch in the order p00, p10, p01, p11
         (bilinear_patch.rs:87-98). emission -> one DiffuseAreaLight per patch."""
         p = _as_f32(p, (-1, 3))
         vi = np.ascontiguousarray(vi, dtype=np.uint32).reshape(-1, 4)
-        self.patch_meshes.append(dict(p=p, vi=vi, reverse=bool(reverse_orientation), swaps=bool(swaps_handedness)))
+        self.patch_meshes.append(dict(p=p, vi=vi, n=None if n is None else _as_f32(n, (-1, 3)), uv=None if uv is None else _as_f32(uv, (-1, 2)),
+                                      reverse=bool(reverse_orientation), swaps=bool(swaps_handedness)))
         base, n = self._patch_count, vi.shape[0]
         self._patch_count += n
         first_prim = self._n_prims
@@ -462,6 +463,8 @@ class SceneBuilder:
             pm.n_patches, pm.n_vertices = m["vi"].shape[0], m["p"].shape[0]
             pm.vertex_indices = m["vi"].ctypes.data_as(abi.c_u32_p)
             pm.p = _fptr(m["p"])
+            pm.n = _fptr(m["n"]) if m["n"] is not None else None
+            pm.uv = _fptr(m["uv"]) if m["uv"] is not None else None
             pm.reverse_orientation, pm.transform_swaps_handedness = int(m["reverse"]), int(m["swaps"])
         materials = (abi.ShmMaterial * len(self.materials))(*self.materials)
         spec = np.concatenate(self.spec).astype(np.float32) if self.spec else np.zeros(1, np.float32)

@@ -405,7 +405,13 @@ def random_scene(lib, seed, width=40, height=32):
     b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], pick(), reverse_orientation=bool(seed % 3 == 0))
     q = np.array([(1.5, 0.1, 2.5), (3.0, 0.1, 2.5), (1.5, 0.1, 3.6), (3.0, 0.1, 3.6)], np.float32)
     q[:, 1] += rng.uniform(0.0, 0.6, 4).astype(np.float32)
-    b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], pick())
+    # the saddle carries per-vertex uv (a sheared, scaled (s, t) frame) and, for some seeds, per-vertex shading normals
+    uv = np.array([(0.0, 0.0), (2.0, 0.3), (0.2, 1.5), (2.3, 1.9)], np.float32)
+    nn = None
+    if seed % 2 == 0:
+        nn = np.array([(0.2, 1.0, 0.1), (-0.1, 1.0, 0.2), (0.1, 1.0, -0.2), (-0.2, 1.0, -0.1)], np.float32)
+        nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+    b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], pick(), n=nn, uv=uv)
     # lights: a triangle pair, a sphere, a rectangular patch and a skewed patch, a point light, sometimes the sky
     p, vi = _quad((-1, 4.5, -1), (1, 4.5, -1), (1, 4.5, 1), (-1, 4.5, 1))
     b.add_mesh(_to_render(p, rfw), vi, black, emission=emit, emission_scale=float(rng.uniform(5, 20)), two_sided=bool(seed % 2))
@@ -413,7 +419,8 @@ def random_scene(lib, seed, width=40, height=32):
     rfo[:3, 3] = np.array([2.5, 3.0, 1.0], np.float32)
     b.add_sphere(0.25, black, render_from_object=(rfw @ rfo).astype(np.float32), emission=emit, emission_scale=8.0)
     q = np.array([(-3.5, 3.0, 0.0), (-2.5, 3.0, 0.0), (-3.5, 3.0, 1.0), (-2.5, 3.0, 1.0)], np.float32)  # faces down
-    b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], black, emission=emit, emission_scale=10.0)
+    down = np.tile(np.array([[0.0, -1.0, 0.0]], np.float32), (4, 1))
+    b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], black, n=(down if seed % 3 == 2 else None), emission=emit, emission_scale=10.0)
     q = q + np.array([5.5, 0.3, 0.5], np.float32)
     q[3, 1] -= np.float32(0.05)
     b.add_patch_mesh(_to_render(q, rfw), [[0, 1, 2, 3]], black, emission=emit, emission_scale=10.0, two_sided=True)

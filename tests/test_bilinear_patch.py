@@ -238,10 +238,55 @@ def test_area_sampling_path_matches_the_cited_formulas(orc):
         assert out[6] == pytest.approx(pdf, rel=2e-4)
 
 
-def test_patch_mesh_with_vertex_attributes_is_rejected(lib):
-    """This ABI version takes patch meshes without per-vertex n / uv: anything else must fail loudly."""
-    sc = scenes.cornell_box(lib, 16, 16, patches=True)
-    dummy = np.zeros(12, np.float32)
-    sc.desc.patch_meshes[0].uv = dummy.ctypes.data_as(abi.c_float_p)
-    with pytest.raises(Exception):
-        oracle_py.Oracle(sc.desc)
+def test_interaction_with_uv_and_normals(orc):
+    """bilinear_patch.rs:258-318, 399-424: with the identity uv layout the (s, t) frame is the (u, v) frame; a scaled, offset
+    layout scales dpdu / dpdv by the inverse and reports st; per-vertex normals give a unit shading normal that the
+    geometric normal is flipped towards, and a shading dpdu rotated into its tangent plane (rotate_from_to,
+    transform.rs:227-253)."""
+    quad = SADDLE
+    wo = fa(0, 1, 0)
+    u, v = 0.3, 0.7
+    base = (C.c_float * 23)()
+    orc.orc_fn_blp_interaction_attr(pts(quad), 0, None, None, u, v, wo, base)
+    ident = (C.c_float * 23)()
+    orc.orc_fn_blp_interaction_attr(pts(quad), 0, None, fa(0, 0, 1, 0, 0, 1, 1, 1), u, v, wo, ident)
+    assert np.allclose(np.array(base[:21]), np.array(ident[:21]), atol=1e-6) and ident[21] == pytest.approx(u) and ident[22] == pytest.approx(v)
+    scaled = (C.c_float * 23)()
+    orc.orc_fn_blp_interaction_attr(pts(quad), 0, None, fa(1, 1, 3, 1, 1, 5, 3, 5), u, v, wo, scaled)  # s = 1 + 2u, t = 1 + 4v
+    b, sc = np.array(base[:], np.float64), np.array(scaled[:], np.float64)
+    assert np.allclose(sc[6:9], b[6:9] / 2, atol=1e-6) and np.allclose(sc[9:12], b[9:12] / 4, atol=1e-6)
+    assert sc[21] == pytest.approx(1 + 2 * u, abs=1e-6) and sc[22] == pytest.approx(1 + 4 * v, abs=1e-6)
+    assert np.allclose(sc[3:6], b[3:6], atol=1e-6)  # same geometric normal
+    # per-vertex normals, all leaning the same way
+    nn = np.array([(0.3, -1.0, 0.1)] * 4, np.float64)
+    nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+    withn = (C.c_float * 23)()
+    orc.orc_fn_blp_interaction_attr(pts(quad), 0, fa(*nn.ravel()), None, u, v, wo, withn)
+    w = np.array(withn[:], np.float64)
+    ns, n, dpdus = w[12:15], w[3:6], w[15:18]
+    assert np.allclose(ns, nn[0], atol=1e-6) and np.dot(n, ns) > 0  # n flipped towards ns (orientation is authoritative)
+    assert np.allclose(np.abs(n), np.abs(b[3:6]), atol=1e-6)
+    assert abs(np.dot(dpdus, ns)) < 1e-4 * np.linalg.norm(dpdus) + 1e-6  # rotated with the normal: tangent to the shading normal
+    assert np.linalg.norm(dpdus) == pytest.approx(np.linalg.norm(b[6:9]), rel=1e-5)
+
+
+def test_rotate_from_to_and_invert_bilinear(orc):
+    """transform.rs:227-253: the rotation maps `from` onto `to` and preserves lengths; vecmath/mod.rs:70-116: invert_bilinear
+    recovers (u, v) from the bilinear interpolation of four uv corners."""
+    rng = np.random.default_rng(4)
+    for _ in range(50):
+        a, b = rng.normal(size=3), rng.normal(size=3)
+        a /= np.linalg.norm(a); b /= np.linalg.norm(b)
+        out = (C.c_float * 3)()
+        orc.orc_fn_rotate_from_to(fa(*a), fa(*b), fa(*a), out)
+        assert np.allclose(np.array(out[:]), b, atol=3e-6)
+        x = rng.normal(size=3)
+        orc.orc_fn_rotate_from_to(fa(*a), fa(*b), fa(*x), out)
+        assert np.linalg.norm(out[:]) == pytest.approx(np.linalg.norm(x), rel=1e-5)
+    corners = np.array([(0.1, 0.2), (1.9, 0.0), (0.0, 1.4), (2.2, 1.7)])  # uv00 uv10 uv01 uv11
+    for _ in range(100):
+        u, v = rng.random(2)
+        pt = (1 - u) * ((1 - v) * corners[0] + v * corners[2]) + u * ((1 - v) * corners[1] + v * corners[3])
+        out = (C.c_float * 2)()
+        orc.orc_fn_invert_bilinear(fa(*pt), fa(*corners.ravel()), out)
+        assert out[0] == pytest.approx(u, abs=2e-4) and out[1] == pytest.approx(v, abs=2e-4)
