@@ -25,6 +25,10 @@
 // PARITY PINNING: pinned at function level by the vectors above; the whole-image result is NOT pinned
 // against the Rust binary, because the reference's sample stream is not reproducible (sampler.rs:117-121,
 // integrator.rs:252-255): the deterministic per-pixel stream of shm/sampling.h is used instead.
+// Parity UNPINNED boundaries (no reference value exists; the choice is defined in the shared headers and documented in
+// DESIGN.md §2 / §4b): the inner random walks of LayeredBxDF and the MixMaterial choice (the reference seeds both from OS
+// entropy), the FMA order of fast_polynomial::poly in RgbSigmoidPolynomial (crate not vendored), BilinearPatch as a whole
+// (no in-source known answers: checked against float64 evaluations of the cited formulas, tests/test_bilinear_patch.py).
 #include <atomic>
 #include <chrono>
 #include <string>
