@@ -305,6 +305,16 @@ def test_sampler_stream_properties(orc):
         assert not np.array_equal(a[:16], np.array(b)[:16])
     # sample_index s starts 65536*s draws into the pixel's sequence: the first draw differs from the continuation
     assert len(set(np.round(a[:64], 7))) > 60
+    # ... and it is EXACTLY the continuation: the jump-ahead (rng_advance_65536, constants folded for the first 16 doublings)
+    # lands where drawing 65536 * s numbers one by one lands
+    m = 3 * 65536 + 32
+    long = (C.c_float * m)()
+    orc.orc_fn_sampler_stream(3, 7, 0, 0, m, long)
+    long = np.array(long)
+    for s_idx in (1, 2, 3):
+        short = (C.c_float * 32)()
+        orc.orc_fn_sampler_stream(3, 7, s_idx, 0, 32, short)
+        assert np.array_equal(np.array(short), long[65536 * s_idx:65536 * s_idx + 32])
 
 
 def test_triangle_light_sampling_consistency(orc):
