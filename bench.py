@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=0, help="non-square frames (e.g. the 3840x2160 of BASELINE config C5): overrides --res")
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--n", type=int, default=599, help="cube-sphere subdivision (599 -> 4 305 612 triangles)")
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
@@ -131,7 +133,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     t0 = time.perf_counter()
-    sc = scenes.ganesha_proxy(lib, args.res, args.res, n=args.n, coated=args.coated)
+    width, height = (args.width or args.res), (args.height or args.res)
+    sc = scenes.ganesha_proxy(lib, width, height, n=args.n, coated=args.coated)
     t_scene = time.perf_counter() - t0
     t0 = time.perf_counter()
     r = render.Renderer(lib, sc.desc, device=local_rank)
@@ -195,7 +198,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'S3c coated ' if args.coated else 'S3 '}ganesha-proxy ({sc.info['n_primitives']} prims, {sc.info['n_nodes']} BVH nodes), "
-                                   f"{args.res}x{args.res}, {args.spp} spp, maxdepth {args.max_depth}, path integrator",
+                                   f"{width}x{height}, {args.spp} spp, maxdepth {args.max_depth}, path integrator",
                        "tiles": "8x8, sharded across ranks in interleaved blocks of tile rows (~8 blocks per rank)" if world > 1 else "8x8",
                        "rays_per_step": rays / args.steps, "paths_per_step": tot["paths"] / args.steps,
                        "film_gather": "RCCL gather to rank 0 (inside the timed region)" if world > 1 else "none"},
