@@ -56,8 +56,9 @@ struct DeviceCounters {
 // Queue bookkeeping that lives in HBM so that no launch needs a host round trip.
 struct QueueState {
     uint32_t n_active[2];   // entries in q_active[0/1]
-    uint32_t n_shadow;      // entries in q_shadow
-    uint32_t pad[5];
+    uint32_t n_shadow[2];   // entries in q_shadow, double-buffered by bounce parity: K3 of bounce b may still be reading its count
+                            // while the counters of bounce b+1 are recycled (K3(b) overlaps K2(b+1) on a second stream)
+    uint32_t pad[4];
 };
 
 // Path state, structure of arrays (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
@@ -158,7 +159,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
     if (slot == 0) {
         qs->n_active[0] = total;
         qs->n_active[1] = 0;
-        qs->n_shadow = 0;
+        qs->n_shadow[0] = 0;
+        qs->n_shadow[1] = 0;
     }
 }
 
@@ -451,7 +453,7 @@ constexpr int SHADE_CHUNK = 2048;  // queue entries per workgroup chunk: ONE glo
 template <bool HAS_LAYERED, bool TRI_ONLY>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
-                                                     DeviceCounters* counters) {
+                                                     DeviceCounters* counters, int shadow_parity) {
     const uint32_t n = qs->n_active[cur];
     __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
     __shared__ uint32_t s_cnt[2], s_base[2];
@@ -643,7 +645,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
       __syncthreads();
       if (threadIdx.x == 0) {
           s_base[0] = s_cnt[0] ? atomicAdd(&qs->n_active[cur ^ 1], s_cnt[0]) : 0u;
-          s_base[1] = s_cnt[1] ? atomicAdd(&qs->n_shadow, s_cnt[1]) : 0u;
+          s_base[1] = s_cnt[1] ? atomicAdd(&qs->n_shadow[shadow_parity], s_cnt[1]) : 0u;
       }
       __syncthreads();
       for (uint32_t j = threadIdx.x; j < s_cnt[0]; j += SHADE2_BLOCK) q_next[s_base[0] + j] = s_next[j];
@@ -654,9 +656,9 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
 }
 
 // Between bounces: recycle the counters (1 thread).
-__global__ void k_next_bounce(QueueState* qs, int cur) {
+__global__ void k_next_bounce(QueueState* qs, int cur, int next_shadow_parity) {
     qs->n_active[cur] = 0;
-    qs->n_shadow = 0;
+    qs->n_shadow[next_shadow_parity] = 0;  // the one the NEXT shade launch fills; this bounce's count stays for its K3
 }
 __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x; i < 8 * 32; i += blockDim.x) heads[i] = 0; }
 
@@ -724,6 +726,9 @@ struct ShmScene {
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
     int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
     uint32_t* d_spill3 = nullptr;
+    uint32_t* d_spill3_any = nullptr;  // the any-hit kernel may run concurrently with the closest-hit one (second stream)
+    hipStream_t stream2 = nullptr;
+    uint64_t overlap_paths = 96ull << 20;  // batches below this many paths run K3(b) beside K2(b+1) (SHM_OVERLAP_PATHS; 0 = never)
     int refill_min = 16;
     uint32_t pix_group = 1024;      // path-slot order [tile][sample][pixel in tile] (SHM_PIX_GROUP; >= n_pix: sample-major)
     int queue_parts = 8;           // k_trace3 queue partitions, one per XCD with stealing (SHM_QUEUE_PARTS: 1 or 8)
@@ -810,17 +815,18 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths) {
 }
 
 template <bool ANY>
-void launch_trace(ShmScene* s, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, const ShmRay* rays, ShmHit* hits,
-                  uint8_t* occluded, float4* L, const float4* contrib) {
+void launch_trace(ShmScene* s, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, const ShmRay* rays,
+                  ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib) {
     uint32_t* heads = s->d_heads3 + (ANY ? 8 * 32 : 0);
-    hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, s->stream, heads);
+    uint32_t* spill = ANY ? s->d_spill3_any : s->d_spill3;
+    hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, stream, heads);
     const int leaf_min = ANY ? s->leaf_min_any : s->leaf_min;
     if (s->flat.has_spheres)
-        hipLaunchKernelGGL((k_trace3<ANY, false>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, heads, rays,
-                           hits, occluded, L, contrib, s->d_counters, s->d_spill3, s->spill3_levels, s->refill_min, leaf_min, s->queue_parts);
+        hipLaunchKernelGGL((k_trace3<ANY, false>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,
+                           hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels, s->refill_min, leaf_min, s->queue_parts);
     else
-        hipLaunchKernelGGL((k_trace3<ANY, true>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, s->stream, s->dsv, queue, n_ptr, n_direct, heads, rays,
-                           hits, occluded, L, contrib, s->d_counters, s->d_spill3, s->spill3_levels, s->refill_min, leaf_min, s->queue_parts);
+        hipLaunchKernelGGL((k_trace3<ANY, true>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,
+                           hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels, s->refill_min, leaf_min, s->queue_parts);
 }
 
 struct EventPool {
@@ -854,6 +860,7 @@ void shm_scene_destroy(ShmScene* s) {
     for (void* p : s->allocs) hipFree(p);
     for (void* p : s->ws_allocs) hipFree(p);
     for (hipEvent_t e : s->events) hipEventDestroy(e);
+    if (s->stream2) hipStreamDestroy(s->stream2);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
 }
@@ -877,6 +884,8 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
     if (hipStreamCreate(&s->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; return fail(SHM_ERR_DEVICE); }
+    if (hipStreamCreate(&s->stream2) != hipSuccess) { g_err = "hipStreamCreate failed"; return fail(SHM_ERR_DEVICE); }
+    if (const char* e = getenv("SHM_OVERLAP_PATHS")) { long long v2 = atoll(e); if (v2 >= 0) s->overlap_paths = (uint64_t)v2; }
 
     const shm_host::FlatScene& f = s->flat;
     SceneView v = f.view();  // scalars + host pointers; pointers replaced below
@@ -925,6 +934,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
         s->trace3_blocks = s->n_cu * per_cu3;
         s->spill3_levels = std::max(0, (int)f.max_leaf_depth + 1 - K3_LDS_N) + 1;
         if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3)) != SHM_OK) return fail(rc);
+        if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3_any)) != SHM_OK) return fail(rc);
     }
     DBG("scene: %u nodes, depth %u, trace blocks %d, spill levels %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->trace3_blocks, s->spill3_levels);
     *out = s;
@@ -997,7 +1007,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     if (pix_per_batch > 64) pix_per_batch &= ~63u;  // whole 8x8 tiles per wavefront
     EventPool ev{s};
     hipEvent_t e_begin = ev.get(), e_end = ev.get();
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_any;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_any, ev_shade;
+    bool used_overlap = false;
     HIP_TRY(hipEventRecord(e_begin, s->stream));
     const int shade_blocks = s->n_cu * 4;
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += pix_per_batch) {
@@ -1007,37 +1018,59 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         hipLaunchKernelGGL(k_generate, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
                            sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs, s->pix_group);
         int cur = 0;
+        // Small batches are tail-dominated (the last rays of a persistent traversal launch take ~0.5 ms whatever its size): there
+        // K3 of bounce b runs on a second stream beside K2 of bounce b+1 — they are independent: K3 reads the shadow buffers and
+        // adds into L, K2 reads the extension rays and writes hit records — and the next shade launch waits for both. Large
+        // batches (the 1-GPU headline frame) keep everything on one stream, so each kernel has the device to itself.
+        const bool overlap = s->overlap_paths > 0 && (uint64_t)total < s->overlap_paths && params->max_depth > 0;
+        hipStream_t any_stream = overlap ? s->stream2 : s->stream;
+        used_overlap = used_overlap || overlap;
+        hipEvent_t k3_done = nullptr;
         for (int bounce = 0; bounce <= params->max_depth; ++bounce) {
+            const int sh = bounce & 1;
             hipEvent_t a = ev.get(), b = ev.get();
             hipEventRecord(a, s->stream);
-            launch_trace<false>(s, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr);
+            launch_trace<false>(s, s->stream, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr);
             hipEventRecord(b, s->stream);
             ev_closest.push_back({a, b});
+            if (overlap && k3_done) hipStreamWaitEvent(s->stream, k3_done, 0);  // shade(b) touches L and refills the shadow buffers
             {
+                hipEvent_t s0 = ev.get(), s1 = ev.get();
+                hipEventRecord(s0, s->stream);
                 auto launch_shade = [&](auto kernel) {
                     hipLaunchKernelGGL(kernel, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
-                                       s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, s->d_counters);
+                                       s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, s->d_counters, sh);
                 };
                 const bool tri_only = !s->flat.has_spheres;
                 if (s->flat.has_layered) { if (tri_only) launch_shade(k_shade<true, true>); else launch_shade(k_shade<true, false>); }
                 else { if (tri_only) launch_shade(k_shade<false, true>); else launch_shade(k_shade<false, false>); }
+                hipEventRecord(s1, s->stream);
+                ev_shade.push_back({s0, s1});
             }
             if (bounce < params->max_depth) {
                 hipEvent_t c = ev.get(), d = ev.get();
-                hipEventRecord(c, s->stream);
-                launch_trace<true>(s, s->d_q_shadow, &s->d_qs->n_shadow, 0, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib);
-                hipEventRecord(d, s->stream);
+                if (overlap) {
+                    hipEvent_t shaded = ev.get();
+                    hipEventRecord(shaded, s->stream);
+                    hipStreamWaitEvent(any_stream, shaded, 0);
+                }
+                hipEventRecord(c, any_stream);
+                launch_trace<true>(s, any_stream, s->d_q_shadow, &s->d_qs->n_shadow[sh], 0, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib);
+                hipEventRecord(d, any_stream);
                 ev_any.push_back({c, d});
+                k3_done = d;
             }
             if (dbg_on()) {  // queue sizes per bounce (costs a sync: debug only)
                 QueueState q;
                 hipStreamSynchronize(s->stream);
+                hipStreamSynchronize(any_stream);
                 hipMemcpy(&q, s->d_qs, sizeof(q), hipMemcpyDeviceToHost);
-                DBG("bounce %d: traced %u, next %u, shadow %u", bounce, q.n_active[cur], q.n_active[cur ^ 1], q.n_shadow);
+                DBG("bounce %d: traced %u, next %u, shadow %u", bounce, q.n_active[cur], q.n_active[cur ^ 1], q.n_shadow[sh]);
             }
-            hipLaunchKernelGGL(k_next_bounce, dim3(1), dim3(1), 0, s->stream, s->d_qs, cur);
+            hipLaunchKernelGGL(k_next_bounce, dim3(1), dim3(1), 0, s->stream, s->d_qs, cur, sh ^ 1);
             cur ^= 1;
         }
+        if (overlap && k3_done) hipStreamWaitEvent(s->stream, k3_done, 0);  // the film reads L
         hipLaunchKernelGGL(k_film, dim3((n_pix + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix, n_samples,
                            s->d_film, s->d_counters, s->pix_group);
     }
@@ -1060,16 +1093,15 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         double mc = 0.0, ma = 0.0;
         for (auto& p : ev_closest) { hipEventElapsedTime(&ms, p.first, p.second); mc += ms; DBG("closest launch %.3f ms", ms); }
         for (auto& p : ev_any) { hipEventElapsedTime(&ms, p.first, p.second); ma += ms; DBG("any launch %.3f ms", ms); }
-        if (dbg_on())
-            for (size_t i = 0; i < ev_any.size() && i < ev_closest.size(); ++i) {
-                hipEventElapsedTime(&ms, ev_closest[i].second, ev_any[i].first);
-                DBG("shade launch %.3f ms", ms);
-            }
+        double msh = 0.0;
+        for (auto& p : ev_shade) { hipEventElapsedTime(&ms, p.first, p.second); msh += ms; DBG("shade launch %.3f ms", ms); }
         stats->ms_trace_closest += mc;
         stats->ms_trace_any += ma;
         float tot = 0.0f;
         hipEventElapsedTime(&tot, e_begin, e_end);
-        stats->ms_shade += (double)tot - mc - ma;
+        // everything that is not traversal: shade + generate + film. Without overlap that is the rest of the wall time; with K3
+        // running beside K2 the kernels' own durations add up to more than the wall time, so the shade launches are summed instead.
+        stats->ms_shade += used_overlap ? msh : (double)tot - mc - ma;
         stats->launches_closest += (uint32_t)ev_closest.size();
         stats->launches_any += (uint32_t)ev_any.size();
     }
@@ -1138,8 +1170,8 @@ static int trace_device_impl(ShmScene* s, bool any, const void* rays_dev, uint32
     for (int r = 0; r < repeat; ++r) {
         hipEvent_t a = ev.get(), b = ev.get();
         hipEventRecord(a, s->stream);
-        if (any) launch_trace<true>(s, nullptr, nullptr, n, (const ShmRay*)rays_dev, nullptr, (uint8_t*)out_dev, nullptr, nullptr);
-        else launch_trace<false>(s, nullptr, nullptr, n, (const ShmRay*)rays_dev, (ShmHit*)out_dev, nullptr, nullptr, nullptr);
+        if (any) launch_trace<true>(s, s->stream, nullptr, nullptr, n, (const ShmRay*)rays_dev, nullptr, (uint8_t*)out_dev, nullptr, nullptr);
+        else launch_trace<false>(s, s->stream, nullptr, nullptr, n, (const ShmRay*)rays_dev, (ShmHit*)out_dev, nullptr, nullptr, nullptr);
         hipEventRecord(b, s->stream);
         evs.push_back({a, b});
     }

@@ -182,6 +182,14 @@ def test_render_decomposition_invariance(env, monkeypatch):
     f3, _ = gpu_small.render(p)
     gpu_small.close()
     assert np.array_equal(f3, f1)
+    # (iv) ... nor on whether the any-hit kernel of bounce b runs on the second stream beside the closest-hit kernel of bounce
+    # b+1 (the default for batches this small) or everything is serialised on one stream
+    monkeypatch.delenv("SHM_BATCH_PATHS")
+    monkeypatch.setenv("SHM_OVERLAP_PATHS", "0")
+    gpu_serial = render.Renderer(lib, sc.desc, 0)
+    f4, s4 = gpu_serial.render(p)
+    gpu_serial.close()
+    assert np.array_equal(f4, f1) and s4["rays_any"] == s1["rays_any"] and s4["nodes_any"] == s1["nodes_any"]
 
 
 def test_full_size_properties_and_crop_parity(env):
