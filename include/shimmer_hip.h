@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SHM_ABI_VERSION 4
+#define SHM_ABI_VERSION 5
 
 /* The library is built with -fvisibility=hidden; only these entry points are exported. */
 #if defined(__GNUC__)
@@ -244,8 +244,15 @@ typedef struct ShmRenderParams {
     uint8_t disable_pixel_jitter;
     uint8_t disable_wavelength_jitter;
     uint8_t force_diffuse;        /* must be 0 (unsupported) */
-    uint8_t pad[4];
+    uint8_t integrator;           /* SHM_INTEGRATOR_* (ABI v5); 0 = "path" */
+    uint8_t sample_lights;        /* SimplePath "samplelights" (default true in the reference, integrator.rs:135-137) */
+    uint8_t sample_bsdf;          /* SimplePath "samplebsdf"   (default true) */
+    uint8_t pad;
 } ShmRenderParams;
+enum {
+    SHM_INTEGRATOR_PATH = 0,        /* PathIntegrator,       integrator.rs:748-963 */
+    SHM_INTEGRATOR_SIMPLE_PATH = 1  /* SimplePathIntegrator, integrator.rs:573-733 */
+};
 
 /* Tile (tile.rs:5-7): Bounds2i, max exclusive. */
 typedef struct ShmTile {
@@ -354,11 +361,12 @@ SHM_API int shm_camera_orthographic(const float world_from_camera[16], const int
                             float focal_distance, ShmCamera* out, float render_from_world_out[16]);
 /* C entry to the C++ host mirror of the reference's integrator interface (shimmer_amd/csrc/host/integrator.hpp):
  * create_integrator(name, {maxdepth, regularize, lightsampler "uniform", spp}, scene)->render(options), integrator.rs:16-42,
- * 52-54, 180-210, 226-322. `name` other than "path" fails the way the reference panics ("Unknown integrator ..."); the message
+ * 52-54, 120-210, 226-322. `name`: "path" or "simplepath" (sample_lights / sample_bsdf are its "samplelights" / "samplebsdf");
+ * anything else fails the way the reference panics ("Unknown integrator ..."); the message
  * is available through shm_last_error(). film_out: pixel_bounds-sized, overwritten; n_waves_out: spp-waves rendered. */
 SHM_API int shm_integrator_render(const char* name, const ShmSceneDesc* scene, int device, int32_t max_depth, int regularize,
-                          int32_t samples_per_pixel, int32_t seed, int disable_pixel_jitter, int disable_wavelength_jitter,
-                          ShmFilmPixel* film_out, ShmStats* stats_out, int32_t* n_waves_out);
+                          int sample_lights, int sample_bsdf, int32_t samples_per_pixel, int32_t seed, int disable_pixel_jitter,
+                          int disable_wavelength_jitter, ShmFilmPixel* film_out, ShmStats* stats_out, int32_t* n_waves_out);
 /* RgbFilm::get_image / get_pixel_rgb (film.rs:647-707, 720-738) over a read-back film: rgb = sum / weight_sum (when the
  * weight is non-zero), plus the (here always zero) splat term, times output_rgb_from_sensor_rgb (film.rs:524; row-major 3x3,
  * passed by the caller, who owns the colour space), with the reference's f16 clamp when write_fp16 is set (film.rs:676-690,

@@ -242,6 +242,84 @@ Spec li(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng, int max_dep
     return l;
 }
 
+// SimplePathIntegrator::li, integrator.rs:586-733: no MIS, no Russian roulette; direct lighting by light sampling
+// (sample_lights) or only by hitting emitters; directions from the BSDF (sample_bsdf) or uniform over the (hemi)sphere.
+Spec li_simple_path(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng, int max_depth, bool sample_lights, bool sample_bsdf,
+                    Counters& c) {
+    Spec l = spec_const(0.0f);
+    bool specular_bounce = true;
+    Spec beta = spec_const(1.0f);
+    int depth = 0;
+    while (!is_zero(beta)) {
+        Hit hit;
+        if (!bvh_intersect(sv, ray.o, ray.d, infinity(), hit, c)) {
+            if (!sample_lights || specular_bounce)
+                for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
+                    const ShmLight& light = sv.lights[sv.infinite_lights[k]];
+                    l = l + beta * (light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda));
+                }
+            break;
+        }
+        SurfaceInteraction si = hit_interaction(sv, hit, -ray.d);
+        const ShmPrimitive& prim = sv.primitives[hit.prim];
+        if (!sample_lights || specular_bounce) {
+            if (prim.area_light >= 0) l = l + beta * area_light_l(sv, sv.lights[prim.area_light], si.n, -ray.d, lambda);
+            else l = l + beta * spec_const(0.0f);  // isect.le() of a non-emitter is a zero spectrum that is still added (interaction.rs:369-377)
+        }
+        if (depth == max_depth) break;
+        depth += 1;
+        BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+        V3 wo = -ray.d;
+        if (sample_lights) {
+            Float p_sel = 0.0f;
+            int li = light_sampler_sample(sv, sampler_get_1d(rng), p_sel);
+            if (li >= 0) {
+                V2 u_light = sampler_get_2d(rng);
+                LightSampleContext ctx = light_ctx_from(si);
+                const ShmLight& light = sv.lights[li];
+                LightLiSample ls;
+                if (light_sample_li(sv, light, ctx, u_light, lambda, ls, false) && !is_zero(ls.l) && ls.pdf > 0.0f) {
+                    V3 wi = ls.wi;
+                    Spec f = bsdf_f(bsdf, wo, wi) * abs_dot(wi, si.shading.n);
+                    if (!is_zero(f)) {
+                        Ray sr = spawn_ray_to_both_offset(si.pi, si.n, ls.p_light_pi, ls.p_light_n);
+                        if (!bvh_intersect_predicate(sv, sr.o, sr.d, 1.0f - SHADOW_EPSILON, c)) l = l + beta * f * ls.l / (p_sel * ls.pdf);
+                    }
+                }
+            }
+        }
+        if (sample_bsdf) {
+            Float u = sampler_get_1d(rng);
+            V2 u2 = sampler_get_2d(rng);
+            BSDFSample bs;
+            if (!bsdf_sample_f(bsdf, wo, u, u2, REFLTRANS_ALL, bs)) break;
+            beta = beta * (bs.f * abs_dot(bs.wi, si.shading.n) / bs.pdf);
+            specular_bounce = flags_is_specular(bs.flags);
+            ray.o = offset_ray_origin(si.pi, si.n, bs.wi);
+            ray.d = bs.wi;
+        } else {
+            uint32_t flags = bsdf_flags(bsdf);
+            Float pdf;
+            V3 wi;
+            if (flags_is_reflective(flags) && flags_is_transmissive(flags)) {
+                wi = sample_uniform_sphere(sampler_get_2d(rng));
+                pdf = uniform_sphere_pdf();
+            } else {
+                wi = sample_uniform_hemisphere(sampler_get_2d(rng));
+                pdf = uniform_hemisphere_pdf();
+                if ((flags_is_reflective(flags) && dot(wo, si.n) * dot(wi, si.n) < 0.0f) ||
+                    (flags_is_transmissive(flags) && dot(wo, si.n) * dot(wi, si.n) > 0.0f))
+                    wi = -wi;
+            }
+            beta = beta * (bsdf_f(bsdf, wo, wi) * abs_dot(wi, si.shading.n) / pdf);
+            specular_bounce = false;
+            ray.o = offset_ray_origin(si.pi, si.n, wi);
+            ray.d = wi;
+        }
+    }
+    return l;
+}
+
 struct Oracle {
     shm_host::FlatScene flat;
     SceneView sv;
@@ -318,7 +396,9 @@ int orc_render_wave(OrcScene* s, const ShmRenderParams* params, const ShmTile* t
                         Float weight;
                         Ray ray = generate_camera_ray(sv, x, y, rng, params->disable_wavelength_jitter != 0,
                                                       params->disable_pixel_jitter != 0, lambda, weight);
-                        Spec L = spec_const(1.0f) * li(sv, ray, lambda, rng, params->max_depth, params->regularize != 0, c);  // camera_ray.weight * li
+                        Spec L = spec_const(1.0f) * ((params->integrator == SHM_INTEGRATOR_SIMPLE_PATH)
+                                                         ? li_simple_path(sv, ray, lambda, rng, params->max_depth, params->sample_lights != 0, params->sample_bsdf != 0, c)
+                                                         : li(sv, ray, lambda, rng, params->max_depth, params->regularize != 0, c));  // camera_ray.weight * li
                         c.paths++;
                         // RgbFilm::add_sample, film.rs:548-574
                         V3 rgb = film_sample_rgb(sv, L, lambda);

@@ -10,7 +10,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 LIB_PATH = ROOT / "csrc" / "libshimmer_hip.so"
 
-SHM_ABI_VERSION = 4
+SHM_ABI_VERSION = 5
 SHM_OK = 0
 SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE, SHM_SHAPE_BILINEAR_PATCH = 0, 1, 2
 SHM_SPECTRUM_CONSTANT, SHM_SPECTRUM_DENSE, SHM_SPECTRUM_PIECEWISE_LINEAR = 0, 1, 2
@@ -19,6 +19,7 @@ SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATER
 SHM_MATERIAL_COATED_DIFFUSE, SHM_MATERIAL_COATED_CONDUCTOR, SHM_MATERIAL_MIX = 4, 5, 6
 SHM_LIGHT_POINT, SHM_LIGHT_DIFFUSE_AREA, SHM_LIGHT_UNIFORM_INFINITE = 0, 1, 2
 SHM_CAMERA_PERSPECTIVE, SHM_CAMERA_ORTHOGRAPHIC = 0, 1
+SHM_INTEGRATOR_PATH, SHM_INTEGRATOR_SIMPLE_PATH = 0, 1
 
 c_float_p = C.POINTER(C.c_float)
 c_u32_p = C.POINTER(C.c_uint32)
@@ -95,7 +96,7 @@ class ShmSceneDesc(C.Structure):
 class ShmRenderParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32), ("regularize", C.c_uint8),
                 ("disable_pixel_jitter", C.c_uint8), ("disable_wavelength_jitter", C.c_uint8), ("force_diffuse", C.c_uint8),
-                ("pad", C.c_uint8 * 4)]
+                ("integrator", C.c_uint8), ("sample_lights", C.c_uint8), ("sample_bsdf", C.c_uint8), ("pad", C.c_uint8)]
 
 
 class ShmTile(C.Structure):
@@ -147,7 +148,7 @@ EXPORTS = {
     "shm_bvh_build": (C.c_int, [c_float_p, C.c_uint32, C.c_int, C.POINTER(ShmBvhNode), c_u32_p, c_u32_p]),
     "shm_tile_bounds": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(ShmTile), c_u32_p]),
     "shm_camera_perspective": (C.c_int, [c_float_p, C.c_float, C.POINTER(C.c_int32), C.c_float, C.c_float, C.POINTER(ShmCamera), c_float_p]),
-    "shm_integrator_render": (C.c_int, [C.c_char_p, C.POINTER(ShmSceneDesc), C.c_int, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_int,
+    "shm_integrator_render": (C.c_int, [C.c_char_p, C.POINTER(ShmSceneDesc), C.c_int, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_int,
                                         C.c_void_p, C.POINTER(ShmStats), C.POINTER(C.c_int32)]),
     "shm_camera_orthographic": (C.c_int, [c_float_p, C.POINTER(C.c_int32), C.c_float, C.c_float, C.POINTER(ShmCamera), c_float_p]),
     "shm_film_get_image": (C.c_int, [C.c_void_p, C.c_uint64, c_float_p, C.c_int, c_float_p]),

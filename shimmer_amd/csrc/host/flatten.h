@@ -35,6 +35,7 @@ struct FlatScene {
     ShmCamera camera;
     ShmFilm film;
     uint32_t max_leaf_depth = 0;  // deepest leaf (root = 0); bounds the traversal stack
+    float scene_radius = 0.0f;
     bool has_spheres = false;  // any non-triangle shape (sphere or bilinear patch): selects k_trace3<.., TRI_ONLY = false>
     bool has_layered = false;  // any Coated* material: selects the k_shade instantiation that carries LayeredBxDF
 
@@ -61,6 +62,7 @@ struct FlatScene {
         v.infinite_lights = infinite_lights.data();
         v.n_infinite_lights = (uint32_t)infinite_lights.size();
         v.spectrum_data = spectrum_data.data();
+        v.scene_radius = scene_radius;
         v.camera = camera;
         for (int i = 0; i < 4; ++i) v.pixel_bounds[i] = film.pixel_bounds[i];
         v.filter_radius[0] = film.filter_radius[0];
@@ -242,6 +244,15 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
             return SHM_ERR_UNSUPPORTED;
         }
         out.prim_recs[s] = rec;
+    }
+
+    // UniformInfiniteLight::preprocess (light.rs:799-803): bounding sphere of the scene bounds = the root node's box
+    if (!out.nodes.empty()) {
+        const ShmBvhNode& root = out.nodes[0];
+        shm::V3 lo = shm::v3(root.bmin[0], root.bmin[1], root.bmin[2]), hi = shm::v3(root.bmax[0], root.bmax[1], root.bmax[2]);
+        shm::V3 center = (lo + hi) / 2.0f;
+        bool inside = center.x >= lo.x && center.x <= hi.x && center.y >= lo.y && center.y <= hi.y && center.z >= lo.z && center.z <= hi.z;
+        out.scene_radius = inside ? shm::distance(center, hi) : 0.0f;
     }
 
     // materials / lights

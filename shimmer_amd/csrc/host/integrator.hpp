@@ -39,6 +39,8 @@ struct PathIntegratorParameters {
     bool regularize = false;                // "regularize"
     std::string light_sampler = "uniform";  // "lightsampler" (light_sampler.rs:24-40: only "uniform" exists on this path)
     int32_t samples_per_pixel = 16;         // Sampler::samples_per_pixel()
+    bool sample_lights = true;              // SimplePath "samplelights" (integrator.rs:135-137)
+    bool sample_bsdf = true;                // SimplePath "samplebsdf"
 };
 
 // integrator.rs:52-54
@@ -59,7 +61,9 @@ class WavefrontPathIntegrator : public Integrator {
 public:
     // `scene` is what the reference hands to create_integrator — camera (+ film), aggregate, lights — already flattened
     // into the ABI's POD description; the arrays are only borrowed for the duration of the constructor.
-    WavefrontPathIntegrator(const ShmSceneDesc& scene, const PathIntegratorParameters& parameters, int device = 0) : params_(parameters) {
+    WavefrontPathIntegrator(const ShmSceneDesc& scene, const PathIntegratorParameters& parameters, int device = 0,
+                            uint8_t integrator = SHM_INTEGRATOR_PATH)
+        : params_(parameters), integrator_(integrator) {
         if (parameters.light_sampler != "uniform") throw IntegratorError("Unknown light sampler " + parameters.light_sampler);
         check(shm_scene_create(&scene, device, &scene_), "shm_scene_create");
         const int32_t* pb = scene.film.pixel_bounds;
@@ -88,6 +92,9 @@ public:
         rp.samples_per_pixel = params_.samples_per_pixel;
         rp.max_depth = params_.max_depth;
         rp.regularize = params_.regularize ? 1 : 0;
+        rp.integrator = integrator_;
+        rp.sample_lights = params_.sample_lights ? 1 : 0;
+        rp.sample_bsdf = params_.sample_bsdf ? 1 : 0;
         rp.disable_pixel_jitter = options.disable_pixel_jitter ? 1 : 0;
         rp.disable_wavelength_jitter = options.disable_wavelength_jitter ? 1 : 0;
         stats_ = ShmStats{};
@@ -119,6 +126,7 @@ private:
         }
     }
     PathIntegratorParameters params_;
+    uint8_t integrator_ = SHM_INTEGRATOR_PATH;
     ShmScene* scene_ = nullptr;
     std::vector<ShmTile> tiles_;
     std::vector<ShmFilmPixel> film_;
@@ -126,12 +134,14 @@ private:
     int32_t width_ = 0, height_ = 0, waves_ = 0;
 };
 
-// integrator.rs:16-42. "simplepath" and "randomwalk" exist in the reference but are outside this backend's contract
-// (not on the default path); anything else is the reference's "Unknown integrator" panic.
+// integrator.rs:16-42. "randomwalk" exists in the reference but is outside this backend's contract (its recursive estimator
+// le + f cos Li / pdf has to be folded backwards along the path); anything else is the reference's "Unknown integrator" panic.
 inline std::unique_ptr<Integrator> create_integrator(const std::string& name, const PathIntegratorParameters& parameters,
                                                      const ShmSceneDesc& scene, int device = 0) {
     if (name == "path") return std::make_unique<WavefrontPathIntegrator>(scene, parameters, device);
-    if (name == "simplepath" || name == "randomwalk") throw IntegratorError("integrator " + name + " is not provided by the wavefront backend");
+    // ImageTileIntegrator::create_simple_path_integrator (integrator.rs:120-147): the same tile / wave driver around SimplePathIntegrator::li
+    if (name == "simplepath") return std::make_unique<WavefrontPathIntegrator>(scene, parameters, device, (uint8_t)SHM_INTEGRATOR_SIMPLE_PATH);
+    if (name == "randomwalk") throw IntegratorError("integrator " + name + " is not provided by the wavefront backend");
     throw IntegratorError("Unknown integrator " + name);
 }
 

@@ -655,6 +655,163 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
     (void)counters;
 }
 
+// ---------------------------------------------------------------------------------------------
+// SimplePathIntegrator::li (integrator.rs:586-733), one vertex per launch, same queues and path state as k_shade. One general
+// instantiation (every material and shape kind): it is the reference's debugging integrator, not a throughput path.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur,
+                                                                           uint32_t* __restrict__ q_next, uint32_t* __restrict__ q_shadow,
+                                                                           QueueState* qs, int cur, ShmRenderParams params, int shadow_parity) {
+    const uint32_t n = qs->n_active[cur];
+    const bool sample_lights = params.sample_lights != 0, sample_bsdf = params.sample_bsdf != 0;
+    __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
+    __shared__ uint32_t s_cnt[2], s_base[2];
+    for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
+      if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+      __syncthreads();
+      for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+        const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
+        bool push_next = false, push_shadow = false;
+        uint32_t path = 0;
+        if (i < n) {
+            path = q_cur[i];
+            const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
+            float4 h0 = hp[0], h1 = hp[1];
+            Hit hit;
+            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y;
+            const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
+            float4 r0 = rp[0], r1 = rp[1];
+            V3 ray_d = v3(r0.w, r1.x, r1.y);
+            auto add_l = [&](const Spec& c) { pa.L[path] = st_spec(ld_spec(pa.L[path]) + c); };
+            Spec beta = ld_spec(pa.beta[path]);
+            Wavelengths lambda;
+            float4 pdf_in;
+            {
+                float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                pdf_in = b;
+                lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
+                lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
+            }
+            uint32_t fl = pa.flags[path];
+            int depth = (int)(fl & 0xffu);
+            // k_generate leaves flags = 0: the reference starts with specular_bounce = true (integrator.rs:601), so bit 8 holds its
+            // negation here ("the last bounce was NOT specular")
+            bool specular_bounce = ((fl >> 8) & 1u) == 0u;
+            if (hit.prim < 0) {
+                if (!sample_lights || specular_bounce)
+                    for (uint32_t li = 0; li < sv.n_infinite_lights; ++li) {
+                        const ShmLight& light = sv.lights[sv.infinite_lights[li]];
+                        add_l(beta * (light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda)));
+                    }
+            } else {
+                SurfaceInteraction si = hit_interaction<false>(sv, hit, -ray_d);
+                const ShmPrimitive prim = sv.primitives[hit.prim];
+                if (!sample_lights || specular_bounce) {
+                    if (prim.area_light >= 0) add_l(beta * area_light_l(sv, sv.lights[prim.area_light], si.n, -ray_d, lambda));
+                    else add_l(beta * spec_const(0.0f));  // isect.le() of a non-emitter: a zero spectrum that is still added
+                }
+                if (depth != params.max_depth) {
+                    depth += 1;
+                    BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+                    V3 wo = -ray_d;
+                    uint32_t pix = pa.pixel[path];
+                    uint2 rs = pa.rng[path];
+                    Rng rng;
+                    rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+                    {
+                        uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
+                        h = mix_bits(h ^ (params.seed + 0x9e3779b97f4a7c15ULL));
+                        rng.inc = (h << 1u) | 1u;
+                    }
+                    if (sample_lights) {
+                        Float p_sel = 0.0f;
+                        int li = light_sampler_sample(sv, sampler_get_1d(rng), p_sel);
+                        if (li >= 0) {
+                            V2 u_light = sampler_get_2d(rng);
+                            LightSampleContext ctx = light_ctx_from(si);
+                            const ShmLight& light = sv.lights[li];
+                            LightLiSample ls;
+                            if (light_sample_li<false>(sv, light, ctx, u_light, lambda, ls, false) && !is_zero(ls.l) && ls.pdf > 0.0f) {
+                                V3 wi = ls.wi;
+                                Spec f = bsdf_f(bsdf, wo, wi) * abs_dot(wi, si.shading.n);
+                                if (!is_zero(f)) {
+                                    Ray sr = spawn_ray_to_both_offset(si.pi, si.n, ls.p_light_pi, ls.p_light_n);
+                                    ShmRay sh;
+                                    sh.o[0] = sr.o.x; sh.o[1] = sr.o.y; sh.o[2] = sr.o.z;
+                                    sh.d[0] = sr.d.x; sh.d[1] = sr.d.y; sh.d[2] = sr.d.z;
+                                    sh.t_max = 1.0f - 0.0001f;  // 1 - SHADOW_EPSILON
+                                    sh.pad = 0.0f;
+                                    pa.shadow_ray[path] = sh;
+                                    pa.shadow_contrib[path] = st_spec(beta * f * ls.l / (p_sel * ls.pdf));  // added to L by K3 if unoccluded
+                                    push_shadow = true;
+                                }
+                            }
+                        }
+                    }
+                    bool alive = true;
+                    V3 wi_next = v3s(0.0f);
+                    if (sample_bsdf) {
+                        Float u = sampler_get_1d(rng);
+                        V2 u2 = sampler_get_2d(rng);
+                        BSDFSample bs;
+                        if (!bsdf_sample_f(bsdf, wo, u, u2, REFLTRANS_ALL, bs)) {
+                            alive = false;
+                        } else {
+                            beta = beta * (bs.f * abs_dot(bs.wi, si.shading.n) / bs.pdf);
+                            specular_bounce = flags_is_specular(bs.flags);
+                            wi_next = bs.wi;
+                        }
+                    } else {
+                        uint32_t flags = bsdf_flags(bsdf);
+                        Float pdf;
+                        if (flags_is_reflective(flags) && flags_is_transmissive(flags)) {
+                            wi_next = sample_uniform_sphere(sampler_get_2d(rng));
+                            pdf = uniform_sphere_pdf();
+                        } else {
+                            wi_next = sample_uniform_hemisphere(sampler_get_2d(rng));
+                            pdf = uniform_hemisphere_pdf();
+                            if ((flags_is_reflective(flags) && dot(wo, si.n) * dot(wi_next, si.n) < 0.0f) ||
+                                (flags_is_transmissive(flags) && dot(wo, si.n) * dot(wi_next, si.n) > 0.0f))
+                                wi_next = -wi_next;
+                        }
+                        beta = beta * (bsdf_f(bsdf, wo, wi_next) * abs_dot(wi_next, si.shading.n) / pdf);
+                        specular_bounce = false;
+                    }
+                    if (alive && !is_zero(beta)) {  // `while !beta.is_zero()` at the top of the next iteration
+                        V3 no = offset_ray_origin(si.pi, si.n, wi_next);
+                        ShmRay nr;
+                        nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z;
+                        nr.d[0] = wi_next.x; nr.d[1] = wi_next.y; nr.d[2] = wi_next.z;
+                        nr.t_max = infinity();
+                        nr.pad = 0.0f;
+                        pa.ray[path] = nr;
+                        pa.beta[path] = st_spec(beta);
+                        pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                        pa.flags[path] = (uint32_t)depth | ((specular_bounce ? 0u : 1u) << 8);
+                        push_next = true;
+                    }
+                    if (lambda.pdf[1] != pdf_in.y || lambda.pdf[2] != pdf_in.z || lambda.pdf[3] != pdf_in.w || lambda.pdf[0] != pdf_in.x)
+                        pa.lambda_pdf[path] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
+                }
+            }
+        }
+        uint32_t s1 = queue_push_slot(&s_cnt[0], push_next);
+        if (push_next) s_next[s1] = path;
+        uint32_t s2 = queue_push_slot(&s_cnt[1], push_shadow);
+        if (push_shadow) s_shadow[s2] = path;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+          s_base[0] = s_cnt[0] ? atomicAdd(&qs->n_active[cur ^ 1], s_cnt[0]) : 0u;
+          s_base[1] = s_cnt[1] ? atomicAdd(&qs->n_shadow[shadow_parity], s_cnt[1]) : 0u;
+      }
+      __syncthreads();
+      for (uint32_t j = threadIdx.x; j < s_cnt[0]; j += SHADE2_BLOCK) q_next[s_base[0] + j] = s_next[j];
+      for (uint32_t j = threadIdx.x; j < s_cnt[1]; j += SHADE2_BLOCK) q_shadow[s_base[1] + j] = s_shadow[j];
+      __syncthreads();
+    }
+}
+
 // Between bounces: recycle the counters (1 thread).
 __global__ void k_next_bounce(QueueState* qs, int cur, int next_shadow_parity) {
     qs->n_active[cur] = 0;
@@ -969,6 +1126,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     if (!s || !params || !tiles || n_tiles == 0 || sample_end <= sample_begin) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
     if (params->force_diffuse) { g_err = "force_diffuse is not supported"; return SHM_ERR_UNSUPPORTED; }
     if (params->max_depth < 0 || params->max_depth > 254) { g_err = "max_depth out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (params->integrator > SHM_INTEGRATOR_SIMPLE_PATH) { g_err = "unknown integrator"; return SHM_ERR_UNSUPPORTED; }
     HIP_TRY(hipSetDevice(s->device));
     int rc;
     const int32_t* pb = s->flat.film.pixel_bounds;
@@ -1042,7 +1200,10 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                                        s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, s->d_counters, sh);
                 };
                 const bool tri_only = !s->flat.has_spheres;
-                if (s->flat.has_layered) { if (tri_only) launch_shade(k_shade<true, true>); else launch_shade(k_shade<true, false>); }
+                if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH)
+                    hipLaunchKernelGGL(k_shade_simple, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
+                                       s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, sh);
+                else if (s->flat.has_layered) { if (tri_only) launch_shade(k_shade<true, true>); else launch_shade(k_shade<true, false>); }
                 else { if (tri_only) launch_shade(k_shade<false, true>); else launch_shade(k_shade<false, false>); }
                 hipEventRecord(s1, s->stream);
                 ev_shade.push_back({s0, s1});
@@ -1194,13 +1355,15 @@ static int trace_device_impl(ShmScene* s, bool any, const void* rays_dev, uint32
 }
 
 int shm_integrator_render(const char* name, const ShmSceneDesc* scene, int device, int32_t max_depth, int regularize,
-                          int32_t samples_per_pixel, int32_t seed, int disable_pixel_jitter, int disable_wavelength_jitter,
-                          ShmFilmPixel* film_out, ShmStats* stats_out, int32_t* n_waves_out) {
+                          int sample_lights, int sample_bsdf, int32_t samples_per_pixel, int32_t seed, int disable_pixel_jitter,
+                          int disable_wavelength_jitter, ShmFilmPixel* film_out, ShmStats* stats_out, int32_t* n_waves_out) {
     if (!name || !scene || !film_out) { g_err = "invalid integrator arguments"; return SHM_ERR_INVALID_ARGUMENT; }
     try {
         shimmer::PathIntegratorParameters p;
         p.max_depth = max_depth;
         p.regularize = regularize != 0;
+        p.sample_lights = sample_lights != 0;
+        p.sample_bsdf = sample_bsdf != 0;
         p.samples_per_pixel = samples_per_pixel;
         std::unique_ptr<shimmer::Integrator> integrator = shimmer::create_integrator(name, p, *scene, device);
         shimmer::Options options;

@@ -45,10 +45,11 @@ SHM_HD Spec area_light_l(const SceneView& sv, const ShmLight& light, V3 n, V3 w,
     return light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
 }
 
-// Light::sample_li with allow_incomplete_pdf = true (the only way PathIntegrator calls it, integrator.rs:927)
+// Light::sample_li. PathIntegrator calls it with allow_incomplete_pdf = true (integrator.rs:927), SimplePathIntegrator with false
+// (integrator.rs:651-655): the flag only matters for the uniform infinite light.
 template <bool TRI_ONLY = false>
 SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const LightSampleContext& ctx, V2 u,
-                            const Wavelengths& lambda, LightLiSample& out) {
+                            const Wavelengths& lambda, LightLiSample& out, bool allow_incomplete_pdf = true) {
     if (light.kind == SHM_LIGHT_POINT) {  // light.rs:452-468
         V3 p = ld3(light.position);
         V3 wi = normalize(p - ctx.p());
@@ -58,7 +59,17 @@ SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const Li
         out.p_light_n = v3s(0.0f);
         return true;
     }
-    if (light.kind == SHM_LIGHT_UNIFORM_INFINITE) return false;  // light.rs:747-749 (allow_incomplete_pdf)
+    if (light.kind == SHM_LIGHT_UNIFORM_INFINITE) {
+        if (allow_incomplete_pdf) return false;  // light.rs:747-749
+        // light.rs:750-766: a uniform spherical sample, its pdf from uniform_hemisphere_pdf() (= 1/4pi there: quirk 2)
+        V3 wi = sample_uniform_sphere(u);
+        out.l = light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
+        out.wi = wi;
+        out.pdf = uniform_hemisphere_pdf();
+        out.p_light_pi = p3i_exact(ctx.p() + wi * (2.0f * sv.scene_radius));
+        out.p_light_n = v3s(0.0f);
+        return true;
+    }
     // DiffuseAreaLight::sample_li, light.rs:632-661
     ShapeSampleContext sctx;
     sctx.pi = ctx.pi; sctx.n = ctx.n; sctx.ns = ctx.ns;

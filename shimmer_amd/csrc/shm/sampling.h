@@ -122,6 +122,13 @@ SHM_HD V3 sample_uniform_sphere(V2 u) {
     Float phi = 2.0f * PI_F * u.y;
     return v3(r * cos(phi), r * sin(phi), z);
 }
+// sampling.rs:295-304
+SHM_HD V3 sample_uniform_hemisphere(V2 u) {
+    Float z = u.x;
+    Float r = safe_sqrt(1.0f - z * z);
+    Float phi = 2.0f * PI_F * u.y;
+    return v3(r * cos(phi), r * sin(phi), z);
+}
 SHM_HD Float uniform_sphere_pdf() { return INV_4PI; }
 SHM_HD Float uniform_hemisphere_pdf() { return INV_4PI; }  // sampling.rs:306-308 (quirk 2)
 // sampling.rs:324-339

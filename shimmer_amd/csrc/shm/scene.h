@@ -59,6 +59,7 @@ struct SceneView {
     const uint32_t* infinite_lights;  // indices into lights (integrator.rs:86-92)
     uint32_t n_infinite_lights;
     const Float* spectrum_data;
+    Float scene_radius;  // Light::preprocess(scene_bounds): Bounds3::bounding_sphere of the aggregate's bounds (bounding_box.rs:460-468)
     ShmCamera camera;
     int32_t pixel_bounds[4];
     Float filter_radius[2];

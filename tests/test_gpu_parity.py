@@ -243,7 +243,7 @@ def test_integrator_mirror_parity(env):
     spp, depth, seed = 21, 5, 6
     film = np.zeros((56, 72), dtype=render.FILM_DTYPE)
     st, waves = abi.ShmStats(), C.c_int32(0)
-    abi.check(lib, lib.shm_integrator_render(b"path", C.byref(sc.desc), 0, depth, 0, spp, seed, 0, 0, film.ctypes.data_as(C.c_void_p),
+    abi.check(lib, lib.shm_integrator_render(b"path", C.byref(sc.desc), 0, depth, 0, 1, 1, spp, seed, 0, 0, film.ctypes.data_as(C.c_void_p),
                                              C.byref(st), C.byref(waves)), "shm_integrator_render")
     fo, so = oracle_py.Oracle(sc.desc).render(render.make_params(seed=seed, spp=spp, max_depth=depth), n_threads=os.cpu_count() or 1)
     assert np.array_equal(film, fo)
@@ -254,3 +254,28 @@ def test_integrator_mirror_parity(env):
 def scn_wave_schedule(spp):
     from shimmer_amd.scene import wave_schedule
     return wave_schedule(spp)
+
+
+@pytest.mark.parametrize("sample_lights,sample_bsdf", [(True, True), (True, False), (False, True), (False, False)])
+def test_simple_path_integrator_parity(env, sample_lights, sample_bsdf):
+    """SimplePathIntegrator (integrator.rs:573-733; create_integrator("simplepath")): every combination of its two switches,
+    on a random scene (all shape / material / light kinds, including the uniform infinite light sampled with
+    allow_incomplete_pdf = false) — the oracle's film and counters bit for bit, through the render params and through the
+    C++ integrator mirror."""
+    import ctypes as C
+    from shimmer_amd import abi
+    lib, oracle_py, render, scenes = env
+    sc = scenes.random_scene(lib, 1)  # seed 1: thin-lens camera + the sky light
+    p = render.make_params(seed=8, spp=6, max_depth=4, integrator="simplepath", sample_lights=sample_lights, sample_bsdf=sample_bsdf)
+    gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+    fg, sg = gpu.render(p)
+    fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
+    assert np.array_equal(fg, fo) and np.isfinite(render.film_to_rgb(fg)).all()
+    for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+        assert sg[k] == so[k], k
+    assert (sg["rays_any"] > 0) == sample_lights
+    film = np.zeros_like(fo)
+    abi.check(lib, lib.shm_integrator_render(b"simplepath", C.byref(sc.desc), 0, 4, 0, int(sample_lights), int(sample_bsdf), 6, 8, 0, 0,
+                                             film.ctypes.data_as(C.c_void_p), None, None), "shm_integrator_render")
+    assert np.array_equal(film, fo)
+    gpu.close(); orc.close()

@@ -101,3 +101,30 @@ def test_dispersion_terminates_secondary_wavelengths(lib):
     assert np.isfinite(rgb).all() and (rgb >= 0).all() and rgb.mean() > 0.01
     assert st["rays_closest"] / st["paths"] > 1.5
     o.close()
+
+
+def test_simple_path_variants_agree_with_the_path_integrator(lib):
+    """SimplePathIntegrator's purpose in the reference (integrator.rs:565-572): with enough samples, sampling lights or not and
+    sampling the BSDF or uniformly must all converge to the same image as the PathIntegrator. Diffuse Cornell box, region
+    means of independent renders within the Monte Carlo noise. (The uniform-direction variants cannot be held to that: the
+    reference's uniform_hemisphere_pdf is 1/4pi — quirk 2, kept — which doubles their throughput per bounce on one-sided
+    surfaces; they are only required to be finite and brighter than the BSDF-sampled ones.)"""
+    sc = scenes.cornell_box(lib, 24, 24)
+    o = oracle_py.Oracle(sc.desc)
+    regions = [(slice(16, 23), slice(4, 20)), (slice(2, 8), slice(4, 20))]
+
+    def means(**kw):
+        film, _ = o.render(render.make_params(seed=3, max_depth=3, **kw), n_threads=8)
+        rgb = render.film_to_rgb(film)
+        assert np.isfinite(rgb).all()
+        return np.array([rgb[r].mean() for r in regions])
+
+    ref = means(spp=256)
+    nee_bsdf = means(spp=256, integrator="simplepath", sample_lights=True, sample_bsdf=True)
+    hit_bsdf = means(spp=1024, integrator="simplepath", sample_lights=False, sample_bsdf=True)
+    assert np.allclose(nee_bsdf, ref, rtol=0.05)
+    assert np.allclose(hit_bsdf, ref, rtol=0.12)  # no light sampling: the 0.6 x 0.6 emitter is only found by chance
+    nee_uni = means(spp=512, integrator="simplepath", sample_lights=True, sample_bsdf=False)
+    hit_uni = means(spp=2048, integrator="simplepath", sample_lights=False, sample_bsdf=False)
+    assert np.all(nee_uni > nee_bsdf) and np.all(hit_uni > hit_bsdf)
+    o.close()
