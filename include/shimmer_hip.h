@@ -251,7 +251,8 @@ typedef struct ShmRenderParams {
 } ShmRenderParams;
 enum {
     SHM_INTEGRATOR_PATH = 0,        /* PathIntegrator,       integrator.rs:748-963 */
-    SHM_INTEGRATOR_SIMPLE_PATH = 1  /* SimplePathIntegrator, integrator.rs:573-733 */
+    SHM_INTEGRATOR_SIMPLE_PATH = 1, /* SimplePathIntegrator, integrator.rs:573-733 */
+    SHM_INTEGRATOR_RANDOM_WALK = 2  /* RandomWalkIntegrator, integrator.rs:445-563: le + f cos Li / (1/4pi), folded innermost-first */
 };
 
 /* Tile (tile.rs:5-7): Bounds2i, max exclusive. */
@@ -361,7 +362,8 @@ SHM_API int shm_camera_orthographic(const float world_from_camera[16], const int
                             float focal_distance, ShmCamera* out, float render_from_world_out[16]);
 /* C entry to the C++ host mirror of the reference's integrator interface (shimmer_amd/csrc/host/integrator.hpp):
  * create_integrator(name, {maxdepth, regularize, lightsampler "uniform", spp}, scene)->render(options), integrator.rs:16-42,
- * 52-54, 120-210, 226-322. `name`: "path" or "simplepath" (sample_lights / sample_bsdf are its "samplelights" / "samplebsdf");
+ * 52-54, 120-210, 226-322. `name`: "path", "simplepath" (sample_lights / sample_bsdf are its "samplelights" / "samplebsdf") or
+ * "randomwalk";
  * anything else fails the way the reference panics ("Unknown integrator ..."); the message
  * is available through shm_last_error(). film_out: pixel_bounds-sized, overwritten; n_waves_out: spp-waves rendered. */
 SHM_API int shm_integrator_render(const char* name, const ShmSceneDesc* scene, int device, int32_t max_depth, int regularize,

@@ -320,6 +320,34 @@ Spec li_simple_path(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng,
     return l;
 }
 
+// RandomWalkIntegrator::li_random_walk, integrator.rs:491-563 (recursive, as there: the innermost term is evaluated first)
+Spec li_random_walk(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng, int depth, int max_depth, Counters& c) {
+    Hit hit;
+    if (!bvh_intersect(sv, ray.o, ray.d, infinity(), hit, c)) {
+        Spec le = spec_const(0.0f);
+        for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
+            const ShmLight& light = sv.lights[sv.infinite_lights[k]];
+            le = le + light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
+        }
+        return le;
+    }
+    SurfaceInteraction si = hit_interaction(sv, hit, -ray.d);
+    const ShmPrimitive& prim = sv.primitives[hit.prim];
+    V3 wo = -ray.d;
+    Spec le = (prim.area_light >= 0) ? area_light_l(sv, sv.lights[prim.area_light], si.n, wo, lambda) : spec_const(0.0f);
+    if (depth == max_depth) return le;
+    BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+    V2 u = sampler_get_2d(rng);
+    V3 wp = sample_uniform_sphere(u);
+    Spec f = bsdf_f(bsdf, wo, wp);
+    if (is_zero(f)) return le;
+    Spec fcos = f * abs_dot(wp, si.shading.n);
+    Ray next;
+    next.o = offset_ray_origin(si.pi, si.n, wp);
+    next.d = wp;
+    return le + fcos * li_random_walk(sv, next, lambda, rng, depth + 1, max_depth, c) / (1.0f / (4.0f * PI_F));
+}
+
 struct Oracle {
     shm_host::FlatScene flat;
     SceneView sv;
@@ -396,7 +424,9 @@ int orc_render_wave(OrcScene* s, const ShmRenderParams* params, const ShmTile* t
                         Float weight;
                         Ray ray = generate_camera_ray(sv, x, y, rng, params->disable_wavelength_jitter != 0,
                                                       params->disable_pixel_jitter != 0, lambda, weight);
-                        Spec L = spec_const(1.0f) * ((params->integrator == SHM_INTEGRATOR_SIMPLE_PATH)
+                        Spec L = spec_const(1.0f) * ((params->integrator == SHM_INTEGRATOR_RANDOM_WALK)
+                                                         ? li_random_walk(sv, ray, lambda, rng, 0, params->max_depth, c)
+                                                         : (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH)
                                                          ? li_simple_path(sv, ray, lambda, rng, params->max_depth, params->sample_lights != 0, params->sample_bsdf != 0, c)
                                                          : li(sv, ray, lambda, rng, params->max_depth, params->regularize != 0, c));  // camera_ray.weight * li
                         c.paths++;

@@ -19,7 +19,7 @@ SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATER
 SHM_MATERIAL_COATED_DIFFUSE, SHM_MATERIAL_COATED_CONDUCTOR, SHM_MATERIAL_MIX = 4, 5, 6
 SHM_LIGHT_POINT, SHM_LIGHT_DIFFUSE_AREA, SHM_LIGHT_UNIFORM_INFINITE = 0, 1, 2
 SHM_CAMERA_PERSPECTIVE, SHM_CAMERA_ORTHOGRAPHIC = 0, 1
-SHM_INTEGRATOR_PATH, SHM_INTEGRATOR_SIMPLE_PATH = 0, 1
+SHM_INTEGRATOR_PATH, SHM_INTEGRATOR_SIMPLE_PATH, SHM_INTEGRATOR_RANDOM_WALK = 0, 1, 2
 
 c_float_p = C.POINTER(C.c_float)
 c_u32_p = C.POINTER(C.c_uint32)

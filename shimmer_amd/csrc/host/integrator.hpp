@@ -134,14 +134,14 @@ private:
     int32_t width_ = 0, height_ = 0, waves_ = 0;
 };
 
-// integrator.rs:16-42. "randomwalk" exists in the reference but is outside this backend's contract (its recursive estimator
-// le + f cos Li / pdf has to be folded backwards along the path); anything else is the reference's "Unknown integrator" panic.
+// integrator.rs:16-42: all three names of the reference; anything else is its "Unknown integrator" panic.
 inline std::unique_ptr<Integrator> create_integrator(const std::string& name, const PathIntegratorParameters& parameters,
                                                      const ShmSceneDesc& scene, int device = 0) {
     if (name == "path") return std::make_unique<WavefrontPathIntegrator>(scene, parameters, device);
     // ImageTileIntegrator::create_simple_path_integrator (integrator.rs:120-147): the same tile / wave driver around SimplePathIntegrator::li
     if (name == "simplepath") return std::make_unique<WavefrontPathIntegrator>(scene, parameters, device, (uint8_t)SHM_INTEGRATOR_SIMPLE_PATH);
-    if (name == "randomwalk") throw IntegratorError("integrator " + name + " is not provided by the wavefront backend");
+    // ImageTileIntegrator::create_random_walk_integrator (integrator.rs:149-175)
+    if (name == "randomwalk") return std::make_unique<WavefrontPathIntegrator>(scene, parameters, device, (uint8_t)SHM_INTEGRATOR_RANDOM_WALK);
     throw IntegratorError("Unknown integrator " + name);
 }
 

@@ -812,6 +812,112 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(Scen
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// RandomWalkIntegrator (integrator.rs:445-563). Its estimator L_k = le_k + f_k cos_k L_{k+1} / (1/4pi) is recursive and
+// evaluated innermost-first there; a wavefront walks the path forwards, so each vertex records (le_k, f_k cos_k) in
+// rw[depth][path] and k_fold_randomwalk evaluates the recursion backwards from the terminal vertex, in the reference's
+// operation order. No light sampling, no shadow rays.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_randomwalk(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur,
+                                                                               uint32_t* __restrict__ q_next, QueueState* qs, int cur,
+                                                                               ShmRenderParams params, float4* __restrict__ rw, uint32_t capacity) {
+    const uint32_t n = qs->n_active[cur];
+    __shared__ uint32_t s_next[SHADE_CHUNK];
+    __shared__ uint32_t s_cnt, s_base;
+    for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
+      if (threadIdx.x == 0) s_cnt = 0;
+      __syncthreads();
+      for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+        const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
+        bool push_next = false;
+        uint32_t path = 0;
+        if (i < n) {
+            path = q_cur[i];
+            const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
+            float4 h0 = hp[0], h1 = hp[1];
+            Hit hit;
+            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y;
+            const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
+            float4 r0 = rp[0], r1 = rp[1];
+            V3 ray_d = v3(r0.w, r1.x, r1.y);
+            Wavelengths lambda;
+            float4 pdf_in;
+            {
+                float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                pdf_in = b;
+                lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
+                lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
+            }
+            const int depth = (int)(pa.flags[path] & 0xffu);
+            float4* rec = rw + (size_t)(2 * depth) * capacity + path;  // le at 2*depth, f cos at 2*depth + 1
+            Spec le = spec_const(0.0f);
+            if (hit.prim < 0) {
+                for (uint32_t li = 0; li < sv.n_infinite_lights; ++li) {
+                    const ShmLight& light = sv.lights[sv.infinite_lights[li]];
+                    le = le + light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
+                }
+                rec[0] = st_spec(le);  // terminal vertex: flags keeps this depth
+            } else {
+                SurfaceInteraction si = hit_interaction<false>(sv, hit, -ray_d);
+                const ShmPrimitive prim = sv.primitives[hit.prim];
+                V3 wo = -ray_d;
+                if (prim.area_light >= 0) le = area_light_l(sv, sv.lights[prim.area_light], si.n, wo, lambda);
+                rec[0] = st_spec(le);
+                if (depth != params.max_depth) {
+                    BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+                    uint32_t pix = pa.pixel[path];
+                    uint2 rs = pa.rng[path];
+                    Rng rng;
+                    rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+                    {
+                        uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
+                        h = mix_bits(h ^ (params.seed + 0x9e3779b97f4a7c15ULL));
+                        rng.inc = (h << 1u) | 1u;
+                    }
+                    V3 wp = sample_uniform_sphere(sampler_get_2d(rng));
+                    Spec f = bsdf_f(bsdf, wo, wp);
+                    if (!is_zero(f)) {
+                        rec[capacity] = st_spec(f * abs_dot(wp, si.shading.n));
+                        V3 no = offset_ray_origin(si.pi, si.n, wp);
+                        ShmRay nr;
+                        nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z;
+                        nr.d[0] = wp.x; nr.d[1] = wp.y; nr.d[2] = wp.z;
+                        nr.t_max = infinity();
+                        nr.pad = 0.0f;
+                        pa.ray[path] = nr;
+                        pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                        pa.flags[path] = (uint32_t)(depth + 1);
+                        push_next = true;
+                    }
+                    if (lambda.pdf[1] != pdf_in.y || lambda.pdf[2] != pdf_in.z || lambda.pdf[3] != pdf_in.w || lambda.pdf[0] != pdf_in.x)
+                        pa.lambda_pdf[path] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
+                }
+            }
+        }
+        uint32_t s1 = queue_push_slot(&s_cnt, push_next);
+        if (push_next) s_next[s1] = path;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&qs->n_active[cur ^ 1], s_cnt) : 0u;
+      __syncthreads();
+      for (uint32_t j = threadIdx.x; j < s_cnt; j += SHADE2_BLOCK) q_next[s_base + j] = s_next[j];
+      __syncthreads();
+    }
+}
+// L = le_T; L = le_k + f_k cos_k * L / (1 / (4 pi)) for k = T-1 .. 0 (integrator.rs:549-562)
+__global__ void __launch_bounds__(SHADE_BLOCK) k_fold_randomwalk(PathArrays pa, const float4* __restrict__ rw, uint32_t capacity, uint32_t total) {
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= total) return;
+    int t = (int)(pa.flags[slot] & 0xffu);
+    Spec l = ld_spec(rw[(size_t)(2 * t) * capacity + slot]);
+    for (int k = t - 1; k >= 0; --k) {
+        Spec le = ld_spec(rw[(size_t)(2 * k) * capacity + slot]);
+        Spec fcos = ld_spec(rw[(size_t)(2 * k + 1) * capacity + slot]);
+        l = le + fcos * l / (1.0f / (4.0f * PI_F));
+    }
+    pa.L[slot] = st_spec(l);
+}
+
 // Between bounces: recycle the counters (1 thread).
 __global__ void k_next_bounce(QueueState* qs, int cur, int next_shadow_parity) {
     qs->n_active[cur] = 0;
@@ -883,6 +989,8 @@ struct ShmScene {
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
     int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
     uint32_t* d_spill3 = nullptr;
+    float4* d_rw = nullptr;          // RandomWalk: (le, f cos) per depth per path, 2 * (max_depth + 1) * capacity float4
+    size_t rw_floats4 = 0;
     uint32_t* d_spill3_any = nullptr;  // the any-hit kernel may run concurrently with the closest-hit one (second stream)
     hipStream_t stream2 = nullptr;
     uint64_t overlap_paths = 96ull << 20;  // batches below this many paths run K3(b) beside K2(b+1) (SHM_OVERLAP_PATHS; 0 = never)
@@ -1016,6 +1124,7 @@ void shm_scene_destroy(ShmScene* s) {
     hipSetDevice(s->device);
     for (void* p : s->allocs) hipFree(p);
     for (void* p : s->ws_allocs) hipFree(p);
+    if (s->d_rw) hipFree(s->d_rw);
     for (hipEvent_t e : s->events) hipEventDestroy(e);
     if (s->stream2) hipStreamDestroy(s->stream2);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -1126,7 +1235,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     if (!s || !params || !tiles || n_tiles == 0 || sample_end <= sample_begin) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
     if (params->force_diffuse) { g_err = "force_diffuse is not supported"; return SHM_ERR_UNSUPPORTED; }
     if (params->max_depth < 0 || params->max_depth > 254) { g_err = "max_depth out of range"; return SHM_ERR_INVALID_ARGUMENT; }
-    if (params->integrator > SHM_INTEGRATOR_SIMPLE_PATH) { g_err = "unknown integrator"; return SHM_ERR_UNSUPPORTED; }
+    if (params->integrator > SHM_INTEGRATOR_RANDOM_WALK) { g_err = "unknown integrator"; return SHM_ERR_UNSUPPORTED; }
     HIP_TRY(hipSetDevice(s->device));
     int rc;
     const int32_t* pb = s->flat.film.pixel_bounds;
@@ -1159,8 +1268,21 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     hipLaunchKernelGGL(k_expand_tiles, dim3((n_tiles + 255) / 256), dim3(256), 0, s->stream, s->d_tiles, s->d_tile_offset, n_tiles, s->d_pixels);
 
     const int n_samples = sample_end - sample_begin;
-    if ((rc = ensure_workspace(s, n_pixels * (uint64_t)n_samples)) != SHM_OK) return rc;
-    uint32_t pix_per_batch = s->capacity / (uint32_t)n_samples;
+    const bool random_walk = params->integrator == SHM_INTEGRATOR_RANDOM_WALK;
+    // (the random walk keeps 32 B per depth per path beside the path state: its batches are capped at 16 Mi paths)
+    if ((rc = ensure_workspace(s, random_walk ? std::min<uint64_t>(n_pixels * (uint64_t)n_samples, 1ull << 24) : n_pixels * (uint64_t)n_samples)) != SHM_OK) return rc;
+    const uint32_t cap_eff = random_walk ? std::min<uint32_t>(s->capacity, 1u << 24) : s->capacity;  // paths per batch
+    if (random_walk) {
+        size_t need = (size_t)2 * (size_t)(params->max_depth + 1) * (size_t)cap_eff;
+        if (s->rw_floats4 < need) {
+            if (s->d_rw) hipFree(s->d_rw);
+            s->d_rw = nullptr;
+            s->rw_floats4 = 0;
+            if (hipMalloc((void**)&s->d_rw, need * sizeof(float4)) != hipSuccess) { g_err = "hipMalloc of the random-walk records failed"; return SHM_ERR_OUT_OF_MEMORY; }
+            s->rw_floats4 = need;
+        }
+    }
+    uint32_t pix_per_batch = cap_eff / (uint32_t)n_samples;
     if (pix_per_batch == 0) { g_err = "spp-wave larger than the path workspace"; return SHM_ERR_INVALID_ARGUMENT; }
     if (pix_per_batch > 64) pix_per_batch &= ~63u;  // whole 8x8 tiles per wavefront
     EventPool ev{s};
@@ -1200,7 +1322,10 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                                        s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, s->d_counters, sh);
                 };
                 const bool tri_only = !s->flat.has_spheres;
-                if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH)
+                if (random_walk)
+                    hipLaunchKernelGGL(k_shade_randomwalk, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
+                                       s->d_q_active[cur ^ 1], s->d_qs, cur, *params, s->d_rw, cap_eff);
+                else if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH)
                     hipLaunchKernelGGL(k_shade_simple, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
                                        s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, sh);
                 else if (s->flat.has_layered) { if (tri_only) launch_shade(k_shade<true, true>); else launch_shade(k_shade<true, false>); }
@@ -1208,7 +1333,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 hipEventRecord(s1, s->stream);
                 ev_shade.push_back({s0, s1});
             }
-            if (bounce < params->max_depth) {
+            if (bounce < params->max_depth && !random_walk) {
                 hipEvent_t c = ev.get(), d = ev.get();
                 if (overlap) {
                     hipEvent_t shaded = ev.get();
@@ -1232,6 +1357,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
             cur ^= 1;
         }
         if (overlap && k3_done) hipStreamWaitEvent(s->stream, k3_done, 0);  // the film reads L
+        if (random_walk)
+            hipLaunchKernelGGL(k_fold_randomwalk, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->pa, s->d_rw, cap_eff, total);
         hipLaunchKernelGGL(k_film, dim3((n_pix + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix, n_samples,
                            s->d_film, s->d_counters, s->pix_group);
     }

@@ -279,3 +279,26 @@ def test_simple_path_integrator_parity(env, sample_lights, sample_bsdf):
                                              film.ctypes.data_as(C.c_void_p), None, None), "shm_integrator_render")
     assert np.array_equal(film, fo)
     gpu.close(); orc.close()
+
+
+def test_random_walk_integrator_parity(env):
+    """RandomWalkIntegrator through create_integrator("randomwalk"): the GPU records (le, f cos) per depth and folds the recursion
+    backwards; film sums and counters must equal the oracle's literal recursion bit for bit (random scene with the sky light,
+    and the Cornell box at a depth where most walks reach the limit)."""
+    import ctypes as C
+    from shimmer_amd import abi
+    lib, oracle_py, render, scenes = env
+    for sc, spp, depth in ((scenes.random_scene(lib, 1), 6, 5), (scenes.cornell_box(lib, 48, 40), 9, 7)):
+        p = render.make_params(seed=4, spp=spp, max_depth=depth, integrator="randomwalk")
+        gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+        fg, sg = gpu.render(p)
+        fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
+        assert np.array_equal(fg, fo) and np.isfinite(render.film_to_rgb(fg)).all() and render.film_to_rgb(fg).max() > 0
+        for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest"):
+            assert sg[k] == so[k], k
+        assert sg["rays_any"] == 0
+        film = np.zeros_like(fo)
+        abi.check(lib, lib.shm_integrator_render(b"randomwalk", C.byref(sc.desc), 0, depth, 0, 1, 1, spp, 4, 0, 0,
+                                                 film.ctypes.data_as(C.c_void_p), None, None), "shm_integrator_render")
+        assert np.array_equal(film, fo)
+        gpu.close(); orc.close()

@@ -253,15 +253,14 @@ def test_film_get_image(lib, tmp_path):
 
 def test_integrator_mirror_errors(lib):
     """create_integrator (integrator.rs:16-42) through the C++ host mirror: an unknown name is the reference's
-    "Unknown integrator" panic turned into an error code + message; the other two reference integrators are named as not
-    provided; without a GPU "path" fails with the no-device error instead of falling back."""
+    "Unknown integrator" panic turned into an error code + message; without a GPU the three integrators the reference knows
+    fail with the no-device error instead of falling back."""
     sc = scenes.cornell_box(lib, 16, 16)
     film = np.zeros((16, 16), dtype=render.FILM_DTYPE)
     args = (C.byref(sc.desc), 0, 5, 0, 1, 1, 2, 0, 0, 0, film.ctypes.data_as(C.c_void_p), None, None)
     assert lib.shm_integrator_render(b"bdpt", *args) == -2 and b"Unknown integrator bdpt" in lib.shm_last_error()
-    assert lib.shm_integrator_render(b"randomwalk", *args) == -2 and b"not provided" in lib.shm_last_error()
     if lib.shm_device_count() == 0:
-        for name in (b"path", b"simplepath"):
+        for name in (b"path", b"simplepath", b"randomwalk"):
             assert lib.shm_integrator_render(name, *args) == -2 and b"no CPU fallback" in lib.shm_last_error()
 
 

@@ -128,3 +128,17 @@ def test_simple_path_variants_agree_with_the_path_integrator(lib):
     hit_uni = means(spp=2048, integrator="simplepath", sample_lights=False, sample_bsdf=False)
     assert np.all(nee_uni > nee_bsdf) and np.all(hit_uni > hit_bsdf)
     o.close()
+
+
+def test_random_walk_integrator_converges_to_the_path_integrator(lib):
+    """RandomWalkIntegrator (integrator.rs:445-563): uniform directions over the whole sphere with the right pdf (1/4pi), light
+    found only by hitting it — an unbiased, very noisy estimator of the same image. Whole-image mean of a small Cornell box at
+    many samples against the path integrator."""
+    sc = scenes.cornell_box(lib, 16, 16)
+    o = oracle_py.Oracle(sc.desc)
+    ref, _ = o.render(render.make_params(seed=1, spp=256, max_depth=3), n_threads=8)
+    rw, st = o.render(render.make_params(seed=1, spp=8192, max_depth=3, integrator="randomwalk"), n_threads=8)
+    a, b = render.film_to_rgb(ref), render.film_to_rgb(rw)
+    assert np.isfinite(b).all() and st["rays_any"] == 0
+    assert b[4:, :].mean() == pytest.approx(a[4:, :].mean(), rel=0.15)  # (rows 0-3 look at the emitter itself: dominated by le_0, trivially equal)
+    o.close()
