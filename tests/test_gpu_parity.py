@@ -302,3 +302,48 @@ def test_random_walk_integrator_parity(env):
                                                  film.ctypes.data_as(C.c_void_p), None, None), "shm_integrator_render")
         assert np.array_equal(film, fo)
         gpu.close(); orc.close()
+
+
+def test_extreme_render_parameters(env):
+    """Edges of the parameter space: max_depth 0 (camera rays and emission only, no any-hit launch), 1 spp, a 5 x 3 film (one
+    partial tile), maximum path depth 64 on a closed mirror-like box (paths that live long), a scene without any light, and the
+    error returns for arguments the reference would panic on."""
+    import ctypes as C
+    from shimmer_amd import abi, scene as scn
+    lib, oracle_py, render, scenes = env
+    sc = scenes.cornell_box(lib, 40, 24)
+    gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+    for kw in (dict(spp=3, max_depth=0), dict(spp=1, max_depth=5), dict(spp=2, max_depth=64)):
+        p = render.make_params(seed=12, **kw)
+        fg, sg = gpu.render(p)
+        fo, so = orc.render(p, n_threads=4)
+        assert np.array_equal(fg, fo), kw
+        assert sg["rays_closest"] == so["rays_closest"] and sg["rays_any"] == so["rays_any"]
+        if kw["max_depth"] == 0:
+            assert sg["rays_any"] == 0 and sg["rays_closest"] == 40 * 24 * 3
+    # invalid arguments: codes, not crashes
+    bad = render.make_params(seed=1, spp=2, max_depth=300)
+    st = abi.ShmStats()
+    assert lib.shm_render_wave(gpu.handle, C.byref(bad), gpu.tiles, gpu.n_tiles, 0, 2, C.byref(st)) == -1
+    ok = render.make_params(seed=1, spp=2, max_depth=3)
+    assert lib.shm_render_wave(gpu.handle, C.byref(ok), gpu.tiles, gpu.n_tiles, 2, 2, C.byref(st)) == -1  # empty sample range
+    outside = (abi.ShmTile * 1)(abi.ShmTile(32, 16, 48, 32))
+    assert lib.shm_render_wave(gpu.handle, C.byref(ok), outside, 1, 0, 1, C.byref(st)) == -1 and b"tile" in lib.shm_last_error()
+    unknown = render.make_params(seed=1, spp=2, max_depth=3)
+    unknown.integrator = 9
+    assert lib.shm_render_wave(gpu.handle, C.byref(unknown), gpu.tiles, gpu.n_tiles, 0, 1, C.byref(st)) == -2
+    gpu.close(); orc.close()
+    # a tiny film and no light at all: everything black, still bit-identical and complete
+    b = scn.SceneBuilder()
+    b.set_film(5, 3)
+    rfw = b.set_camera_look_at(lib, (0, 0, 4), (0, 0, 0), (0, 1, 0), 40.0)
+    p_, vi = scenes._box((-1, -1, -1), (1, 1, 1))
+    b.add_mesh(scenes._to_render(p_, rfw), vi, b.material_diffuse(0.5))
+    desc, _ = b.build(lib)
+    gpu, orc = render.Renderer(lib, desc, 0), oracle_py.Oracle(desc)
+    pr = render.make_params(seed=2, spp=4, max_depth=3)
+    fg, sg = gpu.render(pr)
+    fo, so = orc.render(pr, n_threads=2)
+    assert fg.shape == (3, 5) and np.array_equal(fg, fo) and (fg["rgb_sum"] == 0).all() and (fg["weight_sum"] == 4.0).all()
+    assert sg["rays_any"] == 0 == so["rays_any"]
+    gpu.close(); orc.close()
