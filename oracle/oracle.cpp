@@ -587,6 +587,7 @@ void orc_fn_sample_henyey_greenstein(const float* wo, float g, const float* u, f
 float orc_fn_sample_exponential(float x, float a) { return sample_exponential(x, a); }
 void orc_fn_sample_cosine_hemisphere(const float* u, float* out3) { V3 r = sample_cosine_hemisphere(v2(u[0], u[1])); out3[0] = r.x; out3[1] = r.y; out3[2] = r.z; }
 float orc_fn_power_heuristic(float f, float g) { return power_heuristic(1, f, 1, g); }
+int orc_fn_sample_discrete(const float* weights, int n, float u, float* pmf, float* u_remapped) { return sample_discrete(weights, n, u, pmf, u_remapped); }
 float orc_fn_sampler_stream(int px, int py, int sample_index, uint64_t seed, int n, float* out) {
     Rng r = sampler_start_pixel_sample(px, py, sample_index, seed);
     for (int i = 0; i < n; ++i) out[i] = sampler_get_1d(r);

@@ -80,6 +80,7 @@ def load():
     lib.orc_fn_sample_spherical_rectangle.restype, lib.orc_fn_sample_spherical_rectangle.argtypes = None, [FP, FP, FP, FP, FP, FP]
     lib.orc_fn_invert_spherical_rectangle_sample.restype, lib.orc_fn_invert_spherical_rectangle_sample.argtypes = None, [FP, FP, FP, FP, FP, FP]
     lib.orc_fn_quadratic.restype, lib.orc_fn_quadratic.argtypes = C.c_int, [F, F, F, FP]
+    lib.orc_fn_sample_discrete.restype, lib.orc_fn_sample_discrete.argtypes = C.c_int, [FP, C.c_int, F, FP, FP]
     lib.orc_fn_sample_cosine_hemisphere.restype, lib.orc_fn_sample_cosine_hemisphere.argtypes = None, [FP, FP]
     lib.orc_fn_sampler_stream.restype, lib.orc_fn_sampler_stream.argtypes = F, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, FP]
     lib.orc_fn_offset_ray_origin.restype, lib.orc_fn_offset_ray_origin.argtypes = None, [FP, FP, FP, FP, FP]

@@ -97,6 +97,27 @@ SHM_HD V2 sampler_get_2d(Rng& r) {  // sampler.rs:127-131: x drawn first
     return v2(x, y);
 }
 
+// sampling.rs:201-244 (not reached by the three integrators — the uniform light sampler picks by index — but part of the
+// reference's tested sampling surface: sampling.rs:806-836). Returns the offset or -1 for an empty weight list.
+SHM_HD int sample_discrete(const Float* weights, int n, Float u, Float* pmf, Float* u_remapped) {
+    if (n == 0) {
+        if (pmf) *pmf = 0.0f;
+        return -1;
+    }
+    Float sum_weights = 0.0f;
+    for (int i = 0; i < n; ++i) sum_weights += weights[i];
+    Float up = u * sum_weights;
+    if (up == sum_weights) up = next_float_down(up);
+    int offset = 0;
+    Float sum = 0.0f;
+    while (sum + weights[offset] <= up) {
+        sum += weights[offset];
+        offset += 1;
+    }
+    if (pmf) *pmf = weights[offset] / sum_weights;
+    if (u_remapped) *u_remapped = min((up - sum) / weights[offset], 1.0f - 1.1920929e-7f);
+    return offset;
+}
 // sampling.rs:187-194
 SHM_HD Float power_heuristic(int nf, Float f_pdf, int ng, Float g_pdf) {
     Float f = (Float)nf * f_pdf;

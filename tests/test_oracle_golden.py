@@ -146,6 +146,16 @@ def test_blackbody_known_answers(golden):
     assert d.shape == (471,) and abs(d.max() - 1.0) < 2e-3  # normalised at Wien's peak (446 nm)
 
 
+def test_sample_discrete_reference_known_answers(orc):
+    """sampling.rs:806-836 (sample_discrete_basics), transcribed: the reference's own assertions."""
+    pdf, ur = C.c_float(0.0), C.c_float(-1.0)
+    assert orc.orc_fn_sample_discrete(fa(5.0), 1, 0.251, C.byref(pdf), None) == 0 and pdf.value == 1.0
+    assert orc.orc_fn_sample_discrete(fa(0.5, 0.5), 2, 0.0, C.byref(pdf), None) == 0 and pdf.value == 0.5
+    assert orc.orc_fn_sample_discrete(fa(0.5, 0.5), 2, 0.499, C.byref(pdf), None) == 0 and pdf.value == 0.5
+    assert orc.orc_fn_sample_discrete(fa(0.5, 0.5), 2, 0.5, C.byref(pdf), C.byref(ur)) == 1 and pdf.value == 0.5 and ur.value == 0.0
+    assert orc.orc_fn_sample_discrete(fa(1.0), 0, 0.3, C.byref(pdf), None) == -1 and pdf.value == 0.0  # empty list -> None, pmf 0
+
+
 def test_next_float(orc, golden):
     """float.rs:172-211."""
     assert orc.orc_fn_next_float_up(-0.0) > 0.0
