@@ -654,6 +654,21 @@ void orc_fn_rotate_from_to(const float* from, const float* to, const float* v, f
     V3 r = rot3_apply(rotate_from_to(ld3(from), ld3(to)), ld3(v));
     out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
 }
+// Interval arithmetic (interval.rs:366-414): op 0 = a * b, 1 = a / b, 2 = a + b, 3 = a - b, 4 = sqr(a), 5 = sqrt(a); out = low, high
+void orc_fn_interval_op(int op, float alo, float ahi, float blo, float bhi, float* out2) {
+    Interval a = iv_new(alo, ahi), b = iv_new(blo, bhi), r = a;
+    switch (op) {
+        case 0: r = a * b; break;
+        case 1: r = a / b; break;
+        case 2: r = a + b; break;
+        case 3: r = a - b; break;
+        case 4: r = iv_sqr(a); break;
+        default: r = iv_sqrt(a); break;
+    }
+    out2[0] = r.low; out2[1] = r.high;
+}
+// SquareMatrix<3>::determinant (square_matrix.rs:281-292) as the bilinear patch uses it; m = 9 floats, row-major
+float orc_fn_det3(const float* m) { return det3(ld3(m), ld3(m + 3), ld3(m + 6)); }
 void orc_fn_blp_info(const float* pts, float* out2) {
     PatchData pd = make_patch(pts, 0);
     out2[0] = pd.is_rect ? 1.0f : 0.0f;

@@ -71,6 +71,8 @@ def load():
     lib.orc_fn_blp_info.restype, lib.orc_fn_blp_info.argtypes = None, [FP, FP]
     lib.orc_fn_blp_interaction_attr.restype, lib.orc_fn_blp_interaction_attr.argtypes = None, [FP, C.c_int, FP, FP, F, F, FP, FP]
     lib.orc_fn_invert_bilinear.restype, lib.orc_fn_invert_bilinear.argtypes = None, [FP, FP, FP]
+    lib.orc_fn_interval_op.restype, lib.orc_fn_interval_op.argtypes = None, [C.c_int, F, F, F, F, FP]
+    lib.orc_fn_det3.restype, lib.orc_fn_det3.argtypes = F, [FP]
     lib.orc_fn_rotate_from_to.restype, lib.orc_fn_rotate_from_to.argtypes = None, [FP, FP, FP, FP]
     lib.orc_fn_blp_intersect.restype, lib.orc_fn_blp_intersect.argtypes = C.c_int, [FP, FP, FP, F, FP]
     lib.orc_fn_blp_interaction.restype, lib.orc_fn_blp_interaction.argtypes = None, [FP, C.c_int, F, F, FP, FP]

@@ -156,6 +156,81 @@ def test_sample_discrete_reference_known_answers(orc):
     assert orc.orc_fn_sample_discrete(fa(1.0), 0, 0.3, C.byref(pdf), None) == -1 and pdf.value == 0.0  # empty list -> None, pmf 0
 
 
+def test_math_reference_known_answers(orc):
+    """math.rs:549-570 (lerp, test_difference_of_products) and square_matrix.rs:623-650 (determinants, the 3x3 cases the
+    bilinear patch's Cramer solve uses), transcribed."""
+    assert orc.orc_fn_difference_of_products(10.0, 10.0, 5.0, 5.0) == 75.0
+    assert orc.orc_fn_det3(fa(1, 2, 3, 4, 5, 6, 7, 8, 9)) == 0.0
+    assert orc.orc_fn_det3(fa(2, -3, 1, 2, 0, -1, 1, 4, 5)) == 49.0
+
+
+def test_interval_reference_known_answers(orc):
+    """interval.rs:534-554 (mulassign_interval, divassign_interval): assert_approx_eq in the reference (the bounds are rounded
+    outwards by one ulp), so the same tolerance here plus the outward direction."""
+    out = (C.c_float * 2)()
+    orc.orc_fn_interval_op(0, 0.0, 10.0, 1.0, 2.0, out)
+    assert out[0] <= 0.0 and out[1] >= 20.0 and abs(out[0]) < 1e-30 and ulp_diff(out[1], 20.0) <= 1
+    orc.orc_fn_interval_op(1, 1.0, 10.0, 1.0, 2.0, out)
+    assert out[0] <= 0.5 and out[1] >= 10.0 and ulp_diff(out[0], 0.5) <= 1 and ulp_diff(out[1], 10.0) <= 1
+    orc.orc_fn_interval_op(1, 1.0, 10.0, -1.0, 2.0, out)  # interval.rs:392-395: a divisor straddling zero gives (-inf, inf)
+    assert out[0] == -np.inf and out[1] == np.inf
+
+
+def test_rotate_from_to_reference_known_answers(orc):
+    """transform.rs:916-943 (rotate_from_to), transcribed: exact for the axis cases, approx for the general one."""
+    out = (C.c_float * 3)()
+    z, x, y = (0.0, 0.0, 1.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0)
+    for to in (z, x, y):
+        orc.orc_fn_rotate_from_to(fa(*z), fa(*to), fa(*z), out)
+        assert tuple(out[:]) == to
+    a = np.array([0.1, 0.2, 0.3], np.float32)
+    b = np.array([0.4, 0.5, 0.6], np.float32)
+    a, b = a / np.sqrt((a * a).sum(dtype=np.float32)), b / np.sqrt((b * b).sum(dtype=np.float32))
+    orc.orc_fn_rotate_from_to(fa(*a), fa(*b), fa(*a), out)
+    assert np.allclose(out[:], b, rtol=0, atol=2e-6)
+
+
+def test_triangle_sample_reference_properties(orc):
+    """shape/triangle.rs:809-848 (triangle_sample_with_context): 100 samples of the unit right triangle seen from (0,0,1) are
+    Some, inside [0,1]^2 and on z = 0. The reference draws u from IndependentSampler; here the oracle's own sampler stream."""
+    u = (C.c_float * 200)()
+    orc.orc_fn_sampler_stream(0, 0, 0, 0, 200, u)
+    out = (C.c_float * 7)()
+    for i in range(100):
+        ok = orc.orc_fn_triangle_sample_with_context(fa(0, 0, 0), fa(1, 0, 0), fa(0, 1, 0), fa(0, 0, 1), fa(0, 0, -1), fa(0, 0, -1),
+                                                     fa(u[2 * i], u[2 * i + 1]), out)
+        assert ok == 1
+        assert 0.0 <= out[0] <= 1.0 and 0.0 <= out[1] <= 1.0 and abs(out[2]) < 1e-7 and out[6] > 0.0
+
+
+def test_spectrum_reference_known_answers(lib):
+    """spectra/spectrum.rs:655-660 (get_constant), :764-773 (piecewise_linear_get), :776-785 (densely_sampled_basic), transcribed."""
+    sc = scenes.cornell_box(lib, 8, 8)
+    b = sc.builder
+    pw = b.spectrum_piecewise([0.0, 5.0, 10.0, 100.0], [0.0, 10.0, 20.0, 200.0])
+    ramp = b.spectrum_piecewise([360.0, 820.0], [0.0, 100.0])
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    try:
+        get = lambda s, lam: o.lib.orc_fn_spectrum_get(o.handle, C.byref(s), float(lam))
+        assert get(b.spectrum_constant(5.0), 999.0) == 5.0
+        assert [get(pw, l) for l in (2.5, 7.5, 55.0, 99999.0, 0.0)] == [5.0, 15.0, 110.0, 0.0, 0.0]
+        # DenselySampledSpectrum::new(&spectrum) samples it at every integer nm of [360, 830] (spectrum.rs:185-197)
+        dense_vals = [get(ramp, l) for l in range(360, 831)]
+    finally:
+        o.close()
+    dense = b.spectrum_dense(dense_vals)
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    try:
+        get = lambda s, lam: o.lib.orc_fn_spectrum_get(o.handle, C.byref(s), float(lam))
+        assert get(dense, 360.0) == pytest.approx(0.0, abs=1e-6)
+        assert get(dense, 820.0) == pytest.approx(100.0, rel=1e-6)
+        assert get(dense, 590.0) == pytest.approx(50.0, rel=1e-6)
+    finally:
+        o.close()
+
+
 def test_next_float(orc, golden):
     """float.rs:172-211."""
     assert orc.orc_fn_next_float_up(-0.0) > 0.0
