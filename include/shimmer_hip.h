@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SHM_ABI_VERSION 5
+#define SHM_ABI_VERSION 6
 
 /* The library is built with -fvisibility=hidden; only these entry points are exported. */
 #if defined(__GNUC__)
@@ -119,8 +119,13 @@ enum {
      * hands them over; the device evaluates RgbSigmoidPolynomial::get = s(c0 l^2 + c1 l + c2) (color.rs:333-383). */
     SHM_SPECTRUM_RGB_ALBEDO = 3,       /* RgbAlbedoSpectrum     (:498-528) */
     SHM_SPECTRUM_RGB_UNBOUNDED = 4,    /* RgbUnboundedSpectrum  (:531-565): c = scale (2 max(r,g,b)) */
-    SHM_SPECTRUM_RGB_ILLUMINANT = 5    /* RgbIlluminantSpectrum (:568-607): c = scale; offset / n / lambda_min: the colour space's
+    SHM_SPECTRUM_RGB_ILLUMINANT = 5,   /* RgbIlluminantSpectrum (:568-607): c = scale; offset / n / lambda_min: the colour space's
                                           illuminant as a densely sampled table */
+    /* ABI v6. A SpectrumImageTexture (texture.rs:689-808) bound to a material's SpectrumTexture slot (ShmMaterial a, b, c):
+     * `offset` = index into ShmSceneDesc::image_textures. Not valid for eta (a Spectrum, not a texture, in the reference) nor
+     * for lights. The device filters the MIP pyramid, looks the sigmoid coefficients up in ShmSceneDesc::color_space and
+     * evaluates the resulting Rgb{Albedo,Unbounded,Illuminant}Spectrum at the path's wavelengths. */
+    SHM_SPECTRUM_IMAGE_TEXTURE = 6
 };
 typedef struct ShmSpectrum {
     uint32_t kind;
@@ -184,6 +189,49 @@ enum {
     SHM_CAMERA_ORTHOGRAPHIC = 1  /* camera.rs:658-840: rays start at camera_from_raster(p_film) and run along +z; the reference
                                     has no depth of field for it yet ("TODO Adjust for depth-of-field here", :762) */
 };
+/* ---- image textures (ABI v6) ------------------------------------------------------------------ */
+
+/* One level of a MIPMap pyramid (Image::generate_pyramid, image.rs:699-800): `width * height * n_channels` floats at
+ * ShmSceneDesc::texel_data + texel_offset, row-major from the TOP row, channels interleaved, each value what
+ * Image::get_channel returns for that texel (image.rs:452-476: u8 through the colour encoding, f16 widened, f32 as is). */
+typedef struct ShmImageLevel {
+    int32_t width, height;
+    uint32_t texel_offset;
+    uint32_t pad;
+} ShmImageLevel;
+enum { SHM_TEXMAP_UV = 0, SHM_TEXMAP_SPHERICAL = 1, SHM_TEXMAP_CYLINDRICAL = 2, SHM_TEXMAP_PLANAR = 3 }; /* texture.rs:838-843 */
+enum { SHM_TEXFILTER_POINT = 0, SHM_TEXFILTER_BILINEAR = 1, SHM_TEXFILTER_TRILINEAR = 2, SHM_TEXFILTER_EWA = 3 }; /* mipmap.rs:334-341 */
+enum { SHM_WRAP_BLACK = 0, SHM_WRAP_CLAMP = 1, SHM_WRAP_REPEAT = 2, SHM_WRAP_OCTAHEDRAL_SPHERE = 3 };  /* image.rs:73-78 */
+enum { SHM_SPECTRUM_TYPE_ALBEDO = 0, SHM_SPECTRUM_TYPE_UNBOUNDED = 1, SHM_SPECTRUM_TYPE_ILLUMINANT = 2 };
+/* SpectrumImageTexture = ImageTextureBase {mapping, scale, invert, mipmap} + spectrum_type (texture.rs:19-26, 689-693);
+ * MIPMap {pyramid, color_space, wrap_mode, options} (mipmap.rs:8-14). */
+typedef struct ShmImageTexture {
+    uint32_t mapping;            /* SHM_TEXMAP_* */
+    float su, sv, du, dv;        /* UVMapping (texture.rs:896-905); PlanarMapping: du, dv are its ds, dt */
+    float vs[3], vt[3];          /* PlanarMapping (texture.rs:1012-1019) */
+    float texture_from_render[16]; /* Spherical / Cylindrical / Planar: the matrix m of texture_from_render, row-major */
+    uint32_t filter;             /* SHM_TEXFILTER_* ("filter", default bilinear, texture.rs:738) */
+    float max_anisotropy;        /* "maxanisotropy", default 8 */
+    uint32_t wrap;               /* SHM_WRAP_* ("wrap", default repeat) */
+    float scale;                 /* "scale", default 1 */
+    uint8_t invert;
+    uint8_t spectrum_type;       /* SHM_SPECTRUM_TYPE_* */
+    uint8_t n_channels;          /* 1 or 3 (an RGBA image hands over its RGB: texel_rgb / bilerp read channels 0..2, mipmap.rs:204-231) */
+    uint8_t has_color_space;     /* MIPMap::get_color_space().is_some(); 0: one-channel texture -> constant spectrum (texture.rs:801-805) */
+    uint32_t first_level;        /* index into ShmSceneDesc::image_levels, finest level first */
+    uint32_t n_levels;
+} ShmImageTexture;
+/* What RgbColorSpace::to_rgb_coeffs reads (colorspace.rs:95-98 -> rgb_to_spectra.rs:16-25): the rgb2spec coefficient table of
+ * the colour space's gamut (the `.spec` file the reference loads: res, scale[res], data[3][res][res][res][3]) and its
+ * illuminant (for SHM_SPECTRUM_TYPE_ILLUMINANT). One colour space per scene. */
+typedef struct ShmColorSpace {
+    uint32_t rgb2spec_res;       /* 0: no table (then no texture may have has_color_space) */
+    uint32_t pad;
+    const float* rgb2spec_scale; /* res floats */
+    const float* rgb2spec_data;  /* 3 * res^3 * 3 floats */
+    const float* illuminant;     /* DenselySampledSpectrum 360..=830, 471 floats (may be NULL without ILLUMINANT textures) */
+} ShmColorSpace;
+
 /* PerspectiveCamera / OrthographicCamera after construction (ProjectiveCameraBase, camera.rs:594-642). Matrices row-major. */
 typedef struct ShmCamera {
     float camera_from_raster[16];
@@ -195,6 +243,12 @@ typedef struct ShmCamera {
     float shutter_open, shutter_close;
     uint32_t kind;                /* SHM_CAMERA_* (ABI v4) */
     uint32_t pad;
+    /* ABI v6, read only by scenes with image textures (the ray-differential fallback Camera::approximate_dp_dxy, camera.rs:307-354):
+     * the inverse matrix of render_from_camera and the four vectors CameraBase::find_minimum_differentials leaves (camera.rs:356-440).
+     * shm_camera_perspective / shm_camera_orthographic fill them. */
+    float camera_from_render[16];
+    float min_pos_differential_x[3], min_pos_differential_y[3];
+    float min_dir_differential_x[3], min_dir_differential_y[3];
 } ShmCamera;
 
 /* RgbFilm + PixelSensor (film.rs:470-574, 754-914) + BoxFilter radius (filter.rs:61-105). */
@@ -230,6 +284,15 @@ typedef struct ShmSceneDesc {
     uint32_t n_patch_meshes;      /* ABI v3 */
     uint32_t pad;
     const ShmBilinearPatchMesh* patch_meshes;
+    /* ABI v6: image textures */
+    uint32_t n_image_textures;
+    uint32_t n_image_levels;
+    const ShmImageTexture* image_textures;
+    const ShmImageLevel* image_levels;
+    uint64_t n_texel_floats;
+    const float* texel_data;
+    ShmColorSpace color_space;
+    const float* ewa_filter_lut;  /* MIP_FILTER_LUT (mipmap.rs:390-521), 128 floats; required when a texture uses SHM_TEXFILTER_EWA */
 } ShmSceneDesc;
 
 /* ---- render parameters ----------------------------------------------------------------------- */

@@ -163,7 +163,21 @@ Spec sample_ld(const SceneView& sv, const SurfaceInteraction& intr, const BSDF& 
 }
 
 // integrator.rs:748-895
-Spec li(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng, int max_depth, bool regularize, Counters& c) {
+// What the reference's get_bsdf needs beyond the interaction when image textures are bound: compute_differentials reads the ray's
+// auxiliary rays, the camera, the sampler's spp and options.disable_pixel_jitter (interaction.rs:187-197).
+struct TexParams {
+    bool on;  // the scene binds image textures; off: differentials are dead values and not computed
+    int spp;
+    bool disable_pixel_jitter;
+};
+BSDF get_bsdf_at(const SceneView& sv, SurfaceInteraction& si, const ShmMaterial& m, Wavelengths& lambda, const TexParams& tp, const AuxRays& aux,
+                 Differentials& df) {
+    if (!tp.on) return get_bsdf(sv, si, m, lambda);
+    df = compute_differentials(sv, si, aux, tp.spp, tp.disable_pixel_jitter);
+    return get_bsdf<true>(sv, si, m, lambda, &df);
+}
+
+Spec li(const SceneView& sv, Ray ray, AuxRays aux, const TexParams& tp, Wavelengths& lambda, Rng& rng, int max_depth, bool regularize, Counters& c) {
     Spec l = spec_const(0.0f);
     Spec beta = spec_const(1.0f);
     int depth = 0;
@@ -208,7 +222,8 @@ Spec li(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng, int max_dep
                 }
             }
         }
-        BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+        Differentials df;
+        BSDF bsdf = get_bsdf_at(sv, si, sv.materials[prim.material], lambda, tp, aux, df);
         if (regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
         if (depth == max_depth) break;
         depth += 1;
@@ -227,7 +242,8 @@ Spec li(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng, int max_dep
         any_non_specular_bounces |= !specular_bounce;
         if (flags_is_transmissive(bs.flags)) eta_scale *= sqr(bs.eta);
         prev_intr_ctx = light_ctx_from(si);
-        // spawn_ray_with_differentials -> interaction.spawn_ray(wi), interaction.rs:68-75, 441
+        // spawn_ray_with_differentials: interaction.spawn_ray(wi) (interaction.rs:68-75, 441) + the specular differentials
+        if (tp.on) aux = spawn_ray_differentials(si, df, aux, bs.wi, bs.flags, bs.eta);
         ray.o = offset_ray_origin(si.pi, si.n, bs.wi);
         ray.d = bs.wi;
         if (is_finite(eta_scale)) {
@@ -244,8 +260,8 @@ Spec li(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng, int max_dep
 
 // SimplePathIntegrator::li, integrator.rs:586-733: no MIS, no Russian roulette; direct lighting by light sampling
 // (sample_lights) or only by hitting emitters; directions from the BSDF (sample_bsdf) or uniform over the (hemi)sphere.
-Spec li_simple_path(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng, int max_depth, bool sample_lights, bool sample_bsdf,
-                    Counters& c) {
+Spec li_simple_path(const SceneView& sv, Ray ray, AuxRays aux, const TexParams& tp, Wavelengths& lambda, Rng& rng, int max_depth, bool sample_lights,
+                    bool sample_bsdf, Counters& c) {
     Spec l = spec_const(0.0f);
     bool specular_bounce = true;
     Spec beta = spec_const(1.0f);
@@ -268,7 +284,9 @@ Spec li_simple_path(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng,
         }
         if (depth == max_depth) break;
         depth += 1;
-        BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+        Differentials df;
+        BSDF bsdf = get_bsdf_at(sv, si, sv.materials[prim.material], lambda, tp, aux, df);
+        aux = aux_none();  // every later ray is interaction.spawn_ray(wi): no auxiliary rays (integrator.rs:686, 716)
         V3 wo = -ray.d;
         if (sample_lights) {
             Float p_sel = 0.0f;
@@ -321,7 +339,8 @@ Spec li_simple_path(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng,
 }
 
 // RandomWalkIntegrator::li_random_walk, integrator.rs:491-563 (recursive, as there: the innermost term is evaluated first)
-Spec li_random_walk(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng, int depth, int max_depth, Counters& c) {
+Spec li_random_walk(const SceneView& sv, Ray ray, const AuxRays& aux, const TexParams& tp, Wavelengths& lambda, Rng& rng, int depth, int max_depth,
+                    Counters& c) {
     Hit hit;
     if (!bvh_intersect(sv, ray.o, ray.d, infinity(), hit, c)) {
         Spec le = spec_const(0.0f);
@@ -336,7 +355,8 @@ Spec li_random_walk(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng,
     V3 wo = -ray.d;
     Spec le = (prim.area_light >= 0) ? area_light_l(sv, sv.lights[prim.area_light], si.n, wo, lambda) : spec_const(0.0f);
     if (depth == max_depth) return le;
-    BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+    Differentials df;
+    BSDF bsdf = get_bsdf_at(sv, si, sv.materials[prim.material], lambda, tp, aux, df);
     V2 u = sampler_get_2d(rng);
     V3 wp = sample_uniform_sphere(u);
     Spec f = bsdf_f(bsdf, wo, wp);
@@ -345,7 +365,7 @@ Spec li_random_walk(const SceneView& sv, Ray ray, Wavelengths& lambda, Rng& rng,
     Ray next;
     next.o = offset_ray_origin(si.pi, si.n, wp);
     next.d = wp;
-    return le + fcos * li_random_walk(sv, next, lambda, rng, depth + 1, max_depth, c) / (1.0f / (4.0f * PI_F));
+    return le + fcos * li_random_walk(sv, next, aux_none(), tp, lambda, rng, depth + 1, max_depth, c) / (1.0f / (4.0f * PI_F));
 }
 
 struct Oracle {
@@ -405,6 +425,7 @@ int orc_render_wave(OrcScene* s, const ShmRenderParams* params, const ShmTile* t
     if (!params || !tiles || !film || params->force_diffuse) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
     const SceneView& sv = o->sv;
     const int width = sv.pixel_bounds[2] - sv.pixel_bounds[0];
+    const TexParams tp{o->flat.has_textures, params->samples_per_pixel, params->disable_pixel_jitter != 0};
     if (n_threads < 1) n_threads = 1;
     std::atomic<uint32_t> next(0);
     std::vector<Counters> counters(n_threads);
@@ -422,13 +443,14 @@ int orc_render_wave(OrcScene* s, const ShmRenderParams* params, const ShmTile* t
                         Rng rng = sampler_start_pixel_sample(x, y, si, params->seed);
                         Wavelengths lambda;
                         Float weight;
+                        AuxRays aux = aux_none();
                         Ray ray = generate_camera_ray(sv, x, y, rng, params->disable_wavelength_jitter != 0,
-                                                      params->disable_pixel_jitter != 0, lambda, weight);
+                                                      params->disable_pixel_jitter != 0, lambda, weight, tp.on ? &aux : nullptr, params->samples_per_pixel);
                         Spec L = spec_const(1.0f) * ((params->integrator == SHM_INTEGRATOR_RANDOM_WALK)
-                                                         ? li_random_walk(sv, ray, lambda, rng, 0, params->max_depth, c)
+                                                         ? li_random_walk(sv, ray, aux, tp, lambda, rng, 0, params->max_depth, c)
                                                          : (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH)
-                                                         ? li_simple_path(sv, ray, lambda, rng, params->max_depth, params->sample_lights != 0, params->sample_bsdf != 0, c)
-                                                         : li(sv, ray, lambda, rng, params->max_depth, params->regularize != 0, c));  // camera_ray.weight * li
+                                                         ? li_simple_path(sv, ray, aux, tp, lambda, rng, params->max_depth, params->sample_lights != 0, params->sample_bsdf != 0, c)
+                                                         : li(sv, ray, aux, tp, lambda, rng, params->max_depth, params->regularize != 0, c));  // camera_ray.weight * li
                         c.paths++;
                         // RgbFilm::add_sample, film.rs:548-574
                         V3 rgb = film_sample_rgb(sv, L, lambda);
@@ -768,6 +790,100 @@ void orc_fn_spectrum_sample(OrcScene* s, const ShmSpectrum* sp, const float* lam
     for (int i = 0; i < 4; ++i) { w.lambda[i] = lambda4[i]; w.pdf[i] = 1.0f; }
     Spec r = spectrum_sample(*sp, o->sv.spectrum_data, w);
     for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
+}
+
+
+// ---- image textures (shm/texture.h) ----
+static TextureEvalContext make_tex_ctx(const float* c18) {
+    TextureEvalContext c;
+    c.p = ld3(c18); c.dpdx = ld3(c18 + 3); c.dpdy = ld3(c18 + 6); c.n = ld3(c18 + 9);
+    c.uv = v2(c18[12], c18[13]);
+    c.dudx = c18[14]; c.dudy = c18[15]; c.dvdx = c18[16]; c.dvdy = c18[17];
+    return c;
+}
+float orc_fn_log2(float x) { return shm::log2(x); }
+// TextureMapping2D::map: out = s, t, dsdx, dsdy, dtdx, dtdy
+void orc_fn_texture_map(OrcScene* s, uint32_t tex, const float* ctx18, float* out6) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    TexCoord2D c = texture_map(o->sv.image_textures[tex], make_tex_ctx(ctx18));
+    out6[0] = c.st.x; out6[1] = c.st.y; out6[2] = c.dsdx; out6[3] = c.dsdy; out6[4] = c.dtdx; out6[5] = c.dtdy;
+}
+// MIPMap::filter::<RGB>(st, dst0, dst1)
+void orc_fn_texture_filter(OrcScene* s, uint32_t tex, const float* st, const float* dst0, const float* dst1, float* out3) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    TextureView tv;
+    tv.t = &o->sv.image_textures[tex];
+    tv.levels = o->sv.image_levels + tv.t->first_level;
+    tv.texels = o->sv.texel_data;
+    RGB3 r = tex_filter(tv, o->sv.ewa_lut, v2(st[0], st[1]), v2(dst0[0], dst0[1]), v2(dst1[0], dst1[1]));
+    out3[0] = r.r; out3[1] = r.g; out3[2] = r.b;
+}
+void orc_fn_rgb2spec_fetch(OrcScene* s, const float* rgb, float* out3) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    rgb2spec_fetch(o->sv, rgb3(rgb[0], rgb[1], rgb[2]), out3);
+}
+// SpectrumImageTexture::evaluate at four wavelengths
+void orc_fn_image_texture_evaluate(OrcScene* s, uint32_t tex, const float* ctx18, const float* lambda4, float* out4) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    Wavelengths w;
+    for (int i = 0; i < 4; ++i) { w.lambda[i] = lambda4[i]; w.pdf[i] = 1.0f; }
+    Spec r = image_texture_evaluate(o->sv, tex, make_tex_ctx(ctx18), w);
+    for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
+}
+void orc_fn_approximate_dp_dxy(OrcScene* s, const float* p, const float* n, int spp, int disable_pixel_jitter, float* out6) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    V3 dpdx, dpdy;
+    approximate_dp_dxy(o->sv.camera, ld3(p), ld3(n), spp, disable_pixel_jitter != 0, dpdx, dpdy);
+    out6[0] = dpdx.x; out6[1] = dpdx.y; out6[2] = dpdx.z; out6[3] = dpdy.x; out6[4] = dpdy.y; out6[5] = dpdy.z;
+}
+// The camera ray of a pixel sample with its (scaled) auxiliary rays, intersected with the scene; at the hit the differentials of
+// compute_differentials, with the ray's auxiliary rays (use_aux) or through approximate_dp_dxy. Returns 0 on a miss.
+// out[0..18): ray o, d, rx_o, rx_d, ry_o, ry_d; out[18..44): p, n, uv, dpdu, dpdv, dpdx, dpdy, dudx, dvdx, dudy, dvdy
+int orc_fn_camera_hit_differentials(OrcScene* s, int px, int py, int sample_index, uint64_t seed, int spp, int disable_pixel_jitter, int use_aux,
+                                    float* out) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    Rng rng = sampler_start_pixel_sample(px, py, sample_index, seed);
+    Wavelengths lambda;
+    Float w;
+    AuxRays aux = aux_none();
+    Ray r = generate_camera_ray(o->sv, px, py, rng, false, disable_pixel_jitter != 0, lambda, w, &aux, spp);
+    const V3 rv[6] = {r.o, r.d, aux.rx_o, aux.rx_d, aux.ry_o, aux.ry_d};
+    for (int i = 0; i < 6; ++i) { out[3 * i] = rv[i].x; out[3 * i + 1] = rv[i].y; out[3 * i + 2] = rv[i].z; }
+    Hit h;
+    Counters c;
+    if (!bvh_intersect(o->sv, r.o, r.d, infinity(), h, c)) return 0;
+    SurfaceInteraction si = hit_interaction(o->sv, h, -r.d);
+    Differentials df = compute_differentials(o->sv, si, use_aux ? aux : aux_none(), spp, disable_pixel_jitter != 0);
+    V3 p = si.p();
+    const V3 sv3[6] = {p, si.n, v3(si.uv.x, si.uv.y, 0.0f), si.dpdu, si.dpdv, df.dpdx};
+    float* q = out + 18;
+    q[0] = p.x; q[1] = p.y; q[2] = p.z; q[3] = si.n.x; q[4] = si.n.y; q[5] = si.n.z; q[6] = si.uv.x; q[7] = si.uv.y;
+    q[8] = si.dpdu.x; q[9] = si.dpdu.y; q[10] = si.dpdu.z; q[11] = si.dpdv.x; q[12] = si.dpdv.y; q[13] = si.dpdv.z;
+    q[14] = df.dpdx.x; q[15] = df.dpdx.y; q[16] = df.dpdx.z; q[17] = df.dpdy.x; q[18] = df.dpdy.y; q[19] = df.dpdy.z;
+    q[20] = df.dudx; q[21] = df.dvdx; q[22] = df.dudy; q[23] = df.dvdy;
+    (void)sv3;
+    return 1;
+}
+// spawn_ray_with_differentials for a planar interaction (p, n = ns, dndu = dndv = 0 unless given): out12 = rx_o, rx_d, ry_o, ry_d; returns has
+int orc_fn_spawn_ray_differentials(const float* p, const float* n, const float* wo, const float* dpdx, const float* dpdy, const float* dndx_uv,
+                                   const float* aux12, const float* wi, uint32_t flags, float eta, float* out12) {
+    SurfaceInteraction si;
+    memset(&si, 0, sizeof(si));
+    si.pi = p3i_exact(ld3(p));
+    si.n = ld3(n); si.wo = ld3(wo);
+    si.shading.n = ld3(n);
+    // dndx = dndu * dudx + dndv * dvdx: pass dndu = dndx_uv[0..3), dndv = dndx_uv[3..6) with (dudx, dvdx, dudy, dvdy) = (1, 0, 0, 1)
+    si.shading.dndu = ld3(dndx_uv); si.shading.dndv = ld3(dndx_uv + 3);
+    Differentials df = differentials_zero();
+    df.dpdx = ld3(dpdx); df.dpdy = ld3(dpdy);
+    df.dudx = 1.0f; df.dvdy = 1.0f;
+    AuxRays a;
+    a.has = true;
+    a.rx_o = ld3(aux12); a.rx_d = ld3(aux12 + 3); a.ry_o = ld3(aux12 + 6); a.ry_d = ld3(aux12 + 9);
+    AuxRays r = spawn_ray_differentials(si, df, a, ld3(wi), flags, eta);
+    const V3 rv[4] = {r.rx_o, r.rx_d, r.ry_o, r.ry_d};
+    for (int i = 0; i < 4; ++i) { out12[3 * i] = rv[i].x; out12[3 * i + 1] = rv[i].y; out12[3 * i + 2] = rv[i].z; }
+    return r.has ? 1 : 0;
 }
 
 }  // extern "C"

@@ -73,6 +73,16 @@ def load():
     lib.orc_fn_invert_bilinear.restype, lib.orc_fn_invert_bilinear.argtypes = None, [FP, FP, FP]
     lib.orc_fn_interval_op.restype, lib.orc_fn_interval_op.argtypes = None, [C.c_int, F, F, F, F, FP]
     lib.orc_fn_det3.restype, lib.orc_fn_det3.argtypes = F, [FP]
+    lib.orc_fn_log2.restype, lib.orc_fn_log2.argtypes = F, [F]
+    lib.orc_fn_texture_map.restype, lib.orc_fn_texture_map.argtypes = None, [C.c_void_p, C.c_uint32, FP, FP]
+    lib.orc_fn_texture_filter.restype, lib.orc_fn_texture_filter.argtypes = None, [C.c_void_p, C.c_uint32, FP, FP, FP, FP]
+    lib.orc_fn_rgb2spec_fetch.restype, lib.orc_fn_rgb2spec_fetch.argtypes = None, [C.c_void_p, FP, FP]
+    lib.orc_fn_image_texture_evaluate.restype, lib.orc_fn_image_texture_evaluate.argtypes = None, [C.c_void_p, C.c_uint32, FP, FP, FP]
+    lib.orc_fn_approximate_dp_dxy.restype, lib.orc_fn_approximate_dp_dxy.argtypes = None, [C.c_void_p, FP, FP, C.c_int, C.c_int, FP]
+    lib.orc_fn_camera_hit_differentials.restype = C.c_int
+    lib.orc_fn_camera_hit_differentials.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, FP]
+    lib.orc_fn_spawn_ray_differentials.restype = C.c_int
+    lib.orc_fn_spawn_ray_differentials.argtypes = [FP] * 8 + [C.c_uint32, F, FP]
     lib.orc_fn_rotate_from_to.restype, lib.orc_fn_rotate_from_to.argtypes = None, [FP, FP, FP, FP]
     lib.orc_fn_blp_intersect.restype, lib.orc_fn_blp_intersect.argtypes = C.c_int, [FP, FP, FP, F, FP]
     lib.orc_fn_blp_interaction.restype, lib.orc_fn_blp_interaction.argtypes = None, [FP, C.c_int, F, F, FP, FP]

@@ -10,7 +10,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 LIB_PATH = ROOT / "csrc" / "libshimmer_hip.so"
 
-SHM_ABI_VERSION = 5
+SHM_ABI_VERSION = 6
 SHM_OK = 0
 SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE, SHM_SHAPE_BILINEAR_PATCH = 0, 1, 2
 SHM_SPECTRUM_CONSTANT, SHM_SPECTRUM_DENSE, SHM_SPECTRUM_PIECEWISE_LINEAR = 0, 1, 2
@@ -18,6 +18,11 @@ SHM_SPECTRUM_RGB_ALBEDO, SHM_SPECTRUM_RGB_UNBOUNDED, SHM_SPECTRUM_RGB_ILLUMINANT
 SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATERIAL_THIN_DIELECTRIC = 0, 1, 2, 3
 SHM_MATERIAL_COATED_DIFFUSE, SHM_MATERIAL_COATED_CONDUCTOR, SHM_MATERIAL_MIX = 4, 5, 6
 SHM_LIGHT_POINT, SHM_LIGHT_DIFFUSE_AREA, SHM_LIGHT_UNIFORM_INFINITE = 0, 1, 2
+SHM_SPECTRUM_IMAGE_TEXTURE = 6
+SHM_TEXMAP_UV, SHM_TEXMAP_SPHERICAL, SHM_TEXMAP_CYLINDRICAL, SHM_TEXMAP_PLANAR = 0, 1, 2, 3
+SHM_TEXFILTER_POINT, SHM_TEXFILTER_BILINEAR, SHM_TEXFILTER_TRILINEAR, SHM_TEXFILTER_EWA = 0, 1, 2, 3
+SHM_WRAP_BLACK, SHM_WRAP_CLAMP, SHM_WRAP_REPEAT, SHM_WRAP_OCTAHEDRAL_SPHERE = 0, 1, 2, 3
+SHM_SPECTRUM_TYPE_ALBEDO, SHM_SPECTRUM_TYPE_UNBOUNDED, SHM_SPECTRUM_TYPE_ILLUMINANT = 0, 1, 2
 SHM_CAMERA_PERSPECTIVE, SHM_CAMERA_ORTHOGRAPHIC = 0, 1
 SHM_INTEGRATOR_PATH, SHM_INTEGRATOR_SIMPLE_PATH, SHM_INTEGRATOR_RANDOM_WALK = 0, 1, 2
 
@@ -74,7 +79,27 @@ class ShmLight(C.Structure):
 class ShmCamera(C.Structure):
     _fields_ = [("camera_from_raster", C.c_float * 16), ("render_from_camera", C.c_float * 16), ("dx_camera", C.c_float * 3),
                 ("dy_camera", C.c_float * 3), ("lens_radius", C.c_float), ("focal_distance", C.c_float),
-                ("shutter_open", C.c_float), ("shutter_close", C.c_float), ("kind", C.c_uint32), ("pad", C.c_uint32)]
+                ("shutter_open", C.c_float), ("shutter_close", C.c_float), ("kind", C.c_uint32), ("pad", C.c_uint32),
+                ("camera_from_render", C.c_float * 16), ("min_pos_differential_x", C.c_float * 3),
+                ("min_pos_differential_y", C.c_float * 3), ("min_dir_differential_x", C.c_float * 3),
+                ("min_dir_differential_y", C.c_float * 3)]
+
+
+class ShmImageLevel(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("texel_offset", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class ShmImageTexture(C.Structure):
+    _fields_ = [("mapping", C.c_uint32), ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float),
+                ("vs", C.c_float * 3), ("vt", C.c_float * 3), ("texture_from_render", C.c_float * 16), ("filter", C.c_uint32),
+                ("max_anisotropy", C.c_float), ("wrap", C.c_uint32), ("scale", C.c_float), ("invert", C.c_uint8),
+                ("spectrum_type", C.c_uint8), ("n_channels", C.c_uint8), ("has_color_space", C.c_uint8),
+                ("first_level", C.c_uint32), ("n_levels", C.c_uint32)]
+
+
+class ShmColorSpace(C.Structure):
+    _fields_ = [("rgb2spec_res", C.c_uint32), ("pad", C.c_uint32), ("rgb2spec_scale", c_float_p), ("rgb2spec_data", c_float_p),
+                ("illuminant", c_float_p)]
 
 
 class ShmFilm(C.Structure):
@@ -90,7 +115,10 @@ class ShmSceneDesc(C.Structure):
                 ("n_materials", C.c_uint32), ("materials", C.POINTER(ShmMaterial)), ("n_lights", C.c_uint32),
                 ("lights", C.POINTER(ShmLight)), ("n_spectrum_floats", C.c_uint32), ("spectrum_data", c_float_p),
                 ("camera", ShmCamera), ("film", ShmFilm), ("n_patch_meshes", C.c_uint32), ("pad", C.c_uint32),
-                ("patch_meshes", C.POINTER(ShmBilinearPatchMesh))]
+                ("patch_meshes", C.POINTER(ShmBilinearPatchMesh)),
+                ("n_image_textures", C.c_uint32), ("n_image_levels", C.c_uint32), ("image_textures", C.POINTER(ShmImageTexture)),
+                ("image_levels", C.POINTER(ShmImageLevel)), ("n_texel_floats", C.c_uint64), ("texel_data", c_float_p),
+                ("color_space", ShmColorSpace), ("ewa_filter_lut", c_float_p)]
 
 
 class ShmRenderParams(C.Structure):

@@ -38,6 +38,13 @@ struct FlatScene {
     float scene_radius = 0.0f;
     bool has_spheres = false;  // any non-triangle shape (sphere or bilinear patch): selects k_trace3<.., TRI_ONLY = false>
     bool has_layered = false;  // any Coated* material: selects the k_shade instantiation that carries LayeredBxDF
+    // image textures (ABI v6)
+    std::vector<ShmImageTexture> image_textures;
+    std::vector<ShmImageLevel> image_levels;
+    std::vector<float> texel_data;
+    std::vector<float> rgb2spec_scale, rgb2spec_data, cs_illuminant, ewa_lut;
+    uint32_t rgb2spec_res = 0;
+    bool has_textures = false;  // a material slot binds an image texture: the path carries ray differentials (k_shade<.., HAS_TEX>)
 
     shm::SceneView view() const {
         shm::SceneView v;
@@ -72,11 +79,25 @@ struct FlatScene {
         v.sensor_r_bar = sensor_r.data();
         v.sensor_g_bar = sensor_g.data();
         v.sensor_b_bar = sensor_b.data();
+        v.image_textures = image_textures.data();
+        v.image_levels = image_levels.data();
+        v.texel_data = texel_data.data();
+        v.rgb2spec_res = rgb2spec_res;
+        v.rgb2spec_scale = rgb2spec_scale.data();
+        v.rgb2spec_data = rgb2spec_data.data();
+        v.cs_illuminant = cs_illuminant.data();
+        v.ewa_lut = ewa_lut.data();
         return v;
     }
 };
 
-inline bool check_spectrum(const ShmSpectrum& s, uint32_t n_floats, std::string& err) {
+// n_textures > 0 only for the SpectrumTexture slots of a material (a, b, c): eta and light spectra are plain Spectrum values
+inline bool check_spectrum(const ShmSpectrum& s, uint32_t n_floats, std::string& err, uint32_t n_textures = 0, bool* is_texture = nullptr) {
+    if (s.kind == SHM_SPECTRUM_IMAGE_TEXTURE) {
+        if (s.offset >= n_textures) { err = n_textures ? "image texture index out of range" : "an image texture is not valid in this slot"; return false; }
+        if (is_texture) *is_texture = true;
+        return true;
+    }
     if (s.kind == SHM_SPECTRUM_CONSTANT || s.kind == SHM_SPECTRUM_RGB_ALBEDO || s.kind == SHM_SPECTRUM_RGB_UNBOUNDED) return true;
     if (s.kind == SHM_SPECTRUM_DENSE || s.kind == SHM_SPECTRUM_RGB_ILLUMINANT) {
         if ((uint64_t)s.offset + s.n > n_floats) { err = "dense spectrum out of range"; return false; }
@@ -255,7 +276,47 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         out.scene_radius = inside ? shm::distance(center, hi) : 0.0f;
     }
 
+    // image textures
+    if (d->n_image_textures) {
+        if (!d->image_textures || !d->image_levels || !d->texel_data) { err = "image texture arrays missing"; return SHM_ERR_INVALID_ARGUMENT; }
+        if (d->n_texel_floats >= (1ull << 32)) { err = "more than 2^32 texel floats"; return SHM_ERR_UNSUPPORTED; }
+        out.image_textures.assign(d->image_textures, d->image_textures + d->n_image_textures);
+        out.image_levels.assign(d->image_levels, d->image_levels + d->n_image_levels);
+        out.texel_data.assign(d->texel_data, d->texel_data + d->n_texel_floats);
+        bool need_cs = false, need_illum = false, need_lut = false;
+        for (const ShmImageTexture& t : out.image_textures) {
+            if (t.mapping > SHM_TEXMAP_PLANAR || t.filter > SHM_TEXFILTER_EWA || t.wrap > SHM_WRAP_OCTAHEDRAL_SPHERE || t.spectrum_type > SHM_SPECTRUM_TYPE_ILLUMINANT) { err = "image texture: unknown mapping / filter / wrap / spectrum type"; return SHM_ERR_INVALID_ARGUMENT; }
+            if (t.n_channels != 1 && t.n_channels != 3) { err = "image texture: n_channels must be 1 or 3"; return SHM_ERR_INVALID_ARGUMENT; }
+            if (t.n_levels == 0 || (uint64_t)t.first_level + t.n_levels > d->n_image_levels) { err = "image texture: level range out of bounds"; return SHM_ERR_INVALID_ARGUMENT; }
+            for (uint32_t l = 0; l < t.n_levels; ++l) {
+                const ShmImageLevel& lv = out.image_levels[t.first_level + l];
+                if (lv.width <= 0 || lv.height <= 0 || (uint64_t)lv.texel_offset + (uint64_t)lv.width * (uint64_t)lv.height * t.n_channels > d->n_texel_floats) { err = "image texture: level texels out of bounds"; return SHM_ERR_INVALID_ARGUMENT; }
+            }
+            // MIPMap::filter returns texel(n_levels - 1, (0, 0)) for wide filters (mipmap.rs:165-168): Image::generate_pyramid ends in a 1x1 level
+            need_cs |= t.has_color_space != 0;
+            need_illum |= t.has_color_space && t.spectrum_type == SHM_SPECTRUM_TYPE_ILLUMINANT;
+            need_lut |= t.filter == SHM_TEXFILTER_EWA;
+        }
+        const ShmColorSpace& cs = d->color_space;
+        if (need_cs) {
+            if (cs.rgb2spec_res < 2 || cs.rgb2spec_res > 256 || !cs.rgb2spec_scale || !cs.rgb2spec_data) { err = "image textures with a colour space need ShmSceneDesc::color_space (rgb2spec table)"; return SHM_ERR_INVALID_ARGUMENT; }
+            out.rgb2spec_res = cs.rgb2spec_res;
+            out.rgb2spec_scale.assign(cs.rgb2spec_scale, cs.rgb2spec_scale + cs.rgb2spec_res);
+            size_t r = cs.rgb2spec_res;
+            out.rgb2spec_data.assign(cs.rgb2spec_data, cs.rgb2spec_data + 9 * r * r * r);
+        }
+        if (need_illum) {
+            if (!cs.illuminant) { err = "illuminant image textures need ShmColorSpace::illuminant"; return SHM_ERR_INVALID_ARGUMENT; }
+            out.cs_illuminant.assign(cs.illuminant, cs.illuminant + 471);
+        }
+        if (need_lut) {
+            if (!d->ewa_filter_lut) { err = "EWA-filtered image textures need ShmSceneDesc::ewa_filter_lut"; return SHM_ERR_INVALID_ARGUMENT; }
+            out.ewa_lut.assign(d->ewa_filter_lut, d->ewa_filter_lut + 128);
+        }
+    }
+
     // materials / lights
+    const uint32_t ntex = d->n_image_textures;
     uint32_t nsf = (uint32_t)out.spectrum_data.size();
     for (const ShmMaterial& m : out.materials) {
         if (m.kind > SHM_MATERIAL_MIX) { err = "unsupported material kind"; return SHM_ERR_UNSUPPORTED; }
@@ -276,13 +337,15 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
             }
             continue;
         }
-        if (!check_spectrum(m.a, nsf, err)) return SHM_ERR_INVALID_ARGUMENT;
+        // Dielectric / ThinDielectric keep eta in `a`: a Spectrum, not a texture (material.rs:520-527, 655-660)
+        const bool a_is_texture_slot = !(m.kind == SHM_MATERIAL_DIELECTRIC || m.kind == SHM_MATERIAL_THIN_DIELECTRIC);
+        if (!check_spectrum(m.a, nsf, err, a_is_texture_slot ? ntex : 0, &out.has_textures)) return SHM_ERR_INVALID_ARGUMENT;
         const bool coated = m.kind == SHM_MATERIAL_COATED_DIFFUSE || m.kind == SHM_MATERIAL_COATED_CONDUCTOR;
         if ((m.kind == SHM_MATERIAL_CONDUCTOR || (m.kind == SHM_MATERIAL_COATED_CONDUCTOR && !m.conductor_from_reflectance)) &&
-            !check_spectrum(m.b, nsf, err))
+            !check_spectrum(m.b, nsf, err, ntex, &out.has_textures))
             return SHM_ERR_INVALID_ARGUMENT;
         if (coated) {
-            if (!check_spectrum(m.c, nsf, err) || !check_spectrum(m.d, nsf, err)) return SHM_ERR_INVALID_ARGUMENT;
+            if (!check_spectrum(m.c, nsf, err, ntex, &out.has_textures) || !check_spectrum(m.d, nsf, err)) return SHM_ERR_INVALID_ARGUMENT;
             if (m.max_depth < 0 || m.max_depth > 1024 || m.n_samples < 1 || m.n_samples > 1024) { err = "coated material: max_depth / n_samples out of range"; return SHM_ERR_INVALID_ARGUMENT; }
             out.has_layered = true;
         }

@@ -8,6 +8,7 @@
 //   tile.rs:21-104              Tile::tile
 //   camera.rs:507-523,594-642,893-963   CameraTransform::new, ProjectiveCameraBase::new, PerspectiveCamera::new
 //   transform.rs:263-316        Transform::inverse / look_at / perspective / scale / translate
+//   camera.rs:356-440           CameraBase::find_minimum_differentials (what Camera::approximate_dp_dxy falls back on)
 //   image.rs:1333-1377          Image::write_pfm
 //
 // Third-party pieces the reference pulls in here, restated from their published behaviour (unpinned):
@@ -22,6 +23,7 @@
 #include <vector>
 
 #include "../../../include/shimmer_hip.h"
+#include "../shm/path.h"  // camera_generate_ray_differential for CameraBase::find_minimum_differentials (host use only)
 
 namespace {
 
@@ -330,11 +332,50 @@ static int projective_camera(const float world_from_camera[16], float fov_deg, c
     m4_point(camera_from_raster, py, b);
     m4_point(camera_from_raster, p0, c);
     for (int i = 0; i < 3; ++i) { out->dx_camera[i] = (float)(a[i] - c[i]); out->dy_camera[i] = (float)(b[i] - c[i]); }
+    if (ortho)  // camera.rs:727-728: camera_from_raster.apply(Vector3f::X / ::Y), a vector transform
+        for (int i = 0; i < 3; ++i) { out->dx_camera[i] = (float)camera_from_raster.m[i][0]; out->dy_camera[i] = (float)camera_from_raster.m[i][1]; }
     out->lens_radius = lens_radius;
     out->focal_distance = focal_distance;
     out->shutter_open = 0.0f;
     out->shutter_close = 1.0f;
     out->kind = ortho ? SHM_CAMERA_ORTHOGRAPHIC : SHM_CAMERA_PERSPECTIVE;
+    M4 camera_from_render;
+    if (!m4_inverse(render_from_camera, camera_from_render)) return SHM_ERR_INVALID_ARGUMENT;
+    m4_to_f32(camera_from_render, out->camera_from_render);
+    if (ortho) {  // camera.rs:733-736
+        for (int i = 0; i < 3; ++i) {
+            out->min_dir_differential_x[i] = out->min_dir_differential_y[i] = 0.0f;
+            out->min_pos_differential_x[i] = out->dx_camera[i];
+            out->min_pos_differential_y[i] = out->dy_camera[i];
+        }
+    } else {
+        // CameraBase::find_minimum_differentials, camera.rs:356-440: 512 samples along the film diagonal, p_lens = (0.5, 0.5)
+        using namespace shm;
+        const Float inf = infinity();
+        V3 min_pos_x = v3s(inf), min_pos_y = v3s(inf), min_dir_x = v3s(inf), min_dir_y = v3s(inf);
+        const int n = 512;
+        for (int i = 0; i < n; ++i) {
+            V2 p_film = v2((Float)i / (Float)(n - 1) * (Float)full_resolution[0], (Float)i / (Float)(n - 1) * (Float)full_resolution[1]);
+            AuxRays aux = aux_none();
+            Ray ray = camera_generate_ray_differential(*out, p_film, v2(0.5f, 0.5f), &aux);
+            V3 dox = xf_vector(out->camera_from_render, aux.rx_o - ray.o);
+            if (length(dox) < length(min_pos_x)) min_pos_x = dox;
+            V3 doy = xf_vector(out->camera_from_render, aux.ry_o - ray.o);
+            if (length(doy) < length(min_pos_y)) min_pos_y = doy;
+            ray.d = normalize(ray.d);
+            aux.rx_d = normalize(aux.rx_d);
+            aux.ry_d = normalize(aux.ry_d);
+            Frame f = frame_from_z(ray.d);
+            V3 df = f.to_local(ray.d);
+            V3 dxf = normalize(f.to_local(aux.rx_d));
+            V3 dyf = normalize(f.to_local(aux.ry_d));
+            if (length(dxf - df) < length(min_dir_x)) min_dir_x = dxf - df;
+            if (length(dyf - df) < length(min_dir_y)) min_dir_y = dyf - df;
+        }
+        const V3* src[4] = {&min_pos_x, &min_pos_y, &min_dir_x, &min_dir_y};
+        float* dst[4] = {out->min_pos_differential_x, out->min_pos_differential_y, out->min_dir_differential_x, out->min_dir_differential_y};
+        for (int k = 0; k < 4; ++k) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
+    }
     if (render_from_world_out) m4_to_f32(render_from_world, render_from_world_out);
     return SHM_OK;
 }

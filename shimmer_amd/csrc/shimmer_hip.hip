@@ -77,8 +77,26 @@ struct PathArrays {
     float2* pb_eta;         // p_b, eta_scale
     uint2* rng;             // PCG32 state (inc is re-derived from pixel+seed)
     uint32_t* pixel;        // x | y << 16 (absolute pixel coordinates, < 65536)
-    uint32_t* flags;        // depth | specular_bounce << 8 | any_non_specular << 9
+    uint32_t* flags;        // depth | specular_bounce << 8 | any_non_specular << 9 | ray has auxiliary rays << 10
+    // scenes with image textures only (null otherwise): the ray's AuxiliaryRays (ray.rs:104-135)
+    float4* aux0;           // rx_origin.xyz, rx_direction.x
+    float4* aux1;           // rx_direction.yz, ry_origin.xy
+    float4* aux2;           // ry_origin.z, ry_direction.xyz
 };
+
+__device__ __forceinline__ AuxRays ld_aux(const PathArrays& pa, uint32_t path) {
+    float4 a = pa.aux0[path], b = pa.aux1[path], c = pa.aux2[path];
+    AuxRays x;
+    x.has = true;
+    x.rx_o = v3(a.x, a.y, a.z); x.rx_d = v3(a.w, b.x, b.y);
+    x.ry_o = v3(b.z, b.w, c.x); x.ry_d = v3(c.y, c.z, c.w);
+    return x;
+}
+__device__ __forceinline__ void st_aux(const PathArrays& pa, uint32_t path, const AuxRays& x) {
+    pa.aux0[path] = make_float4(x.rx_o.x, x.rx_o.y, x.rx_o.z, x.rx_d.x);
+    pa.aux1[path] = make_float4(x.rx_d.y, x.rx_d.z, x.ry_o.x, x.ry_o.y);
+    pa.aux2[path] = make_float4(x.ry_o.z, x.ry_d.x, x.ry_d.y, x.ry_d.z);
+}
 
 __device__ __forceinline__ uint32_t wave_lane() { return __lane_id(); }
 
@@ -138,8 +156,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
     Rng rng = sampler_start_pixel_sample(px, py, sample_begin + (int)s_local, params.seed);
     Wavelengths lambda;
     Float weight;
+    const bool has_tex = pa.aux0 != nullptr;
+    AuxRays aux = aux_none();
     Ray r = generate_camera_ray(sv, px, py, rng, params.disable_wavelength_jitter != 0, params.disable_pixel_jitter != 0,
-                                lambda, weight);
+                                lambda, weight, has_tex ? &aux : nullptr, params.samples_per_pixel);
+    if (has_tex) st_aux(pa, slot, aux);
     ShmRay ray;
     ray.o[0] = r.o.x; ray.o[1] = r.o.y; ray.o[2] = r.o.z;
     ray.d[0] = r.d.x; ray.d[1] = r.d.y; ray.d[2] = r.d.z;
@@ -154,7 +175,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
     pa.pb_eta[slot] = make_float2(1.0f, 1.0f);
     pa.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
     pa.pixel[slot] = pix;
-    pa.flags[slot] = 0u;
+    pa.flags[slot] = has_tex ? (1u << 10) : 0u;  // camera rays always carry auxiliary rays (camera.rs:1070-1078)
     q_active[slot] = slot;  // first bounce: identity queue
     if (slot == 0) {
         qs->n_active[0] = total;
@@ -450,7 +471,9 @@ constexpr int SHADE_CHUNK = 2048;  // queue entries per workgroup chunk: ONE glo
 // vertex: f and pdf for NEE, sample_f) are compiled out of it.
 //   TRI_ONLY = true is the instantiation for scenes made of triangles only: no quadric / bilinear-patch interaction and light
 //   sampling code (with it the kernel needs 264 VGPRs, one wave per SIMD; without it 243, two waves).
-template <bool HAS_LAYERED, bool TRI_ONLY>
+//   HAS_TEX = true is the instantiation for scenes that bind image textures: the path carries ray differentials (texture.h),
+//   get_bsdf filters the MIP pyramids. One general instantiation <true, false, true>.
+template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters, int shadow_parity) {
@@ -532,7 +555,14 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                         }
                     }
                 }
-                BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+                // get_bsdf starts with compute_differentials(ray, camera, spp) (interaction.rs:197)
+                Differentials df;
+                AuxRays aux = aux_none();
+                if (HAS_TEX) {
+                    if (fl & (1u << 10)) aux = ld_aux(pa, path);
+                    df = compute_differentials(sv, si, aux, params.samples_per_pixel, params.disable_pixel_jitter != 0);
+                }
+                BSDF bsdf = get_bsdf<HAS_TEX>(sv, si, sv.materials[prim.material], lambda, &df);
                 if (!HAS_LAYERED) __builtin_assume(bsdf.bxdf.kind <= SHM_MATERIAL_THIN_DIELECTRIC);
                 if (params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
                 bool alive = (depth != params.max_depth);  // integrator.rs:830-834
@@ -626,7 +656,12 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                             pa.ctx1[path] = make_float4(nctx.pi.y.high, nctx.pi.z.high, nctx.n.x, nctx.n.y);
                             pa.ctx2[path] = make_float4(nctx.n.z, nctx.ns.x, nctx.ns.y, nctx.ns.z);
                             pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
-                            pa.flags[path] = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9);
+                            uint32_t aux_bit = 0u;
+                            if (HAS_TEX) {  // spawn_ray_with_differentials, interaction.rs:430-514
+                                AuxRays na = spawn_ray_differentials(si, df, aux, bs.wi, bs.flags, bs.eta);
+                                if (na.has) { st_aux(pa, path, na); aux_bit = 1u << 10; }
+                            }
+                            pa.flags[path] = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9) | aux_bit;
                             push_next = true;
                         }
                     }
@@ -653,6 +688,17 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
       __syncthreads();
     }
     (void)counters;
+}
+
+// get_bsdf for the two general (non-throughput) integrator kernels below: with image textures bound it starts with
+// compute_differentials; only camera rays carry auxiliary rays there (every later ray is interaction.spawn_ray(wi),
+// integrator.rs:547, 686, 716), flag bit 10 as in k_shade.
+__device__ BSDF get_bsdf_general(const SceneView& sv, const PathArrays& pa, uint32_t path, uint32_t fl, SurfaceInteraction& si,
+                                 const ShmMaterial& m, Wavelengths& lambda, const ShmRenderParams& params) {
+    if (pa.aux0 == nullptr) return get_bsdf(sv, si, m, lambda);
+    AuxRays aux = (fl & (1u << 10)) ? ld_aux(pa, path) : aux_none();
+    Differentials df = compute_differentials(sv, si, aux, params.samples_per_pixel, params.disable_pixel_jitter != 0);
+    return get_bsdf<true>(sv, si, m, lambda, &df);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -712,7 +758,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(Scen
                 }
                 if (depth != params.max_depth) {
                     depth += 1;
-                    BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+                    BSDF bsdf = get_bsdf_general(sv, pa, path, fl, si, sv.materials[prim.material], lambda, params);
                     V3 wo = -ray_d;
                     uint32_t pix = pa.pixel[path];
                     uint2 rs = pa.rng[path];
@@ -848,7 +894,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_randomwalk(
                 lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
                 lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
             }
-            const int depth = (int)(pa.flags[path] & 0xffu);
+            const uint32_t fl = pa.flags[path];
+            const int depth = (int)(fl & 0xffu);
             float4* rec = rw + (size_t)(2 * depth) * capacity + path;  // le at 2*depth, f cos at 2*depth + 1
             Spec le = spec_const(0.0f);
             if (hit.prim < 0) {
@@ -864,7 +911,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_randomwalk(
                 if (prim.area_light >= 0) le = area_light_l(sv, sv.lights[prim.area_light], si.n, wo, lambda);
                 rec[0] = st_spec(le);
                 if (depth != params.max_depth) {
-                    BSDF bsdf = get_bsdf(sv, si, sv.materials[prim.material], lambda);
+                    BSDF bsdf = get_bsdf_general(sv, pa, path, fl, si, sv.materials[prim.material], lambda, params);
                     uint32_t pix = pa.pixel[path];
                     uint2 rs = pa.rng[path];
                     Rng rng;
@@ -1037,7 +1084,7 @@ static uint64_t max_batch_paths() {
 // The batch limit on THIS device right now: SHM_BATCH_PATHS, bounded by 80 % of the memory that is free (plus what the
 // current workspace already holds), so that a GPU shared with other allocations degrades to more batches, not to an error.
 static uint64_t workspace_cap(const ShmScene* s) {
-    constexpr uint64_t BYTES_PER_PATH = 264 + 3 * 4;  // path state + three queues
+    const uint64_t BYTES_PER_PATH = 264 + 3 * 4 + (s->flat.has_textures ? 48 : 0);  // path state + three queues (+ auxiliary rays)
     uint64_t cap = max_batch_paths();
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -1070,6 +1117,8 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths) {
     WS(ray, ShmRay); WS(hit, ShmHit); WS(shadow_ray, ShmRay); WS(shadow_contrib, float4); WS(L, float4); WS(beta, float4);
     WS(lambda, float4); WS(lambda_pdf, float4); WS(ctx0, float4); WS(ctx1, float4); WS(ctx2, float4); WS(pb_eta, float2);
     WS(rng, uint2); WS(pixel, uint32_t); WS(flags, uint32_t);
+    s->pa.aux0 = s->pa.aux1 = s->pa.aux2 = nullptr;
+    if (s->flat.has_textures) { WS(aux0, float4); WS(aux1, float4); WS(aux2, float4); }
 #undef WS
     if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_active[0])) != SHM_OK) return rc;
     if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_active[1])) != SHM_OK) return rc;
@@ -1175,6 +1224,13 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if ((rc = dev_upload(s, f.sensor_r, &v.sensor_r_bar)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.sensor_g, &v.sensor_g_bar)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.sensor_b, &v.sensor_b_bar)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.image_textures, &v.image_textures)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.image_levels, &v.image_levels)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.texel_data, &v.texel_data)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.rgb2spec_scale, &v.rgb2spec_scale)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.rgb2spec_data, &v.rgb2spec_data)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.cs_illuminant, &v.cs_illuminant)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.ewa_lut, &v.ewa_lut)) != SHM_OK) return fail(rc);
     s->dsv = v;
 
     size_t w = (size_t)(f.film.pixel_bounds[2] - f.film.pixel_bounds[0]);
@@ -1328,6 +1384,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 else if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH)
                     hipLaunchKernelGGL(k_shade_simple, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
                                        s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, sh);
+                else if (s->flat.has_textures) launch_shade(k_shade<true, false, true>);
                 else if (s->flat.has_layered) { if (tri_only) launch_shade(k_shade<true, true>); else launch_shade(k_shade<true, false>); }
                 else { if (tri_only) launch_shade(k_shade<false, true>); else launch_shade(k_shade<false, false>); }
                 hipEventRecord(s1, s->stream);

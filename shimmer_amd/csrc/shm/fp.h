@@ -81,6 +81,7 @@ SHM_HD Float copysign(Float mag, Float sgn) {
 }
 SHM_HD Float floor(Float x) { return __builtin_floorf(x); }
 SHM_HD Float trunc(Float x) { return __builtin_truncf(x); }
+SHM_HD Float ceil(Float x) { return __builtin_ceilf(x); }
 
 // Rust f32::max / f32::min (IEEE maxNum/minNum: a NaN operand is ignored).
 SHM_HD Float max(Float a, Float b) { return is_nan(b) ? a : (is_nan(a) ? b : (a > b ? a : b)); }
@@ -341,6 +342,47 @@ SHM_HD Float log(Float x) {
     y = fma(-0.5f, z, y);
     Float r = m + y;
     return fma(fe, 0.693359375f, r);
+}
+// base-2 log (f32::log2 in the reference is the platform's; this one shares log()'s reduction and polynomial, and is exact
+// for powers of two: m = 0 there). Used for MIP level selection (mipmap.rs:150, 163).
+SHM_HD Float log2(Float x) {
+    if (is_nan(x)) return x;
+    if (x < 0.0f) return (x - x) / (x - x);
+    if (x == 0.0f) return -infinity();
+    if (is_inf(x)) return x;
+    uint32_t ux = float_to_bits(x);
+    int e = 0;
+    if ((ux & 0x7f800000u) == 0) {
+        x = x * 8388608.0f;
+        ux = float_to_bits(x);
+        e = -23;
+    }
+    e += (int)(ux >> 23) - 126;
+    Float m = bits_to_float((ux & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = m + m - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    Float z = m * m;
+    Float p = 7.0376836292e-2f;
+    p = fma(p, m, -1.1514610310e-1f);
+    p = fma(p, m, 1.1676998740e-1f);
+    p = fma(p, m, -1.2420140846e-1f);
+    p = fma(p, m, 1.4249322787e-1f);
+    p = fma(p, m, -1.6668057665e-1f);
+    p = fma(p, m, 2.0000714765e-1f);
+    p = fma(p, m, -2.4999993993e-1f);
+    p = fma(p, m, 3.3333331174e-1f);
+    Float y = m * z * p;
+    y = fma(-0.5f, z, y);
+    // (m + y) * log2(e), with log2(e) - 1 = 0.44269504088896340735992 split off as Cephes log2f does
+    Float r = y * 0.44269504088896340735992f;
+    r = fma(m, 0.44269504088896340735992f, r);
+    r += y;
+    r += m;
+    return r + (Float)e;
 }
 // log1p via the classic u = 1 + y correction.
 SHM_HD Float log1p(Float y) {

@@ -6,16 +6,17 @@
 //   light.rs:632-684              DiffuseAreaLight::{sample_li,pdf_li,l}
 //   light.rs:747-803              UniformInfiniteLight::{sample_li,pdf_li,le}
 //   light_sampler.rs:83-111       UniformLightSampler::{sample_light,pmf_light}
-//   interaction.rs:187-278        SurfaceInteraction::get_bsdf (constant textures: ray differentials are dead
-//                                 values and are not carried; bump_map with a constant displacement is executed
-//                                 literally so that signed zeros match, material.rs:1477-1508)
+//   interaction.rs:187-278        SurfaceInteraction::get_bsdf (ray differentials are carried only in scenes with image
+//                                 textures, texture.h: elsewhere they are dead values; bump_map with a constant
+//                                 displacement is executed literally so that signed zeros match, material.rs:1477-1508)
 //   material.rs:301-311,456-499,603-635,723-742   get_bxdf for Diffuse/Conductor/Dielectric/ThinDielectric
 //   sampling.rs:347-371, filter.rs:99-105         get_camera_sample, BoxFilter::sample
-//   camera.rs:1003-1079           PerspectiveCamera::generate_ray_differential (main ray only)
+//   camera.rs:1003-1079, 769-792  {Perspective,Orthographic}Camera::generate_ray_differential
 //   film.rs:548-574, 907-914      RgbFilm::add_sample, PixelSensor::to_sensor_rgb
 #pragma once
 #include "bxdf.h"
 #include "scene.h"
+#include "texture.h"
 
 namespace shm {
 
@@ -110,9 +111,12 @@ SHM_HD int light_sampler_sample(const SceneView& sv, Float u, Float& p) {
 }
 SHM_HD Float light_sampler_pmf(const SceneView& sv) { return sv.n_lights == 0 ? 0.0f : 1.0f / (Float)sv.n_lights; }
 
-// SurfaceInteraction::get_bsdf (interaction.rs:187-278) for Single materials with constant textures.
+// SurfaceInteraction::get_bsdf (interaction.rs:187-278).
 // lambda is mutable: DielectricMaterial terminates secondary wavelengths for dispersive eta.
-SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMaterial& m_in, Wavelengths& lambda) {
+// HAS_TEX: the scene binds image textures; `df` is what compute_differentials (the first statement of the reference's get_bsdf,
+// interaction.rs:197) left in the interaction. Without textures the differentials are dead values and df may be null.
+template <bool HAS_TEX = false>
+SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMaterial& m_in, Wavelengths& lambda, const Differentials* df = nullptr) {
     // Resolve mixed materials (interaction.rs:205-220, MixMaterial::choose_material material.rs:1308-1329). The reference takes
     // u from the tile's entropy-seeded rng; defined here as a hash of (wo, p, nesting level): reproducible, parity unpinned.
     const ShmMaterial* mp = &m_in;
@@ -139,6 +143,10 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
         V3 ns = normalize(cross(dpdu, dpdv));
         set_shading_geometry(si, ns, dpdu, dpdv, si.shading.dndu, si.shading.dndv, false);
     }
+    // MaterialEvalContext::from(&*self) after the shading geometry is final (interaction.rs:211, 245): TextureEvalContext part
+    TextureEvalContext tctx;
+    if (HAS_TEX) tctx = tex_ctx_from(si, *df);
+    auto tex = [&](const ShmSpectrum& s) { return spectrum_texture_evaluate<HAS_TEX>(sv, s, &tctx, lambda); };
     BxDF b;
     b.kind = m.kind;
     b.r = spec_const(0.0f);
@@ -154,12 +162,12 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
     b.max_depth = 0;
     b.n_samples = 1;
     if (m.kind == SHM_MATERIAL_DIFFUSE) {
-        b.r = clamp(spectrum_sample(m.a, sv.spectrum_data, lambda), 0.0f, 1.0f);  // material.rs:301-311
+        b.r = clamp(tex(m.a), 0.0f, 1.0f);  // material.rs:301-311
     } else if (m.kind == SHM_MATERIAL_CONDUCTOR) {  // material.rs:456-499
         Float ur = m.u_roughness, vr = m.v_roughness;
         if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
-        b.r = spectrum_sample(m.a, sv.spectrum_data, lambda);
-        b.k = spectrum_sample(m.b, sv.spectrum_data, lambda);
+        b.r = tex(m.a);
+        b.k = tex(m.b);
         b.mf = trowbridge_reitz_new(ur, vr);
     } else if (m.kind == SHM_MATERIAL_DIELECTRIC) {  // material.rs:603-635
         Float sampled_eta = spectrum_get(m.a, sv.spectrum_data, lambda.lambda[0]);
@@ -175,7 +183,7 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
         if (sampled_eta == 0.0f) sampled_eta = 1.0f;
         b.eta = sampled_eta;
     } else if (m.kind == SHM_MATERIAL_COATED_DIFFUSE) {  // material.rs:917-963
-        b.r = clamp(spectrum_sample(m.a, sv.spectrum_data, lambda), 0.0f, 1.0f);
+        b.r = clamp(tex(m.a), 0.0f, 1.0f);
         Float ur = m.u_roughness, vr = m.v_roughness;
         if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
         b.mf = trowbridge_reitz_new(ur, vr);
@@ -184,7 +192,7 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
         if (m.d.kind != SHM_SPECTRUM_CONSTANT) terminate_secondary(lambda);
         if (sampled_eta == 0.0f) sampled_eta = 1.0f;
         b.eta = sampled_eta;
-        b.albedo = clamp(spectrum_sample(m.c, sv.spectrum_data, lambda), 0.0f, 1.0f);
+        b.albedo = clamp(tex(m.c), 0.0f, 1.0f);
         b.g = clamp(m.g, -1.0f, 1.0f);
         b.max_depth = m.max_depth;
         b.n_samples = m.n_samples;
@@ -198,10 +206,10 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
         if (ieta == 0.0f) ieta = 1.0f;
         Spec ce, ck;
         if (!m.conductor_from_reflectance) {
-            ce = spectrum_sample(m.a, sv.spectrum_data, lambda);
-            ck = spectrum_sample(m.b, sv.spectrum_data, lambda);
+            ce = tex(m.a);
+            ck = tex(m.b);
         } else {
-            Spec r = clamp(spectrum_sample(m.a, sv.spectrum_data, lambda), 0.0f, 0.9999f);  // "avoid r == 1 NaN case"
+            Spec r = clamp(tex(m.a), 0.0f, 0.9999f);  // "avoid r == 1 NaN case"
             ce = spec_const(1.0f);
             ck = 2.0f * spec_sqrt(r) / spec_sqrt(clamp_zero(spec_const(1.0f) - r));
         }
@@ -215,7 +223,7 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
         b.r = ce;
         b.k = ck;
         b.eta = ieta;
-        b.albedo = clamp(spectrum_sample(m.c, sv.spectrum_data, lambda), 0.0f, 1.0f);
+        b.albedo = clamp(tex(m.c), 0.0f, 1.0f);
         b.g = clamp(m.g, -1.0f, 1.0f);
         b.max_depth = m.max_depth;
         b.n_samples = m.n_samples;
@@ -223,10 +231,71 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
     return bsdf_new(si.shading.n, si.shading.dpdu, b);
 }
 
-// evaluate_pixel_sample head (integrator.rs:338-362): wavelength sample, camera sample, camera ray.
+// {Perspective,Orthographic}Camera::generate_ray_differential (camera.rs:1003-1079, 769-792) for one CameraSample; `aux`
+// (may be null) receives the auxiliary rays.
+SHM_HD Ray camera_generate_ray_differential(const ShmCamera& cam, V2 p_film, V2 p_lens, AuxRays* aux) {
+    V3 p_camera = xf_point(cam.camera_from_raster, v3(p_film.x, p_film.y, 0.0f));
+    Ray base;
+    if (cam.kind == SHM_CAMERA_ORTHOGRAPHIC) {
+        // camera.rs:769-792 returns this ray in CAMERA space: unlike generate_ray (:747-767) it never applies render_from_camera.
+        // The integrators call generate_ray_differential (integrator.rs:351), so that is what is rendered; kept as written (with
+        // CameraWorld render space the two spaces differ by the camera's rotation only). No depth of field there either.
+        base.o = p_camera;
+        base.d = v3(0.0f, 0.0f, 1.0f);
+        if (aux) {
+            aux->has = true;
+            aux->rx_o = base.o + ld3(cam.dx_camera);
+            aux->ry_o = base.o + ld3(cam.dy_camera);
+            aux->rx_d = base.d;
+            aux->ry_d = base.d;
+        }
+        return base;
+    }
+    base.o = v3s(0.0f);
+    base.d = normalize(p_camera);
+    if (cam.lens_radius > 0.0f) {
+        V2 pl = cam.lens_radius * sample_uniform_disk_concentric(p_lens);
+        Float ft = cam.focal_distance / base.d.z;
+        V3 p_focus = base.o + base.d * ft;
+        base.o = v3(pl.x, pl.y, 0.0f);
+        base.d = normalize(p_focus - base.o);
+    }
+    if (aux) {
+        AuxRays a;
+        a.has = true;
+        if (cam.lens_radius > 0.0f) {  // camera.rs:1036-1056
+            V2 pl = cam.lens_radius * sample_uniform_disk_concentric(p_lens);
+            V3 dx = normalize(p_camera + ld3(cam.dx_camera));
+            Float ft = cam.focal_distance / dx.z;
+            V3 p_focus = v3s(0.0f) + ft * dx;
+            a.rx_o = v3(pl.x, pl.y, 0.0f);
+            a.rx_d = normalize(p_focus - a.rx_o);
+            V3 dy = normalize(p_camera + ld3(cam.dy_camera));
+            ft = cam.focal_distance / dy.z;
+            p_focus = v3s(0.0f) + ft * dy;
+            a.ry_o = v3(pl.x, pl.y, 0.0f);
+            a.ry_d = normalize(p_focus - a.ry_o);
+        } else {  // camera.rs:1057-1068
+            a.rx_o = base.o;
+            a.ry_o = base.o;
+            a.rx_d = normalize(p_camera + ld3(cam.dx_camera));
+            a.ry_d = normalize(p_camera + ld3(cam.dy_camera));
+        }
+        // Transform::apply_ray for a RayDifferential, transform.rs:534-555: plain point / vector applies for the auxiliary rays
+        aux->has = true;
+        aux->rx_o = xf_point(cam.render_from_camera, a.rx_o);
+        aux->rx_d = xf_vector(cam.render_from_camera, a.rx_d);
+        aux->ry_o = xf_point(cam.render_from_camera, a.ry_o);
+        aux->ry_d = xf_vector(cam.render_from_camera, a.ry_d);
+    }
+    return xf_ray(cam.render_from_camera, base);
+}
+
+// evaluate_pixel_sample head (integrator.rs:338-362): wavelength sample, camera sample, camera ray (+ its scaled differentials).
 // The sampler dimension order (1d lambda | 2d filter | 2d lens | 1d time) is the reference's.
 SHM_HD Ray generate_camera_ray(const SceneView& sv, int px, int py, Rng& rng, bool disable_wavelength_jitter,
-                               bool disable_pixel_jitter, Wavelengths& lambda, Float& filter_weight) {
+                               bool disable_pixel_jitter, Wavelengths& lambda, Float& filter_weight, AuxRays* aux = nullptr,
+                               int samples_per_pixel = 1) {
     Float lu = disable_wavelength_jitter ? 0.5f : sampler_get_1d(rng);
     lambda = sample_visible(lu);
     // get_camera_sample, sampling.rs:347-371 (filter.sample(get_pixel_2d()) is drawn in both branches)
@@ -242,25 +311,12 @@ SHM_HD Ray generate_camera_ray(const SceneView& sv, int px, int py, Rng& rng, bo
         (void)sampler_get_1d(rng);  // time
     }
     filter_weight = 1.0f;
-    // PerspectiveCamera::generate_ray_differential, camera.rs:1003-1028 (main ray)
-    const ShmCamera& cam = sv.camera;
-    V3 p_camera = xf_point(cam.camera_from_raster, v3(p_film.x, p_film.y, 0.0f));
-    Ray base;
-    if (cam.kind == SHM_CAMERA_ORTHOGRAPHIC) {  // OrthographicCamera::generate_ray_differential, camera.rs:769-792 (no depth of field there)
-        base.o = p_camera;
-        base.d = v3(0.0f, 0.0f, 1.0f);
-        return xf_ray(cam.render_from_camera, base);
+    Ray r = camera_generate_ray_differential(sv.camera, p_film, p_lens, aux);
+    if (aux) {  // integrator.rs:356-362
+        Float ray_diff_scale = max(0.125f, 1.0f / sqrt((Float)samples_per_pixel));
+        if (!disable_pixel_jitter) scale_differentials(r, *aux, ray_diff_scale);
     }
-    base.o = v3s(0.0f);
-    base.d = normalize(p_camera);
-    if (cam.lens_radius > 0.0f) {
-        V2 pl = cam.lens_radius * sample_uniform_disk_concentric(p_lens);
-        Float ft = cam.focal_distance / base.d.z;
-        V3 p_focus = base.o + base.d * ft;
-        base.o = v3(pl.x, pl.y, 0.0f);
-        base.d = normalize(p_focus - base.o);
-    }
-    return xf_ray(cam.render_from_camera, base);
+    return r;
 }
 
 // PixelSensor::to_sensor_rgb + the clamp of RgbFilm::add_sample (film.rs:907-914, 556-565).

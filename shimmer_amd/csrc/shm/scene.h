@@ -8,6 +8,8 @@
 //                A leaf's primitive_offset indexes this array directly: one 48-B read per candidate.
 //   primitives[] material / area-light ids per leaf-order slot (primitive.rs:66-130), read once per path vertex
 //   vi/vn/vs/vuv global per-vertex shading arrays (only read when a mesh has N/S/uv)
+//   texel_data   every MIP level of every image texture as f32, [level][row from the top][x][channel]; image_levels[] holds
+//                {width, height, offset}; the rgb2spec coefficient table (3 x res^3 x 3 floats) sits beside it
 #pragma once
 #include "shapes.h"
 #include "patch.h"
@@ -68,6 +70,15 @@ struct SceneView {
     const Float* sensor_r_bar;
     const Float* sensor_g_bar;
     const Float* sensor_b_bar;
+    // image textures (ABI v6; all null / 0 in a scene without them)
+    const ShmImageTexture* image_textures;
+    const ShmImageLevel* image_levels;
+    const Float* texel_data;
+    uint32_t rgb2spec_res;
+    const Float* rgb2spec_scale;
+    const Float* rgb2spec_data;
+    const Float* cs_illuminant;  // 471 floats, 360..=830
+    const Float* ewa_lut;        // MIP_FILTER_LUT, 128 floats
 };
 
 SHM_HD V3 ld3(const Float* p) { return v3(p[0], p[1], p[2]); }

@@ -90,6 +90,25 @@ def spectrum_to_photometric(dense):
     return acc
 
 
+def generate_pyramid(image):
+    """Image::generate_pyramid (image.rs:699-800) for a float image whose sides are powers of two (other sizes go through
+    float_resize_up first in the reference: host-side, not mirrored): each level is the 2x2 box average of the previous one,
+    f32, summed in the reference's order; the last level is 1x1."""
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    h, w = img.shape[:2]
+    assert h & (h - 1) == 0 and w & (w - 1) == 0, "power-of-two sides only"
+    levels = [img]
+    while img.shape[0] > 1 or img.shape[1] > 1:
+        h, w = img.shape[:2]
+        nh, nw = max(1, (h + 1) // 2), max(1, (w + 1) // 2)
+        y0, x0 = 2 * np.arange(nh), 2 * np.arange(nw)
+        y1, x1 = (y0 + 1 if h > 1 else y0), (x0 + 1 if w > 1 else x0)
+        a, b, c, dd = img[y0][:, x0], img[y0][:, x1], img[y1][:, x0], img[y1][:, x1]
+        img = (f32(0.25) * (((a + b).astype(np.float32) + c).astype(np.float32) + dd).astype(np.float32)).astype(np.float32)
+        levels.append(img)
+    return levels
+
+
 def _as_f32(a, shape=None):
     a = np.ascontiguousarray(a, dtype=np.float32)
     if shape is not None:
@@ -124,6 +143,11 @@ class SceneBuilder:
         self._keep = []
         self._tri_count = 0
         self._emission_cache = {}
+        self.textures = []      # abi.ShmImageTexture
+        self.tex_levels = []    # (width, height, offset)
+        self.texels = []        # float32 arrays
+        self.texel_len = 0
+        self.color_space = None  # dict(res, scale, data, illuminant)
 
     # ---- spectra ----
     def spectrum_constant(self, c):
@@ -165,6 +189,55 @@ class SceneBuilder:
         else:
             s.kind = abi.SHM_SPECTRUM_RGB_ALBEDO
         return s
+
+    # ---- image textures (ABI v6) ----
+    def use_srgb_color_space(self):
+        """RgbColorSpace::SRGB as the device needs it: the rgb2spec coefficient table (tools/gen_rgb2spec.py; the reference loads
+        rgbtospec/srgb.spec, rgb_to_spectra.rs:27-31) and the D65 illuminant, densely sampled."""
+        if self.color_space is None:
+            t = np.load(Path(__file__).resolve().parent / "data" / "rgb2spec_srgb.npz")
+            lam, val = piecewise_from_interleaved(tables()["CIE_ILLUM_D6500"], False)
+            illum = np.interp(np.arange(360, 831, dtype=np.float64), lam.astype(np.float64), val.astype(np.float64)).astype(np.float32)
+            self.color_space = dict(res=int(t["res"]), scale=_as_f32(t["scale"]), data=_as_f32(t["data"]).ravel(), illuminant=illum)
+        return self.color_space
+
+    def add_image_texture(self, image, filter="bilinear", wrap="repeat", scale=1.0, invert=False, spectrum_type="albedo",
+                          mapping="uv", su=1.0, sv=1.0, du=0.0, dv=0.0, max_anisotropy=8.0, texture_from_render=None,
+                          vs=(1.0, 0.0, 0.0), vt=(0.0, 1.0, 0.0), color_space=True, pyramid=None):
+        """SpectrumImageTexture::create (texture.rs:728-775) with its defaults. `image`: (H, W) or (H, W, 3) linear float values,
+        row 0 = top. Returns the ShmSpectrum that binds the texture to a material's spectrum slot. `pyramid` overrides the levels
+        (list of arrays, finest first, ending in 1x1)."""
+        levels = pyramid if pyramid is not None else generate_pyramid(image)
+        nc = 1 if levels[0].ndim == 2 else levels[0].shape[2]
+        assert nc in (1, 3)
+        t = abi.ShmImageTexture()
+        t.mapping = {"uv": abi.SHM_TEXMAP_UV, "spherical": abi.SHM_TEXMAP_SPHERICAL, "cylindrical": abi.SHM_TEXMAP_CYLINDRICAL,
+                     "planar": abi.SHM_TEXMAP_PLANAR}[mapping]
+        t.su, t.sv, t.du, t.dv = float(su), float(sv), float(du), float(dv)
+        t.vs[:], t.vt[:] = [float(x) for x in vs], [float(x) for x in vt]
+        t.texture_from_render[:] = [float(x) for x in _as_f32(IDENTITY if texture_from_render is None else texture_from_render).ravel()]
+        t.filter = {"point": abi.SHM_TEXFILTER_POINT, "bilinear": abi.SHM_TEXFILTER_BILINEAR, "trilinear": abi.SHM_TEXFILTER_TRILINEAR,
+                    "ewa": abi.SHM_TEXFILTER_EWA}[filter.lower()]
+        t.max_anisotropy = float(max_anisotropy)
+        t.wrap = {"black": abi.SHM_WRAP_BLACK, "clamp": abi.SHM_WRAP_CLAMP, "repeat": abi.SHM_WRAP_REPEAT,
+                  "octahedralsphere": abi.SHM_WRAP_OCTAHEDRAL_SPHERE}[wrap]
+        t.scale, t.invert = float(scale), int(bool(invert))
+        t.spectrum_type = {"albedo": abi.SHM_SPECTRUM_TYPE_ALBEDO, "unbounded": abi.SHM_SPECTRUM_TYPE_UNBOUNDED,
+                           "illuminant": abi.SHM_SPECTRUM_TYPE_ILLUMINANT}[spectrum_type]
+        t.n_channels = nc
+        t.has_color_space = int(bool(color_space))
+        if color_space:
+            self.use_srgb_color_space()
+        t.first_level, t.n_levels = len(self.tex_levels), len(levels)
+        for lv in levels:
+            a = _as_f32(lv)
+            self.tex_levels.append((a.shape[1], a.shape[0], self.texel_len))
+            self.texels.append(a.ravel())
+            self.texel_len += a.size
+        self.textures.append(t)
+        sp = abi.ShmSpectrum()
+        sp.kind, sp.offset = abi.SHM_SPECTRUM_IMAGE_TEXTURE, len(self.textures) - 1
+        return sp
 
     def spectrum_named(self, name):
         """NamedSpectrum (spectra/named_spectrum.rs:13-27): metals / glasses as PiecewiseLinear."""
@@ -480,6 +553,23 @@ class SceneBuilder:
         d.camera, d.film = self.camera, self.film
         d.n_patch_meshes, d.patch_meshes = len(self.patch_meshes), patch_meshes
         self._keep = [nodes, prim_arr, lights, meshes, spheres, materials, spec, bounds, order, patch_meshes]
+        if self.textures:
+            textures = (abi.ShmImageTexture * len(self.textures))(*self.textures)
+            levels = (abi.ShmImageLevel * len(self.tex_levels))()
+            for i, (w, h, off) in enumerate(self.tex_levels):
+                levels[i].width, levels[i].height, levels[i].texel_offset = w, h, off
+            texels = np.concatenate(self.texels).astype(np.float32)
+            lut = _as_f32(tables()["MIP_FILTER_LUT"])
+            d.n_image_textures, d.image_textures = len(self.textures), textures
+            d.n_image_levels, d.image_levels = len(self.tex_levels), levels
+            d.n_texel_floats, d.texel_data = texels.size, _fptr(texels)
+            d.ewa_filter_lut = _fptr(lut)
+            self._keep += [textures, levels, texels, lut]
+            if self.color_space is not None:
+                cs = self.color_space
+                d.color_space.rgb2spec_res = cs["res"]
+                d.color_space.rgb2spec_scale, d.color_space.rgb2spec_data = _fptr(cs["scale"]), _fptr(cs["data"])
+                d.color_space.illuminant = _fptr(cs["illuminant"])
         info = dict(n_nodes=n_nodes.value, n_primitives=n, order=order, slot_of_input=slot_of_input, bounds=bounds)
         return d, info
 

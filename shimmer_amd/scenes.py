@@ -83,7 +83,20 @@ def _two_point_spectrum(b, lo, hi):
     return b.spectrum_piecewise(np.array([359.0, 831.0], np.float32), np.array([lo, hi], np.float32))
 
 
-def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=False, patch_skew=0.0):
+def test_image(size=64, channels=3, seed=7):
+    """A deterministic float test image (row 0 = top): a checker of soft colours modulated by value noise, every value in
+    [0.05, 0.95] (no exact zeros: rgb2spec's published fetch divides by the largest component)."""
+    y, x = np.mgrid[0:size, 0:size]
+    checker = (((x // max(1, size // 8)) + (y // max(1, size // 8))) & 1).astype(np.float64)
+    pts = np.stack([x.ravel() / size, y.ravel() / size, np.zeros(size * size)], axis=1)
+    noise = _value_noise(pts, seed, octaves=2).reshape(size, size)
+    base = np.stack([0.15 + 0.7 * checker, 0.25 + 0.5 * (x / (size - 1.0)), 0.8 - 0.6 * checker * (y / (size - 1.0))], axis=2)
+    img = np.clip(base + 0.25 * noise[..., None], 0.05, 0.95).astype(np.float32)
+    return img[..., 1].copy() if channels == 1 else img
+
+
+def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=False, patch_skew=0.0, textured=False,
+                texture_filter=None):
     """S2 (config C2): 5 walls x 2 + 2 boxes x 5 faces x 2 + light 2 = 32 triangles.
     coated=True: the tall box becomes CoatedConductor (rough interface, Cu), the short one CoatedDiffuse with a scattering
     medium between the interfaces, the floor CoatedDiffuse with a smooth interface (SURVEY §8f-1 materials)."""
@@ -104,6 +117,26 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=Fal
         short_m = b.material_mix(white, gold, 0.5)
         tall_m = b.material_mix(b.material_mix(red, green, 0.3), b.material_coated_diffuse(reflectance=0.7, roughness=0.1), 0.6)
         floor_m = b.material_mix(white, black, 0.0)  # amount <= 0: always the first
+    ceil_m, back_m, left_m, right_m = white, white, red, green
+    if textured:
+        # SpectrumImageTexture on every wall, one combination of mapping / filter / wrap / spectrum type each; the
+        # tall box is a mirror and the short one glass so that specular reflection AND transmission differentials reach textures
+        tf = (lambda default: texture_filter or default)
+        img3, img1 = test_image(64, 3), test_image(32, 1, seed=11)
+        to_render = np.asarray(rfw, np.float32).reshape(4, 4)
+        floor_m = b.material_diffuse(b.add_image_texture(img3, filter=tf("ewa"), wrap="repeat", su=3.0, sv=3.0))
+        back_m = b.material_diffuse(b.add_image_texture(img1, filter=tf("trilinear"), wrap="clamp", color_space=False))
+        left_m = b.material_diffuse(b.add_image_texture(img3, filter=tf("point"), wrap="repeat", spectrum_type="unbounded", scale=0.9,
+                                                        mapping="planar", vs=(0.0, 0.5, 0.0), vt=(0.0, 0.0, 0.5), du=0.1, dv=0.2,
+                                                        texture_from_render=np.linalg.inv(to_render.astype(np.float64))))
+        right_m = b.material_diffuse(b.add_image_texture(img3, filter=tf("bilinear"), wrap="black", spectrum_type="illuminant", scale=0.8,
+                                                         mapping="spherical", texture_from_render=np.linalg.inv(to_render.astype(np.float64))))
+        ceil_m = b.material_coated_diffuse(reflectance=b.add_image_texture(img3, filter=tf("ewa"), invert=True, mapping="cylindrical",
+                                                                            max_anisotropy=4.0, wrap="octahedralsphere",
+                                                                            texture_from_render=np.linalg.inv(to_render.astype(np.float64))),
+                                           roughness=0.2, albedo=b.add_image_texture(img1, filter=tf("bilinear")), thickness=0.05)
+        tall_m = b.material_conductor(b.spectrum_named("metal-Ag-eta"), b.spectrum_named("metal-Ag-k"), roughness=0.0)
+        short_m = b.material_dielectric(1.5)
     # room [-1,1] x [0,2] x [-1,1], open towards +z (camera side); inward-facing windings via reversed quads
     def inward(q):
         p, vi = q
@@ -113,13 +146,18 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=Fal
     back = _quad((-1, 0, -1), (-1, 2, -1), (1, 2, -1), (1, 0, -1))
     left = _quad((-1, 0, -1), (-1, 0, 1), (-1, 2, 1), (-1, 2, -1))
     right = inward(_quad((1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1)))
-    p, vi = _merge([ceil_, back])
-    b.add_mesh(_to_render(p, rfw), vi, white)
-    b.add_mesh(_to_render(floor[0], rfw), floor[1], floor_m)
+    quad_uv = np.array([(0, 0), (1, 0), (1, 1), (0, 1)], np.float32) if textured else None
+    if textured:
+        b.add_mesh(_to_render(ceil_[0], rfw), ceil_[1], ceil_m)
+        b.add_mesh(_to_render(back[0], rfw), back[1], back_m, uv=quad_uv)
+    else:
+        p, vi = _merge([ceil_, back])
+        b.add_mesh(_to_render(p, rfw), vi, white)
+    b.add_mesh(_to_render(floor[0], rfw), floor[1], floor_m, uv=quad_uv)
     p, vi = left
-    b.add_mesh(_to_render(p, rfw), vi, red)
+    b.add_mesh(_to_render(p, rfw), vi, left_m)
     p, vi = right
-    b.add_mesh(_to_render(p, rfw), vi, green)
+    b.add_mesh(_to_render(p, rfw), vi, right_m)
     # two boxes, 5 faces each (no bottom), the tall one rotated about y
     def rot_y(p, deg, centre):
         a = np.deg2rad(deg)
@@ -143,7 +181,7 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=Fal
     else:
         p, vi = _quad((-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (0.3, 1.98, 0.3), (-0.3, 1.98, 0.3))
         b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=20.0)
-    return _finish(b, lib, name="S2 cornell box" + (" (coated)" if coated else "") + (" (mix)" if mix else "") + (" (patches)" if patches else ""))
+    return _finish(b, lib, name="S2 cornell box" + (" (coated)" if coated else "") + (" (mix)" if mix else "") + (" (patches)" if patches else "") + (" (textured)" if textured else ""))
 
 
 def _hash3(ix, iy, iz, seed):
@@ -335,10 +373,30 @@ def random_scene(lib, seed, width=40, height=32):
     lens = 0.05 if seed % 2 else 0.0
     # every fourth seed looks through an OrthographicCamera (camera.rs:658-840; its screen window spans [-aspect, aspect] x [-1, 1]
     # world units, so it sees the middle of the scene)
-    rfw = b.set_camera_look_at(lib, (0.0, 1.2, 6.0), (0.0, 0.8, 0.0), (0, 1, 0), 42.0, lens_radius=lens, focal_distance=6.0,
-                               orthographic=bool(seed % 4 == 2))
+    # (the reference's OrthographicCamera::generate_ray_differential leaves its rays in camera space, camera.rs:769-792: such a
+    # camera only sees the scene if its axes are the world's, so the orthographic seeds look down +z with y up, from just in front of the back wall)
+    ortho = bool(seed % 4 == 2)
+    rfw = b.set_camera_look_at(lib, (0.0, 1.0, -2.9) if ortho else (0.0, 1.2, 6.0), (0.0, 1.0, 0.0) if ortho else (0.0, 0.8, 0.0), (0, 1, 0), 42.0,
+                               lens_radius=lens, focal_distance=6.0, orthographic=ortho)
+
+    # seeds >= 12 bind image textures to about half of the spectrum-texture slots, options drawn from their own
+    # generator so that the scenes of the earlier seeds stay what they were
+    trng = np.random.Generator(np.random.PCG64(1000 + seed))
+    world_from_render = np.linalg.inv(np.asarray(rfw, np.float64).reshape(4, 4))
 
     def spec():
+        if seed >= 12 and trng.random() < 0.5:
+            nc = int(trng.choice([1, 3]))
+            return b.add_image_texture(test_image(int(trng.choice([8, 16, 32])), nc, seed=int(trng.integers(0, 99))),
+                                       filter=str(trng.choice(["point", "bilinear", "trilinear", "ewa"])),
+                                       wrap=str(trng.choice(["black", "clamp", "repeat", "octahedralsphere"])),
+                                       scale=float(trng.uniform(0.5, 1.2)), invert=bool(trng.random() < 0.3),
+                                       spectrum_type=str(trng.choice(["albedo", "unbounded", "illuminant"])),
+                                       mapping=str(trng.choice(["uv", "uv", "planar", "spherical", "cylindrical"])),
+                                       su=float(trng.uniform(0.5, 4.0)), sv=float(trng.uniform(0.5, 4.0)), du=float(trng.uniform(0, 1)),
+                                       dv=float(trng.uniform(0, 1)), max_anisotropy=float(trng.choice([1.0, 4.0, 8.0, 16.0])),
+                                       vs=tuple(trng.uniform(-0.5, 0.5, 3)), vt=tuple(trng.uniform(-0.5, 0.5, 3)),
+                                       texture_from_render=world_from_render, color_space=bool(nc == 3 or trng.random() < 0.5))
         k = rng.integers(0, 4)
         if k == 0:
             return float(rng.uniform(0.1, 0.9))

@@ -9,10 +9,10 @@ import pytest
 import oracle_py
 from shimmer_amd import render, scenes
 
-SEEDS = list(range(12))
+SEEDS = list(range(16))  # 12..15 bind image textures
 
 
-@pytest.mark.parametrize("seed", SEEDS[:4])
+@pytest.mark.parametrize("seed", SEEDS[:4] + [12, 13])
 def test_oracle_random_scene(lib, seed):
     sc = scenes.random_scene(lib, seed)
     p = render.make_params(seed=seed, spp=4, max_depth=6)

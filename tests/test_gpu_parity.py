@@ -48,6 +48,8 @@ SCENES = {
     "S2_cornell_patches": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, patches=True), 8, 5),  # BilinearPatch: rectangle light + curved patch
     "S2_cornell_patches_skewed": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, patches=True, patch_skew=2e-3), 4, 5),  # area-sampled patch light
     "S2_cornell_mix": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, mix=True), 8, 5),  # MixMaterial, nested, with a coated leaf
+    # image textures (every mapping / filter / wrap / spectrum type), ray differentials through a mirror and glass
+    "S2_cornell_textured": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, textured=True), 8, 6),
 }
 
 
@@ -302,6 +304,25 @@ def test_random_walk_integrator_parity(env):
                                                  film.ctypes.data_as(C.c_void_p), None, None), "shm_integrator_render")
         assert np.array_equal(film, fo)
         gpu.close(); orc.close()
+
+
+@pytest.mark.parametrize("integrator", ["path", "simplepath", "randomwalk"])
+@pytest.mark.parametrize("texture_filter", ["point", "bilinear", "trilinear", "ewa"])
+def test_textured_parity_per_filter_and_integrator(env, integrator, texture_filter):
+    """Image textures under each MIPMap filter and each integrator (the two general ones only carry the camera ray's
+    differentials, every later vertex goes through Camera::approximate_dp_dxy), with and without pixel jitter (the differential
+    scaling of integrator.rs:356-362 and camera.rs:344-348) and at an spp where that scale is not a power of two."""
+    lib, oracle_py, render, scenes = env
+    sc = scenes.cornell_box(lib, 40, 40, textured=True, texture_filter=texture_filter)
+    gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+    for dpj, spp in ((False, 6), (True, 2)):
+        p = render.make_params(seed=5, spp=spp, max_depth=5, integrator=integrator, disable_pixel_jitter=dpj)
+        fg, sg = gpu.render(p)
+        fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
+        assert np.array_equal(fg, fo) and np.isfinite(render.film_to_rgb(fg)).all() and render.film_to_rgb(fg).max() > 0
+        for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+            assert sg[k] == so[k], k
+    gpu.close(); orc.close()
 
 
 def test_extreme_render_parameters(env):

@@ -267,32 +267,45 @@ def test_integrator_mirror_errors(lib):
 def test_orthographic_camera(lib):
     """OrthographicCamera (camera.rs:658-840) through the host mirror + the oracle's camera-ray generator: every ray runs along
     the view direction, origins span the screen window ([-aspect, aspect] x [-1, 1] around the camera position, y down in
-    raster space), one pixel apart by dx_camera / dy_camera."""
+    raster space), one pixel apart by dx_camera / dy_camera.
+    The integrators call generate_ray_differential (integrator.rs:351), and OrthographicCamera's (camera.rs:769-792) returns its
+    ray in CAMERA space: it never applies render_from_camera, unlike generate_ray (:747-767). That is what the reference renders,
+    so it is what is restated: correct for a camera whose axes are the world's, and the second half of this test pins the
+    behaviour for a rotated one."""
     import oracle_py
     from oracle_py import fa  # noqa: F401
-    b = scn.SceneBuilder()
-    b.set_film(64, 32)
-    rfw = b.set_camera_look_at(lib, (1.0, 2.0, 5.0), (1.0, 2.0, 0.0), (0, 1, 0), 30.0, orthographic=True)
-    assert b.camera.kind == abi.SHM_CAMERA_ORTHOGRAPHIC
-    m = b.material_diffuse(0.5)
-    p = np.array([(-9, -9, -1), (9, -9, -1), (0, 9, -1)], np.float32)
-    pr = (np.c_[p, np.ones(3, np.float32)] @ rfw.T)[:, :3]
-    b.add_mesh(pr, [[0, 1, 2]], m)
-    desc, _ = b.build(lib)
-    o = oracle_py.Oracle(desc)
-    rays = {}
-    for (px, py) in ((0, 0), (63, 0), (0, 31), (32, 16), (33, 16), (32, 17)):
-        out = (C.c_float * 14)()
-        o.lib.orc_fn_camera_ray(o.handle, px, py, 0, 0, out)
-        rays[(px, py)] = np.array(out[:6], np.float64)
+
+    def rays_of(pos, look_at):
+        b = scn.SceneBuilder()
+        b.set_film(64, 32)
+        rfw = b.set_camera_look_at(lib, pos, look_at, (0, 1, 0), 30.0, orthographic=True)
+        assert b.camera.kind == abi.SHM_CAMERA_ORTHOGRAPHIC
+        m = b.material_diffuse(0.5)
+        p = np.array([(-9, -9, 1), (9, -9, 1), (0, 9, 1)], np.float32)
+        pr = (np.c_[p, np.ones(3, np.float32)] @ rfw.T)[:, :3]
+        b.add_mesh(pr, [[0, 1, 2]], m)
+        desc, _ = b.build(lib)
+        o = oracle_py.Oracle(desc)
+        rays = {}
+        for (px, py) in ((0, 0), (63, 0), (0, 31), (32, 16), (33, 16), (32, 17)):
+            out = (C.c_float * 14)()
+            o.lib.orc_fn_camera_ray(o.handle, px, py, 0, 0, out)
+            rays[(px, py)] = np.array(out[:6], np.float64)
+        o.close()
+        return b, rays
+
+    b, rays = rays_of((1.0, 2.0, -5.0), (1.0, 2.0, 0.0))  # looking down +z with y up: camera axes == world axes
     for r in rays.values():
-        assert np.allclose(r[3:], (0, 0, -1), atol=1e-6)  # looking down -z in world == render orientation (CameraWorld translates only)
-    # render space = world translated by -camera position: the film centre is the origin, x spans [-2, 2], y [-1, 1]; look_at's
-    # camera x axis is up x dir = -x_world here (transform.rs:270-303), so raster x = 0 is world x = +2
-    assert abs(rays[(0, 0)][0] - 2.0) < 0.08 and abs(rays[(63, 0)][0] + 2.0) < 0.08
+        assert np.allclose(r[3:], (0, 0, 1), atol=1e-6)
+    # render space = world translated by -camera position: the film centre is the origin, x spans [-2, 2], y [-1, 1]
+    assert abs(rays[(0, 0)][0] + 2.0) < 0.08 and abs(rays[(63, 0)][0] - 2.0) < 0.08
     assert rays[(0, 0)][1] > 0.9 and rays[(0, 31)][1] < -0.9  # raster y grows downwards
     dx = rays[(33, 16)][:3] - rays[(32, 16)][:3]
     dy = rays[(32, 17)][:3] - rays[(32, 16)][:3]
     assert np.allclose(np.abs(dx), np.abs(np.array(list(b.camera.dx_camera))), atol=0.08)  # jittered samples: one pixel +- the jitter
     assert abs(abs(dy[1]) - abs(b.camera.dy_camera[1])) < 0.08
-    o.close()
+    assert np.allclose(b.camera.min_pos_differential_x[:], b.camera.dx_camera[:]) and np.allclose(b.camera.min_dir_differential_y[:], 0)  # camera.rs:733-736
+    # a camera turned to look down -z: the rays are the SAME camera-space rays (still +z), not rotated into render space
+    _, turned = rays_of((1.0, 2.0, 5.0), (1.0, 2.0, 0.0))
+    for k in rays:
+        assert np.array_equal(turned[k], rays[k])

@@ -13,6 +13,7 @@ from pathlib import Path
 import numpy as np
 
 REF = Path("/root/reference/src/spectra")
+MIPMAP = Path("/root/reference/src/mipmap.rs")  # MIP_FILTER_LUT: the 128 tabulated EWA filter weights (a data table like the others)
 OUT = Path(__file__).resolve().parents[1] / "shimmer_amd" / "data" / "spectral_tables.npz"
 WANT = {
     "cie.rs": ["CIE_LAMBDA", "CIE_X", "CIE_Y", "CIE_Z"],
@@ -32,6 +33,10 @@ def main():
                 sys.exit(f"table {name} not found in {fname}")
             vals = [float(x) for x in re.findall(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?", m.group(2))]
             tables[name] = np.asarray(vals, dtype=np.float32)
+    text = MIPMAP.read_text()
+    m = re.search(r"const\s+MIP_FILTER_LUT\s*:\s*\[Float;\s*MIP_FILTER_LUT_SIZE\]\s*=\s*\[(.*?)\];", text, re.S)
+    tables["MIP_FILTER_LUT"] = np.asarray([float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()], dtype=np.float32)
+    assert tables["MIP_FILTER_LUT"].size == 128
     assert tables["CIE_X"].size == 471 and tables["CIE_LAMBDA"][0] == 360.0 and tables["CIE_LAMBDA"][-1] == 830.0
     tables["CIE_Y_INTEGRAL"] = np.float32(106.856895)  # spectra/cie.rs:11
     OUT.parent.mkdir(parents=True, exist_ok=True)
