@@ -18,7 +18,8 @@
 // (one ulp of difference flips Russian-roulette / hit decisions and would void a per-pixel tolerance).
 // Those headers are pinned independently: tests/test_oracle_golden.py checks them against the reference's
 // in-source known answers (aggregate.rs:575-702, shape/shape.rs:299-342, bxdf.rs:1839-1903, float.rs:172-211,
-// sampling.rs:801-836) and against float32 numpy re-evaluations of the cited formulas
+// sampling.rs:801-836, interval.rs:534-554, square_matrix.rs:623-650, transform.rs:916-943, spectra/spectrum.rs:655-785) and
+// against float32 numpy re-evaluations of the cited formulas
 // (tests/golden/gen_golden.py).  The reference itself cannot be built here (Rust nightly + crates.io;
 // no toolchain, no network), so there is no oracle/_ref.
 //
@@ -28,7 +29,9 @@
 // Parity UNPINNED boundaries (no reference value exists; the choice is defined in the shared headers and documented in
 // DESIGN.md §2 / §4b): the inner random walks of LayeredBxDF and the MixMaterial choice (the reference seeds both from OS
 // entropy), the FMA order of fast_polynomial::poly in RgbSigmoidPolynomial (crate not vendored), BilinearPatch as a whole
-// (no in-source known answers: checked against float64 evaluations of the cited formulas, tests/test_bilinear_patch.py).
+// (no in-source known answers: checked against float64 evaluations of the cited formulas, tests/test_bilinear_patch.py),
+// and image textures as a whole (mipmap.rs / texture.rs / camera.rs differentials carry no tests in the reference; rgb2spec's
+// `fetch` and f32::log2 are not vendored): float64 re-evaluations and construction properties in tests/test_textures.py.
 #include <atomic>
 #include <chrono>
 #include <string>
