@@ -170,7 +170,10 @@ typedef struct ShmMaterial {
 enum {
     SHM_LIGHT_POINT = 0,            /* light.rs:392-497 */
     SHM_LIGHT_DIFFUSE_AREA = 1,     /* light.rs:499-690; one per emissive shape (loading/scene.rs:609-624) */
-    SHM_LIGHT_UNIFORM_INFINITE = 2  /* light.rs:692-816 */
+    SHM_LIGHT_UNIFORM_INFINITE = 2, /* light.rs:692-816 */
+    SHM_LIGHT_IMAGE_INFINITE = 3    /* ImageInfinitelight, light.rs:805-981 (ABI v6): `primitive` = index into ShmSceneDesc::image_lights;
+                                       `scale` as for the others; `spectrum` unused (the radiance is the image's RGB as an
+                                       RgbIlluminantSpectrum of ShmSceneDesc::color_space, which must carry table and illuminant) */
 };
 typedef struct ShmLight {
     uint32_t kind;
@@ -231,6 +234,17 @@ typedef struct ShmColorSpace {
     const float* rgb2spec_data;  /* 3 * res^3 * 3 floats */
     const float* illuminant;     /* DenselySampledSpectrum 360..=830, 471 floats (may be NULL without ILLUMINANT textures) */
 } ShmColorSpace;
+
+/* ImageInfinitelight (light.rs:805-816, 915-981): the environment map and the light's transform. The library derives both sampling
+ * distributions from the image exactly as ImageInfinitelight::new does (Image::get_default_sampling_distribution = the channel
+ * average per pixel, image.rs:1379-1405; PiecewiseConstant2D::new, sampling.rs:124-153; the compensated one with the average
+ * subtracted, light.rs:948-955). */
+typedef struct ShmImageInfiniteLight {
+    float render_from_light[16];  /* matrix m, row-major */
+    float light_from_render[16];  /* its inverse m_inv */
+    uint32_t image_level;         /* index into ShmSceneDesc::image_levels: a square image, 3 channels, equal-area octahedral layout */
+    uint32_t pad;
+} ShmImageInfiniteLight;
 
 /* PerspectiveCamera / OrthographicCamera after construction (ProjectiveCameraBase, camera.rs:594-642). Matrices row-major. */
 typedef struct ShmCamera {
@@ -293,6 +307,9 @@ typedef struct ShmSceneDesc {
     const float* texel_data;
     ShmColorSpace color_space;
     const float* ewa_filter_lut;  /* MIP_FILTER_LUT (mipmap.rs:390-521), 128 floats; required when a texture uses SHM_TEXFILTER_EWA */
+    uint32_t n_image_lights;
+    uint32_t pad2;
+    const ShmImageInfiniteLight* image_lights;
 } ShmSceneDesc;
 
 /* ---- render parameters ----------------------------------------------------------------------- */

@@ -149,7 +149,7 @@ Spec sample_ld(const SceneView& sv, const SurfaceInteraction& intr, const BSDF& 
     if (li < 0) return spec_const(0.0f);
     const ShmLight& light = sv.lights[li];
     LightLiSample ls;
-    if (!light_sample_li(sv, light, ctx, u_light, lambda, ls)) return spec_const(0.0f);
+    if (!light_sample_li<false, true>(sv, light, ctx, u_light, lambda, ls)) return spec_const(0.0f);
     if (is_zero(ls.l) || ls.pdf == 0.0f) return spec_const(0.0f);
     V3 wo = intr.wo;
     V3 wi = ls.wi;
@@ -198,11 +198,11 @@ Spec li(const SceneView& sv, Ray ray, AuxRays aux, const TexParams& tp, Waveleng
         if (!found) {
             for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
                 const ShmLight& light = sv.lights[sv.infinite_lights[k]];
-                Spec le = light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);  // light.rs:795-797
+                Spec le = infinite_light_le<true>(sv, light, ray.d, lambda);  // light.rs:795-797 / 900-904
                 if (depth == 0 || specular_bounce) {
                     l = l + beta * le;
                 } else {
-                    Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, prev_intr_ctx, ray.d);
+                    Float p_l = light_sampler_pmf(sv) * light_pdf_li<false, true>(sv, light, prev_intr_ctx, ray.d);
                     Float w_b = power_heuristic(1, p_b, 1, p_l);
                     l = l + beta * w_b * le;
                 }
@@ -219,7 +219,7 @@ Spec li(const SceneView& sv, Ray ray, AuxRays aux, const TexParams& tp, Waveleng
                 if (depth == 0 || specular_bounce) {
                     l = l + beta * le;
                 } else {
-                    Float p_l = light_sampler_pmf(sv) * light_pdf_li(sv, light, prev_intr_ctx, ray.d);
+                    Float p_l = light_sampler_pmf(sv) * light_pdf_li<false, true>(sv, light, prev_intr_ctx, ray.d);
                     Float w_l = power_heuristic(1, p_b, 1, p_l);
                     l = l + beta * w_l * le;
                 }
@@ -275,7 +275,7 @@ Spec li_simple_path(const SceneView& sv, Ray ray, AuxRays aux, const TexParams& 
             if (!sample_lights || specular_bounce)
                 for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
                     const ShmLight& light = sv.lights[sv.infinite_lights[k]];
-                    l = l + beta * (light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda));
+                    l = l + beta * infinite_light_le<true>(sv, light, ray.d, lambda);
                 }
             break;
         }
@@ -299,7 +299,7 @@ Spec li_simple_path(const SceneView& sv, Ray ray, AuxRays aux, const TexParams& 
                 LightSampleContext ctx = light_ctx_from(si);
                 const ShmLight& light = sv.lights[li];
                 LightLiSample ls;
-                if (light_sample_li(sv, light, ctx, u_light, lambda, ls, false) && !is_zero(ls.l) && ls.pdf > 0.0f) {
+                if (light_sample_li<false, true>(sv, light, ctx, u_light, lambda, ls, false) && !is_zero(ls.l) && ls.pdf > 0.0f) {
                     V3 wi = ls.wi;
                     Spec f = bsdf_f(bsdf, wo, wi) * abs_dot(wi, si.shading.n);
                     if (!is_zero(f)) {
@@ -349,7 +349,7 @@ Spec li_random_walk(const SceneView& sv, Ray ray, const AuxRays& aux, const TexP
         Spec le = spec_const(0.0f);
         for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
             const ShmLight& light = sv.lights[sv.infinite_lights[k]];
-            le = le + light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
+            le = le + infinite_light_le<true>(sv, light, ray.d, lambda);
         }
         return le;
     }
@@ -887,6 +887,61 @@ int orc_fn_spawn_ray_differentials(const float* p, const float* n, const float* 
     const V3 rv[4] = {r.rx_o, r.rx_d, r.ry_o, r.ry_d};
     for (int i = 0; i < 4; ++i) { out12[3 * i] = rv[i].x; out12[3 * i + 1] = rv[i].y; out12[3 * i + 2] = rv[i].z; }
     return r.has ? 1 : 0;
+}
+
+
+// ---- ImageInfinitelight ----
+void orc_fn_equal_area_square_to_sphere(const float* uv, float* out3) {
+    V3 d = equal_area_square_to_sphere(v2(uv[0], uv[1]));
+    out3[0] = d.x; out3[1] = d.y; out3[2] = d.z;
+}
+void orc_fn_equal_area_sphere_to_square(const float* d, float* out2) {
+    V2 p = equal_area_sphere_to_square(ld3(d));
+    out2[0] = p.x; out2[1] = p.y;
+}
+// Light::sample_li of light `li` from a point at the origin: out = wi[3], pdf, L[4]; returns 1 if Some
+int orc_fn_light_sample_li(OrcScene* s, uint32_t li, const float* u, int allow_incomplete_pdf, const float* lambda4, float* out8) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    Wavelengths w;
+    for (int i = 0; i < 4; ++i) { w.lambda[i] = lambda4[i]; w.pdf[i] = 1.0f; }
+    LightSampleContext ctx;
+    ctx.pi = p3i_exact(v3s(0.0f)); ctx.n = v3s(0.0f); ctx.ns = v3s(0.0f);
+    LightLiSample ls;
+    if (!light_sample_li<false, true>(o->sv, o->sv.lights[li], ctx, v2(u[0], u[1]), w, ls, allow_incomplete_pdf != 0)) return 0;
+    out8[0] = ls.wi.x; out8[1] = ls.wi.y; out8[2] = ls.wi.z; out8[3] = ls.pdf;
+    for (int i = 0; i < 4; ++i) out8[4 + i] = ls.l.v[i];
+    return 1;
+}
+// ImageInfinitelight::pdf_li with either distribution
+float orc_fn_image_light_pdf(OrcScene* s, uint32_t li, const float* wi, int allow_incomplete_pdf) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    const ShmLight& light = o->sv.lights[li];
+    if (allow_incomplete_pdf) {
+        LightSampleContext ctx;
+        ctx.pi = p3i_exact(v3s(0.0f)); ctx.n = v3s(0.0f); ctx.ns = v3s(0.0f);
+        return light_pdf_li<false, true>(o->sv, light, ctx, ld3(wi));
+    }
+    const ImageLightRec& il = o->sv.image_lights[light.primitive];
+    return pc2d_pdf(o->sv.dist_data, il.distribution, (int)il.n, equal_area_sphere_to_square(xf_vector(il.light_from_render, ld3(wi)))) / (4.0f * PI_F);
+}
+void orc_fn_infinite_light_le(OrcScene* s, uint32_t li, const float* d, const float* lambda4, float* out4) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    Wavelengths w;
+    for (int i = 0; i < 4; ++i) { w.lambda[i] = lambda4[i]; w.pdf[i] = 1.0f; }
+    Spec r = infinite_light_le<true>(o->sv, o->sv.lights[li], ld3(d), w);
+    for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
+}
+// The flattened PiecewiseConstant2D of an image light: which = 0 distribution, 1 compensated. Copies func (n*n) and the marginal
+// cdf (n+1); returns n.
+int orc_fn_image_light_distribution(OrcScene* s, uint32_t li, int which, float* func_out, float* marginal_cdf_out, float* integral_out) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    const ImageLightRec& il = o->sv.image_lights[o->sv.lights[li].primitive];
+    const Dist2DRec& d = which ? il.compensated : il.distribution;
+    const int n = (int)il.n;
+    if (func_out) memcpy(func_out, o->sv.dist_data + d.func, sizeof(float) * n * n);
+    if (marginal_cdf_out) memcpy(marginal_cdf_out, o->sv.dist_data + d.marginal_cdf, sizeof(float) * (n + 1));
+    if (integral_out) *integral_out = d.marginal_int;
+    return n;
 }
 
 }  // extern "C"

@@ -83,6 +83,13 @@ def load():
     lib.orc_fn_camera_hit_differentials.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, FP]
     lib.orc_fn_spawn_ray_differentials.restype = C.c_int
     lib.orc_fn_spawn_ray_differentials.argtypes = [FP] * 8 + [C.c_uint32, F, FP]
+    lib.orc_fn_equal_area_square_to_sphere.restype, lib.orc_fn_equal_area_square_to_sphere.argtypes = None, [FP, FP]
+    lib.orc_fn_equal_area_sphere_to_square.restype, lib.orc_fn_equal_area_sphere_to_square.argtypes = None, [FP, FP]
+    lib.orc_fn_light_sample_li.restype, lib.orc_fn_light_sample_li.argtypes = C.c_int, [C.c_void_p, C.c_uint32, FP, C.c_int, FP, FP]
+    lib.orc_fn_image_light_pdf.restype, lib.orc_fn_image_light_pdf.argtypes = F, [C.c_void_p, C.c_uint32, FP, C.c_int]
+    lib.orc_fn_infinite_light_le.restype, lib.orc_fn_infinite_light_le.argtypes = None, [C.c_void_p, C.c_uint32, FP, FP, FP]
+    lib.orc_fn_image_light_distribution.restype = C.c_int
+    lib.orc_fn_image_light_distribution.argtypes = [C.c_void_p, C.c_uint32, C.c_int, FP, FP, FP]
     lib.orc_fn_rotate_from_to.restype, lib.orc_fn_rotate_from_to.argtypes = None, [FP, FP, FP, FP]
     lib.orc_fn_blp_intersect.restype, lib.orc_fn_blp_intersect.argtypes = C.c_int, [FP, FP, FP, F, FP]
     lib.orc_fn_blp_interaction.restype, lib.orc_fn_blp_interaction.argtypes = None, [FP, C.c_int, F, F, FP, FP]

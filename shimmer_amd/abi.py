@@ -17,7 +17,7 @@ SHM_SPECTRUM_CONSTANT, SHM_SPECTRUM_DENSE, SHM_SPECTRUM_PIECEWISE_LINEAR = 0, 1,
 SHM_SPECTRUM_RGB_ALBEDO, SHM_SPECTRUM_RGB_UNBOUNDED, SHM_SPECTRUM_RGB_ILLUMINANT = 3, 4, 5
 SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATERIAL_THIN_DIELECTRIC = 0, 1, 2, 3
 SHM_MATERIAL_COATED_DIFFUSE, SHM_MATERIAL_COATED_CONDUCTOR, SHM_MATERIAL_MIX = 4, 5, 6
-SHM_LIGHT_POINT, SHM_LIGHT_DIFFUSE_AREA, SHM_LIGHT_UNIFORM_INFINITE = 0, 1, 2
+SHM_LIGHT_POINT, SHM_LIGHT_DIFFUSE_AREA, SHM_LIGHT_UNIFORM_INFINITE, SHM_LIGHT_IMAGE_INFINITE = 0, 1, 2, 3
 SHM_SPECTRUM_IMAGE_TEXTURE = 6
 SHM_TEXMAP_UV, SHM_TEXMAP_SPHERICAL, SHM_TEXMAP_CYLINDRICAL, SHM_TEXMAP_PLANAR = 0, 1, 2, 3
 SHM_TEXFILTER_POINT, SHM_TEXFILTER_BILINEAR, SHM_TEXFILTER_TRILINEAR, SHM_TEXFILTER_EWA = 0, 1, 2, 3
@@ -97,6 +97,11 @@ class ShmImageTexture(C.Structure):
                 ("first_level", C.c_uint32), ("n_levels", C.c_uint32)]
 
 
+class ShmImageInfiniteLight(C.Structure):
+    _fields_ = [("render_from_light", C.c_float * 16), ("light_from_render", C.c_float * 16), ("image_level", C.c_uint32),
+                ("pad", C.c_uint32)]
+
+
 class ShmColorSpace(C.Structure):
     _fields_ = [("rgb2spec_res", C.c_uint32), ("pad", C.c_uint32), ("rgb2spec_scale", c_float_p), ("rgb2spec_data", c_float_p),
                 ("illuminant", c_float_p)]
@@ -118,7 +123,8 @@ class ShmSceneDesc(C.Structure):
                 ("patch_meshes", C.POINTER(ShmBilinearPatchMesh)),
                 ("n_image_textures", C.c_uint32), ("n_image_levels", C.c_uint32), ("image_textures", C.POINTER(ShmImageTexture)),
                 ("image_levels", C.POINTER(ShmImageLevel)), ("n_texel_floats", C.c_uint64), ("texel_data", c_float_p),
-                ("color_space", ShmColorSpace), ("ewa_filter_lut", c_float_p)]
+                ("color_space", ShmColorSpace), ("ewa_filter_lut", c_float_p), ("n_image_lights", C.c_uint32), ("pad2", C.c_uint32),
+                ("image_lights", C.POINTER(ShmImageInfiniteLight))]
 
 
 class ShmRenderParams(C.Structure):

@@ -44,7 +44,10 @@ struct FlatScene {
     std::vector<float> texel_data;
     std::vector<float> rgb2spec_scale, rgb2spec_data, cs_illuminant, ewa_lut;
     uint32_t rgb2spec_res = 0;
-    bool has_textures = false;  // a material slot binds an image texture: the path carries ray differentials (k_shade<.., HAS_TEX>)
+    bool has_textures = false;  // a material slot binds an image texture (the path carries ray differentials) or an image infinite
+                                // light exists (both read the colour-space tables): selects k_shade<.., HAS_TEX>
+    std::vector<shm::ImageLightRec> image_lights;
+    std::vector<float> dist_data;
 
     shm::SceneView view() const {
         shm::SceneView v;
@@ -87,6 +90,8 @@ struct FlatScene {
         v.rgb2spec_data = rgb2spec_data.data();
         v.cs_illuminant = cs_illuminant.data();
         v.ewa_lut = ewa_lut.data();
+        v.image_lights = image_lights.data();
+        v.dist_data = dist_data.data();
         return v;
     }
 };
@@ -109,6 +114,32 @@ inline bool check_spectrum(const ShmSpectrum& s, uint32_t n_floats, std::string&
     }
     err = "unknown spectrum kind";
     return false;
+}
+
+// PiecewiseConstant1D::new_bounded(f, 0, 1) (sampling.rs:27-61) appended to `pool`: func (|f|) at func_off, cdf (n + 1) at cdf_off;
+// returns func_int. f32 arithmetic in the reference's order.
+inline float build_pc1d(const float* f, size_t n, std::vector<float>& pool, size_t func_off, size_t cdf_off) {
+    for (size_t i = 0; i < n; ++i) pool[func_off + i] = f[i] < 0.0f ? -f[i] : f[i];
+    pool[cdf_off] = 0.0f;
+    for (size_t i = 1; i <= n; ++i) pool[cdf_off + i] = pool[cdf_off + i - 1] + pool[func_off + i - 1] * (1.0f - 0.0f) / (float)n;
+    const float func_int = pool[cdf_off + n];
+    if (func_int == 0.0f) for (size_t i = 1; i <= n; ++i) pool[cdf_off + i] = (float)i / (float)n;
+    else for (size_t i = 1; i <= n; ++i) pool[cdf_off + i] /= func_int;
+    return func_int;
+}
+// PiecewiseConstant2D::new(func, n, n, [0,1]^2) (sampling.rs:124-153)
+inline shm::Dist2DRec build_pc2d(const std::vector<float>& d, size_t n, std::vector<float>& pool) {
+    shm::Dist2DRec r{};
+    size_t base = pool.size();
+    pool.resize(base + n * n + n * (n + 1) + n + (n + 1));
+    r.func = (uint32_t)base;
+    r.cdf = (uint32_t)(base + n * n);
+    r.marginal_func = (uint32_t)(base + n * n + n * (n + 1));
+    r.marginal_cdf = r.marginal_func + (uint32_t)n;
+    std::vector<float> integrals(n);
+    for (size_t v = 0; v < n; ++v) integrals[v] = build_pc1d(d.data() + v * n, n, pool, r.func + v * n, r.cdf + v * (n + 1));
+    r.marginal_int = build_pc1d(integrals.data(), n, pool, r.marginal_func, r.marginal_cdf);
+    return r;
 }
 
 // Returns 0 or a negative ShmError; err receives a message.
@@ -315,6 +346,54 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         }
     }
 
+    // ImageInfinitelight::new (light.rs:915-966): the two sampling distributions of each environment map
+    if (d->n_image_lights) {
+        if (!d->image_lights || !d->image_levels || !d->texel_data) { err = "image infinite light arrays missing"; return SHM_ERR_INVALID_ARGUMENT; }
+        const ShmColorSpace& cs = d->color_space;
+        if (cs.rgb2spec_res < 2 || cs.rgb2spec_res > 256 || !cs.rgb2spec_scale || !cs.rgb2spec_data || !cs.illuminant) { err = "an image infinite light needs ShmSceneDesc::color_space (rgb2spec table and illuminant)"; return SHM_ERR_INVALID_ARGUMENT; }
+        if (out.image_levels.empty()) {
+            if (d->n_texel_floats >= (1ull << 32)) { err = "more than 2^32 texel floats"; return SHM_ERR_UNSUPPORTED; }
+            out.image_levels.assign(d->image_levels, d->image_levels + d->n_image_levels);
+            out.texel_data.assign(d->texel_data, d->texel_data + d->n_texel_floats);
+        }
+        if (out.rgb2spec_res == 0) {
+            out.rgb2spec_res = cs.rgb2spec_res;
+            out.rgb2spec_scale.assign(cs.rgb2spec_scale, cs.rgb2spec_scale + cs.rgb2spec_res);
+            size_t r = cs.rgb2spec_res;
+            out.rgb2spec_data.assign(cs.rgb2spec_data, cs.rgb2spec_data + 9 * r * r * r);
+        }
+        if (out.cs_illuminant.empty()) out.cs_illuminant.assign(cs.illuminant, cs.illuminant + 471);
+        for (uint32_t i = 0; i < d->n_image_lights; ++i) {
+            const ShmImageInfiniteLight& il = d->image_lights[i];
+            if (il.image_level >= d->n_image_levels) { err = "image infinite light: image level out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            const ShmImageLevel& lv = out.image_levels[il.image_level];
+            // light.rs:934-937: "Image resolution is non-square; it is unlikely that it is an environment map"
+            if (lv.width <= 0 || lv.width != lv.height) { err = "image infinite light: the environment map must be square"; return SHM_ERR_INVALID_ARGUMENT; }
+            const size_t n = (size_t)lv.width;
+            if ((uint64_t)lv.texel_offset + 3ull * n * n > d->n_texel_floats) { err = "image infinite light: texels out of bounds"; return SHM_ERR_INVALID_ARGUMENT; }
+            if (n > 8192) { err = "image infinite light: environment map larger than 8192^2"; return SHM_ERR_UNSUPPORTED; }
+            shm::ImageLightRec rec{};
+            for (int k = 0; k < 16; ++k) { rec.render_from_light[k] = il.render_from_light[k]; rec.light_from_render[k] = il.light_from_render[k]; }
+            rec.image_level = il.image_level;
+            rec.n = (uint32_t)n;
+            // Image::get_default_sampling_distribution (image.rs:1379-1405): ImageChannelValues::average per pixel, dx_da = 1
+            std::vector<float> dd(n * n);
+            const float* t = out.texel_data.data() + lv.texel_offset;
+            for (size_t k = 0; k < n * n; ++k) dd[k] = (((0.0f + t[3 * k]) + t[3 * k + 1]) + t[3 * k + 2]) / 3.0f;
+            rec.distribution = build_pc2d(dd, n, out.dist_data);
+            // light.rs:948-955: subtract the average, clamp at zero; all zero -> uniform
+            float sum = 0.0f;
+            for (float v : dd) sum += v;
+            const float average = sum / (float)dd.size();
+            bool all_zero = true;
+            for (float& v : dd) { v = shm::max(v - average, 0.0f); all_zero &= (v == 0.0f); }
+            if (all_zero) for (float& v : dd) v = 1.0f;
+            rec.compensated = build_pc2d(dd, n, out.dist_data);
+            out.image_lights.push_back(rec);
+        }
+        out.has_textures = true;
+    }
+
     // materials / lights
     const uint32_t ntex = d->n_image_textures;
     uint32_t nsf = (uint32_t)out.spectrum_data.size();
@@ -352,7 +431,12 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
     }
     for (uint32_t i = 0; i < out.lights.size(); ++i) {
         const ShmLight& l = out.lights[i];
-        if (l.kind > SHM_LIGHT_UNIFORM_INFINITE) { err = "unsupported light kind (ImageInfinite is a SURVEY §8f row)"; return SHM_ERR_UNSUPPORTED; }
+        if (l.kind > SHM_LIGHT_IMAGE_INFINITE) { err = "unsupported light kind"; return SHM_ERR_UNSUPPORTED; }
+        if (l.kind == SHM_LIGHT_IMAGE_INFINITE) {
+            if (l.primitive >= d->n_image_lights) { err = "image infinite light index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            out.infinite_lights.push_back(i);
+            continue;
+        }
         if (l.spectrum.kind != SHM_SPECTRUM_DENSE) { err = "light spectrum must be densely sampled (light.rs:404,551,717)"; return SHM_ERR_INVALID_ARGUMENT; }
         if (!check_spectrum(l.spectrum, nsf, err)) return SHM_ERR_INVALID_ARGUMENT;
         if (l.kind == SHM_LIGHT_DIFFUSE_AREA && l.primitive >= d->n_primitives) { err = "area light primitive out of range"; return SHM_ERR_INVALID_ARGUMENT; }

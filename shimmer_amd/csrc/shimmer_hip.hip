@@ -529,11 +529,11 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                 // integrator.rs:776-794: escaped ray, infinite lights
                 for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
                     const ShmLight& light = sv.lights[sv.infinite_lights[k]];
-                    Spec le = light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
+                    Spec le = infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda);
                     if (depth == 0 || specular_bounce) {
                         add_l(beta * le);
                     } else {
-                        Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY>(sv, light, load_prev_ctx(), ray_d);
+                        Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
                         Float w_b = power_heuristic(1, p_b, 1, p_l);
                         add_l(beta * w_b * le);
                     }
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                         if (depth == 0 || specular_bounce) {
                             add_l(beta * le);
                         } else {
-                            Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY>(sv, light, load_prev_ctx(), ray_d);
+                            Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
                             Float w_l = power_heuristic(1, p_b, 1, p_l);
                             add_l(beta * w_l * le);
                         }
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                         if (li >= 0) {
                             const ShmLight& light = sv.lights[li];
                             LightLiSample ls;
-                            if (light_sample_li<TRI_ONLY>(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
+                            if (light_sample_li<TRI_ONLY, HAS_TEX>(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
                                 V3 wo = si.wo;
                                 V3 wi = ls.wi;
                                 Spec f = bsdf_f(bsdf, wo, wi) * abs_dot(wi, si.shading.n);
@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(Scen
                 if (!sample_lights || specular_bounce)
                     for (uint32_t li = 0; li < sv.n_infinite_lights; ++li) {
                         const ShmLight& light = sv.lights[sv.infinite_lights[li]];
-                        add_l(beta * (light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda)));
+                        add_l(beta * infinite_light_le<true>(sv, light, ray_d, lambda));
                     }
             } else {
                 SurfaceInteraction si = hit_interaction<false>(sv, hit, -ray_d);
@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(Scen
                             LightSampleContext ctx = light_ctx_from(si);
                             const ShmLight& light = sv.lights[li];
                             LightLiSample ls;
-                            if (light_sample_li<false>(sv, light, ctx, u_light, lambda, ls, false) && !is_zero(ls.l) && ls.pdf > 0.0f) {
+                            if (light_sample_li<false, true>(sv, light, ctx, u_light, lambda, ls, false) && !is_zero(ls.l) && ls.pdf > 0.0f) {
                                 V3 wi = ls.wi;
                                 Spec f = bsdf_f(bsdf, wo, wi) * abs_dot(wi, si.shading.n);
                                 if (!is_zero(f)) {
@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_randomwalk(
             if (hit.prim < 0) {
                 for (uint32_t li = 0; li < sv.n_infinite_lights; ++li) {
                     const ShmLight& light = sv.lights[sv.infinite_lights[li]];
-                    le = le + light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
+                    le = le + infinite_light_le<true>(sv, light, ray_d, lambda);
                 }
                 rec[0] = st_spec(le);  // terminal vertex: flags keeps this depth
             } else {
@@ -1231,6 +1231,8 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if ((rc = dev_upload(s, f.rgb2spec_data, &v.rgb2spec_data)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.cs_illuminant, &v.cs_illuminant)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ewa_lut, &v.ewa_lut)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.image_lights, &v.image_lights)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.dist_data, &v.dist_data)) != SHM_OK) return fail(rc);
     s->dsv = v;
 
     size_t w = (size_t)(f.film.pixel_bounds[2] - f.film.pixel_bounds[0]);

@@ -5,6 +5,7 @@
 //   light.rs:392-497              PointLight::{sample_li,pdf_li}
 //   light.rs:632-684              DiffuseAreaLight::{sample_li,pdf_li,l}
 //   light.rs:747-803              UniformInfiniteLight::{sample_li,pdf_li,le}
+//   light.rs:848-904              ImageInfinitelight::{sample_li,pdf_li,le} (arithmetic in texture.h)
 //   light_sampler.rs:83-111       UniformLightSampler::{sample_light,pmf_light}
 //   interaction.rs:187-278        SurfaceInteraction::get_bsdf (ray differentials are carried only in scenes with image
 //                                 textures, texture.h: elsewhere they are dead values; bump_map with a constant
@@ -48,9 +49,25 @@ SHM_HD Spec area_light_l(const SceneView& sv, const ShmLight& light, V3 n, V3 w,
 
 // Light::sample_li. PathIntegrator calls it with allow_incomplete_pdf = true (integrator.rs:927), SimplePathIntegrator with false
 // (integrator.rs:651-655): the flag only matters for the uniform infinite light.
-template <bool TRI_ONLY = false>
+// HAS_TEX (scenes with image textures or an image infinite light: both need the colour-space tables) compiles the
+// ImageInfinitelight branches in.
+template <bool TRI_ONLY = false, bool HAS_TEX = false>
 SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const LightSampleContext& ctx, V2 u,
                             const Wavelengths& lambda, LightLiSample& out, bool allow_incomplete_pdf = true) {
+    if (HAS_TEX && light.kind == SHM_LIGHT_IMAGE_INFINITE) {  // light.rs:848-880
+        const ImageLightRec& il = sv.image_lights[light.primitive];
+        Float map_pdf;
+        V2 uv = pc2d_sample(sv.dist_data, allow_incomplete_pdf ? il.compensated : il.distribution, (int)il.n, u, map_pdf);
+        if (map_pdf == 0.0f) return false;
+        V3 w_light = equal_area_square_to_sphere(uv);
+        V3 wi = xf_vector(il.render_from_light, w_light);
+        out.l = light.scale * image_light_le_uv(sv, il, uv, lambda);
+        out.wi = wi;
+        out.pdf = map_pdf / (4.0f * PI_F);
+        out.p_light_pi = p3i_exact(ctx.p() + wi * (2.0f * sv.scene_radius));
+        out.p_light_n = v3s(0.0f);
+        return true;
+    }
     if (light.kind == SHM_LIGHT_POINT) {  // light.rs:452-468
         V3 p = ld3(light.position);
         V3 wi = normalize(p - ctx.p());
@@ -91,8 +108,14 @@ SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const Li
     return true;
 }
 // Light::pdf_li with allow_incomplete_pdf = true
-template <bool TRI_ONLY = false>
+template <bool TRI_ONLY = false, bool HAS_TEX = false>
 SHM_HD Float light_pdf_li(const SceneView& sv, const ShmLight& light, const LightSampleContext& ctx, V3 wi) {
+    if (HAS_TEX && light.kind == SHM_LIGHT_IMAGE_INFINITE) {  // light.rs:882-892, the compensated distribution
+        const ImageLightRec& il = sv.image_lights[light.primitive];
+        V3 w_light = xf_vector(il.light_from_render, wi);
+        V2 uv = equal_area_sphere_to_square(w_light);
+        return pc2d_pdf(sv.dist_data, il.compensated, (int)il.n, uv) / (4.0f * PI_F);
+    }
     if (light.kind != SHM_LIGHT_DIFFUSE_AREA) return 0.0f;  // light.rs:470-477, 774-775
     ShapeSampleContext sctx;
     sctx.pi = ctx.pi; sctx.n = ctx.n; sctx.ns = ctx.ns;
@@ -100,6 +123,12 @@ SHM_HD Float light_pdf_li(const SceneView& sv, const ShmLight& light, const Ligh
     if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) return sphere_pdf_with_context(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], sctx, wi);
     if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) return blp_pdf_with_context(load_patch(sv, light.primitive), sctx, wi);
     return triangle_pdf_with_context(load_triangle(sv, light.primitive), sctx, wi);
+}
+// Light::le of an infinite light for an escaped ray: UniformInfiniteLight (light.rs:795-797) or ImageInfinitelight (:900-904)
+template <bool HAS_TEX = false>
+SHM_HD Spec infinite_light_le(const SceneView& sv, const ShmLight& light, V3 ray_d, const Wavelengths& lambda) {
+    if (HAS_TEX && light.kind == SHM_LIGHT_IMAGE_INFINITE) return light.scale * image_light_le(sv, sv.image_lights[light.primitive], ray_d, lambda);
+    return light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
 }
 // UniformLightSampler, light_sampler.rs:91-111. Returns light index or -1; p = 1/n.
 SHM_HD int light_sampler_sample(const SceneView& sv, Float u, Float& p) {

@@ -79,6 +79,25 @@ struct SceneView {
     const Float* rgb2spec_data;
     const Float* cs_illuminant;  // 471 floats, 360..=830
     const Float* ewa_lut;        // MIP_FILTER_LUT, 128 floats
+    // image infinite lights: per light its transform + image + the two PiecewiseConstant2D distributions, flattened into dist_data
+    const struct ImageLightRec* image_lights;
+    const Float* dist_data;
+};
+
+// PiecewiseConstant2D (sampling.rs:113-179) of an n x n image, flattened: conditional func [n*n], conditional cdf [n*(n+1)],
+// conditional integrals = marginal func [n], marginal cdf [n+1]; marginal integral beside the offsets.
+struct Dist2DRec {
+    uint32_t func, cdf, marginal_func, marginal_cdf;  // offsets into SceneView::dist_data
+    Float marginal_int;
+    uint32_t pad[3];
+};
+struct ImageLightRec {
+    Float render_from_light[16];
+    Float light_from_render[16];
+    uint32_t image_level;  // ShmImageLevel index: res x res, 3 channels
+    uint32_t n;            // res
+    uint32_t pad[2];
+    Dist2DRec distribution, compensated;
 };
 
 SHM_HD V3 ld3(const Float* p) { return v3(p[0], p[1], p[2]); }

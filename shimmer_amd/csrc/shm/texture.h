@@ -485,6 +485,103 @@ SHM_HD Spec image_texture_evaluate(const SceneView& sv, uint32_t texture_index, 
     return s * dense_table_sample(sv.cs_illuminant, lambda);  // spectrum.rs:600-606
 }
 
+// ---------------------------------------------------------------------------------------------
+// ImageInfinitelight (light.rs:805-981): equal-area octahedral environment map, importance-sampled through a
+// PiecewiseConstant2D (sampling.rs:20-179) — the compensated one under allow_incomplete_pdf (PathIntegrator).
+// ---------------------------------------------------------------------------------------------
+// fast_polynomial 0.1.0 `poly_array` with seven coefficients (math.rs:514). The crate is not vendored: parity unpinned; its
+// documented scheme is Estrin's with FMAs, defined here as ((c6 x^2 + (c5 x + c4)) x^4 + ((c3 x + c2) x^2 + (c1 x + c0))).
+SHM_HD Float poly7_estrin(Float x, const Float c[7]) {
+    Float x2 = x * x, x4 = x2 * x2;
+    Float p01 = fma(c[1], x, c[0]), p23 = fma(c[3], x, c[2]), p45 = fma(c[5], x, c[4]);
+    Float lo = fma(p23, x2, p01), hi = fma(c[6], x2, p45);
+    return fma(hi, x4, lo);
+}
+// math.rs:456-485. Kept as written: phi = (vp - up / r + 1) pi / 4 (PBRT-v4 has (vp - up) / r + 1).
+SHM_HD V3 equal_area_square_to_sphere(V2 p) {
+    Float u = 2.0f * p.x - 1.0f, v = 2.0f * p.y - 1.0f;
+    Float up = abs(u), vp = abs(v);
+    Float signed_distance = 1.0f - (up + vp);
+    Float d = abs(signed_distance);
+    Float r = 1.0f - d;
+    Float phi = ((r == 0.0f) ? 1.0f : (vp - up / r + 1.0f)) * PI_F / 4.0f;
+    Float z = copysign(1.0f - sqr(r), signed_distance);
+    Float cos_phi = copysign(cos(phi), u), sin_phi = copysign(sin(phi), v);
+    return v3(cos_phi * r * safe_sqrt(2.0f - sqr(r)), sin_phi * r * safe_sqrt(2.0f - sqr(r)), z);
+}
+// math.rs:488-540
+SHM_HD V2 equal_area_sphere_to_square(V3 d) {
+    Float x = abs(d.x), y = abs(d.y), z = abs(d.z);
+    Float r = safe_sqrt(1.0f - z);
+    Float a = max(x, y), b = min(x, y);
+    b = (a == 0.0f) ? 0.0f : b / a;
+    const Float t[7] = {0.406758566246788489601959989e-5f, 0.636226545274016134946890922156f, 0.61572017898280213493197203466e-2f,
+                        -0.247333733281268944196501420480f, 0.881770664775316294736387951347e-1f, 0.419038818029165735901852432784e-1f,
+                        -0.251390972343483509333252996350e-1f};
+    Float phi = poly7_estrin(b, t);
+    if (x < y) phi = 1.0f - phi;
+    Float v = phi * r;
+    Float u = r - v;
+    if (d.z < 0.0f) {
+        Float tmp = u; u = v; v = tmp;
+        u = 1.0f - u;
+        v = 1.0f - v;
+    }
+    u = copysign(u, d.x);
+    v = copysign(v, d.y);
+    return v2(0.5f * (u + 1.0f), 0.5f * (v + 1.0f));
+}
+
+// PiecewiseConstant1D::sample, sampling.rs:69-90 (min = 0, max = 1: lerp(t, 0, 1) = 0 * (1 - t) + 1 * t)
+SHM_HD Float pc1d_sample(const Float* func, const Float* cdf, Float func_int, int n, Float u, Float& pdf, int& offset) {
+    offset = find_interval(n + 1, [&](int i) { return cdf[i] <= u; });
+    Float du = u - cdf[offset];
+    if (cdf[offset + 1] - cdf[offset] > 0.0f) du /= cdf[offset + 1] - cdf[offset];
+    pdf = (func_int > 0.0f) ? func[offset] / func_int : 0.0f;
+    return lerp(((Float)offset + du) / (Float)n, 0.0f, 1.0f);
+}
+// PiecewiseConstant2D::sample, sampling.rs:160-168
+SHM_HD V2 pc2d_sample(const Float* data, const Dist2DRec& d, int n, V2 u, Float& pdf) {
+    Float pdf1, pdf0;
+    int iv, iu;
+    Float d1 = pc1d_sample(data + d.marginal_func, data + d.marginal_cdf, d.marginal_int, n, u.y, pdf1, iv);
+    // the row's integral is the marginal's func value (sampling.rs:140-144)
+    Float d0 = pc1d_sample(data + d.func + (uint32_t)(iv * n), data + d.cdf + (uint32_t)(iv * (n + 1)), data[d.marginal_func + (uint32_t)iv], n, u.x, pdf0, iu);
+    pdf = pdf0 * pdf1;
+    return v2(d0, d1);
+}
+// PiecewiseConstant2D::pdf, sampling.rs:170-177 (domain [0,1]^2: Bounds2f::offset is the identity)
+SHM_HD Float pc2d_pdf(const Float* data, const Dist2DRec& d, int n, V2 p) {
+    int iu = float_to_i32(p.x * (Float)n), iv = float_to_i32(p.y * (Float)n);  // `as usize`: saturating, negatives -> 0
+    iu = iu < 0 ? 0 : (iu > n - 1 ? n - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > n - 1 ? n - 1 : iv);
+    return data[d.func + (uint32_t)(iv * n + iu)] / d.marginal_int;
+}
+// ImageInfinitelight::image_le, light.rs:968-977 (lookup_nearest_channel_wrapped, image.rs:590-601) — without the light's scale
+SHM_HD Spec image_light_le_uv(const SceneView& sv, const ImageLightRec& il, V2 uv, const Wavelengths& lambda) {
+    const ShmImageLevel& l = sv.image_levels[il.image_level];
+    int x = float_to_i32(uv.x * (Float)l.width), y = float_to_i32(uv.y * (Float)l.height);
+    RGB3 rgb = rgb3(0.0f, 0.0f, 0.0f);
+    if (remap_pixel_coords(x, y, l.width, l.height, SHM_WRAP_OCTAHEDRAL_SPHERE)) {
+        const Float* t = sv.texel_data + l.texel_offset + (uint32_t)(3 * (y * l.width + x));
+        rgb = rgb3(max(0.0f, t[0]), max(0.0f, t[1]), max(0.0f, t[2]));  // clamp_zero
+    }
+    // RgbIlluminantSpectrum::new + sample, spectrum.rs:573-606
+    Float m = max(max(rgb.r, rgb.g), rgb.b);
+    Float scale = 2.0f * m;
+    Float coeff[3];
+    if (scale != 0.0f) rgb2spec_fetch(sv, rgb / scale, coeff);
+    else rgb2spec_fetch(sv, rgb3(0.0f, 0.0f, 0.0f), coeff);
+    Spec s;
+    for (int i = 0; i < NSPEC; ++i) s.v[i] = scale * rgb_sigmoid(coeff, lambda.lambda[i]);
+    return s * dense_table_sample(sv.cs_illuminant, lambda);
+}
+// ImageInfinitelight::le, light.rs:900-904 (without the light's scale)
+SHM_HD Spec image_light_le(const SceneView& sv, const ImageLightRec& il, V3 ray_d, const Wavelengths& lambda) {
+    V3 w_light = xf_vector(il.light_from_render, ray_d);
+    return image_light_le_uv(sv, il, equal_area_sphere_to_square(w_light), lambda);
+}
+
 // SpectrumTexture::evaluate for a material slot: a constant spectrum texture samples its spectrum (texture.rs:509-513), an image
 // texture filters its pyramid. HAS_TEX = false compiles the image branch out (scenes without textures: identical code as before).
 template <bool HAS_TEX>

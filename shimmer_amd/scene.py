@@ -148,6 +148,7 @@ class SceneBuilder:
         self.texels = []        # float32 arrays
         self.texel_len = 0
         self.color_space = None  # dict(res, scale, data, illuminant)
+        self.image_lights = []  # abi.ShmImageInfiniteLight
 
     # ---- spectra ----
     def spectrum_constant(self, c):
@@ -345,6 +346,26 @@ class SceneBuilder:
         l.kind = abi.SHM_LIGHT_UNIFORM_INFINITE
         l.scale = float(f32(scale) / spectrum_to_photometric(dense_emission))
         l.spectrum = self.spectrum_dense(dense_emission)
+        self.lights.append(l)
+        return len(self.lights) - 1
+
+    def light_image_infinite(self, image, scale=1.0, render_from_light=None):
+        """ImageInfinitelight (light.rs:805-981; created by the "infinite" light with a filename, light.rs:147-190): `image` is a
+        square (n, n, 3) linear-RGB environment map in the equal-area octahedral layout, row 0 first; `scale` is the final scale."""
+        img = _as_f32(image)
+        assert img.ndim == 3 and img.shape[0] == img.shape[1] and img.shape[2] == 3
+        self.use_srgb_color_space()
+        il = abi.ShmImageInfiniteLight()
+        m = np.asarray(IDENTITY if render_from_light is None else render_from_light, np.float64).reshape(4, 4)
+        il.render_from_light[:] = [float(x) for x in _as_f32(m).ravel()]
+        il.light_from_render[:] = [float(x) for x in _as_f32(np.linalg.inv(m)).ravel()]
+        il.image_level = len(self.tex_levels)
+        self.tex_levels.append((img.shape[1], img.shape[0], self.texel_len))
+        self.texels.append(img.ravel())
+        self.texel_len += img.size
+        self.image_lights.append(il)
+        l = abi.ShmLight()
+        l.kind, l.primitive, l.scale = abi.SHM_LIGHT_IMAGE_INFINITE, len(self.image_lights) - 1, float(scale)
         self.lights.append(l)
         return len(self.lights) - 1
 
@@ -553,8 +574,8 @@ class SceneBuilder:
         d.camera, d.film = self.camera, self.film
         d.n_patch_meshes, d.patch_meshes = len(self.patch_meshes), patch_meshes
         self._keep = [nodes, prim_arr, lights, meshes, spheres, materials, spec, bounds, order, patch_meshes]
-        if self.textures:
-            textures = (abi.ShmImageTexture * len(self.textures))(*self.textures)
+        if self.textures or self.image_lights:
+            textures = (abi.ShmImageTexture * max(1, len(self.textures)))(*self.textures)
             levels = (abi.ShmImageLevel * len(self.tex_levels))()
             for i, (w, h, off) in enumerate(self.tex_levels):
                 levels[i].width, levels[i].height, levels[i].texel_offset = w, h, off
@@ -570,6 +591,10 @@ class SceneBuilder:
                 d.color_space.rgb2spec_res = cs["res"]
                 d.color_space.rgb2spec_scale, d.color_space.rgb2spec_data = _fptr(cs["scale"]), _fptr(cs["data"])
                 d.color_space.illuminant = _fptr(cs["illuminant"])
+            if self.image_lights:
+                ils = (abi.ShmImageInfiniteLight * len(self.image_lights))(*self.image_lights)
+                d.n_image_lights, d.image_lights = len(self.image_lights), ils
+                self._keep.append(ils)
         info = dict(n_nodes=n_nodes.value, n_primitives=n, order=order, slot_of_input=slot_of_input, bounds=bounds)
         return d, info
 

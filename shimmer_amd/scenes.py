@@ -342,7 +342,27 @@ def crown_proxy(lib, width=1000, height=1400, level=4, n_glass=64, n_gold=16, se
     return _finish(b, lib, name="S4 crown-proxy")
 
 
-def three_spheres(lib, width=32, height=32, offsets=(-3.5, 0.0, 5.0), camera=(0.0, 0.0, 0.0)):
+def environment_image(n=32, sun=(0.3, 0.5, 0.81), sun_radiance=40.0):
+    """A small synthetic environment map in the equal-area octahedral layout (math.rs:456-485): blue-ish sky fading to a warm
+    horizon, a dim ground, and a sun — bright enough that the compensated distribution (light.rs:948-955) differs from the plain one."""
+    y, x = np.mgrid[0:n, 0:n]
+    u, v = 2.0 * (x + 0.5) / n - 1.0, 2.0 * (y + 0.5) / n - 1.0
+    up, vp = np.abs(u), np.abs(v)
+    sd = 1.0 - (up + vp)
+    r = 1.0 - np.abs(sd)
+    phi = np.where(r == 0, 1.0, (vp - up) / np.where(r == 0, 1.0, r) + 1.0) * np.pi / 4
+    z = np.copysign(1.0 - r * r, sd)
+    d = np.stack([np.copysign(np.cos(phi), u) * r * np.sqrt(2.0 - r * r), np.copysign(np.sin(phi), v) * r * np.sqrt(2.0 - r * r), z], axis=-1)
+    s = np.asarray(sun, np.float64)
+    s /= np.linalg.norm(s)
+    t = np.clip(d[..., 2], 0.0, 1.0)[..., None]
+    sky = (1.0 - t) * np.array([0.9, 0.7, 0.5]) + t * np.array([0.25, 0.45, 0.9])
+    img = np.where(d[..., 2:3] >= 0.0, sky, np.array([0.12, 0.1, 0.08]))
+    img = img + sun_radiance * np.array([1.0, 0.9, 0.7]) * (np.einsum("ijk,k->ij", d, s) > 0.97)[..., None]
+    return img.astype(np.float32)
+
+
+def three_spheres(lib, width=32, height=32, offsets=(-3.5, 0.0, 5.0), camera=(0.0, 0.0, 0.0), environment=None):
     """The reference's set_of_spheres BVH test scene (aggregate.rs:631-702): unit spheres at x = -3.5, 0, 5.
     With the default camera at the origin world == render space, as the reference's unit tests assume (rays are given
     in render space); pass a camera position outside the spheres to render it."""
@@ -358,8 +378,12 @@ def three_spheres(lib, width=32, height=32, offsets=(-3.5, 0.0, 5.0), camera=(0.
         b.add_sphere(1.0, m, render_from_object=rfo)
     # a uniform environment (UniformInfiniteLight, light.rs:692-816): exercises the escaped-ray branch of
     # PathIntegrator::li (integrator.rs:776-794)
-    b.light_uniform_infinite(np.ones(471, np.float32), scale=1.0)
-    return _finish(b, lib, name="three spheres")
+    if environment is None:
+        b.light_uniform_infinite(np.ones(471, np.float32), scale=1.0)
+    else:  # ImageInfinitelight (light.rs:805-981), turned so that +z of the map is the world's +y
+        rot = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float32)
+        b.light_image_infinite(environment, scale=0.01, render_from_light=rot)
+    return _finish(b, lib, name="three spheres" + ("" if environment is None else " (environment map)"))
 
 
 def random_scene(lib, seed, width=40, height=32):
@@ -486,4 +510,13 @@ def random_scene(lib, seed, width=40, height=32):
     b.light_point(pos, emit, scale=float(rng.uniform(2, 10)))
     if seed % 3 == 1:
         b.light_uniform_infinite(blackbody_dense(6500.0), scale=0.3)
+    if seed >= 12 and seed % 2 == 0:  # an ImageInfinitelight under a random rotation (even beside the uniform sky: two infinite lights)
+        a = trng.normal(size=3)
+        a /= np.linalg.norm(a)
+        ang = trng.uniform(0, 2 * np.pi)
+        k = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        rot = np.eye(4)
+        rot[:3, :3] = np.eye(3) + np.sin(ang) * k + (1 - np.cos(ang)) * (k @ k)
+        b.light_image_infinite(environment_image(int(trng.choice([8, 16])), sun=tuple(trng.normal(size=3)), sun_radiance=float(trng.uniform(5, 60))),
+                               scale=float(trng.uniform(0.002, 0.01)), render_from_light=rot)
     return _finish(b, lib, name=f"random scene {seed}")

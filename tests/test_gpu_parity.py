@@ -50,6 +50,8 @@ SCENES = {
     "S2_cornell_mix": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, mix=True), 8, 5),  # MixMaterial, nested, with a coated leaf
     # image textures (every mapping / filter / wrap / spectrum type), ray differentials through a mirror and glass
     "S2_cornell_textured": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, textured=True), 8, 6),
+    # ImageInfinitelight: compensated PiecewiseConstant2D sampling + MIS against BSDF-sampled escapes
+    "three_spheres_environment": lambda scenes, lib: (scenes.three_spheres(lib, 64, 48, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(32)), 8, 5),
 }
 
 
@@ -322,6 +324,22 @@ def test_textured_parity_per_filter_and_integrator(env, integrator, texture_filt
         assert np.array_equal(fg, fo) and np.isfinite(render.film_to_rgb(fg)).all() and render.film_to_rgb(fg).max() > 0
         for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
             assert sg[k] == so[k], k
+    gpu.close(); orc.close()
+
+
+@pytest.mark.parametrize("integrator", ["simplepath", "randomwalk"])
+def test_environment_map_parity_other_integrators(env, integrator):
+    """ImageInfinitelight under the two general integrators: SimplePathIntegrator samples the plain distribution
+    (allow_incomplete_pdf = false), RandomWalkIntegrator only evaluates le on escape."""
+    lib, oracle_py, render, scenes = env
+    sc = scenes.three_spheres(lib, 48, 32, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(16))
+    gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+    p = render.make_params(seed=6, spp=6, max_depth=4, integrator=integrator)
+    fg, sg = gpu.render(p)
+    fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
+    assert np.array_equal(fg, fo) and np.isfinite(render.film_to_rgb(fg)).all() and render.film_to_rgb(fg).max() > 0
+    for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+        assert sg[k] == so[k], k
     gpu.close(); orc.close()
 
 
