@@ -38,6 +38,7 @@ struct FlatScene {
     float scene_radius = 0.0f;
     bool has_spheres = false;  // any non-triangle shape (sphere or bilinear patch): selects k_trace3<.., TRI_ONLY = false>
     bool has_layered = false;  // any Coated* material: selects the k_shade instantiation that carries LayeredBxDF
+    bool diffuse_only = true;  // every material is a DiffuseMaterial: selects the k_shade instantiation with the other BxDFs compiled out
     // image textures (ABI v6)
     std::vector<ShmImageTexture> image_textures;
     std::vector<ShmImageLevel> image_levels;
@@ -399,6 +400,7 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
     uint32_t nsf = (uint32_t)out.spectrum_data.size();
     for (const ShmMaterial& m : out.materials) {
         if (m.kind > SHM_MATERIAL_MIX) { err = "unsupported material kind"; return SHM_ERR_UNSUPPORTED; }
+        if (m.kind != SHM_MATERIAL_DIFFUSE) out.diffuse_only = false;
         if (m.kind == SHM_MATERIAL_MIX) {
             // both branches must reach a single material: follow every path with a step bound (a cycle never terminates)
             if (m.mix_material[0] >= d->n_materials || m.mix_material[1] >= d->n_materials) { err = "mix material index out of range"; return SHM_ERR_INVALID_ARGUMENT; }

@@ -473,7 +473,9 @@ constexpr int SHADE_CHUNK = 2048;  // queue entries per workgroup chunk: ONE glo
 //   sampling code (with it the kernel needs 264 VGPRs, one wave per SIMD; without it 243, two waves).
 //   HAS_TEX = true is the instantiation for scenes that bind image textures: the path carries ray differentials (texture.h),
 //   get_bsdf filters the MIP pyramids. One general instantiation <true, false, true>.
-template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false>
+//   DIFFUSE_ONLY = true is the instantiation for scenes whose materials are all DiffuseMaterial (the headline scene class): the
+//   conductor / dielectric BxDFs and the material dispatch are compiled out of it.
+template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ONLY = false>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters, int shadow_parity) {
@@ -562,8 +564,11 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                     if (fl & (1u << 10)) aux = ld_aux(pa, path);
                     df = compute_differentials(sv, si, aux, params.samples_per_pixel, params.disable_pixel_jitter != 0);
                 }
-                BSDF bsdf = get_bsdf<HAS_TEX>(sv, si, sv.materials[prim.material], lambda, &df);
+                const ShmMaterial& mat = sv.materials[prim.material];
+                if (DIFFUSE_ONLY) __builtin_assume(mat.kind == SHM_MATERIAL_DIFFUSE);
+                BSDF bsdf = get_bsdf<HAS_TEX>(sv, si, mat, lambda, &df);
                 if (!HAS_LAYERED) __builtin_assume(bsdf.bxdf.kind <= SHM_MATERIAL_THIN_DIELECTRIC);
+                if (DIFFUSE_ONLY) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIFFUSE);
                 if (params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
                 bool alive = (depth != params.max_depth);  // integrator.rs:830-834
                 Rng rng;
@@ -1388,6 +1393,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                                        s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, sh);
                 else if (s->flat.has_textures) launch_shade(k_shade<true, false, true>);
                 else if (s->flat.has_layered) { if (tri_only) launch_shade(k_shade<true, true>); else launch_shade(k_shade<true, false>); }
+                else if (tri_only && s->flat.diffuse_only && !getenv("SHM_NO_DIFFUSE_ONLY")) launch_shade(k_shade<false, true, false, true>);
                 else { if (tri_only) launch_shade(k_shade<false, true>); else launch_shade(k_shade<false, false>); }
                 hipEventRecord(s1, s->stream);
                 ev_shade.push_back({s0, s1});
