@@ -147,7 +147,30 @@ enum {
                                          The reference draws the choice from the tile's entropy-seeded SmallRng (integrator.rs:255);
                                          here it is a hash of (wo, p), the way PBRT-v4 defines it: reproducible, parity unpinned. */
 };
-/* Constant textures only (image textures are a "next" row). */
+/* FloatTexture (texture.rs:88-305, 309-403), ABI v6: a node table; children are indices into ShmSceneDesc::float_textures and must
+ * precede their parent (no cycles); a tree (counting a shared child once per use) may hold at most 32 nodes. Materials refer to a node through ShmMaterial::float_tex. */
+enum {
+    SHM_FLOATTEX_CONSTANT = 0,      /* FloatConstantTexture: value */
+    SHM_FLOATTEX_SCALED = 1,        /* FloatScaledTexture:  tex = a, scale = b */
+    SHM_FLOATTEX_MIX = 2,           /* FloatMixTexture:     tex1 = a, tex2 = b, amount = c */
+    SHM_FLOATTEX_DIRECTION_MIX = 3, /* FloatDirectionMixTexture: tex1 = a, tex2 = b, dir */
+    SHM_FLOATTEX_IMAGE = 4          /* FloatImageTexture: image = index into ShmSceneDesc::image_textures (its spectrum_type and
+                                       has_color_space are ignored) */
+};
+typedef struct ShmFloatTexture {
+    uint32_t kind;
+    float value;
+    uint32_t a, b, c;
+    float dir[3];
+    uint32_t image;
+    uint32_t pad[3];
+} ShmFloatTexture;
+/* indices into ShmMaterial::float_tex */
+enum {
+    SHM_FLOATSLOT_DISPLACEMENT = 0, SHM_FLOATSLOT_U_ROUGHNESS = 1, SHM_FLOATSLOT_V_ROUGHNESS = 2, SHM_FLOATSLOT_U2_ROUGHNESS = 3,
+    SHM_FLOATSLOT_V2_ROUGHNESS = 4, SHM_FLOATSLOT_THICKNESS = 5, SHM_FLOATSLOT_G = 6, SHM_FLOATSLOT_MIX_AMOUNT = 7
+};
+/* Every float parameter is a constant unless float_tex[slot] != 0; spectrum slots a, b, c may bind image textures. */
 typedef struct ShmMaterial {
     uint32_t kind;
     uint32_t has_displacement; /* Diffuse: always 1 with a constant-0 texture (material.rs:280, quirk 8) */
@@ -165,6 +188,11 @@ typedef struct ShmMaterial {
     ShmSpectrum b;  /* Conductor / CoatedConductor: k */
     ShmSpectrum c;  /* Coated*: albedo of the medium */
     ShmSpectrum d;  /* Coated*: eta of the dielectric interface */
+    uint32_t float_tex[8];  /* ABI v6: SHM_FLOATSLOT_*: 0 = the constant field above, else 1 + index into ShmSceneDesc::float_textures */
+    uint32_t normal_map;    /* 0 = none, else 1 + index into ShmSceneDesc::image_textures of the normal map (3 channels; only its finest
+                               level, repeat wrap and bilinear lookup are used: material::normal_map, material.rs:1453-1475). Ignored
+                               when has_displacement is set (interaction.rs:223-236), so never reached on a DiffuseMaterial (quirk 8) */
+    uint32_t pad[3];
 } ShmMaterial;
 
 enum {
@@ -308,8 +336,9 @@ typedef struct ShmSceneDesc {
     ShmColorSpace color_space;
     const float* ewa_filter_lut;  /* MIP_FILTER_LUT (mipmap.rs:390-521), 128 floats; required when a texture uses SHM_TEXFILTER_EWA */
     uint32_t n_image_lights;
-    uint32_t pad2;
+    uint32_t n_float_textures;
     const ShmImageInfiniteLight* image_lights;
+    const ShmFloatTexture* float_textures;
 } ShmSceneDesc;
 
 /* ---- render parameters ----------------------------------------------------------------------- */

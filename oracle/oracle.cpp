@@ -890,6 +890,30 @@ int orc_fn_spawn_ray_differentials(const float* p, const float* n, const float* 
 }
 
 
+// FloatTexture::evaluate of node `index`
+float orc_fn_float_texture_evaluate(OrcScene* s, uint32_t index, const float* ctx18) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    return float_texture_evaluate(o->sv, index, make_tex_ctx(ctx18));
+}
+// bump_map (which = 0, tex = float texture node) / normal_map (which = 1, tex = image texture) on a hand-made interaction:
+// geo = p, n (geometric = shading), dpdu, dpdv, dndu, dndv (18 floats), uv, duv = dudx, dudy, dvdx, dvdy; out6 = dpdu', dpdv'
+void orc_fn_bump_or_normal_map(OrcScene* s, int which, uint32_t tex, const float* geo18, const float* uv, const float* duv, float* out6) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    SurfaceInteraction si;
+    memset(&si, 0, sizeof(si));
+    si.pi = p3i_exact(ld3(geo18));
+    si.n = ld3(geo18 + 3);
+    si.uv = v2(uv[0], uv[1]);
+    si.dpdu = ld3(geo18 + 6); si.dpdv = ld3(geo18 + 9); si.dndu = ld3(geo18 + 12); si.dndv = ld3(geo18 + 15);
+    si.shading.n = si.n; si.shading.dpdu = si.dpdu; si.shading.dpdv = si.dpdv; si.shading.dndu = si.dndu; si.shading.dndv = si.dndv;
+    Differentials df = differentials_zero();
+    df.dudx = duv[0]; df.dudy = duv[1]; df.dvdx = duv[2]; df.dvdy = duv[3];
+    V3 a, b;
+    if (which == 0) bump_map_texture(o->sv, tex, si, df, a, b);
+    else normal_map_texture(o->sv, tex, si, a, b);
+    out6[0] = a.x; out6[1] = a.y; out6[2] = a.z; out6[3] = b.x; out6[4] = b.y; out6[5] = b.z;
+}
+
 // ---- ImageInfinitelight ----
 void orc_fn_equal_area_square_to_sphere(const float* uv, float* out3) {
     V3 d = equal_area_square_to_sphere(v2(uv[0], uv[1]));

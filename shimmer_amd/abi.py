@@ -23,6 +23,9 @@ SHM_TEXMAP_UV, SHM_TEXMAP_SPHERICAL, SHM_TEXMAP_CYLINDRICAL, SHM_TEXMAP_PLANAR =
 SHM_TEXFILTER_POINT, SHM_TEXFILTER_BILINEAR, SHM_TEXFILTER_TRILINEAR, SHM_TEXFILTER_EWA = 0, 1, 2, 3
 SHM_WRAP_BLACK, SHM_WRAP_CLAMP, SHM_WRAP_REPEAT, SHM_WRAP_OCTAHEDRAL_SPHERE = 0, 1, 2, 3
 SHM_SPECTRUM_TYPE_ALBEDO, SHM_SPECTRUM_TYPE_UNBOUNDED, SHM_SPECTRUM_TYPE_ILLUMINANT = 0, 1, 2
+SHM_FLOATTEX_CONSTANT, SHM_FLOATTEX_SCALED, SHM_FLOATTEX_MIX, SHM_FLOATTEX_DIRECTION_MIX, SHM_FLOATTEX_IMAGE = 0, 1, 2, 3, 4
+(SHM_FLOATSLOT_DISPLACEMENT, SHM_FLOATSLOT_U_ROUGHNESS, SHM_FLOATSLOT_V_ROUGHNESS, SHM_FLOATSLOT_U2_ROUGHNESS,
+ SHM_FLOATSLOT_V2_ROUGHNESS, SHM_FLOATSLOT_THICKNESS, SHM_FLOATSLOT_G, SHM_FLOATSLOT_MIX_AMOUNT) = range(8)
 SHM_CAMERA_PERSPECTIVE, SHM_CAMERA_ORTHOGRAPHIC = 0, 1
 SHM_INTEGRATOR_PATH, SHM_INTEGRATOR_SIMPLE_PATH, SHM_INTEGRATOR_RANDOM_WALK = 0, 1, 2
 
@@ -68,7 +71,13 @@ class ShmMaterial(C.Structure):
                 ("remap_roughness", C.c_uint32), ("u_roughness", C.c_float), ("v_roughness", C.c_float),
                 ("u2_roughness", C.c_float), ("v2_roughness", C.c_float), ("thickness", C.c_float), ("g", C.c_float),
                 ("max_depth", C.c_int32), ("n_samples", C.c_int32), ("conductor_from_reflectance", C.c_uint32),
-                ("mix_material", C.c_uint32 * 2), ("mix_amount", C.c_float), ("a", ShmSpectrum), ("b", ShmSpectrum), ("c", ShmSpectrum), ("d", ShmSpectrum)]
+                ("mix_material", C.c_uint32 * 2), ("mix_amount", C.c_float), ("a", ShmSpectrum), ("b", ShmSpectrum), ("c", ShmSpectrum), ("d", ShmSpectrum),
+                ("float_tex", C.c_uint32 * 8), ("normal_map", C.c_uint32), ("pad", C.c_uint32 * 3)]
+
+
+class ShmFloatTexture(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("value", C.c_float), ("a", C.c_uint32), ("b", C.c_uint32), ("c", C.c_uint32),
+                ("dir", C.c_float * 3), ("image", C.c_uint32), ("pad", C.c_uint32 * 3)]
 
 
 class ShmLight(C.Structure):
@@ -123,8 +132,8 @@ class ShmSceneDesc(C.Structure):
                 ("patch_meshes", C.POINTER(ShmBilinearPatchMesh)),
                 ("n_image_textures", C.c_uint32), ("n_image_levels", C.c_uint32), ("image_textures", C.POINTER(ShmImageTexture)),
                 ("image_levels", C.POINTER(ShmImageLevel)), ("n_texel_floats", C.c_uint64), ("texel_data", c_float_p),
-                ("color_space", ShmColorSpace), ("ewa_filter_lut", c_float_p), ("n_image_lights", C.c_uint32), ("pad2", C.c_uint32),
-                ("image_lights", C.POINTER(ShmImageInfiniteLight))]
+                ("color_space", ShmColorSpace), ("ewa_filter_lut", c_float_p), ("n_image_lights", C.c_uint32), ("n_float_textures", C.c_uint32),
+                ("image_lights", C.POINTER(ShmImageInfiniteLight)), ("float_textures", C.POINTER(ShmFloatTexture))]
 
 
 class ShmRenderParams(C.Structure):
@@ -160,7 +169,7 @@ class ShmHit(C.Structure):
                 ("phi", C.c_float), ("pad", C.c_uint32 * 2)]
 
 
-assert C.sizeof(ShmMaterial) == 64 + 4 * 32 and C.sizeof(ShmBvhNode) == 32 and C.sizeof(ShmRay) == 32 and C.sizeof(ShmHit) == 32 and C.sizeof(ShmFilmPixel) == 32
+assert C.sizeof(ShmMaterial) == 64 + 4 * 32 + 48 and C.sizeof(ShmFloatTexture) == 48 and C.sizeof(ShmBvhNode) == 32 and C.sizeof(ShmRay) == 32 and C.sizeof(ShmHit) == 32 and C.sizeof(ShmFilmPixel) == 32
 
 # Every symbol include/shimmer_hip.h declares, with its signature (tests check the .so exports all of them).
 EXPORTS = {

@@ -12,7 +12,7 @@
 
 #include "../shm/scene.h"
 
-static_assert(sizeof(ShmMaterial) == 192 && sizeof(ShmSpectrum) == 32 && sizeof(ShmBvhNode) == 32 && sizeof(ShmPrimitive) == 16,
+static_assert(sizeof(ShmMaterial) == 240 && sizeof(ShmFloatTexture) == 48 && sizeof(ShmSpectrum) == 32 && sizeof(ShmBvhNode) == 32 && sizeof(ShmPrimitive) == 16,
               "POD layouts of include/shimmer_hip.h (mirrored by shimmer_amd/abi.py)");
 namespace shm_host {
 
@@ -47,6 +47,9 @@ struct FlatScene {
     uint32_t rgb2spec_res = 0;
     bool has_textures = false;  // a material slot binds an image texture (the path carries ray differentials) or an image infinite
                                 // light exists (both read the colour-space tables): selects k_shade<.., HAS_TEX>
+    std::vector<ShmFloatTexture> float_textures;
+    std::vector<shm::FloatTexRange> ftex_ranges;
+    std::vector<shm::FloatTexOp> ftex_ops;
     std::vector<shm::ImageLightRec> image_lights;
     std::vector<float> dist_data;
 
@@ -91,6 +94,9 @@ struct FlatScene {
         v.rgb2spec_data = rgb2spec_data.data();
         v.cs_illuminant = cs_illuminant.data();
         v.ewa_lut = ewa_lut.data();
+        v.float_textures = float_textures.data();
+        v.ftex_ranges = ftex_ranges.data();
+        v.ftex_ops = ftex_ops.data();
         v.image_lights = image_lights.data();
         v.dist_data = dist_data.data();
         return v;
@@ -395,12 +401,60 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         out.has_textures = true;
     }
 
+    // FloatTexture node table (texture.rs:88-305): children precede parents, nesting <= 4 (float_texture_evaluate's bound)
+    if (d->n_float_textures) {
+        if (!d->float_textures) { err = "float texture array missing"; return SHM_ERR_INVALID_ARGUMENT; }
+        out.float_textures.assign(d->float_textures, d->float_textures + d->n_float_textures);
+        // per node its post-order evaluation program (children first; a child shared by two parents is evaluated once per use, as
+        // the reference's recursion does)
+        out.ftex_ranges.resize(d->n_float_textures);
+        for (uint32_t i = 0; i < d->n_float_textures; ++i) {
+            const ShmFloatTexture& t = out.float_textures[i];
+            if (t.kind > SHM_FLOATTEX_IMAGE) { err = "unknown float texture kind"; return SHM_ERR_INVALID_ARGUMENT; }
+            std::vector<shm::FloatTexOp> prog;
+            auto append_child = [&](uint32_t k) -> int {  // copies the child's program, returns the slot of its root, or -1
+                if (k >= i) return -1;
+                const shm::FloatTexRange cr = out.ftex_ranges[k];
+                const uint32_t base = (uint32_t)prog.size();
+                for (uint32_t q = 0; q < cr.count; ++q) {
+                    shm::FloatTexOp op = out.ftex_ops[cr.first + q];
+                    op.a = (uint8_t)(op.a + base); op.b = (uint8_t)(op.b + base); op.c = (uint8_t)(op.c + base);
+                    prog.push_back(op);
+                }
+                return (int)prog.size() - 1;
+            };
+            shm::FloatTexOp self{};
+            self.node = i;
+            if (t.kind == SHM_FLOATTEX_IMAGE) {
+                if (t.image >= d->n_image_textures) { err = "float image texture: image index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            } else if (t.kind != SHM_FLOATTEX_CONSTANT) {
+                int a = append_child(t.a), b = append_child(t.b), c = (t.kind == SHM_FLOATTEX_MIX) ? append_child(t.c) : 0;
+                if (a < 0 || b < 0 || c < 0) { err = "float texture children must precede their parent"; return SHM_ERR_INVALID_ARGUMENT; }
+                self.a = (uint8_t)a; self.b = (uint8_t)b; self.c = (uint8_t)c;
+            }
+            prog.push_back(self);
+            if (prog.size() > (size_t)shm::FTEX_MAX_OPS) { err = "float texture tree larger than 32 nodes"; return SHM_ERR_UNSUPPORTED; }
+            out.ftex_ranges[i].first = (uint32_t)out.ftex_ops.size();
+            out.ftex_ranges[i].count = (uint32_t)prog.size();
+            out.ftex_ops.insert(out.ftex_ops.end(), prog.begin(), prog.end());
+        }
+    }
+
     // materials / lights
     const uint32_t ntex = d->n_image_textures;
     uint32_t nsf = (uint32_t)out.spectrum_data.size();
     for (const ShmMaterial& m : out.materials) {
         if (m.kind > SHM_MATERIAL_MIX) { err = "unsupported material kind"; return SHM_ERR_UNSUPPORTED; }
         if (m.kind != SHM_MATERIAL_DIFFUSE) out.diffuse_only = false;
+        for (int k = 0; k < 8; ++k)
+            if (m.float_tex[k] != 0u) {
+                if (m.float_tex[k] > d->n_float_textures) { err = "material float texture index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+                out.has_textures = true;
+            }
+        if (m.normal_map != 0u) {
+            if (m.normal_map > d->n_image_textures || out.image_textures[m.normal_map - 1].n_channels != 3) { err = "normal map: image texture index out of range or not RGB"; return SHM_ERR_INVALID_ARGUMENT; }
+            out.has_textures = true;
+        }
         if (m.kind == SHM_MATERIAL_MIX) {
             // both branches must reach a single material: follow every path with a step bound (a cycle never terminates)
             if (m.mix_material[0] >= d->n_materials || m.mix_material[1] >= d->n_materials) { err = "mix material index out of range"; return SHM_ERR_INVALID_ARGUMENT; }

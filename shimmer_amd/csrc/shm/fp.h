@@ -26,8 +26,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define SHM_HD __host__ __device__ inline
+// large leaf routines that are called from many sites (image texture filtering): a real call keeps code size and compile time bounded
+#define SHM_HD_NOINLINE __host__ __device__ inline __attribute__((noinline))
 #else
 #define SHM_HD inline
+#define SHM_HD_NOINLINE inline
 #endif
 
 namespace shm {

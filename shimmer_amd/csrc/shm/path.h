@@ -148,9 +148,17 @@ template <bool HAS_TEX = false>
 SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMaterial& m_in, Wavelengths& lambda, const Differentials* df = nullptr) {
     // Resolve mixed materials (interaction.rs:205-220, MixMaterial::choose_material material.rs:1308-1329). The reference takes
     // u from the tile's entropy-seeded rng; defined here as a hash of (wo, p, nesting level): reproducible, parity unpinned.
+    // MaterialEvalContext::from(&*self) (interaction.rs:211): its TextureEvalContext part never changes below (p, n, uv, differentials)
+    TextureEvalContext tctx;
+    if (HAS_TEX) tctx = tex_ctx_from(si, *df);
+    // a float parameter: the constant field, or the FloatTexture bound to the slot
+    auto fval = [&](const ShmMaterial& mm, int slot, Float constant) {
+        if (HAS_TEX && mm.float_tex[slot] != 0u) return float_texture_evaluate(sv, mm.float_tex[slot] - 1u, tctx);
+        return constant;
+    };
     const ShmMaterial* mp = &m_in;
     for (int level = 0; mp->kind == SHM_MATERIAL_MIX && level < 16; ++level) {
-        Float amt = mp->mix_amount;
+        Float amt = fval(*mp, SHM_FLOATSLOT_MIX_AMOUNT, mp->mix_amount);
         uint32_t pick;
         if (amt <= 0.0f) pick = 0;
         else if (amt >= 1.0f) pick = 1;
@@ -162,19 +170,27 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
         mp = &sv.materials[mp->mix_material[pick]];
     }
     const ShmMaterial& m = *mp;
+    // interaction.rs:223-245: displacement (bump map) takes precedence over a normal map
     if (m.has_displacement) {
-        // bump_map, material.rs:1477-1508, with FloatConstantTexture: u_displace == v_displace == displace.
-        // du, dv are finite and > 0 (interaction.rs:316-339 clamps; 0 -> 0.0005), so (x - x) / du == +0.
-        Float displace = m.displacement;
-        Float du = 0.0005f, dv = 0.0005f;
-        V3 dpdu = si.shading.dpdu + (displace - displace) / du * si.shading.n + displace * si.shading.dndu;
-        V3 dpdv = si.shading.dpdv + (displace - displace) / dv * si.shading.n + displace * si.shading.dndv;
+        V3 dpdu, dpdv;
+        if (HAS_TEX && m.float_tex[SHM_FLOATSLOT_DISPLACEMENT] != 0u) {
+            bump_map_texture(sv, m.float_tex[SHM_FLOATSLOT_DISPLACEMENT] - 1u, si, *df, dpdu, dpdv);
+        } else {
+            // bump_map, material.rs:1477-1508, with FloatConstantTexture: u_displace == v_displace == displace.
+            // du, dv are finite and > 0 (interaction.rs:316-339 clamps; 0 -> 0.0005), so (x - x) / du == +0.
+            Float displace = m.displacement;
+            Float du = 0.0005f, dv = 0.0005f;
+            dpdu = si.shading.dpdu + (displace - displace) / du * si.shading.n + displace * si.shading.dndu;
+            dpdv = si.shading.dpdv + (displace - displace) / dv * si.shading.n + displace * si.shading.dndv;
+        }
+        V3 ns = normalize(cross(dpdu, dpdv));
+        set_shading_geometry(si, ns, dpdu, dpdv, si.shading.dndu, si.shading.dndv, false);
+    } else if (HAS_TEX && m.normal_map != 0u) {
+        V3 dpdu, dpdv;
+        normal_map_texture(sv, m.normal_map - 1u, si, dpdu, dpdv);
         V3 ns = normalize(cross(dpdu, dpdv));
         set_shading_geometry(si, ns, dpdu, dpdv, si.shading.dndu, si.shading.dndv, false);
     }
-    // MaterialEvalContext::from(&*self) after the shading geometry is final (interaction.rs:211, 245): TextureEvalContext part
-    TextureEvalContext tctx;
-    if (HAS_TEX) tctx = tex_ctx_from(si, *df);
     auto tex = [&](const ShmSpectrum& s) { return spectrum_texture_evaluate<HAS_TEX>(sv, s, &tctx, lambda); };
     BxDF b;
     b.kind = m.kind;
@@ -193,7 +209,7 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
     if (m.kind == SHM_MATERIAL_DIFFUSE) {
         b.r = clamp(tex(m.a), 0.0f, 1.0f);  // material.rs:301-311
     } else if (m.kind == SHM_MATERIAL_CONDUCTOR) {  // material.rs:456-499
-        Float ur = m.u_roughness, vr = m.v_roughness;
+        Float ur = fval(m, SHM_FLOATSLOT_U_ROUGHNESS, m.u_roughness), vr = fval(m, SHM_FLOATSLOT_V_ROUGHNESS, m.v_roughness);
         if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
         b.r = tex(m.a);
         b.k = tex(m.b);
@@ -202,7 +218,7 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
         Float sampled_eta = spectrum_get(m.a, sv.spectrum_data, lambda.lambda[0]);
         if (m.a.kind != SHM_SPECTRUM_CONSTANT) terminate_secondary(lambda);
         if (sampled_eta == 0.0f) sampled_eta = 1.0f;
-        Float ur = m.u_roughness, vr = m.v_roughness;
+        Float ur = fval(m, SHM_FLOATSLOT_U_ROUGHNESS, m.u_roughness), vr = fval(m, SHM_FLOATSLOT_V_ROUGHNESS, m.v_roughness);
         if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
         b.eta = sampled_eta;
         b.mf = trowbridge_reitz_new(ur, vr);
@@ -213,23 +229,23 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
         b.eta = sampled_eta;
     } else if (m.kind == SHM_MATERIAL_COATED_DIFFUSE) {  // material.rs:917-963
         b.r = clamp(tex(m.a), 0.0f, 1.0f);
-        Float ur = m.u_roughness, vr = m.v_roughness;
+        Float ur = fval(m, SHM_FLOATSLOT_U_ROUGHNESS, m.u_roughness), vr = fval(m, SHM_FLOATSLOT_V_ROUGHNESS, m.v_roughness);
         if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
         b.mf = trowbridge_reitz_new(ur, vr);
-        b.thickness = m.thickness;
+        b.thickness = fval(m, SHM_FLOATSLOT_THICKNESS, m.thickness);
         Float sampled_eta = spectrum_get(m.d, sv.spectrum_data, lambda.lambda[0]);
         if (m.d.kind != SHM_SPECTRUM_CONSTANT) terminate_secondary(lambda);
         if (sampled_eta == 0.0f) sampled_eta = 1.0f;
         b.eta = sampled_eta;
         b.albedo = clamp(tex(m.c), 0.0f, 1.0f);
-        b.g = clamp(m.g, -1.0f, 1.0f);
+        b.g = clamp(fval(m, SHM_FLOATSLOT_G, m.g), -1.0f, 1.0f);
         b.max_depth = m.max_depth;
         b.n_samples = m.n_samples;
     } else {  // CoatedConductor, material.rs:1189-1256
-        Float iur = m.u_roughness, ivr = m.v_roughness;
+        Float iur = fval(m, SHM_FLOATSLOT_U_ROUGHNESS, m.u_roughness), ivr = fval(m, SHM_FLOATSLOT_V_ROUGHNESS, m.v_roughness);
         if (m.remap_roughness) { iur = roughness_to_alpha(iur); ivr = roughness_to_alpha(ivr); }
         b.mf = trowbridge_reitz_new(iur, ivr);
-        b.thickness = m.thickness;
+        b.thickness = fval(m, SHM_FLOATSLOT_THICKNESS, m.thickness);
         Float ieta = spectrum_get(m.d, sv.spectrum_data, lambda.lambda[0]);
         if (m.d.kind != SHM_SPECTRUM_CONSTANT) terminate_secondary(lambda);
         if (ieta == 0.0f) ieta = 1.0f;
@@ -244,7 +260,7 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
         }
         ce = ce / ieta;
         ck = ck / ieta;
-        Float cur = m.u2_roughness, cvr = m.v2_roughness;
+        Float cur = fval(m, SHM_FLOATSLOT_U2_ROUGHNESS, m.u2_roughness), cvr = fval(m, SHM_FLOATSLOT_V2_ROUGHNESS, m.v2_roughness);
         // material.rs:1239-1243: with remap_roughness the conductor's alphas are derived from the (already remapped)
         // INTERFACE roughness, not from its own: reference behaviour preserved
         if (m.remap_roughness) { cur = roughness_to_alpha(iur); cvr = roughness_to_alpha(ivr); }
@@ -253,7 +269,7 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
         b.k = ck;
         b.eta = ieta;
         b.albedo = clamp(tex(m.c), 0.0f, 1.0f);
-        b.g = clamp(m.g, -1.0f, 1.0f);
+        b.g = clamp(fval(m, SHM_FLOATSLOT_G, m.g), -1.0f, 1.0f);
         b.max_depth = m.max_depth;
         b.n_samples = m.n_samples;
     }

@@ -79,9 +79,25 @@ struct SceneView {
     const Float* rgb2spec_data;
     const Float* cs_illuminant;  // 471 floats, 360..=830
     const Float* ewa_lut;        // MIP_FILTER_LUT, 128 floats
+    const ShmFloatTexture* float_textures;
+    const struct FloatTexRange* ftex_ranges;  // per node: its evaluation program (children first) in ftex_ops
+    const struct FloatTexOp* ftex_ops;
     // image infinite lights: per light its transform + image + the two PiecewiseConstant2D distributions, flattened into dist_data
     const struct ImageLightRec* image_lights;
     const Float* dist_data;
+};
+
+// A FloatTexture tree flattened at scene creation into a post-order program: evaluating the ops in order (each into slot k of a
+// small value array) and combining children by their slots reproduces FloatTexture::evaluate's recursion without device recursion.
+// The reference's lazy branches ("if amt != 1 { t1 = tex1.evaluate() }", texture.rs:244-305) only skip work: evaluation has no side
+// effects, so selecting 0 for a skipped child gives the same value.
+constexpr int FTEX_MAX_OPS = 32;
+struct FloatTexOp {
+    uint32_t node;       // index into SceneView::float_textures
+    uint8_t a, b, c, pad;  // slots of the children within this program
+};
+struct FloatTexRange {
+    uint32_t first, count;  // into SceneView::ftex_ops; the root is the last op
 };
 
 // PiecewiseConstant2D (sampling.rs:113-179) of an n x n image, flattened: conditional func [n*n], conditional cdf [n*(n+1)],

@@ -408,6 +408,133 @@ SHM_HD RGB3 tex_filter(const TextureView& tv, const Float* lut, V2 st, V2 dst0, 
     return lerp_rgb(level - (Float)i_level, tex_bilerp(tv, i_level, st), tex_bilerp(tv, i_level + 1, st));
 }
 
+// TexelType for Float (mipmap.rs:297-312): texel = channel 0; bilerp = channel 0 of a one-channel image, the AVERAGE of the three
+// bilerps of an RGB one (an RGBA image would use its alpha: the ABI hands over 1 or 3 channels)
+SHM_HD Float tex_texel_f(const TextureView& tv, int level, int x, int y) { return tex_channel(tv, level, x, y, 0); }
+SHM_HD Float tex_bilerp_f(const TextureView& tv, int level, V2 st) {
+    if (tv.t->n_channels == 1) return tex_bilerp_channel(tv, level, st, 0);
+    // ImageChannelValues::average, image.rs:275-277
+    return (((0.0f + tex_bilerp_channel(tv, level, st, 0)) + tex_bilerp_channel(tv, level, st, 1)) + tex_bilerp_channel(tv, level, st, 2)) / 3.0f;
+}
+// MIPMap::filter::<Float> / TexelType::ewa for Float: the same control flow as tex_filter / tex_ewa with scalar texels
+SHM_HD Float tex_ewa_f(const TextureView& tv, const Float* lut, int level, V2 st, V2 dst0, V2 dst1) {
+    int n_levels = (int)tv.t->n_levels;
+    if (level >= n_levels) return tex_texel_f(tv, n_levels - 1, 0, 0);
+    const ShmImageLevel& l = tv.levels[level];
+    st.x = st.x * (Float)l.width - 0.5f;
+    st.y = st.y * (Float)l.height - 0.5f;
+    dst0.x *= (Float)l.width;
+    dst0.y *= (Float)l.height;
+    dst1.x *= (Float)l.width;
+    dst1.y *= (Float)l.height;
+    Float a = sqr(dst0.y) + sqr(dst1.y) + 1.0f;
+    Float b = -2.0f * (dst0.x * dst0.y + dst1.x * dst1.y);
+    Float c = sqr(dst0.x) + sqr(dst1.x) + 1.0f;
+    Float inv_f = 1.0f / (a * c - sqr(b) * 0.25f);
+    a *= inv_f;
+    b *= inv_f;
+    c *= inv_f;
+    Float det = -sqr(b) + 4.0f * a * c;
+    Float inv_det = 1.0f / det;
+    Float u_sqrt = safe_sqrt(det * c), v_sqrt = safe_sqrt(a * det);
+    int s0 = float_to_i32(ceil(st.x - 2.0f * inv_det * u_sqrt));
+    int s1 = float_to_i32(floor(st.x + 2.0f * inv_det * u_sqrt));
+    int t0 = float_to_i32(ceil(st.y - 2.0f * inv_det * v_sqrt));
+    int t1 = float_to_i32(floor(st.y + 2.0f * inv_det * v_sqrt));
+    Float sum = 0.0f, sum_wts = 0.0f;
+    for (int it = t0; it <= t1; ++it) {
+        Float tt = (Float)it - st.y;
+        for (int is = s0; is <= s1; ++is) {
+            Float ss = (Float)is - st.x;
+            Float r2 = a * sqr(ss) + b * ss * tt + c * sqr(tt);
+            if (r2 < 1.0f) {
+                int index = float_to_i32(r2 * (Float)MIP_FILTER_LUT_SIZE);
+                if (index < 0) index = 0;
+                if (index > MIP_FILTER_LUT_SIZE - 1) index = MIP_FILTER_LUT_SIZE - 1;
+                Float weight = lut[index];
+                sum = sum + tex_texel_f(tv, level, is, it) * weight;
+                sum_wts += weight;
+            }
+        }
+    }
+    return sum / sum_wts;
+}
+SHM_HD Float tex_filter_f(const TextureView& tv, const Float* lut, V2 st, V2 dst0, V2 dst1) {
+    const ShmImageTexture& t = *tv.t;
+    int n_levels = (int)t.n_levels;
+    if (t.filter == SHM_TEXFILTER_EWA) {
+        if (length_squared(dst0) < length_squared(dst1)) { V2 tmp = dst0; dst0 = dst1; dst1 = tmp; }
+        Float longer_vec_length = sqrt(length_squared(dst0));
+        Float shorter_vec_length = sqrt(length_squared(dst1));
+        if (shorter_vec_length * t.max_anisotropy < longer_vec_length && shorter_vec_length > 0.0f) {
+            Float scale = longer_vec_length / (shorter_vec_length * t.max_anisotropy);
+            dst1 = dst1 * scale;
+            shorter_vec_length *= scale;
+        }
+        if (shorter_vec_length == 0.0f) return tex_bilerp_f(tv, 0, st);
+        Float lod = max(0.0f, (Float)n_levels - 1.0f + log2(shorter_vec_length));
+        int ilod = float_to_i32(floor(lod));
+        return lerp(lod - (Float)ilod, tex_ewa_f(tv, lut, ilod, st, dst0, dst1), tex_ewa_f(tv, lut, ilod + 1, st, dst0, dst1));
+    }
+    Float width = 2.0f * max(max(max(abs(dst0.x), abs(dst0.y)), abs(dst1.x)), abs(dst1.y));
+    Float level = (Float)n_levels - 1.0f + log2(max(width, 1e-8f));
+    if (level >= (Float)n_levels - 1.0f) return tex_texel_f(tv, n_levels - 1, 0, 0);
+    int i_level = float_to_i32(floor(level));
+    if (i_level < 0) i_level = 0;
+    if (t.filter == SHM_TEXFILTER_POINT) {
+        const ShmImageLevel& l = tv.levels[i_level];
+        return tex_texel_f(tv, i_level, float_to_i32(round(st.x * (Float)l.width - 0.5f)), float_to_i32(round(st.y * (Float)l.height - 0.5f)));
+    }
+    if (t.filter == SHM_TEXFILTER_BILINEAR) return tex_bilerp_f(tv, i_level, st);
+    if (i_level == 0) return tex_bilerp_f(tv, 0, st);
+    return lerp(level - (Float)i_level, tex_bilerp_f(tv, i_level, st), tex_bilerp_f(tv, i_level + 1, st));
+}
+SHM_HD TextureView texture_view(const SceneView& sv, uint32_t texture_index) {
+    TextureView tv;
+    tv.t = &sv.image_textures[texture_index];
+    tv.levels = sv.image_levels + tv.t->first_level;
+    tv.texels = sv.texel_data;
+    return tv;
+}
+// FloatImageTexture::evaluate, texture.rs:393-403
+SHM_HD_NOINLINE Float float_image_texture_evaluate(const SceneView& sv, uint32_t texture_index, const TextureEvalContext& ctx) {
+    TextureView tv = texture_view(sv, texture_index);
+    TexCoord2D c = texture_map(*tv.t, ctx);
+    c.st.y = 1.0f - c.st.y;
+    Float v = tex_filter_f(tv, sv.ewa_lut, c.st, v2(c.dsdx, c.dtdx), v2(c.dsdy, c.dtdy)) * tv.t->scale;
+    return tv.t->invert ? max(0.0f, 1.0f - v) : v;
+}
+// FloatTexture::evaluate (texture.rs:142-152): the node's post-order program (scene.h FloatTexOp), children before parents
+SHM_HD_NOINLINE Float float_texture_evaluate(const SceneView& sv, uint32_t index, const TextureEvalContext& ctx) {
+    const FloatTexRange r = sv.ftex_ranges[index];
+    Float vals[FTEX_MAX_OPS];
+    for (uint32_t k = 0; k < r.count; ++k) {
+        const FloatTexOp op = sv.ftex_ops[r.first + k];
+        const ShmFloatTexture& t = sv.float_textures[op.node];
+        Float v;
+        if (t.kind == SHM_FLOATTEX_CONSTANT) {            // texture.rs:175-179
+            v = t.value;
+        } else if (t.kind == SHM_FLOATTEX_IMAGE) {
+            v = float_image_texture_evaluate(sv, t.image, ctx);
+        } else if (t.kind == SHM_FLOATTEX_SCALED) {       // texture.rs:206-214: tex = a, scale = b
+            Float sc = vals[op.b];
+            v = (sc == 0.0f) ? 0.0f : vals[op.a] * sc;
+        } else if (t.kind == SHM_FLOATTEX_MIX) {          // texture.rs:244-260: tex1 = a, tex2 = b, amount = c
+            Float amt = vals[op.c];
+            Float t1 = (amt != 1.0f) ? vals[op.a] : 0.0f;
+            Float t2 = (amt != 0.0f) ? vals[op.b] : 0.0f;
+            v = t1 * (1.0f - amt) + t2 * amt;
+        } else {                                          // FloatDirectionMixTexture, texture.rs:290-305
+            Float amt = dot(ctx.n, ld3(t.dir));
+            Float t1 = (amt != 0.0f) ? vals[op.a] : 0.0f;
+            Float t2 = (amt != 1.0f) ? vals[op.b] : 0.0f;
+            v = amt * t1 + (1.0f - amt) * t2;
+        }
+        vals[k] = v;
+    }
+    return vals[r.count - 1];
+}
+
 // ---------------------------------------------------------------------------------------------
 // RGB -> sigmoid polynomial coefficients: rgb2spec 0.1.1 RGB2Spec::fetch (un-vendored; Jakob & Hanika's rgb2spec_fetch)
 // ---------------------------------------------------------------------------------------------
@@ -454,7 +581,7 @@ SHM_HD void rgb2spec_fetch(const SceneView& sv, RGB3 rgb_in, Float out[3]) {
 }
 
 // SpectrumImageTexture::evaluate, texture.rs:777-808
-SHM_HD Spec image_texture_evaluate(const SceneView& sv, uint32_t texture_index, const TextureEvalContext& ctx, const Wavelengths& lambda) {
+SHM_HD_NOINLINE Spec image_texture_evaluate(const SceneView& sv, uint32_t texture_index, const TextureEvalContext& ctx, const Wavelengths& lambda) {
     TextureView tv;
     tv.t = &sv.image_textures[texture_index];
     tv.levels = sv.image_levels + tv.t->first_level;
@@ -580,6 +707,43 @@ SHM_HD Spec image_light_le_uv(const SceneView& sv, const ImageLightRec& il, V2 u
 SHM_HD Spec image_light_le(const SceneView& sv, const ImageLightRec& il, V3 ray_d, const Wavelengths& lambda) {
     V3 w_light = xf_vector(il.light_from_render, ray_d);
     return image_light_le_uv(sv, il, equal_area_sphere_to_square(w_light), lambda);
+}
+
+// material::bump_map, material.rs:1477-1508, with a FloatTexture displacement (the constant-displacement form stays in get_bsdf).
+// The shifted contexts are TextureEvalContext::from(&NormalBumpEvalContext): their n is the SHADING normal (material.rs:1428-1432).
+SHM_HD void bump_map_texture(const SceneView& sv, uint32_t displacement, const SurfaceInteraction& si, const Differentials& df, V3& dpdu_out, V3& dpdv_out) {
+    TextureEvalContext ctx;
+    ctx.p = si.p(); ctx.dpdx = df.dpdx; ctx.dpdy = df.dpdy; ctx.n = si.shading.n; ctx.uv = si.uv;
+    ctx.dudx = df.dudx; ctx.dudy = df.dudy; ctx.dvdx = df.dvdx; ctx.dvdy = df.dvdy;
+    TextureEvalContext shifted = ctx;
+    Float du = 0.5f * (abs(df.dudx) + abs(df.dudy));
+    if (du == 0.0f) du = 0.0005f;
+    shifted.p = ctx.p + du * si.shading.dpdu;
+    shifted.uv = ctx.uv + v2(du, 0.0f);
+    Float u_displace = float_texture_evaluate(sv, displacement, shifted);
+    Float dv = 0.5f * (abs(df.dvdx) + abs(df.dvdy));
+    if (dv == 0.0f) dv = 0.0005f;
+    shifted.p = ctx.p + dv * si.shading.dpdv;
+    shifted.uv = ctx.uv + v2(0.0f, dv);
+    Float v_displace = float_texture_evaluate(sv, displacement, shifted);
+    Float displace = float_texture_evaluate(sv, displacement, ctx);
+    dpdu_out = si.shading.dpdu + (u_displace - displace) / du * si.shading.n + displace * si.shading.dndu;
+    dpdv_out = si.shading.dpdv + (v_displace - displace) / dv * si.shading.n + displace * si.shading.dndv;
+}
+// material::normal_map, material.rs:1453-1475: the finest level of the image, repeat wrap, bilinear
+SHM_HD void normal_map_texture(const SceneView& sv, uint32_t texture_index, const SurfaceInteraction& si, V3& dpdu_out, V3& dpdv_out) {
+    TextureView tv = texture_view(sv, texture_index);
+    ShmImageTexture repeat = *tv.t;
+    repeat.wrap = SHM_WRAP_REPEAT;
+    tv.t = &repeat;
+    V2 uv = v2(si.uv.x, 1.0f - si.uv.y);
+    V3 ns = v3(2.0f * tex_bilerp_channel(tv, 0, uv, 0) - 1.0f, 2.0f * tex_bilerp_channel(tv, 0, uv, 1) - 1.0f, 2.0f * tex_bilerp_channel(tv, 0, uv, 2) - 1.0f);
+    ns = normalize(ns);
+    Frame frame = frame_from_xz(normalize(si.shading.dpdu), si.shading.n);
+    ns = frame.from_local(ns);
+    Float ulen = length(si.shading.dpdu), vlen = length(si.shading.dpdv);
+    dpdu_out = normalize(gram_schmidt(si.shading.dpdu, ns)) * ulen;
+    dpdv_out = normalize(cross(ns, dpdu_out)) * vlen;
 }
 
 // SpectrumTexture::evaluate for a material slot: a constant spectrum texture samples its spectrum (texture.rs:509-513), an image

@@ -149,6 +149,7 @@ class SceneBuilder:
         self.texel_len = 0
         self.color_space = None  # dict(res, scale, data, illuminant)
         self.image_lights = []  # abi.ShmImageInfiniteLight
+        self.float_textures = []  # abi.ShmFloatTexture
 
     # ---- spectra ----
     def spectrum_constant(self, c):
@@ -348,6 +349,51 @@ class SceneBuilder:
         l.spectrum = self.spectrum_dense(dense_emission)
         self.lights.append(l)
         return len(self.lights) - 1
+
+    # ---- float textures (texture.rs:88-305) ----
+    def _ftex(self, kind, value=0.0, a=0, b=0, c=0, dir=(0.0, 1.0, 0.0), image=0):
+        t = abi.ShmFloatTexture()
+        t.kind, t.value, t.a, t.b, t.c, t.image = kind, float(value), int(a), int(b), int(c), int(image)
+        t.dir[:] = [float(x) for x in dir]
+        self.float_textures.append(t)
+        return len(self.float_textures) - 1
+
+    def _ftex_of(self, v):
+        return v if isinstance(v, (int, np.integer)) and not isinstance(v, bool) else self.ftex_constant(v)
+
+    def ftex_constant(self, value):
+        return self._ftex(abi.SHM_FLOATTEX_CONSTANT, value=value)
+
+    def ftex_scaled(self, tex=1.0, scale=1.0):
+        """"scale": both parameters are float textures (handles, i.e. ints) or numbers (floats)."""
+        a, b = self._ftex_of(tex), self._ftex_of(scale)
+        return self._ftex(abi.SHM_FLOATTEX_SCALED, a=a, b=b)
+
+    def ftex_mix(self, tex1=0.0, tex2=1.0, amount=0.5):
+        a, b, c = self._ftex_of(tex1), self._ftex_of(tex2), self._ftex_of(amount)
+        return self._ftex(abi.SHM_FLOATTEX_MIX, a=a, b=b, c=c)
+
+    def ftex_direction_mix(self, tex1=0.0, tex2=1.0, dir=(0.0, 1.0, 0.0)):
+        a, b = self._ftex_of(tex1), self._ftex_of(tex2)
+        return self._ftex(abi.SHM_FLOATTEX_DIRECTION_MIX, a=a, b=b, dir=dir)
+
+    def ftex_image(self, image, **kw):
+        """"imagemap" float texture: the same options as add_image_texture (FloatImageTexture::create, texture.rs:345-391)."""
+        kw.setdefault("color_space", False)
+        sp = self.add_image_texture(image, **kw)
+        return self._ftex(abi.SHM_FLOATTEX_IMAGE, image=sp.offset)
+
+    def set_float_texture(self, material, slot, ftex):
+        """Bind a float texture handle to one of a material's float parameters (abi.SHM_FLOATSLOT_*)."""
+        m = self.materials[material]
+        m.float_tex[slot] = int(ftex) + 1
+        if slot == abi.SHM_FLOATSLOT_DISPLACEMENT:
+            m.has_displacement = 1
+
+    def set_normal_map(self, material, image):
+        """"normalmap": an RGB image; only reached when the material has no displacement (interaction.rs:223-236)."""
+        sp = self.add_image_texture(image, color_space=False)
+        self.materials[material].normal_map = sp.offset + 1
 
     def light_image_infinite(self, image, scale=1.0, render_from_light=None):
         """ImageInfinitelight (light.rs:805-981; created by the "infinite" light with a filename, light.rs:147-190): `image` is a
@@ -595,6 +641,10 @@ class SceneBuilder:
                 ils = (abi.ShmImageInfiniteLight * len(self.image_lights))(*self.image_lights)
                 d.n_image_lights, d.image_lights = len(self.image_lights), ils
                 self._keep.append(ils)
+        if self.float_textures:
+            fts = (abi.ShmFloatTexture * len(self.float_textures))(*self.float_textures)
+            d.n_float_textures, d.float_textures = len(self.float_textures), fts
+            self._keep.append(fts)
         info = dict(n_nodes=n_nodes.value, n_primitives=n, order=order, slot_of_input=slot_of_input, bounds=bounds)
         return d, info
 

@@ -137,6 +137,23 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=Fal
                                            roughness=0.2, albedo=b.add_image_texture(img1, filter=tf("bilinear")), thickness=0.05)
         tall_m = b.material_conductor(b.spectrum_named("metal-Ag-eta"), b.spectrum_named("metal-Ag-k"), roughness=0.0)
         short_m = b.material_dielectric(1.5)
+        # float textures (texture.rs:88-403) on the float parameters, a bump map and a normal map (interaction.rs:223-245):
+        bump = b.ftex_scaled(b.ftex_image(img1, filter=tf("bilinear"), su=2.0, sv=2.0), 0.03)
+        b.set_float_texture(floor_m, abi.SHM_FLOATSLOT_DISPLACEMENT, bump)              # every DiffuseMaterial has a displacement slot
+        b.set_float_texture(back_m, abi.SHM_FLOATSLOT_DISPLACEMENT, b.ftex_image(img3, filter=tf("ewa"), scale=0.02))  # RGB image as a float: channel 0 / average
+        rough = b.ftex_mix(0.05, b.ftex_image(img1, filter=tf("trilinear"), invert=True), b.ftex_direction_mix(0.2, 0.8, dir=(0.0, -1.0, 0.0)))
+        b.set_float_texture(ceil_m, abi.SHM_FLOATSLOT_U_ROUGHNESS, rough)
+        b.set_float_texture(ceil_m, abi.SHM_FLOATSLOT_THICKNESS, b.ftex_scaled(b.ftex_image(img1, filter=tf("point")), 0.1))
+        b.set_float_texture(ceil_m, abi.SHM_FLOATSLOT_G, b.ftex_constant(0.3))
+        nm = np.stack([0.5 + 0.25 * np.sin(np.arange(16) * 0.8)[None, :].repeat(16, 0), 0.5 + 0.25 * np.cos(np.arange(16) * 0.5)[:, None].repeat(16, 1),
+                       np.full((16, 16), 0.9)], axis=2).astype(np.float32)
+        b.set_normal_map(tall_m, nm)                                                      # conductor: no displacement, so the normal map is reached
+        gold = b.material_conductor(b.spectrum_named("metal-Au-eta"), b.spectrum_named("metal-Au-k"), roughness=0.3)
+        b.set_float_texture(gold, abi.SHM_FLOATSLOT_V_ROUGHNESS, b.ftex_image(img1, filter=tf("bilinear"), scale=0.5))
+        left_m = b.material_mix(left_m, gold, 0.5)
+        b.set_float_texture(left_m, abi.SHM_FLOATSLOT_MIX_AMOUNT, b.ftex_image(img1, filter=tf("point"), su=2.0, sv=3.0, mapping="planar",
+                                                                                 vs=(0.0, 1.0, 0.0), vt=(0.0, 0.0, 1.0),
+                                                                                 texture_from_render=np.linalg.inv(to_render.astype(np.float64))))
     # room [-1,1] x [0,2] x [-1,1], open towards +z (camera side); inward-facing windings via reversed quads
     def inward(q):
         p, vi = q

@@ -23,10 +23,28 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.shm_last_error() is not None
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
     assert C.sizeof(abi.ShmBvhNode) == 32 and C.sizeof(abi.ShmPrimitive) == 16 and C.sizeof(abi.ShmSpectrum) == 32
     assert C.sizeof(abi.ShmRay) == 32 and C.sizeof(abi.ShmHit) == 32 and C.sizeof(abi.ShmFilmPixel) == 32 and C.sizeof(abi.ShmTile) == 16
-    assert C.sizeof(abi.ShmMaterial) == 64 + 4 * 32 and C.sizeof(abi.ShmLight) == 32 + 32 and C.sizeof(abi.ShmRenderParams) == 24
+    assert C.sizeof(abi.ShmMaterial) == 64 + 4 * 32 + 48 and C.sizeof(abi.ShmLight) == 32 + 32 and C.sizeof(abi.ShmRenderParams) == 24
+    # every struct of include/shimmer_hip.h as the C compiler lays it out (size, and the offset of the last field) against ctypes
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no C compiler")
+    names = ["ShmBvhNode", "ShmTriangleMesh", "ShmBilinearPatchMesh", "ShmSphere", "ShmPrimitive", "ShmSpectrum", "ShmFloatTexture",
+             "ShmMaterial", "ShmLight", "ShmImageLevel", "ShmImageTexture", "ShmColorSpace", "ShmImageInfiniteLight", "ShmCamera", "ShmFilm",
+             "ShmSceneDesc", "ShmRenderParams", "ShmTile", "ShmFilmPixel", "ShmStats", "ShmRay", "ShmHit"]
+    last = {n: getattr(abi, n)._fields_[-1][0] for n in names}
+    src = "#include <stdio.h>\n#include <stddef.h>\n#include \"shimmer_hip.h\"\nint main(void) {\n" + "".join(
+        f'  printf("{n} %zu %zu\\n", sizeof({n}), offsetof({n}, {last[n]}));\n' for n in names) + "  return 0;\n}\n"
+    (tmp_path / "probe.c").write_text(src)
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(tmp_path / "probe.c"), "-o", str(tmp_path / "probe")], check=True)
+    for line in subprocess.run([str(tmp_path / "probe")], check=True, capture_output=True, text=True).stdout.splitlines():
+        n, size, off = line.split()
+        t = getattr(abi, n)
+        assert C.sizeof(t) == int(size), n
+        assert getattr(t, last[n]).offset == int(off), n
 
 
 def test_no_device_is_a_loud_error_not_a_fallback(lib):

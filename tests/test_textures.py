@@ -452,6 +452,89 @@ def test_specular_differentials_on_a_plane(orc):
     assert has == 0
 
 
+# ---- float textures, bump and normal maps ---------------------------------------------------------------------
+def test_float_texture_graph(lib):
+    """FloatTexture::evaluate (texture.rs:142-305, 393-403): constant / scale / mix / directionmix / imagemap nodes against a
+    float64 evaluation of the same graph; an RGB image read as a float is channel 0 for texel lookups (point, EWA) and the
+    three-channel AVERAGE for bilinear ones (TexelType for Float, mipmap.rs:297-312)."""
+    sc = scenes.cornell_box(lib, 8, 8)
+    b = sc.builder
+    img1, img3 = scenes.test_image(16, 1, seed=3), scenes.test_image(16, 3, seed=4)
+    t_img1 = b.ftex_image(img1, filter="bilinear", scale=0.7)
+    t_img3p = b.ftex_image(img3, filter="point")
+    t_img3b = b.ftex_image(img3, filter="bilinear", invert=True)
+    t_scaled = b.ftex_scaled(t_img1, 0.25)
+    t_zero = b.ftex_scaled(t_img1, 0.0)
+    t_dir = b.ftex_direction_mix(0.2, t_img1, dir=(0.0, 0.6, 0.8))
+    t_mix = b.ftex_mix(t_scaled, t_dir, t_img3b)
+    t_deep = b.ftex_mix(t_mix, 1.0, b.ftex_scaled(t_mix, t_dir))
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    try:
+        rng = np.random.default_rng(0)
+        for _ in range(40):
+            uv = rng.uniform(0.05, 0.95, 2)
+            n = rng.normal(size=3)
+            n /= np.linalg.norm(n)
+            ctx = fa(0.1, 0.2, 0.3, 1e-3, 0, 0, 0, 1e-3, 0, *n, *uv, 1e-3, 0.0, 0.0, 1e-3)
+            ev = lambda t: float(o.lib.orc_fn_float_texture_evaluate(o.handle, t, ctx))
+            st = (float(f32(uv[0])), 1.0 - float(f32(uv[1])))
+            lv1, lv3 = generate_pyramid(img1), generate_pyramid(img3)
+            v1 = bilerp(lv1[0], st, abi.SHM_WRAP_REPEAT)[0] * 0.7
+            h, w = lv3[0].shape[:2]
+            rnd = lambda v: math.floor(abs(v) + 0.5) * (1 if v >= 0 else -1)
+            v3p = texel(lv3[0], int(rnd(st[0] * w - 0.5)), int(rnd(st[1] * h - 0.5)), abi.SHM_WRAP_REPEAT)[0]
+            v3b = max(0.0, 1.0 - bilerp(lv3[0], st, abi.SHM_WRAP_REPEAT).mean())
+            assert ev(t_img1) == pytest.approx(v1, rel=2e-5) and ev(t_img3b) == pytest.approx(v3b, rel=2e-5, abs=1e-6)
+            if min(abs((st[0] * w - 0.5) % 1 - 0.5), abs((st[1] * h - 0.5) % 1 - 0.5)) > 1e-3:
+                assert ev(t_img3p) == pytest.approx(v3p, rel=1e-6)
+            amt_d = float(n @ np.array([0.0, 0.6, 0.8]))
+            vdir = amt_d * 0.2 + (1 - amt_d) * v1
+            vmix = (v1 * 0.25) * (1 - v3b) + vdir * v3b
+            assert ev(t_scaled) == pytest.approx(v1 * 0.25, rel=2e-5) and ev(t_zero) == 0.0
+            assert ev(t_dir) == pytest.approx(vdir, rel=5e-5, abs=1e-6) and ev(t_mix) == pytest.approx(vmix, rel=5e-5, abs=1e-6)
+            a2 = vmix * vdir
+            assert ev(t_deep) == pytest.approx(vmix * (1 - a2) + 1.0 * a2, rel=1e-4, abs=1e-6)
+    finally:
+        o.close()
+
+
+def test_bump_and_normal_map(lib):
+    """material.rs:1453-1508. A displacement that rises linearly along u tilts dpdu by slope * n and leaves dpdv alone; a constant
+    one changes nothing on a flat surface; a normal map of (0.5, 0.5, 1) is the identity and one leaning towards +s tilts the
+    frame about dpdv."""
+    sc = scenes.cornell_box(lib, 8, 8)
+    b = sc.builder
+    ramp = np.tile((np.arange(32, dtype=np.float32) + 0.5) / 32, (32, 1))  # value = u at texel centres
+    t_ramp = b.ftex_image(ramp, filter="bilinear", wrap="clamp")
+    t_const = b.ftex_constant(0.37)
+    flat = np.zeros((4, 4, 3), np.float32) + np.array([0.5, 0.5, 1.0], np.float32)
+    lean = np.zeros((4, 4, 3), np.float32) + np.array([0.75, 0.5, 0.5 + 0.5 * math.sqrt(0.75)], np.float32)  # (0.5, 0, 0.866) in [-1,1]^3
+    nm_flat = b.add_image_texture(flat, color_space=False).offset
+    nm_lean = b.add_image_texture(lean, color_space=False).offset
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    out = (C.c_float * 6)()
+    geo = fa(0.2, 0.1, 0.0, 0, 0, 1, 2.0, 0, 0, 0, 3.0, 0, 0, 0, 0, 0, 0, 0)  # p, n = +z, dpdu = 2x, dpdv = 3y, dndu = dndv = 0
+    try:
+        o.lib.orc_fn_bump_or_normal_map(o.handle, 0, t_const, geo, fa(0.4, 0.6), fa(1e-3, 0, 0, 1e-3), out)
+        assert np.allclose(out[:], (2, 0, 0, 0, 3, 0), atol=1e-6)
+        o.lib.orc_fn_bump_or_normal_map(o.handle, 0, t_ramp, geo, fa(0.4, 0.6), fa(4e-3, 0, 0, 4e-3), out)
+        assert np.allclose(out[:], (2, 0, 1.0, 0, 3, 0), atol=2e-3)  # d(displacement)/du = 1
+        o.lib.orc_fn_bump_or_normal_map(o.handle, 0, t_ramp, geo, fa(0.4, 0.6), fa(0, 0, 0, 0), out)  # du = dv = 0 -> 0.0005 (material.rs:1486-1489)
+        assert np.allclose(out[:], (2, 0, 1.0, 0, 3, 0), atol=5e-3)
+        o.lib.orc_fn_bump_or_normal_map(o.handle, 1, nm_flat, geo, fa(0.4, 0.6), fa(0, 0, 0, 0), out)
+        assert np.allclose(out[:], (2, 0, 0, 0, 3, 0), atol=1e-5)
+        o.lib.orc_fn_bump_or_normal_map(o.handle, 1, nm_lean, geo, fa(0.4, 0.6), fa(0, 0, 0, 0), out)
+        dpdu, dpdv = np.array(out[0:3]), np.array(out[3:6])
+        ns = np.cross(dpdu, dpdv)
+        ns /= np.linalg.norm(ns)
+        assert np.allclose(ns, (0.5, 0, math.sqrt(0.75)), atol=1e-5)  # the frame is (dpdu, n x dpdu, n): local x = world x here
+        assert np.linalg.norm(dpdu) == pytest.approx(2.0, rel=1e-6) and np.linalg.norm(dpdv) == pytest.approx(3.0, rel=1e-6)
+    finally:
+        o.close()
+
+
 # ---- whole renders --------------------------------------------------------------------------------------------
 def test_point_filtered_constant_texture_renders_exactly_like_the_constant(lib):
     """A one-channel image without a colour space evaluates to from_const(texel) (texture.rs:801-805): with the point filter a
