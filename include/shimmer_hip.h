@@ -486,6 +486,24 @@ SHM_API int shm_film_get_image(const ShmFilmPixel* film, uint64_t n_pixels, cons
                        float* rgb_out);
 /* Image::write_pfm (image.rs:1333-1377): RGB float, bottom-up rows, little-endian (scale -1). */
 SHM_API int shm_write_pfm(const char* path, const float* rgb, int32_t width, int32_t height);
+/* TriQuadMesh::read_ply (shape/mesh.rs:179-358; the "plymesh" shape, shape/shape.rs:97-135): vertex element with float x y z
+ * [nx ny nz] [u v | s t | texture_u texture_v | texture_s texture_t], face element with an int list vertex_indices /
+ * vertex_index (triangles and quads; a quad v0 v1 v2 v3 is stored in bilinear-patch order v0 v1 v3 v2) and optionally
+ * face_indices. ascii, binary_little_endian and binary_big_endian. n and uv are ALWAYS n_vertices long, zero where the file has
+ * no such property — the reference builds them the same way and hands both to the meshes (shape/shape.rs:104-131). Anything
+ * the reference panics on (other elements, non-float vertex properties, unsigned index lists, faces that are neither triangles
+ * nor quads, indices out of range) returns SHM_ERR_INVALID_ARGUMENT with the message in shm_last_error(). Free with shm_ply_free. */
+typedef struct ShmPlyMesh {
+    uint32_t n_vertices, n_tri_indices, n_quad_indices, n_face_indices;
+    float* p;               /* 3 * n_vertices */
+    float* n;               /* 3 * n_vertices */
+    float* uv;              /* 2 * n_vertices */
+    int32_t* tri_indices;   /* n_tri_indices  (3 per triangle) */
+    int32_t* quad_indices;  /* n_quad_indices (4 per quad, patch order) */
+    int32_t* face_indices;  /* n_face_indices */
+} ShmPlyMesh;
+SHM_API int shm_ply_read(const char* filename, ShmPlyMesh* out);
+SHM_API void shm_ply_free(ShmPlyMesh* mesh);
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,12 @@ class ShmImageInfiniteLight(C.Structure):
                 ("pad", C.c_uint32)]
 
 
+class ShmPlyMesh(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32), ("n_tri_indices", C.c_uint32), ("n_quad_indices", C.c_uint32), ("n_face_indices", C.c_uint32),
+                ("p", c_float_p), ("n", c_float_p), ("uv", c_float_p), ("tri_indices", C.POINTER(C.c_int32)),
+                ("quad_indices", C.POINTER(C.c_int32)), ("face_indices", C.POINTER(C.c_int32))]
+
+
 class ShmColorSpace(C.Structure):
     _fields_ = [("rgb2spec_res", C.c_uint32), ("pad", C.c_uint32), ("rgb2spec_scale", c_float_p), ("rgb2spec_data", c_float_p),
                 ("illuminant", c_float_p)]
@@ -196,6 +202,8 @@ EXPORTS = {
     "shm_camera_orthographic": (C.c_int, [c_float_p, C.POINTER(C.c_int32), C.c_float, C.c_float, C.POINTER(ShmCamera), c_float_p]),
     "shm_film_get_image": (C.c_int, [C.c_void_p, C.c_uint64, c_float_p, C.c_int, c_float_p]),
     "shm_write_pfm": (C.c_int, [C.c_char_p, c_float_p, C.c_int32, C.c_int32]),
+    "shm_ply_read": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "shm_ply_free": (None, [C.c_void_p]),
 }
 
 _lib = None

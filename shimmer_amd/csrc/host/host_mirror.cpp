@@ -10,6 +10,7 @@
 //   transform.rs:263-316        Transform::inverse / look_at / perspective / scale / translate
 //   camera.rs:356-440           CameraBase::find_minimum_differentials (what Camera::approximate_dp_dxy falls back on)
 //   image.rs:1333-1377          Image::write_pfm
+//   shape/mesh.rs:179-358       TriQuadMesh::read_ply (the ply-rs 0.1.3 crate parses the container; restated from the PLY format)
 //
 // Third-party pieces the reference pulls in here, restated from their published behaviour (unpinned):
 //   itertools 0.11 `partition` (aggregate.rs:362) and pdqselect 0.1.1 `select_by` (aggregate.rs:371,386);
@@ -24,6 +25,8 @@
 
 #include "../../../include/shimmer_hip.h"
 #include "../shm/path.h"  // camera_generate_ray_differential for CameraBase::find_minimum_differentials (host use only)
+
+extern "C" __attribute__((visibility("hidden"))) void shm_set_last_error(const char* msg);  // shimmer_hip.hip
 
 namespace {
 
@@ -436,6 +439,149 @@ int shm_write_pfm(const char* path, const float* rgb, int32_t width, int32_t hei
     }
     fclose(fp);
     return SHM_OK;
+}
+
+
+// ---- TriQuadMesh::read_ply, shape/mesh.rs:194-287 ---------------------------------------------------------------
+namespace {
+struct PlyProp { std::string name; int type; int count_type; bool is_list; };  // type: index into kPlyTypes
+struct PlyElem { std::string name; size_t count; std::vector<PlyProp> props; };
+const char* const kPlyTypes[][2] = {{"char", "int8"}, {"uchar", "uint8"}, {"short", "int16"}, {"ushort", "uint16"},
+                                    {"int", "int32"}, {"uint", "uint32"}, {"float", "float32"}, {"double", "float64"}};
+const int kPlySize[] = {1, 1, 2, 2, 4, 4, 4, 8};
+int ply_type(const std::string& t) {
+    for (int i = 0; i < 8; ++i) if (t == kPlyTypes[i][0] || t == kPlyTypes[i][1]) return i;
+    return -1;
+}
+struct PlyReader {
+    FILE* fp;
+    int format;  // 0 ascii, 1 binary little endian, 2 binary big endian
+    bool fail = false;
+    double read(int type) {  // one scalar of the given PLY type, as a double
+        if (format == 0) {
+            char tok[64];
+            if (fscanf(fp, "%63s", tok) != 1) { fail = true; return 0.0; }
+            return atof(tok);
+        }
+        unsigned char b[8];
+        const int n = kPlySize[type];
+        if (fread(b, 1, (size_t)n, fp) != (size_t)n) { fail = true; return 0.0; }
+        if (format == 2) std::reverse(b, b + n);
+        switch (type) {
+            case 0: { int8_t v; memcpy(&v, b, 1); return v; }
+            case 1: { uint8_t v; memcpy(&v, b, 1); return v; }
+            case 2: { int16_t v; memcpy(&v, b, 2); return v; }
+            case 3: { uint16_t v; memcpy(&v, b, 2); return v; }
+            case 4: { int32_t v; memcpy(&v, b, 4); return v; }
+            case 5: { uint32_t v; memcpy(&v, b, 4); return v; }
+            case 6: { float v; memcpy(&v, b, 4); return v; }
+            default: { double v; memcpy(&v, b, 8); return v; }
+        }
+    }
+};
+int ply_error(FILE* fp, const std::string& msg) {
+    if (fp) fclose(fp);
+    shm_set_last_error(msg.c_str());
+    return SHM_ERR_INVALID_ARGUMENT;
+}
+}  // namespace
+
+int shm_ply_read(const char* filename, ShmPlyMesh* out) {
+    if (!filename || !out) return SHM_ERR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    FILE* fp = fopen(filename, "rb");
+    if (!fp) return ply_error(nullptr, "Unable to read PLY file");  // mesh.rs:200
+    // header
+    char line[1024];
+    if (!fgets(line, sizeof line, fp) || strncmp(line, "ply", 3) != 0) return ply_error(fp, "not a PLY file");
+    int format = -1;
+    std::vector<PlyElem> elems;
+    bool ended = false;
+    while (fgets(line, sizeof line, fp)) {
+        char a[256] = "", b[256] = "", c[256] = "", d[256] = "", e[256] = "";
+        int n = sscanf(line, "%255s %255s %255s %255s %255s", a, b, c, d, e);
+        if (n <= 0) continue;
+        std::string key = a;
+        if (key == "end_header") { ended = true; break; }
+        if (key == "comment" || key == "obj_info") continue;
+        if (key == "format") {
+            std::string f = b;
+            format = f == "ascii" ? 0 : (f == "binary_little_endian" ? 1 : (f == "binary_big_endian" ? 2 : -1));
+        } else if (key == "element" && n >= 3) {
+            elems.push_back(PlyElem{b, (size_t)strtoull(c, nullptr, 10), {}});
+        } else if (key == "property" && !elems.empty()) {
+            PlyProp p{};
+            if (std::string(b) == "list" && n >= 5) { p.is_list = true; p.count_type = ply_type(c); p.type = ply_type(d); p.name = e; }
+            else if (n >= 3) { p.is_list = false; p.count_type = 0; p.type = ply_type(b); p.name = c; }
+            if (p.type < 0 || p.count_type < 0) return ply_error(fp, "PLY header: unknown property type");
+            elems.back().props.push_back(p);
+        } else {
+            return ply_error(fp, "PLY header: unexpected line");
+        }
+    }
+    if (!ended || format < 0) return ply_error(fp, "PLY header: missing format or end_header");
+    PlyReader rd{fp, format};
+    std::vector<float> p, nn, uv;
+    std::vector<int32_t> tri, quad, face;
+    for (const PlyElem& el : elems) {
+        if (el.name == "vertex") {
+            p.assign(3 * el.count, 0.0f); nn.assign(3 * el.count, 0.0f); uv.assign(2 * el.count, 0.0f);  // PlyVertex::new, mesh.rs:303-314
+            for (size_t i = 0; i < el.count; ++i)
+                for (const PlyProp& pr : el.props) {
+                    // mesh.rs:316-333: every vertex property must be one of these names AND a Float
+                    if (pr.is_list || pr.type != 6) return ply_error(fp, "Vertex: Unexpected key/value combination: key: " + pr.name);
+                    float v = (float)rd.read(pr.type);
+                    const std::string& k = pr.name;
+                    if (k == "x") p[3 * i] = v; else if (k == "y") p[3 * i + 1] = v; else if (k == "z") p[3 * i + 2] = v;
+                    else if (k == "nx") nn[3 * i] = v; else if (k == "ny") nn[3 * i + 1] = v; else if (k == "nz") nn[3 * i + 2] = v;
+                    else if (k == "u" || k == "s" || k == "texture_u" || k == "texture_s") uv[2 * i] = v;
+                    else if (k == "v" || k == "t" || k == "texture_v" || k == "texture_t") uv[2 * i + 1] = v;
+                    else return ply_error(fp, "Vertex: Unexpected key/value combination: key: " + k);
+                }
+        } else if (el.name == "face") {
+            for (size_t i = 0; i < el.count; ++i) {
+                std::vector<int32_t> vi, fi;
+                for (const PlyProp& pr : el.props) {
+                    const std::string& k = pr.name;
+                    const bool known = k == "vertex_indices" || k == "vertex_index" || k == "face_indices";
+                    // mesh.rs:349-356: only ListInt payloads are accepted (ply-rs: a list of `int` / `int32`)
+                    if (!known || !pr.is_list || pr.type != 4) return ply_error(fp, "Face: Unexpected key/value combination: key: " + k);
+                    const long cnt = (long)rd.read(pr.count_type);
+                    if (rd.fail || cnt < 0 || cnt > 1024) return ply_error(fp, "PLY: bad list length");
+                    std::vector<int32_t>& dst = (k == "face_indices") ? fi : vi;
+                    dst.resize((size_t)cnt);
+                    for (long q = 0; q < cnt; ++q) dst[(size_t)q] = (int32_t)rd.read(pr.type);
+                }
+                // mesh.rs:249-276
+                if (!((fi.size() > 0 && vi.size() == 0) || (fi.size() == 0 && vi.size() > 0))) return ply_error(fp, "PLY face: expected either vertex indices or face indices");
+                if (vi.size() == 3) { tri.insert(tri.end(), vi.begin(), vi.end()); }
+                else if (vi.size() == 4) { quad.push_back(vi[0]); quad.push_back(vi[1]); quad.push_back(vi[3]); quad.push_back(vi[2]); }
+                else if (fi.empty()) return ply_error(fp, "Only tris and quads are supported");
+                if (!fi.empty()) face.push_back(fi[0]);
+            }
+        } else {
+            return ply_error(fp, "Unexpected element: " + el.name);  // mesh.rs:222
+        }
+        if (rd.fail) return ply_error(fp, "PLY: unexpected end of file");
+    }
+    fclose(fp);
+    const int32_t nv = (int32_t)(p.size() / 3);
+    for (int32_t idx : tri) if (idx < 0 || idx >= nv) return ply_error(nullptr, "PLY: triangle vertex index out of range");   // mesh.rs:278-282
+    for (int32_t idx : quad) if (idx < 0 || idx >= nv) return ply_error(nullptr, "PLY: quad vertex index out of range");      // mesh.rs:283-287
+    auto dup_f = [](const std::vector<float>& v) { float* r = (float*)malloc(std::max<size_t>(v.size(), 1) * sizeof(float)); if (r && !v.empty()) memcpy(r, v.data(), v.size() * sizeof(float)); return r; };
+    auto dup_i = [](const std::vector<int32_t>& v) { int32_t* r = (int32_t*)malloc(std::max<size_t>(v.size(), 1) * sizeof(int32_t)); if (r && !v.empty()) memcpy(r, v.data(), v.size() * sizeof(int32_t)); return r; };
+    out->n_vertices = (uint32_t)nv;
+    out->n_tri_indices = (uint32_t)tri.size(); out->n_quad_indices = (uint32_t)quad.size(); out->n_face_indices = (uint32_t)face.size();
+    out->p = dup_f(p); out->n = dup_f(nn); out->uv = dup_f(uv);
+    out->tri_indices = dup_i(tri); out->quad_indices = dup_i(quad); out->face_indices = dup_i(face);
+    if (!out->p || !out->n || !out->uv || !out->tri_indices || !out->quad_indices || !out->face_indices) { shm_ply_free(out); return SHM_ERR_OUT_OF_MEMORY; }
+    return SHM_OK;
+}
+
+void shm_ply_free(ShmPlyMesh* m) {
+    if (!m) return;
+    free(m->p); free(m->n); free(m->uv); free(m->tri_indices); free(m->quad_indices); free(m->face_indices);
+    memset(m, 0, sizeof(*m));
 }
 
 }  // extern "C"

@@ -1166,6 +1166,8 @@ struct EventPool {
 extern "C" {
 
 const char* shm_last_error(void) { return g_err.c_str(); }
+// for the host mirror (host_mirror.cpp), which shares this thread-local message; not exported
+__attribute__((visibility("hidden"))) void shm_set_last_error(const char* msg) { g_err = msg ? msg : ""; }
 
 int shm_device_count(void) {
     int n = 0;

@@ -440,6 +440,39 @@ class SceneBuilder:
         self._n_prims += ntri
         return first_prim
 
+    def add_ply(self, lib, filename, material, render_from_object=None, reverse_orientation=False, **light):
+        """The "plymesh" shape (shape/shape.rs:97-135): TriQuadMesh::read_ply through the host mirror, then a TriangleMesh of its
+        triangles and a BilinearPatchMesh of its quads, both with the file's n and uv (zeros where the file has none: the reference
+        hands those over too). Positions go to render space as TriangleMesh::new does (mesh.rs:42-64): points through the matrix,
+        normals through the inverse transpose, negated under reverse_orientation. Returns (first triangle prim, first patch prim)."""
+        m = abi.ShmPlyMesh()
+        abi.check(lib, lib.shm_ply_read(str(filename).encode(), C.byref(m)), "shm_ply_read")
+        try:
+            nv = m.n_vertices
+            p = np.ctypeslib.as_array(m.p, shape=(nv, 3)).copy() if nv else np.zeros((0, 3), np.float32)
+            n = np.ctypeslib.as_array(m.n, shape=(nv, 3)).copy() if nv else np.zeros((0, 3), np.float32)
+            uv = np.ctypeslib.as_array(m.uv, shape=(nv, 2)).copy() if nv else np.zeros((0, 2), np.float32)
+            tri = np.ctypeslib.as_array(m.tri_indices, shape=(m.n_tri_indices,)).copy().reshape(-1, 3) if m.n_tri_indices else None
+            quad = np.ctypeslib.as_array(m.quad_indices, shape=(m.n_quad_indices,)).copy().reshape(-1, 4) if m.n_quad_indices else None
+        finally:
+            lib.shm_ply_free(C.byref(m))
+        rfo = _as_f32(IDENTITY if render_from_object is None else render_from_object, (4, 4))
+        inv = _as_f32(np.linalg.inv(rfo.astype(np.float64)), (4, 4))
+        # apply_point_helper / apply_normal_helper in f32, left to right as written (transform.rs:753-786)
+        pr = ((rfo[None, :3, 0] * p[:, 0:1] + rfo[None, :3, 1] * p[:, 1:2]).astype(np.float32) + rfo[None, :3, 2] * p[:, 2:3]).astype(np.float32) + rfo[None, :3, 3]
+        nr = ((inv[None, 0, :3] * n[:, 0:1] + inv[None, 1, :3] * n[:, 1:2]).astype(np.float32) + inv[None, 2, :3] * n[:, 2:3]).astype(np.float32)
+        if reverse_orientation:
+            nr = -nr
+        swaps = bool(np.linalg.det(rfo[:3, :3].astype(np.float64)) < 0)
+        first_tri = first_patch = None
+        if tri is not None:
+            first_tri = self.add_mesh(pr.astype(np.float32), tri.astype(np.uint32), material, n=nr, uv=uv, reverse_orientation=reverse_orientation,
+                                      swaps_handedness=swaps, **light)
+        if quad is not None:
+            first_patch = self.add_patch_mesh(pr.astype(np.float32), quad.astype(np.uint32), material, n=nr, uv=uv,
+                                              reverse_orientation=reverse_orientation, swaps_handedness=swaps, **light)
+        return first_tri, first_patch
+
     def add_patch_mesh(self, p, vi, material, n=None, uv=None, reverse_orientation=False, swaps_handedness=False, emission=None,
                        emission_scale=1.0, two_sided=False):
         """bilinearmesh (shape/mesh.rs:289-376): vertices in render space, 4 indices per patch in the order p00, p10, p01, p11
