@@ -125,7 +125,10 @@ enum {
      * `offset` = index into ShmSceneDesc::image_textures. Not valid for eta (a Spectrum, not a texture, in the reference) nor
      * for lights. The device filters the MIP pyramid, looks the sigmoid coefficients up in ShmSceneDesc::color_space and
      * evaluates the resulting Rgb{Albedo,Unbounded,Illuminant}Spectrum at the path's wavelengths. */
-    SHM_SPECTRUM_IMAGE_TEXTURE = 6
+    SHM_SPECTRUM_IMAGE_TEXTURE = 6,
+    /* ABI v6. A composite SpectrumTexture (scale / mix / directionmix, texture.rs:536-687, 810-828) bound to a material's
+     * SpectrumTexture slot: `offset` = index into ShmSceneDesc::spectrum_textures (the root of its tree). */
+    SHM_SPECTRUM_TEXTURE_NODE = 7
 };
 typedef struct ShmSpectrum {
     uint32_t kind;
@@ -165,6 +168,23 @@ typedef struct ShmFloatTexture {
     uint32_t image;
     uint32_t pad[3];
 } ShmFloatTexture;
+/* SpectrumTexture node table (texture.rs:411-503): a LEAF is a spectrum or an image texture (SpectrumConstantTexture /
+ * SpectrumImageTexture); composites name their children by index (children precede parents; a tree holds at most 8 nodes) and
+ * their FloatTexture parameter by index into ShmSceneDesc::float_textures. */
+enum {
+    SHM_SPECTEX_LEAF = 0,          /* leaf: any ShmSpectrum kind except TEXTURE_NODE */
+    SHM_SPECTEX_SCALED = 1,        /* SpectrumScaledTexture: tex = a, scale = float texture f */
+    SHM_SPECTEX_MIX = 2,           /* SpectrumMixTexture: tex1 = a, tex2 = b, amount = float texture f */
+    SHM_SPECTEX_DIRECTION_MIX = 3  /* SpectrumDirectionMixTexture: tex1 = a, tex2 = b, dir */
+};
+typedef struct ShmSpectrumTexture {
+    uint32_t kind;
+    uint32_t a, b;
+    uint32_t f;
+    float dir[3];
+    uint32_t pad;
+    ShmSpectrum leaf;
+} ShmSpectrumTexture;
 /* indices into ShmMaterial::float_tex */
 enum {
     SHM_FLOATSLOT_DISPLACEMENT = 0, SHM_FLOATSLOT_U_ROUGHNESS = 1, SHM_FLOATSLOT_V_ROUGHNESS = 2, SHM_FLOATSLOT_U2_ROUGHNESS = 3,
@@ -339,6 +359,9 @@ typedef struct ShmSceneDesc {
     uint32_t n_float_textures;
     const ShmImageInfiniteLight* image_lights;
     const ShmFloatTexture* float_textures;
+    uint32_t n_spectrum_textures;
+    uint32_t pad3;
+    const ShmSpectrumTexture* spectrum_textures;
 } ShmSceneDesc;
 
 /* ---- render parameters ----------------------------------------------------------------------- */

@@ -914,6 +914,16 @@ void orc_fn_bump_or_normal_map(OrcScene* s, int which, uint32_t tex, const float
     out6[0] = a.x; out6[1] = a.y; out6[2] = a.z; out6[3] = b.x; out6[4] = b.y; out6[5] = b.z;
 }
 
+// SpectrumTexture::evaluate of a material slot value (spectrum, image texture or composite node)
+void orc_fn_spectrum_texture_evaluate(OrcScene* s, const ShmSpectrum* sp, const float* ctx18, const float* lambda4, float* out4) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    Wavelengths w;
+    for (int i = 0; i < 4; ++i) { w.lambda[i] = lambda4[i]; w.pdf[i] = 1.0f; }
+    TextureEvalContext ctx = make_tex_ctx(ctx18);
+    Spec r = spectrum_texture_evaluate<true>(o->sv, *sp, &ctx, w);
+    for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
+}
+
 // ---- ImageInfinitelight ----
 void orc_fn_equal_area_square_to_sphere(const float* uv, float* out3) {
     V3 d = equal_area_square_to_sphere(v2(uv[0], uv[1]));

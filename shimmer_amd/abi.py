@@ -18,7 +18,8 @@ SHM_SPECTRUM_RGB_ALBEDO, SHM_SPECTRUM_RGB_UNBOUNDED, SHM_SPECTRUM_RGB_ILLUMINANT
 SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATERIAL_THIN_DIELECTRIC = 0, 1, 2, 3
 SHM_MATERIAL_COATED_DIFFUSE, SHM_MATERIAL_COATED_CONDUCTOR, SHM_MATERIAL_MIX = 4, 5, 6
 SHM_LIGHT_POINT, SHM_LIGHT_DIFFUSE_AREA, SHM_LIGHT_UNIFORM_INFINITE, SHM_LIGHT_IMAGE_INFINITE = 0, 1, 2, 3
-SHM_SPECTRUM_IMAGE_TEXTURE = 6
+SHM_SPECTRUM_IMAGE_TEXTURE, SHM_SPECTRUM_TEXTURE_NODE = 6, 7
+SHM_SPECTEX_LEAF, SHM_SPECTEX_SCALED, SHM_SPECTEX_MIX, SHM_SPECTEX_DIRECTION_MIX = 0, 1, 2, 3
 SHM_TEXMAP_UV, SHM_TEXMAP_SPHERICAL, SHM_TEXMAP_CYLINDRICAL, SHM_TEXMAP_PLANAR = 0, 1, 2, 3
 SHM_TEXFILTER_POINT, SHM_TEXFILTER_BILINEAR, SHM_TEXFILTER_TRILINEAR, SHM_TEXFILTER_EWA = 0, 1, 2, 3
 SHM_WRAP_BLACK, SHM_WRAP_CLAMP, SHM_WRAP_REPEAT, SHM_WRAP_OCTAHEDRAL_SPHERE = 0, 1, 2, 3
@@ -73,6 +74,11 @@ class ShmMaterial(C.Structure):
                 ("max_depth", C.c_int32), ("n_samples", C.c_int32), ("conductor_from_reflectance", C.c_uint32),
                 ("mix_material", C.c_uint32 * 2), ("mix_amount", C.c_float), ("a", ShmSpectrum), ("b", ShmSpectrum), ("c", ShmSpectrum), ("d", ShmSpectrum),
                 ("float_tex", C.c_uint32 * 8), ("normal_map", C.c_uint32), ("pad", C.c_uint32 * 3)]
+
+
+class ShmSpectrumTexture(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("f", C.c_uint32), ("dir", C.c_float * 3), ("pad", C.c_uint32),
+                ("leaf", ShmSpectrum)]
 
 
 class ShmFloatTexture(C.Structure):
@@ -139,7 +145,8 @@ class ShmSceneDesc(C.Structure):
                 ("n_image_textures", C.c_uint32), ("n_image_levels", C.c_uint32), ("image_textures", C.POINTER(ShmImageTexture)),
                 ("image_levels", C.POINTER(ShmImageLevel)), ("n_texel_floats", C.c_uint64), ("texel_data", c_float_p),
                 ("color_space", ShmColorSpace), ("ewa_filter_lut", c_float_p), ("n_image_lights", C.c_uint32), ("n_float_textures", C.c_uint32),
-                ("image_lights", C.POINTER(ShmImageInfiniteLight)), ("float_textures", C.POINTER(ShmFloatTexture))]
+                ("image_lights", C.POINTER(ShmImageInfiniteLight)), ("float_textures", C.POINTER(ShmFloatTexture)),
+                ("n_spectrum_textures", C.c_uint32), ("pad3", C.c_uint32), ("spectrum_textures", C.POINTER(ShmSpectrumTexture))]
 
 
 class ShmRenderParams(C.Structure):

@@ -12,7 +12,7 @@
 
 #include "../shm/scene.h"
 
-static_assert(sizeof(ShmMaterial) == 240 && sizeof(ShmFloatTexture) == 48 && sizeof(ShmSpectrum) == 32 && sizeof(ShmBvhNode) == 32 && sizeof(ShmPrimitive) == 16,
+static_assert(sizeof(ShmMaterial) == 240 && sizeof(ShmFloatTexture) == 48 && sizeof(ShmSpectrumTexture) == 64 && sizeof(ShmSpectrum) == 32 && sizeof(ShmBvhNode) == 32 && sizeof(ShmPrimitive) == 16,
               "POD layouts of include/shimmer_hip.h (mirrored by shimmer_amd/abi.py)");
 namespace shm_host {
 
@@ -50,6 +50,9 @@ struct FlatScene {
     std::vector<ShmFloatTexture> float_textures;
     std::vector<shm::FloatTexRange> ftex_ranges;
     std::vector<shm::FloatTexOp> ftex_ops;
+    std::vector<ShmSpectrumTexture> spectrum_textures;
+    std::vector<shm::FloatTexRange> stex_ranges;
+    std::vector<shm::FloatTexOp> stex_ops;
     std::vector<shm::ImageLightRec> image_lights;
     std::vector<float> dist_data;
 
@@ -97,6 +100,9 @@ struct FlatScene {
         v.float_textures = float_textures.data();
         v.ftex_ranges = ftex_ranges.data();
         v.ftex_ops = ftex_ops.data();
+        v.spectrum_textures = spectrum_textures.data();
+        v.stex_ranges = stex_ranges.data();
+        v.stex_ops = stex_ops.data();
         v.image_lights = image_lights.data();
         v.dist_data = dist_data.data();
         return v;
@@ -105,6 +111,12 @@ struct FlatScene {
 
 // n_textures > 0 only for the SpectrumTexture slots of a material (a, b, c): eta and light spectra are plain Spectrum values
 inline bool check_spectrum(const ShmSpectrum& s, uint32_t n_floats, std::string& err, uint32_t n_textures = 0, bool* is_texture = nullptr) {
+    if (s.kind == SHM_SPECTRUM_TEXTURE_NODE) {
+        // n_textures > 0 marks a SpectrumTexture slot here too; the node index is checked by the caller (it knows the table)
+        if (!is_texture) { err = "a spectrum texture is not valid in this slot"; return false; }
+        *is_texture = true;
+        return true;
+    }
     if (s.kind == SHM_SPECTRUM_IMAGE_TEXTURE) {
         if (s.offset >= n_textures) { err = n_textures ? "image texture index out of range" : "an image texture is not valid in this slot"; return false; }
         if (is_texture) *is_texture = true;
@@ -440,6 +452,47 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         }
     }
 
+    // SpectrumTexture node table: the same post-order programs (<= 8 ops)
+    if (d->n_spectrum_textures) {
+        if (!d->spectrum_textures) { err = "spectrum texture array missing"; return SHM_ERR_INVALID_ARGUMENT; }
+        out.spectrum_textures.assign(d->spectrum_textures, d->spectrum_textures + d->n_spectrum_textures);
+        out.stex_ranges.resize(d->n_spectrum_textures);
+        const uint32_t nsf0 = (uint32_t)out.spectrum_data.size();
+        for (uint32_t i = 0; i < d->n_spectrum_textures; ++i) {
+            const ShmSpectrumTexture& t = out.spectrum_textures[i];
+            if (t.kind > SHM_SPECTEX_DIRECTION_MIX) { err = "unknown spectrum texture kind"; return SHM_ERR_INVALID_ARGUMENT; }
+            std::vector<shm::FloatTexOp> prog;
+            auto append_child = [&](uint32_t k) -> int {
+                if (k >= i) return -1;
+                const shm::FloatTexRange cr = out.stex_ranges[k];
+                const uint32_t base = (uint32_t)prog.size();
+                for (uint32_t q = 0; q < cr.count; ++q) {
+                    shm::FloatTexOp op = out.stex_ops[cr.first + q];
+                    op.a = (uint8_t)(op.a + base); op.b = (uint8_t)(op.b + base);
+                    prog.push_back(op);
+                }
+                return (int)prog.size() - 1;
+            };
+            shm::FloatTexOp self{};
+            self.node = i;
+            if (t.kind == SHM_SPECTEX_LEAF) {
+                if (t.leaf.kind == SHM_SPECTRUM_TEXTURE_NODE) { err = "a spectrum texture leaf cannot be a texture node"; return SHM_ERR_INVALID_ARGUMENT; }
+                bool is_tex = false;
+                if (!check_spectrum(t.leaf, nsf0, err, d->n_image_textures, &is_tex)) return SHM_ERR_INVALID_ARGUMENT;
+            } else {
+                int a = append_child(t.a), b = (t.kind == SHM_SPECTEX_SCALED) ? 0 : append_child(t.b);
+                if (a < 0 || b < 0) { err = "spectrum texture children must precede their parent"; return SHM_ERR_INVALID_ARGUMENT; }
+                self.a = (uint8_t)a; self.b = (uint8_t)b;
+                if (t.kind != SHM_SPECTEX_DIRECTION_MIX && t.f >= d->n_float_textures) { err = "spectrum texture: float texture index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            }
+            prog.push_back(self);
+            if (prog.size() > (size_t)shm::STEX_MAX_OPS) { err = "spectrum texture tree larger than 8 nodes"; return SHM_ERR_UNSUPPORTED; }
+            out.stex_ranges[i].first = (uint32_t)out.stex_ops.size();
+            out.stex_ranges[i].count = (uint32_t)prog.size();
+            out.stex_ops.insert(out.stex_ops.end(), prog.begin(), prog.end());
+        }
+    }
+
     // materials / lights
     const uint32_t ntex = d->n_image_textures;
     uint32_t nsf = (uint32_t)out.spectrum_data.size();
@@ -451,6 +504,8 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
                 if (m.float_tex[k] > d->n_float_textures) { err = "material float texture index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
                 out.has_textures = true;
             }
+        for (const ShmSpectrum* sp : {&m.a, &m.b, &m.c})
+            if (sp->kind == SHM_SPECTRUM_TEXTURE_NODE && sp->offset >= d->n_spectrum_textures) { err = "material spectrum texture index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
         if (m.normal_map != 0u) {
             if (m.normal_map > d->n_image_textures || out.image_textures[m.normal_map - 1].n_channels != 3) { err = "normal map: image texture index out of range or not RGB"; return SHM_ERR_INVALID_ARGUMENT; }
             out.has_textures = true;
@@ -474,7 +529,7 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         }
         // Dielectric / ThinDielectric keep eta in `a`: a Spectrum, not a texture (material.rs:520-527, 655-660)
         const bool a_is_texture_slot = !(m.kind == SHM_MATERIAL_DIELECTRIC || m.kind == SHM_MATERIAL_THIN_DIELECTRIC);
-        if (!check_spectrum(m.a, nsf, err, a_is_texture_slot ? ntex : 0, &out.has_textures)) return SHM_ERR_INVALID_ARGUMENT;
+        if (!check_spectrum(m.a, nsf, err, a_is_texture_slot ? ntex : 0, a_is_texture_slot ? &out.has_textures : nullptr)) return SHM_ERR_INVALID_ARGUMENT;
         const bool coated = m.kind == SHM_MATERIAL_COATED_DIFFUSE || m.kind == SHM_MATERIAL_COATED_CONDUCTOR;
         if ((m.kind == SHM_MATERIAL_CONDUCTOR || (m.kind == SHM_MATERIAL_COATED_CONDUCTOR && !m.conductor_from_reflectance)) &&
             !check_spectrum(m.b, nsf, err, ntex, &out.has_textures))

@@ -1241,6 +1241,9 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if ((rc = dev_upload(s, f.float_textures, &v.float_textures)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ftex_ranges, &v.ftex_ranges)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ftex_ops, &v.ftex_ops)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.spectrum_textures, &v.spectrum_textures)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.stex_ranges, &v.stex_ranges)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.stex_ops, &v.stex_ops)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.image_lights, &v.image_lights)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.dist_data, &v.dist_data)) != SHM_OK) return fail(rc);
     s->dsv = v;

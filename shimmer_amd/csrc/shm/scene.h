@@ -82,6 +82,9 @@ struct SceneView {
     const ShmFloatTexture* float_textures;
     const struct FloatTexRange* ftex_ranges;  // per node: its evaluation program (children first) in ftex_ops
     const struct FloatTexOp* ftex_ops;
+    const ShmSpectrumTexture* spectrum_textures;
+    const struct FloatTexRange* stex_ranges;  // the same post-order programs for SpectrumTexture trees
+    const struct FloatTexOp* stex_ops;
     // image infinite lights: per light its transform + image + the two PiecewiseConstant2D distributions, flattened into dist_data
     const struct ImageLightRec* image_lights;
     const Float* dist_data;
@@ -92,6 +95,7 @@ struct SceneView {
 // The reference's lazy branches ("if amt != 1 { t1 = tex1.evaluate() }", texture.rs:244-305) only skip work: evaluation has no side
 // effects, so selecting 0 for a skipped child gives the same value.
 constexpr int FTEX_MAX_OPS = 32;
+constexpr int STEX_MAX_OPS = 8;
 struct FloatTexOp {
     uint32_t node;       // index into SceneView::float_textures
     uint8_t a, b, c, pad;  // slots of the children within this program

@@ -746,11 +746,44 @@ SHM_HD void normal_map_texture(const SceneView& sv, uint32_t texture_index, cons
     dpdv_out = normalize(cross(ns, dpdu_out)) * vlen;
 }
 
+// A composite SpectrumTexture tree (scale / mix / directionmix over spectrum and image leaves), texture.rs:573-581, 628-645,
+// 810-828, as a post-order program like the float ones
+SHM_HD_NOINLINE Spec spectrum_texture_node_evaluate(const SceneView& sv, uint32_t index, const TextureEvalContext& ctx, const Wavelengths& lambda) {
+    const FloatTexRange r = sv.stex_ranges[index];
+    Spec vals[STEX_MAX_OPS];
+    for (uint32_t k = 0; k < r.count; ++k) {
+        const FloatTexOp op = sv.stex_ops[r.first + k];
+        const ShmSpectrumTexture& t = sv.spectrum_textures[op.node];
+        Spec v;
+        if (t.kind == SHM_SPECTEX_LEAF) {
+            v = (t.leaf.kind == SHM_SPECTRUM_IMAGE_TEXTURE) ? image_texture_evaluate(sv, t.leaf.offset, ctx, lambda)
+                                                            : spectrum_sample(t.leaf, sv.spectrum_data, lambda);
+        } else if (t.kind == SHM_SPECTEX_SCALED) {
+            Float sc = float_texture_evaluate(sv, t.f, ctx);
+            v = (sc == 0.0f) ? spec_const(0.0f) : vals[op.a] * sc;
+        } else if (t.kind == SHM_SPECTEX_MIX) {
+            Float amt = float_texture_evaluate(sv, t.f, ctx);
+            Spec t1 = (amt != 1.0f) ? vals[op.a] : spec_const(0.0f);
+            Spec t2 = (amt != 0.0f) ? vals[op.b] : spec_const(0.0f);
+            v = t1 * (1.0f - amt) + t2 * amt;
+        } else {
+            Float amt = dot(ctx.n, ld3(t.dir));
+            Spec t1 = (amt != 0.0f) ? vals[op.a] : spec_const(0.0f);
+            Spec t2 = (amt != 1.0f) ? vals[op.b] : spec_const(0.0f);
+            v = amt * t1 + (1.0f - amt) * t2;
+        }
+        vals[k] = v;
+    }
+    return vals[r.count - 1];
+}
+
 // SpectrumTexture::evaluate for a material slot: a constant spectrum texture samples its spectrum (texture.rs:509-513), an image
-// texture filters its pyramid. HAS_TEX = false compiles the image branch out (scenes without textures: identical code as before).
+// texture filters its pyramid, a composite evaluates its tree. HAS_TEX = false compiles the texture branches out (scenes without
+// textures: identical code as before).
 template <bool HAS_TEX>
 SHM_HD Spec spectrum_texture_evaluate(const SceneView& sv, const ShmSpectrum& s, const TextureEvalContext* ctx, const Wavelengths& lambda) {
     if (HAS_TEX && s.kind == SHM_SPECTRUM_IMAGE_TEXTURE) return image_texture_evaluate(sv, s.offset, *ctx, lambda);
+    if (HAS_TEX && s.kind == SHM_SPECTRUM_TEXTURE_NODE) return spectrum_texture_node_evaluate(sv, s.offset, *ctx, lambda);
     return spectrum_sample(s, sv.spectrum_data, lambda);
 }
 

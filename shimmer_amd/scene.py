@@ -150,6 +150,7 @@ class SceneBuilder:
         self.color_space = None  # dict(res, scale, data, illuminant)
         self.image_lights = []  # abi.ShmImageInfiniteLight
         self.float_textures = []  # abi.ShmFloatTexture
+        self.spectrum_textures = []  # abi.ShmSpectrumTexture
 
     # ---- spectra ----
     def spectrum_constant(self, c):
@@ -382,6 +383,35 @@ class SceneBuilder:
         kw.setdefault("color_space", False)
         sp = self.add_image_texture(image, **kw)
         return self._ftex(abi.SHM_FLOATTEX_IMAGE, image=sp.offset)
+
+    # ---- composite spectrum textures (texture.rs:536-687) ----
+    def _stex_node(self, v):
+        """A spectrum-texture operand -> node index: a bound ShmSpectrum of kind TEXTURE_NODE is its node, anything else becomes a leaf."""
+        sp = self._spec(v)
+        if sp.kind == abi.SHM_SPECTRUM_TEXTURE_NODE:
+            return sp.offset
+        t = abi.ShmSpectrumTexture()
+        t.kind, t.leaf = abi.SHM_SPECTEX_LEAF, sp
+        self.spectrum_textures.append(t)
+        return len(self.spectrum_textures) - 1
+
+    def _stex(self, kind, a, b=0, f=0, dir=(0.0, 1.0, 0.0)):
+        t = abi.ShmSpectrumTexture()
+        t.kind, t.a, t.b, t.f = kind, int(a), int(b), int(f)
+        t.dir[:] = [float(x) for x in dir]
+        self.spectrum_textures.append(t)
+        sp = abi.ShmSpectrum()
+        sp.kind, sp.offset = abi.SHM_SPECTRUM_TEXTURE_NODE, len(self.spectrum_textures) - 1
+        return sp
+
+    def stex_scaled(self, tex, scale=1.0):
+        return self._stex(abi.SHM_SPECTEX_SCALED, self._stex_node(tex), f=self._ftex_of(scale))
+
+    def stex_mix(self, tex1, tex2, amount=0.5):
+        return self._stex(abi.SHM_SPECTEX_MIX, self._stex_node(tex1), self._stex_node(tex2), f=self._ftex_of(amount))
+
+    def stex_direction_mix(self, tex1, tex2, dir=(0.0, 1.0, 0.0)):
+        return self._stex(abi.SHM_SPECTEX_DIRECTION_MIX, self._stex_node(tex1), self._stex_node(tex2), dir=dir)
 
     def set_float_texture(self, material, slot, ftex):
         """Bind a float texture handle to one of a material's float parameters (abi.SHM_FLOATSLOT_*)."""
@@ -678,6 +708,10 @@ class SceneBuilder:
             fts = (abi.ShmFloatTexture * len(self.float_textures))(*self.float_textures)
             d.n_float_textures, d.float_textures = len(self.float_textures), fts
             self._keep.append(fts)
+        if self.spectrum_textures:
+            sts = (abi.ShmSpectrumTexture * len(self.spectrum_textures))(*self.spectrum_textures)
+            d.n_spectrum_textures, d.spectrum_textures = len(self.spectrum_textures), sts
+            self._keep.append(sts)
         info = dict(n_nodes=n_nodes.value, n_primitives=n, order=order, slot_of_input=slot_of_input, bounds=bounds)
         return d, info
 

@@ -129,8 +129,11 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=Fal
         left_m = b.material_diffuse(b.add_image_texture(img3, filter=tf("point"), wrap="repeat", spectrum_type="unbounded", scale=0.9,
                                                         mapping="planar", vs=(0.0, 0.5, 0.0), vt=(0.0, 0.0, 0.5), du=0.1, dv=0.2,
                                                         texture_from_render=np.linalg.inv(to_render.astype(np.float64))))
-        right_m = b.material_diffuse(b.add_image_texture(img3, filter=tf("bilinear"), wrap="black", spectrum_type="illuminant", scale=0.8,
-                                                         mapping="spherical", texture_from_render=np.linalg.inv(to_render.astype(np.float64))))
+        right_tex = b.add_image_texture(img3, filter=tf("bilinear"), wrap="black", spectrum_type="illuminant", scale=0.8,
+                                        mapping="spherical", texture_from_render=np.linalg.inv(to_render.astype(np.float64)))
+        # a composite spectrum texture (texture.rs:536-687): the image mixed with a smooth spectrum by a float image, then dimmed by direction
+        right_m = b.material_diffuse(b.stex_direction_mix(b.stex_mix(right_tex, _two_point_spectrum(b, 0.6, 0.08), b.ftex_image(img1, filter=tf("point"))),
+                                                          b.stex_scaled(0.5, 0.5), dir=(1.0, 0.0, 0.0)))
         ceil_m = b.material_coated_diffuse(reflectance=b.add_image_texture(img3, filter=tf("ewa"), invert=True, mapping="cylindrical",
                                                                             max_anisotropy=4.0, wrap="octahedralsphere",
                                                                             texture_from_render=np.linalg.inv(to_render.astype(np.float64))),

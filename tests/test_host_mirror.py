@@ -32,7 +32,7 @@ def test_struct_layouts_match_header(tmp_path):
     import subprocess
     if not shutil.which("gcc"):
         pytest.skip("no C compiler")
-    names = ["ShmBvhNode", "ShmTriangleMesh", "ShmBilinearPatchMesh", "ShmSphere", "ShmPrimitive", "ShmSpectrum", "ShmFloatTexture",
+    names = ["ShmBvhNode", "ShmTriangleMesh", "ShmBilinearPatchMesh", "ShmSphere", "ShmPrimitive", "ShmSpectrum", "ShmFloatTexture", "ShmSpectrumTexture", "ShmPlyMesh",
              "ShmMaterial", "ShmLight", "ShmImageLevel", "ShmImageTexture", "ShmColorSpace", "ShmImageInfiniteLight", "ShmCamera", "ShmFilm",
              "ShmSceneDesc", "ShmRenderParams", "ShmTile", "ShmFilmPixel", "ShmStats", "ShmRay", "ShmHit"]
     last = {n: getattr(abi, n)._fields_[-1][0] for n in names}

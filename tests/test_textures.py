@@ -499,6 +499,59 @@ def test_float_texture_graph(lib):
         o.close()
 
 
+def test_composite_spectrum_textures(lib):
+    """SpectrumScaledTexture / SpectrumMixTexture / SpectrumDirectionMixTexture (texture.rs:573-581, 628-645, 810-828) over
+    spectrum and image leaves, against the same expressions evaluated on the leaves' own values."""
+    sc = scenes.cornell_box(lib, 8, 8)
+    b = sc.builder
+    img3, img1 = scenes.test_image(16, 3, seed=8), scenes.test_image(16, 1, seed=9)
+    leaf_img = b.add_image_texture(img3, filter="bilinear")
+    leaf_pw = b.spectrum_piecewise([400.0, 700.0], [0.2, 0.8])
+    f_img = b.ftex_image(img1, filter="bilinear")
+    scaled = b.stex_scaled(leaf_img, 0.5)
+    zero = b.stex_scaled(leaf_img, 0.0)
+    mix = b.stex_mix(leaf_pw, scaled, f_img)
+    dmix = b.stex_direction_mix(mix, 0.25, dir=(0.0, 0.6, 0.8))
+    b.materials[0].a = dmix  # bound to a material: the node table travels through scene creation
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    lams = (452.0, 533.0, 601.5, 688.25)
+    out = (C.c_float * 4)()
+
+    def ev(sp, ctx):
+        o.lib.orc_fn_spectrum_texture_evaluate(o.handle, C.byref(sp), ctx, fa(*lams), out)
+        return np.array(out[:], np.float64)
+
+    try:
+        rng = np.random.default_rng(4)
+        for _ in range(20):
+            uv = rng.uniform(0.05, 0.95, 2)
+            n = rng.normal(size=3)
+            n /= np.linalg.norm(n)
+            ctx = fa(0.1, 0.2, 0.3, 1e-3, 0, 0, 0, 1e-3, 0, *n, *uv, 1e-3, 0.0, 0.0, 1e-3)
+            v_img, v_pw = ev(leaf_img, ctx), ev(leaf_pw, ctx)
+            amt = float(o.lib.orc_fn_float_texture_evaluate(o.handle, f_img, ctx))
+            assert np.allclose(ev(scaled, ctx), v_img * 0.5, rtol=1e-6) and not ev(zero, ctx).any()
+            v_mix = v_pw * (1 - amt) + (v_img * 0.5) * amt
+            assert np.allclose(ev(mix, ctx), v_mix, rtol=1e-5)
+            a = float(n @ np.array([0.0, 0.6, 0.8]))
+            assert np.allclose(ev(dmix, ctx), a * v_mix + (1 - a) * 0.25, rtol=1e-5, atol=1e-6)
+    finally:
+        o.close()
+    # a tree over the node limit, and a composite where only a spectrum may stand, are refused at scene creation
+    big = leaf_pw
+    for _ in range(8):
+        big = b.stex_scaled(big, 0.9)
+    b.materials[0].a = big
+    with pytest.raises(RuntimeError, match="larger than 8"):
+        oracle_py.Oracle(b.build(lib)[0])
+    b2 = scenes.cornell_box(lib, 8, 8).builder  # (every node of the table is validated, bound or not: a fresh table)
+    glass = b2.material_dielectric(1.5)
+    b2.materials[glass].a = b2.stex_scaled(0.5, 0.5)
+    with pytest.raises(RuntimeError, match="not valid in this slot"):
+        oracle_py.Oracle(b2.build(lib)[0])
+
+
 def test_bump_and_normal_map(lib):
     """material.rs:1453-1508. A displacement that rises linearly along u tilts dpdu by slope * n and leaves dpdv alone; a constant
     one changes nothing on a flat surface; a normal map of (0.5, 0.5, 1) is the identity and one leaning towards +s tilts the
