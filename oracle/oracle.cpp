@@ -796,6 +796,15 @@ void orc_fn_spectrum_sample(OrcScene* s, const ShmSpectrum* sp, const float* lam
 }
 
 
+// Transform::apply / apply_inverse for a point (kind 0), vector (1) or normal (2) given the matrix m and its inverse m_inv
+// (transform.rs:363-383, 606-629): the inverse applies swap the two matrices.
+void orc_fn_transform_apply(int kind, int inverse, const float* m, const float* m_inv, const float* v, float* out3) {
+    const float* fwd = inverse ? m_inv : m;
+    const float* bwd = inverse ? m : m_inv;
+    V3 r = (kind == 0) ? xf_point(fwd, ld3(v)) : ((kind == 1) ? xf_vector(fwd, ld3(v)) : xf_normal(bwd, ld3(v)));
+    out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
+
 // ---- image textures (shm/texture.h) ----
 static TextureEvalContext make_tex_ctx(const float* c18) {
     TextureEvalContext c;

@@ -231,6 +231,29 @@ def test_spectrum_reference_known_answers(lib):
         o.close()
 
 
+def test_transform_reference_known_answers(orc):
+    """transform.rs:801-913 (translate_* / scale_* / transform_composition), transcribed: points, vectors and normals through a
+    matrix and its inverse; normals go through the inverse transpose."""
+    def apply(kind, inverse, m, v):
+        m = np.asarray(m, np.float64)
+        out = (C.c_float * 3)()
+        orc.orc_fn_transform_apply(kind, int(inverse), fa(*m.astype(np.float32).ravel()), fa(*np.linalg.inv(m).astype(np.float32).ravel()), fa(*v), out)
+        return tuple(out[:])
+    T = np.eye(4); T[:3, 3] = (10, 20, 40)
+    S = np.diag([2.0, 3.0, 4.0, 1.0])
+    P, V, N = 0, 1, 2
+    assert apply(P, False, T, (1, 2, 3)) == (11.0, 22.0, 43.0) and apply(P, True, T, (1, 2, 3)) == (-9.0, -18.0, -37.0)
+    for kind in (V, N):
+        assert apply(kind, False, T, (1, 2, 3)) == (1.0, 2.0, 3.0) and apply(kind, True, T, (1, 2, 3)) == (1.0, 2.0, 3.0)
+    for kind in (P, V):
+        assert apply(kind, False, S, (1, 2, 3)) == (2.0, 6.0, 12.0) and apply(kind, True, S, (2, 6, 12)) == (1.0, 2.0, 3.0)
+    n = apply(N, False, S, (1, 2, 3))
+    assert n == (0.5, float(f32(0.6666667)), 0.75) and np.allclose(apply(N, True, S, n), (1, 2, 3), rtol=1e-7)
+    assert apply(N, False, np.diag([2.0, 2.0, 2.0, 1.0]), (1, 2, 3)) == (0.5, 1.0, 1.5)
+    C_ = T.copy(); C_[:3, 3] = 1; C_ = C_ @ np.diag([1.0, 2.0, 3.0, 1.0])  # translate(1) * scale(1, 2, 3): scale, then translate
+    assert apply(P, False, C_, (1, 1, 1)) == (2.0, 3.0, 4.0) and apply(P, True, C_, (2, 3, 4)) == (1.0, 1.0, 1.0)
+
+
 def test_next_float(orc, golden):
     """float.rs:172-211."""
     assert orc.orc_fn_next_float_up(-0.0) > 0.0
