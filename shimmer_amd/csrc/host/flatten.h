@@ -337,6 +337,8 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         for (const ShmImageTexture& t : out.image_textures) {
             if (t.mapping > SHM_TEXMAP_PLANAR || t.filter > SHM_TEXFILTER_EWA || t.wrap > SHM_WRAP_OCTAHEDRAL_SPHERE || t.spectrum_type > SHM_SPECTRUM_TYPE_ILLUMINANT) { err = "image texture: unknown mapping / filter / wrap / spectrum type"; return SHM_ERR_INVALID_ARGUMENT; }
             if (t.n_channels != 1 && t.n_channels != 3) { err = "image texture: n_channels must be 1 or 3"; return SHM_ERR_INVALID_ARGUMENT; }
+            // the EWA footprint at its level spans about 2 * max_anisotropy texels per axis: bound the device loop
+            if (!(t.max_anisotropy >= 0.0f && t.max_anisotropy <= 256.0f)) { err = "image texture: max_anisotropy must lie in [0, 256]"; return SHM_ERR_UNSUPPORTED; }
             if (t.n_levels == 0 || (uint64_t)t.first_level + t.n_levels > d->n_image_levels) { err = "image texture: level range out of bounds"; return SHM_ERR_INVALID_ARGUMENT; }
             for (uint32_t l = 0; l < t.n_levels; ++l) {
                 const ShmImageLevel& lv = out.image_levels[t.first_level + l];
