@@ -96,7 +96,22 @@ typedef struct ShmSphere {
     uint8_t pad[6];
 } ShmSphere;
 
-enum { SHM_SHAPE_TRIANGLE = 0, SHM_SHAPE_SPHERE = 1, SHM_SHAPE_BILINEAR_PATCH = 2 };
+enum { SHM_SHAPE_TRIANGLE = 0, SHM_SHAPE_SPHERE = 1, SHM_SHAPE_BILINEAR_PATCH = 2,
+       SHM_SHAPE_INSTANCE = 3 /* ABI v6: a TransformedPrimitive (primitive.rs:136-176): shape_index = index into ShmSceneDesc::instances;
+                                 its material / area_light fields are ignored (the instanced primitives carry their own) */ };
+/* TransformedPrimitive {primitive, render_from_primitive}: the instanced primitive is a BvhAggregate of the object's shapes
+ * (loading/scene.rs:817-829) stored as ANOTHER tree in ShmSceneDesc::nodes starting at root_node (DFS order and absolute
+ * offsets as for the top-level tree at node 0; its leaves index ShmSceneDesc::primitives like every other leaf). An object with a
+ * single shape is a one-leaf tree. Constraints: the instance primitive is alone in its top-level leaf (the reference's builder puts
+ * one primitive per leaf unless centroids coincide); instanced primitives are not instances and carry no area light.
+ * Reference behaviour kept as written: intersect() maps the ray with apply_ray_inverse, intersect_predicate() with the FORWARD
+ * apply_ray (primitive.rs:158-175), and Transform::apply(SurfaceInteraction) maps every vector with the inverse (quirk 6). */
+typedef struct ShmInstance {
+    float render_from_primitive[16];  /* matrix m, row-major */
+    float primitive_from_render[16];  /* m_inv */
+    uint32_t root_node;
+    uint32_t pad[3];
+} ShmInstance;
 
 /* GeometricPrimitive / SimplePrimitive (src/primitive.rs:66-130): shape + material (+ area light).
  * Listed in the order of BvhAggregate::primitives AFTER the build's reordering (aggregate.rs:270),
@@ -360,8 +375,9 @@ typedef struct ShmSceneDesc {
     const ShmImageInfiniteLight* image_lights;
     const ShmFloatTexture* float_textures;
     uint32_t n_spectrum_textures;
-    uint32_t pad3;
+    uint32_t n_instances;
     const ShmSpectrumTexture* spectrum_textures;
+    const ShmInstance* instances;
 } ShmSceneDesc;
 
 /* ---- render parameters ----------------------------------------------------------------------- */
@@ -428,7 +444,9 @@ typedef struct ShmHit {
     float t;
     float b0, b1, b2;
     float phi;
-    uint32_t pad[2];
+    uint32_t instance;  /* 0: a top-level primitive; else 1 + the leaf-order slot of the SHM_SHAPE_INSTANCE primitive it was found
+                           through (prim, t and b* are then in that instance's space) */
+    uint32_t pad;
 } ShmHit;
 
 typedef struct ShmScene ShmScene;

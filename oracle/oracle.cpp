@@ -54,15 +54,21 @@ struct Counters {
 };
 
 // aggregate.rs:71-139
+bool bvh_intersect_from(const SceneView& sv, uint32_t root, V3 ro, V3 rd, Float t_max, Hit& hit, Counters& c);
 bool bvh_intersect(const SceneView& sv, V3 ro, V3 rd, Float t_max, Hit& hit, Counters& c) {
     c.rays_closest++;
+    return bvh_intersect_from(sv, 0, ro, rd, t_max, hit, c);
+}
+// BvhAggregate::intersect of the tree rooted at `root` (the top-level aggregate, or the aggregate of an instanced object)
+bool bvh_intersect_from(const SceneView& sv, uint32_t root, V3 ro, V3 rd, Float t_max, Hit& hit, Counters& c) {
     hit.prim = -1;
+    hit.inst = -1;
     if (sv.n_nodes == 0) return false;
     V3 inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     int dir_is_neg[3] = {inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f};
     bool found = false;
     int to_visit_offset = 0;
-    uint32_t current = 0;
+    uint32_t current = root;
     uint32_t nodes_to_visit[64];
     for (;;) {
         const ShmBvhNode& node = sv.nodes[current];
@@ -71,7 +77,26 @@ bool bvh_intersect(const SceneView& sv, V3 ro, V3 rd, Float t_max, Hit& hit, Cou
             if (node.n_prims > 0) {
                 for (uint32_t i = 0; i < node.n_prims; ++i) {
                     c.tris_closest++;
-                    if (prim_intersect(sv, node.offset + i, ro, rd, t_max, hit)) {
+                    const uint32_t slot = node.offset + i;
+                    if (sv.prim_recs[slot].kind_index & PRIM_INSTANCE_BIT) {
+                        // TransformedPrimitive::intersect, primitive.rs:158-171: the ray goes into the instance's space with
+                        // apply_ray_inverse (t_max shrinks by the origin's error step), the instanced aggregate is traversed, and
+                        // the hit keeps the instance-space parameters; hit_interaction maps the interaction back.
+                        const ShmInstance& in = sv.instances[sv.prim_recs[slot].kind_index & PRIM_INDEX_MASK];
+                        Float t_inst = t_max;
+                        Ray r = xf_ray_inverse(in.primitive_from_render, ro, rd, t_inst);
+                        Hit h2;
+                        if (bvh_intersect_from(sv, in.root_node, r.o, r.d, t_inst, h2, c)) {
+                            hit = h2;
+                            hit.inst = (int32_t)slot;
+                            t_max = hit.t;
+                            found = true;
+                        }
+                        continue;
+                    }
+                    Hit h1;
+                    if (prim_intersect(sv, slot, ro, rd, t_max, h1)) {
+                        hit = h1;
                         t_max = hit.t;
                         found = true;
                     }
@@ -96,13 +121,17 @@ bool bvh_intersect(const SceneView& sv, V3 ro, V3 rd, Float t_max, Hit& hit, Cou
 }
 
 // aggregate.rs:141-203
+bool bvh_intersect_predicate_from(const SceneView& sv, uint32_t root, V3 ro, V3 rd, Float t_max, Counters& c);
 bool bvh_intersect_predicate(const SceneView& sv, V3 ro, V3 rd, Float t_max, Counters& c) {
     c.rays_any++;
+    return bvh_intersect_predicate_from(sv, 0, ro, rd, t_max, c);
+}
+bool bvh_intersect_predicate_from(const SceneView& sv, uint32_t root, V3 ro, V3 rd, Float t_max, Counters& c) {
     if (sv.n_nodes == 0) return false;
     V3 inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     int dir_is_neg[3] = {inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f};
     int to_visit_offset = 0;
-    uint32_t current = 0;
+    uint32_t current = root;
     uint32_t nodes_to_visit[64];
     for (;;) {
         const ShmBvhNode& node = sv.nodes[current];
@@ -111,8 +140,18 @@ bool bvh_intersect_predicate(const SceneView& sv, V3 ro, V3 rd, Float t_max, Cou
             if (node.n_prims > 0) {
                 for (uint32_t i = 0; i < node.n_prims; ++i) {
                     c.tris_any++;
+                    const uint32_t slot = node.offset + i;
+                    if (sv.prim_recs[slot].kind_index & PRIM_INSTANCE_BIT) {
+                        // TransformedPrimitive::intersect_predicate, primitive.rs:173-176: the FORWARD apply_ray, as written there
+                        const ShmInstance& in = sv.instances[sv.prim_recs[slot].kind_index & PRIM_INDEX_MASK];
+                        Ray w;
+                        w.o = ro; w.d = rd;
+                        Ray r = xf_ray(in.render_from_primitive, w);  // the origin is exact: no error step, t_max unchanged
+                        if (bvh_intersect_predicate_from(sv, in.root_node, r.o, r.d, t_max, c)) return true;
+                        continue;
+                    }
                     Hit h;
-                    if (prim_intersect(sv, node.offset + i, ro, rd, t_max, h)) return true;
+                    if (prim_intersect(sv, slot, ro, rd, t_max, h)) return true;
                 }
                 if (to_visit_offset == 0) break;
                 current = nodes_to_visit[--to_visit_offset];
@@ -406,7 +445,7 @@ int orc_trace_closest(OrcScene* s, const ShmRay* rays, uint32_t n, ShmHit* hits,
         bvh_intersect(o->sv, v3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), v3(rays[i].d[0], rays[i].d[1], rays[i].d[2]), rays[i].t_max, h, c);
         memset(&hits[i], 0, sizeof(ShmHit));
         hits[i].prim = h.prim;
-        if (h.prim >= 0) { hits[i].t = h.t; hits[i].b0 = h.b0; hits[i].b1 = h.b1; hits[i].b2 = h.b2; hits[i].phi = h.phi; }
+        if (h.prim >= 0) { hits[i].t = h.t; hits[i].b0 = h.b0; hits[i].b1 = h.b1; hits[i].b2 = h.b2; hits[i].phi = h.phi; hits[i].instance = (uint32_t)(h.inst + 1); }
     }
     if (stats) { memset(stats, 0, sizeof(*stats)); stats->rays_closest = c.rays_closest; stats->nodes_closest = c.nodes_closest; stats->tris_closest = c.tris_closest; }
     return SHM_OK;

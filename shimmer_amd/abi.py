@@ -12,7 +12,7 @@ LIB_PATH = ROOT / "csrc" / "libshimmer_hip.so"
 
 SHM_ABI_VERSION = 6
 SHM_OK = 0
-SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE, SHM_SHAPE_BILINEAR_PATCH = 0, 1, 2
+SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE, SHM_SHAPE_BILINEAR_PATCH, SHM_SHAPE_INSTANCE = 0, 1, 2, 3
 SHM_SPECTRUM_CONSTANT, SHM_SPECTRUM_DENSE, SHM_SPECTRUM_PIECEWISE_LINEAR = 0, 1, 2
 SHM_SPECTRUM_RGB_ALBEDO, SHM_SPECTRUM_RGB_UNBOUNDED, SHM_SPECTRUM_RGB_ILLUMINANT = 3, 4, 5
 SHM_MATERIAL_DIFFUSE, SHM_MATERIAL_CONDUCTOR, SHM_MATERIAL_DIELECTRIC, SHM_MATERIAL_THIN_DIELECTRIC = 0, 1, 2, 3
@@ -74,6 +74,11 @@ class ShmMaterial(C.Structure):
                 ("max_depth", C.c_int32), ("n_samples", C.c_int32), ("conductor_from_reflectance", C.c_uint32),
                 ("mix_material", C.c_uint32 * 2), ("mix_amount", C.c_float), ("a", ShmSpectrum), ("b", ShmSpectrum), ("c", ShmSpectrum), ("d", ShmSpectrum),
                 ("float_tex", C.c_uint32 * 8), ("normal_map", C.c_uint32), ("pad", C.c_uint32 * 3)]
+
+
+class ShmInstance(C.Structure):
+    _fields_ = [("render_from_primitive", C.c_float * 16), ("primitive_from_render", C.c_float * 16), ("root_node", C.c_uint32),
+                ("pad", C.c_uint32 * 3)]
 
 
 class ShmSpectrumTexture(C.Structure):
@@ -146,7 +151,8 @@ class ShmSceneDesc(C.Structure):
                 ("image_levels", C.POINTER(ShmImageLevel)), ("n_texel_floats", C.c_uint64), ("texel_data", c_float_p),
                 ("color_space", ShmColorSpace), ("ewa_filter_lut", c_float_p), ("n_image_lights", C.c_uint32), ("n_float_textures", C.c_uint32),
                 ("image_lights", C.POINTER(ShmImageInfiniteLight)), ("float_textures", C.POINTER(ShmFloatTexture)),
-                ("n_spectrum_textures", C.c_uint32), ("pad3", C.c_uint32), ("spectrum_textures", C.POINTER(ShmSpectrumTexture))]
+                ("n_spectrum_textures", C.c_uint32), ("n_instances", C.c_uint32), ("spectrum_textures", C.POINTER(ShmSpectrumTexture)),
+                ("instances", C.POINTER(ShmInstance))]
 
 
 class ShmRenderParams(C.Structure):
@@ -179,7 +185,7 @@ class ShmRay(C.Structure):
 
 class ShmHit(C.Structure):
     _fields_ = [("prim", C.c_int32), ("t", C.c_float), ("b0", C.c_float), ("b1", C.c_float), ("b2", C.c_float),
-                ("phi", C.c_float), ("pad", C.c_uint32 * 2)]
+                ("phi", C.c_float), ("instance", C.c_uint32), ("pad", C.c_uint32)]
 
 
 assert C.sizeof(ShmMaterial) == 64 + 4 * 32 + 48 and C.sizeof(ShmFloatTexture) == 48 and C.sizeof(ShmBvhNode) == 32 and C.sizeof(ShmRay) == 32 and C.sizeof(ShmHit) == 32 and C.sizeof(ShmFilmPixel) == 32

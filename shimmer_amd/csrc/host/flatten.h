@@ -47,6 +47,8 @@ struct FlatScene {
     uint32_t rgb2spec_res = 0;
     bool has_textures = false;  // a material slot binds an image texture (the path carries ray differentials) or an image infinite
                                 // light exists (both read the colour-space tables): selects k_shade<.., HAS_TEX>
+    std::vector<ShmInstance> instances;
+    bool has_instances = false;
     std::vector<ShmFloatTexture> float_textures;
     std::vector<shm::FloatTexRange> ftex_ranges;
     std::vector<shm::FloatTexOp> ftex_ops;
@@ -97,6 +99,7 @@ struct FlatScene {
         v.rgb2spec_data = rgb2spec_data.data();
         v.cs_illuminant = cs_illuminant.data();
         v.ewa_lut = ewa_lut.data();
+        v.instances = instances.data();
         v.float_textures = float_textures.data();
         v.ftex_ranges = ftex_ranges.data();
         v.ftex_ops = ftex_ops.data();
@@ -310,8 +313,13 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
                        (mesh.n ? 4u : 0u) | (mesh.uv ? 8u : 0u);
             rec.kind_index = shm::PRIM_PATCH_BIT | pr.shape_index;
             out.has_spheres = true;
+        } else if (pr.shape_kind == SHM_SHAPE_INSTANCE) {
+            if (!d->instances || pr.shape_index >= d->n_instances) { err = "instance index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            rec.kind_index = shm::PRIM_INSTANCE_BIT | pr.shape_index;
+            out.has_spheres = true;  // non-triangle code paths
+            out.has_instances = true;
         } else {
-            err = "unsupported shape kind (instances are a SURVEY §8f row)";
+            err = "unsupported shape kind";
             return SHM_ERR_UNSUPPORTED;
         }
         out.prim_recs[s] = rec;
@@ -556,25 +564,42 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         if (l.kind == SHM_LIGHT_UNIFORM_INFINITE) out.infinite_lights.push_back(i);
     }
 
-    // BVH validation + depth (explicit stack; DFS order means child0 = i+1)
+    // BVH validation + depth (explicit stack; DFS order means child0 = i+1). The top-level tree starts at node 0, the tree of every
+    // instanced object at its ShmInstance::root_node; a top-level leaf holding an instance continues into that tree (one more stack
+    // entry for the way back).
+    if (d->n_instances) out.instances.assign(d->instances, d->instances + d->n_instances);
     {
-        std::vector<std::pair<uint32_t, uint32_t>> st;
-        st.push_back({0u, 0u});
+        struct Item { uint32_t node, depth; bool inner; };
+        std::vector<Item> st;
+        st.push_back({0u, 0u, false});
         uint64_t visited = 0;
+        const uint64_t visit_cap = (uint64_t)d->n_nodes * (1ull + d->n_instances);
         while (!st.empty()) {
-            auto [i, depth] = st.back();
+            auto [i, depth, inner] = st.back();
             st.pop_back();
             if (i >= d->n_nodes) { err = "BVH child index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
-            if (++visited > d->n_nodes) { err = "BVH is not a tree"; return SHM_ERR_INVALID_ARGUMENT; }
+            if (++visited > visit_cap) { err = "BVH is not a tree"; return SHM_ERR_INVALID_ARGUMENT; }
             const ShmBvhNode& n = d->nodes[i];
             if (n.n_prims > 0) {
                 if ((uint64_t)n.offset + n.n_prims > d->n_primitives) { err = "BVH leaf range out of bounds"; return SHM_ERR_INVALID_ARGUMENT; }
                 if (depth > out.max_leaf_depth) out.max_leaf_depth = depth;
+                for (uint32_t k = 0; k < n.n_prims; ++k) {
+                    const ShmPrimitive& pr = out.primitives[n.offset + k];
+                    if (pr.shape_kind != SHM_SHAPE_INSTANCE) {
+                        if (inner && pr.area_light >= 0) { err = "an instanced primitive cannot carry an area light"; return SHM_ERR_UNSUPPORTED; }
+                        continue;
+                    }
+                    if (inner) { err = "an instanced primitive cannot itself be an instance"; return SHM_ERR_UNSUPPORTED; }
+                    if (n.n_prims != 1) { err = "an instance must be alone in its BVH leaf"; return SHM_ERR_UNSUPPORTED; }
+                    const ShmInstance& in = out.instances[pr.shape_index];
+                    if (in.root_node == 0 || in.root_node >= d->n_nodes) { err = "instance root node out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+                    st.push_back({in.root_node, depth + 2, true});
+                }
             } else {
                 if (n.axis > 2) { err = "BVH axis out of range"; return SHM_ERR_INVALID_ARGUMENT; }
                 if (n.offset <= i) { err = "BVH second child must follow its parent"; return SHM_ERR_INVALID_ARGUMENT; }
-                st.push_back({n.offset, depth + 1});
-                st.push_back({i + 1, depth + 1});
+                st.push_back({n.offset, depth + 1, inner});
+                st.push_back({i + 1, depth + 1, inner});
             }
         }
     }

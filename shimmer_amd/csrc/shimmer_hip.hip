@@ -244,6 +244,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
     Float t_max = 0.0f;
     int32_t hit_prim = -1;
     Float hit_t = 0.0f, hit_b0 = 0.0f, hit_b1 = 0.0f, hit_b2 = 0.0f, hit_phi = 0.0f;
+    // TransformedPrimitive (TRI_ONLY = false only): the leaf slot of the instance being traversed (-1: the top-level tree), the
+    // instance the current closest hit was found through, t_max as it was outside, and whether this visit found a hit
+    int32_t inst_slot = -1, hit_inst = -1;
+    Float t_outer = 0.0f;
+    bool inst_hit = false;
+    constexpr uint32_t INST_SENTINEL = 0xffffffffu;  // stack entry that marks the way back out of an instance
     int sp = 0;
     uint32_t cur = 0;
     uint32_t leaf_off = 0, leaf_n = 0;
@@ -299,6 +305,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                             rs = ray_shear(rd);
                             if (!TRI_ONLY) rd_full = rd;
                             hit_prim = -1;
+                            hit_inst = -1;
+                            inst_slot = -1;
                             sp = 0;
                             cur = 0;
                             want_pop = false;
@@ -326,6 +334,24 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                     // pointer (which waits on both the LDS and the vector-memory counter)
                     if (sp < K3_LDS_N) cur = st_lds[sp * WAVE];
                     else cur = __builtin_nontemporal_load(st_spill + (size_t)(sp - K3_LDS_N) * WAVE);
+                    if (!TRI_ONLY && cur == INST_SENTINEL) {
+                        // the instanced aggregate is exhausted: back to the ray of the enclosing tree (primitive.rs:158-171 returns);
+                        // t_max is the hit found inside (in the instance's parameterisation, as the reference keeps it) or what it was
+                        const float4* rp = reinterpret_cast<const float4*>(rays + path);
+                        float4 r0 = rp[0], r1 = rp[1];
+                        ro = v3(r0.x, r0.y, r0.z);
+                        V3 rd = v3(r0.w, r1.x, r1.y);
+                        inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        negx = inv_dir.x < 0.0f;
+                        negy = inv_dir.y < 0.0f;
+                        negz = inv_dir.z < 0.0f;
+                        rs = ray_shear(rd);
+                        rd_full = rd;
+                        if (!inst_hit) t_max = t_outer;
+                        inst_slot = -1;
+                        want_pop = true;
+                        go = false;
+                    }
                 }
             }
             if (go) {
@@ -378,12 +404,38 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
             if (__popcll(leaf_mask) >= leaf_min || node_mask == 0ull) {
                 if (state == ST_LEAF) {
                     bool found_any = false;
+                    bool entered = false;
                     for (uint32_t i = 0; i < leaf_n; ++i) {
                         uint32_t slot = leaf_off + i;
                         c_prims++;
                         const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * 48u);
                         float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
                         bool got;
+                        if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_INSTANCE_BIT)) {
+                            // TransformedPrimitive (primitive.rs:158-176; alone in its leaf, flatten.h): leave a marker on the stack, take
+                            // the ray into the instance's space — apply_ray_inverse for intersect, the FORWARD apply_ray for
+                            // intersect_predicate, as the reference writes them — and go on in the instanced aggregate's tree.
+                            const ShmInstance& in = sv.instances[__float_as_uint(q2.y) & PRIM_INDEX_MASK];
+                            if (sp < K3_LDS_N) st_lds[sp * WAVE] = INST_SENTINEL;
+                            else st_spill[(size_t)(sp - K3_LDS_N) * WAVE] = INST_SENTINEL;
+                            sp++;
+                            t_outer = t_max;
+                            inst_slot = (int32_t)slot;
+                            inst_hit = false;
+                            Ray r;
+                            if (ANY) { Ray w; w.o = ro; w.d = rd_full; r = xf_ray(in.render_from_primitive, w); }
+                            else r = xf_ray_inverse(in.primitive_from_render, ro, rd_full, t_max);
+                            ro = r.o;
+                            rd_full = r.d;
+                            inv_dir = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+                            negx = inv_dir.x < 0.0f;
+                            negy = inv_dir.y < 0.0f;
+                            negz = inv_dir.z < 0.0f;
+                            rs = ray_shear(r.d);
+                            cur = in.root_node;
+                            entered = true;
+                            break;
+                        }
                         if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_SPHERE_BIT)) {
                             // Sphere::intersect (sphere.rs:95-196) through the same leaf phase; the hit record carries p_obj and phi
                             QuadricIntersection qi;
@@ -403,9 +455,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                         if (got) {
                             if (ANY) { found_any = true; break; }
                             t_max = hit_t;  // aggregate.rs:105-109
+                            if (!TRI_ONLY) { hit_inst = inst_slot; inst_hit = true; }
                         }
                     }
-                    if (ANY && found_any) {
+                    if (!TRI_ONLY && entered) {
+                        state = ST_NODE;
+                        want_pop = false;
+                    } else if (ANY && found_any) {
                         state = ST_DONE;
                     } else {
                         state = ST_NODE;
@@ -427,7 +483,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
             } else {
                 float4* hp = reinterpret_cast<float4*>(hits + path);
                 hp[0] = make_float4(__int_as_float(hit_prim), hit_t, hit_b0, hit_b1);
-                hp[1] = make_float4(hit_b2, TRI_ONLY ? 0.0f : hit_phi, 0.0f, 0.0f);
+                hp[1] = make_float4(hit_b2, TRI_ONLY ? 0.0f : hit_phi, TRI_ONLY ? 0.0f : __int_as_float(hit_inst + 1), 0.0f);
             }
             state = ST_IDLE;
         }
@@ -495,7 +551,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
             const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
             float4 h0 = hp[0], h1 = hp[1];
             Hit hit;
-            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y;
+            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
             const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
             float4 r0 = rp[0], r1 = rp[1];
             V3 ray_d = v3(r0.w, r1.x, r1.y);
@@ -729,7 +785,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(Scen
             const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
             float4 h0 = hp[0], h1 = hp[1];
             Hit hit;
-            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y;
+            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
             const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
             float4 r0 = rp[0], r1 = rp[1];
             V3 ray_d = v3(r0.w, r1.x, r1.y);
@@ -887,7 +943,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_randomwalk(
             const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
             float4 h0 = hp[0], h1 = hp[1];
             Hit hit;
-            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y;
+            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
             const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
             float4 r0 = rp[0], r1 = rp[1];
             V3 ray_d = v3(r0.w, r1.x, r1.y);
@@ -1238,6 +1294,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if ((rc = dev_upload(s, f.rgb2spec_data, &v.rgb2spec_data)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.cs_illuminant, &v.cs_illuminant)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ewa_lut, &v.ewa_lut)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.instances, &v.instances)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.float_textures, &v.float_textures)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ftex_ranges, &v.ftex_ranges)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ftex_ops, &v.ftex_ops)) != SHM_OK) return fail(rc);

@@ -33,7 +33,8 @@ struct PatchExtra {
 };
 static_assert(sizeof(PatchExtra) == 32, "PatchExtra must be 32 bytes");
 constexpr uint32_t PRIM_PATCH_BIT = 0x40000000u;
-constexpr uint32_t PRIM_INDEX_MASK = 0x3fffffffu;
+constexpr uint32_t PRIM_INSTANCE_BIT = 0x20000000u;  // a TransformedPrimitive: the index is into SceneView::instances, p0..p2 unused
+constexpr uint32_t PRIM_INDEX_MASK = 0x1fffffffu;
 static_assert(sizeof(PrimRec) == 48, "PrimRec must be 48 bytes");
 constexpr uint32_t PRIM_SPHERE_BIT = 0x80000000u;
 
@@ -79,6 +80,7 @@ struct SceneView {
     const Float* rgb2spec_data;
     const Float* cs_illuminant;  // 471 floats, 360..=830
     const Float* ewa_lut;        // MIP_FILTER_LUT, 128 floats
+    const ShmInstance* instances;
     const ShmFloatTexture* float_textures;
     const struct FloatTexRange* ftex_ranges;  // per node: its evaluation program (children first) in ftex_ops
     const struct FloatTexOp* ftex_ops;
@@ -182,14 +184,47 @@ struct Hit {
     Float t;
     Float b0, b1, b2;  // triangle barycentrics | sphere p_obj | bilinear patch (u, v, -)
     Float phi;         // sphere
+    int32_t inst = -1; // leaf-order slot of the TransformedPrimitive the hit was found through (prim, t, b* in its space), -1: none
 };
+
+// Transform::apply_ray_inverse (transform.rs:700-722) into an instance's space: the origin picks up the transform's rounding error
+// (apply_inverse(Point3fi::from(o)), transform.rs:631-698 = xf_point_i with m_inv), is pushed along d to the edge of that error
+// box, and t_max shrinks by the same dt.
+SHM_HD Ray xf_ray_inverse(const Float* minv, V3 ro, V3 rd, Float& t_max) {
+    P3i o = xf_point_i(minv, p3i_exact(ro));
+    V3 d = xf_vector(minv, rd);
+    Float ls = length_squared(d);
+    if (ls > 0.0f) {
+        V3 o_error = v3(o.x.width() / 2.0f, o.y.width() / 2.0f, o.z.width() / 2.0f);
+        Float dt = dot(abs3(d), o_error) / ls;
+        t_max = t_max - dt;
+        o = o + p3i_exact(d * dt);
+    }
+    Ray r;
+    r.o = o.mid();
+    r.d = d;
+    return r;
+}
 
 // Shape::intersect's interaction for the CLOSEST hit only (the reference builds it per accepted
 // candidate, triangle.rs:529-535; the result for the surviving candidate is identical).
 // TRI_ONLY: the caller knows the scene holds triangles only (the GPU shade kernel is instantiated per scene class so that the
 // quadric / patch code does not cost registers where it cannot run); the general form is the default.
 template <bool TRI_ONLY = false>
+SHM_HD SurfaceInteraction hit_interaction_local(const SceneView& sv, const Hit& h, V3 wo);
+// ... and for a hit found through a TransformedPrimitive (primitive.rs:158-171): the interaction is built in the instance's space
+// with the instance-space -ray.d, then mapped by render_from_primitive.apply(SurfaceInteraction) (transform.rs:573-608, quirk 6)
+template <bool TRI_ONLY = false>
 SHM_HD SurfaceInteraction hit_interaction(const SceneView& sv, const Hit& h, V3 wo) {
+    if (!TRI_ONLY && h.inst >= 0) {
+        const ShmInstance& in = sv.instances[sv.prim_recs[h.inst].kind_index & PRIM_INDEX_MASK];
+        V3 wo_local = xf_vector(in.primitive_from_render, wo);  // -(m_inv d) == m_inv (-d) exactly
+        return xf_surface_interaction(in.render_from_primitive, in.primitive_from_render, hit_interaction_local<false>(sv, h, wo_local));
+    }
+    return hit_interaction_local<TRI_ONLY>(sv, h, wo);
+}
+template <bool TRI_ONLY>
+SHM_HD SurfaceInteraction hit_interaction_local(const SceneView& sv, const Hit& h, V3 wo) {
     const PrimRec& pr = sv.prim_recs[h.prim];
     if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) {
         QuadricIntersection qi;

@@ -140,7 +140,7 @@ class Renderer:
         return out, stats.as_dict()
 
 
-HIT_DTYPE = np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"), ("phi", "<f4"), ("pad", "<u4", (2,))])
+HIT_DTYPE = np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"), ("phi", "<f4"), ("instance", "<u4"), ("pad", "<u4")])
 
 
 def film_tensor(renderer, device=None):

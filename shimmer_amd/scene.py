@@ -151,6 +151,10 @@ class SceneBuilder:
         self.image_lights = []  # abi.ShmImageInfiniteLight
         self.float_textures = []  # abi.ShmFloatTexture
         self.spectrum_textures = []  # abi.ShmSpectrumTexture
+        self.owners = []        # per chunk of self.prims: 0 = the scene, k = object definition k (ObjectBegin / ObjectEnd)
+        self.objects = {}       # name -> k
+        self._object = 0
+        self.instances = []     # (object id, render_from_instance 4x4 f32)
 
     # ---- spectra ----
     def spectrum_constant(self, c):
@@ -467,6 +471,7 @@ class SceneBuilder:
                 area = 0.5 * float(np.linalg.norm(np.cross((p1[t] - p0[t]).astype(np.float64), (p2[t] - p0[t]).astype(np.float64))))
                 chunk[t, 3] = self._area_light(first_prim + t, area, emission, emission_scale, two_sided)
         self.prims.append(chunk)
+        self.owners.append(self._object)
         self._n_prims += ntri
         return first_prim
 
@@ -522,6 +527,7 @@ class SceneBuilder:
                 area = 0.5 * (np.linalg.norm(np.cross(q[1] - q[0], q[2] - q[0])) + np.linalg.norm(np.cross(q[1] - q[3], q[2] - q[3])))
                 chunk[t, 3] = self._area_light(first_prim + t, float(area), emission, emission_scale, two_sided)
         self.prims.append(chunk)
+        self.owners.append(self._object)
         self._n_prims += n
         return first_prim
 
@@ -550,6 +556,7 @@ class SceneBuilder:
             area = float(s.phi_max * s.radius * (s.z_max - s.z_min))
             li = self._area_light(prim_index, area, emission, emission_scale, two_sided)
         self.prims.append(np.array([[abi.SHM_SHAPE_SPHERE, len(self.spheres) - 1, material, li]], np.int64))
+        self.owners.append(self._object)
         self._n_prims += 1
         return prim_index
 
@@ -592,6 +599,26 @@ class SceneBuilder:
         return rfw.reshape(4, 4)
 
     # ---- finalize ----
+    # ---- object instancing (loading/scene.rs:814-866; TransformedPrimitive, primitive.rs:136-176) ----
+    def begin_object(self, name):
+        """ObjectBegin: shapes added until end_object() belong to the object definition, not to the scene."""
+        assert self._object == 0 and name not in self.objects
+        self.objects[name] = len(self.objects) + 1
+        self._object = self.objects[name]
+
+    def end_object(self):
+        self._object = 0
+
+    def add_instance(self, name, render_from_instance=None):
+        """ObjectInstance: one TransformedPrimitive of the named object's aggregate."""
+        assert self._object == 0
+        m = _as_f32(IDENTITY if render_from_instance is None else render_from_instance, (4, 4))
+        self.instances.append((self.objects[name], m))
+        self.prims.append(np.array([[abi.SHM_SHAPE_INSTANCE, len(self.instances) - 1, 0, -1]], np.int64))
+        self.owners.append(0)
+        self._n_prims += 1
+        return self._n_prims - 1
+
     def prim_bounds(self):
         """Per-primitive Bounds3f in input order (triangle.rs:507-510; sphere.rs:275-280 + transform.rs:537-549)."""
         n = self._n_prims
@@ -633,17 +660,59 @@ class SceneBuilder:
         assert self.camera is not None and self.film is not None
         n = self._n_prims
         bounds = np.ascontiguousarray(self.prim_bounds())
-        nodes = (abi.ShmBvhNode * (2 * n))()
-        order = np.zeros(n, np.uint32)
-        n_nodes = C.c_uint32(0)
-        abi.check(lib, lib.shm_bvh_build(_fptr(bounds), n, split_method, nodes, C.byref(n_nodes), order.ctypes.data_as(abi.c_u32_p)),
-                  "shm_bvh_build")
+        src = np.concatenate(self.prims, axis=0)
+        owner = np.concatenate([np.full(len(c), o, np.int64) for c, o in zip(self.prims, self.owners)])
+        node_dt = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<u4"), ("n_prims", "<u2"), ("axis", "u1"), ("pad", "u1")])
+
+        def build_tree(idx):
+            """BvhAggregate::new over the primitives idx (input indices): (node records, idx in leaf order)."""
+            b = np.ascontiguousarray(bounds[idx])
+            nd = (abi.ShmBvhNode * (2 * len(idx)))()
+            order = np.zeros(len(idx), np.uint32)
+            cnt = C.c_uint32(0)
+            abi.check(lib, lib.shm_bvh_build(_fptr(b), len(idx), split_method, nd, C.byref(cnt), order.ctypes.data_as(abi.c_u32_p)), "shm_bvh_build")
+            return np.frombuffer(nd, dtype=node_dt)[:cnt.value].copy(), idx[order]
+
+        # the aggregate of every instanced object first (their root bounds give the instances' bounds), then the scene's own tree
+        obj_trees = {}
+        for k in sorted(set(self.objects.values())):
+            idx = np.nonzero(owner == k)[0]
+            assert len(idx) > 0, "empty object definition"
+            obj_trees[k] = build_tree(idx)
+        for ii, (k, m) in enumerate(self.instances):  # Transform::apply(Bounds3f), transform.rs:557-571: the eight corners
+            root = obj_trees[k][0][0]
+            lo, hi = root["bmin"], root["bmax"]
+            pts = []
+            for c in range(8):
+                q = np.array([hi[0] if c & 1 else lo[0], hi[1] if c & 2 else lo[1], hi[2] if c & 4 else lo[2]], np.float32)
+                pts.append([f32(f32(f32(f32(m[r, 0] * q[0]) + f32(m[r, 1] * q[1])) + f32(m[r, 2] * q[2])) + m[r, 3]) for r in range(3)])
+            pts = np.asarray(pts, np.float32)
+            slot = np.nonzero((src[:, 0] == abi.SHM_SHAPE_INSTANCE) & (src[:, 1] == ii))[0][0]
+            bounds[slot, :3], bounds[slot, 3:] = pts.min(axis=0), pts.max(axis=0)
+        top_nodes, top_order = build_tree(np.nonzero(owner == 0)[0])
+        trees = [(top_nodes, top_order)] + [obj_trees[k] for k in sorted(obj_trees)]
+        node_base, prim_base, nb, pb = {}, {}, 0, 0
+        for t, k in zip(trees, [0] + sorted(obj_trees)):
+            node_base[k], prim_base[k] = nb, pb
+            leaf = t[0]["n_prims"] > 0
+            t[0]["offset"][leaf] += pb
+            t[0]["offset"][~leaf] += nb
+            nb += len(t[0])
+            pb += len(t[1])
+        all_nodes = np.concatenate([t[0] for t in trees])
+        order = np.concatenate([t[1] for t in trees]).astype(np.uint32)  # input index of every leaf-order slot
+        nodes = (abi.ShmBvhNode * len(all_nodes)).from_buffer_copy(all_nodes.tobytes())
+        n_nodes = C.c_uint32(len(all_nodes))
         slot_of_input = np.empty(n, np.uint32)
         slot_of_input[order] = np.arange(n, dtype=np.uint32)
         prim_arr = (abi.ShmPrimitive * n)()
         pa = np.frombuffer(prim_arr, dtype=np.dtype([("k", "<u4"), ("i", "<u4"), ("m", "<u4"), ("l", "<i4")]))
-        src = np.concatenate(self.prims, axis=0)
         pa["k"], pa["i"], pa["m"], pa["l"] = src[order, 0], src[order, 1], src[order, 2], src[order, 3]
+        instances = (abi.ShmInstance * max(1, len(self.instances)))()
+        for ii, (k, m) in enumerate(self.instances):
+            instances[ii].render_from_primitive[:] = [float(x) for x in m.ravel()]
+            instances[ii].primitive_from_render[:] = [float(x) for x in _as_f32(np.linalg.inv(m.astype(np.float64))).ravel()]
+            instances[ii].root_node = node_base[k]
         lights = (abi.ShmLight * max(1, len(self.lights)))()
         for i, l in enumerate(self.lights):
             lights[i] = l
@@ -682,7 +751,8 @@ class SceneBuilder:
         d.n_spectrum_floats, d.spectrum_data = spec.size, _fptr(spec)
         d.camera, d.film = self.camera, self.film
         d.n_patch_meshes, d.patch_meshes = len(self.patch_meshes), patch_meshes
-        self._keep = [nodes, prim_arr, lights, meshes, spheres, materials, spec, bounds, order, patch_meshes]
+        d.n_instances, d.instances = len(self.instances), instances
+        self._keep = [nodes, prim_arr, lights, meshes, spheres, materials, spec, bounds, order, patch_meshes, instances]
         if self.textures or self.image_lights:
             textures = (abi.ShmImageTexture * max(1, len(self.textures)))(*self.textures)
             levels = (abi.ShmImageLevel * len(self.tex_levels))()

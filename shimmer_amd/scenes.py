@@ -406,6 +406,68 @@ def three_spheres(lib, width=32, height=32, offsets=(-3.5, 0.0, 5.0), camera=(0.
     return _finish(b, lib, name="three spheres" + ("" if environment is None else " (environment map)"))
 
 
+def instanced_scene(lib, width=64, height=48, n_instances=5, only_object=False, baked=False):
+    """Object instancing: one object definition (an icosphere with per-vertex normals, a partial sphere and a curved
+    bilinear patch, three materials) placed several times with rotated, non-uniformly scaled transforms over a floor lit by a quad
+    light and a point light. `only_object`: just the object's shapes at top level, untransformed, no floor. `baked`: the same
+    placements as explicitly transformed triangle copies (icosphere only) instead of instances — for cross-checks."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    b = SceneBuilder()
+    b.set_film(width, height)
+    rfw = b.set_camera_look_at(lib, (0.0, 2.2, 7.0), (0.0, 0.8, 0.0), (0, 1, 0), 40.0)
+    mats = [b.material_diffuse(_two_point_spectrum(b, 0.7, 0.2)), b.material_conductor(b.spectrum_named("metal-Cu-eta"), b.spectrum_named("metal-Cu-k"), roughness=0.2),
+            b.material_coated_diffuse(reflectance=0.5, roughness=0.1)]
+    sv, sf = icosphere(1)
+    nrm = (sv / np.linalg.norm(sv, axis=1, keepdims=True)).astype(np.float32)
+
+    def object_shapes(to_render=None, ico_only=False):
+        p = (sv * np.float32(0.6)).astype(np.float32)
+        if to_render is not None:
+            p = (np.c_[p.astype(np.float64), np.ones(len(p))] @ to_render.T)[:, :3].astype(np.float32)
+        b.add_mesh(p, sf, mats[0], n=None if to_render is not None else nrm)
+        if ico_only:
+            return
+        rfo = np.eye(4, dtype=np.float32)
+        rfo[:3, 3] = (0.9, 0.1, 0.0)
+        b.add_sphere(0.35, mats[1], render_from_object=rfo, z_min=-0.2, z_max=0.3, phi_max=270.0)
+        q = np.array([(-0.9, -0.4, 0.2), (-0.3, -0.4, 0.4), (-0.9, 0.5, 0.1), (-0.3, 0.4, 0.6)], np.float32)
+        b.add_patch_mesh(q, [[0, 1, 2, 3]], mats[2])
+
+    placements = []
+    for i in range(n_instances):
+        ang, axis = rng.uniform(0, 2 * np.pi), rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        k = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        rot = np.eye(3) + np.sin(ang) * k + (1 - np.cos(ang)) * (k @ k)
+        m = np.eye(4)
+        m[:3, :3] = rot @ np.diag(rng.uniform(0.6, 1.4, 3))
+        m[:3, 3] = (rng.uniform(-2.5, 2.5), rng.uniform(0.8, 1.6), rng.uniform(-1.5, 1.5))
+        placements.append((np.asarray(rfw, np.float64).reshape(4, 4) @ m))
+    if only_object:
+        object_shapes()
+        b.light_point((0.0, 0.0, 0.0), blackbody_dense(5000.0), scale=1.0)
+        return _finish(b, lib, name="instanced object alone")
+    if baked:
+        for m in placements:
+            object_shapes(to_render=m, ico_only=True)
+    else:
+        b.begin_object("blob")
+        object_shapes()
+        b.end_object()
+        for m in placements:
+            b.add_instance("blob", m.astype(np.float32))
+    floor_m = b.material_diffuse(0.6)
+    p, vi = _quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6))
+    b.add_mesh(_to_render(p, rfw), vi, floor_m)
+    black = b.material_diffuse(0.0)
+    p, vi = _quad((-1.5, 5.0, -1.5), (1.5, 5.0, -1.5), (1.5, 5.0, 1.5), (-1.5, 5.0, 1.5))
+    b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=12.0)
+    b.light_point((rfw @ np.array([3.0, 4.0, 4.0, 1.0], np.float32))[:3], blackbody_dense(4000.0), scale=30.0)
+    sc = _finish(b, lib, name="instanced objects" + (" (baked)" if baked else ""))
+    sc.placements = placements
+    return sc
+
+
 def random_scene(lib, seed, width=40, height=32):
     """A seeded random scene for parity fuzzing: every shape kind (triangle meshes with and without per-vertex N / S / uv,
     full and partial transformed spheres, flat and curved bilinear patches), every material kind (including nested mixes

@@ -29,6 +29,7 @@ def cases(scenes, lib):
         "crown_proxy_depth16": (lambda: scenes.crown_proxy(lib, 20, 28, level=1, n_glass=6, n_gold=2), dict(spp=2, max_depth=16, seed=8)),
         "environment_path": (lambda: scenes.three_spheres(lib, 32, 24, camera=(0.75, 0.5, 9.0), environment=env), dict(spp=4, max_depth=4, seed=9)),
         "environment_simplepath": (lambda: scenes.three_spheres(lib, 24, 16, camera=(0.75, 0.5, 9.0), environment=env), dict(spp=2, max_depth=4, seed=10, integrator="simplepath")),
+        "instanced_path": (lambda: scenes.instanced_scene(lib, 32, 24), dict(spp=4, max_depth=4, seed=14)),
         "random_scene_3": (lambda: scenes.random_scene(lib, 3), dict(spp=2, max_depth=6, seed=11)),
         "random_scene_2_ortho_nojitter": (lambda: scenes.random_scene(lib, 2), dict(spp=2, max_depth=5, seed=12, disable_pixel_jitter=True, disable_wavelength_jitter=True)),
         "random_scene_12_textured": (lambda: scenes.random_scene(lib, 12), dict(spp=2, max_depth=6, seed=13)),

@@ -51,6 +51,8 @@ SCENES = {
     # image textures (every mapping / filter / wrap / spectrum type), ray differentials through a mirror and glass
     "S2_cornell_textured": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, textured=True), 8, 6),
     # ImageInfinitelight: compensated PiecewiseConstant2D sampling + MIS against BSDF-sampled escapes
+    # TransformedPrimitive instancing: two-level traversal, inverse map for intersect, the reference's forward map for the predicate
+    "instanced": lambda scenes, lib: (scenes.instanced_scene(lib, 64, 48), 8, 5),
     "three_spheres_environment": lambda scenes, lib: (scenes.three_spheres(lib, 64, 48, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(32)), 8, 5),
 }
 
@@ -66,8 +68,10 @@ def test_trace_bitwise_parity(env, name):
         rays = _rays(sc, 30000, seed, tmax)
         hg, sg = gpu.trace(rays)
         ho, so = orc.trace(rays)
-        for k in ("prim", "t", "b0", "b1", "b2", "phi"):
-            assert np.array_equal(hg[k].view(np.uint32), ho[k].view(np.uint32)), k
+        for k in ("prim", "t", "b0", "b1", "b2", "phi", "instance"):
+            hit = ho["prim"] >= 0  # (the record of a miss is only defined up to prim = -1)
+            assert np.array_equal(hg[k].view(np.uint32)[hit], ho[k].view(np.uint32)[hit]), k
+        assert np.array_equal(hg["prim"], ho["prim"])
         assert (hg["prim"] >= 0).sum() > 100
         assert sg["nodes_closest"] == so["nodes_closest"] and sg["tris_closest"] == so["tris_closest"] and sg["rays_closest"] == 30000
         ag, s2 = gpu.trace(rays, any_hit=True)
