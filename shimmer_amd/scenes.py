@@ -592,6 +592,25 @@ def random_scene(lib, seed, width=40, height=32):
     b.light_point(pos, emit, scale=float(rng.uniform(2, 10)))
     if seed % 3 == 1:
         b.light_uniform_infinite(blackbody_dense(6500.0), scale=0.3)
+    if seed >= 12 and seed % 2 == 1:  # object instancing (primitive.rs:136-176): every shape kind inside, a mirrored placement among them
+        b.begin_object("thing")
+        sv2, sf2 = icosphere(1)
+        b.add_mesh((sv2 * np.float32(0.4)).astype(np.float32), sf2, int(trng.choice(mats)), n=(sv2 / np.linalg.norm(sv2, axis=1, keepdims=True)).astype(np.float32))
+        rfo = np.eye(4, dtype=np.float32)
+        rfo[:3, 3] = (0.6, 0.0, 0.1)
+        b.add_sphere(0.3, int(trng.choice(mats)), render_from_object=rfo, z_min=-0.2, z_max=0.25, phi_max=250.0)
+        q = np.array([(-0.7, -0.3, 0.1), (-0.2, -0.3, 0.3), (-0.7, 0.4, 0.0), (-0.2, 0.3, 0.5)], np.float32)
+        b.add_patch_mesh(q, [[0, 1, 2, 3]], int(trng.choice(mats)))
+        b.end_object()
+        for k in range(3):
+            a = trng.normal(size=3)
+            a /= np.linalg.norm(a)
+            ang = trng.uniform(0, 2 * np.pi)
+            kk = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+            m = np.eye(4)
+            m[:3, :3] = (np.eye(3) + np.sin(ang) * kk + (1 - np.cos(ang)) * (kk @ kk)) @ np.diag(trng.uniform(0.7, 1.5, 3) * np.array([-1.0 if k == 2 else 1.0, 1.0, 1.0]))
+            m[:3, 3] = (trng.uniform(-3, 3), trng.uniform(0.8, 2.5), trng.uniform(-1, 3))
+            b.add_instance("thing", (np.asarray(rfw, np.float64).reshape(4, 4) @ m).astype(np.float32))
     if seed >= 12 and seed % 2 == 0:  # an ImageInfinitelight under a random rotation (even beside the uniform sky: two infinite lights)
         a = trng.normal(size=3)
         a /= np.linalg.norm(a)
