@@ -391,7 +391,7 @@ typedef struct ShmRenderParams {
     uint8_t regularize;
     uint8_t disable_pixel_jitter;
     uint8_t disable_wavelength_jitter;
-    uint8_t force_diffuse;        /* must be 0 (unsupported) */
+    uint8_t force_diffuse;        /* options.force_diffuse: every BSDF becomes DiffuseBxDF(rho_hd estimate), interaction.rs:256-275 */
     uint8_t integrator;           /* SHM_INTEGRATOR_* (ABI v5); 0 = "path" */
     uint8_t sample_lights;        /* SimplePath "samplelights" (default true in the reference, integrator.rs:135-137) */
     uint8_t sample_bsdf;          /* SimplePath "samplebsdf"   (default true) */

@@ -211,12 +211,23 @@ struct TexParams {
     bool on;  // the scene binds image textures; off: differentials are dead values and not computed
     int spp;
     bool disable_pixel_jitter;
+    bool force_diffuse;  // options.force_diffuse (interaction.rs:256-275)
 };
 BSDF get_bsdf_at(const SceneView& sv, SurfaceInteraction& si, const ShmMaterial& m, Wavelengths& lambda, const TexParams& tp, const AuxRays& aux,
-                 Differentials& df) {
-    if (!tp.on) return get_bsdf(sv, si, m, lambda);
-    df = compute_differentials(sv, si, aux, tp.spp, tp.disable_pixel_jitter);
-    return get_bsdf<true>(sv, si, m, lambda, &df);
+                 Differentials& df, Rng& rng) {
+    BSDF bsdf;
+    if (!tp.on) {
+        bsdf = get_bsdf(sv, si, m, lambda);
+    } else {
+        df = compute_differentials(sv, si, aux, tp.spp, tp.disable_pixel_jitter);
+        bsdf = get_bsdf<true>(sv, si, m, lambda, &df);
+    }
+    if (tp.force_diffuse) {  // rho_hd(wo, &[sampler.get_1d()], &[sampler.get_2d()])
+        Float uc = sampler_get_1d(rng);
+        V2 u2 = sampler_get_2d(rng);
+        bsdf_force_diffuse(bsdf, si.wo, uc, u2);
+    }
+    return bsdf;
 }
 
 Spec li(const SceneView& sv, Ray ray, AuxRays aux, const TexParams& tp, Wavelengths& lambda, Rng& rng, int max_depth, bool regularize, Counters& c) {
@@ -265,7 +276,7 @@ Spec li(const SceneView& sv, Ray ray, AuxRays aux, const TexParams& tp, Waveleng
             }
         }
         Differentials df;
-        BSDF bsdf = get_bsdf_at(sv, si, sv.materials[prim.material], lambda, tp, aux, df);
+        BSDF bsdf = get_bsdf_at(sv, si, sv.materials[prim.material], lambda, tp, aux, df, rng);
         if (regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
         if (depth == max_depth) break;
         depth += 1;
@@ -327,7 +338,7 @@ Spec li_simple_path(const SceneView& sv, Ray ray, AuxRays aux, const TexParams& 
         if (depth == max_depth) break;
         depth += 1;
         Differentials df;
-        BSDF bsdf = get_bsdf_at(sv, si, sv.materials[prim.material], lambda, tp, aux, df);
+        BSDF bsdf = get_bsdf_at(sv, si, sv.materials[prim.material], lambda, tp, aux, df, rng);
         aux = aux_none();  // every later ray is interaction.spawn_ray(wi): no auxiliary rays (integrator.rs:686, 716)
         V3 wo = -ray.d;
         if (sample_lights) {
@@ -398,7 +409,7 @@ Spec li_random_walk(const SceneView& sv, Ray ray, const AuxRays& aux, const TexP
     Spec le = (prim.area_light >= 0) ? area_light_l(sv, sv.lights[prim.area_light], si.n, wo, lambda) : spec_const(0.0f);
     if (depth == max_depth) return le;
     Differentials df;
-    BSDF bsdf = get_bsdf_at(sv, si, sv.materials[prim.material], lambda, tp, aux, df);
+    BSDF bsdf = get_bsdf_at(sv, si, sv.materials[prim.material], lambda, tp, aux, df, rng);
     V2 u = sampler_get_2d(rng);
     V3 wp = sample_uniform_sphere(u);
     Spec f = bsdf_f(bsdf, wo, wp);
@@ -464,10 +475,10 @@ int orc_trace_any(OrcScene* s, const ShmRay* rays, uint32_t n, uint8_t* occluded
 int orc_render_wave(OrcScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles,
                     int32_t sample_begin, int32_t sample_end, int n_threads, ShmFilmPixel* film, ShmStats* stats) {
     Oracle* o = reinterpret_cast<Oracle*>(s);
-    if (!params || !tiles || !film || params->force_diffuse) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (!params || !tiles || !film) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
     const SceneView& sv = o->sv;
     const int width = sv.pixel_bounds[2] - sv.pixel_bounds[0];
-    const TexParams tp{o->flat.has_textures, params->samples_per_pixel, params->disable_pixel_jitter != 0};
+    const TexParams tp{o->flat.has_textures, params->samples_per_pixel, params->disable_pixel_jitter != 0, params->force_diffuse != 0};
     if (n_threads < 1) n_threads = 1;
     std::atomic<uint32_t> next(0);
     std::vector<Counters> counters(n_threads);

@@ -86,12 +86,12 @@ public:
     // shm_render_wave over all tiles (the rayon par_iter of :242 is the GPU's job). At the end the film sums are read
     // back; writing the image stays with the caller (film.rs:647-707 / shm_film_get_image + shm_write_pfm).
     void render(const Options& options) override {
-        if (options.force_diffuse) throw IntegratorError("force_diffuse is not supported by the wavefront backend");
         ShmRenderParams rp{};
         rp.seed = (uint64_t)(int64_t)options.seed;
         rp.samples_per_pixel = params_.samples_per_pixel;
         rp.max_depth = params_.max_depth;
         rp.regularize = params_.regularize ? 1 : 0;
+        rp.force_diffuse = options.force_diffuse ? 1 : 0;
         rp.integrator = integrator_;
         rp.sample_lights = params_.sample_lights ? 1 : 0;
         rp.sample_bsdf = params_.sample_bsdf ? 1 : 0;

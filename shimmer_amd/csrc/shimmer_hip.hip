@@ -625,20 +625,30 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                 BSDF bsdf = get_bsdf<HAS_TEX>(sv, si, mat, lambda, &df);
                 if (!HAS_LAYERED) __builtin_assume(bsdf.bxdf.kind <= SHM_MATERIAL_THIN_DIELECTRIC);
                 if (DIFFUSE_ONLY) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIFFUSE);
-                if (params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
-                bool alive = (depth != params.max_depth);  // integrator.rs:830-834
                 Rng rng;
-                if (alive) {
-                    depth += 1;
+                auto load_rng = [&]() {
                     uint32_t pix = pa.pixel[path];
                     uint2 rs = pa.rng[path];
                     rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
                     // inc is a pure function of (pixel, seed): re-derive instead of storing 8 more bytes per path
-                    {
-                        uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
-                        h = mix_bits(h ^ (params.seed + 0x9e3779b97f4a7c15ULL));
-                        rng.inc = (h << 1u) | 1u;
-                    }
+                    uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
+                    h = mix_bits(h ^ (params.seed + 0x9e3779b97f4a7c15ULL));
+                    rng.inc = (h << 1u) | 1u;
+                };
+                // options.force_diffuse (interaction.rs:256-275) draws inside get_bsdf, before the depth test; only the general
+                // instantiation carries it (the host launches that one when the flag is set)
+                const bool forced = HAS_TEX && params.force_diffuse != 0;
+                if (forced) {
+                    load_rng();
+                    Float uc = sampler_get_1d(rng);
+                    V2 u2f = sampler_get_2d(rng);
+                    bsdf_force_diffuse(bsdf, si.wo, uc, u2f);
+                }
+                if (params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
+                bool alive = (depth != params.max_depth);  // integrator.rs:830-834
+                if (alive) {
+                    depth += 1;
+                    if (!forced) load_rng();
                     // integrator.rs:837-841 + 897-963: next-event estimation; the visibility test is deferred to K3
                     if (flags_is_non_specular(bsdf_flags(bsdf))) {
                         LightSampleContext ctx = light_ctx_from(si);
@@ -830,6 +840,11 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(Scen
                         h = mix_bits(h ^ (params.seed + 0x9e3779b97f4a7c15ULL));
                         rng.inc = (h << 1u) | 1u;
                     }
+                    if (params.force_diffuse) {  // interaction.rs:256-275: rho_hd(wo, [get_1d()], [get_2d()]) inside get_bsdf
+                        Float uc = sampler_get_1d(rng);
+                        V2 u2f = sampler_get_2d(rng);
+                        bsdf_force_diffuse(bsdf, si.wo, uc, u2f);
+                    }
                     if (sample_lights) {
                         Float p_sel = 0.0f;
                         int li = light_sampler_sample(sv, sampler_get_1d(rng), p_sel);
@@ -981,6 +996,11 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_randomwalk(
                         uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
                         h = mix_bits(h ^ (params.seed + 0x9e3779b97f4a7c15ULL));
                         rng.inc = (h << 1u) | 1u;
+                    }
+                    if (params.force_diffuse) {
+                        Float uc = sampler_get_1d(rng);
+                        V2 u2f = sampler_get_2d(rng);
+                        bsdf_force_diffuse(bsdf, si.wo, uc, u2f);
                     }
                     V3 wp = sample_uniform_sphere(sampler_get_2d(rng));
                     Spec f = bsdf_f(bsdf, wo, wp);
@@ -1361,7 +1381,6 @@ int shm_film_device_ptr(ShmScene* s, void** ptr_out, uint64_t* bytes_out) {
 int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles, int32_t sample_begin,
                     int32_t sample_end, ShmStats* stats) {
     if (!s || !params || !tiles || n_tiles == 0 || sample_end <= sample_begin) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
-    if (params->force_diffuse) { g_err = "force_diffuse is not supported"; return SHM_ERR_UNSUPPORTED; }
     if (params->max_depth < 0 || params->max_depth > 254) { g_err = "max_depth out of range"; return SHM_ERR_INVALID_ARGUMENT; }
     if (params->integrator > SHM_INTEGRATOR_RANDOM_WALK) { g_err = "unknown integrator"; return SHM_ERR_UNSUPPORTED; }
     HIP_TRY(hipSetDevice(s->device));
@@ -1456,7 +1475,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 else if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH)
                     hipLaunchKernelGGL(k_shade_simple, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
                                        s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, sh);
-                else if (s->flat.has_textures) launch_shade(k_shade<true, false, true>);
+                else if (s->flat.has_textures || params->force_diffuse) launch_shade(k_shade<true, false, true>);  // the general instantiation
                 else if (s->flat.has_layered) { if (tri_only) launch_shade(k_shade<true, true>); else launch_shade(k_shade<true, false>); }
                 else if (tri_only && s->flat.diffuse_only && !getenv("SHM_NO_DIFFUSE_ONLY")) launch_shade(k_shade<false, true, false, true>);
                 else { if (tri_only) launch_shade(k_shade<false, true>); else launch_shade(k_shade<false, false>); }

@@ -800,6 +800,22 @@ SHM_HD bool bsdf_sample_f(const BSDF& b, V3 wo_render, Float u, V2 u2, uint32_t 
     bs.wi = b.shading_frame.from_local(bs.wi);
     return true;
 }
+// options.force_diffuse (interaction.rs:256-275): the BSDF is replaced by a DiffuseBxDF whose reflectance is the one-sample
+// estimate BSDF::rho_hd(wo, [uc], [u2]) (bsdf.rs:99-102 -> bxdf.rs:49-71), in the same shading frame.
+SHM_HD void bsdf_force_diffuse(BSDF& b, V3 wo_render, Float uc, V2 u2) {
+    V3 wo = b.shading_frame.to_local(wo_render);
+    Spec r = spec_const(0.0f);
+    if (wo.z != 0.0f) {
+        BSDFSample bs;
+        // BxDF::sample_f directly (bxdf.rs:57-63): none of the rejections BSDF::sample_f adds (bsdf.rs:60-82)
+        if (bxdf_sample_f(b.bxdf, wo, uc, u2, REFLTRANS_ALL, bs) && bs.pdf > 0.0f) r = r + bs.f * abs_cos_theta(bs.wi) / bs.pdf;
+        r = r / 1.0f;
+    }
+    BxDF d = b.bxdf;
+    d.kind = SHM_MATERIAL_DIFFUSE;
+    d.r = r;
+    b.bxdf = d;
+}
 SHM_HD Float bsdf_pdf(const BSDF& b, V3 wo_render, V3 wi_render, uint32_t sample_flags) {  // bsdf.rs:84-97
     V3 wo = b.shading_frame.to_local(wo_render);
     V3 wi = b.shading_frame.to_local(wi_render);

@@ -347,6 +347,22 @@ def test_environment_map_parity_other_integrators(env, integrator):
     gpu.close(); orc.close()
 
 
+@pytest.mark.parametrize("integrator", ["path", "simplepath", "randomwalk"])
+def test_force_diffuse_parity(env, integrator):
+    """options.force_diffuse (the BSDF of every vertex replaced by DiffuseBxDF(rho_hd estimate), three more sampler dimensions per
+    vertex) on scenes with specular, layered, textured and instanced materials."""
+    lib, oracle_py, render, scenes = env
+    for sc in (scenes.crown_proxy(lib, 30, 42, level=1, n_glass=6, n_gold=2), scenes.cornell_box(lib, 32, 32, textured=True), scenes.random_scene(lib, 13)):
+        gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+        p = render.make_params(seed=9, spp=4, max_depth=6, integrator=integrator, force_diffuse=True)
+        fg, sg = gpu.render(p)
+        fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
+        assert np.array_equal(fg, fo) and np.isfinite(render.film_to_rgb(fg)).all()
+        for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+            assert sg[k] == so[k], k
+        gpu.close(); orc.close()
+
+
 def test_extreme_render_parameters(env):
     """Edges of the parameter space: max_depth 0 (camera rays and emission only, no any-hit launch), 1 spp, a 5 x 3 film (one
     partial tile), maximum path depth 64 on a closed mirror-like box (paths that live long), a scene without any light, and the
