@@ -395,7 +395,7 @@ typedef struct ShmRenderParams {
     uint8_t integrator;           /* SHM_INTEGRATOR_* (ABI v5); 0 = "path" */
     uint8_t sample_lights;        /* SimplePath "samplelights" (default true in the reference, integrator.rs:135-137) */
     uint8_t sample_bsdf;          /* SimplePath "samplebsdf"   (default true) */
-    uint8_t pad;
+    uint8_t disable_texture_filtering; /* options.disable_texture_filtering: compute_differentials leaves zeros (interaction.rs:287-295) */
 } ShmRenderParams;
 enum {
     SHM_INTEGRATOR_PATH = 0,        /* PathIntegrator,       integrator.rs:748-963 */

@@ -212,6 +212,7 @@ struct TexParams {
     int spp;
     bool disable_pixel_jitter;
     bool force_diffuse;  // options.force_diffuse (interaction.rs:256-275)
+    bool disable_texture_filtering;
 };
 BSDF get_bsdf_at(const SceneView& sv, SurfaceInteraction& si, const ShmMaterial& m, Wavelengths& lambda, const TexParams& tp, const AuxRays& aux,
                  Differentials& df, Rng& rng) {
@@ -219,7 +220,7 @@ BSDF get_bsdf_at(const SceneView& sv, SurfaceInteraction& si, const ShmMaterial&
     if (!tp.on) {
         bsdf = get_bsdf(sv, si, m, lambda);
     } else {
-        df = compute_differentials(sv, si, aux, tp.spp, tp.disable_pixel_jitter);
+        df = compute_differentials(sv, si, aux, tp.spp, tp.disable_pixel_jitter, tp.disable_texture_filtering);
         bsdf = get_bsdf<true>(sv, si, m, lambda, &df);
     }
     if (tp.force_diffuse) {  // rho_hd(wo, &[sampler.get_1d()], &[sampler.get_2d()])
@@ -478,7 +479,7 @@ int orc_render_wave(OrcScene* s, const ShmRenderParams* params, const ShmTile* t
     if (!params || !tiles || !film) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
     const SceneView& sv = o->sv;
     const int width = sv.pixel_bounds[2] - sv.pixel_bounds[0];
-    const TexParams tp{o->flat.has_textures, params->samples_per_pixel, params->disable_pixel_jitter != 0, params->force_diffuse != 0};
+    const TexParams tp{o->flat.has_textures, params->samples_per_pixel, params->disable_pixel_jitter != 0, params->force_diffuse != 0, params->disable_texture_filtering != 0};
     if (n_threads < 1) n_threads = 1;
     std::atomic<uint32_t> next(0);
     std::vector<Counters> counters(n_threads);

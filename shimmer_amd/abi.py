@@ -158,7 +158,7 @@ class ShmSceneDesc(C.Structure):
 class ShmRenderParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32), ("regularize", C.c_uint8),
                 ("disable_pixel_jitter", C.c_uint8), ("disable_wavelength_jitter", C.c_uint8), ("force_diffuse", C.c_uint8),
-                ("integrator", C.c_uint8), ("sample_lights", C.c_uint8), ("sample_bsdf", C.c_uint8), ("pad", C.c_uint8)]
+                ("integrator", C.c_uint8), ("sample_lights", C.c_uint8), ("sample_bsdf", C.c_uint8), ("disable_texture_filtering", C.c_uint8)]
 
 
 class ShmTile(C.Structure):

@@ -29,6 +29,7 @@ struct Options {
     bool disable_pixel_jitter = false;
     bool disable_wavelength_jitter = false;
     bool force_diffuse = false;
+    bool disable_texture_filtering = false;
     bool wavefront = true;  // main.rs:152-155: the flag that selects this backend
 };
 
@@ -92,6 +93,7 @@ public:
         rp.max_depth = params_.max_depth;
         rp.regularize = params_.regularize ? 1 : 0;
         rp.force_diffuse = options.force_diffuse ? 1 : 0;
+        rp.disable_texture_filtering = options.disable_texture_filtering ? 1 : 0;
         rp.integrator = integrator_;
         rp.sample_lights = params_.sample_lights ? 1 : 0;
         rp.sample_bsdf = params_.sample_bsdf ? 1 : 0;

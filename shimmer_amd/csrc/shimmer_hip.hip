@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                 AuxRays aux = aux_none();
                 if (HAS_TEX) {
                     if (fl & (1u << 10)) aux = ld_aux(pa, path);
-                    df = compute_differentials(sv, si, aux, params.samples_per_pixel, params.disable_pixel_jitter != 0);
+                    df = compute_differentials(sv, si, aux, params.samples_per_pixel, params.disable_pixel_jitter != 0, params.disable_texture_filtering != 0);
                 }
                 const ShmMaterial& mat = sv.materials[prim.material];
                 if (DIFFUSE_ONLY) __builtin_assume(mat.kind == SHM_MATERIAL_DIFFUSE);
@@ -768,7 +768,7 @@ __device__ BSDF get_bsdf_general(const SceneView& sv, const PathArrays& pa, uint
                                  const ShmMaterial& m, Wavelengths& lambda, const ShmRenderParams& params) {
     if (pa.aux0 == nullptr) return get_bsdf(sv, si, m, lambda);
     AuxRays aux = (fl & (1u << 10)) ? ld_aux(pa, path) : aux_none();
-    Differentials df = compute_differentials(sv, si, aux, params.samples_per_pixel, params.disable_pixel_jitter != 0);
+    Differentials df = compute_differentials(sv, si, aux, params.samples_per_pixel, params.disable_pixel_jitter != 0, params.disable_texture_filtering != 0);
     return get_bsdf<true>(sv, si, m, lambda, &df);
 }
 

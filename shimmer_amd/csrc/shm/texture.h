@@ -95,9 +95,10 @@ SHM_HD void approximate_dp_dxy(const ShmCamera& cam, V3 p, V3 n, int samples_per
     dpdy = spp_scale * xf_vector(cam.render_from_camera, rot3_apply_transpose(down_z_from_camera, py - p_down_z));
 }
 
-// interaction.rs:280-366 (options.disable_texture_filtering is not part of the ABI: false)
+// interaction.rs:280-366
 SHM_HD Differentials compute_differentials(const SceneView& sv, const SurfaceInteraction& si, const AuxRays& aux, int samples_per_pixel,
-                                           bool disable_pixel_jitter) {
+                                           bool disable_pixel_jitter, bool disable_texture_filtering = false) {
+    if (disable_texture_filtering) return differentials_zero();  // :287-295
     Differentials r;
     V3 p = si.p();
     if (aux.has && dot(si.n, aux.rx_d) != 0.0f && dot(si.n, aux.ry_d) != 0.0f) {

@@ -321,8 +321,8 @@ def test_textured_parity_per_filter_and_integrator(env, integrator, texture_filt
     lib, oracle_py, render, scenes = env
     sc = scenes.cornell_box(lib, 40, 40, textured=True, texture_filter=texture_filter)
     gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
-    for dpj, spp in ((False, 6), (True, 2)):
-        p = render.make_params(seed=5, spp=spp, max_depth=5, integrator=integrator, disable_pixel_jitter=dpj)
+    for dpj, spp, dtf in ((False, 6, False), (True, 2, False), (False, 3, True)):
+        p = render.make_params(seed=5, spp=spp, max_depth=5, integrator=integrator, disable_pixel_jitter=dpj, disable_texture_filtering=dtf)
         fg, sg = gpu.render(p)
         fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
         assert np.array_equal(fg, fo) and np.isfinite(render.film_to_rgb(fg)).all() and render.film_to_rgb(fg).max() > 0

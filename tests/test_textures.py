@@ -625,3 +625,19 @@ def test_textured_render_is_finite_and_textured(lib, integrator):
     assert np.isfinite(rgb).all() and rgb.mean() > 0.01
     floor = rgb[34:39, 8:32, :]  # the EWA-filtered checker on the floor: neighbouring columns differ by more than noise alone would
     assert floor.std(axis=1).mean() > 0.02
+
+
+def test_disable_texture_filtering(lib):
+    """options.disable_texture_filtering (interaction.rs:287-295): zero differentials, so every filter reads the finest level
+    (width 0 -> level 0; EWA's shorter axis 0 -> bilerp(0), mipmap.rs:141-144) and bump maps step by 0.0005."""
+    sc = scenes.cornell_box(lib, 32, 32, textured=True)
+    o = oracle_py.Oracle(sc.desc)
+    try:
+        a, _ = o.render(render.make_params(spp=4, max_depth=4, seed=2), n_threads=8)
+        b, _ = o.render(render.make_params(spp=4, max_depth=4, seed=2, disable_texture_filtering=True), n_threads=8)
+        out = (C.c_float * 44)()
+    finally:
+        o.close()
+    ra, rb = a["rgb_sum"] / a["weight_sum"][..., None], b["rgb_sum"] / b["weight_sum"][..., None]
+    assert np.isfinite(rb).all() and not np.array_equal(a, b)
+    assert abs(rb.mean() / ra.mean() - 1) < 0.2  # same scene, sharper textures
