@@ -1475,7 +1475,9 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 else if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH)
                     hipLaunchKernelGGL(k_shade_simple, dim3(shade_blocks), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur],
                                        s->d_q_active[cur ^ 1], s->d_q_shadow, s->d_qs, cur, *params, sh);
-                else if (s->flat.has_textures || params->force_diffuse) launch_shade(k_shade<true, false, true>);  // the general instantiation
+                else if (s->flat.has_textures || params->force_diffuse) {  // the general instantiations (textures, image lights, force_diffuse)
+                    if (s->flat.has_layered) launch_shade(k_shade<true, false, true>); else launch_shade(k_shade<false, false, true>);
+                }
                 else if (s->flat.has_layered) { if (tri_only) launch_shade(k_shade<true, true>); else launch_shade(k_shade<true, false>); }
                 else if (tri_only && s->flat.diffuse_only && !getenv("SHM_NO_DIFFUSE_ONLY")) launch_shade(k_shade<false, true, false, true>);
                 else { if (tri_only) launch_shade(k_shade<false, true>); else launch_shade(k_shade<false, false>); }

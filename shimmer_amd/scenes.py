@@ -96,7 +96,7 @@ def test_image(size=64, channels=3, seed=7):
 
 
 def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=False, patch_skew=0.0, textured=False,
-                texture_filter=None):
+                texture_filter=None, textured_coated_ceiling=True):
     """S2 (config C2): 5 walls x 2 + 2 boxes x 5 faces x 2 + light 2 = 32 triangles.
     coated=True: the tall box becomes CoatedConductor (rough interface, Cu), the short one CoatedDiffuse with a scattering
     medium between the interfaces, the floor CoatedDiffuse with a smooth interface (SURVEY §8f-1 materials)."""
@@ -134,10 +134,12 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=Fal
         # a composite spectrum texture (texture.rs:536-687): the image mixed with a smooth spectrum by a float image, then dimmed by direction
         right_m = b.material_diffuse(b.stex_direction_mix(b.stex_mix(right_tex, _two_point_spectrum(b, 0.6, 0.08), b.ftex_image(img1, filter=tf("point"))),
                                                           b.stex_scaled(0.5, 0.5), dir=(1.0, 0.0, 0.0)))
-        ceil_m = b.material_coated_diffuse(reflectance=b.add_image_texture(img3, filter=tf("ewa"), invert=True, mapping="cylindrical",
-                                                                            max_anisotropy=4.0, wrap="octahedralsphere",
-                                                                            texture_from_render=np.linalg.inv(to_render.astype(np.float64))),
-                                           roughness=0.2, albedo=b.add_image_texture(img1, filter=tf("bilinear")), thickness=0.05)
+        ceil_tex = b.add_image_texture(img3, filter=tf("ewa"), invert=True, mapping="cylindrical", max_anisotropy=4.0, wrap="octahedralsphere",
+                                       texture_from_render=np.linalg.inv(to_render.astype(np.float64)))
+        if textured_coated_ceiling:
+            ceil_m = b.material_coated_diffuse(reflectance=ceil_tex, roughness=0.2, albedo=b.add_image_texture(img1, filter=tf("bilinear")), thickness=0.05)
+        else:  # no LayeredBxDF anywhere: the scene class of the lighter textured shade instantiation
+            ceil_m = b.material_conductor(b.spectrum_named("metal-Al-eta"), b.spectrum_named("metal-Al-k"), roughness=0.3)
         tall_m = b.material_conductor(b.spectrum_named("metal-Ag-eta"), b.spectrum_named("metal-Ag-k"), roughness=0.0)
         short_m = b.material_dielectric(1.5)
         # float textures (texture.rs:88-403) on the float parameters, a bump map and a normal map (interaction.rs:223-245):

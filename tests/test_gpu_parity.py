@@ -50,6 +50,7 @@ SCENES = {
     "S2_cornell_mix": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, mix=True), 8, 5),  # MixMaterial, nested, with a coated leaf
     # image textures (every mapping / filter / wrap / spectrum type), ray differentials through a mirror and glass
     "S2_cornell_textured": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, textured=True), 8, 6),
+    "S2_cornell_textured_nocoat": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, textured=True, textured_coated_ceiling=False), 6, 6),  # k_shade<false, false, true>
     # ImageInfinitelight: compensated PiecewiseConstant2D sampling + MIS against BSDF-sampled escapes
     # TransformedPrimitive instancing: two-level traversal, inverse map for intersect, the reference's forward map for the predicate
     "instanced": lambda scenes, lib: (scenes.instanced_scene(lib, 64, 48), 8, 5),

@@ -14,6 +14,7 @@ CONFIGS = [
     ("C4 crown-proxy 1000x1400x256 d32", lambda: scenes.crown_proxy(lib, 1000, 1400), 256, 32),
     ("S3c coated ganesha 1024x1024x64", lambda: scenes.ganesha_proxy(lib, 1024, 1024, coated=True), 64, 5),
     ("C2t cornell textured 512x512x64", lambda: scenes.cornell_box(lib, 512, 512, textured=True), 64, 6),
+    ("C2u cornell textured, no coated 512x512x64", lambda: scenes.cornell_box(lib, 512, 512, textured=True, textured_coated_ceiling=False), 64, 6),
     ("E3 spheres + environment map 512x384x64", lambda: scenes.three_spheres(lib, 512, 384, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(64)), 64, 5),
 ]
 only = sys.argv[1:] 
