@@ -9,6 +9,10 @@
 //   integrator.rs:326-396   evaluate_pixel_sample
 //   integrator.rs:748-895   PathIntegrator::li
 //   integrator.rs:897-963   PathIntegrator::sample_ld
+//   integrator.rs:586-733   SimplePathIntegrator::li
+//   integrator.rs:491-563   RandomWalkIntegrator::li_random_walk (recursive, as there)
+//   interaction.rs:187-278  get_bsdf's frame: compute_differentials first, force_diffuse last (the body is shm/path.h get_bsdf)
+//   primitive.rs:136-176    TransformedPrimitive::{intersect, intersect_predicate}: the nested traversal of an instanced aggregate
 //   integrator.rs:100-116   IntegratorBase::{intersect, intersect_predicate, unoccluded}, SHADOW_EPSILON
 //   aggregate.rs:71-203     BvhAggregate::{intersect, intersect_predicate} (64-entry stack, near child first)
 //   film.rs:548-574         RgbFilm::add_sample
@@ -878,7 +882,7 @@ void orc_fn_texture_filter(OrcScene* s, uint32_t tex, const float* st, const flo
     tv.t = &o->sv.image_textures[tex];
     tv.levels = o->sv.image_levels + tv.t->first_level;
     tv.texels = o->sv.texel_data;
-    RGB3 r = tex_filter(tv, o->sv.ewa_lut, v2(st[0], st[1]), v2(dst0[0], dst0[1]), v2(dst1[0], dst1[1]));
+    RGB3 r = tex_filter<RGB3>(tv, o->sv.ewa_lut, v2(st[0], st[1]), v2(dst0[0], dst0[1]), v2(dst1[0], dst1[1]));
     out3[0] = r.r; out3[1] = r.g; out3[2] = r.b;
 }
 void orc_fn_rgb2spec_fetch(OrcScene* s, const float* rgb, float* out3) {

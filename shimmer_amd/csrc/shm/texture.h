@@ -328,10 +328,33 @@ SHM_HD RGB3 tex_bilerp(const TextureView& tv, int level, V2 st) {
 }
 
 constexpr int MIP_FILTER_LUT_SIZE = 128;  // mipmap.rs:390
+
+// TexelType (mipmap.rs:233-331): what MIPMap::filter is generic over. RGB: texel_rgb / three bilerps (:201-219, :314-330).
+// Float: texel = channel 0; bilerp = channel 0 of a one-channel image, the AVERAGE of the three bilerps of an RGB one (:297-312;
+// an RGBA image would use its alpha: the ABI hands over 1 or 3 channels).
+template <typename T> struct TexelOps;
+template <> struct TexelOps<RGB3> {
+    static SHM_HD RGB3 zero() { return rgb3(0.0f, 0.0f, 0.0f); }
+    static SHM_HD RGB3 texel(const TextureView& tv, int level, int x, int y) { return tex_texel(tv, level, x, y); }
+    static SHM_HD RGB3 bilerp(const TextureView& tv, int level, V2 st) { return tex_bilerp(tv, level, st); }
+    static SHM_HD RGB3 lerp(Float t, RGB3 a, RGB3 b) { return lerp_rgb(t, a, b); }
+};
+template <> struct TexelOps<Float> {
+    static SHM_HD Float zero() { return 0.0f; }
+    static SHM_HD Float texel(const TextureView& tv, int level, int x, int y) { return tex_channel(tv, level, x, y, 0); }
+    static SHM_HD Float bilerp(const TextureView& tv, int level, V2 st) {
+        if (tv.t->n_channels == 1) return tex_bilerp_channel(tv, level, st, 0);
+        // ImageChannelValues::average, image.rs:275-277
+        return (((0.0f + tex_bilerp_channel(tv, level, st, 0)) + tex_bilerp_channel(tv, level, st, 1)) + tex_bilerp_channel(tv, level, st, 2)) / 3.0f;
+    }
+    static SHM_HD Float lerp(Float t, Float a, Float b) { return shm::lerp(t, a, b); }
+};
+
 // TexelType::ewa, mipmap.rs:233-295
-SHM_HD RGB3 tex_ewa(const TextureView& tv, const Float* lut, int level, V2 st, V2 dst0, V2 dst1) {
+template <typename T>
+SHM_HD T tex_ewa(const TextureView& tv, const Float* lut, int level, V2 st, V2 dst0, V2 dst1) {
     int n_levels = (int)tv.t->n_levels;
-    if (level >= n_levels) return tex_texel(tv, n_levels - 1, 0, 0);
+    if (level >= n_levels) return TexelOps<T>::texel(tv, n_levels - 1, 0, 0);
     const ShmImageLevel& l = tv.levels[level];
     st.x = st.x * (Float)l.width - 0.5f;
     st.y = st.y * (Float)l.height - 0.5f;
@@ -353,7 +376,7 @@ SHM_HD RGB3 tex_ewa(const TextureView& tv, const Float* lut, int level, V2 st, V
     int s1 = float_to_i32(floor(st.x + 2.0f * inv_det * u_sqrt));
     int t0 = float_to_i32(ceil(st.y - 2.0f * inv_det * v_sqrt));
     int t1 = float_to_i32(floor(st.y + 2.0f * inv_det * v_sqrt));
-    RGB3 sum = rgb3(0.0f, 0.0f, 0.0f);
+    T sum = TexelOps<T>::zero();
     Float sum_wts = 0.0f;
     for (int it = t0; it <= t1; ++it) {
         Float tt = (Float)it - st.y;
@@ -365,7 +388,7 @@ SHM_HD RGB3 tex_ewa(const TextureView& tv, const Float* lut, int level, V2 st, V
                 if (index < 0) index = 0;
                 if (index > MIP_FILTER_LUT_SIZE - 1) index = MIP_FILTER_LUT_SIZE - 1;
                 Float weight = lut[index];
-                sum = sum + tex_texel(tv, level, is, it) * weight;
+                sum = sum + TexelOps<T>::texel(tv, level, is, it) * weight;
                 sum_wts += weight;
             }
         }
@@ -373,8 +396,9 @@ SHM_HD RGB3 tex_ewa(const TextureView& tv, const Float* lut, int level, V2 st, V
     return sum / sum_wts;
 }
 
-// MIPMap::filter::<RGB>, mipmap.rs:121-199
-SHM_HD RGB3 tex_filter(const TextureView& tv, const Float* lut, V2 st, V2 dst0, V2 dst1) {
+// MIPMap::filter::<T>, mipmap.rs:121-199
+template <typename T>
+SHM_HD T tex_filter(const TextureView& tv, const Float* lut, V2 st, V2 dst0, V2 dst1) {
     const ShmImageTexture& t = *tv.t;
     int n_levels = (int)t.n_levels;
     if (t.filter == SHM_TEXFILTER_EWA) {
@@ -386,109 +410,27 @@ SHM_HD RGB3 tex_filter(const TextureView& tv, const Float* lut, V2 st, V2 dst0, 
             dst1 = dst1 * scale;
             shorter_vec_length *= scale;
         }
-        if (shorter_vec_length == 0.0f) return tex_bilerp(tv, 0, st);
+        if (shorter_vec_length == 0.0f) return TexelOps<T>::bilerp(tv, 0, st);
         Float lod = max(0.0f, (Float)n_levels - 1.0f + log2(shorter_vec_length));
         int ilod = float_to_i32(floor(lod));
-        return lerp_rgb(lod - (Float)ilod, tex_ewa(tv, lut, ilod, st, dst0, dst1), tex_ewa(tv, lut, ilod + 1, st, dst0, dst1));
+        return TexelOps<T>::lerp(lod - (Float)ilod, tex_ewa<T>(tv, lut, ilod, st, dst0, dst1), tex_ewa<T>(tv, lut, ilod + 1, st, dst0, dst1));
     }
     // reduce(|acc, e| acc.max(e)) over [|dst0.x|, |dst0.y|, |dst1.x|, |dst1.y|]
     Float width = 2.0f * max(max(max(abs(dst0.x), abs(dst0.y)), abs(dst1.x)), abs(dst1.y));
     Float level = (Float)n_levels - 1.0f + log2(max(width, 1e-8f));
-    if (level >= (Float)n_levels - 1.0f) return tex_texel(tv, n_levels - 1, 0, 0);
+    if (level >= (Float)n_levels - 1.0f) return TexelOps<T>::texel(tv, n_levels - 1, 0, 0);
     int i_level = float_to_i32(floor(level));
     if (i_level < 0) i_level = 0;
     if (t.filter == SHM_TEXFILTER_POINT) {
         const ShmImageLevel& l = tv.levels[i_level];
         int sx = float_to_i32(round(st.x * (Float)l.width - 0.5f));
         int sy = float_to_i32(round(st.y * (Float)l.height - 0.5f));
-        return tex_texel(tv, i_level, sx, sy);
+        return TexelOps<T>::texel(tv, i_level, sx, sy);
     }
-    if (t.filter == SHM_TEXFILTER_BILINEAR) return tex_bilerp(tv, i_level, st);
+    if (t.filter == SHM_TEXFILTER_BILINEAR) return TexelOps<T>::bilerp(tv, i_level, st);
     // Trilinear
-    if (i_level == 0) return tex_bilerp(tv, 0, st);
-    return lerp_rgb(level - (Float)i_level, tex_bilerp(tv, i_level, st), tex_bilerp(tv, i_level + 1, st));
-}
-
-// TexelType for Float (mipmap.rs:297-312): texel = channel 0; bilerp = channel 0 of a one-channel image, the AVERAGE of the three
-// bilerps of an RGB one (an RGBA image would use its alpha: the ABI hands over 1 or 3 channels)
-SHM_HD Float tex_texel_f(const TextureView& tv, int level, int x, int y) { return tex_channel(tv, level, x, y, 0); }
-SHM_HD Float tex_bilerp_f(const TextureView& tv, int level, V2 st) {
-    if (tv.t->n_channels == 1) return tex_bilerp_channel(tv, level, st, 0);
-    // ImageChannelValues::average, image.rs:275-277
-    return (((0.0f + tex_bilerp_channel(tv, level, st, 0)) + tex_bilerp_channel(tv, level, st, 1)) + tex_bilerp_channel(tv, level, st, 2)) / 3.0f;
-}
-// MIPMap::filter::<Float> / TexelType::ewa for Float: the same control flow as tex_filter / tex_ewa with scalar texels
-SHM_HD Float tex_ewa_f(const TextureView& tv, const Float* lut, int level, V2 st, V2 dst0, V2 dst1) {
-    int n_levels = (int)tv.t->n_levels;
-    if (level >= n_levels) return tex_texel_f(tv, n_levels - 1, 0, 0);
-    const ShmImageLevel& l = tv.levels[level];
-    st.x = st.x * (Float)l.width - 0.5f;
-    st.y = st.y * (Float)l.height - 0.5f;
-    dst0.x *= (Float)l.width;
-    dst0.y *= (Float)l.height;
-    dst1.x *= (Float)l.width;
-    dst1.y *= (Float)l.height;
-    Float a = sqr(dst0.y) + sqr(dst1.y) + 1.0f;
-    Float b = -2.0f * (dst0.x * dst0.y + dst1.x * dst1.y);
-    Float c = sqr(dst0.x) + sqr(dst1.x) + 1.0f;
-    Float inv_f = 1.0f / (a * c - sqr(b) * 0.25f);
-    a *= inv_f;
-    b *= inv_f;
-    c *= inv_f;
-    Float det = -sqr(b) + 4.0f * a * c;
-    Float inv_det = 1.0f / det;
-    Float u_sqrt = safe_sqrt(det * c), v_sqrt = safe_sqrt(a * det);
-    int s0 = float_to_i32(ceil(st.x - 2.0f * inv_det * u_sqrt));
-    int s1 = float_to_i32(floor(st.x + 2.0f * inv_det * u_sqrt));
-    int t0 = float_to_i32(ceil(st.y - 2.0f * inv_det * v_sqrt));
-    int t1 = float_to_i32(floor(st.y + 2.0f * inv_det * v_sqrt));
-    Float sum = 0.0f, sum_wts = 0.0f;
-    for (int it = t0; it <= t1; ++it) {
-        Float tt = (Float)it - st.y;
-        for (int is = s0; is <= s1; ++is) {
-            Float ss = (Float)is - st.x;
-            Float r2 = a * sqr(ss) + b * ss * tt + c * sqr(tt);
-            if (r2 < 1.0f) {
-                int index = float_to_i32(r2 * (Float)MIP_FILTER_LUT_SIZE);
-                if (index < 0) index = 0;
-                if (index > MIP_FILTER_LUT_SIZE - 1) index = MIP_FILTER_LUT_SIZE - 1;
-                Float weight = lut[index];
-                sum = sum + tex_texel_f(tv, level, is, it) * weight;
-                sum_wts += weight;
-            }
-        }
-    }
-    return sum / sum_wts;
-}
-SHM_HD Float tex_filter_f(const TextureView& tv, const Float* lut, V2 st, V2 dst0, V2 dst1) {
-    const ShmImageTexture& t = *tv.t;
-    int n_levels = (int)t.n_levels;
-    if (t.filter == SHM_TEXFILTER_EWA) {
-        if (length_squared(dst0) < length_squared(dst1)) { V2 tmp = dst0; dst0 = dst1; dst1 = tmp; }
-        Float longer_vec_length = sqrt(length_squared(dst0));
-        Float shorter_vec_length = sqrt(length_squared(dst1));
-        if (shorter_vec_length * t.max_anisotropy < longer_vec_length && shorter_vec_length > 0.0f) {
-            Float scale = longer_vec_length / (shorter_vec_length * t.max_anisotropy);
-            dst1 = dst1 * scale;
-            shorter_vec_length *= scale;
-        }
-        if (shorter_vec_length == 0.0f) return tex_bilerp_f(tv, 0, st);
-        Float lod = max(0.0f, (Float)n_levels - 1.0f + log2(shorter_vec_length));
-        int ilod = float_to_i32(floor(lod));
-        return lerp(lod - (Float)ilod, tex_ewa_f(tv, lut, ilod, st, dst0, dst1), tex_ewa_f(tv, lut, ilod + 1, st, dst0, dst1));
-    }
-    Float width = 2.0f * max(max(max(abs(dst0.x), abs(dst0.y)), abs(dst1.x)), abs(dst1.y));
-    Float level = (Float)n_levels - 1.0f + log2(max(width, 1e-8f));
-    if (level >= (Float)n_levels - 1.0f) return tex_texel_f(tv, n_levels - 1, 0, 0);
-    int i_level = float_to_i32(floor(level));
-    if (i_level < 0) i_level = 0;
-    if (t.filter == SHM_TEXFILTER_POINT) {
-        const ShmImageLevel& l = tv.levels[i_level];
-        return tex_texel_f(tv, i_level, float_to_i32(round(st.x * (Float)l.width - 0.5f)), float_to_i32(round(st.y * (Float)l.height - 0.5f)));
-    }
-    if (t.filter == SHM_TEXFILTER_BILINEAR) return tex_bilerp_f(tv, i_level, st);
-    if (i_level == 0) return tex_bilerp_f(tv, 0, st);
-    return lerp(level - (Float)i_level, tex_bilerp_f(tv, i_level, st), tex_bilerp_f(tv, i_level + 1, st));
+    if (i_level == 0) return TexelOps<T>::bilerp(tv, 0, st);
+    return TexelOps<T>::lerp(level - (Float)i_level, TexelOps<T>::bilerp(tv, i_level, st), TexelOps<T>::bilerp(tv, i_level + 1, st));
 }
 SHM_HD TextureView texture_view(const SceneView& sv, uint32_t texture_index) {
     TextureView tv;
@@ -502,7 +444,7 @@ SHM_HD_NOINLINE Float float_image_texture_evaluate(const SceneView& sv, uint32_t
     TextureView tv = texture_view(sv, texture_index);
     TexCoord2D c = texture_map(*tv.t, ctx);
     c.st.y = 1.0f - c.st.y;
-    Float v = tex_filter_f(tv, sv.ewa_lut, c.st, v2(c.dsdx, c.dtdx), v2(c.dsdy, c.dtdy)) * tv.t->scale;
+    Float v = tex_filter<Float>(tv, sv.ewa_lut, c.st, v2(c.dsdx, c.dtdx), v2(c.dsdy, c.dtdy)) * tv.t->scale;
     return tv.t->invert ? max(0.0f, 1.0f - v) : v;
 }
 // FloatTexture::evaluate (texture.rs:142-152): the node's post-order program (scene.h FloatTexOp), children before parents
@@ -589,7 +531,7 @@ SHM_HD_NOINLINE Spec image_texture_evaluate(const SceneView& sv, uint32_t textur
     tv.texels = sv.texel_data;
     TexCoord2D c = texture_map(*tv.t, ctx);
     c.st.y = 1.0f - c.st.y;
-    RGB3 rgb = tex_filter(tv, sv.ewa_lut, c.st, v2(c.dsdx, c.dtdx), v2(c.dsdy, c.dtdy)) * tv.t->scale;
+    RGB3 rgb = tex_filter<RGB3>(tv, sv.ewa_lut, c.st, v2(c.dsdx, c.dtdx), v2(c.dsdy, c.dtdy)) * tv.t->scale;
     if (tv.t->invert) rgb = rgb3(1.0f, 1.0f, 1.0f) - rgb;
     rgb = rgb3(max(0.0f, rgb.r), max(0.0f, rgb.g), max(0.0f, rgb.b));  // clamp_zero, color.rs:204-210
     if (!tv.t->has_color_space) return spec_const(rgb.r);
