@@ -105,6 +105,7 @@ def main():
                     "headline diffuse one: a side measurement, not the BASELINE config")
     ap.add_argument("--shard-of", type=int, default=0, help="development: render only the tiles rank 0 of N would own (no gather), "
                     "to estimate the per-rank time of an N-GPU run on one GPU")
+    ap.add_argument("--shard-rank", type=int, default=0, help="development: which rank's tiles --shard-of renders")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL init + film gather path even with one rank")
     args = ap.parse_args()
 
@@ -144,7 +145,7 @@ def main():
     params = render.make_params(seed=args.seed, spp=args.spp, max_depth=args.max_depth)
     my_tiles = None if world == 1 else render.shard_tiles(r.n_tiles, r.tiles_per_row, rank, world)
     if world == 1 and args.shard_of > 1:
-        my_tiles = render.shard_tiles(r.n_tiles, r.tiles_per_row, 0, args.shard_of)
+        my_tiles = render.shard_tiles(r.n_tiles, r.tiles_per_row, args.shard_rank, args.shard_of)
 
     def barrier():
         if use_dist:

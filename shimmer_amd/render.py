@@ -5,6 +5,7 @@ no data-path collective while rendering); the per-rank film slabs are gathered w
 torch.distributed (plumbing only — all arithmetic happens inside libshimmer_hip.so).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -57,7 +58,7 @@ def shard_tiles(n_tiles, tiles_per_row, rank, world_size, rows_per_block=None):
     are spread over all ranks."""
     if rows_per_block is None:
         tile_rows = (n_tiles + tiles_per_row - 1) // tiles_per_row
-        rows_per_block = max(1, tile_rows // (world_size * 8))
+        rows_per_block = max(1, tile_rows // (world_size * int(os.environ.get("SHM_SHARD_BLOCKS", "8"))))
     idx = np.arange(n_tiles)
     block = (idx // tiles_per_row) // rows_per_block
     return idx[(block % world_size) == rank]
