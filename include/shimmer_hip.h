@@ -37,7 +37,7 @@ extern "C" {
 typedef enum ShmError {
     SHM_OK = 0,
     SHM_ERR_INVALID_ARGUMENT = -1,
-    SHM_ERR_UNSUPPORTED = -2,   /* scene uses a feature outside the contracted path */
+    SHM_ERR_UNSUPPORTED = -2,   /* valid input the backend does not take (nested instances, trees over the node limits, BVH deeper than 64, ...) */
     SHM_ERR_DEVICE = -3,        /* HIP runtime error; see shm_last_error() */
     SHM_ERR_NO_DEVICE = -4,     /* no gfx950 device visible: there is NO CPU fallback */
     SHM_ERR_OUT_OF_MEMORY = -5,
