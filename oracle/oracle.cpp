@@ -860,6 +860,18 @@ void orc_fn_transform_apply(int kind, int inverse, const float* m, const float* 
     out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
 }
 
+// vecmath: out = length(a), length_squared(a), angle_between(normalize(a), normalize(b)), normalize(a)[3], gram_schmidt(b, normalize(a))[3]
+void orc_fn_vecmath(const float* a, const float* b, float* out9) {
+    V3 va = ld3(a), vb = ld3(b);
+    out9[0] = length(va);
+    out9[1] = length_squared(va);
+    out9[2] = angle_between(normalize(va), normalize(vb));
+    V3 n = normalize(va);
+    out9[3] = n.x; out9[4] = n.y; out9[5] = n.z;
+    V3 g = gram_schmidt(vb, n);
+    out9[6] = g.x; out9[7] = g.y; out9[8] = g.z;
+}
+
 // ---- image textures (shm/texture.h) ----
 static TextureEvalContext make_tex_ctx(const float* c18) {
     TextureEvalContext c;

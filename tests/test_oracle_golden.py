@@ -254,6 +254,24 @@ def test_transform_reference_known_answers(orc):
     assert apply(P, False, C_, (1, 1, 1)) == (2.0, 3.0, 4.0) and apply(P, True, C_, (2, 3, 4)) == (1.0, 1.0, 1.0)
 
 
+def test_vecmath_reference_known_answers(orc):
+    """vecmath/vector.rs:1601-1755 and vecmath/normal.rs:903-996, transcribed: lengths, normalize, dot, cross, gram_schmidt and —
+    through this repository's own asin — angle_between == 0.18623877 exactly."""
+    out = (C.c_float * 9)()
+    orc.orc_fn_vecmath(fa(5, 6, 7), fa(1, 0, 0), out)
+    assert out[0] == f32(10.488089) and out[1] == 110.0
+    orc.orc_fn_vecmath(fa(0, 10, 0), fa(1, 0, 0), out)
+    assert tuple(out[3:6]) == (0.0, 1.0, 0.0)
+    orc.orc_fn_vecmath(fa(1, 2, 3), fa(3, 4, 5), out)
+    assert out[2] == f32(0.18623877)
+    assert orc.orc_fn_dot(fa(0, 1, 2), fa(3, 4, 5)) == 14.0 and orc.orc_fn_dot(fa(0, 1, 2), fa(-3, -4, -5)) == -14.0
+    c = (C.c_float * 3)()
+    orc.orc_fn_cross(fa(3, -3, 1), fa(4, 9, 2), c)
+    assert tuple(c[:]) == (-15.0, -2.0, 39.0)
+    orc.orc_fn_vecmath(fa(1, -1, 1), fa(1, 0, 1), out)  # gram_schmidt(v2, normalize(v1)): approx_eq in the reference
+    assert np.allclose(out[6:9], (1 / 3, 2 / 3, 1 / 3), rtol=0, atol=2e-7)
+
+
 def test_next_float(orc, golden):
     """float.rs:172-211."""
     assert orc.orc_fn_next_float_up(-0.0) > 0.0
