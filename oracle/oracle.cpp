@@ -22,7 +22,8 @@
 // (one ulp of difference flips Russian-roulette / hit decisions and would void a per-pixel tolerance).
 // Those headers are pinned independently: tests/test_oracle_golden.py checks them against the reference's
 // in-source known answers (aggregate.rs:575-702, shape/shape.rs:299-342, bxdf.rs:1839-1903, float.rs:172-211,
-// sampling.rs:801-836, interval.rs:534-554, square_matrix.rs:623-650, transform.rs:916-943, spectra/spectrum.rs:655-785) and
+// sampling.rs:801-836, interval.rs:534-554, square_matrix.rs:623-650, transform.rs:801-943, spectra/spectrum.rs:655-785,
+// vecmath/vector.rs:1601-1755, vecmath/normal.rs:903-996, bounding_box.rs:1038-1046, math.rs:549-570) and
 // against float32 numpy re-evaluations of the cited formulas
 // (tests/golden/gen_golden.py).  The reference itself cannot be built here (Rust nightly + crates.io;
 // no toolchain, no network), so there is no oracle/_ref.
@@ -871,6 +872,9 @@ void orc_fn_vecmath(const float* a, const float* b, float* out9) {
     V3 g = gram_schmidt(vb, n);
     out9[6] = g.x; out9[7] = g.y; out9[8] = g.z;
 }
+
+// Light::preprocess: the radius of Bounds3::bounding_sphere of the scene bounds (bounding_box.rs:460-468), as flatten.h computes it
+float orc_fn_scene_radius(OrcScene* s) { return reinterpret_cast<Oracle*>(s)->flat.scene_radius; }
 
 // ---- image textures (shm/texture.h) ----
 static TextureEvalContext make_tex_ctx(const float* c18) {

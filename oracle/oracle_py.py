@@ -96,6 +96,7 @@ def load():
     lib.orc_fn_spectrum_texture_evaluate.argtypes = [C.c_void_p, C.POINTER(abi.ShmSpectrum), FP, FP, FP]
     lib.orc_fn_transform_apply.restype, lib.orc_fn_transform_apply.argtypes = None, [C.c_int, C.c_int, FP, FP, FP, FP]
     lib.orc_fn_vecmath.restype, lib.orc_fn_vecmath.argtypes = None, [FP, FP, FP]
+    lib.orc_fn_scene_radius.restype, lib.orc_fn_scene_radius.argtypes = F, [C.c_void_p]
     lib.orc_fn_rotate_from_to.restype, lib.orc_fn_rotate_from_to.argtypes = None, [FP, FP, FP, FP]
     lib.orc_fn_blp_intersect.restype, lib.orc_fn_blp_intersect.argtypes = C.c_int, [FP, FP, FP, F, FP]
     lib.orc_fn_blp_interaction.restype, lib.orc_fn_blp_interaction.argtypes = None, [FP, C.c_int, F, F, FP, FP]

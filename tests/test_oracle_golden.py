@@ -272,6 +272,22 @@ def test_vecmath_reference_known_answers(orc):
     assert np.allclose(out[6:9], (1 / 3, 2 / 3, 1 / 3), rtol=0, atol=2e-7)
 
 
+def test_bounding_sphere_reference_known_answer(lib):
+    """bounding_box.rs:1038-1046 (bounds3_bounding_sphere): the sphere around [-4,-4,-10] .. [4,4,10] has radius 11.489125 — what
+    infinite lights take as the scene radius (light.rs:799-803, 906-910)."""
+    b = scn.SceneBuilder()
+    b.set_film(8, 8)
+    b.set_camera_look_at(lib, (0, 0, 30), (0, 0, 0), (0, 1, 0), 40.0)
+    m = b.material_diffuse(0.5)
+    b.add_mesh(np.array([(-4, -4, -10), (4, 4, 10), (4, -4, 10)], np.float32), [[0, 1, 2]], m)
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    try:
+        assert o.lib.orc_fn_scene_radius(o.handle) == f32(11.489125)
+    finally:
+        o.close()
+
+
 def test_next_float(orc, golden):
     """float.rs:172-211."""
     assert orc.orc_fn_next_float_up(-0.0) > 0.0
