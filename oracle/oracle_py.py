@@ -27,9 +27,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    import os
+    path = os.environ.get("ORACLE_LIB") or str(LIB_PATH)  # tests/test_sanitizers.py points this at the ASan / UBSan build
+    if not os.path.exists(path):
         subprocess.check_call(["make", "-C", str(ROOT)])
-    lib = C.CDLL(str(LIB_PATH))
+    lib = C.CDLL(path)
     lib.orc_last_error.restype = C.c_char_p
     lib.orc_scene_create.argtypes = [C.POINTER(abi.ShmSceneDesc), C.POINTER(C.c_void_p)]
     lib.orc_scene_destroy.argtypes = [C.c_void_p]

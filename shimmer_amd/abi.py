@@ -238,7 +238,10 @@ def load_library(path=None):
         raise ShimmerHipError(f"{p} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). There is no CPU fallback for the render path.")
     lib = C.CDLL(str(p), mode=getattr(os, "RTLD_NOW", 2))
+    host_only = os.environ.get("SHM_HOST_ONLY") == "1"  # tests/test_sanitizers.py: the host mirror linked on its own (no device entry points)
     for name, (res, args) in EXPORTS.items():
+        if host_only and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
