@@ -120,7 +120,8 @@ typedef struct ShmPrimitive {
     uint32_t shape_kind;   /* SHM_SHAPE_* */
     uint32_t shape_index;  /* triangle: global triangle index (mesh base + tri_index); sphere: index;
                               bilinear patch: global patch index (patch-mesh base + blp_index) */
-    uint32_t material;     /* index into materials */
+    uint32_t material;     /* index into materials. 0xffffffff (the reference's `material: None`, a medium interface that li() skips with
+                              skip_intersection, interaction.rs:410-427) is rejected with SHM_ERR_UNSUPPORTED: media are todo!() there */
     int32_t area_light;    /* index into lights, or -1 */
 } ShmPrimitive;
 
@@ -458,7 +459,9 @@ SHM_API void shm_scene_destroy(ShmScene* scene);
 /* Film accumulation buffer resident in HBM, pixel_bounds-sized, zero-initialised. */
 SHM_API int shm_film_clear(ShmScene* scene);
 /* Render one spp-wave [sample_begin, sample_end) (integrator.rs:257-260) of the given tiles into the
- * device film (+=).  Blocking.  stats may be NULL. */
+ * device film (+=).  Blocking.  stats may be NULL.  The tiles of one call must be pairwise disjoint and inside pixel_bounds
+ * (Tile::tile's exclusive ownership, which the reference's unsynchronised film writes rely on, integrator.rs:277-295):
+ * overlapping tiles return SHM_ERR_INVALID_ARGUMENT. */
 SHM_API int shm_render_wave(ShmScene* scene, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles,
                     int32_t sample_begin, int32_t sample_end, ShmStats* stats);
 /* Copy the device film to a caller-allocated pixel_bounds-sized row-major array. */

@@ -268,6 +268,10 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         const ShmPrimitive& pr = d->primitives[s];
         shm::PrimRec rec;
         memset(&rec, 0, sizeof(rec));
+        // GeometricPrimitive::material == None marks an interface between media: get_bsdf returns None and li() continues the ray with
+        // skip_intersection (interaction.rs:199-202, 410-427; integrator.rs:816-822). Media are todo!() in the reference, so no scene
+        // reaches that branch there; here the index is plain and the all-ones value is named and rejected rather than misread.
+        if (pr.material == 0xffffffffu) { err = "primitive without a material (medium interface, skip_intersection) is not supported"; return SHM_ERR_UNSUPPORTED; }
         if (pr.material >= d->n_materials) { err = "primitive material out of range"; return SHM_ERR_INVALID_ARGUMENT; }
         if (pr.area_light >= (int32_t)d->n_lights) { err = "primitive area light out of range"; return SHM_ERR_INVALID_ARGUMENT; }
         if (pr.shape_kind == SHM_SHAPE_SPHERE) {

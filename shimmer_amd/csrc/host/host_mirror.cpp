@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -486,14 +488,37 @@ int ply_error(FILE* fp, const std::string& msg) {
 }
 }  // namespace
 
+static int ply_read_impl(FILE* fp, ShmPlyMesh* out, bool& fp_closed);
+
 int shm_ply_read(const char* filename, ShmPlyMesh* out) {
     if (!filename || !out) return SHM_ERR_INVALID_ARGUMENT;
     memset(out, 0, sizeof(*out));
     FILE* fp = fopen(filename, "rb");
     if (!fp) return ply_error(nullptr, "Unable to read PLY file");  // mesh.rs:200
+    // the element counts come from an untrusted header: nothing may unwind across the ABI
+    bool fp_closed = false;
+    try {
+        return ply_read_impl(fp, out, fp_closed);
+    } catch (const std::bad_alloc&) {
+        if (!fp_closed) fclose(fp);
+        shm_ply_free(out);
+        shm_set_last_error("PLY: out of memory");
+        return SHM_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception& e) {
+        if (!fp_closed) fclose(fp);
+        shm_ply_free(out);
+        shm_set_last_error((std::string("PLY: ") + e.what()).c_str());
+        return SHM_ERR_INVALID_ARGUMENT;
+    }
+}
+
+// ply_error closes the file on every error return; fp_closed tells the wrapper whether an exception found it open
+static int ply_read_impl(FILE* fp, ShmPlyMesh* out, bool& fp_closed) {
+    long file_size = 0;
+    if (fseek(fp, 0, SEEK_END) == 0) { file_size = ftell(fp); fseek(fp, 0, SEEK_SET); }
     // header
     char line[1024];
-    if (!fgets(line, sizeof line, fp) || strncmp(line, "ply", 3) != 0) return ply_error(fp, "not a PLY file");
+    if (!fgets(line, sizeof line, fp) || strncmp(line, "ply", 3) != 0) return fp_closed = true, ply_error(fp, "not a PLY file");
     int format = -1;
     std::vector<PlyElem> elems;
     bool ended = false;
@@ -513,30 +538,34 @@ int shm_ply_read(const char* filename, ShmPlyMesh* out) {
             PlyProp p{};
             if (std::string(b) == "list" && n >= 5) { p.is_list = true; p.count_type = ply_type(c); p.type = ply_type(d); p.name = e; }
             else if (n >= 3) { p.is_list = false; p.count_type = 0; p.type = ply_type(b); p.name = c; }
-            if (p.type < 0 || p.count_type < 0) return ply_error(fp, "PLY header: unknown property type");
+            if (p.type < 0 || p.count_type < 0) return fp_closed = true, ply_error(fp, "PLY header: unknown property type");
             elems.back().props.push_back(p);
         } else {
-            return ply_error(fp, "PLY header: unexpected line");
+            return fp_closed = true, ply_error(fp, "PLY header: unexpected line");
         }
     }
-    if (!ended || format < 0) return ply_error(fp, "PLY header: missing format or end_header");
+    if (!ended || format < 0) return fp_closed = true, ply_error(fp, "PLY header: missing format or end_header");
     PlyReader rd{fp, format};
     std::vector<float> p, nn, uv;
     std::vector<int32_t> tri, quad, face;
     for (const PlyElem& el : elems) {
+        // an element record takes at least one byte per property (ascii: a digit; binary: >= 1 byte): a count the file cannot hold is
+        // a corrupt or hostile header, rejected before anything is sized from it
+        if (el.count > (size_t)std::max(file_size, 0L) || el.count * std::max<size_t>(el.props.size(), 1) > (size_t)std::max(file_size, 0L) || el.count > 0x7fffffffull / 4)
+            return fp_closed = true, ply_error(fp, "PLY header: element count exceeds what the file can hold");
         if (el.name == "vertex") {
             p.assign(3 * el.count, 0.0f); nn.assign(3 * el.count, 0.0f); uv.assign(2 * el.count, 0.0f);  // PlyVertex::new, mesh.rs:303-314
             for (size_t i = 0; i < el.count; ++i)
                 for (const PlyProp& pr : el.props) {
                     // mesh.rs:316-333: every vertex property must be one of these names AND a Float
-                    if (pr.is_list || pr.type != 6) return ply_error(fp, "Vertex: Unexpected key/value combination: key: " + pr.name);
+                    if (pr.is_list || pr.type != 6) return fp_closed = true, ply_error(fp, "Vertex: Unexpected key/value combination: key: " + pr.name);
                     float v = (float)rd.read(pr.type);
                     const std::string& k = pr.name;
                     if (k == "x") p[3 * i] = v; else if (k == "y") p[3 * i + 1] = v; else if (k == "z") p[3 * i + 2] = v;
                     else if (k == "nx") nn[3 * i] = v; else if (k == "ny") nn[3 * i + 1] = v; else if (k == "nz") nn[3 * i + 2] = v;
                     else if (k == "u" || k == "s" || k == "texture_u" || k == "texture_s") uv[2 * i] = v;
                     else if (k == "v" || k == "t" || k == "texture_v" || k == "texture_t") uv[2 * i + 1] = v;
-                    else return ply_error(fp, "Vertex: Unexpected key/value combination: key: " + k);
+                    else return fp_closed = true, ply_error(fp, "Vertex: Unexpected key/value combination: key: " + k);
                 }
         } else if (el.name == "face") {
             for (size_t i = 0; i < el.count; ++i) {
@@ -545,26 +574,27 @@ int shm_ply_read(const char* filename, ShmPlyMesh* out) {
                     const std::string& k = pr.name;
                     const bool known = k == "vertex_indices" || k == "vertex_index" || k == "face_indices";
                     // mesh.rs:349-356: only ListInt payloads are accepted (ply-rs: a list of `int` / `int32`)
-                    if (!known || !pr.is_list || pr.type != 4) return ply_error(fp, "Face: Unexpected key/value combination: key: " + k);
+                    if (!known || !pr.is_list || pr.type != 4) return fp_closed = true, ply_error(fp, "Face: Unexpected key/value combination: key: " + k);
                     const long cnt = (long)rd.read(pr.count_type);
-                    if (rd.fail || cnt < 0 || cnt > 1024) return ply_error(fp, "PLY: bad list length");
+                    if (rd.fail || cnt < 0 || cnt > 1024) return fp_closed = true, ply_error(fp, "PLY: bad list length");
                     std::vector<int32_t>& dst = (k == "face_indices") ? fi : vi;
                     dst.resize((size_t)cnt);
                     for (long q = 0; q < cnt; ++q) dst[(size_t)q] = (int32_t)rd.read(pr.type);
                 }
                 // mesh.rs:249-276
-                if (!((fi.size() > 0 && vi.size() == 0) || (fi.size() == 0 && vi.size() > 0))) return ply_error(fp, "PLY face: expected either vertex indices or face indices");
+                if (!((fi.size() > 0 && vi.size() == 0) || (fi.size() == 0 && vi.size() > 0))) return fp_closed = true, ply_error(fp, "PLY face: expected either vertex indices or face indices");
                 if (vi.size() == 3) { tri.insert(tri.end(), vi.begin(), vi.end()); }
                 else if (vi.size() == 4) { quad.push_back(vi[0]); quad.push_back(vi[1]); quad.push_back(vi[3]); quad.push_back(vi[2]); }
-                else if (fi.empty()) return ply_error(fp, "Only tris and quads are supported");
+                else if (fi.empty()) return fp_closed = true, ply_error(fp, "Only tris and quads are supported");
                 if (!fi.empty()) face.push_back(fi[0]);
             }
         } else {
-            return ply_error(fp, "Unexpected element: " + el.name);  // mesh.rs:222
+            return fp_closed = true, ply_error(fp, "Unexpected element: " + el.name);  // mesh.rs:222
         }
-        if (rd.fail) return ply_error(fp, "PLY: unexpected end of file");
+        if (rd.fail) return fp_closed = true, ply_error(fp, "PLY: unexpected end of file");
     }
     fclose(fp);
+    fp_closed = true;
     const int32_t nv = (int32_t)(p.size() / 3);
     for (int32_t idx : tri) if (idx < 0 || idx >= nv) return ply_error(nullptr, "PLY: triangle vertex index out of range");   // mesh.rs:278-282
     for (int32_t idx : quad) if (idx < 0 || idx >= nv) return ply_error(nullptr, "PLY: quad vertex index out of range");      // mesh.rs:283-287

@@ -66,7 +66,9 @@ public:
                             uint8_t integrator = SHM_INTEGRATOR_PATH)
         : params_(parameters), integrator_(integrator) {
         if (parameters.light_sampler != "uniform") throw IntegratorError("Unknown light sampler " + parameters.light_sampler);
-        check(shm_scene_create(&scene, device, &scene_), "shm_scene_create");
+        ShmScene* created = nullptr;
+        check(shm_scene_create(&scene, device, &created), "shm_scene_create");
+        scene_.reset(created);  // owned from here on: a later throw in this constructor still releases the device copies
         const int32_t* pb = scene.film.pixel_bounds;
         width_ = pb[2] - pb[0];
         height_ = pb[3] - pb[1];
@@ -77,9 +79,7 @@ public:
         tiles_.resize(n);
         film_.assign((size_t)width_ * (size_t)height_, ShmFilmPixel{});
     }
-    ~WavefrontPathIntegrator() override {
-        if (scene_) shm_scene_destroy(scene_);
-    }
+    ~WavefrontPathIntegrator() override = default;
     WavefrontPathIntegrator(const WavefrontPathIntegrator&) = delete;
     WavefrontPathIntegrator& operator=(const WavefrontPathIntegrator&) = delete;
 
@@ -100,18 +100,18 @@ public:
         rp.disable_pixel_jitter = options.disable_pixel_jitter ? 1 : 0;
         rp.disable_wavelength_jitter = options.disable_wavelength_jitter ? 1 : 0;
         stats_ = ShmStats{};
-        check(shm_film_clear(scene_), "shm_film_clear");
+        check(shm_film_clear(scene_.get()), "shm_film_clear");
         const int32_t spp = params_.samples_per_pixel;
         int32_t wave_start = 0, wave_end = 1, next_wave_size = 1;
         waves_ = 0;
         while (wave_start < spp) {
-            check(shm_render_wave(scene_, &rp, tiles_.data(), (uint32_t)tiles_.size(), wave_start, wave_end, &stats_), "shm_render_wave");
+            check(shm_render_wave(scene_.get(), &rp, tiles_.data(), (uint32_t)tiles_.size(), wave_start, wave_end, &stats_), "shm_render_wave");
             ++waves_;
             wave_start = wave_end;
             wave_end = std::min(spp, wave_end + next_wave_size);
             next_wave_size = std::min(2 * next_wave_size, 64);
         }
-        check(shm_film_read(scene_, film_.data()), "shm_film_read");
+        check(shm_film_read(scene_.get(), film_.data()), "shm_film_read");
     }
 
     const std::vector<ShmFilmPixel>& film() const { return film_; }  // RgbFilm pixels {rgb_sum, weight_sum}, row-major
@@ -129,7 +129,8 @@ private:
     }
     PathIntegratorParameters params_;
     uint8_t integrator_ = SHM_INTEGRATOR_PATH;
-    ShmScene* scene_ = nullptr;
+    struct SceneDeleter { void operator()(ShmScene* s) const { shm_scene_destroy(s); } };
+    std::unique_ptr<ShmScene, SceneDeleter> scene_;
     std::vector<ShmTile> tiles_;
     std::vector<ShmFilmPixel> film_;
     ShmStats stats_{};

@@ -42,6 +42,17 @@ thread_local std::string g_err;
         }                                                                                        \
     } while (0)
 
+// every kernel launch is followed by LAUNCH_TRY: a failed launch (bad configuration, missing code object) is reported by the call that
+// made it, not by the stream synchronisation at the end
+#define LAUNCH_TRY(what)                                                                         \
+    do {                                                                                         \
+        hipError_t _e = hipGetLastError();                                                       \
+        if (_e != hipSuccess) {                                                                  \
+            g_err = std::string("launch of ") + (what) + ": " + hipGetErrorString(_e);           \
+            return SHM_ERR_DEVICE;                                                               \
+        }                                                                                        \
+    } while (0)
+
 static bool dbg_on() { static int v = -1; if (v < 0) v = getenv("SHM_DEBUG") ? 1 : 0; return v == 1; }
 #define DBG(...) do { if (dbg_on()) { fprintf(stderr, "[shm] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
 
@@ -1110,6 +1121,7 @@ struct ShmScene {
     ShmTile* d_tiles = nullptr;
     uint32_t* d_tile_offset = nullptr;
     size_t tiles_capacity = 0;
+    std::vector<uint64_t> tile_bitmap;  // host scratch of the disjointness check in shm_render_wave
     int n_cu = 256;
     // tuned traversal (k_trace3)
     int trace3_blocks = 0;
@@ -1210,7 +1222,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths) {
 }
 
 template <bool ANY>
-void launch_trace(ShmScene* s, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, const ShmRay* rays,
+int launch_trace(ShmScene* s, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, const ShmRay* rays,
                   ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib) {
     uint32_t* heads = s->d_heads3 + (ANY ? 8 * 32 : 0);
     uint32_t* spill = ANY ? s->d_spill3_any : s->d_spill3;
@@ -1222,15 +1234,18 @@ void launch_trace(ShmScene* s, hipStream_t stream, const uint32_t* queue, const 
     else
         hipLaunchKernelGGL((k_trace3<ANY, true>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,
                            hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels, s->refill_min, leaf_min, s->queue_parts);
+    LAUNCH_TRY(ANY ? "k_trace3<any>" : "k_trace3<closest>");
+    return SHM_OK;
 }
 
 struct EventPool {
     ShmScene* s;
     size_t used = 0;
+    bool failed = false;  // hipEventCreate failed: checked once per render (events are only used for timing / stream ordering)
     hipEvent_t get() {
         if (used == s->events.size()) {
-            hipEvent_t e;
-            hipEventCreate(&e);
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) { failed = true; return nullptr; }
             s->events.push_back(e);
         }
         return s->events[used++];
@@ -1257,6 +1272,9 @@ void shm_scene_destroy(ShmScene* s) {
     for (void* p : s->allocs) hipFree(p);
     for (void* p : s->ws_allocs) hipFree(p);
     if (s->d_rw) hipFree(s->d_rw);
+    if (s->d_tiles) hipFree(s->d_tiles);
+    if (s->d_tile_offset) hipFree(s->d_tile_offset);
+    if (s->d_pixels) hipFree(s->d_pixels);
     for (hipEvent_t e : s->events) hipEventDestroy(e);
     if (s->stream2) hipStreamDestroy(s->stream2);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -1400,13 +1418,39 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         n_pixels += (uint64_t)(tl.x1 - tl.x0) * (uint64_t)(tl.y1 - tl.y0);
     }
     if (n_pixels > 0xffffffffull) { g_err = "too many pixels"; return SHM_ERR_INVALID_ARGUMENT; }
+    // Tiles must be disjoint: the film update is one unsynchronised read-modify-write per pixel, as in the reference
+    // (integrator.rs:277-295 relies on Tile::tile's exclusive ownership). One bit per film pixel, one masked word per tile row.
+    {
+        const uint32_t fw = (uint32_t)(pb[2] - pb[0]);
+        const size_t words_per_row = (fw + 63u) / 64u;
+        s->tile_bitmap.assign(words_per_row * (size_t)(pb[3] - pb[1]), 0ull);
+        for (uint32_t t = 0; t < n_tiles; ++t) {
+            const ShmTile& tl = tiles[t];
+            const uint32_t x0 = (uint32_t)(tl.x0 - pb[0]), x1 = (uint32_t)(tl.x1 - pb[0]);
+            for (int y = tl.y0; y < tl.y1; ++y) {
+                uint64_t* row = s->tile_bitmap.data() + (size_t)(y - pb[1]) * words_per_row;
+                for (uint32_t w0 = x0 / 64u; w0 * 64u < x1; ++w0) {
+                    const uint32_t lo = std::max(x0, w0 * 64u) - w0 * 64u, hi = std::min(x1, w0 * 64u + 64u) - w0 * 64u;  // bits [lo, hi)
+                    const uint64_t mask = (hi - lo == 64u ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+                    if (row[w0] & mask) { g_err = "tiles overlap (each pixel must belong to at most one tile of a call)"; return SHM_ERR_INVALID_ARGUMENT; }
+                    row[w0] |= mask;
+                }
+            }
+        }
+    }
+    // the tile / pixel lists are regrown on demand; the superseded buffers are released (the stream is idle between calls)
     if (s->tiles_capacity < n_tiles) {
-        if ((rc = dev_alloc<ShmTile>(s, n_tiles, &s->d_tiles)) != SHM_OK) return rc;
-        if ((rc = dev_alloc<uint32_t>(s, n_tiles, &s->d_tile_offset)) != SHM_OK) return rc;
+        if (s->d_tiles) hipFree(s->d_tiles);
+        if (s->d_tile_offset) hipFree(s->d_tile_offset);
+        s->d_tiles = nullptr; s->d_tile_offset = nullptr; s->tiles_capacity = 0;
+        if (hipMalloc((void**)&s->d_tiles, (size_t)n_tiles * sizeof(ShmTile)) != hipSuccess ||
+            hipMalloc((void**)&s->d_tile_offset, (size_t)n_tiles * sizeof(uint32_t)) != hipSuccess) { g_err = "hipMalloc of the tile list failed"; return SHM_ERR_OUT_OF_MEMORY; }
         s->tiles_capacity = n_tiles;
     }
     if (s->pixels_capacity < n_pixels) {
-        if ((rc = dev_alloc<uint32_t>(s, n_pixels, &s->d_pixels)) != SHM_OK) return rc;
+        if (s->d_pixels) hipFree(s->d_pixels);
+        s->d_pixels = nullptr; s->pixels_capacity = 0;
+        if (hipMalloc((void**)&s->d_pixels, (size_t)n_pixels * sizeof(uint32_t)) != hipSuccess) { g_err = "hipMalloc of the pixel list failed"; return SHM_ERR_OUT_OF_MEMORY; }
         s->pixels_capacity = n_pixels;
     }
     HIP_TRY(hipMemcpyAsync(s->d_tiles, tiles, n_tiles * sizeof(ShmTile), hipMemcpyHostToDevice, s->stream));
@@ -1418,8 +1462,15 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     const bool random_walk = params->integrator == SHM_INTEGRATOR_RANDOM_WALK;
     // (the random walk keeps 32 B per depth per path beside the path state: its batches are capped at 16 Mi paths)
     if ((rc = ensure_workspace(s, random_walk ? std::min<uint64_t>(n_pixels * (uint64_t)n_samples, 1ull << 24) : n_pixels * (uint64_t)n_samples)) != SHM_OK) return rc;
-    const uint32_t cap_eff = random_walk ? std::min<uint32_t>(s->capacity, 1u << 24) : s->capacity;  // paths per batch
+    uint32_t cap_eff = random_walk ? std::min<uint32_t>(s->capacity, 1u << 24) : s->capacity;  // paths per batch
     if (random_walk) {
+        // 32 B per depth per path (up to 8 KB per path at max_depth 254): shrink the batch until the records fit in 80 % of what is free
+        const size_t per_path = (size_t)2 * (size_t)(params->max_depth + 1) * sizeof(float4);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t avail = (size_t)((double)(free_b + s->rw_floats4 * sizeof(float4)) * 0.8);
+            while (cap_eff > 4096u && (size_t)cap_eff * per_path > avail) cap_eff = (cap_eff / 2u + 63u) & ~63u;
+        }
         size_t need = (size_t)2 * (size_t)(params->max_depth + 1) * (size_t)cap_eff;
         if (s->rw_floats4 < need) {
             if (s->d_rw) hipFree(s->d_rw);
@@ -1444,6 +1495,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         const uint32_t* pixels = s->d_pixels + p0;
         hipLaunchKernelGGL(k_generate, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
                            sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs, s->pix_group);
+        LAUNCH_TRY("k_generate");
         int cur = 0;
         // Small batches are tail-dominated (the last rays of a persistent traversal launch take ~0.5 ms whatever its size): there
         // K3 of bounce b runs on a second stream beside K2 of bounce b+1 — they are independent: K3 reads the shadow buffers and
@@ -1457,7 +1509,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
             const int sh = bounce & 1;
             hipEvent_t a = ev.get(), b = ev.get();
             hipEventRecord(a, s->stream);
-            launch_trace<false>(s, s->stream, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr);
+            if ((rc = launch_trace<false>(s, s->stream, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr)) != SHM_OK) return rc;
             hipEventRecord(b, s->stream);
             ev_closest.push_back({a, b});
             if (overlap && k3_done) hipStreamWaitEvent(s->stream, k3_done, 0);  // shade(b) touches L and refills the shadow buffers
@@ -1481,6 +1533,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 else if (s->flat.has_layered) { if (tri_only) launch_shade(k_shade<true, true>); else launch_shade(k_shade<true, false>); }
                 else if (tri_only && s->flat.diffuse_only && !getenv("SHM_NO_DIFFUSE_ONLY")) launch_shade(k_shade<false, true, false, true>);
                 else { if (tri_only) launch_shade(k_shade<false, true>); else launch_shade(k_shade<false, false>); }
+                LAUNCH_TRY("k_shade");
                 hipEventRecord(s1, s->stream);
                 ev_shade.push_back({s0, s1});
             }
@@ -1492,7 +1545,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     hipStreamWaitEvent(any_stream, shaded, 0);
                 }
                 hipEventRecord(c, any_stream);
-                launch_trace<true>(s, any_stream, s->d_q_shadow, &s->d_qs->n_shadow[sh], 0, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib);
+                if ((rc = launch_trace<true>(s, any_stream, s->d_q_shadow, &s->d_qs->n_shadow[sh], 0, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib)) != SHM_OK) return rc;
                 hipEventRecord(d, any_stream);
                 ev_any.push_back({c, d});
                 k3_done = d;
@@ -1512,6 +1565,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
             hipLaunchKernelGGL(k_fold_randomwalk, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->pa, s->d_rw, cap_eff, total);
         hipLaunchKernelGGL(k_film, dim3((n_pix + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix, n_samples,
                            s->d_film, s->d_counters, s->pix_group);
+        LAUNCH_TRY("k_film");
+        if (ev.failed) { g_err = "hipEventCreate failed"; return SHM_ERR_DEVICE; }
     }
     HIP_TRY(hipEventRecord(e_end, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1609,8 +1664,9 @@ static int trace_device_impl(ShmScene* s, bool any, const void* rays_dev, uint32
     for (int r = 0; r < repeat; ++r) {
         hipEvent_t a = ev.get(), b = ev.get();
         hipEventRecord(a, s->stream);
-        if (any) launch_trace<true>(s, s->stream, nullptr, nullptr, n, (const ShmRay*)rays_dev, nullptr, (uint8_t*)out_dev, nullptr, nullptr);
-        else launch_trace<false>(s, s->stream, nullptr, nullptr, n, (const ShmRay*)rays_dev, (ShmHit*)out_dev, nullptr, nullptr, nullptr);
+        int rc = any ? launch_trace<true>(s, s->stream, nullptr, nullptr, n, (const ShmRay*)rays_dev, nullptr, (uint8_t*)out_dev, nullptr, nullptr)
+                     : launch_trace<false>(s, s->stream, nullptr, nullptr, n, (const ShmRay*)rays_dev, (ShmHit*)out_dev, nullptr, nullptr, nullptr);
+        if (rc != SHM_OK) return rc;
         hipEventRecord(b, s->stream);
         evs.push_back({a, b});
     }
