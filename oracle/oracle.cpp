@@ -1058,5 +1058,98 @@ int orc_fn_image_light_distribution(OrcScene* s, uint32_t li, int which, float* 
     return n;
 }
 
+// ---- unit entry points for the leaf fixtures of tests/golden/golden_leaves.json (tests/test_leaf_golden.py) ----
+// Triangle::interaction_from_intersection (triangle.rs:305-504). p9 = p0 p1 p2; n9 / s9 / uv6 may be NULL (mesh without them).
+// out35 = pi.low[3], pi.high[3], uv[2], n[3], dpdu[3], dpdv[3], shading n[3], shading dpdu[3], shading dpdv[3], dndu[3], dndv[3],
+// shading dndu[3], shading dndv[3] (dndu/dndv of the interaction stay zero: SurfaceInteraction::new receives Normal3f::ZERO)
+void orc_fn_triangle_interaction(const float* p9, const float* n9, const float* s9, const float* uv6, int flip, const float* b3,
+                                 const float* wo, float* out) {
+    TriangleData tr;
+    memset(&tr, 0, sizeof(tr));
+    tr.p0 = ld3(p9); tr.p1 = ld3(p9 + 3); tr.p2 = ld3(p9 + 6);
+    tr.flip = flip != 0;
+    if (n9) { tr.has_n = true; tr.n0 = ld3(n9); tr.n1 = ld3(n9 + 3); tr.n2 = ld3(n9 + 6); }
+    if (s9) { tr.has_s = true; tr.s0 = ld3(s9); tr.s1 = ld3(s9 + 3); tr.s2 = ld3(s9 + 6); }
+    if (uv6) { tr.has_uv = true; tr.uv0 = v2(uv6[0], uv6[1]); tr.uv1 = v2(uv6[2], uv6[3]); tr.uv2 = v2(uv6[4], uv6[5]); }
+    TriangleIntersection ti;
+    ti.b0 = b3[0]; ti.b1 = b3[1]; ti.b2 = b3[2]; ti.t = 1.0f;
+    SurfaceInteraction si = triangle_interaction(tr, ti, ld3(wo));
+    float* o = out;
+    auto put3 = [&](V3 v) { *o++ = v.x; *o++ = v.y; *o++ = v.z; };
+    put3(v3(si.pi.x.low, si.pi.y.low, si.pi.z.low));
+    put3(v3(si.pi.x.high, si.pi.y.high, si.pi.z.high));
+    *o++ = si.uv.x; *o++ = si.uv.y;
+    put3(si.n); put3(si.dpdu); put3(si.dpdv);
+    put3(si.shading.n); put3(si.shading.dpdu); put3(si.shading.dpdv);
+    put3(si.dndu); put3(si.dndv); put3(si.shading.dndu); put3(si.shading.dndv);
+}
+// Sphere::sample_with_context / pdf_with_context (sphere.rs:339-457). out7 = p[3] (interval midpoint), n[3], pdf
+int orc_fn_sphere_sample_with_context(const ShmSphere* sp, const float* ctx_p, const float* ctx_n, const float* ctx_ns, const float* u, float* out7) {
+    ShapeSampleContext c;
+    c.pi = p3i_exact(ld3(ctx_p)); c.n = ld3(ctx_n); c.ns = ld3(ctx_ns);
+    ShapeSample ss;
+    if (!sphere_sample_with_context(*sp, c, v2(u[0], u[1]), ss)) return 0;
+    V3 p = ss.pi.mid();
+    out7[0] = p.x; out7[1] = p.y; out7[2] = p.z; out7[3] = ss.n.x; out7[4] = ss.n.y; out7[5] = ss.n.z; out7[6] = ss.pdf;
+    return 1;
+}
+float orc_fn_sphere_pdf_with_context(const ShmSphere* sp, const float* ctx_p, const float* ctx_n, const float* ctx_ns, const float* wi) {
+    ShapeSampleContext c;
+    c.pi = p3i_exact(ld3(ctx_p)); c.n = ld3(ctx_n); c.ns = ld3(ctx_ns);
+    return sphere_pdf_with_context(*sp, c, ld3(wi));
+}
+// DiffuseAreaLight::l (light.rs:668-684) with a DenselySampledSpectrum l_emit given as a table from lambda_min in 1-nm steps
+void orc_fn_area_light_l(int two_sided, float scale, const float* table, int n_table, int lambda_min, const float* n, const float* w,
+                         const float* lambda4, float* out4) {
+    SceneView sv;
+    memset(&sv, 0, sizeof(sv));
+    sv.spectrum_data = table;
+    ShmLight light;
+    memset(&light, 0, sizeof(light));
+    light.kind = SHM_LIGHT_DIFFUSE_AREA;
+    light.two_sided = two_sided ? 1u : 0u;
+    light.scale = scale;
+    light.spectrum.kind = SHM_SPECTRUM_DENSE;
+    light.spectrum.offset = 0; light.spectrum.n = (uint32_t)n_table; light.spectrum.lambda_min = lambda_min;
+    Wavelengths wl;
+    for (int i = 0; i < 4; ++i) { wl.lambda[i] = lambda4[i]; wl.pdf[i] = 1.0f; }
+    Spec r = area_light_l(sv, light, ld3(n), ld3(w), wl);
+    for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
+}
+// Light::pdf_li of light `li` of a scene (DiffuseAreaLight::pdf_li = shape.pdf_with_context, light.rs:663-666)
+float orc_fn_light_pdf_li(OrcScene* s, uint32_t li, const float* ctx_p, const float* ctx_n, const float* ctx_ns, const float* wi) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    LightSampleContext ctx;
+    ctx.pi = p3i_exact(ld3(ctx_p)); ctx.n = ld3(ctx_n); ctx.ns = ld3(ctx_ns);
+    return light_pdf_li<false, true>(o->sv, o->sv.lights[li], ctx, ld3(wi));
+}
+// PixelSensor::to_sensor_rgb + RgbFilm::add_sample (film.rs:548-574, 907-914) on one pixel {rgb_sum[3], weight_sum} (doubles), with the
+// sensor given as three 360..=830 nm tables
+void orc_fn_film_add_sample(const float* r_bar, const float* g_bar, const float* b_bar, float imaging_ratio, float max_component_value,
+                            const float* L4, const float* lambda4, const float* pdf4, float weight, double* pixel4, float* rgb_out3) {
+    SceneView sv;
+    memset(&sv, 0, sizeof(sv));
+    sv.sensor_r_bar = r_bar; sv.sensor_g_bar = g_bar; sv.sensor_b_bar = b_bar;
+    sv.imaging_ratio = imaging_ratio; sv.max_component_value = max_component_value;
+    Spec L;
+    Wavelengths w;
+    for (int i = 0; i < 4; ++i) { L.v[i] = L4[i]; w.lambda[i] = lambda4[i]; w.pdf[i] = pdf4[i]; }
+    V3 rgb = film_sample_rgb(sv, L, w);
+    if (rgb_out3) { rgb_out3[0] = rgb.x; rgb_out3[1] = rgb.y; rgb_out3[2] = rgb.z; }
+    pixel4[0] += (double)(weight * rgb.x);
+    pixel4[1] += (double)(weight * rgb.y);
+    pixel4[2] += (double)(weight * rgb.z);
+    pixel4[3] += (double)weight;
+}
+// PerspectiveCamera::generate_ray_differential (camera.rs:1003-1079) for an explicit CameraSample. out18 = o[3], d[3], rx_o[3],
+// rx_d[3], ry_o[3], ry_d[3]
+void orc_fn_camera_ray_differential(const ShmCamera* cam, const float* p_film, const float* p_lens, float* out18) {
+    AuxRays aux = aux_none();
+    Ray r = camera_generate_ray_differential(*cam, v2(p_film[0], p_film[1]), v2(p_lens[0], p_lens[1]), &aux);
+    float* o = out18;
+    auto put3 = [&](V3 v) { *o++ = v.x; *o++ = v.y; *o++ = v.z; };
+    put3(r.o); put3(r.d); put3(aux.rx_o); put3(aux.rx_d); put3(aux.ry_o); put3(aux.ry_d);
+}
+
 }  // extern "C"
 #pragma GCC visibility pop
