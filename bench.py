@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""bench.py — Mray/s (primary + secondary rays) of the wavefront path tracer on the BASELINE.json headline config:
-S3 "ganesha-proxy" (4 305 626 primitives, 8.52 M BVH nodes), 1024x1024, 256 spp, maxdepth 5, on N MI355X of one node.
+"""bench.py — Mray/s (primary + secondary rays) of the wavefront path tracer on the BASELINE.json configurations.
 
-A step = one whole ImageTileIntegrator::render of that frame (all spp-waves 1,1,2,...,64,64,64 over all 8x8 tiles).
-Scene arrays are resident in HBM before the timed region; tiles are sharded across ranks (no collective while
-rendering) and the film slabs are gathered to rank 0 over RCCL inside the timed region.
+  N = 1  the headline configuration (configs[2]): S3 "ganesha-proxy" (4 305 626 primitives, 8.52 M BVH nodes), 1024x1024,
+         256 spp, maxdepth 5. A step = one whole ImageTileIntegrator::render of that frame (all spp-waves over all 8x8 tiles).
+  N > 1  the scaling configuration (configs[4], "C5"): the same scene at 3840x2160, 1024 spp, tiles sharded across the N GPUs
+         inside the library (shm_render_sharded: C++ tile sharding, no collective while rendering, RCCL gather of the film rows
+         to rank 0 inside the timed region). Launched by the driver through torch.distributed.run (one process per GPU);
+         torch.distributed is the control plane only (unique-id broadcast, barrier, max-over-ranks time).
+Scene arrays are resident in HBM before the timed region. --width/--height/--spp override either default.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--spp S] [--res R] [--no-cpu-baseline]
-N > 1 is launched by the driver through torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the env).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--spp S] [--res R] [--no-cpu-baseline] [--no-side]
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -20,60 +22,60 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # MI355X_MICROARCH.md: measured-achievable copy rate
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def pmc_traffic(args):
-    """HBM traffic of the K2 kernel per launch from the committed rocprofv3 PMC passes of THIS configuration
-    (tools/profile_gpu.sh -> profiles/*.traffic.json): 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md
-    section HBM) + WRITE_SIZE, in bytes. None when no profile of this configuration is committed."""
+def pmc_profile(args):
+    """Counters of the K2 kernel per launch from the committed rocprofv3 PMC passes of THIS configuration
+    (tools/profile_gpu.sh -> profiles/traffic_*.json): HBM traffic = 2 x FETCH_SIZE (the gfx950 correction of
+    MI355X_MICROARCH.md section HBM) + WRITE_SIZE, in bytes, and (when the pass was collected) the mean number of active lanes
+    per VALU instruction. None when no profile of this configuration is committed."""
     f = ROOT / "profiles" / f"traffic_res{args.res}_spp{args.spp}_n{args.n}_depth{args.max_depth}.json"
-    if not f.exists():
-        return None
+    if not f.exists() or args.width or args.height:
+        return None, None
     t = json.loads(f.read_text()).get("k_trace3<closest>")
     if not t:
-        return None
-    return 2.0 * t.get("FETCH_SIZE_bytes_per_dispatch_raw", 0.0) + t.get("WRITE_SIZE_bytes_per_dispatch_raw", 0.0)
+        return None, None
+    traffic = 2.0 * t.get("FETCH_SIZE_bytes_per_dispatch_raw", 0.0) + t.get("WRITE_SIZE_bytes_per_dispatch_raw", 0.0)
+    return traffic, t.get("valu_lanes_active")
 
 
 def cpu_baseline(sc, params_full, host_lib, budget_s=15.0):
-    """The CPU oracle (kind "port": a C++ restatement of the reference loop, oracle/oracle.cpp) timed on this box's host
-    cores on a bounded sample of the same workload: a centred crop of the frame at a reduced spp."""
+    """The CPU oracle (kind "port": a C++ restatement of the reference loop, oracle/oracle.cpp) timed on this box's host cores on a
+    bounded UNBIASED sample of the same workload: every k-th 8x8 tile of the whole frame (row-major tile order, so object, walls
+    and floor are sampled in the frame's own proportions) at the full spp."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle_py
-    from shimmer_amd import render, scene as scn
+    from shimmer_amd import abi, render, scene as scn
 
     cores = os.cpu_count() or 1
     orc = oracle_py.Oracle(sc.desc)
-    pb = orc.pixel_bounds
-    w, h = pb[2] - pb[0], pb[3] - pb[1]
+    tiles, n_tiles = scn.tiles_for(host_lib, orc.pixel_bounds)
 
-    def crop_tiles(side):
-        cw, ch = min(w, side), min(h, side)
-        x0, y0 = pb[0] + (w - cw) // 2, pb[1] + (h - ch) // 2
-        return (cw, ch) + scn.tiles_for(host_lib, (x0, y0, x0 + cw, y0 + ch))
-
-    def run(side, spp):
-        cw, ch, tiles, n_tiles = crop_tiles(side)
+    def run(stride, spp, offset=0):
+        idx = list(range(offset, n_tiles, stride))
+        sub = (abi.ShmTile * len(idx))(*[tiles[i] for i in idx])
         p = render.make_params(seed=params_full.seed, spp=spp, max_depth=params_full.max_depth)
         t0 = time.perf_counter()
-        _, st = orc.render(p, n_threads=cores, tiles=tiles, n_tiles=n_tiles)
-        return cw, ch, st["rays_closest"] + st["rays_any"], time.perf_counter() - t0
+        _, st = orc.render(p, n_threads=cores, tiles=sub, n_tiles=len(idx))
+        return len(idx), st["rays_closest"] + st["rays_any"], time.perf_counter() - t0
 
-    # probe (1 and 5 spp on the 256^2 crop) to size the sample to ~budget_s seconds of wall time on all host cores
-    run(256, 1)  # thread start-up, page faults
-    _, _, _, t0 = run(256, 1)
-    _, _, rays1, t1 = run(256, 5)
+    # probe: 1 and 5 spp on every 61st tile (61 is coprime with the tiles per row: no column aliasing) sizes the sample to ~budget_s
+    run(61, 1)  # thread start-up, page faults
+    n_probe, _, t0 = run(61, 1)
+    _, rays1, t1 = run(61, 5)
     full = params_full.samples_per_pixel
-    want = budget_s / max((t1 - t0) / 4.0, 1e-4)  # spp the 256^2 crop could take (fixed per-call cost cancels)
-    side, spp = 256, int(max(1, min(full, want)))
-    if want > full:
-        side, spp = 512, int(max(1, min(full, want / 4.0)))
-    cw, ch, rays, dt = run(side, spp)
+    per_tile_spp = max((t1 - t0) / 4.0, 1e-5) / n_probe           # seconds per tile per spp (fixed per-call cost cancels)
+    want_tiles = budget_s / (per_tile_spp * full)
+    stride = int(max(1, min(n_tiles, round(n_tiles / max(want_tiles, 1.0)))))
+    while stride > 1 and stride % 2 == 0 and ((orc.width + 7) // 8) % 2 == 0:
+        stride += 1  # keep the stride odd when the tile row length is even: the sample walks across columns
+    n_used, rays, dt = run(stride, full)
     orc.close()
     model = ""
     try:
@@ -84,8 +86,52 @@ def cpu_baseline(sc, params_full, host_lib, budget_s=15.0):
     except OSError:
         pass
     return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/oracle.cpp, {cores} threads over 8x8 tiles, centred {cw}x{ch} crop of the same frame at {spp} spp "
-                      f"({rays} rays in {dt:.1f} s; probe {rays1} rays in {t1:.2f} s); cpu: {model}"}
+            "sample": f"oracle/oracle.cpp, {cores} threads over 8x8 tiles; every {stride}th tile of the whole frame ({n_used} of {n_tiles} tiles, "
+                      f"unbiased tile sample) at the full {full} spp ({rays} rays in {dt:.1f} s; probe {rays1} rays in {t1:.2f} s); cpu: {model}"}
+
+
+def side_results(lib, args, render, scenes, headline_scene, log):
+    """Other BASELINE.json configurations and the material the real Ganesha uses, timed on this GPU in the same run (one warm-up +
+    one timed frame each; informational, outside `value`)."""
+    import ctypes as C
+    out = {}
+
+    def timed(name, desc, spp, depth, prims):
+        r = render.Renderer(lib, desc, device=0)
+        p = render.make_params(seed=0, spp=spp, max_depth=depth)
+        r.clear()
+        r.render_device(p)
+        r.clear()
+        t0 = time.perf_counter()
+        st = r.render_device(p)
+        dt = time.perf_counter() - t0
+        r.close()
+        rays = st["rays_closest"] + st["rays_any"]
+        out[name] = {"Mray_s": rays / dt / 1e6, "ms": dt * 1e3, "rays": rays, "prims": prims, "spp": spp, "max_depth": depth,
+                     "ms_closest": st["ms_trace_closest"], "ms_any": st["ms_trace_any"], "ms_shade": st["ms_shade"]}
+        log(f"[bench] side {name}: {rays / dt / 1e6:.0f} Mray/s ({dt * 1e3:.1f} ms)")
+
+    try:
+        # S3 with the object's material switched to CoatedDiffuse in place (the reference's Ganesha render uses it): same geometry, BVH
+        b = headline_scene.builder
+        tmp = type(b)()
+        tmp.material_coated_diffuse(reflectance=0.4, roughness=0.05, thickness=0.01)
+        saved = type(tmp.materials[0])()
+        C.memmove(C.byref(saved), C.byref(headline_scene.desc.materials[0]), C.sizeof(saved))
+        C.memmove(C.byref(headline_scene.desc.materials[0]), C.byref(tmp.materials[0]), C.sizeof(saved))
+        try:
+            timed("coated_S3_1024x1024_spp64", headline_scene.desc, 64, args.max_depth, headline_scene.info["n_primitives"])
+        finally:
+            C.memmove(C.byref(headline_scene.desc.materials[0]), C.byref(saved), C.sizeof(saved))
+        sc = scenes.crown_proxy(lib, 1000, 1400)
+        timed("C4_crown_proxy_1000x1400_spp256_depth32", sc.desc, 256, 32, sc.info["n_primitives"])
+        sc = scenes.cornell_box(lib, 512, 512)
+        timed("C2_cornell_512x512_spp64", sc.desc, 64, 5, sc.info["n_primitives"])
+        sc = scenes.cornell_box(lib, 512, 512, textured=True)
+        timed("textured_cornell_512x512_spp64_depth6", sc.desc, 64, 6, sc.info["n_primitives"])
+    except Exception as e:  # reporting only
+        out["error"] = str(e)
+    return out
 
 
 def main():
@@ -93,20 +139,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--spp", type=int, default=0, help="default: 256 at N = 1 (headline), 1024 at N > 1 (C5)")
     ap.add_argument("--res", type=int, default=1024)
-    ap.add_argument("--width", type=int, default=0, help="non-square frames (e.g. the 3840x2160 of BASELINE config C5): overrides --res")
+    ap.add_argument("--width", type=int, default=0, help="non-square frames: overrides --res (default at N > 1: 3840x2160, BASELINE config C5)")
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--n", type=int, default=599, help="cube-sphere subdivision (599 -> 4 305 612 triangles)")
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the side configurations (coated S3, C4, C2, textured Cornell)")
     ap.add_argument("--coated", action="store_true", help="S3 with a CoatedDiffuse object (LayeredBxDF, SURVEY 8f-1) instead of the "
                     "headline diffuse one: a side measurement, not the BASELINE config")
     ap.add_argument("--shard-of", type=int, default=0, help="development: render only the tiles rank 0 of N would own (no gather), "
                     "to estimate the per-rank time of an N-GPU run on one GPU")
     ap.add_argument("--shard-rank", type=int, default=0, help="development: which rank's tiles --shard-of renders")
-    ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL init + film gather path even with one rank")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL communicator + shm_render_sharded path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,6 +163,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    c5 = world > 1 and not (args.width or args.height)
+    if c5:
+        args.width, args.height = 3840, 2160
+    if not args.spp:
+        args.spp = 1024 if world > 1 else 256
 
     import numpy as np
     import torch
@@ -143,9 +195,16 @@ def main():
     if rank == 0:
         log(f"[bench] scene {sc.name}: {sc.info['n_primitives']} prims, {sc.info['n_nodes']} nodes; build {t_scene:.1f}s, upload {t_upload:.2f}s")
     params = render.make_params(seed=args.seed, spp=args.spp, max_depth=args.max_depth)
-    my_tiles = None if world == 1 else render.shard_tiles(r.n_tiles, r.tiles_per_row, rank, world)
+    if use_dist:
+        # the library's own RCCL communicator: rank 0 draws the unique id, torch.distributed (control plane) carries its 128 bytes
+        uid = torch.zeros(abi.SHM_DIST_ID_BYTES, dtype=torch.uint8, device=device)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(r.dist_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        r.dist_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+    my_tiles = None
     if world == 1 and args.shard_of > 1:
-        my_tiles = render.shard_tiles(r.n_tiles, r.tiles_per_row, args.shard_rank, args.shard_of)
+        my_tiles = render.shard_tiles(r.n_tiles, r.tiles_per_row, args.shard_rank, args.shard_of, lib=lib)
 
     def barrier():
         if use_dist:
@@ -153,13 +212,10 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        r.clear()
-        st = r.render_device(params, my_tiles)
-        film = None
         if use_dist:
-            film = render.gather_film(render.film_tensor(r, device), rank, world, r.height, r.width, to_host=False)
-            torch.cuda.synchronize(device)  # the send must have read this rank's film before the next step clears it
-        return st, film
+            return r.render_sharded(params)  # clear + this rank's tiles + RCCL gather of the film rows into rank 0's device film
+        r.clear()
+        return r.render_device(params, my_tiles)
 
     for _ in range(args.warmup):
         step()
@@ -167,11 +223,12 @@ def main():
     t0 = time.perf_counter()
     acc = {}
     for _ in range(args.steps):
-        st, film = step()
+        st = step()
         for k, v in st.items():
             acc[k] = acc.get(k, 0) + v
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -180,6 +237,12 @@ def main():
         c = torch.tensor([acc[k] for k in keys], dtype=torch.float64, device=device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         tot = {k: float(v) for k, v in zip(keys, c.tolist())}
+        mine = torch.tensor([acc["ms_total"] / args.steps, acc["ms_gather"] / args.steps, acc["rays_closest"] + acc["rays_any"],
+                             acc["gather_bytes"] / args.steps], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": i, "render_ms": float(v[0]), "gather_ms": float(v[1]), "rays_per_step": float(v[2]) / args.steps,
+                     "gather_MB": float(v[3]) / 1e6} for i, v in enumerate(allr)]
     else:
         tot = {k: float(v) for k, v in acc.items()}
 
@@ -193,18 +256,29 @@ def main():
         ms = acc["ms_trace_closest"]
         achieved = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         launches = max(1, acc["launches_closest"])
+        traffic, lanes = pmc_profile(args) if world == 1 else (None, None)
+        hbm_counter = traffic / (ms / launches * 1e-3) / 1e9 if traffic and ms > 0 else None
         out = {
             "metric": "Mray/s (primary+secondary) at 1024^2 256spp Ganesha; 1/2/4/8-GPU scaling",
             "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'S3c coated ' if args.coated else 'S3 '}ganesha-proxy ({sc.info['n_primitives']} prims, {sc.info['n_nodes']} BVH nodes), "
-                                   f"{width}x{height}, {args.spp} spp, maxdepth {args.max_depth}, path integrator",
-                       "tiles": "8x8, sharded across ranks in interleaved blocks of tile rows (~8 blocks per rank)" if world > 1 else "8x8",
+                                   f"{width}x{height}, {args.spp} spp, maxdepth {args.max_depth}, path integrator"
+                                   + (" [BASELINE configs[4], the multi-GPU scaling frame]" if c5 else ""),
+                       "tiles": "8x8, sharded across ranks in interleaved blocks of tile rows (~8 blocks per rank) by shm_shard_tiles" if world > 1 else "8x8",
                        "rays_per_step": rays / args.steps, "paths_per_step": tot["paths"] / args.steps,
-                       "film_gather": "RCCL gather to rank 0 (inside the timed region)" if world > 1 else "none"},
+                       "film_gather": "RCCL ncclSend/ncclRecv of each rank's film rows into rank 0's device film, inside the library and inside the "
+                                      "timed region" if use_dist else "none"},
+            # `achieved` is the ALGORITHMIC byte rate of the kernel (what the traversal would read if every node / primitive
+            # visit came from memory), `frac` = achieved / HBM peak. The kernel's gathers are largely served by L2 / MALL, so this is NOT
+            # HBM utilisation: `hbm_counter_GBs` (PMC traffic / launch time) is, and the kernel is VALU-issue bound (`bound_note`).
             "roofline": {"bound": "hbm", "kernel": "k_trace3<closest> (BvhAggregate::intersect)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args) if world == 1 else None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS, "hbm_counter_GBs": hbm_counter,
+                         "hbm_counter_frac": (hbm_counter / HBM_PEAK_GBS) if hbm_counter else None, "lanes_active": lanes,
+                         "bound_note": "algorithmic-bytes rate; gathers are cache-served (L2/MALL), the kernel is bound by VALU issue at "
+                                       "partial lane occupancy — see hbm_counter_* for real HBM utilisation",
                          "bytes_per_launch": bytes_alg / launches, "avg_launch_ms": ms / launches, "launches": launches,
                          "nodes_per_ray": acc["nodes_closest"] / max(1, acc["rays_closest"]),
                          "prims_per_ray": acc["tris_closest"] / max(1, acc["rays_closest"]),
@@ -216,27 +290,32 @@ def main():
                                  "nodes_per_ray": acc["nodes_any"] / max(1, acc["rays_any"]), "prims_per_ray": acc["tris_any"] / max(1, acc["rays_any"]),
                                  "any_Mray_s_in_kernel": acc["rays_any"] / (acc["ms_trace_any"] * 1e-3) / 1e6 if acc["ms_trace_any"] > 0 else 0.0},
             "breakdown_ms_per_step": {"trace_closest": acc["ms_trace_closest"] / args.steps, "trace_any": acc["ms_trace_any"] / args.steps,
-                                      "shade_generate_film": acc["ms_shade"] / args.steps, "gpu_total": acc["ms_total"] / args.steps},
+                                      "shade_generate_film": acc["ms_shade"] / args.steps, "gpu_total": acc["ms_total"] / args.steps,
+                                      "film_gather": acc.get("ms_gather", 0.0) / args.steps},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(sc, params, lib)
-            except Exception as e:  # the baseline is reporting only; never let it hide the GPU number
-                out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        result_line = json.dumps(out)
-    if use_dist and rank == 0 and film is not None:
-        # the gathered film must equal what this rank's library holds when it is the only rank (self-check of the gather)
-        host = film.cpu().numpy().view(render.FILM_DTYPE).reshape(r.height, r.width)
-        if world == 1 and not np.array_equal(host, r.read_film()):
-            raise SystemExit("film gather mismatch")
-        if not (host["weight_sum"] == float(args.spp)).all():  # every pixel of the frame received all its samples, from some rank
-            raise SystemExit("gathered film is incomplete")
-    if rank == 0 and world == 1 and not args.shard_of:
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+    if use_dist and rank == 0:
+        # the gathered film: every pixel of the frame received all its samples, from some rank
+        host = r.read_film()
+        if not (host["weight_sum"] == float(args.spp)).all() or not np.isfinite(host["rgb_sum"]).all():
+            raise SystemExit("gathered film is incomplete or not finite")
+        if world == 1:
+            r.dist_selftest()  # film rows through the RCCL send / recv group, looped back to this rank
+    if rank == 0 and world == 1 and not use_dist and not args.shard_of:
         # self-check outside the timed region: every pixel received all its samples, all sums finite
         host = r.read_film()
         if not (host["weight_sum"] == float(args.spp)).all() or not np.isfinite(host["rgb_sum"]).all():
             raise SystemExit("film is incomplete or not finite")
     r.close()
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(sc, params, lib)
+            except Exception as e:  # the baseline is reporting only; never let it hide the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        if not args.no_side and not args.coated and not args.shard_of and (width, height) == (1024, 1024):
+            out["side_results"] = side_results(lib, args, render, scenes, sc, log)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -245,7 +324,7 @@ def main():
         # last thing on stdout
         import ctypes
         ctypes.CDLL(None).fflush(None)
-        print(result_line, flush=True)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

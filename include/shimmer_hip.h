@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SHM_ABI_VERSION 6
+#define SHM_ABI_VERSION 7
 
 /* The library is built with -fvisibility=hidden; only these entry points are exported. */
 #if defined(__GNUC__)
@@ -429,6 +429,9 @@ typedef struct ShmStats {
     double ms_shade;           /* K1 + K5 + K6 */
     uint32_t launches_closest;
     uint32_t launches_any;
+    /* ABI v7 (multi-GPU entry points): */
+    double ms_gather;          /* HIP-event time of the film gather on this rank's render stream (RCCL send / recv group or xGMI peer copies) */
+    uint64_t gather_bytes;     /* film bytes this rank sent (peers) or received (root) */
 } ShmStats;
 
 typedef struct ShmRay {
@@ -489,6 +492,44 @@ SHM_API int shm_trace_closest_device(ShmScene* scene, const void* rays_dev, uint
                              ShmStats* stats);
 SHM_API int shm_trace_any_device(ShmScene* scene, const void* rays_dev, uint32_t n, void* occluded_dev, int repeat,
                          ShmStats* stats);
+
+/* ---- multi-GPU (ABI v7) -------------------------------------------------------------------------------------------
+ * Pixels are independent and tile ownership is exclusive (the reference's one parallel region, integrator.rs:242-304, relies on that
+ * for its unsynchronised film writes), so the frame shards by tiles with the scene replicated per GPU and NO collective while
+ * rendering; one exchange at the end brings every rank's film rows to the root. Sharding is by blocks of whole tile rows, so a
+ * rank's pixels are full-width row ranges of the film: only those rows travel (33 MB per rank of the 265 MB film at 3840x2160 on 8
+ * GPUs), straight from one device film into the other, and no sum is needed. */
+
+/* Static interleaved sharding of the row-major tile list Tile::tile emits: blocks of `rows_per_block` tile rows, block b belongs to
+ * rank b % world. rows_per_block 0 = the default (about 8 blocks per rank: expensive image regions are spread over all ranks).
+ * idx_out (capacity n_tiles) receives this rank's tile indices in increasing order. */
+SHM_API int shm_shard_tiles(uint32_t n_tiles, uint32_t tiles_per_row, int32_t rank, int32_t world, int32_t rows_per_block,
+                            uint32_t* idx_out, uint32_t* n_out);
+
+/* One process per GPU (the layout of `torchrun` / MPI launches): an RCCL communicator per scene. The host distributes the 128-byte
+ * unique id from rank 0 to every rank by whatever control channel it has (MPI_Bcast, a TCP store, torch.distributed), then every
+ * rank calls shm_dist_init (collective: ncclCommInitRank on the scene's device). */
+#define SHM_DIST_ID_BYTES 128
+SHM_API int shm_dist_unique_id(uint8_t id_out[SHM_DIST_ID_BYTES]);
+SHM_API int shm_dist_init(ShmScene* scene, int32_t rank, int32_t world, const uint8_t id[SHM_DIST_ID_BYTES]);
+SHM_API int shm_dist_finalize(ShmScene* scene);   /* also done by shm_scene_destroy */
+/* Whole ImageTileIntegrator::render of the scene's frame on `world` GPUs (collective): clears the device film, renders all spp-waves
+ * of THIS rank's tiles (Tile::tile(pixel_bounds, 8, 8) sharded with shm_shard_tiles), then gathers the film rows of every rank into
+ * rank 0's device film with one RCCL group (ncclRecv per block on the root, ncclSend on the owners; each peer -> root transfer rides its
+ * own xGMI link). On return rank 0's device film (shm_film_read / shm_film_device_ptr) holds the complete frame, bit-identical to a
+ * single-GPU render; the other ranks hold their own rows. stats (may be NULL) is this rank's. Without shm_dist_init it renders the
+ * whole frame on this GPU (world = 1). */
+SHM_API int shm_render_sharded(ShmScene* scene, const ShmRenderParams* params, ShmStats* stats);
+/* Test entry: sends this rank's film rows to ITSELF through the same RCCL send / recv group into a scratch film and compares
+ * (exercises the RCCL transport on a one-GPU box). SHM_OK when every byte matches. */
+SHM_API int shm_dist_selftest(ShmScene* scene);
+
+/* One process, n devices: the same frame with one host thread and one scene replica per entry of `devices` (HIP ordinals; an ordinal may
+ * repeat, which shares that GPU between two replicas — used by the tests on a one-GPU box), tiles sharded as above, film rows gathered
+ * into the first device's film with hipMemcpyPeerAsync over xGMI, then read back. film_out: pixel_bounds-sized, overwritten.
+ * stats_per_device: n_devices entries or NULL. A C-only caller renders on every GPU of a node with this one call. */
+SHM_API int shm_render_multi(const ShmSceneDesc* desc, const int32_t* devices, int32_t n_devices, const ShmRenderParams* params,
+                             ShmFilmPixel* film_out, ShmStats* stats_per_device);
 
 SHM_API const char* shm_last_error(void);   /* thread-local, never NULL */
 SHM_API int shm_device_count(void);

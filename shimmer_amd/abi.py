@@ -10,8 +10,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 LIB_PATH = ROOT / "csrc" / "libshimmer_hip.so"
 
-SHM_ABI_VERSION = 6
+SHM_ABI_VERSION = 7
 SHM_OK = 0
+SHM_DIST_ID_BYTES = 128
 SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE, SHM_SHAPE_BILINEAR_PATCH, SHM_SHAPE_INSTANCE = 0, 1, 2, 3
 SHM_SPECTRUM_CONSTANT, SHM_SPECTRUM_DENSE, SHM_SPECTRUM_PIECEWISE_LINEAR = 0, 1, 2
 SHM_SPECTRUM_RGB_ALBEDO, SHM_SPECTRUM_RGB_UNBOUNDED, SHM_SPECTRUM_RGB_ILLUMINANT = 3, 4, 5
@@ -173,7 +174,7 @@ class ShmStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("nodes_closest", C.c_uint64),
                 ("tris_closest", C.c_uint64), ("nodes_any", C.c_uint64), ("tris_any", C.c_uint64), ("ms_total", C.c_double),
                 ("ms_trace_closest", C.c_double), ("ms_trace_any", C.c_double), ("ms_shade", C.c_double),
-                ("launches_closest", C.c_uint32), ("launches_any", C.c_uint32)]
+                ("launches_closest", C.c_uint32), ("launches_any", C.c_uint32), ("ms_gather", C.c_double), ("gather_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -217,6 +218,13 @@ EXPORTS = {
     "shm_write_pfm": (C.c_int, [C.c_char_p, c_float_p, C.c_int32, C.c_int32]),
     "shm_ply_read": (C.c_int, [C.c_char_p, C.c_void_p]),
     "shm_ply_free": (None, [C.c_void_p]),
+    "shm_shard_tiles": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, c_u32_p, c_u32_p]),
+    "shm_dist_unique_id": (C.c_int, [C.c_void_p]),
+    "shm_dist_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "shm_dist_finalize": (C.c_int, [C.c_void_p]),
+    "shm_render_sharded": (C.c_int, [C.c_void_p, C.POINTER(ShmRenderParams), C.POINTER(ShmStats)]),
+    "shm_dist_selftest": (C.c_int, [C.c_void_p]),
+    "shm_render_multi": (C.c_int, [C.POINTER(ShmSceneDesc), C.POINTER(C.c_int32), C.c_int32, C.POINTER(ShmRenderParams), C.c_void_p, C.POINTER(ShmStats)]),
 }
 
 _lib = None

@@ -1,0 +1,256 @@
+// k_shade.inl — the fused K4+K5 kernel template (one path vertex of PathIntegrator::li per launch), included by the k_shade_*.hip
+// translation units, each of which instantiates one scene class.
+#pragma once
+#include "wavefront.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// K4+K5: one path vertex (integrator.rs:772-892 for the vertex found by K2).
+// ---------------------------------------------------------------------------------------------
+// HAS_LAYERED = false is the instantiation for scenes without Coated* materials: the LayeredBxDF random walks (three per
+// vertex: f and pdf for NEE, sample_f) are compiled out of it.
+//   TRI_ONLY = true is the instantiation for scenes made of triangles only: no quadric / bilinear-patch interaction and light
+//   sampling code (with it the kernel needs 264 VGPRs, one wave per SIMD; without it 243, two waves).
+//   HAS_TEX = true is the instantiation for scenes that bind image textures: the path carries ray differentials (texture.h),
+//   get_bsdf filters the MIP pyramids. One general instantiation <true, false, true>.
+//   DIFFUSE_ONLY = true is the instantiation for scenes whose materials are all DiffuseMaterial (the headline scene class): the
+//   conductor / dielectric BxDFs and the material dispatch are compiled out of it.
+template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ONLY = false>
+__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
+                                                     uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
+                                                     DeviceCounters* counters, int shadow_parity) {
+    const uint32_t n = qs->n_active[cur];
+    __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
+    __shared__ uint32_t s_cnt[2], s_base[2];
+    for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
+      if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+      __syncthreads();
+      for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+        const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
+        bool active = i < n;
+        bool push_next = false, push_shadow = false;
+        uint32_t path = 0;
+        if (active) {
+            path = q_cur[i];
+            const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
+            float4 h0 = hp[0], h1 = hp[1];
+            Hit hit;
+            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
+            const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
+            float4 r0 = rp[0], r1 = rp[1];
+            V3 ray_d = v3(r0.w, r1.x, r1.y);
+            // L is only touched by a vertex that adds emission (most do not): loaded and stored inside add_l
+            auto add_l = [&](const Spec& c) { pa.L[path] = st_spec(ld_spec(pa.L[path]) + c); };
+            Spec beta = ld_spec(pa.beta[path]);
+            Wavelengths lambda;
+            float4 pdf_in;
+            {
+                float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                pdf_in = b;
+                lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
+                lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
+            }
+            uint32_t fl = pa.flags[path];
+            int depth = (int)(fl & 0xffu);
+            bool specular_bounce = (fl >> 8) & 1u;
+            bool any_non_specular_bounces = (fl >> 9) & 1u;
+            float2 pe = pa.pb_eta[path];
+            Float p_b = pe.x, eta_scale = pe.y;
+            // the previous vertex's context is only needed for the MIS weight of an emitter that was hit
+            auto load_prev_ctx = [&]() {
+                LightSampleContext c;
+                float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path];
+                c.pi.x = iv2(c0.x, c0.w);
+                c.pi.y = iv2(c0.y, c1.x);
+                c.pi.z = iv2(c0.z, c1.y);
+                c.n = v3(c1.z, c1.w, c2.x);
+                c.ns = v3(c2.y, c2.z, c2.w);
+                return c;
+            };
+            if (hit.prim < 0) {
+                // integrator.rs:776-794: escaped ray, infinite lights
+                for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
+                    const ShmLight& light = sv.lights[sv.infinite_lights[k]];
+                    Spec le = infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda);
+                    if (depth == 0 || specular_bounce) {
+                        add_l(beta * le);
+                    } else {
+                        Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
+                        Float w_b = power_heuristic(1, p_b, 1, p_l);
+                        add_l(beta * w_b * le);
+                    }
+                }
+            } else {
+                SurfaceInteraction si = hit_interaction<TRI_ONLY>(sv, hit, -ray_d);
+                const ShmPrimitive prim = sv.primitives[hit.prim];
+                // integrator.rs:798-813: emission at the hit
+                if (prim.area_light >= 0) {
+                    const ShmLight& light = sv.lights[prim.area_light];
+                    Spec le = area_light_l(sv, light, si.n, -ray_d, lambda);
+                    if (!is_zero(le)) {
+                        if (depth == 0 || specular_bounce) {
+                            add_l(beta * le);
+                        } else {
+                            Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
+                            Float w_l = power_heuristic(1, p_b, 1, p_l);
+                            add_l(beta * w_l * le);
+                        }
+                    }
+                }
+                // get_bsdf starts with compute_differentials(ray, camera, spp) (interaction.rs:197)
+                Differentials df;
+                AuxRays aux = aux_none();
+                if (HAS_TEX) {
+                    if (fl & (1u << 10)) aux = ld_aux(pa, path);
+                    df = compute_differentials(sv, si, aux, params.samples_per_pixel, params.disable_pixel_jitter != 0, params.disable_texture_filtering != 0);
+                }
+                const ShmMaterial& mat = sv.materials[prim.material];
+                if (DIFFUSE_ONLY) __builtin_assume(mat.kind == SHM_MATERIAL_DIFFUSE);
+                BSDF bsdf = get_bsdf<HAS_TEX>(sv, si, mat, lambda, &df);
+                if (!HAS_LAYERED) __builtin_assume(bsdf.bxdf.kind <= SHM_MATERIAL_THIN_DIELECTRIC);
+                if (DIFFUSE_ONLY) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIFFUSE);
+                Rng rng;
+                auto load_rng = [&]() {
+                    uint32_t pix = pa.pixel[path];
+                    uint2 rs = pa.rng[path];
+                    rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+                    // inc is a pure function of (pixel, seed): re-derive instead of storing 8 more bytes per path
+                    uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
+                    h = mix_bits(h ^ (params.seed + 0x9e3779b97f4a7c15ULL));
+                    rng.inc = (h << 1u) | 1u;
+                };
+                // options.force_diffuse (interaction.rs:256-275) draws inside get_bsdf, before the depth test; only the general
+                // instantiation carries it (the host launches that one when the flag is set)
+                const bool forced = HAS_TEX && params.force_diffuse != 0;
+                if (forced) {
+                    load_rng();
+                    Float uc = sampler_get_1d(rng);
+                    V2 u2f = sampler_get_2d(rng);
+                    bsdf_force_diffuse(bsdf, si.wo, uc, u2f);
+                }
+                if (params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
+                bool alive = (depth != params.max_depth);  // integrator.rs:830-834
+                if (alive) {
+                    depth += 1;
+                    if (!forced) load_rng();
+                    // integrator.rs:837-841 + 897-963: next-event estimation; the visibility test is deferred to K3
+                    if (flags_is_non_specular(bsdf_flags(bsdf))) {
+                        LightSampleContext ctx = light_ctx_from(si);
+                        uint32_t bf = bsdf_flags(bsdf);
+                        if (flags_is_reflective(bf) && !flags_is_transmissive(bf)) ctx.pi = p3i_exact(offset_ray_origin(si.pi, si.n, si.wo));
+                        else if (flags_is_transmissive(bf) && !flags_is_reflective(bf)) ctx.pi = p3i_exact(offset_ray_origin(si.pi, si.n, -si.wo));
+                        Float u = sampler_get_1d(rng);
+                        Float p_sel = 0.0f;
+                        int li = light_sampler_sample(sv, u, p_sel);
+                        V2 u_light = sampler_get_2d(rng);
+                        if (li >= 0) {
+                            const ShmLight& light = sv.lights[li];
+                            LightLiSample ls;
+                            if (light_sample_li<TRI_ONLY, HAS_TEX>(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
+                                V3 wo = si.wo;
+                                V3 wi = ls.wi;
+                                Spec f = bsdf_f(bsdf, wo, wi) * abs_dot(wi, si.shading.n);
+                                if (!is_zero(f)) {
+                                    Ray sr = spawn_ray_to_both_offset(si.pi, si.n, ls.p_light_pi, ls.p_light_n);
+                                    Float p_l = p_sel * ls.pdf;
+                                    Spec ld;
+                                    if (light_is_delta(light)) {
+                                        ld = ls.l * f / p_l;
+                                    } else {
+                                        Float pb2 = bsdf_pdf(bsdf, wo, wi, REFLTRANS_ALL);
+                                        Float w_l = power_heuristic(1, p_l, 1, pb2);
+                                        ld = w_l * ls.l * f / p_l;
+                                    }
+                                    ShmRay s;
+                                    s.o[0] = sr.o.x; s.o[1] = sr.o.y; s.o[2] = sr.o.z;
+                                    s.d[0] = sr.d.x; s.d[1] = sr.d.y; s.d[2] = sr.d.z;
+                                    s.t_max = 1.0f - 0.0001f;  // 1 - SHADOW_EPSILON, integrator.rs:66,115
+                                    s.pad = 0.0f;
+                                    pa.shadow_ray[path] = s;
+                                    pa.shadow_contrib[path] = st_spec(beta * ld);
+                                    push_shadow = true;
+                                }
+                            }
+                        }
+                    }
+                    // integrator.rs:843-857: sample the BSDF
+                    V3 wo = -ray_d;
+                    Float u = sampler_get_1d(rng);
+                    V2 u2 = sampler_get_2d(rng);
+                    BSDFSample bs;
+                    if (!bsdf_sample_f(bsdf, wo, u, u2, REFLTRANS_ALL, bs)) {
+                        alive = false;
+                    } else {
+                        // integrator.rs:859-872
+                        beta = beta * (bs.f * abs_dot(bs.wi, si.shading.n) / bs.pdf);
+                        p_b = bs.pdf_is_proportional ? bsdf_pdf(bsdf, wo, bs.wi, REFLTRANS_ALL) : bs.pdf;
+                        specular_bounce = flags_is_specular(bs.flags);
+                        any_non_specular_bounces |= !specular_bounce;
+                        if (flags_is_transmissive(bs.flags)) eta_scale *= sqr(bs.eta);
+                        LightSampleContext nctx = light_ctx_from(si);
+                        V3 no = offset_ray_origin(si.pi, si.n, bs.wi);  // integrator.rs:875 -> interaction.rs:68-75
+                        // integrator.rs:878-891: Russian roulette
+                        if (is_finite(eta_scale)) {
+                            Spec rr_beta = beta * eta_scale;
+                            if (max_component_value(rr_beta) < 1.0f && depth > 1) {
+                                Float q = max(0.0f, 1.0f - max_component_value(rr_beta));
+                                if (sampler_get_1d(rng) < q) alive = false;
+                                else beta = beta / (1.0f - q);
+                            }
+                        }
+                        if (alive) {
+                            ShmRay nr;
+                            nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z;
+                            nr.d[0] = bs.wi.x; nr.d[1] = bs.wi.y; nr.d[2] = bs.wi.z;
+                            nr.t_max = infinity();
+                            nr.pad = 0.0f;
+                            pa.ray[path] = nr;
+                            pa.beta[path] = st_spec(beta);
+                            pa.pb_eta[path] = make_float2(p_b, eta_scale);
+                            pa.ctx0[path] = make_float4(nctx.pi.x.low, nctx.pi.y.low, nctx.pi.z.low, nctx.pi.x.high);
+                            pa.ctx1[path] = make_float4(nctx.pi.y.high, nctx.pi.z.high, nctx.n.x, nctx.n.y);
+                            pa.ctx2[path] = make_float4(nctx.n.z, nctx.ns.x, nctx.ns.y, nctx.ns.z);
+                            pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                            uint32_t aux_bit = 0u;
+                            if (HAS_TEX) {  // spawn_ray_with_differentials, interaction.rs:430-514
+                                AuxRays na = spawn_ray_differentials(si, df, aux, bs.wi, bs.flags, bs.eta);
+                                if (na.has) { st_aux(pa, path, na); aux_bit = 1u << 10; }
+                            }
+                            pa.flags[path] = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9) | aux_bit;
+                            push_next = true;
+                        }
+                    }
+                }
+                // terminate_secondary may have changed the pdfs (material.rs:609-619): written back only then
+                if (lambda.pdf[1] != pdf_in.y || lambda.pdf[2] != pdf_in.z || lambda.pdf[3] != pdf_in.w || lambda.pdf[0] != pdf_in.x)
+                    pa.lambda_pdf[path] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
+            }
+        }
+        // stage the queue entries of this chunk in LDS (wave-aggregated LDS atomics)
+        uint32_t s1 = queue_push_slot(&s_cnt[0], push_next);
+        if (push_next) s_next[s1] = path;
+        uint32_t s2 = queue_push_slot(&s_cnt[1], push_shadow);
+        if (push_shadow) s_shadow[s2] = path;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+          s_base[0] = s_cnt[0] ? atomicAdd(&qs->n_active[cur ^ 1], s_cnt[0]) : 0u;
+          s_base[1] = s_cnt[1] ? atomicAdd(&qs->n_shadow[shadow_parity], s_cnt[1]) : 0u;
+      }
+      __syncthreads();
+      for (uint32_t j = threadIdx.x; j < s_cnt[0]; j += SHADE2_BLOCK) q_next[s_base[0] + j] = s_next[j];
+      for (uint32_t j = threadIdx.x; j < s_cnt[1]; j += SHADE2_BLOCK) q_shadow[s_base[1] + j] = s_shadow[j];
+      __syncthreads();
+    }
+    (void)counters;
+}
+}  // namespace
+
+
+#define WF_SHADE_LAUNCH(KERNEL)                                                                                                              \
+    do {                                                                                                                                     \
+        hipLaunchKernelGGL(KERNEL, dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], s->d_q_active[a.cur ^ 1], \
+                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity);                                        \
+        LAUNCH_TRY("k_shade");                                                                                                               \
+    } while (0)

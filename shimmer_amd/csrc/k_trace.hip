@@ -1,0 +1,347 @@
+// k_trace.hip — K2 / K3: BVH traversal of the gfx950 wavefront path tracer (see wavefront.h).
+//   aggregate.rs:71-139    BvhAggregate::intersect           -> k_trace3<false, TRI_ONLY> (persistent waves, LDS stack)
+//   aggregate.rs:141-203   BvhAggregate::intersect_predicate -> k_trace3<true, TRI_ONLY>
+#include "wavefront.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// K2 / K3: BVH traversal. The reference's traversal (aggregate.rs:71-203: test the current node, push the far child
+// untested, enter the near child; pop on a miss or after a leaf) executed as UNIFORM steps, because the profile of the
+// first, reference-shaped kernel (one ray per lane from root to done; profiles/r01_v1) showed ~10 of 64 lanes active per
+// VALU instruction: issue-bound by divergence, not by HBM (FETCH_SIZE is 3-6x below the algorithmic bytes).  (A variant
+// that fetched and tested both children at the parent was measured and dropped: same results, more loads, no gain.)
+//   ANY       intersect_predicate (early out, no hit record) vs intersect (closest hit)
+//   TRI_ONLY  scenes made of triangles only; otherwise the leaf phase also carries Sphere::intersect (sphere.rs:95-196)
+//  * every loop iteration is one identical step for every lane that has a node to test: [pop if requested] -> fetch the
+//    32-B record -> slab test -> push far / enter near, or mark the leaf pending, or request a pop.  No nested loops;
+//  * leaf (triangle) tests are POSTPONED: a lane that reached a leaf waits until at least `leaf_min` lanes of its wave
+//    have a pending leaf (or no lane can take a node step), then the watertight test runs for all of them at once;
+//  * finished lanes are refilled from the queue (one wave-aggregated atomic) once `refill_min` lanes are idle;
+//  * stack levels [0, LDS_N) live in LDS as [level][lane]; any deeper level goes to a per-lane HBM region laid out the
+//    same way.
+// Node and primitive visit counts equal the reference's in both modes (it is the same algorithm, node for node).
+// ---------------------------------------------------------------------------------------------
+#ifndef K3_CHUNK_MAX
+#define K3_CHUNK_MAX 1024
+#endif
+enum : uint32_t { ST_IDLE = 0, ST_NODE = 1, ST_LEAF = 2, ST_DONE = 3 };
+
+template <bool ANY, bool TRI_ONLY>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
+                                                       uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
+                                                       ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
+                                                       float4* __restrict__ L, const float4* __restrict__ contrib,
+                                                       DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
+                                                       int refill_min, int leaf_min, int queue_parts) {
+    __shared__ uint32_t lds_stack[(TRACE_BLOCK / WAVE) * K3_LDS_N * WAVE];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave_in_block = threadIdx.x / WAVE;
+    uint32_t* const st_lds = lds_stack + wave_in_block * K3_LDS_N * WAVE + lane;
+    uint32_t* const st_spill = spill + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE + lane;
+    const uint32_t n = n_ptr ? *n_ptr : n_direct;
+    const char* __restrict__ node_base = reinterpret_cast<const char*>(sv.nodes);
+    const char* __restrict__ prim_base = reinterpret_cast<const char*>(sv.prim_recs);
+    uint32_t c_nodes = 0, c_prims = 0, c_rays = 0;
+
+    uint32_t state = ST_IDLE;
+    bool exhausted = false;  // wave-uniform
+    uint32_t w_next = 0, w_end = 0;  // wave-uniform private range of the queue
+    // chunk size: large enough that the single head word sees few atomics (it saturates near 88 dequeues/us,
+    // MI355X_MICROARCH.md "dequeue"), small enough that the last chunks balance across the resident waves
+    const uint32_t n_waves = gridDim.x * (TRACE_BLOCK / WAVE);
+    uint32_t chunk = n / (n_waves * 8u);
+    chunk = chunk < 64u ? 64u : (chunk > (uint32_t)K3_CHUNK_MAX ? (uint32_t)K3_CHUNK_MAX : chunk);
+    chunk = (chunk + 63u) & ~63u;
+    bool want_pop = false;
+    uint32_t path = 0;
+    V3 ro = v3s(0.0f), inv_dir = v3s(0.0f);
+    V3 rd_full = v3s(0.0f);  // the direction itself is only kept for non-triangle shapes (TRI_ONLY = false)
+    bool negx = false, negy = false, negz = false;
+    RayShear rs;
+    rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
+    Float t_max = 0.0f;
+    int32_t hit_prim = -1;
+    Float hit_t = 0.0f, hit_b0 = 0.0f, hit_b1 = 0.0f, hit_b2 = 0.0f, hit_phi = 0.0f;
+    // TransformedPrimitive (TRI_ONLY = false only): the leaf slot of the instance being traversed (-1: the top-level tree), the
+    // instance the current closest hit was found through, t_max as it was outside, and whether this visit found a hit
+    int32_t inst_slot = -1, hit_inst = -1;
+    Float t_outer = 0.0f;
+    bool inst_hit = false;
+    constexpr uint32_t INST_SENTINEL = 0xffffffffu;  // stack entry that marks the way back out of an instance
+    int sp = 0;
+    uint32_t cur = 0;
+    uint32_t leaf_off = 0, leaf_n = 0;
+
+    // Stack storage by level: [0, K3_LDS_N) in LDS, anything deeper in the per-lane HBM spill. (The first version kept
+    // the LDS window at levels 6..31 and spilled the bottom levels: those are written at the start of every ray and again
+    // whenever the traversal comes back near the root, and as HBM stores they made WRITE_SIZE 7x the algorithmic hit writes
+    // — profiles/r01_v4. Holding them in registers through select chains was measured too: slower than LDS.)
+    // Queue partitions: the queue is cut into `queue_parts` contiguous ranges, each with its own head word (own 128-B
+    // line). A wave starts in the partition of the XCD it runs on — queue order is image order (pix_group), so one XCD's L2
+    // serves one image region's part of the BVH, and 8 head words see 1/8 of the atomics each (one word saturates near
+    // 88 dequeues/us: MI355X_MICROARCH.md "dequeue") — and moves on to the next partition when its own has run dry.
+    const uint32_t n_parts = (uint32_t)queue_parts;
+    const uint32_t part_size = ((n + n_parts * 64u - 1u) / (n_parts * 64u)) * 64u;
+    uint32_t part = (n_parts > 1u) ? (__builtin_amdgcn_s_getreg(6164 /* HW_REG_XCC_ID, bits [3:0] */) & (n_parts - 1u)) : 0u;
+    uint32_t parts_left = n_parts;
+    for (;;) {
+        // ---- refill idle lanes from the wave-private chunk [w_next, w_end); one atomic per `chunk` rays ----
+        unsigned long long idle = __ballot(state == ST_IDLE);
+        if (idle != 0ull) {
+            int n_idle = __popcll(idle);
+            if (!exhausted && (n_idle >= refill_min || idle == ~0ull)) {
+                while (w_next >= w_end && !exhausted) {
+                    const uint32_t p_begin = part * part_size;
+                    const uint32_t p_end = (p_begin < n) ? ((n - p_begin < part_size) ? n : p_begin + part_size) : p_begin;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(head + part * 32u, chunk);
+                    base = __shfl(base, 0);
+                    if (base < p_end - p_begin) {
+                        w_next = p_begin + base;
+                        w_end = (p_end - w_next < chunk) ? p_end : w_next + chunk;
+                    } else {
+                        part = (part + 1u == n_parts) ? 0u : part + 1u;
+                        if (--parts_left == 0u) exhausted = true;
+                    }
+                }
+                if (!exhausted) {
+                    uint32_t take = min((uint32_t)n_idle, w_end - w_next);
+                    if (state == ST_IDLE) {
+                        uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                        if (rank < take) {
+                            uint32_t qi = w_next + rank;
+                            path = queue ? queue[qi] : qi;
+                            const float4* rp = reinterpret_cast<const float4*>(rays + path);
+                            float4 r0 = rp[0], r1 = rp[1];
+                            ro = v3(r0.x, r0.y, r0.z);
+                            V3 rd = v3(r0.w, r1.x, r1.y);
+                            t_max = r1.z;
+                            inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);  // aggregate.rs:76-81
+                            negx = inv_dir.x < 0.0f;
+                            negy = inv_dir.y < 0.0f;
+                            negz = inv_dir.z < 0.0f;
+                            rs = ray_shear(rd);
+                            if (!TRI_ONLY) rd_full = rd;
+                            hit_prim = -1;
+                            hit_inst = -1;
+                            inst_slot = -1;
+                            sp = 0;
+                            cur = 0;
+                            want_pop = false;
+                            state = ST_NODE;
+                            c_rays++;
+                        }
+                    }
+                    w_next += take;
+                }
+            }
+            if (__ballot(state != ST_IDLE) == 0ull) {
+                if (exhausted) break;
+                continue;  // private chunk was empty: fetch the next one
+            }
+        }
+        // ---- one uniform node step ----
+        if (state == ST_NODE) {
+            bool go = true;
+            if (want_pop) {
+                want_pop = false;
+                if (sp == 0) { state = ST_DONE; go = false; }
+                else {
+                    sp--;
+                    // two different load flavours, so that the compiler cannot merge them into one flat_load of a selected
+                    // pointer (which waits on both the LDS and the vector-memory counter)
+                    if (sp < K3_LDS_N) cur = st_lds[sp * WAVE];
+                    else cur = __builtin_nontemporal_load(st_spill + (size_t)(sp - K3_LDS_N) * WAVE);
+                    if (!TRI_ONLY && cur == INST_SENTINEL) {
+                        // the instanced aggregate is exhausted: back to the ray of the enclosing tree (primitive.rs:158-171 returns);
+                        // t_max is the hit found inside (in the instance's parameterisation, as the reference keeps it) or what it was
+                        const float4* rp = reinterpret_cast<const float4*>(rays + path);
+                        float4 r0 = rp[0], r1 = rp[1];
+                        ro = v3(r0.x, r0.y, r0.z);
+                        V3 rd = v3(r0.w, r1.x, r1.y);
+                        inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        negx = inv_dir.x < 0.0f;
+                        negy = inv_dir.y < 0.0f;
+                        negz = inv_dir.z < 0.0f;
+                        rs = ray_shear(rd);
+                        rd_full = rd;
+                        if (!inst_hit) t_max = t_outer;
+                        inst_slot = -1;
+                        want_pop = true;
+                        go = false;
+                    }
+                }
+            }
+            if (go) {
+                const float4* np = reinterpret_cast<const float4*>(node_base + ((size_t)cur << 5));
+                float4 na = np[0], nb = np[1];
+                c_nodes++;
+                // Bounds3f::intersect_p_cached (bounding_box.rs:520-563), signs held as lane masks
+                const Float g = 1.0f + 2.0f * gamma(3);
+                Float t0 = ((negx ? na.w : na.x) - ro.x) * inv_dir.x;
+                Float t1 = ((negx ? na.x : na.w) - ro.x) * inv_dir.x;
+                Float ty0 = ((negy ? nb.x : na.y) - ro.y) * inv_dir.y;
+                Float ty1 = ((negy ? na.y : nb.x) - ro.y) * inv_dir.y;
+                t1 *= g;
+                ty1 *= g;
+                bool hit_box = !(t0 > ty1 || ty0 > t1);
+                if (ty0 > t0) t0 = ty0;
+                if (ty1 < t1) t1 = ty1;
+                Float tz0 = ((negz ? nb.y : na.z) - ro.z) * inv_dir.z;
+                Float tz1 = ((negz ? na.z : nb.y) - ro.z) * inv_dir.z;
+                tz1 *= g;
+                hit_box = hit_box && !(t0 > tz1 || tz0 > t1);
+                if (tz0 > t0) t0 = tz0;
+                if (tz1 < t1) t1 = tz1;
+                hit_box = hit_box && (t0 < t_max) && (t1 > 0.0f);
+                uint32_t offset = __float_as_uint(nb.z);
+                uint32_t meta = __float_as_uint(nb.w);
+                uint32_t n_prims = meta & 0xffffu;
+                if (!hit_box) {
+                    want_pop = true;
+                } else if (n_prims > 0) {
+                    leaf_off = offset;
+                    leaf_n = n_prims;
+                    state = ST_LEAF;
+                } else {
+                    uint32_t axis = (meta >> 16) & 0xffu;
+                    bool neg = (axis == 0) ? negx : ((axis == 1) ? negy : negz);
+                    uint32_t far_child = neg ? cur + 1 : offset;   // aggregate.rs:119-127
+                    uint32_t near_child = neg ? offset : cur + 1;
+                    if (sp < K3_LDS_N) st_lds[sp * WAVE] = far_child;
+                    else st_spill[(size_t)(sp - K3_LDS_N) * WAVE] = far_child;
+                    sp++;
+                    cur = near_child;
+                }
+            }
+        }
+        // ---- postponed leaf phase ----
+        unsigned long long leaf_mask = __ballot(state == ST_LEAF);
+        if (leaf_mask != 0ull) {
+            unsigned long long node_mask = __ballot(state == ST_NODE);
+            if (__popcll(leaf_mask) >= leaf_min || node_mask == 0ull) {
+                if (state == ST_LEAF) {
+                    bool found_any = false;
+                    bool entered = false;
+                    for (uint32_t i = 0; i < leaf_n; ++i) {
+                        uint32_t slot = leaf_off + i;
+                        c_prims++;
+                        const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * 48u);
+                        float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+                        bool got;
+                        if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_INSTANCE_BIT)) {
+                            // TransformedPrimitive (primitive.rs:158-176; alone in its leaf, flatten.h): leave a marker on the stack, take
+                            // the ray into the instance's space — apply_ray_inverse for intersect, the FORWARD apply_ray for
+                            // intersect_predicate, as the reference writes them — and go on in the instanced aggregate's tree.
+                            const ShmInstance& in = sv.instances[__float_as_uint(q2.y) & PRIM_INDEX_MASK];
+                            if (sp < K3_LDS_N) st_lds[sp * WAVE] = INST_SENTINEL;
+                            else st_spill[(size_t)(sp - K3_LDS_N) * WAVE] = INST_SENTINEL;
+                            sp++;
+                            t_outer = t_max;
+                            inst_slot = (int32_t)slot;
+                            inst_hit = false;
+                            Ray r;
+                            if (ANY) { Ray w; w.o = ro; w.d = rd_full; r = xf_ray(in.render_from_primitive, w); }
+                            else r = xf_ray_inverse(in.primitive_from_render, ro, rd_full, t_max);
+                            ro = r.o;
+                            rd_full = r.d;
+                            inv_dir = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+                            negx = inv_dir.x < 0.0f;
+                            negy = inv_dir.y < 0.0f;
+                            negz = inv_dir.z < 0.0f;
+                            rs = ray_shear(r.d);
+                            cur = in.root_node;
+                            entered = true;
+                            break;
+                        }
+                        if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_SPHERE_BIT)) {
+                            // Sphere::intersect (sphere.rs:95-196) through the same leaf phase; the hit record carries p_obj and phi
+                            QuadricIntersection qi;
+                            got = sphere_basic_intersect(sv.spheres[__float_as_uint(q2.y) & PRIM_INDEX_MASK], ro, rd_full, t_max, qi);
+                            if (got) { hit_prim = (int32_t)slot; hit_t = qi.t_hit; hit_b0 = qi.p_obj.x; hit_b1 = qi.p_obj.y; hit_b2 = qi.p_obj.z; hit_phi = qi.phi; }
+                        } else if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_PATCH_BIT)) {
+                            // BilinearPatch::intersect (bilinear_patch.rs:144-236): the record holds p00, p10, p01; (u, v) go in b0, b1
+                            BilinearIntersection bi;
+                            got = blp_intersect(ro, rd_full, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x),
+                                                ld3(sv.patches[__float_as_uint(q2.y) & PRIM_INDEX_MASK].p11), bi);
+                            if (got) { hit_prim = (int32_t)slot; hit_t = bi.t; hit_b0 = bi.u; hit_b1 = bi.v; hit_b2 = 0.0f; hit_phi = 0.0f; }
+                        } else {
+                            TriangleIntersection ti;
+                            got = intersect_triangle_pre(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
+                            if (got) { hit_prim = (int32_t)slot; hit_t = ti.t; hit_b0 = ti.b0; hit_b1 = ti.b1; hit_b2 = ti.b2; hit_phi = 0.0f; }
+                        }
+                        if (got) {
+                            if (ANY) { found_any = true; break; }
+                            t_max = hit_t;  // aggregate.rs:105-109
+                            if (!TRI_ONLY) { hit_inst = inst_slot; inst_hit = true; }
+                        }
+                    }
+                    if (!TRI_ONLY && entered) {
+                        state = ST_NODE;
+                        want_pop = false;
+                    } else if (ANY && found_any) {
+                        state = ST_DONE;
+                    } else {
+                        state = ST_NODE;
+                        want_pop = true;
+                    }
+                }
+            }
+        }
+        // ---- retire finished rays ----
+        if (state == ST_DONE) {
+            if (ANY) {
+                bool occl = hit_prim >= 0;
+                if (occluded_out) occluded_out[path] = occl ? 1 : 0;
+                if (L && !occl) {
+                    float4 l = L[path], c = contrib[path];
+                    l.x += c.x; l.y += c.y; l.z += c.z; l.w += c.w;
+                    L[path] = l;
+                }
+            } else {
+                float4* hp = reinterpret_cast<float4*>(hits + path);
+                hp[0] = make_float4(__int_as_float(hit_prim), hit_t, hit_b0, hit_b1);
+                hp[1] = make_float4(hit_b2, TRI_ONLY ? 0.0f : hit_phi, TRI_ONLY ? 0.0f : __int_as_float(hit_inst + 1), 0.0f);
+            }
+            state = ST_IDLE;
+        }
+    }
+    unsigned long long w_nodes = c_nodes, w_prims = c_prims, w_rays = c_rays;
+    for (int off = 32; off > 0; off >>= 1) {
+        w_nodes += __shfl_down(w_nodes, off);
+        w_prims += __shfl_down(w_prims, off);
+        w_rays += __shfl_down(w_rays, off);
+    }
+    if (lane == 0 && w_rays) {
+        if (ANY) {
+            atomicAdd(&counters->rays_any, w_rays);
+            atomicAdd(&counters->nodes_any, w_nodes);
+            atomicAdd(&counters->tris_any, w_prims);
+        } else {
+            atomicAdd(&counters->rays_closest, w_rays);
+            atomicAdd(&counters->nodes_closest, w_nodes);
+            atomicAdd(&counters->tris_closest, w_prims);
+        }
+    }
+}
+
+__global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x; i < 8 * 32; i += blockDim.x) heads[i] = 0; }
+}  // namespace
+
+int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, const ShmRay* rays,
+                    ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib) {
+    uint32_t* heads = s->d_heads3 + (any ? 8 * 32 : 0);
+    uint32_t* spill = any ? s->d_spill3_any : s->d_spill3;
+    hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, stream, heads);
+    const int leaf_min = any ? s->leaf_min_any : s->leaf_min;
+    const bool tri_only = !s->flat.has_spheres;
+#define TRACE_LAUNCH(ANY, TRI)                                                                                                                   \
+    hipLaunchKernelGGL((k_trace3<ANY, TRI>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
+                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels, s->refill_min, leaf_min, s->queue_parts)
+    if (any) { if (tri_only) TRACE_LAUNCH(true, true); else TRACE_LAUNCH(true, false); }
+    else { if (tri_only) TRACE_LAUNCH(false, true); else TRACE_LAUNCH(false, false); }
+#undef TRACE_LAUNCH
+    LAUNCH_TRY(any ? "k_trace3<any>" : "k_trace3<closest>");
+    return SHM_OK;
+}

@@ -1,0 +1,701 @@
+// render.hip — the MI355X (gfx950, wave64) wavefront path tracer behind include/shimmer_hip.h.
+//
+// Replaces the tile-parallel loop of the reference (paths relative to /root/reference/src):
+//   integrator.rs:226-322  ImageTileIntegrator::render      -> shm_render / shm_render_device / shm_render_wave (host loop below)
+//   integrator.rs:326-396  evaluate_pixel_sample            -> K1 k_generate
+//   aggregate.rs:71-139    BvhAggregate::intersect          -> K2 k_trace3<false, TRI_ONLY> (persistent waves, LDS stack)
+//   aggregate.rs:141-203   BvhAggregate::intersect_predicate-> K3 k_trace3<true, TRI_ONLY>
+//   integrator.rs:772-892  PathIntegrator::li loop body     -> K4+K5 k_shade<HAS_LAYERED, TRI_ONLY> (one path vertex per launch)
+//   integrator.rs:897-963  PathIntegrator::sample_ld        -> inside k_shade (shadow ray deferred to K3)
+//   film.rs:548-574        RgbFilm::add_sample              -> K6 k_film (per-pixel ordered f64 sums)
+// Leaf arithmetic is the single-source header library csrc/shm/*.h (compiled with -ffp-contract=off).
+//
+// Execution model: one (pixel, sample) per lane; paths live in SoA arrays in HBM; each bounce is
+// trace_closest -> shade -> trace_any over index queues compacted with wave-aggregated atomics; queue
+// sizes stay on the device (persistent / grid-stride kernels read them), so a whole render (all fused spp-waves)
+// is enqueued on one HIP stream without host round trips. There is no CPU fallback anywhere in this file.
+#include "wavefront.h"
+#include "host/integrator.hpp"
+
+std::string& shm_err() {
+    thread_local std::string e;
+    return e;
+}
+#define g_err shm_err()
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// K0: expand the tile list into a pixel list (reference loop order inside a tile: x outer, y inner;
+// integrator.rs:257-258).  One thread per tile; tiny.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_expand_tiles(const ShmTile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t* pixels) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    ShmTile tl = tiles[t];
+    uint32_t k = tile_offset[t];
+    for (int x = tl.x0; x < tl.x1; ++x)
+        for (int y = tl.y0; y < tl.y1; ++y) pixels[k++] = (uint32_t)x | ((uint32_t)y << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: camera rays for one batch. Path slots are ordered [pixel group][sample][pixel in group] with groups of `pix_group`
+// consecutive pixels of the tile-ordered pixel list (pix_group >= n_pix is the plain sample-major order
+// slot = s_local * n_pix + p_local; pix_group = 64 keeps all samples of one 8x8 tile adjacent in the queues, so that a
+// wave's private queue range, and an XCD's queue partition, is a compact image region).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t slot_of(uint32_t p_local, uint32_t s_local, uint32_t n_pix, uint32_t n_samples, uint32_t pix_group) {
+    uint32_t g = p_local / pix_group;
+    uint32_t g0 = g * pix_group;
+    uint32_t pg = min(pix_group, n_pix - g0);
+    return g0 * n_samples + s_local * pg + (p_local - g0);
+}
+
+__global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArrays pa, const uint32_t* pixels, uint32_t n_pix,
+                                                        int sample_begin, int n_samples, ShmRenderParams params,
+                                                        uint32_t* q_active, QueueState* qs, uint32_t pix_group) {
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t total = n_pix * (uint32_t)n_samples;
+    if (slot >= total) return;
+    uint32_t g = slot / (pix_group * (uint32_t)n_samples);
+    uint32_t g0 = g * pix_group;
+    uint32_t pg = min(pix_group, n_pix - g0);
+    uint32_t rem = slot - g0 * (uint32_t)n_samples;
+    uint32_t s_local = rem / pg;
+    uint32_t p_local = g0 + (rem - s_local * pg);
+    uint32_t pix = pixels[p_local];
+    int px = (int)(pix & 0xffffu), py = (int)(pix >> 16);
+    Rng rng = sampler_start_pixel_sample(px, py, sample_begin + (int)s_local, params.seed);
+    Wavelengths lambda;
+    Float weight;
+    const bool has_tex = pa.aux0 != nullptr;
+    AuxRays aux = aux_none();
+    Ray r = generate_camera_ray(sv, px, py, rng, params.disable_wavelength_jitter != 0, params.disable_pixel_jitter != 0,
+                                lambda, weight, has_tex ? &aux : nullptr, params.samples_per_pixel);
+    if (has_tex) st_aux(pa, slot, aux);
+    ShmRay ray;
+    ray.o[0] = r.o.x; ray.o[1] = r.o.y; ray.o[2] = r.o.z;
+    ray.d[0] = r.d.x; ray.d[1] = r.d.y; ray.d[2] = r.d.z;
+    ray.t_max = infinity();
+    ray.pad = 0.0f;
+    pa.ray[slot] = ray;
+    pa.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    pa.lambda[slot] = make_float4(lambda.lambda[0], lambda.lambda[1], lambda.lambda[2], lambda.lambda[3]);
+    pa.lambda_pdf[slot] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
+    // (ctx0..2, the previous vertex's LightSampleContext, are first read at depth >= 1, after k_shade has written them)
+    pa.pb_eta[slot] = make_float2(1.0f, 1.0f);
+    pa.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+    pa.pixel[slot] = pix;
+    pa.flags[slot] = has_tex ? (1u << 10) : 0u;  // camera rays always carry auxiliary rays (camera.rs:1070-1078)
+    q_active[slot] = slot;  // first bounce: identity queue
+    if (slot == 0) {
+        qs->n_active[0] = total;
+        qs->n_active[1] = 0;
+        qs->n_shadow[0] = 0;
+        qs->n_shadow[1] = 0;
+    }
+}
+
+// Between bounces: recycle the counters (1 thread).
+__global__ void k_next_bounce(QueueState* qs, int cur, int next_shadow_parity) {
+    qs->n_active[cur] = 0;
+    qs->n_shadow[next_shadow_parity] = 0;  // the one the NEXT shade launch fills; this bounce's count stays for its K3
+}
+// ---------------------------------------------------------------------------------------------
+// K6: RgbFilm::add_sample for every sample of the batch, per pixel in sample order (f64 sums are
+// order dependent; the reference adds samples of a pixel in increasing sample_index).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SHADE_BLOCK) k_film(SceneView sv, PathArrays pa, const uint32_t* pixels, uint32_t n_pix, int n_samples,
+                                                    ShmFilmPixel* film, DeviceCounters* counters, uint32_t pix_group) {
+    uint32_t p_local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p_local >= n_pix) return;
+    uint32_t pix = pixels[p_local];
+    int px = (int)(pix & 0xffffu), py = (int)(pix >> 16);
+    int width = sv.pixel_bounds[2] - sv.pixel_bounds[0];
+    ShmFilmPixel* fp = film + (size_t)(py - sv.pixel_bounds[1]) * (size_t)width + (size_t)(px - sv.pixel_bounds[0]);
+    double r = fp->rgb_sum[0], g = fp->rgb_sum[1], b = fp->rgb_sum[2], w = fp->weight_sum;
+    for (int s = 0; s < n_samples; ++s) {
+        uint32_t slot = slot_of(p_local, (uint32_t)s, n_pix, (uint32_t)n_samples, pix_group);
+        Spec L = ld_spec(pa.L[slot]);
+        Wavelengths lambda;
+        float4 a = pa.lambda[slot], c = pa.lambda_pdf[slot];
+        lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
+        lambda.pdf[0] = c.x; lambda.pdf[1] = c.y; lambda.pdf[2] = c.z; lambda.pdf[3] = c.w;
+        V3 rgb = film_sample_rgb(sv, L, lambda);
+        const Float weight = 1.0f;  // BoxFilter::sample weight (filter.rs:104)
+        r += (double)(weight * rgb.x);
+        g += (double)(weight * rgb.y);
+        b += (double)(weight * rgb.z);
+        w += (double)weight;
+    }
+    fp->rgb_sum[0] = r; fp->rgb_sum[1] = g; fp->rgb_sum[2] = b; fp->weight_sum = w;
+    if (p_local == 0) atomicAdd(&counters->paths, (unsigned long long)n_pix * (unsigned long long)n_samples);
+}
+
+}  // namespace
+
+namespace {
+
+template <typename T>
+int dev_upload(ShmScene* s, const std::vector<T>& v, const T** out) {
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    s->allocs.push_back(d);
+    if (!v.empty()) HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const T*>(d);
+    return SHM_OK;
+}
+template <typename T>
+int dev_alloc(ShmScene* s, size_t n, T** out) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)));
+    s->allocs.push_back(d);
+    *out = reinterpret_cast<T*>(d);
+    return SHM_OK;
+}
+
+// Path workspace sized to the work: up to SHM_BATCH_PATHS (default 256 Mi paths = 71 GB of the 288 GB) so that all 256 spp
+// of the 1024^2 frame are ONE batch (6 closest + 5 any launches for the whole frame). Small batches starve the persistent traversal kernels: with ~400 K resident lanes a
+// 1 M-ray launch gives each lane ~3 rays and the launch time is set by the longest ray, not by throughput (profiles/r01_*).
+static uint64_t max_batch_paths() {
+    uint64_t max_cap = 1ull << 28;
+    if (const char* e = getenv("SHM_BATCH_PATHS")) {
+        long long v = atoll(e);
+        if (v >= 4096) max_cap = (uint64_t)v;
+    }
+    return max_cap;
+}
+
+// The batch limit on THIS device right now: SHM_BATCH_PATHS, bounded by 80 % of the memory that is free (plus what the
+// current workspace already holds), so that a GPU shared with other allocations degrades to more batches, not to an error.
+static uint64_t workspace_cap(const ShmScene* s) {
+    const uint64_t BYTES_PER_PATH = 264 + 3 * 4 + (s->flat.has_textures ? 48 : 0);  // path state + three queues (+ auxiliary rays)
+    uint64_t cap = max_batch_paths();
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        uint64_t avail = (uint64_t)free_b + (uint64_t)s->capacity * BYTES_PER_PATH;
+        uint64_t by_mem = (uint64_t)((double)avail * 0.8) / BYTES_PER_PATH;
+        if (by_mem < cap) cap = by_mem;
+    }
+    return std::max<uint64_t>(cap, 4096);
+}
+
+int ensure_workspace(ShmScene* s, uint64_t needed_paths) {
+    uint64_t max_cap = workspace_cap(s);
+    uint64_t want = std::min<uint64_t>(std::max<uint64_t>(needed_paths, 4096), max_cap);
+    want = (want + 4095ull) & ~4095ull;
+    if (want > 0xfffff000ull) want = 0xfffff000ull;
+    if (s->capacity >= want) return SHM_OK;
+    for (void* p : s->ws_allocs) hipFree(p);
+    s->ws_allocs.clear();
+    s->capacity = 0;
+    uint32_t cap = (uint32_t)want;
+    auto ws_alloc = [&](size_t bytes, void** out) -> int {
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess) { g_err = "hipMalloc of the path workspace failed"; return SHM_ERR_OUT_OF_MEMORY; }
+        s->ws_allocs.push_back(d);
+        *out = d;
+        return SHM_OK;
+    };
+    int rc;
+#define WS(field, type) if ((rc = ws_alloc((size_t)cap * sizeof(type), (void**)&s->pa.field)) != SHM_OK) return rc
+    WS(ray, ShmRay); WS(hit, ShmHit); WS(shadow_ray, ShmRay); WS(shadow_contrib, float4); WS(L, float4); WS(beta, float4);
+    WS(lambda, float4); WS(lambda_pdf, float4); WS(ctx0, float4); WS(ctx1, float4); WS(ctx2, float4); WS(pb_eta, float2);
+    WS(rng, uint2); WS(pixel, uint32_t); WS(flags, uint32_t);
+    s->pa.aux0 = s->pa.aux1 = s->pa.aux2 = nullptr;
+    if (s->flat.has_textures) { WS(aux0, float4); WS(aux1, float4); WS(aux2, float4); }
+#undef WS
+    if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_active[0])) != SHM_OK) return rc;
+    if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_active[1])) != SHM_OK) return rc;
+    if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_shadow)) != SHM_OK) return rc;
+    s->capacity = cap;
+    DBG("workspace: %u paths (%.2f GB)", cap, (double)cap * 276.0 / 1e9);
+    return SHM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* shm_last_error(void) { return g_err.c_str(); }
+// for the host mirror (host_mirror.cpp), which shares this thread-local message; not exported
+__attribute__((visibility("hidden"))) void shm_set_last_error(const char* msg) { g_err = msg ? msg : ""; }
+
+int shm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void shm_scene_destroy(ShmScene* s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    wf_dist_release(s);
+    for (void* p : s->allocs) hipFree(p);
+    for (void* p : s->ws_allocs) hipFree(p);
+    if (s->d_rw) hipFree(s->d_rw);
+    if (s->d_tiles) hipFree(s->d_tiles);
+    if (s->d_tile_offset) hipFree(s->d_tile_offset);
+    if (s->d_pixels) hipFree(s->d_pixels);
+    for (hipEvent_t e : s->events) hipEventDestroy(e);
+    if (s->stream2) hipStreamDestroy(s->stream2);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
+    if (!out) { g_err = "out is null"; return SHM_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    ShmScene* s = new ShmScene();
+    int rc = shm_host::flatten_scene(desc, s->flat, g_err);
+    if (rc != SHM_OK) { delete s; return rc; }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+        g_err = "no HIP device visible (libshimmer_hip has no CPU fallback)";
+        delete s;
+        return SHM_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n_dev) { g_err = "device ordinal out of range"; delete s; return SHM_ERR_INVALID_ARGUMENT; }
+    s->device = device;
+    auto fail = [&](int code) { shm_scene_destroy(s); return code; };
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return fail(SHM_ERR_DEVICE); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreate(&s->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; return fail(SHM_ERR_DEVICE); }
+    if (hipStreamCreate(&s->stream2) != hipSuccess) { g_err = "hipStreamCreate failed"; return fail(SHM_ERR_DEVICE); }
+    if (const char* e = getenv("SHM_OVERLAP_PATHS")) { long long v2 = atoll(e); if (v2 >= 0) s->overlap_paths = (uint64_t)v2; }
+
+    const shm_host::FlatScene& f = s->flat;
+    SceneView v = f.view();  // scalars + host pointers; pointers replaced below
+    if ((rc = dev_upload(s, f.nodes, &v.nodes)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.prim_recs, &v.prim_recs)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.primitives, &v.primitives)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.mesh_flags, &v.mesh_flags)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.vi, &v.vi)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.vn, &v.vn)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.vs, &v.vs)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.vuv, &v.vuv)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.spheres, &v.spheres)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.patches, &v.patches)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.patch_vi, &v.patch_vi)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.patch_vn, &v.patch_vn)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.patch_vuv, &v.patch_vuv)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.materials, &v.materials)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.lights, &v.lights)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.infinite_lights, &v.infinite_lights)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.spectrum_data, &v.spectrum_data)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.sensor_r, &v.sensor_r_bar)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.sensor_g, &v.sensor_g_bar)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.sensor_b, &v.sensor_b_bar)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.image_textures, &v.image_textures)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.image_levels, &v.image_levels)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.texel_data, &v.texel_data)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.rgb2spec_scale, &v.rgb2spec_scale)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.rgb2spec_data, &v.rgb2spec_data)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.cs_illuminant, &v.cs_illuminant)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.ewa_lut, &v.ewa_lut)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.instances, &v.instances)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.float_textures, &v.float_textures)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.ftex_ranges, &v.ftex_ranges)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.ftex_ops, &v.ftex_ops)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.spectrum_textures, &v.spectrum_textures)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.stex_ranges, &v.stex_ranges)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.stex_ops, &v.stex_ops)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.image_lights, &v.image_lights)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, f.dist_data, &v.dist_data)) != SHM_OK) return fail(rc);
+    s->dsv = v;
+
+    size_t w = (size_t)(f.film.pixel_bounds[2] - f.film.pixel_bounds[0]);
+    size_t h = (size_t)(f.film.pixel_bounds[3] - f.film.pixel_bounds[1]);
+    s->n_film_pixels = w * h;
+    if ((rc = dev_alloc<ShmFilmPixel>(s, s->n_film_pixels, &s->d_film)) != SHM_OK) return fail(rc);
+    if (hipMemset(s->d_film, 0, s->n_film_pixels * sizeof(ShmFilmPixel)) != hipSuccess) { g_err = "hipMemset film"; return fail(SHM_ERR_DEVICE); }
+    if ((rc = dev_alloc<QueueState>(s, 1, &s->d_qs)) != SHM_OK) return fail(rc);
+    if ((rc = dev_alloc<DeviceCounters>(s, 1, &s->d_counters)) != SHM_OK) return fail(rc);
+    if ((rc = dev_alloc<uint32_t>(s, 2 * 8 * 32, &s->d_heads3)) != SHM_OK) return fail(rc);
+    hipMemset(s->d_qs, 0, sizeof(QueueState));
+    hipMemset(s->d_counters, 0, sizeof(DeviceCounters));
+
+    // Tuning knobs (development): defaults are the measured optimum on S3
+    if (const char* e = getenv("SHM_PIX_GROUP")) { long long v2 = atoll(e); if (v2 >= 1) s->pix_group = (uint32_t)std::min<long long>(v2, 0x7fffffffll); }
+    if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
+    if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = v2; }
+    {
+        int per_cu3 = 6;  // persistent grid: 26 KiB of LDS per 256-thread workgroup -> 6 workgroups (24 waves) per CU
+        if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 6) per_cu3 = v2; }
+        if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
+        if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
+        s->trace3_blocks = s->n_cu * per_cu3;
+        s->spill3_levels = std::max(0, (int)f.max_leaf_depth + 1 - K3_LDS_N) + 1;
+        if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3)) != SHM_OK) return fail(rc);
+        if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3_any)) != SHM_OK) return fail(rc);
+    }
+    DBG("scene: %u nodes, depth %u, trace blocks %d, spill levels %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->trace3_blocks, s->spill3_levels);
+    *out = s;
+    return SHM_OK;
+}
+
+int shm_film_clear(ShmScene* s) {
+    if (!s) return SHM_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemsetAsync(s->d_film, 0, s->n_film_pixels * sizeof(ShmFilmPixel), s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return SHM_OK;
+}
+
+int shm_film_read(ShmScene* s, ShmFilmPixel* film_out) {
+    if (!s || !film_out) return SHM_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(film_out, s->d_film, s->n_film_pixels * sizeof(ShmFilmPixel), hipMemcpyDeviceToHost));
+    return SHM_OK;
+}
+
+int shm_film_device_ptr(ShmScene* s, void** ptr_out, uint64_t* bytes_out) {
+    if (!s || !ptr_out || !bytes_out) return SHM_ERR_INVALID_ARGUMENT;
+    *ptr_out = s->d_film;
+    *bytes_out = (uint64_t)(s->n_film_pixels * sizeof(ShmFilmPixel));
+    return SHM_OK;
+}
+
+int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles, int32_t sample_begin,
+                    int32_t sample_end, ShmStats* stats) {
+    if (!s || !params || !tiles || n_tiles == 0 || sample_end <= sample_begin) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (params->max_depth < 0 || params->max_depth > 254) { g_err = "max_depth out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (params->integrator > SHM_INTEGRATOR_RANDOM_WALK) { g_err = "unknown integrator"; return SHM_ERR_UNSUPPORTED; }
+    HIP_TRY(hipSetDevice(s->device));
+    int rc;
+    const int32_t* pb = s->flat.film.pixel_bounds;
+    // pixel list for these tiles
+    std::vector<uint32_t> tile_offset(n_tiles);
+    uint64_t n_pixels = 0;
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        const ShmTile& tl = tiles[t];
+        if (tl.x0 < pb[0] || tl.y0 < pb[1] || tl.x1 > pb[2] || tl.y1 > pb[3] || tl.x1 <= tl.x0 || tl.y1 <= tl.y0 || tl.x1 > 65535 || tl.y1 > 65535 ||
+            tl.x0 < 0 || tl.y0 < 0) {
+            g_err = "tile outside pixel bounds";
+            return SHM_ERR_INVALID_ARGUMENT;
+        }
+        tile_offset[t] = (uint32_t)n_pixels;
+        n_pixels += (uint64_t)(tl.x1 - tl.x0) * (uint64_t)(tl.y1 - tl.y0);
+    }
+    if (n_pixels > 0xffffffffull) { g_err = "too many pixels"; return SHM_ERR_INVALID_ARGUMENT; }
+    // Tiles must be disjoint: the film update is one unsynchronised read-modify-write per pixel, as in the reference
+    // (integrator.rs:277-295 relies on Tile::tile's exclusive ownership). One bit per film pixel, one masked word per tile row.
+    {
+        const uint32_t fw = (uint32_t)(pb[2] - pb[0]);
+        const size_t words_per_row = (fw + 63u) / 64u;
+        s->tile_bitmap.assign(words_per_row * (size_t)(pb[3] - pb[1]), 0ull);
+        for (uint32_t t = 0; t < n_tiles; ++t) {
+            const ShmTile& tl = tiles[t];
+            const uint32_t x0 = (uint32_t)(tl.x0 - pb[0]), x1 = (uint32_t)(tl.x1 - pb[0]);
+            for (int y = tl.y0; y < tl.y1; ++y) {
+                uint64_t* row = s->tile_bitmap.data() + (size_t)(y - pb[1]) * words_per_row;
+                for (uint32_t w0 = x0 / 64u; w0 * 64u < x1; ++w0) {
+                    const uint32_t lo = std::max(x0, w0 * 64u) - w0 * 64u, hi = std::min(x1, w0 * 64u + 64u) - w0 * 64u;  // bits [lo, hi)
+                    const uint64_t mask = (hi - lo == 64u ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+                    if (row[w0] & mask) { g_err = "tiles overlap (each pixel must belong to at most one tile of a call)"; return SHM_ERR_INVALID_ARGUMENT; }
+                    row[w0] |= mask;
+                }
+            }
+        }
+    }
+    // the tile / pixel lists are regrown on demand; the superseded buffers are released (the stream is idle between calls)
+    if (s->tiles_capacity < n_tiles) {
+        if (s->d_tiles) hipFree(s->d_tiles);
+        if (s->d_tile_offset) hipFree(s->d_tile_offset);
+        s->d_tiles = nullptr; s->d_tile_offset = nullptr; s->tiles_capacity = 0;
+        if (hipMalloc((void**)&s->d_tiles, (size_t)n_tiles * sizeof(ShmTile)) != hipSuccess ||
+            hipMalloc((void**)&s->d_tile_offset, (size_t)n_tiles * sizeof(uint32_t)) != hipSuccess) { g_err = "hipMalloc of the tile list failed"; return SHM_ERR_OUT_OF_MEMORY; }
+        s->tiles_capacity = n_tiles;
+    }
+    if (s->pixels_capacity < n_pixels) {
+        if (s->d_pixels) hipFree(s->d_pixels);
+        s->d_pixels = nullptr; s->pixels_capacity = 0;
+        if (hipMalloc((void**)&s->d_pixels, (size_t)n_pixels * sizeof(uint32_t)) != hipSuccess) { g_err = "hipMalloc of the pixel list failed"; return SHM_ERR_OUT_OF_MEMORY; }
+        s->pixels_capacity = n_pixels;
+    }
+    HIP_TRY(hipMemcpyAsync(s->d_tiles, tiles, n_tiles * sizeof(ShmTile), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_tile_offset, tile_offset.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), s->stream));
+    hipLaunchKernelGGL(k_expand_tiles, dim3((n_tiles + 255) / 256), dim3(256), 0, s->stream, s->d_tiles, s->d_tile_offset, n_tiles, s->d_pixels);
+
+    const int n_samples = sample_end - sample_begin;
+    const bool random_walk = params->integrator == SHM_INTEGRATOR_RANDOM_WALK;
+    // (the random walk keeps 32 B per depth per path beside the path state: its batches are capped at 16 Mi paths)
+    if ((rc = ensure_workspace(s, random_walk ? std::min<uint64_t>(n_pixels * (uint64_t)n_samples, 1ull << 24) : n_pixels * (uint64_t)n_samples)) != SHM_OK) return rc;
+    uint32_t cap_eff = random_walk ? std::min<uint32_t>(s->capacity, 1u << 24) : s->capacity;  // paths per batch
+    if (random_walk) {
+        // 32 B per depth per path (up to 8 KB per path at max_depth 254): shrink the batch until the records fit in 80 % of what is free
+        const size_t per_path = (size_t)2 * (size_t)(params->max_depth + 1) * sizeof(float4);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t avail = (size_t)((double)(free_b + s->rw_floats4 * sizeof(float4)) * 0.8);
+            while (cap_eff > 4096u && (size_t)cap_eff * per_path > avail) cap_eff = (cap_eff / 2u + 63u) & ~63u;
+        }
+        size_t need = (size_t)2 * (size_t)(params->max_depth + 1) * (size_t)cap_eff;
+        if (s->rw_floats4 < need) {
+            if (s->d_rw) hipFree(s->d_rw);
+            s->d_rw = nullptr;
+            s->rw_floats4 = 0;
+            if (hipMalloc((void**)&s->d_rw, need * sizeof(float4)) != hipSuccess) { g_err = "hipMalloc of the random-walk records failed"; return SHM_ERR_OUT_OF_MEMORY; }
+            s->rw_floats4 = need;
+        }
+    }
+    uint32_t pix_per_batch = cap_eff / (uint32_t)n_samples;
+    if (pix_per_batch == 0) { g_err = "spp-wave larger than the path workspace"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (pix_per_batch > 64) pix_per_batch &= ~63u;  // whole 8x8 tiles per wavefront
+    EventPool ev{s};
+    hipEvent_t e_begin = ev.get(), e_end = ev.get();
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_any, ev_shade;
+    bool used_overlap = false;
+    HIP_TRY(hipEventRecord(e_begin, s->stream));
+    const int shade_blocks = s->n_cu * 4;
+    for (uint64_t p0 = 0; p0 < n_pixels; p0 += pix_per_batch) {
+        uint32_t n_pix = (uint32_t)std::min<uint64_t>(pix_per_batch, n_pixels - p0);
+        uint32_t total = n_pix * (uint32_t)n_samples;
+        const uint32_t* pixels = s->d_pixels + p0;
+        hipLaunchKernelGGL(k_generate, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
+                           sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs, s->pix_group);
+        LAUNCH_TRY("k_generate");
+        int cur = 0;
+        // Small batches are tail-dominated (the last rays of a persistent traversal launch take ~0.5 ms whatever its size): there
+        // K3 of bounce b runs on a second stream beside K2 of bounce b+1 — they are independent: K3 reads the shadow buffers and
+        // adds into L, K2 reads the extension rays and writes hit records — and the next shade launch waits for both. Large
+        // batches (the 1-GPU headline frame) keep everything on one stream, so each kernel has the device to itself.
+        const bool overlap = s->overlap_paths > 0 && (uint64_t)total < s->overlap_paths && params->max_depth > 0;
+        hipStream_t any_stream = overlap ? s->stream2 : s->stream;
+        used_overlap = used_overlap || overlap;
+        hipEvent_t k3_done = nullptr;
+        for (int bounce = 0; bounce <= params->max_depth; ++bounce) {
+            const int sh = bounce & 1;
+            hipEvent_t a = ev.get(), b = ev.get();
+            hipEventRecord(a, s->stream);
+            if ((rc = wf_launch_trace(s, false, s->stream, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr)) != SHM_OK) return rc;
+            hipEventRecord(b, s->stream);
+            ev_closest.push_back({a, b});
+            if (overlap && k3_done) hipStreamWaitEvent(s->stream, k3_done, 0);  // shade(b) touches L and refills the shadow buffers
+            {
+                hipEvent_t s0 = ev.get(), s1 = ev.get();
+                hipEventRecord(s0, s->stream);
+                const ShadeArgs sa{s->stream, cur, *params, sh, shade_blocks};
+                const bool tri_only = !s->flat.has_spheres;
+                if (random_walk) rc = wf_launch_shade_randomwalk(s, sa, cap_eff);
+                else if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH) rc = wf_launch_shade_simple(s, sa);
+                else if (s->flat.has_textures || params->force_diffuse)  // the general instantiations (textures, image lights, force_diffuse)
+                    rc = s->flat.has_layered ? wf_launch_shade_tex_layered(s, sa) : wf_launch_shade_tex(s, sa);
+                else if (s->flat.has_layered) rc = wf_launch_shade_layered(s, sa, tri_only);
+                else rc = wf_launch_shade_lean(s, sa, tri_only, s->flat.diffuse_only && !getenv("SHM_NO_DIFFUSE_ONLY"));
+                if (rc != SHM_OK) return rc;
+                hipEventRecord(s1, s->stream);
+                ev_shade.push_back({s0, s1});
+            }
+            if (bounce < params->max_depth && !random_walk) {
+                hipEvent_t c = ev.get(), d = ev.get();
+                if (overlap) {
+                    hipEvent_t shaded = ev.get();
+                    hipEventRecord(shaded, s->stream);
+                    hipStreamWaitEvent(any_stream, shaded, 0);
+                }
+                hipEventRecord(c, any_stream);
+                if ((rc = wf_launch_trace(s, true, any_stream, s->d_q_shadow, &s->d_qs->n_shadow[sh], 0, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib)) != SHM_OK) return rc;
+                hipEventRecord(d, any_stream);
+                ev_any.push_back({c, d});
+                k3_done = d;
+            }
+            if (dbg_on()) {  // queue sizes per bounce (costs a sync: debug only)
+                QueueState q;
+                hipStreamSynchronize(s->stream);
+                hipStreamSynchronize(any_stream);
+                hipMemcpy(&q, s->d_qs, sizeof(q), hipMemcpyDeviceToHost);
+                DBG("bounce %d: traced %u, next %u, shadow %u", bounce, q.n_active[cur], q.n_active[cur ^ 1], q.n_shadow[sh]);
+            }
+            hipLaunchKernelGGL(k_next_bounce, dim3(1), dim3(1), 0, s->stream, s->d_qs, cur, sh ^ 1);
+            cur ^= 1;
+        }
+        if (overlap && k3_done) hipStreamWaitEvent(s->stream, k3_done, 0);  // the film reads L
+        if (random_walk)
+            if ((rc = wf_launch_fold_randomwalk(s, s->stream, cap_eff, total)) != SHM_OK) return rc;
+        hipLaunchKernelGGL(k_film, dim3((n_pix + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix, n_samples,
+                           s->d_film, s->d_counters, s->pix_group);
+        LAUNCH_TRY("k_film");
+        if (ev.failed) { g_err = "hipEventCreate failed"; return SHM_ERR_DEVICE; }
+    }
+    HIP_TRY(hipEventRecord(e_end, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        DeviceCounters c;
+        HIP_TRY(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+        stats->paths += c.paths;
+        stats->rays_closest += c.rays_closest;
+        stats->rays_any += c.rays_any;
+        stats->nodes_closest += c.nodes_closest;
+        stats->tris_closest += c.tris_closest;
+        stats->nodes_any += c.nodes_any;
+        stats->tris_any += c.tris_any;
+        float ms = 0.0f;
+        hipEventElapsedTime(&ms, e_begin, e_end);
+        stats->ms_total += ms;
+        double mc = 0.0, ma = 0.0;
+        for (auto& p : ev_closest) { hipEventElapsedTime(&ms, p.first, p.second); mc += ms; DBG("closest launch %.3f ms", ms); }
+        for (auto& p : ev_any) { hipEventElapsedTime(&ms, p.first, p.second); ma += ms; DBG("any launch %.3f ms", ms); }
+        double msh = 0.0;
+        for (auto& p : ev_shade) { hipEventElapsedTime(&ms, p.first, p.second); msh += ms; DBG("shade launch %.3f ms", ms); }
+        stats->ms_trace_closest += mc;
+        stats->ms_trace_any += ma;
+        float tot = 0.0f;
+        hipEventElapsedTime(&tot, e_begin, e_end);
+        // everything that is not traversal: shade + generate + film. Without overlap that is the rest of the wall time; with K3
+        // running beside K2 the kernels' own durations add up to more than the wall time, so the shade launches are summed instead.
+        stats->ms_shade += used_overlap ? msh : (double)tot - mc - ma;
+        stats->launches_closest += (uint32_t)ev_closest.size();
+        stats->launches_any += (uint32_t)ev_any.size();
+    }
+    return SHM_OK;
+}
+
+int shm_render_device(ShmScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles, ShmStats* stats) {
+    if (!s || !params) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    // ImageTileIntegrator::render's wave schedule (integrator.rs:231-233, 306-308: 1,1,2,4,...,64,64,...). The waves only
+    // exist there to show progress / write intermediate images (TODO at :311); a pixel's samples are added to the film in
+    // increasing sample_index whatever the grouping, so consecutive waves are fused into launches of at least 64 spp (the
+    // reference's own maximum wave size) and as many more as fit the path workspace in one batch (a rank that owns 1/8 of
+    // the tiles takes all 256 spp at once), without changing a single film sum. SHM_FUSE_WAVES=0 keeps one launch per wave.
+    bool fuse = true;
+    if (const char* e = getenv("SHM_FUSE_WAVES")) fuse = atoi(e) != 0;
+    int spp = params->samples_per_pixel;
+    uint64_t n_pixels = 0;
+    for (uint32_t t = 0; tiles && t < n_tiles; ++t)
+        n_pixels += (uint64_t)std::max(0, tiles[t].x1 - tiles[t].x0) * (uint64_t)std::max(0, tiles[t].y1 - tiles[t].y0);
+    HIP_TRY(hipSetDevice(s->device));
+    const int max_fuse = (int)std::min<uint64_t>(std::max<uint64_t>(64, n_pixels ? workspace_cap(s) / n_pixels : 64), 1u << 20);
+    int wave_start = 0, wave_end = 1, next_wave_size = 1;
+    int pend_begin = 0, pend_end = 0;
+    while (wave_start < spp) {
+        if (pend_end == pend_begin) pend_begin = wave_start;
+        pend_end = wave_end;
+        int nws = wave_end;  // advance the reference's schedule
+        wave_start = wave_end;
+        wave_end = std::min(spp, nws + next_wave_size);
+        next_wave_size = std::min(2 * next_wave_size, 64);
+        bool flush = !fuse || wave_start >= spp || (wave_end - pend_begin) > max_fuse;
+        if (flush) {
+            int rc = shm_render_wave(s, params, tiles, n_tiles, pend_begin, pend_end, stats);
+            if (rc != SHM_OK) return rc;
+            pend_begin = pend_end;
+        }
+    }
+    return SHM_OK;
+}
+
+int shm_render(ShmScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles, ShmFilmPixel* film, ShmStats* stats) {
+    if (!s || !params || !film) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (stats) memset(stats, 0, sizeof(*stats));
+    int rc = shm_film_clear(s);
+    if (rc != SHM_OK) return rc;
+    rc = shm_render_device(s, params, tiles, n_tiles, stats);
+    if (rc != SHM_OK) return rc;
+    std::vector<ShmFilmPixel> tmp(s->n_film_pixels);
+    rc = shm_film_read(s, tmp.data());
+    if (rc != SHM_OK) return rc;
+    for (size_t i = 0; i < tmp.size(); ++i) {
+        film[i].rgb_sum[0] += tmp[i].rgb_sum[0];
+        film[i].rgb_sum[1] += tmp[i].rgb_sum[1];
+        film[i].rgb_sum[2] += tmp[i].rgb_sum[2];
+        film[i].weight_sum += tmp[i].weight_sum;
+    }
+    return SHM_OK;
+}
+
+static int trace_device_impl(ShmScene* s, bool any, const void* rays_dev, uint32_t n, void* out_dev, int repeat, ShmStats* stats) {
+    if (!s || !rays_dev || !out_dev || n == 0 || repeat < 1) { g_err = "invalid trace arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), s->stream));
+    EventPool ev{s};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    for (int r = 0; r < repeat; ++r) {
+        hipEvent_t a = ev.get(), b = ev.get();
+        hipEventRecord(a, s->stream);
+        int rc = any ? wf_launch_trace(s, true, s->stream, nullptr, nullptr, n, (const ShmRay*)rays_dev, nullptr, (uint8_t*)out_dev, nullptr, nullptr)
+                     : wf_launch_trace(s, false, s->stream, nullptr, nullptr, n, (const ShmRay*)rays_dev, (ShmHit*)out_dev, nullptr, nullptr, nullptr);
+        if (rc != SHM_OK) return rc;
+        hipEventRecord(b, s->stream);
+        evs.push_back({a, b});
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        DeviceCounters c;
+        HIP_TRY(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+        stats->rays_closest = c.rays_closest; stats->rays_any = c.rays_any;
+        stats->nodes_closest = c.nodes_closest; stats->tris_closest = c.tris_closest;
+        stats->nodes_any = c.nodes_any; stats->tris_any = c.tris_any;
+        double tot = 0.0;
+        for (auto& p : evs) { float ms = 0.0f; hipEventElapsedTime(&ms, p.first, p.second); tot += ms; }
+        if (any) { stats->ms_trace_any = tot; stats->launches_any = (uint32_t)repeat; }
+        else { stats->ms_trace_closest = tot; stats->launches_closest = (uint32_t)repeat; }
+        stats->ms_total = tot;
+    }
+    return SHM_OK;
+}
+
+int shm_integrator_render(const char* name, const ShmSceneDesc* scene, int device, int32_t max_depth, int regularize,
+                          int sample_lights, int sample_bsdf, int32_t samples_per_pixel, int32_t seed, int disable_pixel_jitter,
+                          int disable_wavelength_jitter, ShmFilmPixel* film_out, ShmStats* stats_out, int32_t* n_waves_out) {
+    if (!name || !scene || !film_out) { g_err = "invalid integrator arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    try {
+        shimmer::PathIntegratorParameters p;
+        p.max_depth = max_depth;
+        p.regularize = regularize != 0;
+        p.sample_lights = sample_lights != 0;
+        p.sample_bsdf = sample_bsdf != 0;
+        p.samples_per_pixel = samples_per_pixel;
+        std::unique_ptr<shimmer::Integrator> integrator = shimmer::create_integrator(name, p, *scene, device);
+        shimmer::Options options;
+        options.seed = seed;
+        options.disable_pixel_jitter = disable_pixel_jitter != 0;
+        options.disable_wavelength_jitter = disable_wavelength_jitter != 0;
+        integrator->render(options);
+        auto* w = static_cast<shimmer::WavefrontPathIntegrator*>(integrator.get());
+        std::copy(w->film().begin(), w->film().end(), film_out);
+        if (stats_out) *stats_out = w->stats();
+        if (n_waves_out) *n_waves_out = w->waves();
+        return SHM_OK;
+    } catch (const shimmer::IntegratorError& e) {
+        g_err = e.what();
+        return SHM_ERR_UNSUPPORTED;
+    } catch (const std::exception& e) {  // nothing unwinds across the ABI
+        g_err = e.what();
+        return SHM_ERR_INTERNAL;
+    }
+}
+
+int shm_trace_closest_device(ShmScene* s, const void* rays_dev, uint32_t n, void* hits_dev, int repeat, ShmStats* stats) {
+    return trace_device_impl(s, false, rays_dev, n, hits_dev, repeat, stats);
+}
+int shm_trace_any_device(ShmScene* s, const void* rays_dev, uint32_t n, void* occluded_dev, int repeat, ShmStats* stats) {
+    return trace_device_impl(s, true, rays_dev, n, occluded_dev, repeat, stats);
+}
+
+static int trace_host_impl(ShmScene* s, bool any, const ShmRay* rays, uint32_t n, void* out, ShmStats* stats) {
+    if (!s || !rays || !out || n == 0) { g_err = "invalid trace arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(s->device));
+    void *d_rays = nullptr, *d_out = nullptr;
+    size_t out_bytes = any ? (size_t)n : (size_t)n * sizeof(ShmHit);
+    HIP_TRY(hipMalloc(&d_rays, (size_t)n * sizeof(ShmRay)));
+    if (hipMalloc(&d_out, out_bytes) != hipSuccess) { hipFree(d_rays); g_err = "hipMalloc"; return SHM_ERR_OUT_OF_MEMORY; }
+    int rc = SHM_OK;
+    if (hipMemcpy(d_rays, rays, (size_t)n * sizeof(ShmRay), hipMemcpyHostToDevice) != hipSuccess) { g_err = "hipMemcpy rays"; rc = SHM_ERR_DEVICE; }
+    if (rc == SHM_OK) rc = trace_device_impl(s, any, d_rays, n, d_out, 1, stats);
+    if (rc == SHM_OK && hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) { g_err = "hipMemcpy out"; rc = SHM_ERR_DEVICE; }
+    hipFree(d_rays);
+    hipFree(d_out);
+    return rc;
+}
+int shm_trace_closest(ShmScene* s, const ShmRay* rays, uint32_t n, ShmHit* hits_out, ShmStats* stats) { return trace_host_impl(s, false, rays, n, hits_out, stats); }
+int shm_trace_any(ShmScene* s, const ShmRay* rays, uint32_t n, uint8_t* occluded_out, ShmStats* stats) { return trace_host_impl(s, true, rays, n, occluded_out, stats); }
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+// wavefront.h — shared declarations of the gfx950 wavefront path tracer behind include/shimmer_hip.h: path state (SoA in HBM), queue
+// bookkeeping, the scene object, and the launchers each kernel translation unit exports. The kernels are split over several .hip files
+// (k_trace.hip, k_shade_*.hip, render.hip) so that they compile in parallel; nothing here is exported from the library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "host/flatten.h"
+#include "shm/path.h"
+
+using namespace shm;
+
+// thread-local message behind shm_last_error() (defined in render.hip)
+__attribute__((visibility("hidden"))) std::string& shm_err();
+
+namespace wf {
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            shm_err() = std::string(#expr) + ": " + hipGetErrorString(_e);                           \
+            return SHM_ERR_DEVICE;                                                               \
+        }                                                                                        \
+    } while (0)
+
+// every kernel launch is followed by LAUNCH_TRY: a failed launch (bad configuration, missing code object) is reported by the call that
+// made it, not by the stream synchronisation at the end
+#define LAUNCH_TRY(what)                                                                         \
+    do {                                                                                         \
+        hipError_t _e = hipGetLastError();                                                       \
+        if (_e != hipSuccess) {                                                                  \
+            shm_err() = std::string("launch of ") + (what) + ": " + hipGetErrorString(_e);           \
+            return SHM_ERR_DEVICE;                                                               \
+        }                                                                                        \
+    } while (0)
+
+static inline bool dbg_on() { static int v = -1; if (v < 0) v = getenv("SHM_DEBUG") ? 1 : 0; return v == 1; }
+#define DBG(...) do { if (dbg_on()) { fprintf(stderr, "[shm] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
+
+constexpr int WAVE = 64;
+constexpr int TRACE_BLOCK = 256;  // 4 waves per workgroup
+constexpr int SHADE_BLOCK = 128;
+
+struct DeviceCounters {
+    unsigned long long rays_closest, rays_any, nodes_closest, tris_closest, nodes_any, tris_any, paths;
+};
+
+// Queue bookkeeping that lives in HBM so that no launch needs a host round trip.
+struct QueueState {
+    uint32_t n_active[2];   // entries in q_active[0/1]
+    uint32_t n_shadow[2];   // entries in q_shadow, double-buffered by bounce parity: K3 of bounce b may still be reading its count
+                            // while the counters of bounce b+1 are recycled (K3(b) overlaps K2(b+1) on a second stream)
+    uint32_t pad[4];
+};
+
+// Path state, structure of arrays (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
+struct PathArrays {
+    ShmRay* ray;            // 32 B: o, d, t_max — input of K2
+    ShmHit* hit;            // 32 B: output of K2
+    ShmRay* shadow_ray;     // 32 B: input of K3
+    float4* shadow_contrib; // beta * Ld, added to L by K3 when unoccluded
+    float4* L;
+    float4* beta;
+    float4* lambda;
+    float4* lambda_pdf;
+    float4* ctx0;           // prev_intr_ctx: pi.low.xyz, pi.high.x
+    float4* ctx1;           //                pi.high.yz, n.xy
+    float4* ctx2;           //                n.z, ns.xyz
+    float2* pb_eta;         // p_b, eta_scale
+    uint2* rng;             // PCG32 state (inc is re-derived from pixel+seed)
+    uint32_t* pixel;        // x | y << 16 (absolute pixel coordinates, < 65536)
+    uint32_t* flags;        // depth | specular_bounce << 8 | any_non_specular << 9 | ray has auxiliary rays << 10
+    // scenes with image textures only (null otherwise): the ray's AuxiliaryRays (ray.rs:104-135)
+    float4* aux0;           // rx_origin.xyz, rx_direction.x
+    float4* aux1;           // rx_direction.yz, ry_origin.xy
+    float4* aux2;           // ry_origin.z, ry_direction.xyz
+};
+
+__device__ __forceinline__ AuxRays ld_aux(const PathArrays& pa, uint32_t path) {
+    float4 a = pa.aux0[path], b = pa.aux1[path], c = pa.aux2[path];
+    AuxRays x;
+    x.has = true;
+    x.rx_o = v3(a.x, a.y, a.z); x.rx_d = v3(a.w, b.x, b.y);
+    x.ry_o = v3(b.z, b.w, c.x); x.ry_d = v3(c.y, c.z, c.w);
+    return x;
+}
+__device__ __forceinline__ void st_aux(const PathArrays& pa, uint32_t path, const AuxRays& x) {
+    pa.aux0[path] = make_float4(x.rx_o.x, x.rx_o.y, x.rx_o.z, x.rx_d.x);
+    pa.aux1[path] = make_float4(x.rx_d.y, x.rx_d.z, x.ry_o.x, x.ry_o.y);
+    pa.aux2[path] = make_float4(x.ry_o.z, x.ry_d.x, x.ry_d.y, x.ry_d.z);
+}
+
+__device__ __forceinline__ uint32_t wave_lane() { return __lane_id(); }
+
+// Wave-aggregated append: one atomic per wave, lanes get consecutive slots.
+__device__ __forceinline__ uint32_t queue_push_slot(uint32_t* counter, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    uint32_t lane = wave_lane();
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    return base + rank;
+}
+__device__ __forceinline__ Spec ld_spec(const float4& f) { Spec s; s.v[0] = f.x; s.v[1] = f.y; s.v[2] = f.z; s.v[3] = f.w; return s; }
+__device__ __forceinline__ float4 st_spec(const Spec& s) { return make_float4(s.v[0], s.v[1], s.v[2], s.v[3]); }
+constexpr int SHADE2_BLOCK = 256;
+constexpr int SHADE_CHUNK = 2048;  // queue entries per workgroup chunk: ONE global atomic per queue per chunk (a single
+                                   // counter word saturates near 88 atomics/us: MI355X_MICROARCH.md "dequeue")
+// Two waves per SIMD for every instantiation: the lean one needs 236 VGPRs anyway; the ones with the quadric / patch or the
+// LayeredBxDF code want 264 / 460 and are better off spilling a little than running one wave per SIMD (measured: patch scene
+// shade 16.6 -> 10.9 ms, coated S3 187 -> 177 ms; 3 or 4 waves lose to spills).
+#ifndef K_SHADE_WAVES
+#define K_SHADE_WAVES 2
+#endif
+#define K_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(K_SHADE_WAVES, K_SHADE_WAVES)))
+constexpr int K3_LDS_N = 26;   // k_trace3: stack levels [0, K3_LDS_N) -> LDS (6.5 KiB per wave), deeper levels -> HBM spill
+}  // namespace wf
+using namespace wf;
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+struct ShmScene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    shm_host::FlatScene flat;
+    SceneView dsv;                 // device pointers
+    std::vector<void*> allocs;
+    std::vector<void*> ws_allocs;  // path workspace (regrown on demand)
+    ShmFilmPixel* d_film = nullptr;
+    size_t n_film_pixels = 0;
+    // path workspace
+    uint32_t capacity = 0;
+    PathArrays pa;
+    uint32_t* d_q_active[2] = {nullptr, nullptr};
+    uint32_t* d_q_shadow = nullptr;
+    QueueState* d_qs = nullptr;
+    DeviceCounters* d_counters = nullptr;
+    uint32_t* d_pixels = nullptr;
+    size_t pixels_capacity = 0;
+    ShmTile* d_tiles = nullptr;
+    uint32_t* d_tile_offset = nullptr;
+    size_t tiles_capacity = 0;
+    std::vector<uint64_t> tile_bitmap;  // host scratch of the disjointness check in shm_render_wave
+    int n_cu = 256;
+    // tuned traversal (k_trace3)
+    int trace3_blocks = 0;
+    int spill3_levels = 1;
+    int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
+    int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
+    uint32_t* d_spill3 = nullptr;
+    float4* d_rw = nullptr;          // RandomWalk: (le, f cos) per depth per path, 2 * (max_depth + 1) * capacity float4
+    size_t rw_floats4 = 0;
+    uint32_t* d_spill3_any = nullptr;  // the any-hit kernel may run concurrently with the closest-hit one (second stream)
+    hipStream_t stream2 = nullptr;
+    uint64_t overlap_paths = 96ull << 20;  // batches below this many paths run K3(b) beside K2(b+1) (SHM_OVERLAP_PATHS; 0 = never)
+    int refill_min = 16;
+    uint32_t pix_group = 1024;      // path-slot order [tile][sample][pixel in tile] (SHM_PIX_GROUP; >= n_pix: sample-major)
+    int queue_parts = 8;           // k_trace3 queue partitions, one per XCD with stealing (SHM_QUEUE_PARTS: 1 or 8)
+    uint32_t* d_heads3 = nullptr;  // [2 (closest, any)][8 partitions][32 dwords: one 128-B line per head word]
+    std::vector<hipEvent_t> events;
+    struct DistState* dist = nullptr;  // multi-GPU state (dist.hip): communicator, this rank's tile shard, the gather plan
+};
+// dist.hip: releases s->dist (RCCL communicator included); called by shm_scene_destroy
+__attribute__((visibility("hidden"))) void wf_dist_release(ShmScene* s);
+
+struct EventPool {
+    ShmScene* s;
+    size_t used = 0;
+    bool failed = false;  // hipEventCreate failed: checked once per render (events are only used for timing / stream ordering)
+    hipEvent_t get() {
+        if (used == s->events.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) { failed = true; return nullptr; }
+            s->events.push_back(e);
+        }
+        return s->events[used++];
+    }
+};
+
+// ---- launchers exported by the kernel translation units (hidden visibility: library-internal) ----
+#define WF_INTERNAL __attribute__((visibility("hidden")))
+// k_trace.hip: BvhAggregate::intersect (any = false) / intersect_predicate (any = true) over a queue of path slots
+WF_INTERNAL int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct,
+                                const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib);
+// k_shade_*.hip: one path vertex of PathIntegrator::li for every entry of q_active[cur] (fused kernels, one per scene class)
+struct ShadeArgs {
+    hipStream_t stream;
+    int cur;
+    ShmRenderParams params;
+    int shadow_parity;
+    int blocks;
+};
+WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a, bool tri_only, bool diffuse_only);  // <false, TRI_ONLY, false, DIFFUSE_ONLY>
+WF_INTERNAL int wf_launch_shade_layered(ShmScene* s, const ShadeArgs& a, bool tri_only);                   // <true, TRI_ONLY>
+WF_INTERNAL int wf_launch_shade_tex_layered(ShmScene* s, const ShadeArgs& a);                              // <true, false, true>
+WF_INTERNAL int wf_launch_shade_tex(ShmScene* s, const ShadeArgs& a);                                      // <false, false, true>
+WF_INTERNAL int wf_launch_shade_simple(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_shade_randomwalk(ShmScene* s, const ShadeArgs& a, uint32_t cap_eff);
+WF_INTERNAL int wf_launch_fold_randomwalk(ShmScene* s, hipStream_t stream, uint32_t cap_eff, uint32_t total);

@@ -52,16 +52,15 @@ def film_to_rgb(film):
     return out
 
 
-def shard_tiles(n_tiles, tiles_per_row, rank, world_size, rows_per_block=None):
-    """Static interleaved sharding: blocks of `rows_per_block` tile rows, block b -> rank b % world.
-    Default block height: about 8 blocks per rank, so that expensive image regions (the object) and cheap ones (walls)
-    are spread over all ranks."""
-    if rows_per_block is None:
-        tile_rows = (n_tiles + tiles_per_row - 1) // tiles_per_row
-        rows_per_block = max(1, tile_rows // (world_size * int(os.environ.get("SHM_SHARD_BLOCKS", "8"))))
-    idx = np.arange(n_tiles)
-    block = (idx // tiles_per_row) // rows_per_block
-    return idx[(block % world_size) == rank]
+def shard_tiles(n_tiles, tiles_per_row, rank, world_size, rows_per_block=None, lib=None):
+    """Static interleaved sharding through the C ABI (shm_shard_tiles): blocks of `rows_per_block` tile rows, block b ->
+    rank b % world. Default block height: about 8 blocks per rank, so that expensive image regions (the object) and cheap ones
+    (walls) are spread over all ranks."""
+    lib = lib or abi.load_library()
+    idx = (C.c_uint32 * max(1, n_tiles))()
+    n = C.c_uint32()
+    abi.check(lib, lib.shm_shard_tiles(n_tiles, tiles_per_row, rank, world_size, int(rows_per_block or 0), idx, C.byref(n)), "shm_shard_tiles")
+    return np.frombuffer(idx, dtype=np.uint32, count=n.value).astype(np.int64)
 
 
 class Renderer:
@@ -112,6 +111,26 @@ class Renderer:
             abi.check(self.lib, self.lib.shm_render_device(self.handle, C.byref(params), tiles, n, C.byref(stats)), "shm_render_device")
         return stats.as_dict()
 
+    # ---- multi-GPU behind the C ABI (one process per GPU; include/shimmer_hip.h "multi-GPU") ----
+    def dist_unique_id(self):
+        """Rank 0: the 128-byte RCCL unique id the host distributes to every rank (any control channel)."""
+        buf = (C.c_uint8 * abi.SHM_DIST_ID_BYTES)()
+        abi.check(self.lib, self.lib.shm_dist_unique_id(buf), "shm_dist_unique_id")
+        return bytes(buf)
+
+    def dist_init(self, rank, world, unique_id):
+        buf = (C.c_uint8 * abi.SHM_DIST_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        abi.check(self.lib, self.lib.shm_dist_init(self.handle, rank, world, buf), "shm_dist_init")
+
+    def render_sharded(self, params):
+        """Collective: clear, render this rank's tile shard, gather the film rows into rank 0's device film over RCCL."""
+        stats = abi.ShmStats()
+        abi.check(self.lib, self.lib.shm_render_sharded(self.handle, C.byref(params), C.byref(stats)), "shm_render_sharded")
+        return stats.as_dict()
+
+    def dist_selftest(self):
+        abi.check(self.lib, self.lib.shm_dist_selftest(self.handle), "shm_dist_selftest")
+
     def read_film(self):
         film = np.zeros((self.height, self.width), dtype=FILM_DTYPE)
         abi.check(self.lib, self.lib.shm_film_read(self.handle, film.ctypes.data_as(C.c_void_p)), "shm_film_read")
@@ -161,9 +180,20 @@ def film_tensor(renderer, device=None):
     return torch.from_numpy(renderer.read_film().view(np.float64).reshape(-1).copy())
 
 
+def render_multi(lib, desc, devices, params):
+    """One process, n devices: shm_render_multi (one host thread + scene replica per device, film rows gathered over xGMI peer copies).
+    Returns (film, [stats per device])."""
+    pb = desc.film.pixel_bounds
+    film = np.zeros((pb[3] - pb[1], pb[2] - pb[0]), dtype=FILM_DTYPE)
+    devs = (C.c_int32 * len(devices))(*devices)
+    stats = (abi.ShmStats * len(devices))()
+    abi.check(lib, lib.shm_render_multi(C.byref(desc), devs, len(devices), C.byref(params), film.ctypes.data_as(C.c_void_p), stats), "shm_render_multi")
+    return film, [st.as_dict() for st in stats]
+
+
 def gather_film(local, rank, world_size, height, width, to_host=True):
-    """C1 of SURVEY §2.1: gather the per-rank film slabs (flat float64 tensors) to rank 0 over RCCL (backend
-    'nccl' on ROCm; 'gloo' in the CPU tests).  Pixel ownership is exclusive (tiles are disjoint) and untouched
+    """TEST HARNESS (the product's gather is shm_render_sharded / shm_render_multi behind the C ABI): gather the per-rank films
+    (flat float64 tensors) to rank 0 through torch.distributed ('gloo' in the CPU tests, 'nccl' = RCCL on a GPU).  Pixel ownership is exclusive (tiles are disjoint) and untouched
     pixels are exactly 0.0, so adding the slabs reproduces the single-process film bit for bit.
     to_host=False leaves the summed film on rank 0's device (a flat float64 tensor): the read-back is the caller's business
     (the reference writes its image once at the end, integrator.rs:311-321) and stays out of a timed region."""

@@ -1,0 +1,134 @@
+"""Multi-GPU behind the C ABI on the one-GPU test box (run with `pytest -m gpu`):
+  * shm_render_multi with 1, 2 and 3 replicas (device ordinal 0 repeated: the replicas share the GPU, which exercises the host
+    threads, the C++ tile sharding and the per-block peer copies of the film rows) == the single-scene film == the oracle's, bit for bit;
+  * the one-process-per-GPU path: shm_dist_unique_id -> shm_dist_init (RCCL communicator, world 1) -> shm_render_sharded, and
+    shm_dist_selftest, which pushes the film rows through the same ncclSend / ncclRecv group to the rank itself;
+  * config C5's SHAPE (BASELINE.json configs[4]): the tiles rank r of 8 owns of a 3840x2160 frame, rendered by the GPU and by the
+    oracle on the same tile list; and the torch harness's gather over the `nccl` backend with world_size 1.
+The 8-rank run itself only happens at the driver's round end (RCCL refuses two ranks on one device)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py
+from shimmer_amd import abi, render, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small_s3(gpu_lib):
+    sc = scenes.ganesha_proxy(gpu_lib, 160, 104, n=24)
+    p = render.make_params(seed=5, spp=6, max_depth=5)
+    r = render.Renderer(gpu_lib, sc.desc, device=0)
+    film, stats = r.render(p)
+    r.close()
+    return sc, p, film, stats
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_render_multi_equals_single_device(gpu_lib, small_s3, devices):
+    sc, p, film, stats = small_s3
+    got, st = render.render_multi(gpu_lib, sc.desc, devices, p)
+    assert np.array_equal(got, film)
+    assert sum(s["rays_closest"] + s["rays_any"] for s in st) == stats["rays_closest"] + stats["rays_any"]
+    assert sum(s["paths"] for s in st) == 160 * 104 * 6
+    if len(devices) > 1:
+        assert all(s["paths"] > 0 for s in st)  # every replica rendered a share
+        moved = sum(s["gather_bytes"] for s in st)
+        own0 = render.shard_tiles(13 * 20, 20, 0, len(devices))
+        assert moved == (160 * 104 - sum(64 for _ in own0)) * 32  # every row the root does not own travelled exactly once
+
+
+def test_render_multi_equals_oracle(gpu_lib, small_s3):
+    sc, p, film, _ = small_s3
+    o = oracle_py.Oracle(sc.desc)
+    ref, _ = o.render(p, n_threads=os.cpu_count() or 4)
+    o.close()
+    got, _ = render.render_multi(gpu_lib, sc.desc, [0, 0], p)
+    assert np.array_equal(got, ref)
+
+
+def test_render_multi_rejects_bad_arguments(gpu_lib, small_s3):
+    sc, p, _, _ = small_s3
+    with pytest.raises(abi.ShimmerHipError):
+        render.render_multi(gpu_lib, sc.desc, [99], p)  # no such device: reported, nothing unwinds
+    with pytest.raises(abi.ShimmerHipError):
+        render.render_multi(gpu_lib, sc.desc, [], p)
+
+
+def test_dist_world1_rccl_render_and_loopback(gpu_lib, small_s3):
+    """RCCL inside the library: communicator of one rank, shm_render_sharded (== the plain render), and the send / recv group
+    looped back to the rank itself."""
+    sc, p, film, stats = small_s3
+    r = render.Renderer(gpu_lib, sc.desc, device=0)
+    uid = r.dist_unique_id()
+    assert len(uid) == abi.SHM_DIST_ID_BYTES and any(uid)
+    r.dist_init(0, 1, uid)
+    st = r.render_sharded(p)
+    assert np.array_equal(r.read_film(), film)
+    assert st["rays_closest"] == stats["rays_closest"] and st["gather_bytes"] == 0
+    r.dist_selftest()
+    st2 = r.render_sharded(p)  # the communicator survives a second frame
+    assert st2["paths"] == st["paths"] and np.array_equal(r.read_film(), film)
+    abi.check(gpu_lib, gpu_lib.shm_dist_finalize(r.handle), "shm_dist_finalize")
+    r.close()
+
+
+def test_render_sharded_without_communicator_is_the_whole_frame(gpu_lib, small_s3):
+    sc, p, film, _ = small_s3
+    r = render.Renderer(gpu_lib, sc.desc, device=0)
+    r.render_sharded(p)
+    assert np.array_equal(r.read_film(), film)
+    r.close()
+
+
+@pytest.mark.parametrize("rank", [0, 3, 7])
+def test_c5_shaped_shard_matches_oracle(gpu_lib, rank):
+    """BASELINE configs[4] in shape: a 3840x2160 frame (129 600 tiles of 8x8, 480 per row), the shard rank r of 8 owns, 1 spp — the
+    GPU film of those tiles equals the oracle's on the same tile list, and nothing outside them is touched."""
+    sc = scenes.ganesha_proxy(gpu_lib, 3840, 2160, n=32)
+    r = render.Renderer(gpu_lib, sc.desc, device=0)
+    assert r.n_tiles == 129600 and r.tiles_per_row == 480
+    mine = render.shard_tiles(r.n_tiles, r.tiles_per_row, rank, 8, lib=gpu_lib)
+    assert abs(len(mine) - 129600 // 8) <= 480 * 4
+    p = render.make_params(seed=3, spp=1, max_depth=5)
+    r.clear()
+    st = r.render_device(p, mine)
+    film = r.read_film()
+    r.close()
+    assert st["paths"] == len(mine) * 64
+    o = oracle_py.Oracle(sc.desc)
+    sub = (abi.ShmTile * len(mine))(*[r.tiles[int(i)] for i in mine])
+    ref, so = o.render(p, n_threads=os.cpu_count() or 4, tiles=sub, n_tiles=len(mine))
+    o.close()
+    assert np.array_equal(film, ref)
+    assert st["rays_closest"] == so["rays_closest"] and st["nodes_closest"] == so["nodes_closest"] and st["tris_any"] == so["tris_any"]
+    owned = np.zeros((2160, 3840), bool)
+    for i in mine:
+        t = r.tiles[int(i)]
+        owned[t.y0:t.y1, t.x0:t.x1] = True
+    assert (film["weight_sum"][owned] == 1.0).all() and (film["weight_sum"][~owned] == 0.0).all()
+
+
+def test_torch_harness_gather_over_nccl_world1(gpu_lib, small_s3):
+    """The torch.distributed harness (render.gather_film) over backend `nccl` (= RCCL) with one rank: zero-copy view of the HBM film."""
+    import torch
+    import torch.distributed as dist
+    sc, p, film, _ = small_s3
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        r = render.Renderer(gpu_lib, sc.desc, device=0)
+        r.clear()
+        r.render_device(p)
+        total = render.gather_film(render.film_tensor(r, device), 0, 1, r.height, r.width)
+        assert np.array_equal(total, film)
+        r.close()
+    finally:
+        dist.destroy_process_group()

@@ -222,6 +222,10 @@ def test_scene_validation_errors(orc, lib):
     d.materials[0].kind = 9  # e.g. a coated material: SURVEY §8f row, not in the contract
     assert orc.orc_scene_create(C.byref(d), C.byref(h)) == -2
     d.materials[0].kind = keep
+    keep = d.primitives[0].material
+    d.primitives[0].material = 0xffffffff  # the reference's `material: None` (medium interface, skip_intersection): named and rejected
+    assert orc.orc_scene_create(C.byref(d), C.byref(h)) == -2
+    d.primitives[0].material = keep
     keep = d.nodes[0].offset
     d.nodes[0].offset = 10 ** 6
     assert orc.orc_scene_create(C.byref(d), C.byref(h)) == -1
