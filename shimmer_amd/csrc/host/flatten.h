@@ -38,6 +38,8 @@ struct FlatScene {
     float scene_radius = 0.0f;
     bool has_spheres = false;  // any non-triangle shape (sphere or bilinear patch): selects k_trace3<.., TRI_ONLY = false>
     bool has_layered = false;  // any Coated* material: selects the k_shade instantiation that carries LayeredBxDF
+    bool has_class[4] = {false, false, false, false};  // BxDF classes present in the material table (staged shading launches one scatter
+                                                       // kernel per class): 0 diffuse, 1 conductor, 2 dielectric / thin dielectric, 3 coated
     bool diffuse_only = true;  // every material is a DiffuseMaterial: selects the k_shade instantiation with the other BxDFs compiled out
     // image textures (ABI v6)
     std::vector<ShmImageTexture> image_textures;
@@ -513,6 +515,10 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
     for (const ShmMaterial& m : out.materials) {
         if (m.kind > SHM_MATERIAL_MIX) { err = "unsupported material kind"; return SHM_ERR_UNSUPPORTED; }
         if (m.kind != SHM_MATERIAL_DIFFUSE) out.diffuse_only = false;
+        if (m.kind == SHM_MATERIAL_DIFFUSE) out.has_class[0] = true;
+        else if (m.kind == SHM_MATERIAL_CONDUCTOR) out.has_class[1] = true;
+        else if (m.kind == SHM_MATERIAL_DIELECTRIC || m.kind == SHM_MATERIAL_THIN_DIELECTRIC) out.has_class[2] = true;
+        else if (m.kind == SHM_MATERIAL_COATED_DIFFUSE || m.kind == SHM_MATERIAL_COATED_CONDUCTOR) out.has_class[3] = true;
         for (int k = 0; k < 8; ++k)
             if (m.float_tex[k] != 0u) {
                 if (m.float_tex[k] > d->n_float_textures) { err = "material float texture index out of range"; return SHM_ERR_INVALID_ARGUMENT; }

@@ -1,0 +1,250 @@
+// k_scatter.inl — staged shading, second half of a path vertex (integrator.rs:836-892 + sample_ld :897-963), ONE KERNEL PER BxDF CLASS
+// over the class queue k_vertex filled: next-event estimation (light sample, BSDF f and pdf, deferred shadow ray), BSDF::sample_f, the
+// throughput update, Russian roulette and the spawned ray. A wave of k_scatter<CLASS_DIELECTRIC> only ever runs dielectric code, one of
+// k_scatter<CLASS_LAYERED> only the LayeredBxDF random walks: the queues are sorted by material class by construction.
+// The BSDF is rebuilt from the parameter block (PathArrays::bx*, fr, ctx0..2) exactly as get_bsdf left it.
+#pragma once
+#include "wavefront.h"
+
+namespace {
+
+template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
+__device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArrays& pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
+                                             uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, const ShmRenderParams& params, int shadow_parity) {
+    const uint32_t n = qs->n_scatter[CLASS];
+    __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
+    __shared__ uint32_t s_cnt[2], s_base[2];
+    for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
+      if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+      __syncthreads();
+      for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+        const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
+        bool push_next = false, push_shadow = false;
+        uint32_t path = 0;
+        if (i < n) {
+            path = q_cur[i];
+            // ---- the vertex as k_vertex left it ----
+            BSDF bsdf;
+            {
+                BxDF& b = bsdf.bxdf;
+                const float4 p2 = pa.bx2[path];
+                const uint32_t meta = __float_as_uint(p2.w);
+                b.kind = meta & 0xffu;
+                b.max_depth = (int)((meta >> 8) & 0xfffu);
+                b.n_samples = (int)(meta >> 20);
+                b.eta = p2.x;
+                b.mf.alpha_x = p2.y;
+                b.mf.alpha_y = p2.z;
+                b.r = ld_spec(pa.bx0[path]);
+                b.k = (CLASS == CLASS_CONDUCTOR || CLASS == CLASS_LAYERED) ? ld_spec(pa.bx1[path]) : spec_const(0.0f);
+                if (CLASS == CLASS_LAYERED) {
+                    b.albedo = ld_spec(pa.bx3[path]);
+                    const float4 p4 = pa.bx4[path];
+                    b.mf2.alpha_x = p4.x; b.mf2.alpha_y = p4.y; b.thickness = p4.z; b.g = p4.w;
+                } else {
+                    b.albedo = spec_const(0.0f);
+                    b.mf2.alpha_x = 0.0f; b.mf2.alpha_y = 0.0f; b.thickness = 0.0f; b.g = 0.0f;
+                }
+            }
+            // the class is a property of the queue: the dispatch inside bxdf_f / bxdf_pdf / bxdf_sample_f folds to this class's code
+            // (plus DiffuseBxDF, which options.force_diffuse substitutes below)
+            if (CLASS == CLASS_DIFFUSE) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIFFUSE);
+            if (CLASS == CLASS_CONDUCTOR) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_CONDUCTOR);
+            if (CLASS == CLASS_DIELECTRIC) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIELECTRIC || bsdf.bxdf.kind == SHM_MATERIAL_THIN_DIELECTRIC);
+            if (CLASS == CLASS_LAYERED) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_COATED_DIFFUSE || bsdf.bxdf.kind == SHM_MATERIAL_COATED_CONDUCTOR);
+            P3i si_pi;
+            V3 si_n, ns;
+            {
+                const float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path], f = pa.fr[path];
+                si_pi.x = iv2(c0.x, c0.w);
+                si_pi.y = iv2(c0.y, c1.x);
+                si_pi.z = iv2(c0.z, c1.y);
+                si_n = v3(c1.z, c1.w, c2.x);
+                ns = v3(c2.y, c2.z, c2.w);
+                // Frame::from_xz (frame.rs:14-17): y = z cross x
+                bsdf.shading_frame.x = v3(f.x, f.y, f.z);
+                bsdf.shading_frame.z = ns;
+                bsdf.shading_frame.y = cross(ns, bsdf.shading_frame.x);
+            }
+            const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
+            const float4 r0 = rp[0], r1 = rp[1];
+            const V3 wo = -v3(r0.w, r1.x, r1.y);  // li()'s wo = -ray.d (integrator.rs:844)
+            // intr.wo, what sample_ld and get_bsdf use: bitwise -ray.d for a top-level triangle; a quadric or an instanced primitive
+            // builds its interaction in object space and maps it back (sphere.rs:254-270, primitive.rs:165-170), so it is carried
+            V3 si_wo = wo;
+            if (!TRI_ONLY) { const float4 w4 = pa.siwo[path]; si_wo = v3(w4.x, w4.y, w4.z); }
+            Spec beta = ld_spec(pa.beta[path]);
+            Wavelengths lambda;
+            {
+                const float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
+                lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
+            }
+            const uint32_t fl = pa.flags[path];
+            int depth = (int)(fl & 0xffu);
+            bool specular_bounce = (fl >> 8) & 1u;
+            bool any_non_specular_bounces = (fl >> 9) & 1u;
+            Float p_b, eta_scale = pa.pb_eta[path].y;
+            Rng rng;
+            {
+                const uint32_t pix = pa.pixel[path];
+                const uint2 rs = pa.rng[path];
+                rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
+                // inc is a pure function of (pixel, seed): re-derived instead of stored
+                uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
+                h = mix_bits(h ^ (params.seed + 0x9e3779b97f4a7c15ULL));
+                rng.inc = (h << 1u) | 1u;
+            }
+            // options.force_diffuse (interaction.rs:256-275) draws inside get_bsdf, i.e. before anything else of this half
+            if (params.force_diffuse) {
+                Float uc = sampler_get_1d(rng);
+                V2 u2f = sampler_get_2d(rng);
+                bsdf_force_diffuse(bsdf, si_wo, uc, u2f);
+            }
+            if (params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
+            bool alive = true;
+            depth += 1;
+            // integrator.rs:837-841 + 897-963: next-event estimation; the visibility test is deferred to K3
+            const uint32_t bf = bsdf_flags(bsdf);
+            if (flags_is_non_specular(bf)) {
+                LightSampleContext ctx;
+                ctx.pi = si_pi; ctx.n = si_n; ctx.ns = ns;
+                if (flags_is_reflective(bf) && !flags_is_transmissive(bf)) ctx.pi = p3i_exact(offset_ray_origin(si_pi, si_n, si_wo));
+                else if (flags_is_transmissive(bf) && !flags_is_reflective(bf)) ctx.pi = p3i_exact(offset_ray_origin(si_pi, si_n, -si_wo));
+                Float u = sampler_get_1d(rng);
+                Float p_sel = 0.0f;
+                int li = light_sampler_sample(sv, u, p_sel);
+                V2 u_light = sampler_get_2d(rng);
+                if (li >= 0) {
+                    const ShmLight& light = sv.lights[li];
+                    LightLiSample ls;
+                    if (light_sample_li<TRI_ONLY, HAS_TEX>(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
+                        V3 wi = ls.wi;
+                        Spec f = bsdf_f(bsdf, si_wo, wi) * abs_dot(wi, ns);
+                        if (!is_zero(f)) {
+                            Ray sr = spawn_ray_to_both_offset(si_pi, si_n, ls.p_light_pi, ls.p_light_n);
+                            Float p_l = p_sel * ls.pdf;
+                            Spec ld;
+                            if (light_is_delta(light)) {
+                                ld = ls.l * f / p_l;
+                            } else {
+                                Float pb2 = bsdf_pdf(bsdf, si_wo, wi, REFLTRANS_ALL);
+                                Float w_l = power_heuristic(1, p_l, 1, pb2);
+                                ld = w_l * ls.l * f / p_l;
+                            }
+                            ShmRay s;
+                            s.o[0] = sr.o.x; s.o[1] = sr.o.y; s.o[2] = sr.o.z;
+                            s.d[0] = sr.d.x; s.d[1] = sr.d.y; s.d[2] = sr.d.z;
+                            s.t_max = 1.0f - 0.0001f;  // 1 - SHADOW_EPSILON, integrator.rs:66,115
+                            s.pad = 0.0f;
+                            pa.shadow_ray[path] = s;
+                            pa.shadow_contrib[path] = st_spec(beta * ld);
+                            push_shadow = true;
+                        }
+                    }
+                }
+            }
+            // integrator.rs:843-857: sample the BSDF
+            Float u = sampler_get_1d(rng);
+            V2 u2 = sampler_get_2d(rng);
+            BSDFSample bs;
+            if (!bsdf_sample_f(bsdf, wo, u, u2, REFLTRANS_ALL, bs)) {
+                alive = false;
+            } else {
+                // integrator.rs:859-872
+                beta = beta * (bs.f * abs_dot(bs.wi, ns) / bs.pdf);
+                p_b = bs.pdf_is_proportional ? bsdf_pdf(bsdf, wo, bs.wi, REFLTRANS_ALL) : bs.pdf;
+                specular_bounce = flags_is_specular(bs.flags);
+                any_non_specular_bounces |= !specular_bounce;
+                if (flags_is_transmissive(bs.flags)) eta_scale *= sqr(bs.eta);
+                V3 no = offset_ray_origin(si_pi, si_n, bs.wi);  // integrator.rs:875 -> interaction.rs:68-75
+                // integrator.rs:878-891: Russian roulette
+                if (is_finite(eta_scale)) {
+                    Spec rr_beta = beta * eta_scale;
+                    if (max_component_value(rr_beta) < 1.0f && depth > 1) {
+                        Float q = max(0.0f, 1.0f - max_component_value(rr_beta));
+                        if (sampler_get_1d(rng) < q) alive = false;
+                        else beta = beta / (1.0f - q);
+                    }
+                }
+                if (alive) {
+                    ShmRay nr;
+                    nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z;
+                    nr.d[0] = bs.wi.x; nr.d[1] = bs.wi.y; nr.d[2] = bs.wi.z;
+                    nr.t_max = infinity();
+                    nr.pad = 0.0f;
+                    pa.ray[path] = nr;
+                    pa.beta[path] = st_spec(beta);
+                    pa.pb_eta[path] = make_float2(p_b, eta_scale);
+                    // (ctx0..2 already hold this vertex's context: the next vertex's prev_intr_ctx)
+                    pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                    uint32_t aux_bit = 0u;
+                    if (HAS_TEX && CLASS != CLASS_DIFFUSE && (fl & (1u << 10)) &&
+                        (bs.flags == BXDF_SPECULAR_REFLECTION || bs.flags == BXDF_SPECULAR_TRANSMISSION)) {
+                        // spawn_ray_with_differentials, interaction.rs:430-514 (only specular bounces carry differentials on)
+                        const float4 d0 = pa.dd0[path], d1 = pa.dd1[path], d2 = pa.dd2[path];
+                        AuxRays na = spawn_ray_differentials_pre(si_pi.mid(), si_wo, ns, v3(d0.x, d0.y, d0.z), v3(d0.w, d1.x, d1.y), v3(d1.z, d1.w, d2.x),
+                                                                 v3(d2.y, d2.z, d2.w), ld_aux(pa, path), bs.wi, bs.flags, bs.eta);
+                        if (na.has) { st_aux(pa, path, na); aux_bit = 1u << 10; }
+                    }
+                    pa.flags[path] = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9) | aux_bit;
+                    push_next = true;
+                }
+            }
+        }
+        // stage the queue entries of this chunk in LDS (wave-aggregated LDS atomics)
+        uint32_t s1 = queue_push_slot(&s_cnt[0], push_next);
+        if (push_next) s_next[s1] = path;
+        uint32_t s2 = queue_push_slot(&s_cnt[1], push_shadow);
+        if (push_shadow) s_shadow[s2] = path;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+          s_base[0] = s_cnt[0] ? atomicAdd(&qs->n_active[cur ^ 1], s_cnt[0]) : 0u;
+          s_base[1] = s_cnt[1] ? atomicAdd(&qs->n_shadow[shadow_parity], s_cnt[1]) : 0u;
+      }
+      __syncthreads();
+      for (uint32_t j = threadIdx.x; j < s_cnt[0]; j += SHADE2_BLOCK) q_next[s_base[0] + j] = s_next[j];
+      for (uint32_t j = threadIdx.x; j < s_cnt[1]; j += SHADE2_BLOCK) q_shadow[s_base[1] + j] = s_shadow[j];
+      __syncthreads();
+    }
+}
+
+// two waves per SIMD (<= 256 VGPRs): every class fits without spilling except the LayeredBxDF walks ...
+template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
+__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_scatter(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
+                                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
+                                                                      int shadow_parity) {
+    scatter_body<CLASS, TRI_ONLY, HAS_TEX>(sv, pa, q_cur, q_next, q_shadow, qs, cur, params, shadow_parity);
+}
+// ... which get one wave per SIMD and the whole 512-entry unified register file instead of 586 spilled VGPRs (SHM_LAYERED_WAVES=2 selects
+// the two-wave build for A/B runs)
+template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
+__global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) k_scatter_w1(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur,
+                                                                                                         uint32_t* __restrict__ q_next, uint32_t* __restrict__ q_shadow,
+                                                                                                         QueueState* qs, int cur, ShmRenderParams params, int shadow_parity) {
+    scatter_body<CLASS, TRI_ONLY, HAS_TEX>(sv, pa, q_cur, q_next, q_shadow, qs, cur, params, shadow_parity);
+}
+
+}  // namespace
+
+#define WF_SCATTER_LAUNCH(CLASS, TRI, TEX)                                                                                                      \
+    do {                                                                                                                                        \
+        hipLaunchKernelGGL((k_scatter<CLASS, TRI, TEX>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_scatter[CLASS], \
+                           s->d_q_active[a.cur ^ 1], s->d_q_shadow, s->d_qs, a.cur, a.params, a.shadow_parity);                                \
+        LAUNCH_TRY("k_scatter");                                                                                                                \
+    } while (0)
+#define WF_SCATTER_LAUNCH_W1(CLASS, TRI, TEX)                                                                                                   \
+    do {                                                                                                                                        \
+        hipLaunchKernelGGL((k_scatter_w1<CLASS, TRI, TEX>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_scatter[CLASS], \
+                           s->d_q_active[a.cur ^ 1], s->d_q_shadow, s->d_qs, a.cur, a.params, a.shadow_parity);                                \
+        LAUNCH_TRY("k_scatter_w1");                                                                                                             \
+    } while (0)
+static inline bool layered_two_waves() { static int v = -1; if (v < 0) { const char* e = getenv("SHM_LAYERED_WAVES"); v = (e && atoi(e) == 2) ? 1 : 0; } return v == 1; }
+// the three scene classes every BxDF class is instantiated for
+#define WF_SCATTER_DISPATCH(CLASS)                                                  \
+    do {                                                                            \
+        if (has_tex) WF_SCATTER_LAUNCH(CLASS, false, true);                         \
+        else if (tri_only) WF_SCATTER_LAUNCH(CLASS, true, false);                   \
+        else WF_SCATTER_LAUNCH(CLASS, false, false);                                \
+    } while (0)

@@ -1,0 +1,149 @@
+// k_vertex.inl — staged shading, first half of a path vertex (integrator.rs:772-834 for the vertex K2 found): escaped rays and
+// infinite lights, the interaction, emission with its MIS weight, get_bsdf (compute_differentials, MixMaterial resolution, bump /
+// normal maps, every texture evaluation -> the BxDF's parameters) and the depth test. What survives is written as a parameter block
+// (PathArrays::bx*, fr, ctx0..2) and pushed to the queue of its BxDF CLASS, so that the second half (k_scatter.inl: NEE, sample_f,
+// Russian roulette) runs one kernel per class over material-sorted, wave-coherent queues (north star: "wavefront-sorted queues";
+// SURVEY K5). Neither half holds the other's live state: the fused kernel of round 1 spilled up to 942 VGPRs in its general
+// instantiations. The arithmetic of a path is the fused kernel's, operation for operation: films stay bit-identical.
+#pragma once
+#include "wavefront.h"
+
+namespace {
+
+template <bool TRI_ONLY, bool HAS_TEX>
+__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_vertex(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* q_s0, uint32_t* q_s1,
+                                                                     uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, ShmRenderParams params) {
+    const uint32_t n = qs->n_active[cur];
+    __shared__ uint32_t s_q[N_BXDF_CLASSES][SHADE_CHUNK];
+    __shared__ uint32_t s_cnt[N_BXDF_CLASSES], s_base[N_BXDF_CLASSES];
+    uint32_t* const q_out[N_BXDF_CLASSES] = {q_s0, q_s1, q_s2, q_s3};
+    for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
+      if (threadIdx.x < N_BXDF_CLASSES) s_cnt[threadIdx.x] = 0;
+      __syncthreads();
+      for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+        const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
+        int push_class = -1;
+        uint32_t path = 0;
+        if (i < n) {
+            path = q_cur[i];
+            const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
+            float4 h0 = hp[0], h1 = hp[1];
+            Hit hit;
+            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
+            const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
+            float4 r0 = rp[0], r1 = rp[1];
+            V3 ray_d = v3(r0.w, r1.x, r1.y);
+            auto add_l = [&](const Spec& c) { pa.L[path] = st_spec(ld_spec(pa.L[path]) + c); };
+            Wavelengths lambda;
+            float4 pdf_in;
+            {
+                float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                pdf_in = b;
+                lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
+                lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
+            }
+            const uint32_t fl = pa.flags[path];
+            const int depth = (int)(fl & 0xffu);
+            const bool specular_bounce = (fl >> 8) & 1u;
+            // beta, p_b and the previous vertex's context are only needed when something is emitted towards the path
+            auto load_prev_ctx = [&]() {
+                LightSampleContext c;
+                float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path];
+                c.pi.x = iv2(c0.x, c0.w);
+                c.pi.y = iv2(c0.y, c1.x);
+                c.pi.z = iv2(c0.z, c1.y);
+                c.n = v3(c1.z, c1.w, c2.x);
+                c.ns = v3(c2.y, c2.z, c2.w);
+                return c;
+            };
+            auto emit = [&](const Spec& le, const ShmLight& light) {  // integrator.rs:779-792 / 802-812
+                Spec beta = ld_spec(pa.beta[path]);
+                if (depth == 0 || specular_bounce) {
+                    add_l(beta * le);
+                } else {
+                    Float p_b = pa.pb_eta[path].x;
+                    Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
+                    Float w = power_heuristic(1, p_b, 1, p_l);
+                    add_l(beta * w * le);
+                }
+            };
+            if (hit.prim < 0) {
+                // integrator.rs:776-794: escaped ray, infinite lights
+                for (uint32_t li = 0; li < sv.n_infinite_lights; ++li) {
+                    const ShmLight& light = sv.lights[sv.infinite_lights[li]];
+                    emit(infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda), light);
+                }
+            } else {
+                SurfaceInteraction si = hit_interaction<TRI_ONLY>(sv, hit, -ray_d);
+                const ShmPrimitive prim = sv.primitives[hit.prim];
+                // integrator.rs:798-813: emission at the hit
+                if (prim.area_light >= 0) {
+                    const ShmLight& light = sv.lights[prim.area_light];
+                    Spec le = area_light_l(sv, light, si.n, -ray_d, lambda);
+                    if (!is_zero(le)) emit(le, light);
+                }
+                // get_bsdf starts with compute_differentials(ray, camera, spp) (interaction.rs:197)
+                Differentials df;
+                if (HAS_TEX) {
+                    AuxRays aux = aux_none();
+                    if (fl & (1u << 10)) aux = ld_aux(pa, path);
+                    df = compute_differentials(sv, si, aux, params.samples_per_pixel, params.disable_pixel_jitter != 0, params.disable_texture_filtering != 0);
+                }
+                BSDF bsdf = get_bsdf<HAS_TEX>(sv, si, sv.materials[prim.material], lambda, &df);
+                if (depth != params.max_depth) {  // integrator.rs:830-834
+                    const BxDF& b = bsdf.bxdf;
+                    pa.bx0[path] = st_spec(b.r);
+                    if (pa.bx1) pa.bx1[path] = st_spec(b.k);
+                    pa.bx2[path] = make_float4(b.eta, b.mf.alpha_x, b.mf.alpha_y,
+                                               __uint_as_float(b.kind | ((uint32_t)b.max_depth << 8) | ((uint32_t)b.n_samples << 20)));
+                    if (pa.bx3) {
+                        pa.bx3[path] = st_spec(b.albedo);
+                        pa.bx4[path] = make_float4(b.mf2.alpha_x, b.mf2.alpha_y, b.thickness, b.g);
+                    }
+                    const V3 fx = bsdf.shading_frame.x;
+                    pa.fr[path] = make_float4(fx.x, fx.y, fx.z, 0.0f);
+                    if (!TRI_ONLY) pa.siwo[path] = make_float4(si.wo.x, si.wo.y, si.wo.z, 0.0f);  // differs from -ray.d for quadrics / instances
+                    // this vertex's LightSampleContext (light.rs:1001-1009): the scatter half's geometry, and the next vertex's prev_intr_ctx
+                    pa.ctx0[path] = make_float4(si.pi.x.low, si.pi.y.low, si.pi.z.low, si.pi.x.high);
+                    pa.ctx1[path] = make_float4(si.pi.y.high, si.pi.z.high, si.n.x, si.n.y);
+                    pa.ctx2[path] = make_float4(si.n.z, si.shading.n.x, si.shading.n.y, si.shading.n.z);
+                    if (HAS_TEX) {  // the surface part of spawn_ray_with_differentials (interaction.rs:436-440)
+                        V3 dndx = si.shading.dndu * df.dudx + si.shading.dndv * df.dvdx;
+                        V3 dndy = si.shading.dndu * df.dudy + si.shading.dndv * df.dvdy;
+                        pa.dd0[path] = make_float4(df.dpdx.x, df.dpdx.y, df.dpdx.z, df.dpdy.x);
+                        pa.dd1[path] = make_float4(df.dpdy.y, df.dpdy.z, dndx.x, dndx.y);
+                        pa.dd2[path] = make_float4(dndx.z, dndy.x, dndy.y, dndy.z);
+                    }
+                    push_class = bxdf_class_of(b.kind);
+                }
+                // terminate_secondary may have changed the pdfs (material.rs:609-619): written back only then
+                if (lambda.pdf[1] != pdf_in.y || lambda.pdf[2] != pdf_in.z || lambda.pdf[3] != pdf_in.w || lambda.pdf[0] != pdf_in.x)
+                    pa.lambda_pdf[path] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
+            }
+        }
+        // stage the class queues of this chunk in LDS (wave-aggregated LDS atomics), material-sorted by construction
+#pragma unroll
+        for (int c = 0; c < N_BXDF_CLASSES; ++c) {
+            const bool mine = push_class == c;
+            uint32_t slot = queue_push_slot(&s_cnt[c], mine);
+            if (mine) s_q[c][slot] = path;
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < N_BXDF_CLASSES) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&qs->n_scatter[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < N_BXDF_CLASSES; ++c)
+          for (uint32_t j = threadIdx.x; j < s_cnt[c]; j += SHADE2_BLOCK) q_out[c][s_base[c] + j] = s_q[c][j];
+      __syncthreads();
+    }
+}
+
+}  // namespace
+
+#define WF_VERTEX_LAUNCH(TRI, TEX)                                                                                                             \
+    do {                                                                                                                                       \
+        hipLaunchKernelGGL((k_vertex<TRI, TEX>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur],          \
+                           s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params);              \
+        LAUNCH_TRY("k_vertex");                                                                                                                \
+    } while (0)

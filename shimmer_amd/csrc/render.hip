@@ -94,12 +94,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
         qs->n_active[1] = 0;
         qs->n_shadow[0] = 0;
         qs->n_shadow[1] = 0;
+        qs->n_scatter[0] = qs->n_scatter[1] = qs->n_scatter[2] = qs->n_scatter[3] = 0;
     }
 }
 
 // Between bounces: recycle the counters (1 thread).
 __global__ void k_next_bounce(QueueState* qs, int cur, int next_shadow_parity) {
     qs->n_active[cur] = 0;
+    qs->n_scatter[0] = qs->n_scatter[1] = qs->n_scatter[2] = qs->n_scatter[3] = 0;
     qs->n_shadow[next_shadow_parity] = 0;  // the one the NEXT shade launch fills; this bounce's count stays for its K3
 }
 // ---------------------------------------------------------------------------------------------
@@ -170,8 +172,30 @@ static uint64_t max_batch_paths() {
 
 // The batch limit on THIS device right now: SHM_BATCH_PATHS, bounded by 80 % of the memory that is free (plus what the
 // current workspace already holds), so that a GPU shared with other allocations degrades to more batches, not to an error.
+// staged shading (k_vertex -> k_scatter<class>): everything but all-diffuse triangle scenes without textures, which keep the fused kernel
+// (one BxDF class: nothing to sort, and the parameter block would be pure traffic). SHM_FUSED=1 runs the fused kernels of round 1
+// everywhere (A/B measurements); options.force_diffuse always takes the staged path.
+static bool scene_is_lean(const ShmScene* s) { return !s->flat.has_spheres && s->flat.diffuse_only && !s->flat.has_textures; }
+static bool use_staged(const ShmScene* s, const ShmRenderParams* params) {
+    if (params->integrator != SHM_INTEGRATOR_PATH) return false;
+    static int fused = -1;
+    if (fused < 0) fused = (getenv("SHM_FUSED") && atoi(getenv("SHM_FUSED")) != 0) ? 1 : 0;
+    if (fused) return false;
+    return !scene_is_lean(s) || params->force_diffuse != 0;
+}
+static uint64_t staging_bytes_per_path(const ShmScene* s) {
+    const shm_host::FlatScene& f = s->flat;
+    uint64_t b = 16 * 3;  // bx0, bx2, fr
+    if (f.has_class[CLASS_CONDUCTOR] || f.has_class[CLASS_LAYERED]) b += 16;  // bx1
+    if (f.has_class[CLASS_LAYERED]) b += 32;                                   // bx3, bx4
+    if (f.has_spheres) b += 16;                                                // siwo
+    if (f.has_textures) b += 48;                                               // dd0..2
+    for (int c = 0; c < N_BXDF_CLASSES; ++c) if (f.has_class[c]) b += 4;       // class queues
+    return b;
+}
 static uint64_t workspace_cap(const ShmScene* s) {
-    const uint64_t BYTES_PER_PATH = 264 + 3 * 4 + (s->flat.has_textures ? 48 : 0);  // path state + three queues (+ auxiliary rays)
+    // path state + three queues (+ auxiliary rays) (+ the staging arrays of every scene class but the lean one)
+    const uint64_t BYTES_PER_PATH = 264 + 3 * 4 + (s->flat.has_textures ? 48 : 0) + ((s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
     uint64_t cap = max_batch_paths();
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -182,12 +206,14 @@ static uint64_t workspace_cap(const ShmScene* s) {
     return std::max<uint64_t>(cap, 4096);
 }
 
-int ensure_workspace(ShmScene* s, uint64_t needed_paths) {
+int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
     uint64_t max_cap = workspace_cap(s);
     uint64_t want = std::min<uint64_t>(std::max<uint64_t>(needed_paths, 4096), max_cap);
     want = (want + 4095ull) & ~4095ull;
     if (want > 0xfffff000ull) want = 0xfffff000ull;
-    if (s->capacity >= want) return SHM_OK;
+    need_staged = need_staged || s->ws_staged || !scene_is_lean(s);
+    if (s->capacity >= want && (s->ws_staged || !need_staged)) return SHM_OK;
+    want = std::max<uint64_t>(want, s->capacity);
     for (void* p : s->ws_allocs) hipFree(p);
     s->ws_allocs.clear();
     s->capacity = 0;
@@ -206,6 +232,20 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths) {
     WS(rng, uint2); WS(pixel, uint32_t); WS(flags, uint32_t);
     s->pa.aux0 = s->pa.aux1 = s->pa.aux2 = nullptr;
     if (s->flat.has_textures) { WS(aux0, float4); WS(aux1, float4); WS(aux2, float4); }
+    s->pa.bx0 = s->pa.bx1 = s->pa.bx2 = s->pa.bx3 = s->pa.bx4 = s->pa.fr = s->pa.siwo = s->pa.dd0 = s->pa.dd1 = s->pa.dd2 = nullptr;
+    for (int c = 0; c < N_BXDF_CLASSES; ++c) s->d_q_scatter[c] = nullptr;
+    s->ws_staged = false;
+    if (need_staged) {
+        const shm_host::FlatScene& f = s->flat;
+        WS(bx0, float4); WS(bx2, float4); WS(fr, float4);
+        if (f.has_class[CLASS_CONDUCTOR] || f.has_class[CLASS_LAYERED]) WS(bx1, float4);
+        if (f.has_class[CLASS_LAYERED]) { WS(bx3, float4); WS(bx4, float4); }
+        if (f.has_spheres) WS(siwo, float4);
+        if (f.has_textures) { WS(dd0, float4); WS(dd1, float4); WS(dd2, float4); }
+        for (int c = 0; c < N_BXDF_CLASSES; ++c)
+            if (f.has_class[c] && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_scatter[c])) != SHM_OK) return rc;
+        s->ws_staged = true;
+    }
 #undef WS
     if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_active[0])) != SHM_OK) return rc;
     if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_active[1])) != SHM_OK) return rc;
@@ -424,7 +464,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     const int n_samples = sample_end - sample_begin;
     const bool random_walk = params->integrator == SHM_INTEGRATOR_RANDOM_WALK;
     // (the random walk keeps 32 B per depth per path beside the path state: its batches are capped at 16 Mi paths)
-    if ((rc = ensure_workspace(s, random_walk ? std::min<uint64_t>(n_pixels * (uint64_t)n_samples, 1ull << 24) : n_pixels * (uint64_t)n_samples)) != SHM_OK) return rc;
+    const bool staged = use_staged(s, params);
+    if ((rc = ensure_workspace(s, random_walk ? std::min<uint64_t>(n_pixels * (uint64_t)n_samples, 1ull << 24) : n_pixels * (uint64_t)n_samples, staged)) != SHM_OK) return rc;
     uint32_t cap_eff = random_walk ? std::min<uint32_t>(s->capacity, 1u << 24) : s->capacity;  // paths per batch
     if (random_walk) {
         // 32 B per depth per path (up to 8 KB per path at max_depth 254): shrink the batch until the records fit in 80 % of what is free
@@ -481,7 +522,18 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 hipEventRecord(s0, s->stream);
                 const ShadeArgs sa{s->stream, cur, *params, sh, shade_blocks};
                 const bool tri_only = !s->flat.has_spheres;
-                if (random_walk) rc = wf_launch_shade_randomwalk(s, sa, cap_eff);
+                if (staged) {
+                    // hit half (interaction, emission, get_bsdf -> parameter block, class queues), then one scattering kernel per BxDF
+                    // class the scene holds, each over its own material-sorted queue
+                    const bool has_tex = s->flat.has_textures;
+                    rc = has_tex ? wf_launch_vertex_tex(s, sa) : (tri_only ? wf_launch_vertex_tri(s, sa) : wf_launch_vertex_gen(s, sa));
+                    if (rc == SHM_OK && s->flat.has_class[CLASS_DIFFUSE]) rc = wf_launch_scatter_diffuse(s, sa, tri_only, has_tex);
+                    if (rc == SHM_OK && s->flat.has_class[CLASS_CONDUCTOR]) rc = wf_launch_scatter_conductor(s, sa, tri_only, has_tex);
+                    if (rc == SHM_OK && s->flat.has_class[CLASS_DIELECTRIC]) rc = wf_launch_scatter_dielectric(s, sa, tri_only, has_tex);
+                    if (rc == SHM_OK && s->flat.has_class[CLASS_LAYERED])
+                        rc = has_tex ? wf_launch_scatter_layered_tex(s, sa) : (tri_only ? wf_launch_scatter_layered_tri(s, sa) : wf_launch_scatter_layered_gen(s, sa));
+                }
+                else if (random_walk) rc = wf_launch_shade_randomwalk(s, sa, cap_eff);
                 else if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH) rc = wf_launch_shade_simple(s, sa);
                 else if (s->flat.has_textures || params->force_diffuse)  // the general instantiations (textures, image lights, force_diffuse)
                     rc = s->flat.has_layered ? wf_launch_shade_tex_layered(s, sa) : wf_launch_shade_tex(s, sa);

@@ -128,37 +128,36 @@ SHM_HD Differentials compute_differentials(const SceneView& sv, const SurfaceInt
     return r;
 }
 
-// interaction.rs:430-514: the auxiliary rays of the ray spawned towards wi (the main ray is interaction.spawn_ray(wi) as before)
-SHM_HD AuxRays spawn_ray_differentials(const SurfaceInteraction& si, const Differentials& df, const AuxRays& aux_i, V3 wi, uint32_t flags, Float eta) {
+// interaction.rs:430-514: the auxiliary rays of the ray spawned towards wi (the main ray is interaction.spawn_ray(wi) as before).
+// _pre takes the surface part (p, wo, shading normal, dp/dx, dp/dy and the normal derivatives dn/dx = dndu du/dx + dndv dv/dx,
+// interaction.rs:436-440) as values: the staged shading computes it where the interaction lives and uses it one kernel later.
+SHM_HD AuxRays spawn_ray_differentials_pre(V3 p, V3 wo, V3 n, V3 dpdx, V3 dpdy, V3 dndx, V3 dndy, const AuxRays& aux_i, V3 wi, uint32_t flags, Float eta) {
     AuxRays rd = aux_none();
     if (aux_i.has) {
-        V3 n = si.shading.n;
-        V3 dndx = si.shading.dndu * df.dudx + si.shading.dndv * df.dvdx;
-        V3 dndy = si.shading.dndu * df.dudy + si.shading.dndv * df.dvdy;
-        V3 dwodx = -aux_i.rx_d - si.wo;
-        V3 dwody = -aux_i.ry_d - si.wo;
+        V3 dwodx = -aux_i.rx_d - wo;
+        V3 dwody = -aux_i.ry_d - wo;
         if (flags == BXDF_SPECULAR_REFLECTION) {
             rd.has = true;
-            rd.rx_o = si.p() + df.dpdx;
-            rd.ry_o = si.p() + df.dpdy;
-            Float dwo_dotn_dx = dot(dwodx, n) + dot(si.wo, dndx);
-            Float dwo_dotn_dy = dot(dwody, n) + dot(si.wo, dndy);
-            rd.rx_d = wi - dwodx + 2.0f * (dot(si.wo, n) * dndx + dwo_dotn_dx * n);
-            rd.ry_d = wi - dwody + 2.0f * (dot(si.wo, n) * dndy + dwo_dotn_dy * n);
+            rd.rx_o = p + dpdx;
+            rd.ry_o = p + dpdy;
+            Float dwo_dotn_dx = dot(dwodx, n) + dot(wo, dndx);
+            Float dwo_dotn_dy = dot(dwody, n) + dot(wo, dndy);
+            rd.rx_d = wi - dwodx + 2.0f * (dot(wo, n) * dndx + dwo_dotn_dx * n);
+            rd.ry_d = wi - dwody + 2.0f * (dot(wo, n) * dndy + dwo_dotn_dy * n);
         } else if (flags == BXDF_SPECULAR_TRANSMISSION) {
             rd.has = true;
-            rd.rx_o = si.p() + df.dpdx;
-            rd.ry_o = si.p() + df.dpdy;
-            if (dot(si.wo, n) < 0.0f) {
+            rd.rx_o = p + dpdx;
+            rd.ry_o = p + dpdy;
+            if (dot(wo, n) < 0.0f) {
                 n = -n;
                 dndx = -dndx;
                 dndy = -dndy;
             }
-            Float dwo_dotn_dx = dot(dwodx, n) + dot(si.wo, dndx);
-            Float dwo_dotn_dy = dot(dwody, n) + dot(si.wo, dndy);
-            Float mu = dot(si.wo, n) / eta - abs_dot(wi, n);
-            Float dmudx = dwo_dotn_dx * (1.0f / eta + 1.0f / sqr(eta) * dot(si.wo, n) / dot(wi, n));
-            Float dmudy = dwo_dotn_dy * (1.0f / eta + 1.0f / sqr(eta) * dot(si.wo, n) / dot(wi, n));
+            Float dwo_dotn_dx = dot(dwodx, n) + dot(wo, dndx);
+            Float dwo_dotn_dy = dot(dwody, n) + dot(wo, dndy);
+            Float mu = dot(wo, n) / eta - abs_dot(wi, n);
+            Float dmudx = dwo_dotn_dx * (1.0f / eta + 1.0f / sqr(eta) * dot(wo, n) / dot(wi, n));
+            Float dmudy = dwo_dotn_dy * (1.0f / eta + 1.0f / sqr(eta) * dot(wo, n) / dot(wi, n));
             rd.rx_d = wi - eta * dwodx + (mu * dndx + dmudx * n);
             rd.ry_d = wi - eta * dwody + (mu * dndy + dmudy * n);
         }
@@ -167,6 +166,11 @@ SHM_HD AuxRays spawn_ray_differentials(const SurfaceInteraction& si, const Diffe
                    length_squared(rd.ry_o) > 1e16f))
         rd.has = false;
     return rd;
+}
+SHM_HD AuxRays spawn_ray_differentials(const SurfaceInteraction& si, const Differentials& df, const AuxRays& aux_i, V3 wi, uint32_t flags, Float eta) {
+    V3 dndx = si.shading.dndu * df.dudx + si.shading.dndv * df.dvdx;
+    V3 dndy = si.shading.dndu * df.dudy + si.shading.dndv * df.dvdy;
+    return spawn_ray_differentials_pre(si.p(), si.wo, si.shading.n, df.dpdx, df.dpdy, dndx, dndy, aux_i, wi, flags, eta);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -57,7 +57,7 @@ struct QueueState {
     uint32_t n_active[2];   // entries in q_active[0/1]
     uint32_t n_shadow[2];   // entries in q_shadow, double-buffered by bounce parity: K3 of bounce b may still be reading its count
                             // while the counters of bounce b+1 are recycled (K3(b) overlaps K2(b+1) on a second stream)
-    uint32_t pad[4];
+    uint32_t n_scatter[4];  // staged shading: entries in q_scatter[class], filled by k_vertex, drained by k_scatter<class>
 };
 
 // Path state, structure of arrays (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
@@ -81,7 +81,25 @@ struct PathArrays {
     float4* aux0;           // rx_origin.xyz, rx_direction.x
     float4* aux1;           // rx_direction.yz, ry_origin.xy
     float4* aux2;           // ry_origin.z, ry_direction.xyz
+    // staged shading (k_vertex -> k_scatter<class>; null when the scene runs the fused kernel): the BxDF parameter block get_bsdf
+    // left at this vertex and the x axis of its shading frame. The rest of the vertex geometry (pi, n, ns) is ctx0..2, which
+    // k_vertex overwrites with THIS vertex's LightSampleContext once the previous one has served the emitter MIS weight.
+    float4* bx0;            // r[4]: reflectance (Diffuse, CoatedDiffuse) / conductor eta (Conductor, CoatedConductor)
+    float4* bx1;            // k[4]: conductor absorption (scenes with conductors or coated materials)
+    float4* bx2;            // eta, alpha_x, alpha_y, kind | max_depth << 8 | n_samples << 20 (as bits)
+    float4* bx3;            // albedo[4]                         (scenes with coated materials)
+    float4* bx4;            // alpha_x2, alpha_y2, thickness, g  (scenes with coated materials)
+    float4* fr;             // shading frame x = normalize(dpdus) (y = z cross x is recomputed; z = ns lives in ctx2)
+    float4* siwo;           // intr.wo (scenes with non-triangle shapes or instances only: elsewhere it is -ray.d bit for bit)
+    // scenes with image textures only: what Igehy's specular differentials need beside the auxiliary rays (interaction.rs:430-514)
+    float4* dd0;            // dpdx.xyz, dpdy.x
+    float4* dd1;            // dpdy.yz, dndx.xy
+    float4* dd2;            // dndx.z, dndy.xyz
 };
+enum : int { CLASS_DIFFUSE = 0, CLASS_CONDUCTOR = 1, CLASS_DIELECTRIC = 2, CLASS_LAYERED = 3, N_BXDF_CLASSES = 4 };
+__host__ __device__ inline int bxdf_class_of(uint32_t kind) {
+    return kind == SHM_MATERIAL_DIFFUSE ? CLASS_DIFFUSE : (kind == SHM_MATERIAL_CONDUCTOR ? CLASS_CONDUCTOR : (kind <= SHM_MATERIAL_THIN_DIELECTRIC ? CLASS_DIELECTRIC : CLASS_LAYERED));
+}
 
 __device__ __forceinline__ AuxRays ld_aux(const PathArrays& pa, uint32_t path) {
     float4 a = pa.aux0[path], b = pa.aux1[path], c = pa.aux2[path];
@@ -144,6 +162,9 @@ struct ShmScene {
     PathArrays pa;
     uint32_t* d_q_active[2] = {nullptr, nullptr};
     uint32_t* d_q_shadow = nullptr;
+    uint32_t* d_q_scatter[4] = {nullptr, nullptr, nullptr, nullptr};  // staged shading: one queue per BxDF class present in the scene
+    bool staged = false;           // the scene class runs k_vertex -> k_scatter<class> (everything but all-diffuse triangle scenes without textures)
+    bool ws_staged = false;        // the workspace holds the staging arrays
     QueueState* d_qs = nullptr;
     DeviceCounters* d_counters = nullptr;
     uint32_t* d_pixels = nullptr;
@@ -205,6 +226,17 @@ WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a, bool tri_o
 WF_INTERNAL int wf_launch_shade_layered(ShmScene* s, const ShadeArgs& a, bool tri_only);                   // <true, TRI_ONLY>
 WF_INTERNAL int wf_launch_shade_tex_layered(ShmScene* s, const ShadeArgs& a);                              // <true, false, true>
 WF_INTERNAL int wf_launch_shade_tex(ShmScene* s, const ShadeArgs& a);                                      // <false, false, true>
+// staged shading (k_vertex_*.hip, k_scatter_*.hip): the hit half of a vertex (interaction, emission + MIS, get_bsdf with its texture
+// evaluation -> BxDF parameter block, pushed to the queue of its BxDF class), then per class the scattering half (NEE, sample_f, RR)
+WF_INTERNAL int wf_launch_vertex_tri(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_vertex_gen(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_vertex_tex(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_scatter_diffuse(ShmScene* s, const ShadeArgs& a, bool tri_only, bool has_tex);
+WF_INTERNAL int wf_launch_scatter_conductor(ShmScene* s, const ShadeArgs& a, bool tri_only, bool has_tex);
+WF_INTERNAL int wf_launch_scatter_dielectric(ShmScene* s, const ShadeArgs& a, bool tri_only, bool has_tex);
+WF_INTERNAL int wf_launch_scatter_layered_tri(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_scatter_layered_gen(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_scatter_layered_tex(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_simple(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_randomwalk(ShmScene* s, const ShadeArgs& a, uint32_t cap_eff);
 WF_INTERNAL int wf_launch_fold_randomwalk(ShmScene* s, hipStream_t stream, uint32_t cap_eff, uint32_t total);

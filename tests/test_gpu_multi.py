@@ -113,22 +113,40 @@ def test_c5_shaped_shard_matches_oracle(gpu_lib, rank):
     assert (film["weight_sum"][owned] == 1.0).all() and (film["weight_sum"][~owned] == 0.0).all()
 
 
-def test_torch_harness_gather_over_nccl_world1(gpu_lib, small_s3):
-    """The torch.distributed harness (render.gather_film) over backend `nccl` (= RCCL) with one rank: zero-copy view of the HBM film."""
+def _nccl_world1_worker(rank, port, out_path):
+    # a fresh process that imports torch FIRST (torch ships its own HIP runtime: it must be the one the process initialises)
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    sys.path.insert(0, str(root))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
     import torch
     import torch.distributed as dist
-    sc, p, film, _ = small_s3
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
+    from shimmer_amd import abi as abi_, render as render_, scenes as scenes_
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-    try:
-        r = render.Renderer(gpu_lib, sc.desc, device=0)
-        r.clear()
-        r.render_device(p)
-        total = render.gather_film(render.film_tensor(r, device), 0, 1, r.height, r.width)
-        assert np.array_equal(total, film)
-        r.close()
-    finally:
-        dist.destroy_process_group()
+    lib = abi_.load_library()
+    sc = scenes_.ganesha_proxy(lib, 160, 104, n=24)
+    p = render_.make_params(seed=5, spp=6, max_depth=5)
+    r = render_.Renderer(lib, sc.desc, device=0)
+    r.clear()
+    r.render_device(p)
+    total = render_.gather_film(render_.film_tensor(r, device), 0, 1, r.height, r.width)
+    np.save(out_path, total.view(np.float64))
+    r.close()
+    dist.destroy_process_group()
+
+
+def test_torch_harness_gather_over_nccl_world1(gpu_lib, small_s3, tmp_path):
+    """The torch.distributed harness (render.gather_film) over backend `nccl` (= RCCL) with one rank: zero-copy view of the HBM film."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "film.npy"
+    mp.spawn(_nccl_world1_worker, args=(port, str(out)), nprocs=1, join=True)
+    _, _, film, _ = small_s3
+    assert np.array_equal(np.load(out), film.view(np.float64))
