@@ -210,15 +210,16 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
     }
 }
 
-// two waves per SIMD (<= 256 VGPRs): every class fits without spilling except the LayeredBxDF walks ...
+// two waves per SIMD (<= 256 VGPRs): every class fits without spilling except the LayeredBxDF walks (586 spilled VGPRs). Measured on the
+// coated S3 (1024^2 x 64 spp): two waves with the spills 85.6 ms of shading per frame, one wave per SIMD without them (k_scatter_w1,
+// SHM_LAYERED_WAVES=1) 99.2 ms — latency hiding beats the scratch traffic, so two waves stay the default.
 template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_scatter(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                                       uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                                       int shadow_parity) {
     scatter_body<CLASS, TRI_ONLY, HAS_TEX>(sv, pa, q_cur, q_next, q_shadow, qs, cur, params, shadow_parity);
 }
-// ... which get one wave per SIMD and the whole 512-entry unified register file instead of 586 spilled VGPRs (SHM_LAYERED_WAVES=2 selects
-// the two-wave build for A/B runs)
+// one wave per SIMD and the whole 512-entry unified register file: no spills, less latency hiding (see above)
 template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
 __global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) k_scatter_w1(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur,
                                                                                                          uint32_t* __restrict__ q_next, uint32_t* __restrict__ q_shadow,
@@ -240,7 +241,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_
                            s->d_q_active[a.cur ^ 1], s->d_q_shadow, s->d_qs, a.cur, a.params, a.shadow_parity);                                \
         LAUNCH_TRY("k_scatter_w1");                                                                                                             \
     } while (0)
-static inline bool layered_two_waves() { static int v = -1; if (v < 0) { const char* e = getenv("SHM_LAYERED_WAVES"); v = (e && atoi(e) == 2) ? 1 : 0; } return v == 1; }
+static inline bool layered_two_waves() { static int v = -1; if (v < 0) { const char* e = getenv("SHM_LAYERED_WAVES"); v = (e && atoi(e) == 1) ? 0 : 1; } return v == 1; }
 // the three scene classes every BxDF class is instantiated for
 #define WF_SCATTER_DISPATCH(CLASS)                                                  \
     do {                                                                            \

@@ -1,5 +1,5 @@
-// k_shade.inl — the fused K4+K5 kernel template (one path vertex of PathIntegrator::li per launch), included by the k_shade_*.hip
-// translation units, each of which instantiates one scene class.
+// k_shade.inl — the fused K4+K5 kernel template (one whole path vertex of PathIntegrator::li per launch), instantiated by
+// k_shade_lean.hip for the all-diffuse triangle scene class (every other class runs the staged k_vertex -> k_scatter<class>).
 #pragma once
 #include "wavefront.h"
 

@@ -1,9 +1,9 @@
-// k_shade_lean.hip — fused shade kernels of the scene classes without LayeredBxDF and without textures.
+// k_shade_lean.hip — the fused shade kernel of the one scene class that keeps it: triangles only, every material a DiffuseMaterial, no
+// textures (the headline scene class). One BxDF class means there is nothing to sort, and the staged pipeline's parameter block would be
+// pure HBM traffic; every other scene class runs k_vertex -> k_scatter<class> (k_vertex.inl, k_scatter.inl).
 #include "k_shade.inl"
 
-int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a, bool tri_only, bool diffuse_only) {
-    if (tri_only && diffuse_only) WF_SHADE_LAUNCH((k_shade<false, true, false, true>));
-    else if (tri_only) WF_SHADE_LAUNCH((k_shade<false, true>));
-    else WF_SHADE_LAUNCH((k_shade<false, false>));
+int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a) {
+    WF_SHADE_LAUNCH((k_shade<false, true, false, true>));
     return SHM_OK;
 }

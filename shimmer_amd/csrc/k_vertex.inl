@@ -11,8 +11,8 @@
 namespace {
 
 template <bool TRI_ONLY, bool HAS_TEX>
-__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_vertex(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* q_s0, uint32_t* q_s1,
-                                                                     uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, ShmRenderParams params) {
+__device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArrays& pa, const uint32_t* __restrict__ q_cur, uint32_t* q_s0, uint32_t* q_s1,
+                                            uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, const ShmRenderParams& params) {
     const uint32_t n = qs->n_active[cur];
     __shared__ uint32_t s_q[N_BXDF_CLASSES][SHADE_CHUNK];
     __shared__ uint32_t s_cnt[N_BXDF_CLASSES], s_base[N_BXDF_CLASSES];
@@ -139,8 +139,27 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_vertex(SceneView 
     }
 }
 
+template <bool TRI_ONLY, bool HAS_TEX>
+__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_vertex(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* q_s0, uint32_t* q_s1,
+                                                                     uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, ShmRenderParams params) {
+    vertex_body<TRI_ONLY, HAS_TEX>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params);
+}
+// three waves per SIMD (<= 168 VGPRs): the triangle-only instantiation needs 159 and is bound by the latency of its gathers
+template <bool TRI_ONLY, bool HAS_TEX>
+__global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_vertex_w3(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur,
+                                                                                                        uint32_t* q_s0, uint32_t* q_s1, uint32_t* q_s2, uint32_t* q_s3,
+                                                                                                        QueueState* qs, int cur, ShmRenderParams params) {
+    vertex_body<TRI_ONLY, HAS_TEX>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params);
+}
+
 }  // namespace
 
+#define WF_VERTEX_LAUNCH_W3(TRI, TEX)                                                                                                          \
+    do {                                                                                                                                       \
+        hipLaunchKernelGGL((k_vertex_w3<TRI, TEX>), dim3(a.blocks * 3 / 2), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], \
+                           s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params);              \
+        LAUNCH_TRY("k_vertex_w3");                                                                                                             \
+    } while (0)
 #define WF_VERTEX_LAUNCH(TRI, TEX)                                                                                                             \
     do {                                                                                                                                       \
         hipLaunchKernelGGL((k_vertex<TRI, TEX>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur],          \

@@ -173,14 +173,12 @@ static uint64_t max_batch_paths() {
 // The batch limit on THIS device right now: SHM_BATCH_PATHS, bounded by 80 % of the memory that is free (plus what the
 // current workspace already holds), so that a GPU shared with other allocations degrades to more batches, not to an error.
 // staged shading (k_vertex -> k_scatter<class>): everything but all-diffuse triangle scenes without textures, which keep the fused kernel
-// (one BxDF class: nothing to sort, and the parameter block would be pure traffic). SHM_FUSED=1 runs the fused kernels of round 1
-// everywhere (A/B measurements); options.force_diffuse always takes the staged path.
+// (one BxDF class: nothing to sort, and the parameter block would be pure traffic); options.force_diffuse always takes the staged path.
+// (Round-2 A/B against the fused general kernels of round 1, same box: coated S3 1 208 -> 1 724 Mray/s, textured Cornell 768 -> 906,
+// crown-proxy C4 1 758 -> 1 735, Cornell with patches 2 840 -> 2 634: the staged pipeline replaced them everywhere.)
 static bool scene_is_lean(const ShmScene* s) { return !s->flat.has_spheres && s->flat.diffuse_only && !s->flat.has_textures; }
 static bool use_staged(const ShmScene* s, const ShmRenderParams* params) {
     if (params->integrator != SHM_INTEGRATOR_PATH) return false;
-    static int fused = -1;
-    if (fused < 0) fused = (getenv("SHM_FUSED") && atoi(getenv("SHM_FUSED")) != 0) ? 1 : 0;
-    if (fused) return false;
     return !scene_is_lean(s) || params->force_diffuse != 0;
 }
 static uint64_t staging_bytes_per_path(const ShmScene* s) {
@@ -188,7 +186,7 @@ static uint64_t staging_bytes_per_path(const ShmScene* s) {
     uint64_t b = 16 * 3;  // bx0, bx2, fr
     if (f.has_class[CLASS_CONDUCTOR] || f.has_class[CLASS_LAYERED]) b += 16;  // bx1
     if (f.has_class[CLASS_LAYERED]) b += 32;                                   // bx3, bx4
-    if (f.has_spheres) b += 16;                                                // siwo
+    if (f.has_spheres || f.has_textures) b += 16;                              // siwo (the textured kernels are the general ones)
     if (f.has_textures) b += 48;                                               // dd0..2
     for (int c = 0; c < N_BXDF_CLASSES; ++c) if (f.has_class[c]) b += 4;       // class queues
     return b;
@@ -240,7 +238,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
         WS(bx0, float4); WS(bx2, float4); WS(fr, float4);
         if (f.has_class[CLASS_CONDUCTOR] || f.has_class[CLASS_LAYERED]) WS(bx1, float4);
         if (f.has_class[CLASS_LAYERED]) { WS(bx3, float4); WS(bx4, float4); }
-        if (f.has_spheres) WS(siwo, float4);
+        if (f.has_spheres || f.has_textures) WS(siwo, float4);  // every instantiation with TRI_ONLY = false writes it
         if (f.has_textures) { WS(dd0, float4); WS(dd1, float4); WS(dd2, float4); }
         for (int c = 0; c < N_BXDF_CLASSES; ++c)
             if (f.has_class[c] && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_scatter[c])) != SHM_OK) return rc;
@@ -535,10 +533,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 }
                 else if (random_walk) rc = wf_launch_shade_randomwalk(s, sa, cap_eff);
                 else if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH) rc = wf_launch_shade_simple(s, sa);
-                else if (s->flat.has_textures || params->force_diffuse)  // the general instantiations (textures, image lights, force_diffuse)
-                    rc = s->flat.has_layered ? wf_launch_shade_tex_layered(s, sa) : wf_launch_shade_tex(s, sa);
-                else if (s->flat.has_layered) rc = wf_launch_shade_layered(s, sa, tri_only);
-                else rc = wf_launch_shade_lean(s, sa, tri_only, s->flat.diffuse_only && !getenv("SHM_NO_DIFFUSE_ONLY"));
+                else rc = wf_launch_shade_lean(s, sa);
                 if (rc != SHM_OK) return rc;
                 hipEventRecord(s1, s->stream);
                 ev_shade.push_back({s0, s1});

@@ -214,7 +214,7 @@ struct EventPool {
 // k_trace.hip: BvhAggregate::intersect (any = false) / intersect_predicate (any = true) over a queue of path slots
 WF_INTERNAL int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct,
                                 const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib);
-// k_shade_*.hip: one path vertex of PathIntegrator::li for every entry of q_active[cur] (fused kernels, one per scene class)
+// shading of one path vertex of PathIntegrator::li for every entry of q_active[cur]
 struct ShadeArgs {
     hipStream_t stream;
     int cur;
@@ -222,10 +222,7 @@ struct ShadeArgs {
     int shadow_parity;
     int blocks;
 };
-WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a, bool tri_only, bool diffuse_only);  // <false, TRI_ONLY, false, DIFFUSE_ONLY>
-WF_INTERNAL int wf_launch_shade_layered(ShmScene* s, const ShadeArgs& a, bool tri_only);                   // <true, TRI_ONLY>
-WF_INTERNAL int wf_launch_shade_tex_layered(ShmScene* s, const ShadeArgs& a);                              // <true, false, true>
-WF_INTERNAL int wf_launch_shade_tex(ShmScene* s, const ShadeArgs& a);                                      // <false, false, true>
+WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a);  // the fused kernel: all-diffuse triangle scenes without textures
 // staged shading (k_vertex_*.hip, k_scatter_*.hip): the hit half of a vertex (interaction, emission + MIS, get_bsdf with its texture
 // evaluation -> BxDF parameter block, pushed to the queue of its BxDF class), then per class the scattering half (NEE, sample_f, RR)
 WF_INTERNAL int wf_launch_vertex_tri(ShmScene* s, const ShadeArgs& a);

@@ -14,10 +14,14 @@ out = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"k_(trace\d?|shade\w*|generate|film|expand_tiles|next_bounce|reset_heads3)", name)
+    m = re.search(r"k_(trace\d?|shade\w*|vertex|scatter\w*|generate|film|expand_tiles|next_bounce|reset_heads3|fold\w*)", name)
     if not m:
         return name[:48]
     k = m.group(0)
+    if k.startswith("k_scatter") or k.startswith("k_vertex") or k == "k_shade":  # template arguments name the class / scene class
+        t = re.search(r"<([^>]*)>", name)
+        if t:
+            k += "<" + t.group(1).replace("true", "1").replace("false", "0").replace(" ", "") + ">"
     if k.startswith("k_trace"):
         t = re.search(r"k_trace\d?<(\w+)(?:, (\w+))?>", name)
         if t:
