@@ -35,8 +35,6 @@ struct FlatScene {
     ShmCamera camera;
     ShmFilm film;
     uint32_t max_leaf_depth = 0;  // deepest leaf (root = 0); bounds the traversal stack
-    uint32_t stack16_level = 0xffffffffu;  // triangle-only scenes: the first depth at which every subtree has < 65 536 nodes (the traversal
-                                           // kernel's compact LDS stack keeps 16-bit offsets from an anchor node below it); else 0xffffffff
     float scene_radius = 0.0f;
     bool has_spheres = false;  // any non-triangle shape (sphere or bilinear patch): selects k_trace3<.., TRI_ONLY = false>
     bool has_layered = false;  // any Coated* material: selects the k_shade instantiation that carries LayeredBxDF
@@ -584,9 +582,6 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         struct Item { uint32_t node, depth; bool inner; };
         std::vector<Item> st;
         st.push_back({0u, 0u, false});
-        const bool want_sizes = !out.has_spheres && d->n_instances == 0;
-        std::vector<uint8_t> node_depth;
-        if (want_sizes) node_depth.assign(d->n_nodes, 0xffu);
         uint64_t visited = 0;
         const uint64_t visit_cap = (uint64_t)d->n_nodes * (1ull + d->n_instances);
         while (!st.empty()) {
@@ -595,7 +590,6 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
             if (i >= d->n_nodes) { err = "BVH child index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
             if (++visited > visit_cap) { err = "BVH is not a tree"; return SHM_ERR_INVALID_ARGUMENT; }
             const ShmBvhNode& n = d->nodes[i];
-            if (want_sizes) node_depth[i] = (uint8_t)std::min<uint32_t>(depth, 254u);
             if (n.n_prims > 0) {
                 if ((uint64_t)n.offset + n.n_prims > d->n_primitives) { err = "BVH leaf range out of bounds"; return SHM_ERR_INVALID_ARGUMENT; }
                 if (depth > out.max_leaf_depth) out.max_leaf_depth = depth;
@@ -617,22 +611,6 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
                 st.push_back({n.offset, depth + 1, inner});
                 st.push_back({i + 1, depth + 1, inner});
             }
-        }
-        if (want_sizes) {
-            // subtree sizes in one reverse pass (DFS order: both children follow their parent), then the largest subtree per depth
-            std::vector<uint32_t> size(d->n_nodes, 1u);
-            uint32_t max_size[64] = {0};
-            bool ok = true;
-            for (uint32_t i = d->n_nodes; i-- > 0;) {
-                const ShmBvhNode& n = d->nodes[i];
-                if (node_depth[i] == 0xffu) { ok = false; break; }  // a node no path from the root reaches: not a plain DFS tree
-                if (n.n_prims == 0) size[i] = 1u + size[i + 1] + size[n.offset];
-                const uint32_t dep = node_depth[i];
-                if (dep < 64 && size[i] > max_size[dep]) max_size[dep] = size[i];
-            }
-            if (ok)
-                for (uint32_t dep = 0; dep < 64; ++dep)
-                    if (max_size[dep] <= 65535u) { out.stack16_level = dep; break; }
         }
     }
     // The reference's traversal stack is [usize; 64] (aggregate.rs:90); deeper trees would index out of bounds there.

@@ -27,30 +27,17 @@ namespace {
 #endif
 enum : uint32_t { ST_IDLE = 0, ST_NODE = 1, ST_LEAF = 2, ST_DONE = 3 };
 
-// COMPACT (triangle-only scenes): the per-lane stack takes 80 B of LDS instead of 104 — levels [0, A) hold absolute node indices, levels
-// [A, A + B) 16-bit offsets from an ANCHOR node, B = 40 - 2 A — so that a 256-thread workgroup needs 20 KiB and EIGHT of them fit a CU
-// (32 waves, the hardware maximum) instead of six. The traversal kernels wait on their node gathers half of their wave cycles, and their
-// time falls with resident waves (measured on S3 at 3 / 4 / 5 / 6 workgroups per CU: K2 253 / 206 / 179 / 163 ms per frame).
-// The anchor is the node at which the entry of level A was pushed: every entry of a level >= A was pushed while that one was pending,
-// i.e. inside the anchor's subtree, and in the DFS layout (aggregate.rs:425-467) a descendant's index exceeds its ancestor's by at most the
-// subtree size. `A` is chosen per scene (shm_scene_create) as the first depth at which every subtree has fewer than 65 536 nodes.
-template <bool ANY, bool TRI_ONLY, bool COMPACT>
+template <bool ANY, bool TRI_ONLY>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
                                                        uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
                                                        ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
                                                        float4* __restrict__ L, const float4* __restrict__ contrib,
                                                        DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
-                                                       int refill_min, int leaf_min, int queue_parts, int stack_a) {
-    constexpr int LDS_DWORDS_PER_LANE = COMPACT ? K3_COMPACT_BYTES / 4 : K3_LDS_N;
-    __shared__ uint32_t lds_stack[(TRACE_BLOCK / WAVE) * LDS_DWORDS_PER_LANE * WAVE];
+                                                       int refill_min, int leaf_min, int queue_parts) {
+    __shared__ uint32_t lds_stack[(TRACE_BLOCK / WAVE) * K3_LDS_N * WAVE];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave_in_block = threadIdx.x / WAVE;
-    uint32_t* const st_lds = lds_stack + wave_in_block * LDS_DWORDS_PER_LANE * WAVE + lane;
-    // COMPACT: levels [0, A) as dwords [level][lane], then levels [A, A + B) as halfwords [level - A][lane]
-    const int A = COMPACT ? stack_a : K3_LDS_N;
-    const int LDS_LEVELS = COMPACT ? A + (K3_COMPACT_BYTES / 2 - 2 * A) : K3_LDS_N;  // A + B
-    uint16_t* const st_lds16 = reinterpret_cast<uint16_t*>(lds_stack + wave_in_block * LDS_DWORDS_PER_LANE * WAVE + (COMPACT ? A * WAVE : 0)) + lane;
-    uint32_t anchor = 0;
+    uint32_t* const st_lds = lds_stack + wave_in_block * K3_LDS_N * WAVE + lane;
     uint32_t* const st_spill = spill + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE + lane;
     const uint32_t n = n_ptr ? *n_ptr : n_direct;
     const char* __restrict__ node_base = reinterpret_cast<const char*>(sv.nodes);
@@ -164,9 +151,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                     sp--;
                     // two different load flavours, so that the compiler cannot merge them into one flat_load of a selected
                     // pointer (which waits on both the LDS and the vector-memory counter)
-                    if (sp < A) cur = st_lds[sp * WAVE];
-                    else if (COMPACT && sp < LDS_LEVELS) cur = anchor + (uint32_t)st_lds16[(sp - A) * WAVE];
-                    else cur = __builtin_nontemporal_load(st_spill + (size_t)(sp - LDS_LEVELS) * WAVE);
+                    if (sp < K3_LDS_N) cur = st_lds[sp * WAVE];
+                    else cur = __builtin_nontemporal_load(st_spill + (size_t)(sp - K3_LDS_N) * WAVE);
                     if (!TRI_ONLY && cur == INST_SENTINEL) {
                         // the instanced aggregate is exhausted: back to the ray of the enclosing tree (primitive.rs:158-171 returns);
                         // t_max is the hit found inside (in the instance's parameterisation, as the reference keeps it) or what it was
@@ -223,11 +209,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                     bool neg = (axis == 0) ? negx : ((axis == 1) ? negy : negz);
                     uint32_t far_child = neg ? cur + 1 : offset;   // aggregate.rs:119-127
                     uint32_t near_child = neg ? offset : cur + 1;
-                    if (sp < A) st_lds[sp * WAVE] = far_child;
-                    else if (COMPACT && sp < LDS_LEVELS) {
-                        if (sp == A) anchor = cur;  // the node at which level A is pushed: every deeper entry lies in its subtree
-                        st_lds16[(sp - A) * WAVE] = (uint16_t)(far_child - anchor);
-                    } else st_spill[(size_t)(sp - LDS_LEVELS) * WAVE] = far_child;
+                    if (sp < K3_LDS_N) st_lds[sp * WAVE] = far_child;
+                    else st_spill[(size_t)(sp - K3_LDS_N) * WAVE] = far_child;
                     sp++;
                     cur = near_child;
                 }
@@ -252,8 +235,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                             // the ray into the instance's space — apply_ray_inverse for intersect, the FORWARD apply_ray for
                             // intersect_predicate, as the reference writes them — and go on in the instanced aggregate's tree.
                             const ShmInstance& in = sv.instances[__float_as_uint(q2.y) & PRIM_INDEX_MASK];
-                            if (sp < A) st_lds[sp * WAVE] = INST_SENTINEL;  // (TRI_ONLY = false is never COMPACT: A == LDS_LEVELS == K3_LDS_N)
-                            else st_spill[(size_t)(sp - LDS_LEVELS) * WAVE] = INST_SENTINEL;
+                            if (sp < K3_LDS_N) st_lds[sp * WAVE] = INST_SENTINEL;
+                            else st_spill[(size_t)(sp - K3_LDS_N) * WAVE] = INST_SENTINEL;
                             sp++;
                             t_outer = t_max;
                             inst_slot = (int32_t)slot;
@@ -348,18 +331,16 @@ __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x;
 
 int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, const ShmRay* rays,
                     ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib) {
-    if (s->trace_mode == 4 && !s->flat.has_spheres) return wf_launch_trace4(s, any, stream, queue, n_ptr, n_direct, rays, hits, occluded, L, contrib);
     uint32_t* heads = s->d_heads3 + (any ? 8 * 32 : 0);
     uint32_t* spill = any ? s->d_spill3_any : s->d_spill3;
     hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, stream, heads);
     const int leaf_min = any ? s->leaf_min_any : s->leaf_min;
     const bool tri_only = !s->flat.has_spheres;
-    const bool compact = tri_only && s->stack_a > 0;
-#define TRACE_LAUNCH(ANY, TRI, CMP)                                                                                                                  \
-    hipLaunchKernelGGL((k_trace3<ANY, TRI, CMP>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
-                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels, s->refill_min, leaf_min, s->queue_parts, s->stack_a)
-    if (any) { if (compact) TRACE_LAUNCH(true, true, true); else if (tri_only) TRACE_LAUNCH(true, true, false); else TRACE_LAUNCH(true, false, false); }
-    else { if (compact) TRACE_LAUNCH(false, true, true); else if (tri_only) TRACE_LAUNCH(false, true, false); else TRACE_LAUNCH(false, false, false); }
+#define TRACE_LAUNCH(ANY, TRI)                                                                                                                   \
+    hipLaunchKernelGGL((k_trace3<ANY, TRI>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
+                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels, s->refill_min, leaf_min, s->queue_parts)
+    if (any) { if (tri_only) TRACE_LAUNCH(true, true); else TRACE_LAUNCH(true, false); }
+    else { if (tri_only) TRACE_LAUNCH(false, true); else TRACE_LAUNCH(false, false); }
 #undef TRACE_LAUNCH
     LAUNCH_TRY(any ? "k_trace3<any>" : "k_trace3<closest>");
     return SHM_OK;

@@ -179,9 +179,8 @@ static uint64_t max_batch_paths() {
 static bool scene_is_lean(const ShmScene* s) { return !s->flat.has_spheres && s->flat.diffuse_only && !s->flat.has_textures; }
 static bool use_staged(const ShmScene* s, const ShmRenderParams* params) {
     if (params->integrator != SHM_INTEGRATOR_PATH) return false;
-    static int all = -1;
-    if (all < 0) all = (getenv("SHM_STAGED_ALL") && atoi(getenv("SHM_STAGED_ALL")) != 0) ? 1 : 0;  // A/B: the lean class through the staged pipeline too
-    return all || !scene_is_lean(s) || params->force_diffuse != 0;
+    // (the lean class through the staged pipeline, measured: shade + generate + film 130 -> 165 ms per headline frame)
+    return !scene_is_lean(s) || params->force_diffuse != 0;
 }
 static uint64_t staging_bytes_per_path(const ShmScene* s) {
     const shm_host::FlatScene& f = s->flat;
@@ -366,34 +365,11 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
         if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 6) per_cu3 = v2; }
         if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
         if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
-        // the compact stack (k_trace3<.., COMPACT>): A absolute levels, B = 40 - 2 A relative ones; A is the first depth whose subtrees all
-        // hold fewer than 65 536 nodes (at least 4, so that B <= 32; at most 16, so that B >= 8). 20 KiB per workgroup -> 8 per CU.
-        int lds_levels = K3_LDS_N;
-        if (!f.has_spheres && f.stack16_level <= 16u && !getenv("SHM_NO_COMPACT_STACK")) {
-            s->stack_a = std::max(4, (int)f.stack16_level);
-            lds_levels = s->stack_a + (K3_COMPACT_BYTES / 2 - 2 * s->stack_a);
-            per_cu3 = 8;
-            if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) per_cu3 = v2; }
-        }
         s->trace3_blocks = s->n_cu * per_cu3;
-        s->spill3_levels = std::max(0, (int)f.max_leaf_depth + 1 - lds_levels) + 1;
+        s->spill3_levels = std::max(0, (int)f.max_leaf_depth + 1 - K3_LDS_N) + 1;
         if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3)) != SHM_OK) return fail(rc);
         if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3_any)) != SHM_OK) return fail(rc);
     }
-    {
-        int per_cu4 = 11;  // ~14 KB of LDS per one-wave workgroup -> 11 per CU
-        if (const char* e = getenv("SHM_TRACE")) { int v2 = atoi(e); if (v2 == 3 || v2 == 4) s->trace_mode = v2; }
-        if (const char* e = getenv("SHM_TRACE4_WAVES_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 16) per_cu4 = v2; }
-        if (const char* e = getenv("SHM_LEAF_MIN4")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min4 = v2; }
-        if (const char* e = getenv("SHM_LEAF_MIN4_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min4_any = v2; }
-        if (const char* e = getenv("SHM_REFILL_MIN4")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min4 = v2; }
-        s->trace4_blocks = s->n_cu * per_cu4;
-        s->spill4_levels = std::max(0, (int)f.max_leaf_depth + 1 - wf_trace4_lds_levels()) + 1;
-        const size_t n4 = (size_t)s->trace4_blocks * (size_t)s->spill4_levels * (size_t)wf_trace4_pool();
-        if ((rc = dev_alloc<uint32_t>(s, n4, &s->d_spill4)) != SHM_OK) return fail(rc);
-        if ((rc = dev_alloc<uint32_t>(s, n4, &s->d_spill4_any)) != SHM_OK) return fail(rc);
-    }
-    DBG("compact stack: first 16-bit level %u -> A = %d", f.stack16_level, s->stack_a);
     DBG("scene: %u nodes, depth %u, trace blocks %d, spill levels %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->trace3_blocks, s->spill3_levels);
     *out = s;
     return SHM_OK;

@@ -142,7 +142,6 @@ constexpr int SHADE_CHUNK = 2048;  // queue entries per workgroup chunk: ONE glo
 #endif
 #define K_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(K_SHADE_WAVES, K_SHADE_WAVES)))
 constexpr int K3_LDS_N = 26;   // k_trace3: stack levels [0, K3_LDS_N) -> LDS (6.5 KiB per wave), deeper levels -> HBM spill
-constexpr int K3_COMPACT_BYTES = 80;  // k_trace3<.., COMPACT>: LDS bytes of stack per lane: A absolute levels (4 B) + B = 40 - 2 A relative ones (2 B)
 }  // namespace wf
 using namespace wf;
 
@@ -178,18 +177,9 @@ struct ShmScene {
     // tuned traversal (k_trace3)
     int trace3_blocks = 0;
     int spill3_levels = 1;
-    int stack_a = 0;               // > 0: the compact LDS stack with `stack_a` absolute levels (triangle-only scenes whose subtrees allow it)
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
     int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
     uint32_t* d_spill3 = nullptr;
-    // pool traversal (k_trace4, triangle-only scenes)
-    int trace_mode = 3;            // 3: k_trace3 (default); 4: the LDS ray-pool kernel k_trace4 for triangle scenes (SHM_TRACE=4; measured slower)
-    int trace4_blocks = 0;         // one wave per workgroup
-    int spill4_levels = 1;
-    int leaf_min4 = 32, leaf_min4_any = 24;  // pool-wide pending leaves before a leaf phase runs (SHM_LEAF_MIN4, SHM_LEAF_MIN4_ANY)
-    int refill_min4 = 16;          // free slots before the pool is refilled (SHM_REFILL_MIN4)
-    uint32_t* d_spill4 = nullptr;
-    uint32_t* d_spill4_any = nullptr;
     float4* d_rw = nullptr;          // RandomWalk: (le, f cos) per depth per path, 2 * (max_depth + 1) * capacity float4
     size_t rw_floats4 = 0;
     uint32_t* d_spill3_any = nullptr;  // the any-hit kernel may run concurrently with the closest-hit one (second stream)
@@ -224,11 +214,6 @@ struct EventPool {
 // k_trace.hip: BvhAggregate::intersect (any = false) / intersect_predicate (any = true) over a queue of path slots
 WF_INTERNAL int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct,
                                 const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib);
-// k_trace4.hip: the same for triangle-only scenes with a wave-level ray pool in LDS
-WF_INTERNAL int wf_launch_trace4(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct,
-                                 const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib);
-WF_INTERNAL int wf_trace4_pool();
-WF_INTERNAL int wf_trace4_lds_levels();
 // shading of one path vertex of PathIntegrator::li for every entry of q_active[cur]
 struct ShadeArgs {
     hipStream_t stream;
