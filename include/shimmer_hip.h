@@ -590,6 +590,34 @@ typedef struct ShmPlyMesh {
 SHM_API int shm_ply_read(const char* filename, ShmPlyMesh* out);
 SHM_API void shm_ply_free(ShmPlyMesh* mesh);
 
+/* ---- PBRT-v4 scene front end (ABI v7) ------------------------------------------------------------------------------
+ * The reference's loader (loading/tokenizer.rs, parser.rs:216-351, parser_target.rs:50-184, scene.rs:1221-2033) restated in C++ for the
+ * directive set the repository's scenes use: transforms (LookAt Translate Scale Rotate Identity Transform ConcatTransform CoordinateSystem
+ * CoordSysTransform ReverseOrientation), Camera (perspective / orthographic), Film (rgb), Sampler (independent), PixelFilter (box),
+ * Integrator (path / simplepath / randomwalk), Option, WorldBegin, AttributeBegin / End, Material / MakeNamedMaterial / NamedMaterial
+ * (diffuse conductor dielectric thindielectric coateddiffuse coatedconductor mix), Texture (float / spectrum: constant scale mix
+ * directionmix), AreaLightSource (diffuse), LightSource (point infinite), Shape (trianglemesh bilinearmesh sphere plymesh), ObjectBegin /
+ * ObjectEnd / ObjectInstance, Include — with the reference's parameter names and defaults. Spectra: "float", "spectrum" (lambda / value
+ * pairs or a named spectrum), "blackbody"; "rgb" needs the colour space's rgb2spec table and is reported as SHM_ERR_UNSUPPORTED, as is
+ * everything else outside the list (image files, media, animated transforms): nothing is silently rendered as something else. Errors carry
+ * file:line in shm_last_error(). The returned description owns every array it points to; free it with shm_pbrt_free. */
+typedef struct ShmPbrtScene {
+    ShmSceneDesc desc;          /* ready for shm_scene_create */
+    ShmRenderParams params;     /* Sampler "pixelsamples" / "seed", Integrator "maxdepth" / "regularize" / "samplelights" / "samplebsdf", Option flags */
+    char integrator[32];        /* "path" (default), "simplepath", "randomwalk": the name create_integrator receives */
+    char output_filename[256];  /* Film "filename" (default "shimmer.pfm", film.rs:232-243) */
+    void* owner;                /* the loader's storage */
+} ShmPbrtScene;
+SHM_API int shm_scene_load_pbrt(const char* path, ShmPbrtScene** out);
+/* The same from a string; base_dir (may be NULL) resolves Include and plymesh file names. */
+SHM_API int shm_scene_parse_pbrt(const char* text, const char* base_dir, ShmPbrtScene** out);
+SHM_API void shm_pbrt_free(ShmPbrtScene* scene);
+/* Two pieces of the front end the scene generators of this repository share with the loader, so that both hand the library bit-identical
+ * inputs: DenselySampledSpectrum::new(BlackbodySpectrum::new(T)) at 360..=830 nm (spectra/spectrum.rs:430-489) and the world_from_camera
+ * matrix of Transform::look_at (transform.rs:270-303), both in f32 as the reference computes them. */
+SHM_API int shm_blackbody_dense(float temperature_kelvin, float out471[471]);
+SHM_API int shm_look_at(const float eye[3], const float look[3], const float up[3], float world_from_camera_out[16]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,6 +191,10 @@ class ShmHit(C.Structure):
 
 assert C.sizeof(ShmMaterial) == 64 + 4 * 32 + 48 and C.sizeof(ShmFloatTexture) == 48 and C.sizeof(ShmBvhNode) == 32 and C.sizeof(ShmRay) == 32 and C.sizeof(ShmHit) == 32 and C.sizeof(ShmFilmPixel) == 32
 
+class ShmPbrtScene(C.Structure):
+    _fields_ = [("desc", ShmSceneDesc), ("params", ShmRenderParams), ("integrator", C.c_char * 32), ("output_filename", C.c_char * 256), ("owner", C.c_void_p)]
+
+
 # Every symbol include/shimmer_hip.h declares, with its signature (tests check the .so exports all of them).
 EXPORTS = {
     "shm_scene_create": (C.c_int, [C.POINTER(ShmSceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
@@ -224,6 +228,11 @@ EXPORTS = {
     "shm_dist_finalize": (C.c_int, [C.c_void_p]),
     "shm_render_sharded": (C.c_int, [C.c_void_p, C.POINTER(ShmRenderParams), C.POINTER(ShmStats)]),
     "shm_dist_selftest": (C.c_int, [C.c_void_p]),
+    "shm_scene_load_pbrt": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(ShmPbrtScene))]),
+    "shm_scene_parse_pbrt": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.POINTER(ShmPbrtScene))]),
+    "shm_pbrt_free": (None, [C.POINTER(ShmPbrtScene)]),
+    "shm_blackbody_dense": (C.c_int, [C.c_float, c_float_p]),
+    "shm_look_at": (C.c_int, [c_float_p, c_float_p, c_float_p, c_float_p]),
     "shm_render_multi": (C.c_int, [C.POINTER(ShmSceneDesc), C.POINTER(C.c_int32), C.c_int32, C.POINTER(ShmRenderParams), C.c_void_p, C.POINTER(ShmStats)]),
 }
 

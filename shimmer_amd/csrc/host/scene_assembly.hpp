@@ -1,0 +1,456 @@
+// scene_assembly.hpp — C++ scene assembly for the PBRT-v4 loader (host/pbrt_loader.cpp): what the reference does between its parsed
+// entities and the objects create_integrator receives, flattened into the ABI's ShmSceneDesc. Restates (paths relative to
+// /root/reference/src):
+//   spectra/spectrum.rs:179-196, 313-372, 430-489, 617-631  DenselySampledSpectrum::new, PiecewiseLinearSpectrum::{new, from_interleaved},
+//                                                            BlackbodySpectrum, spectrum_to_photometric
+//   spectra/named_spectrum.rs:30-46                          the named metal / glass / illuminant spectra
+//   shape/mesh.rs:22-70, shape/triangle.rs:507-510, shape/sphere.rs:40-92, 275-280, shape/bilinear_patch.rs:430-433   meshes in render space, bounds
+//   light.rs:560-612, 424-452, 112-160                       DiffuseAreaLight / PointLight / infinite light creation (scale / photometric)
+//   loading/scene.rs:609-624, 721-886                        one area light per emissive shape; BvhAggregate per object definition + instances
+//   aggregate.rs:207-467 (shm_bvh_build), camera.rs (shm_camera_perspective / _orthographic), film.rs:225-330, 767-800
+// Host-side only. The same numerics are reachable from Python through shm_blackbody_dense / shm_look_at, so that the generators of
+// shimmer_amd/scenes.py and this loader hand bit-identical inputs to the library.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/shimmer_hip.h"
+#include "pbrt_math.hpp"
+
+namespace pbrt {
+
+#include "spectral_tables.inc"
+
+struct LoadError : std::runtime_error {
+    int code;
+    LoadError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+[[noreturn]] inline void fail(const std::string& m, int code = SHM_ERR_INVALID_ARGUMENT) { throw LoadError(code, m); }
+
+inline std::vector<float> table(const uint32_t* bits, size_t n) {
+    std::vector<float> v(n);
+    memcpy(v.data(), bits, n * sizeof(float));
+    return v;
+}
+#define PBRT_TABLE(NAME) pbrt::table(pbrt::TBL_##NAME, sizeof(pbrt::TBL_##NAME) / sizeof(uint32_t))
+
+// PiecewiseLinearSpectrum::from_interleaved (spectrum.rs:324-372) without the normalisation -> (lambda[], value[])
+inline void from_interleaved(const std::vector<float>& s, std::vector<float>& lam, std::vector<float>& val) {
+    lam.clear(); val.clear();
+    if (s[0] > 360.0f) { lam.push_back(359.0f); val.push_back(s[1]); }
+    for (size_t i = 0; i + 1 < s.size(); i += 2) { lam.push_back(s[i]); val.push_back(s[i + 1]); }
+    if (lam.back() < 830.0f) { lam.push_back(831.0f); val.push_back(val.back()); }
+}
+inline float piecewise_get(const std::vector<float>& lam, const std::vector<float>& val, float x) {  // spectrum.rs:374-392
+    if (x < lam.front() || x > lam.back()) return 0.0f;
+    // find_interval: the last i with lam[i] <= x, clamped to [0, n - 2]
+    size_t lo = 0, hi = lam.size();
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (lam[mid] <= x) lo = mid + 1; else hi = mid; }
+    long o = (long)lo - 1;
+    if (o < 0) o = 0;
+    if (o > (long)lam.size() - 2) o = (long)lam.size() - 2;
+    const float t = (x - lam[o]) / (lam[o + 1] - lam[o]);
+    return val[o] * (1.0f - t) + val[o + 1] * t;  // lerp(t, a, b) = a (1 - t) + b t (math.rs:246-252)
+}
+inline std::vector<float> piecewise_to_dense(const std::vector<float>& lam, const std::vector<float>& val) {
+    std::vector<float> d(471);
+    for (int l = 360; l <= 830; ++l) d[l - 360] = piecewise_get(lam, val, (float)l);
+    return d;
+}
+// DenselySampledSpectrum::new(BlackbodySpectrum::new(T)) at 360..=830 nm, f32 as the reference (spectrum.rs:430-489)
+inline std::vector<float> blackbody_dense(float t) {
+    auto bb = [t](float lam_nm) {
+        const float c = 299792458.0f, h = 6.62606957e-34f, kb = 1.3806488e-23f;
+        const float l = lam_nm * 1e-9f;
+        const float l5 = l * l * l * l * l;
+        const float e = expf((h * c) / (l * kb * t));
+        return (2.0f * h * c * c) / (l5 * (e - 1.0f));
+    };
+    const float lambda_max = 2.8977721e-3f / t;
+    const float norm = 1.0f / bb(lambda_max * 1e9f);
+    std::vector<float> d(471);
+    for (int l = 360; l <= 830; ++l) d[l - 360] = bb((float)l) * norm;
+    return d;
+}
+inline float spectrum_to_photometric(const std::vector<float>& dense) {  // spectrum.rs:617-631 over a 360..=830 table
+    const std::vector<float> y = PBRT_TABLE(CIE_Y);
+    float acc = 0.0f;
+    for (int i = 0; i < 471; ++i) acc += y[i] * dense[i];
+    return acc;
+}
+// Spectrum::get_named_spectrum(StdIllumD65): from_interleaved(CIE_ILLUM_D6500, normalize = true), densely sampled
+inline std::vector<float> illuminant_d65_dense() {
+    std::vector<float> lam, val;
+    from_interleaved(PBRT_TABLE(CIE_ILLUM_D6500), lam, val);
+    std::vector<float> dense = piecewise_to_dense(lam, val);
+    const std::vector<float> y = PBRT_TABLE(CIE_Y);
+    float integral = 0.0f;
+    for (int i = 0; i < 471; ++i) integral += dense[i] * y[i];
+    const std::vector<float> yi = PBRT_TABLE(CIE_Y_INTEGRAL);
+    const float k = yi[0] / integral;
+    for (float& v : val) v *= k;
+    return piecewise_to_dense(lam, val);
+}
+
+// A spectrum value as parsed, before it is bound to a use (material slot: kept in its own kind; light: densely sampled)
+struct SpectrumValue {
+    enum Kind { NONE, CONSTANT, PIECEWISE, DENSE, RGB, TEXTURE } kind = NONE;
+    float c = 0.0f;
+    std::vector<float> lam, val;   // PIECEWISE
+    std::vector<float> dense;      // DENSE (blackbody)
+    float rgb[3] = {0, 0, 0};
+    std::string texture;           // TEXTURE: name of a spectrum texture
+    std::string key;               // identity for pooling (one table per distinct emission spectrum)
+};
+
+class Assembly {
+public:
+    struct Mesh {
+        std::vector<float> p, n, s, uv;
+        std::vector<uint32_t> vi;
+        bool reverse = false, swaps = false;
+    };
+    struct Prim {
+        uint32_t kind, index, material;
+        int32_t light;
+        uint32_t owner;  // 0 = the scene, k = object definition k
+        float b[6];
+    };
+    std::vector<float> spec;
+    std::vector<ShmMaterial> materials;
+    std::vector<ShmLight> lights;
+    std::vector<Mesh> meshes, patch_meshes;
+    std::vector<ShmSphere> spheres;
+    std::vector<Prim> prims;
+    std::vector<ShmFloatTexture> float_textures;
+    std::vector<ShmSpectrumTexture> spectrum_textures;
+    std::map<std::string, uint32_t> objects;
+    struct Inst { uint32_t object; M4 m; };
+    std::vector<Inst> instances;
+    uint32_t n_tris = 0, n_patches = 0;
+    ShmCamera camera;
+    ShmFilm film;
+    bool have_camera = false;
+    std::vector<float> sensor_x = PBRT_TABLE(CIE_X), sensor_y = PBRT_TABLE(CIE_Y), sensor_z = PBRT_TABLE(CIE_Z);
+    std::map<std::string, std::pair<ShmSpectrum, float>> emission_cache;  // key -> (pooled dense table, photometric integral)
+
+    // ---- spectra ----
+    static ShmSpectrum spec_constant(float c) {
+        ShmSpectrum s;
+        memset(&s, 0, sizeof(s));
+        s.kind = SHM_SPECTRUM_CONSTANT;
+        s.c = c;
+        return s;
+    }
+    uint32_t pool(const std::vector<float>& v) {
+        const uint32_t off = (uint32_t)spec.size();
+        spec.insert(spec.end(), v.begin(), v.end());
+        return off;
+    }
+    ShmSpectrum spec_dense(const std::vector<float>& v) {
+        ShmSpectrum s;
+        memset(&s, 0, sizeof(s));
+        s.kind = SHM_SPECTRUM_DENSE;
+        s.offset = pool(v);
+        s.n = 471;
+        s.lambda_min = 360;
+        return s;
+    }
+    ShmSpectrum spec_piecewise(const std::vector<float>& lam, const std::vector<float>& val) {
+        ShmSpectrum s;
+        memset(&s, 0, sizeof(s));
+        s.kind = SHM_SPECTRUM_PIECEWISE_LINEAR;
+        std::vector<float> both(lam);
+        both.insert(both.end(), val.begin(), val.end());
+        s.offset = pool(both);
+        s.n = (uint32_t)lam.size();
+        return s;
+    }
+    // a material slot: constants and piecewise-linear spectra keep their kind; a blackbody becomes its dense table
+    ShmSpectrum bind(const SpectrumValue& v, const std::map<std::string, ShmSpectrum>& spectrum_texture_names) {
+        switch (v.kind) {
+            case SpectrumValue::CONSTANT: return spec_constant(v.c);
+            case SpectrumValue::PIECEWISE: return spec_piecewise(v.lam, v.val);
+            case SpectrumValue::DENSE: return spec_dense(v.dense);
+            case SpectrumValue::TEXTURE: {
+                auto it = spectrum_texture_names.find(v.texture);
+                if (it == spectrum_texture_names.end()) fail("Couldn't find spectrum texture named \"" + v.texture + "\"");
+                return it->second;
+            }
+            case SpectrumValue::RGB: fail("\"rgb\" parameters need the colour space's rgb2spec table, which this loader does not carry: give the spectrum as \"spectrum\" samples", SHM_ERR_UNSUPPORTED);
+            default: fail("missing spectrum");
+        }
+    }
+    // a light's emission: DenselySampledSpectrum::new(spectrum) (light.rs:525-527, 416-419)
+    std::vector<float> dense_of(const SpectrumValue& v) {
+        switch (v.kind) {
+            case SpectrumValue::CONSTANT: return std::vector<float>(471, v.c);
+            case SpectrumValue::PIECEWISE: return piecewise_to_dense(v.lam, v.val);
+            case SpectrumValue::DENSE: return v.dense;
+            case SpectrumValue::RGB: fail("\"rgb\" light spectra need the colour space's rgb2spec table: give \"blackbody\" or \"spectrum\" samples", SHM_ERR_UNSUPPORTED);
+            default: fail("a light's spectrum cannot be a texture");
+        }
+    }
+
+    // ---- shapes (vertices already in render space) ----
+    void tri_bounds(const Mesh& m, uint32_t t, float b[6]) const {
+        for (int k = 0; k < 3; ++k) { b[k] = INFINITY; b[3 + k] = -INFINITY; }
+        for (int c = 0; c < 3; ++c) {
+            const float* q = &m.p[3 * m.vi[3 * t + c]];
+            for (int k = 0; k < 3; ++k) { b[k] = std::min(b[k], q[k]); b[3 + k] = std::max(b[3 + k], q[k]); }
+        }
+    }
+    int area_light(uint32_t prim_index, float area, const SpectrumValue& L, float scale, bool two_sided) {
+        ShmLight l;
+        memset(&l, 0, sizeof(l));
+        l.kind = SHM_LIGHT_DIFFUSE_AREA;
+        l.primitive = prim_index;
+        l.two_sided = two_sided ? 1u : 0u;
+        l.area = area;
+        auto it = emission_cache.find(L.key);
+        if (it == emission_cache.end()) {
+            const std::vector<float> dense = dense_of(L);
+            it = emission_cache.emplace(L.key, std::make_pair(spec_dense(dense), spectrum_to_photometric(dense))).first;
+        }
+        l.scale = scale / it->second.second;  // light.rs:598: scale /= spectrum_to_photometric(L)
+        l.spectrum = it->second.first;
+        lights.push_back(l);
+        return (int)lights.size() - 1;
+    }
+    struct Emission {
+        bool on = false;
+        SpectrumValue L;
+        float scale = 1.0f, power = -1.0f;
+        bool two_sided = false;
+    };
+    void add_mesh(Mesh&& mesh, uint32_t material, const Emission& em, uint32_t owner) {
+        const uint32_t ntri = (uint32_t)(mesh.vi.size() / 3);
+        const uint32_t base = n_tris;
+        n_tris += ntri;
+        meshes.push_back(std::move(mesh));
+        const Mesh& m = meshes.back();
+        for (uint32_t t = 0; t < ntri; ++t) {
+            Prim pr{SHM_SHAPE_TRIANGLE, base + t, material, -1, owner, {0}};
+            tri_bounds(m, t, pr.b);
+            if (em.on) {
+                const float* a = &m.p[3 * m.vi[3 * t]];
+                const float* b = &m.p[3 * m.vi[3 * t + 1]];
+                const float* c = &m.p[3 * m.vi[3 * t + 2]];
+                const double e1[3] = {(double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2]}, e2[3] = {(double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2]};
+                const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                const float area = (float)(0.5 * std::sqrt(cx * cx + cy * cy + cz * cz));  // Triangle::area (only the light's `area` field: phi())
+                float scale = em.scale;
+                pr.light = area_light((uint32_t)prims.size(), area, em.L, scale, em.two_sided);
+                if (em.power > 0.0f) lights.back().scale *= em.power / ((em.two_sided ? 2.0f : 1.0f) * area * 3.14159265358979323846f);  // light.rs:600-611
+            }
+            prims.push_back(pr);
+        }
+    }
+    void add_patch_mesh(Mesh&& mesh, uint32_t material, const Emission& em, uint32_t owner) {
+        const uint32_t n = (uint32_t)(mesh.vi.size() / 4);
+        const uint32_t base = n_patches;
+        n_patches += n;
+        patch_meshes.push_back(std::move(mesh));
+        const Mesh& m = patch_meshes.back();
+        for (uint32_t t = 0; t < n; ++t) {
+            Prim pr{SHM_SHAPE_BILINEAR_PATCH, base + t, material, -1, owner, {0}};
+            for (int k = 0; k < 3; ++k) { pr.b[k] = INFINITY; pr.b[3 + k] = -INFINITY; }
+            double q[4][3];
+            for (int c = 0; c < 4; ++c) {
+                const float* v = &m.p[3 * m.vi[4 * t + c]];
+                for (int k = 0; k < 3; ++k) { pr.b[k] = std::min(pr.b[k], v[k]); pr.b[3 + k] = std::max(pr.b[3 + k], v[k]); q[c][k] = v[k]; }
+            }
+            if (em.on) {
+                auto tri_area = [](const double* a, const double* b, const double* c) {
+                    const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+                    const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                    return 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+                };
+                const float area = (float)(tri_area(q[0], q[1], q[2]) + tri_area(q[3], q[1], q[2]));
+                pr.light = area_light((uint32_t)prims.size(), area, em.L, em.scale, em.two_sided);
+                if (em.power > 0.0f) lights.back().scale *= em.power / ((em.two_sided ? 2.0f : 1.0f) * area * 3.14159265358979323846f);
+            }
+            prims.push_back(pr);
+        }
+    }
+    void add_sphere(float radius, float z_min_in, float z_max_in, float phi_max_deg, const Xf& render_from_object, bool reverse, uint32_t material, const Emission& em,
+                    uint32_t owner) {
+        ShmSphere s;
+        memset(&s, 0, sizeof(s));
+        auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        const float zmin = std::min(z_min_in, z_max_in), zmax = std::max(z_min_in, z_max_in);
+        s.radius = radius;
+        s.z_min = clampf(zmin, -radius, radius);                                // sphere.rs:40-53
+        s.z_max = clampf(zmax, -radius, radius);
+        s.theta_z_min = acosf(clampf(zmin / radius, -1.0f, 1.0f));
+        s.theta_z_max = acosf(clampf(zmax / radius, -1.0f, 1.0f));
+        s.phi_max = (3.14159265358979323846f / 180.0f) * clampf(phi_max_deg, 0.0f, 360.0f);
+        memcpy(s.render_from_object, render_from_object.m.m, sizeof(float) * 16);
+        memcpy(s.object_from_render, render_from_object.inv.m, sizeof(float) * 16);
+        s.reverse_orientation = reverse ? 1 : 0;
+        s.transform_swaps_handedness = swaps_handedness(render_from_object.m) ? 1 : 0;
+        spheres.push_back(s);
+        Prim pr{SHM_SHAPE_SPHERE, (uint32_t)spheres.size() - 1, material, -1, owner, {0}};
+        // Sphere::bounds = render_from_object.apply(Bounds3f{(-r, -r, z_min), (r, r, z_max)}) (sphere.rs:275-280; transform.rs:557-571: the eight corners)
+        for (int k = 0; k < 3; ++k) { pr.b[k] = INFINITY; pr.b[3 + k] = -INFINITY; }
+        for (int c = 0; c < 8; ++c) {
+            const V3 q = shm::v3(c & 1 ? radius : -radius, c & 2 ? radius : -radius, c & 4 ? s.z_max : s.z_min);
+            const M4& m = render_from_object.m;
+            const float p[3] = {m.m[0][0] * q.x + m.m[0][1] * q.y + m.m[0][2] * q.z + m.m[0][3], m.m[1][0] * q.x + m.m[1][1] * q.y + m.m[1][2] * q.z + m.m[1][3],
+                                m.m[2][0] * q.x + m.m[2][1] * q.y + m.m[2][2] * q.z + m.m[2][3]};
+            for (int k = 0; k < 3; ++k) { pr.b[k] = std::min(pr.b[k], p[k]); pr.b[3 + k] = std::max(pr.b[3 + k], p[k]); }
+        }
+        if (em.on) {
+            const float area = s.phi_max * s.radius * (s.z_max - s.z_min);  // sphere.rs:282-284
+            pr.light = area_light((uint32_t)prims.size(), area, em.L, em.scale, em.two_sided);
+            if (em.power > 0.0f) lights.back().scale *= em.power / ((em.two_sided ? 2.0f : 1.0f) * area * 3.14159265358979323846f);
+        }
+        prims.push_back(pr);
+    }
+
+    // ---- the flattened description (owns every array desc points to) ----
+    struct Built {
+        ShmSceneDesc desc;
+        std::vector<ShmBvhNode> nodes;
+        std::vector<ShmPrimitive> primitives;
+        std::vector<ShmTriangleMesh> meshes;
+        std::vector<ShmBilinearPatchMesh> patch_meshes;
+        std::vector<ShmInstance> instances;
+        std::unique_ptr<Assembly> owner;
+    };
+    // BvhAggregate::new per object definition and for the scene (loading/scene.rs:721-886), then the ABI's leaf-ordered arrays
+    static std::unique_ptr<Built> build(std::unique_ptr<Assembly> self_owned) {
+        Assembly& a = *self_owned;
+        if (!a.have_camera) fail("the scene has no Camera");
+        if (a.prims.empty()) fail("the scene has no shapes");
+        std::unique_ptr<Built> out(new Built());
+        const uint32_t n = (uint32_t)a.prims.size();
+        const uint32_t n_objects = (uint32_t)a.objects.size();
+        struct Tree { std::vector<ShmBvhNode> nodes; std::vector<uint32_t> order; };
+        auto build_tree = [&](const std::vector<uint32_t>& idx) {
+            Tree t;
+            std::vector<float> b(6 * idx.size());
+            for (size_t i = 0; i < idx.size(); ++i) memcpy(&b[6 * i], a.prims[idx[i]].b, sizeof(float) * 6);
+            t.nodes.resize(2 * idx.size());
+            std::vector<uint32_t> ord(idx.size());
+            uint32_t cnt = 0;
+            if (shm_bvh_build(b.data(), (uint32_t)idx.size(), 0, t.nodes.data(), &cnt, ord.data()) != SHM_OK) fail(std::string("BVH build failed: ") + shm_last_error());
+            t.nodes.resize(cnt);
+            t.order.resize(idx.size());
+            for (size_t i = 0; i < idx.size(); ++i) t.order[i] = idx[ord[i]];
+            return t;
+        };
+        std::vector<Tree> obj_trees(n_objects + 1);
+        for (uint32_t k = 1; k <= n_objects; ++k) {
+            std::vector<uint32_t> idx;
+            for (uint32_t i = 0; i < n; ++i) if (a.prims[i].owner == k) idx.push_back(i);
+            if (idx.empty()) fail("empty object definition");
+            obj_trees[k] = build_tree(idx);
+        }
+        // an instance's bounds: the object's root bounds through render_from_instance (transform.rs:557-571)
+        for (uint32_t ii = 0; ii < a.instances.size(); ++ii) {
+            const ShmBvhNode& root = obj_trees[a.instances[ii].object].nodes[0];
+            const M4& m = a.instances[ii].m;
+            for (Prim& pr : a.prims) {
+                if (pr.kind != SHM_SHAPE_INSTANCE || pr.index != ii) continue;
+                for (int k = 0; k < 3; ++k) { pr.b[k] = INFINITY; pr.b[3 + k] = -INFINITY; }
+                for (int c = 0; c < 8; ++c) {
+                    const float q[3] = {c & 1 ? root.bmax[0] : root.bmin[0], c & 2 ? root.bmax[1] : root.bmin[1], c & 4 ? root.bmax[2] : root.bmin[2]};
+                    for (int r = 0; r < 3; ++r) {
+                        const float v = m.m[r][0] * q[0] + m.m[r][1] * q[1] + m.m[r][2] * q[2] + m.m[r][3];
+                        pr.b[r] = std::min(pr.b[r], v);
+                        pr.b[3 + r] = std::max(pr.b[3 + r], v);
+                    }
+                }
+            }
+        }
+        std::vector<uint32_t> top;
+        for (uint32_t i = 0; i < n; ++i) if (a.prims[i].owner == 0) top.push_back(i);
+        if (top.empty()) fail("the scene has no shapes outside object definitions");
+        obj_trees[0] = build_tree(top);
+        std::vector<uint32_t> node_base(n_objects + 1), order;
+        uint32_t nb = 0, pb = 0;
+        for (uint32_t k = 0; k <= n_objects; ++k) {
+            node_base[k] = nb;
+            for (ShmBvhNode nd : obj_trees[k].nodes) {
+                nd.offset += nd.n_prims > 0 ? pb : nb;
+                out->nodes.push_back(nd);
+            }
+            nb += (uint32_t)obj_trees[k].nodes.size();
+            pb += (uint32_t)obj_trees[k].order.size();
+            order.insert(order.end(), obj_trees[k].order.begin(), obj_trees[k].order.end());
+        }
+        std::vector<uint32_t> slot_of_input(n);
+        for (uint32_t s = 0; s < n; ++s) slot_of_input[order[s]] = s;
+        out->primitives.resize(n);
+        for (uint32_t s = 0; s < n; ++s) {
+            const Prim& pr = a.prims[order[s]];
+            out->primitives[s] = ShmPrimitive{pr.kind, pr.index, pr.material, pr.light};
+        }
+        for (ShmLight& l : a.lights) if (l.kind == SHM_LIGHT_DIFFUSE_AREA) l.primitive = slot_of_input[l.primitive];
+        for (const Inst& in : a.instances) {
+            ShmInstance si;
+            memset(&si, 0, sizeof(si));
+            memcpy(si.render_from_primitive, in.m.m, sizeof(float) * 16);
+            M4 inv;
+            if (!m4_inverse(in.m, inv)) fail("singular instance transform");
+            memcpy(si.primitive_from_render, inv.m, sizeof(float) * 16);
+            si.root_node = node_base[in.object];
+            out->instances.push_back(si);
+        }
+        for (const Mesh& m : a.meshes) {
+            ShmTriangleMesh mm;
+            memset(&mm, 0, sizeof(mm));
+            mm.n_triangles = (uint32_t)(m.vi.size() / 3);
+            mm.n_vertices = (uint32_t)(m.p.size() / 3);
+            mm.vertex_indices = m.vi.data();
+            mm.p = m.p.data();
+            mm.n = m.n.empty() ? nullptr : m.n.data();
+            mm.s = m.s.empty() ? nullptr : m.s.data();
+            mm.uv = m.uv.empty() ? nullptr : m.uv.data();
+            mm.reverse_orientation = m.reverse;
+            mm.transform_swaps_handedness = m.swaps;
+            out->meshes.push_back(mm);
+        }
+        for (const Mesh& m : a.patch_meshes) {
+            ShmBilinearPatchMesh pm;
+            memset(&pm, 0, sizeof(pm));
+            pm.n_patches = (uint32_t)(m.vi.size() / 4);
+            pm.n_vertices = (uint32_t)(m.p.size() / 3);
+            pm.vertex_indices = m.vi.data();
+            pm.p = m.p.data();
+            pm.n = m.n.empty() ? nullptr : m.n.data();
+            pm.uv = m.uv.empty() ? nullptr : m.uv.data();
+            pm.reverse_orientation = m.reverse;
+            pm.transform_swaps_handedness = m.swaps;
+            out->patch_meshes.push_back(pm);
+        }
+        if (a.spec.empty()) a.spec.push_back(0.0f);
+        ShmSceneDesc& d = out->desc;
+        memset(&d, 0, sizeof(d));
+        d.abi_version = SHM_ABI_VERSION;
+        d.n_nodes = (uint32_t)out->nodes.size(); d.nodes = out->nodes.data();
+        d.n_primitives = n; d.primitives = out->primitives.data();
+        d.n_meshes = (uint32_t)out->meshes.size(); d.meshes = out->meshes.data();
+        d.n_spheres = (uint32_t)a.spheres.size(); d.spheres = a.spheres.data();
+        d.n_materials = (uint32_t)a.materials.size(); d.materials = a.materials.data();
+        d.n_lights = (uint32_t)a.lights.size(); d.lights = a.lights.data();
+        d.n_spectrum_floats = (uint32_t)a.spec.size(); d.spectrum_data = a.spec.data();
+        a.film.sensor_r_bar = a.sensor_x.data(); a.film.sensor_g_bar = a.sensor_y.data(); a.film.sensor_b_bar = a.sensor_z.data();  // PixelSensor::new cie1931 (film.rs:823-837)
+        d.camera = a.camera;
+        d.film = a.film;
+        d.n_patch_meshes = (uint32_t)out->patch_meshes.size(); d.patch_meshes = out->patch_meshes.data();
+        d.n_instances = (uint32_t)out->instances.size(); d.instances = out->instances.data();
+        d.n_float_textures = (uint32_t)a.float_textures.size(); d.float_textures = a.float_textures.data();
+        d.n_spectrum_textures = (uint32_t)a.spectrum_textures.size(); d.spectrum_textures = a.spectrum_textures.data();
+        out->owner = std::move(self_owned);
+        return out;
+    }
+};
+
+}  // namespace pbrt

@@ -28,22 +28,13 @@ f32 = np.float32
 
 
 def blackbody_dense(temperature):
-    """DenselySampledSpectrum::new(BlackbodySpectrum::new(T)) at 360..830 nm (f32 arithmetic as the reference)."""
-    t = f32(temperature)
-
-    def bb(lam_nm):
-        c = f32(299792458.0)
-        h = f32(6.62606957e-34)
-        kb = f32(1.3806488e-23)
-        l = (lam_nm * f32(1e-9)).astype(np.float32)
-        l5 = (l * l * l * l * l).astype(np.float32)
-        e = np.exp(((h * c) / (l * kb * t)).astype(np.float32)).astype(np.float32)
-        return ((f32(2.0) * h * c * c) / (l5 * (e - f32(1.0)))).astype(np.float32)
-
-    lambda_max = f32(2.8977721e-3) / t
-    norm = f32(1.0) / bb(np.asarray([lambda_max * f32(1e9)], dtype=np.float32))[0]
-    lam = np.arange(360, 831, dtype=np.float32)
-    return (bb(lam) * norm).astype(np.float32)
+    """DenselySampledSpectrum::new(BlackbodySpectrum::new(T)) at 360..830 nm, f32 as the reference computes it (spectra/spectrum.rs:430-489),
+    through the host library (shm_blackbody_dense): the one implementation the C++ PBRT loader uses too, so that a generated scene and the
+    same scene loaded from .pbrt text carry bit-identical emission tables."""
+    out = np.zeros(471, np.float32)
+    lib = abi.load_library()
+    abi.check(lib, lib.shm_blackbody_dense(float(temperature), out.ctypes.data_as(abi.c_float_p)), "shm_blackbody_dense")
+    return out
 
 
 def piecewise_from_interleaved(samples, normalize=False):
@@ -575,17 +566,10 @@ class SceneBuilder:
         self.film = f
 
     def set_camera_look_at(self, lib, pos, look_at, up, fov, lens_radius=0.0, focal_distance=1e6, orthographic=False):
-        """Transform::look_at (transform.rs:270-303) -> world_from_camera, then shm_camera_perspective.
+        """Transform::look_at (transform.rs:270-303, through shm_look_at) -> world_from_camera, then shm_camera_perspective.
         Returns render_from_world (4x4 f32) so that callers can move world-space geometry into render space."""
-        pos, look_at, up = (np.asarray(v, np.float64) for v in (pos, look_at, up))
-        d = look_at - pos
-        d /= np.linalg.norm(d)
-        right = np.cross(up / np.linalg.norm(up), d)
-        right /= np.linalg.norm(right)
-        new_up = np.cross(d, right)
-        wfc = np.eye(4)
-        wfc[:3, 0], wfc[:3, 1], wfc[:3, 2], wfc[:3, 3] = right, new_up, d, pos
-        wfc32 = _as_f32(wfc)
+        wfc32 = np.zeros(16, np.float32)  # Transform::look_at in f32, exactly as the reference (and the C++ PBRT loader) computes it
+        abi.check(lib, lib.shm_look_at(_fptr(_as_f32(pos)), _fptr(_as_f32(look_at)), _fptr(_as_f32(up)), _fptr(wfc32)), "shm_look_at")
         cam = abi.ShmCamera()
         rfw = np.zeros(16, np.float32)
         res = (C.c_int32 * 2)(*self.film.full_resolution)

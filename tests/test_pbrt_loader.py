@@ -1,0 +1,323 @@
+"""The C++ PBRT-v4 front end (shm_scene_parse_pbrt / shm_scene_load_pbrt; reference: loading/parser.rs:216-351, loading/scene.rs:1221-2033)
+against the repository's Python scene generators: the same scene written as .pbrt text must come back as the SAME ShmSceneDesc — BVH
+nodes, leaf-ordered primitives, meshes, spheres, materials, lights, spectra, camera and film byte for byte — and therefore render to the
+same film (sha256 of the oracle's f64 sums). Plus the parser's own behaviour: defaults of the reference, named materials, textures,
+object instances, transforms, Include, and errors with file:line instead of panics."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_py
+from shimmer_amd import abi, render, scene as scn, scenes
+
+
+def load(lib, text, base_dir=None):
+    out = C.POINTER(abi.ShmPbrtScene)()
+    rc = lib.shm_scene_parse_pbrt(text.encode(), base_dir.encode() if base_dir else None, C.byref(out))
+    if rc != 0:
+        raise abi.ShimmerHipError(f"{rc}: {lib.shm_last_error().decode()}")
+    return out
+
+
+def arr(ptr, n, ctype=None):
+    if n == 0 or not ptr:
+        return b""
+    size = C.sizeof(ptr._type_) * n
+    return C.string_at(ptr, size)
+
+
+def mesh_bytes(desc):
+    out = []
+    for i in range(desc.n_meshes):
+        m = desc.meshes[i]
+        out.append((m.n_triangles, m.n_vertices, arr(m.vertex_indices, 3 * m.n_triangles), arr(m.p, 3 * m.n_vertices), arr(m.n, 3 * m.n_vertices) if m.n else b"",
+                    arr(m.s, 3 * m.n_vertices) if m.s else b"", arr(m.uv, 2 * m.n_vertices) if m.uv else b"", m.reverse_orientation, m.transform_swaps_handedness))
+    return out
+
+
+def spectrum_content(desc, sp):
+    """A ShmSpectrum resolved to what it evaluates: kind + parameters + the table floats it points at (pool offsets are layout, not content)."""
+    data = np.ctypeslib.as_array(desc.spectrum_data, shape=(max(1, desc.n_spectrum_floats),))
+    n = {abi.SHM_SPECTRUM_DENSE: sp.n, abi.SHM_SPECTRUM_PIECEWISE_LINEAR: 2 * sp.n}.get(sp.kind, 0)
+    return (sp.kind, np.float32(sp.c).tobytes(), sp.n if n else 0, sp.lambda_min if sp.kind == abi.SHM_SPECTRUM_DENSE else 0, data[sp.offset:sp.offset + n].tobytes())
+
+
+def assert_same_scene(a, b, exact_pool=True):
+    assert a.n_nodes == b.n_nodes and arr(a.nodes, a.n_nodes) == arr(b.nodes, b.n_nodes)
+    assert a.n_primitives == b.n_primitives and arr(a.primitives, a.n_primitives) == arr(b.primitives, b.n_primitives)
+    assert mesh_bytes(a) == mesh_bytes(b)
+    assert a.n_spheres == b.n_spheres and arr(a.spheres, a.n_spheres) == arr(b.spheres, b.n_spheres)
+    assert bytes(a.camera) == bytes(b.camera)
+    fa, fb = a.film, b.film
+    assert list(fa.pixel_bounds) == list(fb.pixel_bounds) and list(fa.full_resolution) == list(fb.full_resolution) and list(fa.filter_radius) == list(fb.filter_radius)
+    assert fa.imaging_ratio == fb.imaging_ratio and fa.max_component_value == fb.max_component_value
+    for t in ("sensor_r_bar", "sensor_g_bar", "sensor_b_bar"):
+        assert arr(getattr(fa, t), 471) == arr(getattr(fb, t), 471)
+    assert a.n_materials == b.n_materials
+    for i in range(a.n_materials):
+        ma, mb = a.materials[i], b.materials[i]
+        for f, _ in abi.ShmMaterial._fields_:
+            va, vb = getattr(ma, f), getattr(mb, f)
+            if isinstance(va, abi.ShmSpectrum):
+                assert spectrum_content(a, va) == spectrum_content(b, vb), (i, f)
+            elif hasattr(va, "__len__"):
+                assert list(va) == list(vb), (i, f)
+            else:
+                assert va == vb or (va != va and vb != vb), (i, f)
+    assert a.n_lights == b.n_lights
+    for i in range(a.n_lights):
+        la, lb = a.lights[i], b.lights[i]
+        assert (la.kind, la.primitive, la.two_sided, list(la.position)) == (lb.kind, lb.primitive, lb.two_sided, list(lb.position))
+        assert np.float32(la.scale).tobytes() == np.float32(lb.scale).tobytes() and abs(la.area - lb.area) <= 1e-6 * abs(lb.area)
+        assert spectrum_content(a, la.spectrum) == spectrum_content(b, lb.spectrum)
+    if exact_pool:
+        assert arr(a.spectrum_data, a.n_spectrum_floats) == arr(b.spectrum_data, b.n_spectrum_floats)
+
+
+def film_sha(desc, params):
+    o = oracle_py.Oracle(desc)
+    try:
+        film, _ = o.render(params, n_threads=8)
+    finally:
+        o.close()
+    return hashlib.sha256(np.ascontiguousarray(film).tobytes()).hexdigest()
+
+
+S1_TEXT = """
+# S1 (BASELINE configs[0]): unit sphere, one-sided quad emitter, floor — shimmer_amd/scenes.py sphere_light
+LookAt 0 1 5   0 0 0   0 1 0
+Camera "perspective" "float fov" [ 40 ]
+Film "rgb" "integer xresolution" [ 48 ] "integer yresolution" 40 "string filename" "s1.pfm"
+Sampler "independent" "integer pixelsamples" 4
+Integrator "path" "integer maxdepth" [ 5 ]
+WorldBegin
+MakeNamedMaterial "grey" "string type" "diffuse" "float reflectance" 0.5
+MakeNamedMaterial "black" "string type" "diffuse" "float reflectance" 0
+NamedMaterial "grey"
+Shape "sphere" "float radius" 1
+AttributeBegin
+  NamedMaterial "black"
+  AreaLightSource "diffuse" "blackbody L" [ 6500 ] "float scale" 10
+  Shape "trianglemesh" "point3 P" [ -1 3 -1   1 3 -1   1 3 1   -1 3 1 ] "integer indices" [ 0 1 2  0 2 3 ]
+AttributeEnd
+Shape "trianglemesh" "point3 P" [ -4 -1 -4   -4 -1 4   4 -1 4   4 -1 -4 ] "integer indices" [ 0 1 2 0 2 3 ]
+"""
+
+
+def test_s1_text_equals_generator(lib):
+    """The default material slot 0 of the loader (scene.rs:1296-1300 installs "diffuse") precedes the named ones; the generator has none."""
+    got = load(lib, S1_TEXT)
+    try:
+        want = scenes.sphere_light(lib, 48, 40)
+        d = got.contents.desc
+        # materials: loader = [default diffuse 0.5, grey, black]; generator = [grey, black]: compare through the primitives' materials
+        assert d.n_materials == want.desc.n_materials + 1
+        prim_g = np.frombuffer(arr(d.primitives, d.n_primitives), np.uint32).reshape(-1, 4).copy()
+        prim_w = np.frombuffer(arr(want.desc.primitives, want.desc.n_primitives), np.uint32).reshape(-1, 4)
+        prim_g[:, 2] -= 1
+        assert np.array_equal(prim_g, prim_w)
+        assert arr(d.nodes, d.n_nodes) == arr(want.desc.nodes, want.desc.n_nodes)
+        assert mesh_bytes(d) == mesh_bytes(want.desc)
+        assert arr(d.spheres, 1) == arr(want.desc.spheres, 1)
+        assert bytes(d.camera) == bytes(want.desc.camera)
+        assert arr(d.spectrum_data, d.n_spectrum_floats) == arr(want.desc.spectrum_data, want.desc.n_spectrum_floats)  # one pooled blackbody table
+        for i in range(d.n_lights):
+            assert np.float32(d.lights[i].scale).tobytes() == np.float32(want.desc.lights[i].scale).tobytes()
+            assert d.lights[i].primitive == want.desc.lights[i].primitive
+        s = got.contents
+        assert (s.params.samples_per_pixel, s.params.max_depth, s.integrator, s.output_filename) == (4, 5, b"path", b"s1.pfm")
+        p = render.make_params(seed=3, spp=4, max_depth=5)
+        assert film_sha(d, p) == film_sha(want.desc, p)  # the same film, bit for bit
+    finally:
+        lib.shm_pbrt_free(got)
+
+
+def _pbrt_floats(a):
+    return " ".join(repr(float(np.float32(x))) for x in np.asarray(a).ravel())
+
+
+def cornell_text(record):
+    """S2 as .pbrt text from the generator's own recorded calls (world-space vertices, spectra by content)."""
+    lines = ["LookAt %s  %s  %s" % tuple(_pbrt_floats(v) for v in record["look_at"]), 'Camera "perspective" "float fov" [ %r ]' % record["fov"],
+             'Film "rgb" "integer xresolution" %d "integer yresolution" %d' % record["res"], "WorldBegin"]
+    for i, m in enumerate(record["materials"]):
+        lines.append('MakeNamedMaterial "m%d" "string type" "diffuse" %s' % (i, m))
+    for mesh in record["meshes"]:
+        lines.append("AttributeBegin")
+        lines.append('  NamedMaterial "m%d"' % mesh["material"])
+        if mesh["emission"]:
+            lines.append('  AreaLightSource "diffuse" "blackbody L" [ %r ] "float scale" %r' % mesh["emission"])
+        lines.append('  Shape "trianglemesh" "point3 P" [ %s ] "integer indices" [ %s ]' % (_pbrt_floats(mesh["p"]), " ".join(str(int(x)) for x in mesh["vi"].ravel())))
+        lines.append("AttributeEnd")
+    return "\n".join(lines) + "\n"
+
+
+def test_cornell_text_equals_generator(lib, monkeypatch):
+    """S2 (BASELINE configs[1]): record what the generator feeds its builder (world-space vertices before the render-space translation),
+    print that as .pbrt text, load it: same BVH, meshes, lights, camera, spectra -> same film."""
+    record = {"meshes": [], "materials": []}
+    world = []
+    orig_to_render = scenes._to_render
+    monkeypatch.setattr(scenes, "_to_render", lambda p, rfw: (world.append(np.asarray(p, np.float32)), orig_to_render(p, rfw))[1])
+    orig_look = scn.SceneBuilder.set_camera_look_at
+    orig_mesh = scn.SceneBuilder.add_mesh
+    orig_diffuse = scn.SceneBuilder.material_diffuse
+
+    def look(self, lib_, pos, look_at, up, fov, **kw):
+        record["look_at"], record["fov"] = (pos, look_at, up), float(fov)
+        return orig_look(self, lib_, pos, look_at, up, fov, **kw)
+
+    def mesh(self, p, vi, material, emission=None, emission_scale=1.0, **kw):
+        record["meshes"].append(dict(p=world[-1], vi=np.asarray(vi), material=material, emission=(6500.0, float(emission_scale)) if emission is not None else None))
+        return orig_mesh(self, p, vi, material, emission=emission, emission_scale=emission_scale, **kw)
+
+    def diffuse(self, reflectance):
+        if isinstance(reflectance, abi.ShmSpectrum):  # the 2-knot piecewise-linear wall colours: written as lambda / value pairs
+            k = reflectance
+            pool = np.concatenate(self.spec)
+            lam, val = pool[k.offset:k.offset + k.n], pool[k.offset + k.n:k.offset + 2 * k.n]
+            record["materials"].append('"spectrum reflectance" [ %s ]' % " ".join("%r %r" % (float(a), float(b)) for a, b in zip(lam, val)))
+        else:
+            record["materials"].append('"float reflectance" %r' % float(reflectance))
+        return orig_diffuse(self, reflectance)
+
+    monkeypatch.setattr(scn.SceneBuilder, "set_camera_look_at", look)
+    monkeypatch.setattr(scn.SceneBuilder, "add_mesh", mesh)
+    monkeypatch.setattr(scn.SceneBuilder, "material_diffuse", diffuse)
+    want = scenes.cornell_box(lib, 40, 40)
+    record["res"] = (40, 40)
+    text = cornell_text(record)
+    got = load(lib, text)
+    try:
+        d = got.contents.desc
+        assert d.n_primitives == 32 == want.desc.n_primitives
+        prim_g = np.frombuffer(arr(d.primitives, 32), np.uint32).reshape(-1, 4).copy()
+        prim_w = np.frombuffer(arr(want.desc.primitives, 32), np.uint32).reshape(-1, 4)
+        prim_g[:, 2] -= 1  # the loader's default material occupies slot 0
+        assert np.array_equal(prim_g, prim_w)
+        assert arr(d.nodes, d.n_nodes) == arr(want.desc.nodes, want.desc.n_nodes)
+        assert mesh_bytes(d) == mesh_bytes(want.desc)
+        assert bytes(d.camera) == bytes(want.desc.camera)
+        for i in range(want.desc.n_materials):
+            assert spectrum_content(d, d.materials[i + 1].a) == spectrum_content(want.desc, want.desc.materials[i].a)
+        p = render.make_params(seed=1, spp=2, max_depth=5)
+        assert film_sha(d, p) == film_sha(want.desc, p)
+    finally:
+        lib.shm_pbrt_free(got)
+
+
+def test_defaults_materials_textures_instances(lib, tmp_path):
+    """Reference defaults and the rest of the directive set: default camera / film / sampler / integrator (scene.rs:1225-1262: perspective
+    fov 90, 1280x720, independent 4 spp, path maxdepth 5), Cu conductor defaults, coated materials, named spectra, float / spectrum texture
+    graphs, mix of named materials, transforms, ReverseOrientation, an object instanced twice, a point and an infinite light, Include."""
+    (tmp_path / "inc.pbrt").write_text('Shape "sphere" "float radius" 0.25\n')
+    text = """
+    Film "rgb" "integer xresolution" 32 "integer yresolution" 16 "integer pixelbounds" [ 4 28 2 14 ] "float iso" 200
+    Camera "perspective"
+    WorldBegin
+    LightSource "point" "point3 from" [ 0 4 0 ] "blackbody I" 5000 "float scale" 3
+    LightSource "infinite" "float scale" 0.5
+    Texture "rough" "float" "mix" "float tex1" 0.1 "float tex2" 0.4 "float amount" 0.25
+    Texture "tint" "spectrum" "scale" "spectrum tex" [ 400 0.2 700 0.9 ] "float scale" 0.5
+    MakeNamedMaterial "gold" "string type" "conductor" "spectrum eta" "metal-Au-eta" "spectrum k" "metal-Au-k" "texture roughness" "rough"
+    MakeNamedMaterial "copper" "string type" "conductor"
+    MakeNamedMaterial "glass" "string type" "dielectric" "spectrum eta" "glass-BK7"
+    MakeNamedMaterial "paint" "string type" "coateddiffuse" "texture reflectance" "tint" "float thickness" 0.02 "integer maxdepth" 6
+    MakeNamedMaterial "both" "string type" "mix" "string materials" [ "gold" "paint" ] "float amount" 0.3
+    ObjectBegin "ball"
+      NamedMaterial "glass"
+      Include "inc.pbrt"
+    ObjectEnd
+    AttributeBegin
+      Translate 0 0 5
+      ObjectInstance "ball"
+      Translate 1 0 0
+      Scale 2 2 2
+      ObjectInstance "ball"
+    AttributeEnd
+    AttributeBegin
+      NamedMaterial "both"
+      Translate 0 -1 6
+      Rotate 90 1 0 0
+      ReverseOrientation
+      Shape "bilinearmesh" "point3 P" [ -3 -3 0  3 -3 0  -3 3 0  3 3 0 ] "normal N" [ 0 0 1  0 0 1  0 0 1  0 0 1 ]
+    AttributeEnd
+    NamedMaterial "copper"
+    Shape "trianglemesh" "point3 P" [ -1 0 4  1 0 4  0 1 4 ]
+    """
+    got = load(lib, text, str(tmp_path))
+    try:
+        s = got.contents
+        d = s.desc
+        assert (s.params.samples_per_pixel, s.params.max_depth, s.integrator, s.output_filename) == (4, 5, b"path", b"shimmer.pfm")
+        assert list(d.film.pixel_bounds) == [4, 2, 28, 14] and list(d.film.full_resolution) == [32, 16] and d.film.imaging_ratio == 2.0
+        assert d.camera.kind == abi.SHM_CAMERA_PERSPECTIVE and d.camera.lens_radius == 0.0 and d.camera.focal_distance == 1e6
+        kinds = [d.materials[i].kind for i in range(d.n_materials)]
+        assert kinds == [abi.SHM_MATERIAL_DIFFUSE, abi.SHM_MATERIAL_CONDUCTOR, abi.SHM_MATERIAL_CONDUCTOR, abi.SHM_MATERIAL_DIELECTRIC, abi.SHM_MATERIAL_COATED_DIFFUSE,
+                         abi.SHM_MATERIAL_MIX]
+        gold, copper, glass, paint, both = (d.materials[i] for i in range(1, 6))
+        assert gold.float_tex[abi.SHM_FLOATSLOT_U_ROUGHNESS] != 0 and gold.float_tex[abi.SHM_FLOATSLOT_V_ROUGHNESS] == gold.float_tex[abi.SHM_FLOATSLOT_U_ROUGHNESS]
+        assert gold.remap_roughness == 1 and copper.a.kind == abi.SHM_SPECTRUM_PIECEWISE_LINEAR and copper.u_roughness == 0.0  # defaults: metal-Cu-eta / k
+        assert glass.a.kind == abi.SHM_SPECTRUM_PIECEWISE_LINEAR  # dispersive: terminate_secondary on the device
+        assert paint.a.kind == abi.SHM_SPECTRUM_TEXTURE_NODE and abs(paint.thickness - 0.02) < 1e-9 and paint.max_depth == 6 and paint.n_samples == 1 and paint.d.c == 1.5
+        assert list(both.mix_material) == [1, 4] and abs(both.mix_amount - 0.3) < 1e-7
+        assert d.n_float_textures >= 4 and d.n_spectrum_textures == 2 and d.n_instances == 2 and d.n_spheres == 1 and d.n_patch_meshes == 1 and d.n_meshes == 1
+        assert d.patch_meshes[0].reverse_orientation == 1
+        i0, i1 = d.instances[0], d.instances[1]
+        m0, m1 = np.array(list(i0.render_from_primitive)).reshape(4, 4), np.array(list(i1.render_from_primitive)).reshape(4, 4)
+        assert np.allclose(m0, np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 5], [0, 0, 0, 1]])) and np.allclose(m1[:3, :3], 2 * np.eye(3)) and np.allclose(m1[:3, 3], [1, 0, 5])
+        assert i0.root_node == i1.root_node > 0
+        lk = [d.lights[i].kind for i in range(d.n_lights)]
+        assert lk == [abi.SHM_LIGHT_POINT, abi.SHM_LIGHT_UNIFORM_INFINITE] and list(d.lights[0].position) == [0.0, 4.0, 0.0]
+        # the description is a valid scene: the oracle accepts and renders it
+        o = oracle_py.Oracle(d)
+        film, st = o.render(render.make_params(seed=0, spp=2, max_depth=4), n_threads=4)
+        o.close()
+        assert np.isfinite(film["rgb_sum"]).all() and film["rgb_sum"].sum() > 0 and (film["weight_sum"][2:14, 4:28] == 2).all()
+    finally:
+        lib.shm_pbrt_free(got)
+
+
+@pytest.mark.parametrize("text,code,needle", [
+    ('WorldBegin\nShape "sphere"\nFoo', -1, "<string>:3: unknown directive"),
+    ('Shape "sphere"', -1, "only allowed after WorldBegin"),
+    ('WorldBegin\nShape "trianglemesh" "point3 P" [ 0 0 0 1 0 0 0 1 0 0 0 1 ]', -1, "indices"),
+    ('WorldBegin\nMaterial "diffuse" "rgb reflectance" [ 0.5 0.5 0.5 ]\nShape "sphere"', -2, "rgb"),
+    ('WorldBegin\nNamedMaterial "nope"', -1, "named material not found"),
+    ('WorldBegin\nAttributeEnd', -1, "Unmatched"),
+    ('WorldBegin\nMakeNamedMedium "fog"', -2, "media"),
+    ('WorldBegin\nShape "curve"', -2, "not supported"),
+    ('Integrator "bdpt"\nWorldBegin', -1, "Unknown integrator"),
+    ('WorldBegin\nShape "sphere" "float radius" [ abc ]', -1, "expected a number"),
+    ('WorldBegin', -1, "no shapes"),
+])
+def test_errors_are_codes_with_line_numbers(lib, text, code, needle):
+    out = C.POINTER(abi.ShmPbrtScene)()
+    rc = lib.shm_scene_parse_pbrt(text.encode(), None, C.byref(out))
+    assert rc == code and not out
+    assert needle in lib.shm_last_error().decode(), lib.shm_last_error()
+
+
+def test_load_from_file_and_look_at_blackbody_helpers(lib, tmp_path):
+    f = tmp_path / "s1.pbrt"
+    f.write_text(S1_TEXT)
+    out = C.POINTER(abi.ShmPbrtScene)()
+    abi.check(lib, lib.shm_scene_load_pbrt(str(f).encode(), C.byref(out)), "shm_scene_load_pbrt")
+    assert out.contents.desc.n_primitives == 5
+    lib.shm_pbrt_free(out)
+    assert lib.shm_scene_load_pbrt(str(tmp_path / "missing.pbrt").encode(), C.byref(out)) == -1
+    # shm_look_at = Transform::look_at's world_from_camera (transform.rs:270-303): an orthonormal frame at `eye` looking at `look`
+    m = np.zeros(16, np.float32)
+    abi.check(lib, lib.shm_look_at(scn._fptr(np.array([1, 2, 3], np.float32)), scn._fptr(np.array([1, 2, 7], np.float32)), scn._fptr(np.array([0, 1, 0], np.float32)),
+                                   scn._fptr(m)), "shm_look_at")
+    assert np.array_equal(m.reshape(4, 4), np.array([[1, 0, 0, 1], [0, 1, 0, 2], [0, 0, 1, 3], [0, 0, 0, 1]], np.float32))
+    assert lib.shm_look_at(scn._fptr(np.zeros(3, np.float32)), scn._fptr(np.zeros(3, np.float32)), scn._fptr(np.array([0, 1, 0], np.float32)), scn._fptr(m)) == -1
+    # blackbody: normalised to 1 at the Wien peak (spectrum.rs:452-461), float64 Planck within float32 rounding
+    bb = scn.blackbody_dense(6500.0)
+    lam = np.arange(360, 831) * 1e-9
+    planck = (2 * 6.62606957e-34 * 299792458.0 ** 2) / (lam ** 5 * (np.exp(6.62606957e-34 * 299792458.0 / (lam * 1.3806488e-23 * 6500.0)) - 1))
+    lmax = 2.8977721e-3 / 6500.0
+    peak = (2 * 6.62606957e-34 * 299792458.0 ** 2) / (lmax ** 5 * (np.exp(6.62606957e-34 * 299792458.0 / (lmax * 1.3806488e-23 * 6500.0)) - 1))
+    assert np.allclose(bb, planck / peak, rtol=2e-5) and bb.max() <= 1.0 + 1e-6
