@@ -293,7 +293,7 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
                 dst[1] = mesh.p[3ull * vidx + 1];
                 dst[2] = mesh.p[3ull * vidx + 2];
             }
-            rec.kind_index = 0;
+            rec.kind_index = shm::triangle_is_degenerate(shm::ld3(rec.p0), shm::ld3(rec.p1), shm::ld3(rec.p2)) ? shm::PRIM_DEGENERATE_BIT : 0u;
             rec.mesh = m;
             rec.tri = pr.shape_index;
         } else if (pr.shape_kind == SHM_SHAPE_BILINEAR_PATCH) {

@@ -34,7 +34,10 @@ struct PatchExtra {
 static_assert(sizeof(PatchExtra) == 32, "PatchExtra must be 32 bytes");
 constexpr uint32_t PRIM_PATCH_BIT = 0x40000000u;
 constexpr uint32_t PRIM_INSTANCE_BIT = 0x20000000u;  // a TransformedPrimitive: the index is into SceneView::instances, p0..p2 unused
-constexpr uint32_t PRIM_INDEX_MASK = 0x1fffffffu;
+constexpr uint32_t PRIM_DEGENERATE_BIT = 0x10000000u;  // a triangle whose edge cross product is exactly zero (triangle.rs:182-185 rejects it before anything
+                                                       // else): evaluated once at scene creation with the shared arithmetic, so the traversal kernel
+                                                       // skips 20 instructions of every leaf test (the oracle evaluates the check itself)
+constexpr uint32_t PRIM_INDEX_MASK = 0x0fffffffu;
 static_assert(sizeof(PrimRec) == 48, "PrimRec must be 48 bytes");
 constexpr uint32_t PRIM_SPHERE_BIT = 0x80000000u;
 

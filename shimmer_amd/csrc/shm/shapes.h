@@ -78,9 +78,16 @@ SHM_HD RayShear ray_shear(V3 rd) {
     return r;
 }
 
-// shape/triangle.rs:173-302 with the ray constants precomputed.
+// triangle.rs:182-185: "return no intersection if the triangle is degenerate" — a property of the triangle alone
+SHM_HD bool triangle_is_degenerate(V3 p0, V3 p1, V3 p2) { return length_squared(cross(p2 - p0, p1 - p0)) == 0.0f; }
+// shape/triangle.rs:186-302 with the ray constants precomputed: everything after the degeneracy check (callers that hold the
+// precomputed PRIM_DEGENERATE_BIT use this one; intersect_triangle_pre below is the whole function).
+SHM_HD bool intersect_triangle_nondegenerate(V3 ro, const RayShear& rs, Float t_max, V3 p0, V3 p1, V3 p2, TriangleIntersection& out);
 SHM_HD bool intersect_triangle_pre(V3 ro, const RayShear& rs, Float t_max, V3 p0, V3 p1, V3 p2, TriangleIntersection& out) {
-    if (length_squared(cross(p2 - p0, p1 - p0)) == 0.0f) return false;
+    if (triangle_is_degenerate(p0, p1, p2)) return false;
+    return intersect_triangle_nondegenerate(ro, rs, t_max, p0, p1, p2, out);
+}
+SHM_HD bool intersect_triangle_nondegenerate(V3 ro, const RayShear& rs, Float t_max, V3 p0, V3 p1, V3 p2, TriangleIntersection& out) {
     V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
     p0t = permute_cyclic(p0t, rs.kz);
     p1t = permute_cyclic(p1t, rs.kz);

@@ -190,10 +190,14 @@ class SceneBuilder:
 
     # ---- image textures (ABI v6) ----
     def use_srgb_color_space(self):
-        """RgbColorSpace::SRGB as the device needs it: the rgb2spec coefficient table (tools/gen_rgb2spec.py; the reference loads
-        rgbtospec/srgb.spec, rgb_to_spectra.rs:27-31) and the D65 illuminant, densely sampled."""
+        """RgbColorSpace::SRGB as the device needs it: the rgb2spec coefficient table at the reference's resolution 64 (tools/gen_rgb2spec.py;
+        the reference loads rgbtospec/srgb.spec, rgb_to_spectra.rs:27-31) and the D65 illuminant, densely sampled."""
         if self.color_space is None:
-            t = np.load(Path(__file__).resolve().parent / "data" / "rgb2spec_srgb.npz")
+            f = Path(__file__).resolve().parent / "data" / "rgb2spec_srgb_res64.npz"
+            if not f.exists():  # generated once by __graft_entry__.build() (tools/gen_rgb2spec.py, about two minutes on three cores)
+                import subprocess, sys
+                subprocess.check_call([sys.executable, str(Path(__file__).resolve().parents[1] / "tools" / "gen_rgb2spec.py"), "64"])
+            t = np.load(f)
             lam, val = piecewise_from_interleaved(tables()["CIE_ILLUM_D6500"], False)
             illum = np.interp(np.arange(360, 831, dtype=np.float64), lam.astype(np.float64), val.astype(np.float64)).astype(np.float32)
             self.color_space = dict(res=int(t["res"]), scale=_as_f32(t["scale"]), data=_as_f32(t["data"]).ravel(), illuminant=illum)

@@ -257,7 +257,7 @@ def test_rgb2spec_fetch(env):
             x = (c[0] * lam + c[1]) * lam + c[2]
             s = 0.5 + 0.5 * x / np.sqrt(1 + x * x)
             back = m @ ((xyz_bar * d65 * s).sum(axis=1) / (xyz_bar[1] * d65).sum())
-            assert np.allclose(back, rgb32, atol=0.03), (rgb32, back)
+            assert np.allclose(back, rgb32, atol=0.002)  # resolution 64, as the reference's table (0.03 at the resolution 16 of round 1), (rgb32, back)
     o.lib.orc_fn_rgb2spec_fetch(o.handle, fa(0.0, 0.0, 0.0), out)  # black: defined as the zero spectrum (texture.h)
     assert out[0] == 0.0 and out[1] == 0.0 and out[2] == -np.inf
 
