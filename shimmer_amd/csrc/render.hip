@@ -158,11 +158,12 @@ int dev_alloc(ShmScene* s, size_t n, T** out) {
     return SHM_OK;
 }
 
-// Path workspace sized to the work: up to SHM_BATCH_PATHS (default 256 Mi paths = 71 GB of the 288 GB) so that all 256 spp
-// of the 1024^2 frame are ONE batch (6 closest + 5 any launches for the whole frame). Small batches starve the persistent traversal kernels: with ~400 K resident lanes a
+// Path workspace sized to the work: up to SHM_BATCH_PATHS (default 512 Mi paths: 148 GB of the 288 GB for a lean scene, bounded by 80 % of
+// what is free) so that all 256 spp of the 1024^2 frame (268 M paths, 71 GB) and all 256 spp of the 1000x1400 crown-proxy frame (358 M paths:
+// its 23 late bounces of < 1 M rays cost ~2.3 ms each whatever the batch holds, once instead of twice) are ONE batch. Small batches starve the persistent traversal kernels: with ~400 K resident lanes a
 // 1 M-ray launch gives each lane ~3 rays and the launch time is set by the longest ray, not by throughput (profiles/r01_*).
 static uint64_t max_batch_paths() {
-    uint64_t max_cap = 1ull << 28;
+    uint64_t max_cap = 1ull << 29;
     if (const char* e = getenv("SHM_BATCH_PATHS")) {
         long long v = atoll(e);
         if (v >= 4096) max_cap = (uint64_t)v;

@@ -426,7 +426,12 @@ SHM_HD uint32_t base_flags(const BaseBxDF& b) {
         default: return BXDF_REFLECTION | BXDF_TRANSMISSION | BXDF_SPECULAR;
     }
 }
-SHM_HD Spec base_f(const BaseBxDF& b, V3 wo, V3 wi, int mode = MODE_RADIANCE) {
+// SHM_BASE_BXDF_CALL: a translation unit may ask for these three dispatchers as REAL calls (the LayeredBxDF scatter kernel, whose three random
+// walks reach them from ~30 sites: inlined, the kernel is 125 k instructions); everywhere else they inline as before. Same arithmetic either way.
+#ifndef SHM_BASE_BXDF_CALL
+#define SHM_BASE_BXDF_CALL SHM_HD
+#endif
+SHM_BASE_BXDF_CALL Spec base_f(const BaseBxDF& b, V3 wo, V3 wi, int mode = MODE_RADIANCE) {
     switch (b.kind) {
         case SHM_MATERIAL_DIFFUSE: return diffuse_f(b, wo, wi);
         case SHM_MATERIAL_CONDUCTOR: return conductor_f(b, wo, wi);
@@ -434,7 +439,7 @@ SHM_HD Spec base_f(const BaseBxDF& b, V3 wo, V3 wi, int mode = MODE_RADIANCE) {
         default: return spec_const(0.0f);
     }
 }
-SHM_HD bool base_sample_f(const BaseBxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out, int mode = MODE_RADIANCE) {
+SHM_BASE_BXDF_CALL bool base_sample_f(const BaseBxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out, int mode = MODE_RADIANCE) {
     switch (b.kind) {
         case SHM_MATERIAL_DIFFUSE: return diffuse_sample_f(b, wo, u, sample_flags, out);
         case SHM_MATERIAL_CONDUCTOR: return conductor_sample_f(b, wo, u, sample_flags, out);
@@ -442,7 +447,7 @@ SHM_HD bool base_sample_f(const BaseBxDF& b, V3 wo, Float uc, V2 u, uint32_t sam
         default: return thin_dielectric_sample_f(b, wo, uc, sample_flags, out);
     }
 }
-SHM_HD Float base_pdf(const BaseBxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
+SHM_BASE_BXDF_CALL Float base_pdf(const BaseBxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
     switch (b.kind) {
         case SHM_MATERIAL_DIFFUSE: return diffuse_pdf(b, wo, wi, sample_flags);
         case SHM_MATERIAL_CONDUCTOR: return conductor_pdf(b, wo, wi, sample_flags);
