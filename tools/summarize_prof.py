@@ -68,5 +68,10 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
                 if c in ("FETCH_SIZE", "WRITE_SIZE"):
                     traffic.setdefault(k, {})[c + "_bytes_per_dispatch_raw"] = v * 1024 / n
                     traffic[k]["dispatches"] = n
+            # mean active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) when that pass was collected
+            if "SQ_THREAD_CYCLES_VALU" in acc[k] and acc[k].get("SQ_ACTIVE_INST_VALU", 0) > 0:
+                lanes = acc[k]["SQ_THREAD_CYCLES_VALU"] / acc[k]["SQ_ACTIVE_INST_VALU"]
+                traffic.setdefault(k, {})["valu_lanes_active"] = lanes
+                print(f"{k:24s} {'lanes per VALU instr':22s} {lanes:20.1f}")
 import json
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
