@@ -595,12 +595,18 @@ SHM_API void shm_ply_free(ShmPlyMesh* mesh);
  * directive set the repository's scenes use: transforms (LookAt Translate Scale Rotate Identity Transform ConcatTransform CoordinateSystem
  * CoordSysTransform ReverseOrientation), Camera (perspective / orthographic), Film (rgb), Sampler (independent), PixelFilter (box),
  * Integrator (path / simplepath / randomwalk), Option, WorldBegin, AttributeBegin / End, Material / MakeNamedMaterial / NamedMaterial
- * (diffuse conductor dielectric thindielectric coateddiffuse coatedconductor mix), Texture (float / spectrum: constant scale mix
- * directionmix), AreaLightSource (diffuse), LightSource (point infinite), Shape (trianglemesh bilinearmesh sphere plymesh), ObjectBegin /
- * ObjectEnd / ObjectInstance, Include — with the reference's parameter names and defaults. Spectra: "float", "spectrum" (lambda / value
- * pairs or a named spectrum), "blackbody"; "rgb" needs the colour space's rgb2spec table and is reported as SHM_ERR_UNSUPPORTED, as is
- * everything else outside the list (image files, media, animated transforms): nothing is silently rendered as something else. Errors carry
- * file:line in shm_last_error(). The returned description owns every array it points to; free it with shm_pbrt_free. */
+ * (diffuse conductor dielectric thindielectric coateddiffuse coatedconductor mix, "normalmap"), Texture (float / spectrum: constant scale
+ * mix directionmix imagemap — with the uv / spherical / cylindrical / planar mappings), AreaLightSource (diffuse), LightSource (point,
+ * infinite: uniform or an environment image), Shape (trianglemesh bilinearmesh sphere plymesh), ObjectBegin / ObjectEnd / ObjectInstance,
+ * Include — with the reference's parameter names and defaults. Spectra: "float", "spectrum" (lambda / value pairs, a named spectrum or a
+ * spectrum file), "blackbody", and "rgb" as RgbAlbedo / RgbUnbounded / RgbIlluminantSpectrum by the slot that reads it (paramdict.rs:605-656)
+ * through the sRGB rgb2spec coefficient table — the `.spec` file the reference loads from rgbtospec/srgb.spec (rgb_to_spectra.rs:27-31),
+ * looked for in $SHM_RGB2SPEC_SRGB, <scene dir>/rgbtospec/srgb.spec, ./rgbtospec/srgb.spec, then the table tools/gen_rgb2spec.py writes
+ * beside this library. Image files are PNG, the one format the reference reads (image.rs:1140-1311), decoded and turned into MIP pyramids
+ * exactly as Image::read / MIPMap::create_from_file / Image::generate_pyramid do (host/image_io.hpp). What the reference leaves todo!() or
+ * this backend does not take (media, Import, portals, animated transforms, other colour spaces) is SHM_ERR_UNSUPPORTED: nothing is silently
+ * rendered as something else. Errors carry file:line in shm_last_error(). The returned description owns every array it points to; free
+ * it with shm_pbrt_free. */
 typedef struct ShmPbrtScene {
     ShmSceneDesc desc;          /* ready for shm_scene_create */
     ShmRenderParams params;     /* Sampler "pixelsamples" / "seed", Integrator "maxdepth" / "regularize" / "samplelights" / "samplebsdf", Option flags */
@@ -617,6 +623,19 @@ SHM_API void shm_pbrt_free(ShmPbrtScene* scene);
  * matrix of Transform::look_at (transform.rs:270-303), both in f32 as the reference computes them. */
 SHM_API int shm_blackbody_dense(float temperature_kelvin, float out471[471]);
 SHM_API int shm_look_at(const float eye[3], const float look[3], const float up[3], float world_from_camera_out[16]);
+/* The image side of the front end for hosts that fill ShmSceneDesc themselves: Image::read (PNG; `encoding` "sRGB" / "linear" / "gamma <g>",
+ * NULL = "sRGB"; image.rs:1140-1311, color.rs:487-525), then — with build_pyramid — MIPMap::create_from_file's channel selection and
+ * Image::generate_pyramid for the wrap mode (mipmap.rs:42-99, image.rs:699-802, 1007-1138). Levels come finest first with texel offsets
+ * relative to `texels`; channels: 1 ("Y") or 3 (R, G, B; an alpha plane is dropped — file_channels says what the file held, 4 with
+ * build_pyramid meaning the alpha was not all ones). has_color_space: the RGB PNG's sRGB colour space (ImageMetadata::color_space). */
+typedef struct ShmLoadedImage {
+    uint32_t n_levels, n_channels, file_channels, has_color_space;
+    uint64_t n_texel_floats;
+    ShmImageLevel* levels;
+    float* texels;
+} ShmLoadedImage;
+SHM_API int shm_image_load_png(const char* path, const char* encoding, uint32_t wrap /* SHM_WRAP_* */, int build_pyramid, ShmLoadedImage* out);
+SHM_API void shm_image_free(ShmLoadedImage* image);
 
 #ifdef __cplusplus
 }

@@ -195,6 +195,11 @@ class ShmPbrtScene(C.Structure):
     _fields_ = [("desc", ShmSceneDesc), ("params", ShmRenderParams), ("integrator", C.c_char * 32), ("output_filename", C.c_char * 256), ("owner", C.c_void_p)]
 
 
+class ShmLoadedImage(C.Structure):
+    _fields_ = [("n_levels", C.c_uint32), ("n_channels", C.c_uint32), ("file_channels", C.c_uint32), ("has_color_space", C.c_uint32),
+                ("n_texel_floats", C.c_uint64), ("levels", C.POINTER(ShmImageLevel)), ("texels", c_float_p)]
+
+
 # Every symbol include/shimmer_hip.h declares, with its signature (tests check the .so exports all of them).
 EXPORTS = {
     "shm_scene_create": (C.c_int, [C.POINTER(ShmSceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
@@ -233,6 +238,8 @@ EXPORTS = {
     "shm_pbrt_free": (None, [C.POINTER(ShmPbrtScene)]),
     "shm_blackbody_dense": (C.c_int, [C.c_float, c_float_p]),
     "shm_look_at": (C.c_int, [c_float_p, c_float_p, c_float_p, c_float_p]),
+    "shm_image_load_png": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.POINTER(ShmLoadedImage)]),
+    "shm_image_free": (None, [C.POINTER(ShmLoadedImage)]),
     "shm_render_multi": (C.c_int, [C.POINTER(ShmSceneDesc), C.POINTER(C.c_int32), C.c_int32, C.POINTER(ShmRenderParams), C.c_void_p, C.POINTER(ShmStats)]),
 }
 

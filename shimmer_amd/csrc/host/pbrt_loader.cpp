@@ -10,16 +10,21 @@
 // Scope: the directives the repository's scenes need — LookAt Translate Scale Rotate Identity Transform ConcatTransform CoordinateSystem
 // CoordSysTransform ReverseOrientation Camera (perspective / orthographic) Film (rgb) Sampler PixelFilter (box) Integrator Option
 // WorldBegin AttributeBegin/End Attribute Material MakeNamedMaterial NamedMaterial Texture (float / spectrum: constant scale mix
-// directionmix) AreaLightSource (diffuse) LightSource (point infinite) Shape (trianglemesh bilinearmesh sphere plymesh) ObjectBegin/End
-// ObjectInstance Include. What the reference itself leaves todo!() or this backend does not take (media, image files other than what the
-// library reads, "rgb" spectra without a colour-space table, animated transforms) is reported as SHM_ERR_UNSUPPORTED with the line number,
-// never rendered as something else. Host-side only.
+// directionmix imagemap) AreaLightSource (diffuse) LightSource (point, infinite: uniform or an environment image) Shape (trianglemesh
+// bilinearmesh sphere plymesh) ObjectBegin/End ObjectInstance Include; spectra as "spectrum" samples / named tables / files, "blackbody",
+// and "rgb" through the sRGB rgb2spec table (the `.spec` file the reference loads); PNG images (the only format the reference reads,
+// host/image_io.hpp) for textures, normal maps and environment lights. What the reference itself leaves todo!() or this backend does not
+// take (media, Import, portals, animated transforms, other colour spaces) is reported as SHM_ERR_UNSUPPORTED with the line number, never
+// rendered as something else. Host-side only.
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <set>
 #include <sstream>
 
+#include "image_io.hpp"
 #include "scene_assembly.hpp"
 
 extern "C" __attribute__((visibility("hidden"))) void shm_set_last_error(const char* msg);  // render.hip
@@ -162,6 +167,18 @@ public:
         memset(&a_->film, 0, sizeof(a_->film));
         // BasicSceneBuilder::new (scene.rs:1221-1304): the default material is "diffuse" with default parameters
         gs_.material = make_material("diffuse", Params(), 0);
+        // RgbColorSpace::SRGB's coefficient table (rgb_to_spectra.rs:27-31 reads rgbtospec/srgb.spec from the working directory): an explicit
+        // file first, then the reference's own location (beside the scene, then the working directory), then the table tools/gen_rgb2spec.py
+        // leaves beside this library
+        if (const char* e = getenv("SHM_RGB2SPEC_SRGB")) a_->rgb2spec_search.push_back(e);
+        if (!base_dir.empty()) a_->rgb2spec_search.push_back(base_dir + "/rgbtospec/srgb.spec");
+        a_->rgb2spec_search.push_back("rgbtospec/srgb.spec");
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void*>(&shm_set_last_error), &info) && info.dli_fname) {
+            std::string lib(info.dli_fname);
+            const size_t slash = lib.find_last_of('/');
+            a_->rgb2spec_search.push_back((slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/../data/rgb2spec_srgb_res64.spec");
+        }
         settings_.spp = 4;
         settings_.max_depth = 5;
     }
@@ -197,7 +214,21 @@ private:
     std::map<std::string, Xf> coordinate_systems_;
     std::map<std::string, int> named_materials_;
     std::map<std::string, uint32_t> float_texture_names_;
-    std::map<std::string, ShmSpectrum> spectrum_texture_names_;
+    // A named spectrum texture exists once per SpectrumType in the reference (scene.rs:268-294, 380-520: albedo / unbounded / illuminant
+    // NamedTextures); here the albedo flavour is made at the Texture directive and the other two when a slot of that type first names it.
+    // Definitions without RGB content are the same in the three flavours and share one node.
+    struct SpectrumTexDef {
+        std::string cls;
+        Params ps;
+        Xf rfo;
+        int line = 0;
+        bool type_dependent = false;
+        bool have[3] = {false, false, false};
+        ShmSpectrum variant[3];
+    };
+    std::map<std::string, SpectrumTexDef> spectrum_textures_;
+    struct LoadedImage { uint32_t first_level, n_levels, n_channels, file_channels; bool color_space; };
+    std::map<std::string, LoadedImage> image_cache_;  // TexInfo (texture.rs:77-84): filename + wrap + encoding -> the MIP pyramid's levels
     bool world_ = false;
     uint32_t object_ = 0;
     // pre-world entities (scene.rs:1578-1660): kept until WorldBegin, where the camera transform is known
@@ -252,8 +283,26 @@ private:
                 {"metal-Al-k", {TBL_AL_K_SAMPLES, sizeof(TBL_AL_K_SAMPLES) / 4}}};
             if (p.s[0] == "StdIllum-D65") { v.kind = SpectrumValue::DENSE; v.dense = illuminant_d65_dense(); return v; }
             auto it = named.find(p.s[0]);
-            if (it == named.end()) fail(tk.where(p.line) + ": spectrum files / unknown named spectrum \"" + p.s[0] + "\"", SHM_ERR_UNSUPPORTED);
             v.kind = SpectrumValue::PIECEWISE;
+            if (it == named.end()) {  // Spectrum::read_from_file -> PiecewiseLinearSpectrum::read (spectrum.rs:90-108, 372-398): wavelength value pairs
+                std::ifstream in(p.s[0]);
+                if (!in) fail(tk.where(p.line) + ": Unable to read/invalid spectrum file " + p.s[0]);
+                std::vector<float> vals;
+                std::string word;
+                while (in >> word) {
+                    char* end = nullptr;
+                    vals.push_back(strtof(word.c_str(), &end));
+                    if (end == word.c_str() || *end) fail(tk.where(p.line) + ": " + p.s[0] + ": Unable to parse float value!");
+                }
+                if (vals.empty() || vals.size() % 2) fail(tk.where(p.line) + ": Unable to read/invalid spectrum file " + p.s[0]);
+                for (size_t i = 0; i + 1 < vals.size(); i += 2) {
+                    if (i > 0 && vals[i] <= v.lam.back()) fail(tk.where(p.line) + ": " + p.s[0] + ": Spectrum file invalid, wavelengths not increasing");
+                    v.lam.push_back(vals[i]);
+                    v.val.push_back(vals[i + 1]);
+                }
+                if (v.lam.size() < 2) fail(tk.where(p.line) + ": " + p.s[0] + ": a spectrum needs at least two samples");
+                return v;
+            }
             from_interleaved(table(it->second.first, it->second.second), v.lam, v.val);
         } else if (p.type == "texture") { if (p.s.empty()) fail(tk.where(p.line) + ": texture parameter without a name"); v.kind = SpectrumValue::TEXTURE; v.texture = p.s[0]; }
         else fail(tk.where(p.line) + ": parameter \"" + p.name + "\" is not a spectrum");
@@ -267,10 +316,16 @@ private:
         Tokenizer dummy(p.name, "default");
         return spectrum_of(p, dummy);
     }
-    ShmSpectrum slot(const Params& ps, const std::string& name, Tokenizer* tk, const SpectrumValue* dflt) {
+    ShmSpectrum slot(const Params& ps, const std::string& name, Tokenizer* tk, const SpectrumValue* dflt, SpectrumType type) {
+        static const std::map<std::string, ShmSpectrum> none;
         const Param* p = ps.find(name);
-        if (!p) return a_->bind(*dflt, spectrum_texture_names_);
-        return a_->bind(spectrum_of(*p, *tk), spectrum_texture_names_);
+        if (!p) return a_->bind(*dflt, none, type);
+        Param q = *p;
+        if (q.type == "spectrum" && !q.s.empty() && q.f.empty() && q.s[0].find('.') != std::string::npos) q.s[0] = resolve(q.s[0]);  // a spectrum file
+        const SpectrumValue v = spectrum_of(q, *tk);
+        if (v.kind == SpectrumValue::TEXTURE) return spectrum_texture_ref(v.texture, type, *tk, p->line);
+        try { return a_->bind(v, none, type); }
+        catch (const LoadError& e) { fail(tk->where(p->line) + ": parameter \"" + name + "\": " + e.what(), e.code); }
     }
     // a float parameter or the float texture bound to it: sets ShmMaterial::float_tex[slot] when it names a texture
     float float_or_texture(const Params& ps, const std::string& name, float dflt, ShmMaterial& m, int slot_index, Tokenizer* tk) {
@@ -313,23 +368,23 @@ private:
                 m.displacement = float_or_texture(ps, "displacement", 0.0f, m, SHM_FLOATSLOT_DISPLACEMENT, tk);
             }
         };
-        if (ps.find("normalmap")) fail("normal maps need an image file reader: not supported by this loader", SHM_ERR_UNSUPPORTED);
+        const std::string normal_map_file = resolve(ps.one_string("normalmap", ""));
         if (type == "diffuse") {
             m.kind = SHM_MATERIAL_DIFFUSE;
-            m.a = slot(ps, "reflectance", tk, &c05);
+            m.a = slot(ps, "reflectance", tk, &c05, SPECTRUM_ALBEDO);
             displacement(true);
         } else if (type == "conductor") {
             m.kind = SHM_MATERIAL_CONDUCTOR;
             if (ps.find("reflectance")) fail("conductor \"reflectance\" is not representable in ShmMaterial: give eta and k", SHM_ERR_UNSUPPORTED);
             const SpectrumValue cu_eta = named_value("metal-Cu-eta"), cu_k = named_value("metal-Cu-k");
-            m.a = slot(ps, "eta", tk, &cu_eta);
-            m.b = slot(ps, "k", tk, &cu_k);
+            m.a = slot(ps, "eta", tk, &cu_eta, SPECTRUM_UNBOUNDED);
+            m.b = slot(ps, "k", tk, &cu_k, SPECTRUM_UNBOUNDED);
             roughness("", m.u_roughness, m.v_roughness, SHM_FLOATSLOT_U_ROUGHNESS, SHM_FLOATSLOT_V_ROUGHNESS);
             m.remap_roughness = ps.one_bool("remaproughness", true);
             displacement(false);
         } else if (type == "dielectric" || type == "thindielectric") {
             m.kind = type == "dielectric" ? SHM_MATERIAL_DIELECTRIC : SHM_MATERIAL_THIN_DIELECTRIC;
-            m.a = slot(ps, "eta", tk, &c15);  // material.rs:546-553: a float "eta" is a constant spectrum, default 1.5
+            m.a = slot(ps, "eta", tk, &c15, SPECTRUM_UNBOUNDED);  // material.rs:546-553: a float "eta" is a constant spectrum, default 1.5
             if (m.a.kind >= SHM_SPECTRUM_IMAGE_TEXTURE) fail("dielectric eta cannot be a texture");
             if (type == "dielectric") {
                 roughness("", m.u_roughness, m.v_roughness, SHM_FLOATSLOT_U_ROUGHNESS, SHM_FLOATSLOT_V_ROUGHNESS);
@@ -338,14 +393,14 @@ private:
             displacement(false);
         } else if (type == "coateddiffuse") {
             m.kind = SHM_MATERIAL_COATED_DIFFUSE;
-            m.a = slot(ps, "reflectance", tk, &c05);
+            m.a = slot(ps, "reflectance", tk, &c05, SPECTRUM_ALBEDO);
             roughness("", m.u_roughness, m.v_roughness, SHM_FLOATSLOT_U_ROUGHNESS, SHM_FLOATSLOT_V_ROUGHNESS);
             m.thickness = float_or_texture(ps, "thickness", 0.01f, m, SHM_FLOATSLOT_THICKNESS, tk);
-            m.d = slot(ps, "eta", tk, &c15);
+            m.d = slot(ps, "eta", tk, &c15, SPECTRUM_UNBOUNDED);
             m.max_depth = ps.one_int("maxdepth", 10);
             m.n_samples = ps.one_int("nsamples", 1);
             m.g = float_or_texture(ps, "g", 0.0f, m, SHM_FLOATSLOT_G, tk);
-            m.c = slot(ps, "albedo", tk, &c0);
+            m.c = slot(ps, "albedo", tk, &c0, SPECTRUM_ALBEDO);
             m.remap_roughness = ps.one_bool("remaproughness", true);
             displacement(false);
         } else if (type == "coatedconductor") {
@@ -353,20 +408,20 @@ private:
             roughness("interface.", m.u_roughness, m.v_roughness, SHM_FLOATSLOT_U_ROUGHNESS, SHM_FLOATSLOT_V_ROUGHNESS);
             roughness("conductor.", m.u2_roughness, m.v2_roughness, SHM_FLOATSLOT_U2_ROUGHNESS, SHM_FLOATSLOT_V2_ROUGHNESS);
             m.thickness = float_or_texture(ps, "thickness", 0.01f, m, SHM_FLOATSLOT_THICKNESS, tk);
-            m.d = slot(ps, "interface.eta", tk, &c15);
+            m.d = slot(ps, "interface.eta", tk, &c15, SPECTRUM_UNBOUNDED);
             if (ps.find("reflectance")) {
                 if (ps.find("conductor.eta") || ps.find("k")) fail("Cannot specify both reflectance and conductor eta/k for conductor material.");
                 m.conductor_from_reflectance = 1;
-                m.a = slot(ps, "reflectance", tk, &c05);
+                m.a = slot(ps, "reflectance", tk, &c05, SPECTRUM_ALBEDO);
             } else {
                 const SpectrumValue cu_eta = named_value("metal-Cu-eta"), cu_k = named_value("metal-Cu-k");
-                m.a = slot(ps, "conductor.eta", tk, &cu_eta);
-                m.b = slot(ps, "k", tk, &cu_k);
+                m.a = slot(ps, "conductor.eta", tk, &cu_eta, SPECTRUM_UNBOUNDED);
+                m.b = slot(ps, "k", tk, &cu_k, SPECTRUM_UNBOUNDED);
             }
             m.max_depth = ps.one_int("maxdepth", 10);
             m.n_samples = ps.one_int("nsamples", 1);
             m.g = float_or_texture(ps, "g", 0.0f, m, SHM_FLOATSLOT_G, tk);
-            m.c = slot(ps, "albedo", tk, &c0);
+            m.c = slot(ps, "albedo", tk, &c0, SPECTRUM_ALBEDO);
             m.remap_roughness = ps.one_bool("remaproughness", true);
             displacement(false);
         } else if (type == "mix") {  // material.rs:56-110: "materials" names two NAMED materials
@@ -383,6 +438,18 @@ private:
             fail("\"interface\" materials (media boundaries) are todo!() in the reference and not supported", SHM_ERR_UNSUPPORTED);
         } else {
             fail("Material \"" + type + "\" unknown.");
+        }
+        if (!normal_map_file.empty() && type != "mix") {
+            // load_normal_map (scene.rs:347-378): read with the LINEAR encoding, must have R, G, B; normal_map() reads only the finest level
+            // with WrapMode::Repeat and bilerp (material.rs:1453-1475) — the ABI takes it as an image texture with those settings
+            const LoadedImage im = load_image(normal_map_file, WRAP_REPEAT, "linear", *tk, 0, true);
+            if (im.n_channels != 3) fail("Normal map \"" + normal_map_file + "\" should have RGB channels.");
+            ShmImageTexture t = default_image_texture();
+            t.n_channels = 3;
+            t.first_level = im.first_level;
+            t.n_levels = im.n_levels;
+            a_->image_textures.push_back(t);
+            m.normal_map = (uint32_t)a_->image_textures.size();
         }
         a_->materials.push_back(m);
         return (int)a_->materials.size() - 1;
@@ -403,11 +470,11 @@ private:
         a_->float_textures.push_back(t);
         return (uint32_t)a_->float_textures.size() - 1;
     }
-    uint32_t spectrum_texture_operand(const Params& ps, const std::string& name, float dflt, Tokenizer& tk) {
+    uint32_t spectrum_texture_operand(const Params& ps, const std::string& name, float dflt, Tokenizer& tk, SpectrumType type) {
         SpectrumValue d;
         d.kind = SpectrumValue::CONSTANT;
         d.c = dflt;
-        const ShmSpectrum sp = slot(ps, name, &tk, &d);
+        const ShmSpectrum sp = slot(ps, name, &tk, &d, type);
         if (sp.kind == SHM_SPECTRUM_TEXTURE_NODE) return sp.offset;
         ShmSpectrumTexture t;
         memset(&t, 0, sizeof(t));
@@ -416,8 +483,158 @@ private:
         a_->spectrum_textures.push_back(t);
         return (uint32_t)a_->spectrum_textures.size() - 1;
     }
+    // ---- images: Image::read -> MIPMap::create_from_file -> Image::generate_pyramid (host/image_io.hpp) -> the ABI's level / texel tables ----
+    static ShmImageTexture default_image_texture() {
+        ShmImageTexture t;
+        memset(&t, 0, sizeof(t));
+        t.mapping = SHM_TEXMAP_UV;
+        t.su = t.sv = 1.0f;
+        t.vs[0] = 1.0f; t.vt[1] = 1.0f;
+        const M4 id = m4_identity();
+        memcpy(t.texture_from_render, id.m, sizeof(float) * 16);
+        t.filter = SHM_TEXFILTER_BILINEAR;
+        t.max_anisotropy = 8.0f;
+        t.wrap = SHM_WRAP_REPEAT;
+        t.scale = 1.0f;
+        t.n_channels = 3;
+        return t;
+    }
+    LoadedImage load_image(const std::string& file, WrapMode wrap, const std::string& encoding, Tokenizer& tk, int line, bool finest_level_only) {
+        const std::string key = file + "|" + std::to_string((int)wrap) + "|" + encoding + (finest_level_only ? "|0" : "");
+        auto it = image_cache_.find(key);
+        if (it != image_cache_.end()) return it->second;
+        LoadedImage out;
+        try {
+            HostImage image = image_read(file, ColorEncoding::get(encoding));
+            std::vector<HostImage> pyramid;
+            if (finest_level_only) pyramid.push_back(image);
+            else pyramid = generate_pyramid(mipmap_select_channels(image), wrap);
+            out.first_level = (uint32_t)a_->image_levels.size();
+            out.n_levels = (uint32_t)pyramid.size();
+            out.color_space = image.srgb_color_space;
+            // texel_rgb / bilerp read channels 0..2 of a 4-channel image (mipmap.rs:203-231, 317-331): the alpha plane is not handed over
+            const int keep = pyramid[0].nc == 4 ? 3 : pyramid[0].nc;
+            out.n_channels = (uint32_t)keep;
+            for (const HostImage& lv : pyramid) {
+                ShmImageLevel l;
+                memset(&l, 0, sizeof(l));
+                l.width = lv.res[0];
+                l.height = lv.res[1];
+                if (a_->texels.size() > 0xffffffffull) fail("image textures: more than 2^32 texel floats");
+                l.texel_offset = (uint32_t)a_->texels.size();
+                a_->image_levels.push_back(l);
+                for (int y = 0; y < lv.res[1]; ++y) for (int x = 0; x < lv.res[0]; ++x) for (int c = 0; c < keep; ++c) a_->texels.push_back(lv.get(x, y, c));
+            }
+            out.file_channels = (uint32_t)pyramid[0].nc;  // (4: an alpha plane that is not all ones — FloatImageTexture's bilerp would read it)
+        } catch (const LoadError& e) { fail(tk.where(line) + ": " + e.what(), e.code); }
+        image_cache_[key] = out;
+        return out;
+    }
+    // ImageTextureBase parameters (texture.rs:345-391, 728-775) + TextureMapping2D::create (texture.rs:846-880)
+    uint32_t image_texture(const Params& ps, const Xf& render_from_texture, SpectrumType type, bool spectrum, Tokenizer& tk, int line) {
+        ShmImageTexture t = default_image_texture();
+        const std::string mapping = ps.one_string("mapping", "uv");
+        if (mapping == "uv") {
+            t.mapping = SHM_TEXMAP_UV;
+            t.su = ps.one_float("uscale", 1.0f); t.sv = ps.one_float("vscale", 1.0f);
+            t.du = ps.one_float("udelta", 0.0f); t.dv = ps.one_float("vdelta", 0.0f);
+        } else if (mapping == "spherical" || mapping == "cylindrical" || mapping == "planar") {
+            t.mapping = mapping == "spherical" ? SHM_TEXMAP_SPHERICAL : (mapping == "cylindrical" ? SHM_TEXMAP_CYLINDRICAL : SHM_TEXMAP_PLANAR);
+            memcpy(t.texture_from_render, render_from_texture.inv.m, sizeof(float) * 16);  // render_from_texture.inverse()
+            if (mapping == "planar") {
+                const std::vector<float> v1 = ps.floats("v1"), v2 = ps.floats("v2");
+                if (v1.size() == 3) memcpy(t.vs, v1.data(), 12);
+                if (v2.size() == 3) memcpy(t.vt, v2.data(), 12);
+                t.du = ps.one_float("udelta", 0.0f); t.dv = ps.one_float("vdelta", 0.0f);
+            }
+        } else fail(tk.where(line) + ": Unknown texture mapping type " + mapping);
+        t.max_anisotropy = ps.one_float("maxanisotropy", 8.0f);
+        const std::string filter = ps.one_string("filter", "bilinear");  // FilterFunction::parse (mipmap.rs:343-360)
+        if (filter == "point") t.filter = SHM_TEXFILTER_POINT;
+        else if (filter == "bilinear") t.filter = SHM_TEXFILTER_BILINEAR;
+        else if (filter == "trilinear") t.filter = SHM_TEXFILTER_TRILINEAR;
+        else if (filter == "ewa" || filter == "EWA") t.filter = SHM_TEXFILTER_EWA;
+        else fail(tk.where(line) + ": Unknown filter function " + filter);
+        const std::string wrap = ps.one_string("wrap", "repeat");  // WrapMode::parse (image.rs:81-94)
+        if (wrap == "repeat") t.wrap = SHM_WRAP_REPEAT;
+        else if (wrap == "clamp") t.wrap = SHM_WRAP_CLAMP;
+        else if (wrap == "black") t.wrap = SHM_WRAP_BLACK;
+        else if (wrap == "octahedralsphere") t.wrap = SHM_WRAP_OCTAHEDRAL_SPHERE;
+        else fail(tk.where(line) + ": Unknown wrap mode " + wrap);
+        t.scale = ps.one_float("scale", 1.0f);
+        t.invert = ps.one_bool("invert", false) ? 1 : 0;
+        const std::string file = resolve(ps.one_string("filename", ""));
+        if (file.empty()) fail(tk.where(line) + ": No filename provided for texture.");
+        const size_t dot = file.find_last_of('.');
+        const std::string encoding = ps.one_string("encoding", (dot != std::string::npos && file.substr(dot + 1) == "png") ? "sRGB" : "linear");
+        const LoadedImage im = load_image(file, (WrapMode)t.wrap, encoding, tk, line, false);
+        t.first_level = im.first_level;
+        t.n_levels = im.n_levels;
+        t.n_channels = (uint8_t)im.n_channels;
+        t.spectrum_type = (uint8_t)type;
+        if (spectrum) {
+            t.has_color_space = im.color_space ? 1 : 0;
+            if (im.color_space) a_->need_color_space();
+        } else if (im.file_channels == 4) {
+            // TexelType for Float reads channel 0 in texel() but the ALPHA channel in bilerp() of a 4-channel image (mipmap.rs:296-309)
+            fail(tk.where(line) + ": float imagemap of an RGBA image with a non-opaque alpha channel is not supported", SHM_ERR_UNSUPPORTED);
+        }
+        a_->image_textures.push_back(t);
+        return (uint32_t)a_->image_textures.size() - 1;
+    }
+    static bool params_have_rgb(const Params& ps) {
+        for (const Param& p : ps.v) if (p.type == "rgb") return true;
+        return false;
+    }
+    // one flavour of a named spectrum texture (SpectrumTexture::create, texture.rs:420-503)
+    ShmSpectrum make_spectrum_texture(const SpectrumTexDef& def, SpectrumType type, Tokenizer& tk) {
+        const Params& ps = def.ps;
+        const std::string& cls = def.cls;
+        const int line = def.line;
+        ShmSpectrumTexture t;
+        memset(&t, 0, sizeof(t));
+        if (cls == "constant") {
+            SpectrumValue one;
+            one.kind = SpectrumValue::CONSTANT;
+            one.c = 1.0f;
+            return slot(ps, "value", &tk, &one, type);
+        }
+        if (cls == "imagemap") {
+            ShmSpectrum sp;
+            memset(&sp, 0, sizeof(sp));
+            sp.kind = SHM_SPECTRUM_IMAGE_TEXTURE;
+            sp.offset = image_texture(ps, def.rfo, type, true, tk, line);
+            return sp;
+        }
+        if (cls == "scale") { t.kind = SHM_SPECTEX_SCALED; t.a = spectrum_texture_operand(ps, "tex", 1.0f, tk, type); t.f = float_texture_operand(ps, "scale", 1.0f, tk); }
+        else if (cls == "mix") { t.kind = SHM_SPECTEX_MIX; t.a = spectrum_texture_operand(ps, "tex1", 0.0f, tk, type); t.b = spectrum_texture_operand(ps, "tex2", 1.0f, tk, type); t.f = float_texture_operand(ps, "amount", 0.5f, tk); }
+        else if (cls == "directionmix") {
+            t.kind = SHM_SPECTEX_DIRECTION_MIX;
+            t.a = spectrum_texture_operand(ps, "tex1", 0.0f, tk, type);
+            t.b = spectrum_texture_operand(ps, "tex2", 1.0f, tk, type);
+            const std::vector<float> d = ps.floats("dir");
+            const V3 dir = xf_vector(def.rfo.m, d.size() == 3 ? shm::v3(d[0], d[1], d[2]) : shm::v3(0.0f, 1.0f, 0.0f));
+            t.dir[0] = dir.x; t.dir[1] = dir.y; t.dir[2] = dir.z;
+        } else if (cls == "ptex") fail(tk.where(line) + ": ptex textures are not part of the reference", SHM_ERR_UNSUPPORTED);
+        else fail(tk.where(line) + ": Texture " + cls + " unknown");
+        a_->spectrum_textures.push_back(t);
+        ShmSpectrum sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.kind = SHM_SPECTRUM_TEXTURE_NODE;
+        sp.offset = (uint32_t)a_->spectrum_textures.size() - 1;
+        return sp;
+    }
+    ShmSpectrum spectrum_texture_ref(const std::string& name, SpectrumType type, Tokenizer& tk, int line) {
+        auto it = spectrum_textures_.find(name);
+        if (it == spectrum_textures_.end()) fail(tk.where(line) + ": Couldn't find spectrum texture named \"" + name + "\"");
+        SpectrumTexDef& def = it->second;
+        if (!def.have[type]) {
+            def.variant[type] = make_spectrum_texture(def, type, tk);
+            def.have[type] = true;
+        }
+        return def.variant[type];
+    }
     void texture(const std::string& name, const std::string& ty, const std::string& cls, const Params& ps, Tokenizer& tk, int line) {
-        if (cls == "imagemap" || cls == "ptex") fail(tk.where(line) + ": image textures need an image file reader: not supported by this loader", SHM_ERR_UNSUPPORTED);
         if (ty == "float") {
             if (float_texture_names_.count(name)) fail(tk.where(line) + ": Texture \"" + name + "\" being redefined");
             ShmFloatTexture t;
@@ -432,36 +649,25 @@ private:
                 const std::vector<float> d = ps.floats("dir");
                 const V3 dir = xf_vector(render_from_object().m, d.size() == 3 ? shm::v3(d[0], d[1], d[2]) : shm::v3(0.0f, 1.0f, 0.0f));  // texture.rs:265-270: in render space
                 t.dir[0] = dir.x; t.dir[1] = dir.y; t.dir[2] = dir.z;
-            } else fail(tk.where(line) + ": float texture class \"" + cls + "\" is not supported", SHM_ERR_UNSUPPORTED);
+            } else if (cls == "imagemap") { t.kind = SHM_FLOATTEX_IMAGE; t.image = image_texture(ps, render_from_object(), SPECTRUM_ALBEDO, false, tk, line); }
+            else if (cls == "ptex") fail(tk.where(line) + ": ptex textures are not part of the reference", SHM_ERR_UNSUPPORTED);
+            else fail(tk.where(line) + ": Texture " + cls + " unknown");
             a_->float_textures.push_back(t);
             float_texture_names_[name] = (uint32_t)a_->float_textures.size() - 1;
         } else if (ty == "spectrum") {
-            if (spectrum_texture_names_.count(name)) fail(tk.where(line) + ": Texture \"" + name + "\" being redefined");
-            ShmSpectrumTexture t;
-            memset(&t, 0, sizeof(t));
-            if (cls == "constant") {
-                SpectrumValue one;
-                one.kind = SpectrumValue::CONSTANT;
-                one.c = 1.0f;
-                spectrum_texture_names_[name] = slot(ps, "value", &tk, &one);
-                return;
-            }
-            if (cls == "scale") { t.kind = SHM_SPECTEX_SCALED; t.a = spectrum_texture_operand(ps, "tex", 1.0f, tk); t.f = float_texture_operand(ps, "scale", 1.0f, tk); }
-            else if (cls == "mix") { t.kind = SHM_SPECTEX_MIX; t.a = spectrum_texture_operand(ps, "tex1", 0.0f, tk); t.b = spectrum_texture_operand(ps, "tex2", 1.0f, tk); t.f = float_texture_operand(ps, "amount", 0.5f, tk); }
-            else if (cls == "directionmix") {
-                t.kind = SHM_SPECTEX_DIRECTION_MIX;
-                t.a = spectrum_texture_operand(ps, "tex1", 0.0f, tk);
-                t.b = spectrum_texture_operand(ps, "tex2", 1.0f, tk);
-                const std::vector<float> d = ps.floats("dir");
-                const V3 dir = xf_vector(render_from_object().m, d.size() == 3 ? shm::v3(d[0], d[1], d[2]) : shm::v3(0.0f, 1.0f, 0.0f));
-                t.dir[0] = dir.x; t.dir[1] = dir.y; t.dir[2] = dir.z;
-            } else fail(tk.where(line) + ": spectrum texture class \"" + cls + "\" is not supported", SHM_ERR_UNSUPPORTED);
-            a_->spectrum_textures.push_back(t);
-            ShmSpectrum sp;
-            memset(&sp, 0, sizeof(sp));
-            sp.kind = SHM_SPECTRUM_TEXTURE_NODE;
-            sp.offset = (uint32_t)a_->spectrum_textures.size() - 1;
-            spectrum_texture_names_[name] = sp;
+            if (spectrum_textures_.count(name)) fail(tk.where(line) + ": Texture \"" + name + "\" being redefined");
+            SpectrumTexDef def;
+            def.cls = cls;
+            def.ps = ps;
+            def.rfo = render_from_object();
+            def.line = line;
+            def.type_dependent = cls == "imagemap" || params_have_rgb(ps);
+            for (const Param& p : ps.v)
+                if (p.type == "texture" && !p.s.empty()) { auto it = spectrum_textures_.find(p.s[0]); if (it != spectrum_textures_.end() && it->second.type_dependent) def.type_dependent = true; }
+            def.variant[SPECTRUM_ALBEDO] = make_spectrum_texture(def, SPECTRUM_ALBEDO, tk);
+            def.have[SPECTRUM_ALBEDO] = true;
+            if (!def.type_dependent) { def.variant[SPECTRUM_UNBOUNDED] = def.variant[SPECTRUM_ILLUMINANT] = def.variant[SPECTRUM_ALBEDO]; def.have[SPECTRUM_UNBOUNDED] = def.have[SPECTRUM_ILLUMINANT] = true; }
+            spectrum_textures_[name] = def;
         } else fail(tk.where(line) + ": texture type \"" + ty + "\" unknown (float or spectrum)");
     }
 
@@ -564,8 +770,53 @@ private:
             l.position[0] = pos.x; l.position[1] = pos.y; l.position[2] = pos.z;
             l.scale = scale;
             l.spectrum = a_->spec_dense(dense);
+        } else if (type == "infinite" && !ps.one_string("filename", "").empty()) {  // light.rs:147-236: ImageInfinitelight
+            if (ps.find("portal")) fail(tk.where(line) + ": portal infinite lights are todo!() in the reference", SHM_ERR_UNSUPPORTED);
+            if (ps.find("L")) fail(tk.where(line) + ": Can't specify both emission L and filename with ImageInfinitelight");
+            const std::string file = resolve(ps.one_string("filename", ""));
+            HostImage image;
+            try { image = image_read(file, ColorEncoding::get("srgb")); }  // Image::read(path, None): the sRGB encoding (image.rs:1152-1156)
+            catch (const LoadError& e) { fail(tk.where(line) + ": " + e.what(), e.code); }
+            if (!image.srgb_color_space) fail(tk.where(line) + ": " + file + ": Expected color space (a grey PNG carries none, light.rs:169)");
+            if (image.nc < 3) fail(tk.where(line) + ": Infinite image light sources must have RGB channels");
+            if (image.res[0] != image.res[1]) fail(tk.where(line) + ": " + file + ": image resolution is non-square; it's unlikely that it is an equal-area environment map (light.rs:918-923)");
+            a_->need_color_space();
+            scale /= spectrum_to_photometric(a_->cs_illuminant);
+            const float e_v = ps.one_float("illuminance", -1.0f);
+            if (e_v > 0.0f) {  // light.rs:191-221: the upper hemisphere's illuminance of the map
+                float lum[3];
+                a_->srgb_luminance_vector(lum);
+                float illuminance = 0.0f;
+                for (int y = 0; y < image.res[1]; ++y) {
+                    const float v = ((float)y + 0.5f) / (float)image.res[1];
+                    for (int x = 0; x < image.res[0]; ++x) {
+                        const float u = ((float)x + 0.5f) / (float)image.res[0];
+                        const V3 w = shm::equal_area_square_to_sphere(shm::v2(u, v));
+                        if (w.z <= 0.0f) continue;
+                        for (int c = 0; c < 3; ++c) illuminance += image.get(x, y, c) * lum[c] * w.z;
+                    }
+                }
+                illuminance *= 2.0f * 3.14159265358979323846f / (float)(image.res[0] * image.res[1]);
+                scale *= e_v / illuminance;
+            }
+            ShmImageInfiniteLight il;
+            memset(&il, 0, sizeof(il));
+            const Xf rfl = render_from_object();
+            memcpy(il.render_from_light, rfl.m.m, sizeof(float) * 16);
+            memcpy(il.light_from_render, rfl.inv.m, sizeof(float) * 16);
+            il.image_level = (uint32_t)a_->image_levels.size();
+            ShmImageLevel lv;
+            memset(&lv, 0, sizeof(lv));
+            lv.width = image.res[0]; lv.height = image.res[1];
+            lv.texel_offset = (uint32_t)a_->texels.size();
+            a_->image_levels.push_back(lv);
+            for (int y = 0; y < image.res[1]; ++y) for (int x = 0; x < image.res[0]; ++x) for (int c = 0; c < 3; ++c) a_->texels.push_back(image.get(x, y, c));  // select_channels(R, G, B)
+            a_->image_lights.push_back(il);
+            l.kind = SHM_LIGHT_IMAGE_INFINITE;
+            l.primitive = (uint32_t)a_->image_lights.size() - 1;
+            l.scale = scale;
         } else if (type == "infinite") {
-            if (!ps.one_string("filename", "").empty() || ps.find("portal")) fail(tk.where(line) + ": image / portal infinite lights need an image file reader: not supported by this loader", SHM_ERR_UNSUPPORTED);
+            if (ps.find("portal")) fail(tk.where(line) + ": portal infinite lights are todo!() in the reference", SHM_ERR_UNSUPPORTED);
             l.kind = SHM_LIGHT_UNIFORM_INFINITE;
             SpectrumValue d65;
             d65.kind = SpectrumValue::DENSE;
@@ -859,6 +1110,57 @@ int shm_blackbody_dense(float temperature_kelvin, float out471[471]) {
     const std::vector<float> d = pbrt::blackbody_dense(temperature_kelvin);
     memcpy(out471, d.data(), sizeof(float) * 471);
     return SHM_OK;
+}
+
+int shm_image_load_png(const char* path, const char* encoding, uint32_t wrap, int build_pyramid, ShmLoadedImage* out) {
+    if (!path || !out || wrap > SHM_WRAP_OCTAHEDRAL_SPHERE) return SHM_ERR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    try {
+        const pbrt::HostImage image = pbrt::image_read(path, pbrt::ColorEncoding::get(encoding ? encoding : "sRGB"));
+        std::vector<pbrt::HostImage> levels;
+        if (build_pyramid) levels = pbrt::generate_pyramid(pbrt::mipmap_select_channels(image), (pbrt::WrapMode)wrap);
+        else levels.push_back(image);
+        const int keep = levels[0].nc >= 3 ? 3 : 1;
+        out->n_levels = (uint32_t)levels.size();
+        out->n_channels = (uint32_t)keep;
+        out->file_channels = (uint32_t)levels[0].nc;
+        out->has_color_space = image.srgb_color_space ? 1u : 0u;
+        uint64_t total = 0;
+        for (const pbrt::HostImage& lv : levels) total += (uint64_t)lv.res[0] * (uint64_t)lv.res[1] * (uint64_t)keep;
+        if (total > 0xffffffffull) pbrt::fail("image pyramid: more than 2^32 texel floats");
+        out->levels = static_cast<ShmImageLevel*>(calloc(levels.size(), sizeof(ShmImageLevel)));
+        out->texels = static_cast<float*>(malloc(sizeof(float) * (size_t)total));
+        if (!out->levels || !out->texels) { shm_image_free(out); return SHM_ERR_OUT_OF_MEMORY; }
+        uint64_t k = 0;
+        for (size_t i = 0; i < levels.size(); ++i) {
+            const pbrt::HostImage& lv = levels[i];
+            out->levels[i].width = lv.res[0];
+            out->levels[i].height = lv.res[1];
+            out->levels[i].texel_offset = (uint32_t)k;
+            for (int y = 0; y < lv.res[1]; ++y) for (int x = 0; x < lv.res[0]; ++x) for (int c = 0; c < keep; ++c) out->texels[k++] = lv.get(x, y, c);
+        }
+        out->n_texel_floats = total;
+        return SHM_OK;
+    } catch (const pbrt::LoadError& e) {
+        shm_image_free(out);
+        shm_set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        shm_image_free(out);
+        shm_set_last_error("out of memory while reading the image");
+        return SHM_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception& e) {
+        shm_image_free(out);
+        shm_set_last_error(e.what());
+        return SHM_ERR_INTERNAL;
+    }
+}
+
+void shm_image_free(ShmLoadedImage* image) {
+    if (!image) return;
+    free(image->levels);
+    free(image->texels);
+    memset(image, 0, sizeof(*image));
 }
 
 int shm_look_at(const float eye[3], const float look[3], const float up[3], float world_from_camera_out[16]) {

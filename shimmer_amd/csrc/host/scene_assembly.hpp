@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../../include/shimmer_hip.h"
+#include "../shm/path.h"  // (texture.h) rgb2spec_fetch: RgbColorSpace::to_rgb_coeffs on the host, the same code the device runs for image textures
 #include "pbrt_math.hpp"
 
 namespace pbrt {
@@ -107,6 +108,31 @@ struct SpectrumValue {
     std::string texture;           // TEXTURE: name of a spectrum texture
     std::string key;               // identity for pooling (one table per distinct emission spectrum)
 };
+// paramdict.rs SpectrumType: what an "rgb" value (or an RGB image texture) becomes at the slot that reads it
+enum SpectrumType { SPECTRUM_ALBEDO = SHM_SPECTRUM_TYPE_ALBEDO, SPECTRUM_UNBOUNDED = SHM_SPECTRUM_TYPE_UNBOUNDED, SPECTRUM_ILLUMINANT = SHM_SPECTRUM_TYPE_ILLUMINANT };
+
+// the rgb2spec coefficient table of a colour space: the `.spec` file of Jakob & Hanika's rgb2spec (crate rgb2spec 0.1.1 RGB2Spec::load:
+// "SPEC" magic, u32 resolution, f32 scale[res], f32 data[3 * res^3 * 3], little-endian; rgb_to_spectra.rs:27-31 loads rgbtospec/srgb.spec)
+struct Rgb2SpecTable {
+    uint32_t res = 0;
+    std::vector<float> scale, data;
+};
+inline bool rgb2spec_load(const std::string& path, Rgb2SpecTable& t) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[4];
+    uint32_t res = 0;
+    bool ok = fread(magic, 1, 4, f) == 4 && fread(&res, 4, 1, f) == 1 && memcmp(magic, "SPEC", 4) == 0 && res >= 2 && res <= 1024;
+    if (ok) {
+        t.res = res;
+        t.scale.resize(res);
+        t.data.resize((size_t)3 * res * res * res * 3);
+        ok = fread(t.scale.data(), sizeof(float), t.scale.size(), f) == t.scale.size() && fread(t.data.data(), sizeof(float), t.data.size(), f) == t.data.size();
+    }
+    fclose(f);
+    if (!ok) fail(path + ": not an rgb2spec coefficient file (\"SPEC\", resolution, scale[res], data[3][res][res][res][3])");
+    return true;
+}
 
 class Assembly {
 public:
@@ -138,6 +164,94 @@ public:
     bool have_camera = false;
     std::vector<float> sensor_x = PBRT_TABLE(CIE_X), sensor_y = PBRT_TABLE(CIE_Y), sensor_z = PBRT_TABLE(CIE_Z);
     std::map<std::string, std::pair<ShmSpectrum, float>> emission_cache;  // key -> (pooled dense table, photometric integral)
+    // image textures / lights and the colour space they (and "rgb" parameters) need
+    std::vector<ShmImageTexture> image_textures;
+    std::vector<ShmImageLevel> image_levels;
+    std::vector<float> texels;
+    std::vector<ShmImageInfiniteLight> image_lights;
+    std::vector<float> ewa_lut = PBRT_TABLE(MIP_FILTER_LUT);
+    Rgb2SpecTable rgb2spec;
+    std::vector<float> cs_illuminant;       // RgbColorSpace::SRGB.illuminant: StdIllum-D65, densely sampled (colorspace.rs:139, 65)
+    std::vector<std::string> rgb2spec_search;  // where the table is looked for, in order
+    // RgbColorSpace::SRGB's coefficient table, loaded the first time something needs it
+    void need_color_space() {
+        if (rgb2spec.res) return;
+        std::string tried;
+        for (const std::string& p : rgb2spec_search) {
+            if (p.empty()) continue;
+            if (rgb2spec_load(p, rgb2spec)) break;
+            tried += (tried.empty() ? "" : ", ") + p;
+        }
+        if (!rgb2spec.res)
+            fail("\"rgb\" values and RGB images need the sRGB rgb2spec coefficient table (the reference loads rgbtospec/srgb.spec, rgb_to_spectra.rs:27-31); not found in: " +
+                     tried + " — set SHM_RGB2SPEC_SRGB or run tools/gen_rgb2spec.py", SHM_ERR_UNSUPPORTED);
+        cs_illuminant = illuminant_d65_dense();
+    }
+    // RgbColorSpace::to_rgb_coeffs (colorspace.rs:95-98 -> rgb_to_spectra.rs:16-25 -> RGB2Spec::fetch)
+    void rgb_coeffs(const float rgb[3], float out[3]) {
+        need_color_space();
+        shm::SceneView sv;
+        memset(&sv, 0, sizeof(sv));
+        sv.rgb2spec_res = rgb2spec.res;
+        sv.rgb2spec_scale = rgb2spec.scale.data();
+        sv.rgb2spec_data = rgb2spec.data.data();
+        shm::rgb2spec_fetch(sv, shm::rgb3(rgb[0], rgb[1], rgb[2]), out);
+    }
+    // RgbAlbedoSpectrum / RgbUnboundedSpectrum / RgbIlluminantSpectrum::new (spectrum.rs:502-509, 536-547, 574-588)
+    ShmSpectrum spec_rgb(const float rgb[3], SpectrumType type) {
+        if (rgb[0] < 0.0f || rgb[1] < 0.0f || rgb[2] < 0.0f) fail("RGB parameter has negative component");  // paramdict.rs:628-633
+        ShmSpectrum s;
+        memset(&s, 0, sizeof(s));
+        if (type == SPECTRUM_ALBEDO) {
+            if (rgb[0] > 1.0f || rgb[1] > 1.0f || rgb[2] > 1.0f) fail("RGB parameter has component value > 1.0");  // paramdict.rs:641-646
+            s.kind = SHM_SPECTRUM_RGB_ALBEDO;
+            rgb_coeffs(rgb, s.rgb_c);
+            return s;
+        }
+        const float m = std::max(std::max(rgb[0], rgb[1]), rgb[2]);
+        const float scale = 2.0f * m;
+        const float scaled[3] = {scale != 0.0f ? rgb[0] / scale : 0.0f, scale != 0.0f ? rgb[1] / scale : 0.0f, scale != 0.0f ? rgb[2] / scale : 0.0f};
+        rgb_coeffs(scaled, s.rgb_c);
+        s.c = scale;
+        if (type == SPECTRUM_UNBOUNDED) { s.kind = SHM_SPECTRUM_RGB_UNBOUNDED; return s; }
+        s.kind = SHM_SPECTRUM_RGB_ILLUMINANT;
+        if (cs_illuminant_offset == ~0u) cs_illuminant_offset = pool(cs_illuminant);
+        s.offset = cs_illuminant_offset;
+        s.n = 471;
+        s.lambda_min = 360;
+        return s;
+    }
+    uint32_t cs_illuminant_offset = ~0u;
+    // RgbColorSpace::SRGB.luminance_vector(): row 1 of xyz_from_rgb (colorspace.rs:38-72, 107-114). With Y = 1 for the three primaries that row
+    // is c = rgb^-1 W itself, W = XYZ::from_spectrum(D65) (f32 running sums as inner_product, spectrum.rs:609-615). The 3x3 inverse of the
+    // reference is built from compensated difference_of_products; here it is evaluated in f64 and rounded once.
+    void srgb_luminance_vector(float lum[3]) {
+        need_color_space();
+        float w[3];
+        const std::vector<float>* bars[3] = {&sensor_x, &sensor_y, &sensor_z};
+        const std::vector<float> yi = PBRT_TABLE(CIE_Y_INTEGRAL);
+        for (int k = 0; k < 3; ++k) {
+            float acc = 0.0f;
+            for (int i = 0; i < 471; ++i) acc += (*bars[k])[i] * cs_illuminant[i];
+            w[k] = acc / yi[0];
+        }
+        const float xy[3][2] = {{0.64f, 0.33f}, {0.3f, 0.6f}, {0.15f, 0.06f}};
+        double m[3][3];
+        for (int j = 0; j < 3; ++j) { m[0][j] = xy[j][0] * 1.0f / xy[j][1]; m[1][j] = 1.0; m[2][j] = (1.0f - xy[j][0] - xy[j][1]) * 1.0f / xy[j][1]; }
+        const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        double inv[3][3];
+        inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det; inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det;
+        inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det; inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+        inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det; inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+        for (int k = 0; k < 3; ++k) lum[k] = (float)(inv[k][0] * w[0] + inv[k][1] * w[1] + inv[k][2] * w[2]);
+    }
+    // Spectrum::get of an RGB-derived spectrum at the 471 integer wavelengths (DenselySampledSpectrum::new of it: lights)
+    std::vector<float> rgb_dense(const float rgb[3], SpectrumType type) {
+        ShmSpectrum s = spec_rgb(rgb, type);
+        std::vector<float> d(471);
+        for (int l = 360; l <= 830; ++l) d[l - 360] = shm::spectrum_get(s, spec.data(), (float)l);
+        return d;
+    }
 
     // ---- spectra ----
     static ShmSpectrum spec_constant(float c) {
@@ -172,7 +286,7 @@ public:
         return s;
     }
     // a material slot: constants and piecewise-linear spectra keep their kind; a blackbody becomes its dense table
-    ShmSpectrum bind(const SpectrumValue& v, const std::map<std::string, ShmSpectrum>& spectrum_texture_names) {
+    ShmSpectrum bind(const SpectrumValue& v, const std::map<std::string, ShmSpectrum>& spectrum_texture_names, SpectrumType type = SPECTRUM_ALBEDO) {
         switch (v.kind) {
             case SpectrumValue::CONSTANT: return spec_constant(v.c);
             case SpectrumValue::PIECEWISE: return spec_piecewise(v.lam, v.val);
@@ -182,17 +296,17 @@ public:
                 if (it == spectrum_texture_names.end()) fail("Couldn't find spectrum texture named \"" + v.texture + "\"");
                 return it->second;
             }
-            case SpectrumValue::RGB: fail("\"rgb\" parameters need the colour space's rgb2spec table, which this loader does not carry: give the spectrum as \"spectrum\" samples", SHM_ERR_UNSUPPORTED);
+            case SpectrumValue::RGB: return spec_rgb(v.rgb, type);
             default: fail("missing spectrum");
         }
     }
     // a light's emission: DenselySampledSpectrum::new(spectrum) (light.rs:525-527, 416-419)
-    std::vector<float> dense_of(const SpectrumValue& v) {
+    std::vector<float> dense_of(const SpectrumValue& v, SpectrumType type = SPECTRUM_ILLUMINANT) {
         switch (v.kind) {
             case SpectrumValue::CONSTANT: return std::vector<float>(471, v.c);
             case SpectrumValue::PIECEWISE: return piecewise_to_dense(v.lam, v.val);
             case SpectrumValue::DENSE: return v.dense;
-            case SpectrumValue::RGB: fail("\"rgb\" light spectra need the colour space's rgb2spec table: give \"blackbody\" or \"spectrum\" samples", SHM_ERR_UNSUPPORTED);
+            case SpectrumValue::RGB: return rgb_dense(v.rgb, type);
             default: fail("a light's spectrum cannot be a texture");
         }
     }
@@ -448,6 +562,17 @@ public:
         d.n_instances = (uint32_t)out->instances.size(); d.instances = out->instances.data();
         d.n_float_textures = (uint32_t)a.float_textures.size(); d.float_textures = a.float_textures.data();
         d.n_spectrum_textures = (uint32_t)a.spectrum_textures.size(); d.spectrum_textures = a.spectrum_textures.data();
+        d.n_image_textures = (uint32_t)a.image_textures.size(); d.image_textures = a.image_textures.data();
+        d.n_image_levels = (uint32_t)a.image_levels.size(); d.image_levels = a.image_levels.data();
+        d.n_texel_floats = a.texels.size(); d.texel_data = a.texels.data();
+        d.n_image_lights = (uint32_t)a.image_lights.size(); d.image_lights = a.image_lights.data();
+        if (!a.image_textures.empty() || !a.image_lights.empty()) d.ewa_filter_lut = a.ewa_lut.data();
+        if (a.rgb2spec.res) {  // ShmColorSpace (only when something asked for it: RGB images, image lights)
+            d.color_space.rgb2spec_res = a.rgb2spec.res;
+            d.color_space.rgb2spec_scale = a.rgb2spec.scale.data();
+            d.color_space.rgb2spec_data = a.rgb2spec.data.data();
+            d.color_space.illuminant = a.cs_illuminant.data();
+        }
         out->owner = std::move(self_owned);
         return out;
     }

@@ -198,8 +198,9 @@ class SceneBuilder:
                 import subprocess, sys
                 subprocess.check_call([sys.executable, str(Path(__file__).resolve().parents[1] / "tools" / "gen_rgb2spec.py"), "64"])
             t = np.load(f)
-            lam, val = piecewise_from_interleaved(tables()["CIE_ILLUM_D6500"], False)
-            illum = np.interp(np.arange(360, 831, dtype=np.float64), lam.astype(np.float64), val.astype(np.float64)).astype(np.float32)
+            # RgbColorSpace::SRGB.illuminant = DenselySampledSpectrum::new(StdIllum-D65), the normalised table (colorspace.rs:65, 139;
+            # named_spectrum.rs:52-56) — the same floats the C++ front end hands over (host/scene_assembly.hpp illuminant_d65_dense)
+            illum = piecewise_to_dense(*piecewise_from_interleaved(tables()["CIE_ILLUM_D6500"], True))
             self.color_space = dict(res=int(t["res"]), scale=_as_f32(t["scale"]), data=_as_f32(t["data"]).ravel(), illuminant=illum)
         return self.color_space
 

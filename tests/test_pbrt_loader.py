@@ -284,7 +284,14 @@ def test_defaults_materials_textures_instances(lib, tmp_path):
     ('WorldBegin\nShape "sphere"\nFoo', -1, "<string>:3: unknown directive"),
     ('Shape "sphere"', -1, "only allowed after WorldBegin"),
     ('WorldBegin\nShape "trianglemesh" "point3 P" [ 0 0 0 1 0 0 0 1 0 0 0 1 ]', -1, "indices"),
-    ('WorldBegin\nMaterial "diffuse" "rgb reflectance" [ 0.5 0.5 0.5 ]\nShape "sphere"', -2, "rgb"),
+    ('WorldBegin\nMaterial "diffuse" "rgb reflectance" [ 0.5 1.5 0.5 ]\nShape "sphere"', -1, "<string>:2: parameter \"reflectance\": RGB parameter has component value > 1.0"),
+    ('WorldBegin\nMaterial "conductor" "rgb k" [ 0.5 -1 0.5 ]\nShape "sphere"', -1, "negative component"),
+    ('WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "nope.png"\nShape "sphere"', -1, "<string>:2: unable to read"),
+    ('WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "a.exr"\nShape "sphere"', -2, "Unsupported file extension"),
+    ('WorldBegin\nTexture "t" "float" "imagemap" "string filename" "a.png" "string filter" "cubic"\nShape "sphere"', -1, "Unknown filter function"),
+    ('WorldBegin\nTexture "t" "float" "wrinkled"\nShape "sphere"', -1, "Texture wrinkled unknown"),
+    ('WorldBegin\nLightSource "infinite" "string filename" "e.png" "point3 portal" [ 0 0 0 1 0 0 1 1 0 0 1 0 ]\nShape "sphere"', -2, "portal"),
+    ('WorldBegin\nImport "other.pbrt"', -2, "Import"),
     ('WorldBegin\nNamedMaterial "nope"', -1, "named material not found"),
     ('WorldBegin\nAttributeEnd', -1, "Unmatched"),
     ('WorldBegin\nMakeNamedMedium "fog"', -2, "media"),
@@ -321,3 +328,110 @@ def test_load_from_file_and_look_at_blackbody_helpers(lib, tmp_path):
     lmax = 2.8977721e-3 / 6500.0
     peak = (2 * 6.62606957e-34 * 299792458.0 ** 2) / (lmax ** 5 * (np.exp(6.62606957e-34 * 299792458.0 / (lmax * 1.3806488e-23 * 6500.0)) - 1))
     assert np.allclose(bb, planck / peak, rtol=2e-5) and bb.max() <= 1.0 + 1e-6
+
+
+def test_rgb_spectra_png_textures_normal_map_and_environment_light(lib, tmp_path):
+    """The rest of the reference's front end: "rgb" values become RgbAlbedo / RgbUnbounded / RgbIlluminantSpectrum by the slot that reads them
+    (paramdict.rs:605-656; spectrum.rs:502-509, 536-547, 574-588) through the sRGB rgb2spec table; "imagemap" textures, "normalmap" and the
+    "infinite" light's "filename" read PNG files (image.rs:1140-1311) into the ABI's level / texel tables; a named spectrum texture exists
+    per spectrum type (scene.rs:268-294, 380-520), so the same image bound to a reflectance and to a conductor's eta is two ShmImageTextures
+    over ONE pyramid."""
+    from test_image_io import load_png, write_png
+    from test_textures import fetch64
+    rng = np.random.default_rng(11)
+    write_png(tmp_path / "albedo.png", rng.integers(0, 256, size=(8, 8, 3)), 8, 2, filters=(1, 4))
+    write_png(tmp_path / "bump.png", rng.integers(0, 256, size=(4, 4, 1)), 8, 0)
+    write_png(tmp_path / "nmap.png", rng.integers(0, 256, size=(4, 4, 3)), 8, 2)
+    write_png(tmp_path / "env.png", rng.integers(0, 256, size=(16, 16, 4)), 8, 6)
+    (tmp_path / "tint.spd").write_text("400 0.1\n550 0.6 700 0.9\n")
+    text = """
+    Film "rgb" "integer xresolution" 24 "integer yresolution" 16
+    Camera "perspective" "float fov" 50
+    WorldBegin
+    AttributeBegin
+      Rotate 30 0 1 0
+      LightSource "infinite" "string filename" "env.png" "float scale" 2
+    AttributeEnd
+    LightSource "point" "rgb I" [ 1 0.5 0.25 ] "point3 from" [ 0 3 2 ]
+    Texture "wood" "spectrum" "imagemap" "string filename" "albedo.png" "string filter" "trilinear" "float uscale" 2 "float vdelta" 0.25
+    Texture "bumps" "float" "imagemap" "string filename" "bump.png" "string wrap" "clamp" "string encoding" "linear" "float scale" 0.05
+    Texture "blend" "spectrum" "mix" "texture tex1" "wood" "rgb tex2" [ 0.9 0.1 0.1 ] "float amount" 0.25
+    Texture "plain" "spectrum" "constant" "spectrum value" "tint.spd"
+    Material "diffuse" "texture reflectance" "blend" "texture displacement" "bumps"
+    Shape "trianglemesh" "point3 P" [ -2 -1 3  2 -1 3  2 -1 7  -2 -1 7 ] "integer indices" [ 0 1 2 0 2 3 ] "point2 uv" [ 0 0 1 0 1 1 0 1 ]
+    Material "conductor" "texture eta" "wood" "rgb k" [ 2 3 4 ] "float roughness" 0.2
+    Translate 0 0 5
+    Shape "sphere" "float radius" 0.7
+    Material "coateddiffuse" "rgb reflectance" [ 0.2 0.5 0.7 ] "string normalmap" "nmap.png" "texture albedo" "plain"
+    Translate 1.5 0 0
+    Shape "sphere" "float radius" 0.5
+    AttributeBegin
+      AreaLightSource "diffuse" "rgb L" [ 1 1 1 ] "float scale" 4
+      Translate -3 2 0
+      Shape "sphere" "float radius" 0.25
+    AttributeEnd
+    """
+    got = load(lib, text, str(tmp_path))
+    try:
+        d = got.contents.desc
+        b = scn.SceneBuilder()
+        cs = b.use_srgb_color_space()
+        # ShmColorSpace: the table and the normalised D65 the Python generators use too, bit for bit
+        assert d.color_space.rgb2spec_res == 64 and arr(d.color_space.rgb2spec_scale, 64) == cs["scale"].tobytes()
+        assert arr(d.color_space.rgb2spec_data, 3 * 64 ** 3 * 3) == cs["data"].tobytes() and arr(d.color_space.illuminant, 471) == cs["illuminant"].tobytes()
+        # image textures: wood (albedo, at the Texture directive), bumps, wood again (unbounded, when the conductor's eta names it), the normal map
+        it = [d.image_textures[i] for i in range(d.n_image_textures)]
+        assert [(t.spectrum_type, t.filter, t.wrap, t.n_channels, t.has_color_space) for t in it] == [
+            (abi.SHM_SPECTRUM_TYPE_ALBEDO, abi.SHM_TEXFILTER_TRILINEAR, abi.SHM_WRAP_REPEAT, 3, 1), (0, abi.SHM_TEXFILTER_BILINEAR, abi.SHM_WRAP_CLAMP, 1, 0),
+            (abi.SHM_SPECTRUM_TYPE_UNBOUNDED, abi.SHM_TEXFILTER_TRILINEAR, abi.SHM_WRAP_REPEAT, 3, 1), (0, abi.SHM_TEXFILTER_BILINEAR, abi.SHM_WRAP_REPEAT, 3, 0)]
+        assert (it[0].su, it[0].sv, it[0].du, it[0].dv, it[1].scale) == (2.0, 1.0, 0.0, 0.25, np.float32(0.05))
+        assert (it[0].first_level, it[0].n_levels) == (it[2].first_level, it[2].n_levels) == (1, 4)  # level 0 of the table is the environment map
+        assert (it[3].n_levels, it[1].n_levels) == (1, 3)  # the normal map hands over its finest level only (material.rs:1453-1475)
+        texels = np.ctypeslib.as_array(d.texel_data, shape=(d.n_texel_floats,))
+
+        def level(i, nc):
+            lv = d.image_levels[i]
+            return texels[lv.texel_offset:lv.texel_offset + lv.width * lv.height * nc].reshape(lv.height, lv.width, nc)
+
+        wood, _ = load_png(lib, tmp_path / "albedo.png", "sRGB", pyramid=True)
+        for k, lv in enumerate(wood):
+            assert np.array_equal(level(1 + k, 3), lv)
+        bump, _ = load_png(lib, tmp_path / "bump.png", "linear", wrap=abi.SHM_WRAP_CLAMP, pyramid=True)
+        assert np.array_equal(level(it[1].first_level, 1), bump[0])
+        nmap, _ = load_png(lib, tmp_path / "nmap.png", "linear")
+        assert np.array_equal(level(it[3].first_level, 3), nmap[0])
+        env, _ = load_png(lib, tmp_path / "env.png", "sRGB")
+        assert d.n_image_lights == 1 and d.image_lights[0].image_level == 0 and np.array_equal(level(0, 3), env[0])
+        m = np.array(list(d.image_lights[0].render_from_light)).reshape(4, 4)
+        assert np.allclose(m[:3, :3], [[np.cos(np.pi / 6), 0, np.sin(np.pi / 6)], [0, 1, 0], [-np.sin(np.pi / 6), 0, np.cos(np.pi / 6)]], atol=1e-6)
+        lights = [d.lights[i] for i in range(d.n_lights)]
+        assert [l.kind for l in lights] == [abi.SHM_LIGHT_IMAGE_INFINITE, abi.SHM_LIGHT_POINT, abi.SHM_LIGHT_DIFFUSE_AREA]
+        photometric = float(scn.spectrum_to_photometric(cs["illuminant"]))
+        assert lights[0].scale == pytest.approx(2.0 / photometric, rel=1e-6)  # light.rs:181: scale / spectrum_to_photometric(cs.illuminant)
+        # materials: [default, diffuse(blend), conductor, coateddiffuse]
+        diffuse, conductor, coated = d.materials[1], d.materials[2], d.materials[3]
+        assert diffuse.a.kind == abi.SHM_SPECTRUM_TEXTURE_NODE and diffuse.float_tex[abi.SHM_FLOATSLOT_DISPLACEMENT] != 0 and diffuse.has_displacement == 1
+        node = d.spectrum_textures[diffuse.a.offset]
+        leaf1, leaf2 = d.spectrum_textures[node.a].leaf, d.spectrum_textures[node.b].leaf
+        assert node.kind == abi.SHM_SPECTEX_MIX and (leaf1.kind, leaf1.offset) == (abi.SHM_SPECTRUM_IMAGE_TEXTURE, 0) and leaf2.kind == abi.SHM_SPECTRUM_RGB_ALBEDO
+        assert np.allclose(list(leaf2.rgb_c), fetch64(cs, [0.9, 0.1, 0.1]), rtol=2e-4, atol=1e-6)
+        assert (conductor.a.kind, conductor.a.offset) == (abi.SHM_SPECTRUM_IMAGE_TEXTURE, 2) and conductor.b.kind == abi.SHM_SPECTRUM_RGB_UNBOUNDED and conductor.b.c == 8.0
+        assert np.allclose(list(conductor.b.rgb_c), fetch64(cs, [0.25, 0.375, 0.5]), rtol=2e-4, atol=1e-6)  # rgb / (2 max), spectrum.rs:538-541
+        assert coated.a.kind == abi.SHM_SPECTRUM_RGB_ALBEDO and np.allclose(list(coated.a.rgb_c), fetch64(cs, [0.2, 0.5, 0.7]), rtol=2e-4, atol=1e-6)
+        assert coated.normal_map == 4 and coated.c.kind == abi.SHM_SPECTRUM_PIECEWISE_LINEAR and coated.c.n == 3  # the spectrum file
+        # RgbIlluminantSpectrum(1, 1, 1) = 2 s(0.5, 0.5, 0.5) D65 = D65 up to the table's fit (the light stores it densely sampled)
+        spec = np.ctypeslib.as_array(d.spectrum_data, shape=(d.n_spectrum_floats,))
+        area = spec[lights[2].spectrum.offset:lights[2].spectrum.offset + 471]
+        assert np.allclose(area, cs["illuminant"], rtol=0.02) and lights[2].scale == pytest.approx(4.0 / float(scn.spectrum_to_photometric(area)), rel=1e-6)
+        point = spec[lights[1].spectrum.offset:lights[1].spectrum.offset + 471]
+        c = fetch64(cs, [0.5, 0.25, 0.125])
+        lam = np.arange(360.0, 831.0)
+        x = (c[0] * lam + c[1]) * lam + c[2]
+        assert np.allclose(point, 2.0 * (0.5 + 0.5 * x / np.sqrt(1 + x * x)) * cs["illuminant"], rtol=2e-3)
+        # and it is a valid scene: the oracle renders it
+        o = oracle_py.Oracle(d)
+        film, _ = o.render(render.make_params(seed=0, spp=2, max_depth=4), n_threads=4)
+        o.close()
+        assert np.isfinite(film["rgb_sum"]).all() and film["rgb_sum"].sum() > 0
+    finally:
+        lib.shm_pbrt_free(got)

@@ -29,10 +29,10 @@ def test_cpu_suite_under_asan_and_ubsan():
     subprocess.run(["make", "-C", str(ROOT / "oracle"), "asan"], check=True, capture_output=True)
     env = dict(os.environ, LD_PRELOAD=libasan + (" " + libstdcxx if libstdcxx and Path(libstdcxx).exists() else ""), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1",
                ORACLE_LIB=str(ROOT / "oracle" / "_build" / "liboracle_asan.so"), SHM_LIB=str(ROOT / "oracle" / "_build" / "libhostmirror_asan.so"),
-               SHM_HOST_ONLY="1")
+               SHM_HOST_ONLY="1", SHM_RGB2SPEC_SRGB=str(ROOT / "shimmer_amd" / "data" / "rgb2spec_srgb_res64.spec"))  # (the loader's default is beside the PRODUCT library)
     # everything that runs without a device entry point (those live in shimmer_hip.hip, which only hipcc builds)
     files = ["test_oracle_golden.py", "test_textures.py", "test_image_light.py", "test_instancing.py", "test_ply.py", "test_layered.py",
-             "test_bilinear_patch.py", "test_spectra.py", "test_fuzz_scenes.py", "test_golden_films.py", "test_oracle_render.py", "test_host_mirror.py", "test_pbrt_loader.py", "test_leaf_golden.py"]
+             "test_bilinear_patch.py", "test_spectra.py", "test_fuzz_scenes.py", "test_golden_films.py", "test_oracle_render.py", "test_host_mirror.py", "test_pbrt_loader.py", "test_leaf_golden.py", "test_image_io.py"]
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "not gpu", "-p", "no:cacheprovider",
            "-k", "not exports_every_declared and not no_device and not integrator_mirror_errors"] + [str(ROOT / "tests" / f) for f in files]
     r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=1500)

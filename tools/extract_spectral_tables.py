@@ -14,6 +14,7 @@ import numpy as np
 
 REF = Path("/root/reference/src/spectra")
 MIPMAP = Path("/root/reference/src/mipmap.rs")  # MIP_FILTER_LUT: the 128 tabulated EWA filter weights (a data table like the others)
+COLOR = Path("/root/reference/src/color.rs")    # SRGB_TO_LINEAR_LUT: the 256 tabulated sRGB decode values (IEC 61966-2-1 EOTF of i / 255)
 OUT = Path(__file__).resolve().parents[1] / "shimmer_amd" / "data" / "spectral_tables.npz"
 WANT = {
     "cie.rs": ["CIE_LAMBDA", "CIE_X", "CIE_Y", "CIE_Z"],
@@ -37,6 +38,9 @@ def main():
     m = re.search(r"const\s+MIP_FILTER_LUT\s*:\s*\[Float;\s*MIP_FILTER_LUT_SIZE\]\s*=\s*\[(.*?)\];", text, re.S)
     tables["MIP_FILTER_LUT"] = np.asarray([float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()], dtype=np.float32)
     assert tables["MIP_FILTER_LUT"].size == 128
+    m = re.search(r"const\s+SRGB_TO_LINEAR_LUT\s*:\s*\[Float;\s*256\]\s*=\s*\[(.*?)\];", COLOR.read_text(), re.S)
+    tables["SRGB_TO_LINEAR_LUT"] = np.asarray([float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()], dtype=np.float32)
+    assert tables["SRGB_TO_LINEAR_LUT"].size == 256 and tables["SRGB_TO_LINEAR_LUT"][255] == 1.0
     assert tables["CIE_X"].size == 471 and tables["CIE_LAMBDA"][0] == 360.0 and tables["CIE_LAMBDA"][-1] == 830.0
     tables["CIE_Y_INTEGRAL"] = np.float32(106.856895)  # spectra/cie.rs:11
     OUT.parent.mkdir(parents=True, exist_ok=True)
