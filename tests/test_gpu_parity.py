@@ -227,6 +227,87 @@ def test_full_size_properties_and_crop_parity(env):
     orc.close()
 
 
+def test_headline_frame_at_full_size(env):
+    """BASELINE.json configs[2] exactly as bench.py times it — S3 with 4 305 626 primitives, 1024 x 1024, 256 spp, maxdepth 5, one 268 M-path
+    batch — through the size-independent properties the path offers, plus an oracle crop at the full sample count:
+      (i)   two renders are identical (the persistent queues hand rays to lanes in a run-dependent order; nothing may depend on it);
+      (ii)  every pixel holds exactly 256 samples and finite sums; paths = pixels x spp; closest-hit rays >= paths; shadow rays <= closest;
+      (iii) the frame rendered as two interleaved tile sets into one device film equals the whole render, bit for bit;
+      (iv)  a 16 x 16 pixel block in the object's silhouette at all 256 samples equals the oracle's film of those tiles, bit for bit,
+            and the node / triangle visit counters of that block equal the oracle's."""
+    lib, oracle_py, render, scenes = env
+    from shimmer_amd import scene as scn
+    sc = scenes.ganesha_proxy(lib, 1024, 1024)
+    assert sc.info["n_primitives"] == 4305626
+    p = render.make_params(seed=0, spp=256, max_depth=5)
+    gpu = render.Renderer(lib, sc.desc, 0)
+    gpu.clear()
+    s1 = gpu.render_device(p)
+    f1 = gpu.read_film()
+    gpu.clear()
+    s2 = gpu.render_device(p)
+    f2 = gpu.read_film()
+    assert np.array_equal(f1, f2)
+    for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+        assert s1[k] == s2[k], k
+    assert (f1["weight_sum"] == 256.0).all() and np.isfinite(f1["rgb_sum"]).all() and (f1["rgb_sum"] >= 0).all()
+    assert s1["paths"] == 1024 * 1024 * 256 and s1["rays_closest"] >= s1["paths"] and 0 < s1["rays_any"] <= s1["rays_closest"]
+    assert s1["rays_closest"] + s1["rays_any"] > 1_000_000_000  # the 1.2 G rays of the headline number
+    gpu.clear()
+    idx = np.arange(gpu.n_tiles)
+    gpu.render_device(p, tile_indices=idx[idx % 2 == 0])
+    gpu.render_device(p, tile_indices=idx[idx % 2 == 1])
+    assert np.array_equal(gpu.read_film(), f1)
+    crop = (504, 440, 520, 456)  # (x0, y0, x1, y1): on the displaced cube-sphere
+    tiles, n = scn.tiles_for(lib, crop)
+    orc = oracle_py.Oracle(sc.desc)
+    fo, so = orc.render(p, n_threads=os.cpu_count() or 1, tiles=tiles, n_tiles=n)
+    orc.close()
+    assert np.array_equal(f1[440:456, 504:520], fo[440:456, 504:520])
+    # the same tiles alone on the GPU: counters equal the oracle's
+    sel = np.array([i for i in range(gpu.n_tiles) if (lambda t: t.x0 >= 504 and t.x1 <= 520 and t.y0 >= 440 and t.y1 <= 456)(gpu.tiles[i])])
+    assert len(sel) == n == 4
+    gpu.clear()
+    sc_ = gpu.render_device(p, tile_indices=sel)
+    for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+        assert sc_[k] == so[k], k
+    gpu.close()
+
+
+def test_c4_frame_at_full_size(env):
+    """BASELINE.json configs[3] at its own size — the crown proxy (64 dispersive-glass + 16 rough-gold icospheres, 410 k triangles), 1000 x 1400,
+    256 spp, maxdepth 32 (358 M paths in one batch, 33 bounces through the staged vertex / per-class scatter kernels): run-to-run identity,
+    sample counts, and a 16 x 16 block through glass at all 256 samples against the oracle, film and counters bit for bit."""
+    lib, oracle_py, render, scenes = env
+    from shimmer_amd import scene as scn
+    sc = scenes.crown_proxy(lib, 1000, 1400)
+    p = render.make_params(seed=0, spp=256, max_depth=32)
+    gpu = render.Renderer(lib, sc.desc, 0)
+    gpu.clear()
+    s1 = gpu.render_device(p)
+    f1 = gpu.read_film()
+    gpu.clear()
+    s2 = gpu.render_device(p)
+    assert np.array_equal(gpu.read_film(), f1)
+    for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+        assert s1[k] == s2[k], k
+    assert (f1["weight_sum"] == 256.0).all() and np.isfinite(f1["rgb_sum"]).all() and s1["paths"] == 1000 * 1400 * 256
+    x0, y0 = 496, 696
+    tiles, n = scn.tiles_for(lib, (x0, y0, x0 + 16, y0 + 16))
+    orc = oracle_py.Oracle(sc.desc)
+    fo, so = orc.render(p, n_threads=os.cpu_count() or 1, tiles=tiles, n_tiles=n)
+    orc.close()
+    assert np.array_equal(f1[y0:y0 + 16, x0:x0 + 16], fo[y0:y0 + 16, x0:x0 + 16])
+    sel = np.array([i for i in range(gpu.n_tiles) if (lambda t: t.x0 >= x0 and t.x1 <= x0 + 16 and t.y0 >= y0 and t.y1 <= y0 + 16)(gpu.tiles[i])])
+    assert len(sel) == n == 4
+    gpu.clear()
+    sb = gpu.render_device(p, tile_indices=sel)
+    for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+        assert sb[k] == so[k], k
+    assert so["rays_closest"] / so["paths"] > 3.0  # the block is on the glass: long specular chains
+    gpu.close()
+
+
 def test_no_silent_fallback(env):
     """The product never routes through the oracle: libshimmer_hip.so exports no orc_* symbol, and a Renderer holds a
     device film pointer."""

@@ -15,6 +15,10 @@ CONFIGS = [
     ("S3c coated ganesha 1024x1024x64", lambda: scenes.ganesha_proxy(lib, 1024, 1024, coated=True), 64, 5),
     ("C2t cornell textured 512x512x64", lambda: scenes.cornell_box(lib, 512, 512, textured=True), 64, 6),
     ("C2u cornell textured, no coated 512x512x64", lambda: scenes.cornell_box(lib, 512, 512, textured=True, textured_coated_ceiling=False), 64, 6),
+    ("C2f-point cornell textured, every filter point", lambda: scenes.cornell_box(lib, 512, 512, textured=True, texture_filter="point"), 64, 6),
+    ("C2f-bilinear cornell textured, every filter bilinear", lambda: scenes.cornell_box(lib, 512, 512, textured=True, texture_filter="bilinear"), 64, 6),
+    ("C2f-trilinear cornell textured, every filter trilinear", lambda: scenes.cornell_box(lib, 512, 512, textured=True, texture_filter="trilinear"), 64, 6),
+    ("C2f-ewa cornell textured, every filter ewa", lambda: scenes.cornell_box(lib, 512, 512, textured=True, texture_filter="ewa"), 64, 6),
     ("E3 spheres + environment map 512x384x64", lambda: scenes.three_spheres(lib, 512, 384, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(64)), 64, 5),
 ]
 only = sys.argv[1:] 
