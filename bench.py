@@ -266,7 +266,7 @@ def main():
             "config": {"workload": f"{'S3c coated ' if args.coated else 'S3 '}ganesha-proxy ({sc.info['n_primitives']} prims, {sc.info['n_nodes']} BVH nodes), "
                                    f"{width}x{height}, {args.spp} spp, maxdepth {args.max_depth}, path integrator"
                                    + (" [BASELINE configs[4], the multi-GPU scaling frame]" if c5 else ""),
-                       "tiles": "8x8, sharded across ranks in interleaved blocks of tile rows (~8 blocks per rank) by shm_shard_tiles" if world > 1 else "8x8",
+                       "tiles": "8x8, sharded across ranks in interleaved blocks of tile rows (~16 blocks per rank) by shm_shard_tiles" if world > 1 else "8x8",
                        "rays_per_step": rays / args.steps, "paths_per_step": tot["paths"] / args.steps,
                        "film_gather": "RCCL ncclSend/ncclRecv of each rank's film rows into rank 0's device film, inside the library and inside the "
                                       "timed region" if use_dist else "none"},

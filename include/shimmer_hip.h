@@ -501,7 +501,7 @@ SHM_API int shm_trace_any_device(ShmScene* scene, const void* rays_dev, uint32_t
  * GPUs), straight from one device film into the other, and no sum is needed. */
 
 /* Static interleaved sharding of the row-major tile list Tile::tile emits: blocks of `rows_per_block` tile rows, block b belongs to
- * rank b % world. rows_per_block 0 = the default (about 8 blocks per rank: expensive image regions are spread over all ranks).
+ * rank b % world. rows_per_block 0 = the default (about 16 blocks per rank: expensive image regions are spread over all ranks).
  * idx_out (capacity n_tiles) receives this rank's tile indices in increasing order. */
 SHM_API int shm_shard_tiles(uint32_t n_tiles, uint32_t tiles_per_row, int32_t rank, int32_t world, int32_t rows_per_block,
                             uint32_t* idx_out, uint32_t* n_out);

@@ -38,7 +38,9 @@ namespace {
     } while (0)
 
 int default_rows_per_block(uint32_t tile_rows, int world) {
-    int blocks_per_rank = 8;
+    // 16 blocks per rank: measured on the C5 frame (3840x2160, S3) by rendering every rank's tile set on one GPU (tools/shard_balance.py,
+    // profiles/r02_shard_balance.txt): mean / max of the per-rank times is 0.93 with 8 blocks per rank, 0.99 with 16 and with 33
+    int blocks_per_rank = 16;
     if (const char* e = getenv("SHM_SHARD_BLOCKS")) { int v = atoi(e); if (v >= 1) blocks_per_rank = v; }
     return std::max(1, (int)tile_rows / (world * blocks_per_rank));
 }

@@ -54,7 +54,7 @@ def film_to_rgb(film):
 
 def shard_tiles(n_tiles, tiles_per_row, rank, world_size, rows_per_block=None, lib=None):
     """Static interleaved sharding through the C ABI (shm_shard_tiles): blocks of `rows_per_block` tile rows, block b ->
-    rank b % world. Default block height: about 8 blocks per rank, so that expensive image regions (the object) and cheap ones
+    rank b % world. Default block height: about 16 blocks per rank, so that expensive image regions (the object) and cheap ones
     (walls) are spread over all ranks."""
     lib = lib or abi.load_library()
     idx = (C.c_uint32 * max(1, n_tiles))()

@@ -62,5 +62,5 @@ def test_shard_tiles_partition():
     parts = [render.shard_tiles(n_tiles, per_row, r, 8) for r in range(8)]
     allidx = np.sort(np.concatenate(parts))
     assert np.array_equal(allidx, np.arange(n_tiles))  # disjoint and complete
-    assert max(len(p) for p in parts) == min(len(p) for p in parts)  # 128 tile rows in 2-row blocks, 8 blocks per rank
+    assert max(len(p) for p in parts) == min(len(p) for p in parts)  # 128 tile rows in 1-row blocks, 16 blocks per rank
     assert len(np.unique(np.diff(parts[0]) > 1)) == 2  # interleaved, not one contiguous band
