@@ -27,22 +27,32 @@ namespace {
 #endif
 enum : uint32_t { ST_IDLE = 0, ST_NODE = 1, ST_LEAF = 2, ST_DONE = 3 };
 
-template <bool ANY, bool TRI_ONLY>
-__global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
-                                                       uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
-                                                       ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
-                                                       float4* __restrict__ L, const float4* __restrict__ contrib,
-                                                       DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
-                                                       int refill_min, int leaf_min, int queue_parts) {
+// LDS_N = the stack levels held in LDS. Occupancy is what the kernel is most sensitive to after its instruction count (measured on the headline
+// frame: 5 / 6 / 7 waves per SIMD = 186 / 166 / 158 ms for the closest-hit launches, 6 / 8 = 95.5 / 87.0 ms for the any-hit ones), and a 256-thread
+// workgroup needs LDS_N KiB of the CU's 160: the four entry points below trade stack levels in LDS for resident waves as far as their registers
+// allow — closest-hit: 72 VGPRs = 7 waves, 22 levels; any-hit: 64 VGPRs = 8 waves, 19 levels; the instantiations with quadrics / patches /
+// instances need > 120 VGPRs (3-4 waves) and keep 26 levels. Deeper levels go to the HBM spill (a BVH of 4.3 M triangles is 32 deep).
+template <bool ANY, bool TRI_ONLY, int LDS_N>
+__device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
+                                            uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
+                                            ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
+                                            float4* __restrict__ L, const float4* __restrict__ contrib,
+                                            DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
+                                            int refill_min, int leaf_min, int queue_parts) {
+    constexpr int K3_LDS_N = LDS_N;
     __shared__ uint32_t lds_stack[(TRACE_BLOCK / WAVE) * K3_LDS_N * WAVE];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave_in_block = threadIdx.x / WAVE;
     uint32_t* const st_lds = lds_stack + wave_in_block * K3_LDS_N * WAVE + lane;
-    uint32_t* const st_spill = spill + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE + lane;
+    // (wave-uniform base; the lane offset is added where a spill level is touched — rare — instead of living in two VGPRs)
+    uint32_t* const st_spill_wave = spill + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE;
     const uint32_t n = n_ptr ? *n_ptr : n_direct;
     const char* __restrict__ node_base = reinterpret_cast<const char*>(sv.nodes);
     const char* __restrict__ prim_base = reinterpret_cast<const char*>(sv.prim_recs);
-    uint32_t c_nodes = 0, c_prims = 0, c_rays = 0;
+    // visit counters: rays and node visits are counted per wave in scalar registers (one popcount of the lanes that took the step), only the
+    // primitive count — a loop of per-lane length — stays per lane
+    uint32_t c_prims = 0;
+    unsigned long long w_nodes = 0, w_rays = 0;
 
     uint32_t state = ST_IDLE;
     bool exhausted = false;  // wave-uniform
@@ -62,7 +72,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
     rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
     Float t_max = 0.0f;
     int32_t hit_prim = -1;
-    Float hit_t = 0.0f, hit_b0 = 0.0f, hit_b1 = 0.0f, hit_b2 = 0.0f, hit_phi = 0.0f;
+    Float hit_b0 = 0.0f, hit_b1 = 0.0f, hit_b2 = 0.0f, hit_phi = 0.0f;  // (the hit's t is t_max itself: aggregate.rs:105-109 shrinks the ray to it)
     // TransformedPrimitive (TRI_ONLY = false only): the leaf slot of the instance being traversed (-1: the top-level tree), the
     // instance the current closest hit was found through, t_max as it was outside, and whether this visit found a hit
     int32_t inst_slot = -1, hit_inst = -1;
@@ -108,7 +118,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                 if (!exhausted) {
                     uint32_t take = min((uint32_t)n_idle, w_end - w_next);
                     if (state == ST_IDLE) {
-                        uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                        // idle lanes below this one (v_mbcnt: no 64-bit lane mask to keep in registers)
+                        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                         if (rank < take) {
                             uint32_t qi = w_next + rank;
                             path = queue ? queue[qi] : qi;
@@ -130,10 +141,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                             cur = 0;
                             want_pop = false;
                             state = ST_NODE;
-                            c_rays++;
                         }
                     }
                     w_next += take;
+                    w_rays += take;
                 }
             }
             if (__ballot(state != ST_IDLE) == 0ull) {
@@ -142,6 +153,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
             }
         }
         // ---- one uniform node step ----
+        bool visited = false;
         if (state == ST_NODE) {
             bool go = true;
             if (want_pop) {
@@ -152,7 +164,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                     // two different load flavours, so that the compiler cannot merge them into one flat_load of a selected
                     // pointer (which waits on both the LDS and the vector-memory counter)
                     if (sp < K3_LDS_N) cur = st_lds[sp * WAVE];
-                    else cur = __builtin_nontemporal_load(st_spill + (size_t)(sp - K3_LDS_N) * WAVE);
+                    else cur = __builtin_nontemporal_load(st_spill_wave + (size_t)(sp - K3_LDS_N) * WAVE + lane);
                     if (!TRI_ONLY && cur == INST_SENTINEL) {
                         // the instanced aggregate is exhausted: back to the ray of the enclosing tree (primitive.rs:158-171 returns);
                         // t_max is the hit found inside (in the instance's parameterisation, as the reference keeps it) or what it was
@@ -176,7 +188,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
             if (go) {
                 const float4* np = reinterpret_cast<const float4*>(node_base + ((size_t)cur << 5));
                 float4 na = np[0], nb = np[1];
-                c_nodes++;
+                visited = true;
                 // Bounds3f::intersect_p_cached (bounding_box.rs:520-563), signs held as lane masks
                 const Float g = 1.0f + 2.0f * gamma(3);
                 Float t0 = ((negx ? na.w : na.x) - ro.x) * inv_dir.x;
@@ -210,12 +222,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                     uint32_t far_child = neg ? cur + 1 : offset;   // aggregate.rs:119-127
                     uint32_t near_child = neg ? offset : cur + 1;
                     if (sp < K3_LDS_N) st_lds[sp * WAVE] = far_child;
-                    else st_spill[(size_t)(sp - K3_LDS_N) * WAVE] = far_child;
+                    else st_spill_wave[(size_t)(sp - K3_LDS_N) * WAVE + lane] = far_child;
                     sp++;
                     cur = near_child;
                 }
             }
         }
+        w_nodes += (unsigned long long)__popcll(__ballot(visited));
         // ---- postponed leaf phase ----
         unsigned long long leaf_mask = __ballot(state == ST_LEAF);
         if (leaf_mask != 0ull) {
@@ -236,7 +249,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                             // intersect_predicate, as the reference writes them — and go on in the instanced aggregate's tree.
                             const ShmInstance& in = sv.instances[__float_as_uint(q2.y) & PRIM_INDEX_MASK];
                             if (sp < K3_LDS_N) st_lds[sp * WAVE] = INST_SENTINEL;
-                            else st_spill[(size_t)(sp - K3_LDS_N) * WAVE] = INST_SENTINEL;
+                            else st_spill_wave[(size_t)(sp - K3_LDS_N) * WAVE + lane] = INST_SENTINEL;
                             sp++;
                             t_outer = t_max;
                             inst_slot = (int32_t)slot;
@@ -259,22 +272,21 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                             // Sphere::intersect (sphere.rs:95-196) through the same leaf phase; the hit record carries p_obj and phi
                             QuadricIntersection qi;
                             got = sphere_basic_intersect(sv.spheres[__float_as_uint(q2.y) & PRIM_INDEX_MASK], ro, rd_full, t_max, qi);
-                            if (got) { hit_prim = (int32_t)slot; hit_t = qi.t_hit; hit_b0 = qi.p_obj.x; hit_b1 = qi.p_obj.y; hit_b2 = qi.p_obj.z; hit_phi = qi.phi; }
+                            if (got) { hit_prim = (int32_t)slot; t_max = qi.t_hit; hit_b0 = qi.p_obj.x; hit_b1 = qi.p_obj.y; hit_b2 = qi.p_obj.z; hit_phi = qi.phi; }
                         } else if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_PATCH_BIT)) {
                             // BilinearPatch::intersect (bilinear_patch.rs:144-236): the record holds p00, p10, p01; (u, v) go in b0, b1
                             BilinearIntersection bi;
                             got = blp_intersect(ro, rd_full, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x),
                                                 ld3(sv.patches[__float_as_uint(q2.y) & PRIM_INDEX_MASK].p11), bi);
-                            if (got) { hit_prim = (int32_t)slot; hit_t = bi.t; hit_b0 = bi.u; hit_b1 = bi.v; hit_b2 = 0.0f; hit_phi = 0.0f; }
+                            if (got) { hit_prim = (int32_t)slot; t_max = bi.t; hit_b0 = bi.u; hit_b1 = bi.v; hit_b2 = 0.0f; hit_phi = 0.0f; }
                         } else {
                             TriangleIntersection ti;
                             got = !(__float_as_uint(q2.y) & PRIM_DEGENERATE_BIT) &&
                                   intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
-                            if (got) { hit_prim = (int32_t)slot; hit_t = ti.t; hit_b0 = ti.b0; hit_b1 = ti.b1; hit_b2 = ti.b2; hit_phi = 0.0f; }
+                            if (got) { hit_prim = (int32_t)slot; t_max = ti.t; hit_b0 = ti.b0; hit_b1 = ti.b1; hit_b2 = ti.b2; hit_phi = 0.0f; }
                         }
                         if (got) {
                             if (ANY) { found_any = true; break; }
-                            t_max = hit_t;  // aggregate.rs:105-109
                             if (!TRI_ONLY) { hit_inst = inst_slot; inst_hit = true; }
                         }
                     }
@@ -302,18 +314,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
                 }
             } else {
                 float4* hp = reinterpret_cast<float4*>(hits + path);
-                hp[0] = make_float4(__int_as_float(hit_prim), hit_t, hit_b0, hit_b1);
+                hp[0] = make_float4(__int_as_float(hit_prim), hit_prim >= 0 ? t_max : 0.0f, hit_b0, hit_b1);
                 hp[1] = make_float4(hit_b2, TRI_ONLY ? 0.0f : hit_phi, TRI_ONLY ? 0.0f : __int_as_float(hit_inst + 1), 0.0f);
             }
             state = ST_IDLE;
         }
     }
-    unsigned long long w_nodes = c_nodes, w_prims = c_prims, w_rays = c_rays;
-    for (int off = 32; off > 0; off >>= 1) {
-        w_nodes += __shfl_down(w_nodes, off);
-        w_prims += __shfl_down(w_prims, off);
-        w_rays += __shfl_down(w_rays, off);
-    }
+    unsigned long long w_prims = c_prims;
+    for (int off = 32; off > 0; off >>= 1) w_prims += __shfl_down(w_prims, off);
     if (lane == 0 && w_rays) {
         if (ANY) {
             atomicAdd(&counters->rays_any, w_rays);
@@ -327,8 +335,50 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(SceneView sv, const uint
     }
 }
 
+#define K3_PARAMS SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_direct, uint32_t* head,                    \
+                  const ShmRay* __restrict__ rays, ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out, float4* __restrict__ L,                 \
+                  const float4* __restrict__ contrib, DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels, int refill_min, int leaf_min, \
+                  int queue_parts
+#define K3_ARGS sv, queue, n_ptr, n_direct, head, rays, hits, occluded_out, L, contrib, counters, spill, spill_levels, refill_min, leaf_min, queue_parts
+template <bool ANY, bool TRI_ONLY> struct K3Shape;  // {LDS levels, workgroups per CU} of each entry point
+template <> struct K3Shape<false, true> { static constexpr int LDS = 22, PER_CU = 7; };
+template <> struct K3Shape<true, true> { static constexpr int LDS = 19, PER_CU = 8; };
+template <> struct K3Shape<false, false> { static constexpr int LDS = 26, PER_CU = 4; };
+template <> struct K3Shape<true, false> { static constexpr int LDS = 26, PER_CU = 4; };
+template <bool ANY, bool TRI_ONLY>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(K3_PARAMS);
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7))) k_trace3<false, true>(K3_PARAMS) {
+    trace3_body<false, true, K3Shape<false, true>::LDS>(K3_ARGS);
+}
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_trace3<true, true>(K3_PARAMS) {
+    trace3_body<true, true, K3Shape<true, true>::LDS>(K3_ARGS);
+}
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace3<false, false>(K3_PARAMS) { trace3_body<false, false, K3Shape<false, false>::LDS>(K3_ARGS); }
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace3<true, false>(K3_PARAMS) { trace3_body<true, false, K3Shape<true, false>::LDS>(K3_ARGS); }
+
 __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x; i < 8 * 32; i += blockDim.x) heads[i] = 0; }
 }  // namespace
+
+int wf_trace_prepare(ShmScene* s) {
+    const bool tri_only = !s->flat.has_spheres;
+    for (int any = 0; any < 2; ++any) {
+        const int lds = tri_only ? (any ? K3Shape<true, true>::LDS : K3Shape<false, true>::LDS) : K3Shape<false, false>::LDS;
+        int per_cu = tri_only ? (any ? K3Shape<true, true>::PER_CU : K3Shape<false, true>::PER_CU) : K3Shape<false, false>::PER_CU;
+        if (s->trace3_per_cu_override > 0) per_cu = std::min(per_cu, s->trace3_per_cu_override);
+        s->trace3_blocks[any] = s->n_cu * per_cu;
+        s->spill3_levels[any] = std::max(0, (int)s->flat.max_leaf_depth + 1 - lds) + 1;
+        const size_t words = (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[any] * WAVE;
+        void* d = nullptr;
+        if (hipMalloc(&d, words * sizeof(uint32_t)) != hipSuccess) { shm_err() = "hipMalloc of the traversal stack spill failed"; return SHM_ERR_OUT_OF_MEMORY; }
+        s->allocs.push_back(d);
+        (any ? s->d_spill3_any : s->d_spill3) = static_cast<uint32_t*>(d);
+    }
+    return SHM_OK;
+}
 
 int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, const ShmRay* rays,
                     ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib) {
@@ -338,8 +388,8 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
     const int leaf_min = any ? s->leaf_min_any : s->leaf_min;
     const bool tri_only = !s->flat.has_spheres;
 #define TRACE_LAUNCH(ANY, TRI)                                                                                                                   \
-    hipLaunchKernelGGL((k_trace3<ANY, TRI>), dim3(s->trace3_blocks), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
-                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels, s->refill_min, leaf_min, s->queue_parts)
+    hipLaunchKernelGGL((k_trace3<ANY, TRI>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
+                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], s->refill_min, leaf_min, s->queue_parts)
     if (any) { if (tri_only) TRACE_LAUNCH(true, true); else TRACE_LAUNCH(true, false); }
     else { if (tri_only) TRACE_LAUNCH(false, true); else TRACE_LAUNCH(false, false); }
 #undef TRACE_LAUNCH

@@ -364,17 +364,12 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_PIX_GROUP")) { long long v2 = atoll(e); if (v2 >= 1) s->pix_group = (uint32_t)std::min<long long>(v2, 0x7fffffffll); }
     if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = v2; }
-    {
-        int per_cu3 = 6;  // persistent grid: 26 KiB of LDS per 256-thread workgroup -> 6 workgroups (24 waves) per CU
-        if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 6) per_cu3 = v2; }
-        if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
-        if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
-        s->trace3_blocks = s->n_cu * per_cu3;
-        s->spill3_levels = std::max(0, (int)f.max_leaf_depth + 1 - K3_LDS_N) + 1;
-        if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3)) != SHM_OK) return fail(rc);
-        if ((rc = dev_alloc<uint32_t>(s, (size_t)s->trace3_blocks * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels * WAVE, &s->d_spill3_any)) != SHM_OK) return fail(rc);
-    }
-    DBG("scene: %u nodes, depth %u, trace blocks %d, spill levels %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->trace3_blocks, s->spill3_levels);
+    if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) s->trace3_per_cu_override = v2; }
+    if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
+    if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
+    if ((rc = wf_trace_prepare(s)) != SHM_OK) return fail(rc);
+    DBG("scene: %u nodes, depth %u, trace blocks %d / %d, spill levels %d / %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->trace3_blocks[0], s->trace3_blocks[1],
+        s->spill3_levels[0], s->spill3_levels[1]);
     *out = s;
     return SHM_OK;
 }

@@ -141,7 +141,6 @@ constexpr int SHADE_CHUNK = 2048;  // queue entries per workgroup chunk: ONE glo
 #define K_SHADE_WAVES 2
 #endif
 #define K_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(K_SHADE_WAVES, K_SHADE_WAVES)))
-constexpr int K3_LDS_N = 26;   // k_trace3: stack levels [0, K3_LDS_N) -> LDS (6.5 KiB per wave), deeper levels -> HBM spill
 }  // namespace wf
 using namespace wf;
 
@@ -175,8 +174,9 @@ struct ShmScene {
     std::vector<uint64_t> tile_bitmap;  // host scratch of the disjointness check in shm_render_wave
     int n_cu = 256;
     // tuned traversal (k_trace3)
-    int trace3_blocks = 0;
-    int spill3_levels = 1;
+    int trace3_blocks[2] = {0, 0};   // persistent grid of the closest-hit [0] / any-hit [1] entry point this scene uses (k_trace.hip: K3Shape)
+    int spill3_levels[2] = {1, 1};   // stack levels beyond the entry point's LDS levels (HBM spill)
+    int trace3_per_cu_override = 0;  // SHM_TRACE3_BLOCKS_PER_CU (development)
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
     int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
     uint32_t* d_spill3 = nullptr;
@@ -212,6 +212,7 @@ struct EventPool {
 // ---- launchers exported by the kernel translation units (hidden visibility: library-internal) ----
 #define WF_INTERNAL __attribute__((visibility("hidden")))
 // k_trace.hip: BvhAggregate::intersect (any = false) / intersect_predicate (any = true) over a queue of path slots
+WF_INTERNAL int wf_trace_prepare(ShmScene* s);  // grid sizes + stack spill buffers of the two traversal kernels (at scene creation)
 WF_INTERNAL int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct,
                                 const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib);
 // shading of one path vertex of PathIntegrator::li for every entry of q_active[cur]
