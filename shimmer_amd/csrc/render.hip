@@ -51,6 +51,9 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t p_local, uint32_t s_local, 
     return g0 * n_samples + s_local * pg + (p_local - g0);
 }
 
+// HAS_TEX: scenes that bind image textures carry the camera ray's auxiliary rays (a compile-time switch: with a run-time pointer the
+// auxiliary-ray record lived in scratch memory, 52 B of stores per path, in every scene)
+template <bool HAS_TEX>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArrays pa, const uint32_t* pixels, uint32_t n_pix,
                                                         int sample_begin, int n_samples, ShmRenderParams params,
                                                         uint32_t* q_active, QueueState* qs, uint32_t pix_group) {
@@ -68,11 +71,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
     Rng rng = sampler_start_pixel_sample(px, py, sample_begin + (int)s_local, params.seed);
     Wavelengths lambda;
     Float weight;
-    const bool has_tex = pa.aux0 != nullptr;
+    constexpr bool has_tex = HAS_TEX;
     AuxRays aux = aux_none();
     Ray r = generate_camera_ray(sv, px, py, rng, params.disable_wavelength_jitter != 0, params.disable_pixel_jitter != 0,
-                                lambda, weight, has_tex ? &aux : nullptr, params.samples_per_pixel);
-    if (has_tex) st_aux(pa, slot, aux);
+                                lambda, weight, HAS_TEX ? &aux : nullptr, params.samples_per_pixel);
+    if (HAS_TEX) st_aux(pa, slot, aux);
     ShmRay ray;
     ray.o[0] = r.o.x; ray.o[1] = r.o.y; ray.o[2] = r.o.z;
     ray.d[0] = r.d.x; ray.d[1] = r.d.y; ray.d[2] = r.d.z;
@@ -495,8 +498,12 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         uint32_t n_pix = (uint32_t)std::min<uint64_t>(pix_per_batch, n_pixels - p0);
         uint32_t total = n_pix * (uint32_t)n_samples;
         const uint32_t* pixels = s->d_pixels + p0;
-        hipLaunchKernelGGL(k_generate, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
-                           sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs, s->pix_group);
+        if (s->pa.aux0)
+            hipLaunchKernelGGL(k_generate<true>, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
+                               sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs, s->pix_group);
+        else
+            hipLaunchKernelGGL(k_generate<false>, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
+                               sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs, s->pix_group);
         LAUNCH_TRY("k_generate");
         int cur = 0;
         // Small batches are tail-dominated (the last rays of a persistent traversal launch take ~0.5 ms whatever its size): there
