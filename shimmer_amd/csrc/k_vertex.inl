@@ -10,22 +10,54 @@
 
 namespace {
 
-template <bool TRI_ONLY, bool HAS_TEX>
+// The queue K2 leaves is in image order: neighbouring lanes hit different materials, and this half of the vertex is where materials differ most
+// (which textures are filtered and how, which spectra are looked up). SORT: the workgroup first counting-sorts its 2048-entry chunk by the
+// material of the primitive each path hit (64 bins + one for escaped rays; two passes over hit.prim -> primitive.material, LDS atomics), then
+// works through the chunk in that order, so that the 64 lanes of a wave mostly evaluate ONE material. Paths are independent and every later
+// queue is order-agnostic: films and counters do not change.
+constexpr int VERTEX_SORT_BINS = 64;
+template <bool TRI_ONLY, bool HAS_TEX, bool SORT>
 __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArrays& pa, const uint32_t* __restrict__ q_cur, uint32_t* q_s0, uint32_t* q_s1,
                                             uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, const ShmRenderParams& params) {
     const uint32_t n = qs->n_active[cur];
     __shared__ uint32_t s_q[N_BXDF_CLASSES][SHADE_CHUNK];
     __shared__ uint32_t s_cnt[N_BXDF_CLASSES], s_base[N_BXDF_CLASSES];
+    __shared__ uint32_t s_sorted[SORT ? SHADE_CHUNK : 1];
+    __shared__ uint32_t s_bin[SORT ? VERTEX_SORT_BINS + 1 : 1];
     uint32_t* const q_out[N_BXDF_CLASSES] = {q_s0, q_s1, q_s2, q_s3};
     for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
       if (threadIdx.x < N_BXDF_CLASSES) s_cnt[threadIdx.x] = 0;
+      if (SORT) {
+          auto key_of = [&](uint32_t path) -> uint32_t {
+              const int prim = __float_as_int(reinterpret_cast<const float*>(pa.hit + path)[0]);
+              if (prim < 0) return (uint32_t)VERTEX_SORT_BINS;
+              const uint32_t m = sv.primitives[prim].material;
+              return m < (uint32_t)VERTEX_SORT_BINS ? m : (uint32_t)VERTEX_SORT_BINS - 1u;
+          };
+          if (threadIdx.x <= VERTEX_SORT_BINS) s_bin[threadIdx.x] = 0;
+          __syncthreads();
+          for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+              const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
+              if (i < n) atomicAdd(&s_bin[key_of(q_cur[i])], 1u);
+          }
+          __syncthreads();
+          if (threadIdx.x == 0) {  // exclusive prefix over 65 bins: the bins become cursors
+              uint32_t acc = 0;
+              for (int b = 0; b <= VERTEX_SORT_BINS; ++b) { const uint32_t c = s_bin[b]; s_bin[b] = acc; acc += c; }
+          }
+          __syncthreads();
+          for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+              const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
+              if (i < n) { const uint32_t path = q_cur[i]; s_sorted[atomicAdd(&s_bin[key_of(path)], 1u)] = path; }
+          }
+      }
       __syncthreads();
       for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
         const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
         int push_class = -1;
         uint32_t path = 0;
         if (i < n) {
-            path = q_cur[i];
+            path = SORT ? s_sorted[k * SHADE2_BLOCK + threadIdx.x] : q_cur[i];
             const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
             float4 h0 = hp[0], h1 = hp[1];
             Hit hit;
@@ -139,30 +171,37 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
     }
 }
 
-template <bool TRI_ONLY, bool HAS_TEX>
+template <bool TRI_ONLY, bool HAS_TEX, bool SORT = false>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_vertex(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* q_s0, uint32_t* q_s1,
                                                                      uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, ShmRenderParams params) {
-    vertex_body<TRI_ONLY, HAS_TEX>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params);
+    vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params);
 }
 // three waves per SIMD (<= 168 VGPRs): the triangle-only instantiation needs 159 and is bound by the latency of its gathers
-template <bool TRI_ONLY, bool HAS_TEX>
+template <bool TRI_ONLY, bool HAS_TEX, bool SORT = false>
 __global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_vertex_w3(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur,
                                                                                                         uint32_t* q_s0, uint32_t* q_s1, uint32_t* q_s2, uint32_t* q_s3,
                                                                                                         QueueState* qs, int cur, ShmRenderParams params) {
-    vertex_body<TRI_ONLY, HAS_TEX>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params);
+    vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params);
 }
 
 }  // namespace
 
-#define WF_VERTEX_LAUNCH_W3(TRI, TEX)                                                                                                          \
+// material-sorted chunks: on when the scene holds more than one material (SHM_VERTEX_SORT=0 / 1 overrides, for A/B runs)
+static inline bool wf_vertex_sort(const ShmScene* s) {
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("SHM_VERTEX_SORT"); forced = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
+    if (forced >= 0) return forced == 1;
+    return s->flat.materials.size() > 1;
+}
+#define WF_VERTEX_LAUNCH_W3(TRI, TEX, SORT)                                                                                                    \
     do {                                                                                                                                       \
-        hipLaunchKernelGGL((k_vertex_w3<TRI, TEX>), dim3(a.blocks * 3 / 2), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], \
+        hipLaunchKernelGGL((k_vertex_w3<TRI, TEX, SORT>), dim3(a.blocks * 3 / 2), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], \
                            s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params);              \
         LAUNCH_TRY("k_vertex_w3");                                                                                                             \
     } while (0)
-#define WF_VERTEX_LAUNCH(TRI, TEX)                                                                                                             \
+#define WF_VERTEX_LAUNCH(TRI, TEX, SORT)                                                                                                       \
     do {                                                                                                                                       \
-        hipLaunchKernelGGL((k_vertex<TRI, TEX>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur],          \
+        hipLaunchKernelGGL((k_vertex<TRI, TEX, SORT>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur],          \
                            s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params);              \
         LAUNCH_TRY("k_vertex");                                                                                                                \
     } while (0)

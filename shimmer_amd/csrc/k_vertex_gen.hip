@@ -2,6 +2,7 @@
 #include "k_vertex.inl"
 
 int wf_launch_vertex_gen(ShmScene* s, const ShadeArgs& a) {
-    WF_VERTEX_LAUNCH(false, false);
+    if (wf_vertex_sort(s)) WF_VERTEX_LAUNCH(false, false, true);
+    else WF_VERTEX_LAUNCH(false, false, false);
     return SHM_OK;
 }

@@ -2,6 +2,7 @@
 #include "k_vertex.inl"
 
 int wf_launch_vertex_tex(ShmScene* s, const ShadeArgs& a) {
-    WF_VERTEX_LAUNCH(false, true);
+    if (wf_vertex_sort(s)) WF_VERTEX_LAUNCH(false, true, true);
+    else WF_VERTEX_LAUNCH(false, true, false);
     return SHM_OK;
 }
