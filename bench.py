@@ -298,15 +298,23 @@ def main():
     if use_dist and rank == 0:
         # the gathered film: every pixel of the frame received all its samples, from some rank
         host = r.read_film()
-        if not (host["weight_sum"] == float(args.spp)).all() or not np.isfinite(host["rgb_sum"]).all():
-            raise SystemExit("gathered film is incomplete or not finite")
+        if not (host["weight_sum"] == float(args.spp)).all():
+            raise SystemExit("gathered film is incomplete")
+        out["nonfinite_pixels"] = int((~np.isfinite(host["rgb_sum"]).all(axis=-1)).sum())  # (reference behaviour in coated scenes: DESIGN.md §2)
+        if out["nonfinite_pixels"] and not args.coated:
+            raise SystemExit("gathered film is not finite")
         if world == 1:
             r.dist_selftest()  # film rows through the RCCL send / recv group, looped back to this rank
     if rank == 0 and world == 1 and not use_dist and not args.shard_of:
         # self-check outside the timed region: every pixel received all its samples, all sums finite
         host = r.read_film()
-        if not (host["weight_sum"] == float(args.spp)).all() or not np.isfinite(host["rgb_sum"]).all():
-            raise SystemExit("film is incomplete or not finite")
+        if not (host["weight_sum"] == float(args.spp)).all():
+            raise SystemExit("film is incomplete")
+        # LayeredBxDF::pdf of the reference can return 0 / 0 ("Reference quirks preserved"): counted, and fatal only where no
+        # coated material exists
+        out["nonfinite_pixels"] = int((~np.isfinite(host["rgb_sum"]).all(axis=-1)).sum())
+        if out["nonfinite_pixels"] and not args.coated:
+            raise SystemExit("film is not finite")
     r.close()
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:

@@ -206,6 +206,11 @@ Spec sample_ld(const SceneView& sv, const SurfaceInteraction& intr, const BSDF& 
     if (light_is_delta(light)) return ls.l * f / p_l;
     Float p_b = bsdf_pdf(bsdf, wo, wi, REFLTRANS_ALL);
     Float w_l = power_heuristic(1, p_l, 1, p_b);
+#ifdef ORC_TRACE
+    if (!(f.v[0] == f.v[0]) || !(p_b == p_b) || !(w_l == w_l) || !(p_l == p_l))
+        fprintf(stderr, "[trace] sample_ld: f %g %g %g %g  p_b %g  p_l %g  w_l %g  ls.l %g  ls.pdf %g  wo.ns %g wi.ns %g\n", f.v[0], f.v[1], f.v[2], f.v[3], p_b, p_l, w_l, ls.l.v[0],
+                ls.pdf, dot(wo, intr.shading.n), dot(wi, intr.shading.n));
+#endif
     return w_l * ls.l * f / p_l;
 }
 
@@ -289,12 +294,20 @@ Spec li(const SceneView& sv, Ray ray, AuxRays aux, const TexParams& tp, Waveleng
         if (flags_is_non_specular(bsdf_flags(bsdf))) {
             Spec ld = sample_ld(sv, si, bsdf, lambda, rng, c);
             l = l + beta * ld;
+#ifdef ORC_TRACE
+            if (!(ld.v[0] == ld.v[0]) || !(beta.v[0] == beta.v[0])) fprintf(stderr, "[trace] depth %d: ld %g %g %g %g beta %g kind %d\n", depth, ld.v[0], ld.v[1], ld.v[2], ld.v[3], beta.v[0], bsdf.bxdf.kind);
+#endif
         }
         V3 wo = -ray.d;
         Float u = sampler_get_1d(rng);
         V2 u2 = sampler_get_2d(rng);
         BSDFSample bs;
         if (!bsdf_sample_f(bsdf, wo, u, u2, REFLTRANS_ALL, bs)) break;
+#ifdef ORC_TRACE
+        if (!(bs.f.v[0] == bs.f.v[0]) || !(bs.pdf == bs.pdf) || bs.pdf == 0.0f || !(bs.wi.x == bs.wi.x))
+            fprintf(stderr, "[trace] depth %d: sample_f f %g %g %g %g pdf %g wi %g %g %g flags %u kind %d wo.n %g\n", depth, bs.f.v[0], bs.f.v[1], bs.f.v[2], bs.f.v[3], bs.pdf,
+                    bs.wi.x, bs.wi.y, bs.wi.z, bs.flags, bsdf.bxdf.kind, dot(wo, si.shading.n));
+#endif
         beta = beta * (bs.f * abs_dot(bs.wi, si.shading.n) / bs.pdf);
         p_b = bs.pdf_is_proportional ? bsdf_pdf(bsdf, wo, bs.wi, REFLTRANS_ALL) : bs.pdf;
         specular_bounce = flags_is_specular(bs.flags);
