@@ -308,6 +308,31 @@ def test_c4_frame_at_full_size(env):
     gpu.close()
 
 
+def test_layered_pdf_zero_over_zero_is_the_references(env):
+    """LayeredBxDF::pdf (bxdf.rs:1491-1506) takes the reflecting interface's sample without testing its pdf: a cosine-hemisphere sample on the
+    horizon gives power_heuristic(1, 0, 1, 0) = 0 / 0 and the NaN reaches the film (evaluate_pixel_sample leaves it, integrator.rs:377-382).
+    Found on the coated S3 frame at pixel (714, 268), sample 83: the HIP path must poison the same pixel and match every other one, bit
+    for bit."""
+    lib, oracle_py, render, scenes = env
+    from shimmer_amd import scene as scn
+    sc = scenes.ganesha_proxy(lib, 1024, 1024, coated=True)
+    p = render.make_params(seed=0, spp=128, max_depth=5)
+    x, y, sample = 714, 268, 83
+    x0, y0 = x & ~7, y & ~7
+    tiles, n = scn.tiles_for(lib, (x0, y0, x0 + 8, y0 + 8))
+    orc = oracle_py.Oracle(sc.desc)
+    fo, _ = orc.render(p, n_threads=1, tiles=tiles, n_tiles=n, waves=[(sample, sample + 1)])
+    orc.close()
+    assert np.isnan(fo["rgb_sum"][y, x]).all() and np.isfinite(fo["rgb_sum"][y0:y0 + 8, x0:x0 + 8]).sum() == 3 * 63
+    gpu = render.Renderer(lib, sc.desc, 0)
+    sel = np.array([i for i in range(gpu.n_tiles) if (gpu.tiles[i].x0, gpu.tiles[i].y0) == (x0, y0)])
+    gpu.clear()
+    gpu.render_waves(p, tile_indices=sel, waves=[(sample, sample + 1)])
+    fg = gpu.read_film()
+    gpu.close()
+    assert np.array_equal(fg[y0:y0 + 8, x0:x0 + 8].view(np.uint64), fo[y0:y0 + 8, x0:x0 + 8].view(np.uint64))  # NaN bits included
+
+
 def test_no_silent_fallback(env):
     """The product never routes through the oracle: libshimmer_hip.so exports no orc_* symbol, and a Renderer holds a
     device film pointer."""
