@@ -9,7 +9,7 @@
 //   camera.rs:676-705, 850-890, film.rs:225-330, 482-495, 767-800, sampler.rs:95-99, integrator.rs:16-75
 // Scope: the directives the repository's scenes need — LookAt Translate Scale Rotate Identity Transform ConcatTransform CoordinateSystem
 // CoordSysTransform ReverseOrientation Camera (perspective / orthographic) Film (rgb) Sampler PixelFilter (box) Integrator Option
-// WorldBegin AttributeBegin/End Attribute Material MakeNamedMaterial NamedMaterial Texture (float / spectrum: constant scale mix
+// WorldBegin AttributeBegin/End Attribute (per-target default parameters) Material MakeNamedMaterial NamedMaterial Texture (float / spectrum: constant scale mix
 // directionmix imagemap) AreaLightSource (diffuse) LightSource (point, infinite: uniform or an environment image) Shape (trianglemesh
 // bilinearmesh sphere plymesh) ObjectBegin/End ObjectInstance Include; spectra as "spectrum" samples / named tables / files, "blackbody",
 // and "rgb" through the sRGB rgb2spec table (the `.spec` file the reference loads); PNG images (the only format the reference reads,
@@ -158,7 +158,16 @@ struct GraphicsState {
     bool reverse_orientation = false;
     int material = 0;            // index into Assembly::materials
     Assembly::Emission area_light;
+    Params shape_attributes, light_attributes, material_attributes, texture_attributes;  // Attribute "target" ... (scene.rs:1714-1730)
 };
+// ParameterDictionary::new_with_unowned (paramdict.rs:440-455): the directive's own parameters, last one first, then the target's attributes,
+// last one first — a lookup takes the first match, so the directive overrides the attribute and a repeated name resolves to its last value
+static Params with_attributes(const Params& own, const Params& attributes) {
+    Params out;
+    out.v.assign(own.v.rbegin(), own.v.rend());
+    out.v.insert(out.v.end(), attributes.v.rbegin(), attributes.v.rend());
+    return out;
+}
 
 class Loader {
 public:
@@ -958,12 +967,20 @@ private:
             if (stack_.empty()) fail(tk.where(t.line) + ": Unmatched attribute_end statement.");
             gs_ = stack_.back();
             stack_.pop_back();
-        } else if (d == "Attribute") { read_string(tk, t); parse_params(tk); }  // per-target default parameters: accepted, not applied
-        else if (d == "Material") { need_world(t, tk, true); const std::string ty = read_string(tk, t); const Params ps = parse_params(tk); gs_.material = make_material(ty, ps, &tk); }
+        } else if (d == "Attribute") {  // scene.rs:1714-1730: default parameters for what follows of that kind, within the attribute scope
+            const std::string target = read_string(tk, t);
+            const Params ps = parse_params(tk);
+            Params* dst = target == "shape" ? &gs_.shape_attributes : target == "light" ? &gs_.light_attributes : target == "material" ? &gs_.material_attributes
+                          : target == "texture" ? &gs_.texture_attributes : nullptr;
+            if (target == "medium") fail(tk.where(t.line) + ": participating media are todo!() in the reference and not supported", SHM_ERR_UNSUPPORTED);
+            if (!dst) fail(tk.where(t.line) + ": Unknown attribute target " + target);
+            dst->v.insert(dst->v.end(), ps.v.begin(), ps.v.end());
+        }
+        else if (d == "Material") { need_world(t, tk, true); const std::string ty = read_string(tk, t); const Params ps = with_attributes(parse_params(tk), gs_.material_attributes); gs_.material = make_material(ty, ps, &tk); }
         else if (d == "MakeNamedMaterial") {
             need_world(t, tk, true);
             const std::string name = read_string(tk, t);
-            const Params ps = parse_params(tk);
+            const Params ps = with_attributes(parse_params(tk), gs_.material_attributes);
             if (named_materials_.count(name)) fail(tk.where(t.line) + ": named material \"" + name + "\" redefined");
             const std::string ty = ps.one_string("type", "");
             if (ty.empty()) fail(tk.where(t.line) + ": MakeNamedMaterial \"" + name + "\" has no \"string type\"");
@@ -977,11 +994,11 @@ private:
         } else if (d == "Texture") {
             need_world(t, tk, true);
             const std::string name = read_string(tk, t), ty = read_string(tk, t), cls = read_string(tk, t);
-            texture(name, ty, cls, parse_params(tk), tk, t.line);
+            texture(name, ty, cls, with_attributes(parse_params(tk), gs_.texture_attributes), tk, t.line);
         } else if (d == "AreaLightSource") {
             need_world(t, tk, true);
             const std::string ty = read_string(tk, t);
-            const Params ps = parse_params(tk);
+            const Params ps = with_attributes(parse_params(tk), gs_.light_attributes);
             if (ty != "diffuse") fail(tk.where(t.line) + ": area light \"" + ty + "\" unknown (diffuse)");
             if (!ps.one_string("filename", "").empty()) fail(tk.where(t.line) + ": image area lights are todo!() in the reference", SHM_ERR_UNSUPPORTED);
             Assembly::Emission em;
@@ -993,8 +1010,8 @@ private:
             em.power = ps.one_float("power", -1.0f);
             em.two_sided = ps.one_bool("twosided", false);
             gs_.area_light = em;
-        } else if (d == "LightSource") { need_world(t, tk, true); const std::string ty = read_string(tk, t); light_source(ty, parse_params(tk), tk, t.line); }
-        else if (d == "Shape") { need_world(t, tk, true); const std::string ty = read_string(tk, t); shape(ty, parse_params(tk), tk, t.line); }
+        } else if (d == "LightSource") { need_world(t, tk, true); const std::string ty = read_string(tk, t); light_source(ty, with_attributes(parse_params(tk), gs_.light_attributes), tk, t.line); }
+        else if (d == "Shape") { need_world(t, tk, true); const std::string ty = read_string(tk, t); shape(ty, with_attributes(parse_params(tk), gs_.shape_attributes), tk, t.line); }
         else if (d == "ObjectBegin") {  // scene.rs:1904-1982
             need_world(t, tk, true);
             const std::string name = read_string(tk, t);

@@ -435,3 +435,37 @@ def test_rgb_spectra_png_textures_normal_map_and_environment_light(lib, tmp_path
         assert np.isfinite(film["rgb_sum"]).all() and film["rgb_sum"].sum() > 0
     finally:
         lib.shm_pbrt_free(got)
+
+
+def test_attribute_directive_sets_defaults_in_scope(lib):
+    """Attribute "target" params (scene.rs:1714-1730 + ParameterDictionary::new_with_unowned, paramdict.rs:440-455): defaults for the shapes /
+    lights / materials / textures that follow inside the attribute scope; a directive's own parameter wins; a repeated name resolves to its last
+    value."""
+    text = """
+    Camera "perspective"
+    WorldBegin
+    AttributeBegin
+      Attribute "material" "float reflectance" 0.25
+      Attribute "shape" "float radius" 2
+      Attribute "light" "float scale" 3
+      Material "diffuse"
+      Shape "sphere"
+      Material "diffuse" "float reflectance" 0.75 "float reflectance" 0.5
+      Shape "sphere" "float radius" 0.5
+      LightSource "point" "float scale" 1
+      LightSource "point"
+    AttributeEnd
+    Material "diffuse"
+    Shape "sphere"
+    """
+    got = load(lib, text)
+    try:
+        d = got.contents.desc
+        assert [d.materials[i].a.c for i in range(d.n_materials)] == [0.5, 0.25, 0.5, 0.5]  # default slot, attribute, last repeated value, out of scope
+        assert sorted(d.spheres[i].radius for i in range(d.n_spheres)) == [0.5, 1.0, 2.0]
+        assert d.lights[1].scale == pytest.approx(3.0 * d.lights[0].scale, rel=1e-6)
+    finally:
+        lib.shm_pbrt_free(got)
+    out = C.POINTER(abi.ShmPbrtScene)()
+    assert lib.shm_scene_parse_pbrt(b'WorldBegin\nAttribute "camera" "float fov" 3\nShape "sphere"', None, C.byref(out)) == -1
+    assert "Unknown attribute target camera" in lib.shm_last_error().decode()
