@@ -121,6 +121,8 @@ def side_results(lib, args, render, scenes, headline_scene, log):
         C.memmove(C.byref(headline_scene.desc.materials[0]), C.byref(tmp.materials[0]), C.sizeof(saved))
         try:
             timed("coated_S3_1024x1024_spp64", headline_scene.desc, 64, args.max_depth, headline_scene.info["n_primitives"])
+            # ... and at the headline's own sample count: the headline frame with the real scene's material
+            timed("coated_S3_1024x1024_spp256", headline_scene.desc, 256, args.max_depth, headline_scene.info["n_primitives"])
         finally:
             C.memmove(C.byref(headline_scene.desc.materials[0]), C.byref(saved), C.sizeof(saved))
         sc = scenes.crown_proxy(lib, 1000, 1400)
