@@ -52,9 +52,9 @@ int main(int argc, char** argv) {
         rays += stats[i].rays_closest + stats[i].rays_any;
         if (stats[i].ms_total > ms) ms = stats[i].ms_total;
     }
-    /* RgbFilm::get_image with the film's XYZ sensor -> linear sRGB (IEC 61966-2-1), then Image::write_pfm */
-    const float srgb_from_xyz[9] = {3.2404542f, -1.5371385f, -0.4985314f, -0.9692660f, 1.8760108f, 0.0415560f, 0.0556434f, -0.2040259f, 1.0572252f};
-    if (shm_film_get_image(film, (uint64_t)w * (uint64_t)h, srgb_from_xyz, 0, rgb) != SHM_OK) return die("shm_film_get_image");
+    /* RgbFilm::get_image with the film's output matrix (XYZ sensor -> linear sRGB, times the white balance if the Film asked for one), then
+     * Image::write_pfm */
+    if (shm_film_get_image(film, (uint64_t)w * (uint64_t)h, s->output_rgb_from_sensor_rgb, 0, rgb) != SHM_OK) return die("shm_film_get_image");
     if (shm_write_pfm(out_path, rgb, w, h) != SHM_OK) return die("shm_write_pfm");
     printf("%s: %dx%d, %d spp, integrator %s, %d device(s): %llu rays, %.1f ms on the slowest device -> %s\n", argv[1], w, h, s->params.samples_per_pixel,
            s->integrator, n_devices, rays, ms, out_path);

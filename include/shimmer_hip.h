@@ -613,6 +613,9 @@ typedef struct ShmPbrtScene {
     char integrator[32];        /* "path" (default), "simplepath", "randomwalk": the name create_integrator receives */
     char output_filename[256];  /* Film "filename" (default "shimmer.pfm", film.rs:232-243) */
     void* owner;                /* the loader's storage */
+    float output_rgb_from_sensor_rgb[9]; /* RgbFilm::new (film.rs:524): rgb_from_xyz of sRGB (from its primaries and the D65 white, colorspace.rs:38-72)
+                                   times the sensor's matrix — the identity, or the von Kries white balance of Film "whitebalance" (color.rs:404-416,
+                                   the illuminant from DenselySampledSpectrum::d, spectrum.rs:215-262). Row-major; what shm_film_get_image takes. */
 } ShmPbrtScene;
 SHM_API int shm_scene_load_pbrt(const char* path, ShmPbrtScene** out);
 /* The same from a string; base_dir (may be NULL) resolves Include and plymesh file names. */

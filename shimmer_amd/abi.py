@@ -192,7 +192,8 @@ class ShmHit(C.Structure):
 assert C.sizeof(ShmMaterial) == 64 + 4 * 32 + 48 and C.sizeof(ShmFloatTexture) == 48 and C.sizeof(ShmBvhNode) == 32 and C.sizeof(ShmRay) == 32 and C.sizeof(ShmHit) == 32 and C.sizeof(ShmFilmPixel) == 32
 
 class ShmPbrtScene(C.Structure):
-    _fields_ = [("desc", ShmSceneDesc), ("params", ShmRenderParams), ("integrator", C.c_char * 32), ("output_filename", C.c_char * 256), ("owner", C.c_void_p)]
+    _fields_ = [("desc", ShmSceneDesc), ("params", ShmRenderParams), ("integrator", C.c_char * 32), ("output_filename", C.c_char * 256), ("owner", C.c_void_p),
+                ("output_rgb_from_sensor_rgb", C.c_float * 9)]
 
 
 class ShmLoadedImage(C.Structure):

@@ -196,6 +196,7 @@ public:
         bool regularize = false, sample_lights = true, sample_bsdf = true;
         std::string integrator = "path", filename = "shimmer.pfm", sampler = "independent";
         int seed = 0;
+        float white_balance = 0.0f;
         bool disable_pixel_jitter = false, disable_wavelength_jitter = false, force_diffuse = false, disable_texture_filtering = false;
     } settings_;
 
@@ -865,8 +866,11 @@ private:
             if (pb[2] <= pb[0] || pb[3] <= pb[1]) fail("Degenerate pixel bounds provided to film");
         }
         memcpy(f.pixel_bounds, pb, sizeof(pb));
-        if (film_params_.one_string("sensor", "cie1931") != "cie1931" || film_params_.one_float("whitebalance", 0.0f) != 0.0f)
-            fail("only the cie1931 sensor without white balancing is supported", SHM_ERR_UNSUPPORTED);
+        // PixelSensor::create (film.rs:767-818): a named camera sensor needs "<name>_r/_g/_b" spectra that NamedSpectrum does not hold — the
+        // reference panics on every name but cie1931; "whitebalance" is a colour temperature for the von Kries matrix of the output transform
+        if (film_params_.one_string("sensor", "cie1931") != "cie1931")
+            fail(tk.where(line) + ": Unknown sensor type \"" + film_params_.one_string("sensor", "") + "\" (the reference knows cie1931 only)");
+        settings_.white_balance = film_params_.one_float("whitebalance", 0.0f);
         const float shutter_open = camera_params_.one_float("shutteropen", 0.0f), shutter_close = camera_params_.one_float("shutterclose", 1.0f);
         f.imaging_ratio = (shutter_close - shutter_open) * film_params_.one_float("iso", 100.0f) / 100.0f;  // film.rs:785
         f.max_component_value = film_params_.one_float("maxcomponentvalue", INFINITY);
@@ -1079,6 +1083,7 @@ static int load_text(const std::string& text, const std::string& name, const std
         p.integrator = st.integrator == "path" ? SHM_INTEGRATOR_PATH : (st.integrator == "simplepath" ? SHM_INTEGRATOR_SIMPLE_PATH : SHM_INTEGRATOR_RANDOM_WALK);
         snprintf(scene->integrator, sizeof(scene->integrator), "%s", st.integrator.c_str());
         snprintf(scene->output_filename, sizeof(scene->output_filename), "%s", st.filename.c_str());
+        Assembly::film_output_matrix(st.white_balance, scene->output_rgb_from_sensor_rgb);
         Holder* h = new Holder();
         h->built = std::move(built);
         scene->owner = h;

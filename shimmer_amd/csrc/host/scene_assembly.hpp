@@ -222,6 +222,82 @@ public:
         return s;
     }
     uint32_t cs_illuminant_offset = ~0u;
+    // ---- RgbFilm::new's output matrix (film.rs:482-545, 767-850; colorspace.rs:38-72; color.rs:392-416; spectrum.rs:215-262) ----
+    // xyz_from_rgb of sRGB as RgbColorSpace::new builds it from the primaries and W = XYZ::from_spectrum(D65): rgb * diag(rgb^-1 W). The
+    // reference's 3x3 algebra is compensated f32; here f64, rounded once at the end.
+    static void srgb_matrices(const std::vector<float>& d65_dense, double xyz_from_rgb[3][3], double rgb_from_xyz[3][3], double white_xy[2]) {
+        const std::vector<float> bx = PBRT_TABLE(CIE_X), by = PBRT_TABLE(CIE_Y), bz = PBRT_TABLE(CIE_Z), yi = PBRT_TABLE(CIE_Y_INTEGRAL);
+        const std::vector<float>* bars[3] = {&bx, &by, &bz};
+        double w[3];
+        for (int k = 0; k < 3; ++k) {
+            float acc = 0.0f;
+            for (int i = 0; i < 471; ++i) acc += (*bars[k])[i] * d65_dense[i];
+            w[k] = (double)(acc / yi[0]);
+        }
+        white_xy[0] = w[0] / (w[0] + w[1] + w[2]);
+        white_xy[1] = w[1] / (w[0] + w[1] + w[2]);
+        const float xy[3][2] = {{0.64f, 0.33f}, {0.3f, 0.6f}, {0.15f, 0.06f}};
+        double m[3][3], inv[3][3];
+        for (int j = 0; j < 3; ++j) { m[0][j] = xy[j][0] * 1.0f / xy[j][1]; m[1][j] = 1.0; m[2][j] = (1.0f - xy[j][0] - xy[j][1]) * 1.0f / xy[j][1]; }
+        invert3(m, inv);
+        double c[3];
+        for (int k = 0; k < 3; ++k) c[k] = inv[k][0] * w[0] + inv[k][1] * w[1] + inv[k][2] * w[2];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) xyz_from_rgb[i][j] = m[i][j] * c[j];
+        invert3(xyz_from_rgb, rgb_from_xyz);
+    }
+    static void invert3(const double m[3][3], double inv[3][3]) {
+        const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det; inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det;
+        inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det; inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+        inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det; inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+    }
+    // DenselySampledSpectrum::d(temperature) (spectrum.rs:215-262), with the reference's `2.9678e6 / cct * cct` as written
+    static std::vector<float> d_illuminant_dense(float temperature) {
+        const float cct = temperature * 1.4388f / 1.4380f;
+        if (cct < 4000.0f) {  // "CIE D ill-defined, use blackbody": BlackbodySpectrum::new(cct).get at the integer wavelengths
+            return blackbody_dense(cct);
+        }
+        const float x = cct <= 7000.0f ? -4.607f * 1e9f / (cct * cct * cct) + 2.9678f * 1e6f / cct * cct + 0.09911f * 1e3f / cct + 0.244063f
+                                      : -2.0064f * 1e9f / (cct * cct * cct) + 1.9018f * 1e6f / cct * cct + 0.24748f * 1e3f / cct + 0.23704f;
+        const float y = -3.0f * x * x + 2.870f * x - 0.275f;
+        const float m = 0.0241f + 0.2562f * x - 0.7341f * y;
+        const float m1 = (-1.3515f - 1.7703f * x + 5.9114f * y) / m;
+        const float m2 = (0.0300f - 31.4424f * x + 30.0717f * y) / m;
+        const std::vector<float> lam = PBRT_TABLE(CIE_S_LAMBDA), s0 = PBRT_TABLE(CIE_S0), s1 = PBRT_TABLE(CIE_S1), s2 = PBRT_TABLE(CIE_S2);
+        std::vector<float> val(lam.size());
+        for (size_t i = 0; i < lam.size(); ++i) val[i] = (s0[i] + s1[i] * m1 + s2[i] * m2) * 0.01f;
+        return piecewise_to_dense(lam, val);
+    }
+    // film.rs:524: output_rgb_from_sensor_rgb = color_space.rgb_from_xyz * sensor.xyz_from_sensor_rgb, the sensor's matrix being the von Kries
+    // white balance (color.rs:404-416) from the "whitebalance" illuminant's white to the colour space's, or the identity without one
+    static void film_output_matrix(float white_balance_temp, float out9[9]) {
+        const std::vector<float> d65 = illuminant_d65_dense();
+        double xyz_from_rgb[3][3], rgb_from_xyz[3][3], target_xy[2];
+        srgb_matrices(d65, xyz_from_rgb, rgb_from_xyz, target_xy);
+        double sensor[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        if (white_balance_temp != 0.0f) {
+            const std::vector<float> illum = d_illuminant_dense(white_balance_temp);
+            double dummy1[3][3], dummy2[3][3], src_xy[2];
+            srgb_matrices(illum, dummy1, dummy2, src_xy);  // (only its XYZ::from_spectrum(illum).xy() part is used)
+            static const double lms_from_xyz[3][3] = {{0.8951, 0.2664, -0.1614}, {-0.7502, 1.7135, 0.0367}, {0.0389, -0.0685, 1.0296}};
+            static const double xyz_from_lms[3][3] = {{0.986993, -0.147054, 0.159963}, {0.432305, 0.51836, 0.0492912}, {-0.00852866, 0.0400428, 0.968487}};
+            auto from_xy = [](const double xy[2], double xyz[3]) { xyz[0] = xy[0] / xy[1]; xyz[1] = 1.0; xyz[2] = (1.0 - xy[0] - xy[1]) / xy[1]; };
+            double sx[3], dx[3], sl[3], dl[3];
+            from_xy(src_xy, sx);
+            from_xy(target_xy, dx);
+            for (int k = 0; k < 3; ++k) { sl[k] = lms_from_xyz[k][0] * sx[0] + lms_from_xyz[k][1] * sx[1] + lms_from_xyz[k][2] * sx[2]; dl[k] = lms_from_xyz[k][0] * dx[0] + lms_from_xyz[k][1] * dx[1] + lms_from_xyz[k][2] * dx[2]; }
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k < 3; ++k) acc += xyz_from_lms[i][k] * (dl[k] / sl[k]) * lms_from_xyz[k][j];
+                sensor[i][j] = acc;
+            }
+        }
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) acc += rgb_from_xyz[i][k] * sensor[k][j];
+            out9[3 * i + j] = (float)acc;
+        }
+    }
     // RgbColorSpace::SRGB.luminance_vector(): row 1 of xyz_from_rgb (colorspace.rs:38-72, 107-114). With Y = 1 for the three primaries that row
     // is c = rgb^-1 W itself, W = XYZ::from_spectrum(D65) (f32 running sums as inner_product, spectrum.rs:609-615). The 3x3 inverse of the
     // reference is built from compensated difference_of_products; here it is evaluated in f64 and rounded once.

@@ -38,7 +38,13 @@ def test_c_example_renders_pbrt_file(gpu_lib, tmp_path):
     rr = render.Renderer(gpu_lib, sc.desc, device=0)
     film, _ = rr.render(render.make_params(seed=0, spp=8, max_depth=5))
     rr.close()
-    want = render.film_get_image(gpu_lib, film, render.SRGB_FROM_XYZ)
+    # the example converts with the matrix the loader hands over (RgbFilm::new's output_rgb_from_sensor_rgb)
+    loaded = C.POINTER(abi.ShmPbrtScene)()
+    abi.check(gpu_lib, gpu_lib.shm_scene_parse_pbrt(S1_TEXT.encode(), None, C.byref(loaded)), "shm_scene_parse_pbrt")
+    matrix = np.array(list(loaded.contents.output_rgb_from_sensor_rgb), np.float32).reshape(3, 3)
+    gpu_lib.shm_pbrt_free(loaded)
+    assert np.allclose(matrix, render.SRGB_FROM_XYZ, atol=2e-3)
+    want = render.film_get_image(gpu_lib, film, matrix)
     assert np.array_equal(img, want)
     # a scene file the loader rejects: the message with file:line reaches the caller, exit code 1
     bad = tmp_path / "bad.pbrt"

@@ -469,3 +469,33 @@ def test_attribute_directive_sets_defaults_in_scope(lib):
     out = C.POINTER(abi.ShmPbrtScene)()
     assert lib.shm_scene_parse_pbrt(b'WorldBegin\nAttribute "camera" "float fov" 3\nShape "sphere"', None, C.byref(out)) == -1
     assert "Unknown attribute target camera" in lib.shm_last_error().decode()
+
+
+def test_film_output_matrix_and_white_balance(lib):
+    """RgbFilm::new (film.rs:524): output_rgb_from_sensor_rgb = rgb_from_xyz(sRGB, built from the primaries and the D65 white, colorspace.rs:38-72)
+    x the sensor's matrix — the identity for the cie1931 sensor, or the von Kries transform of Film "whitebalance" (color.rs:404-416) from the
+    white of DenselySampledSpectrum::d(T) (spectrum.rs:215-262) to the colour space's."""
+    def matrix(film_params=""):
+        got = load(lib, f'Film "rgb" {film_params}\nCamera "perspective"\nWorldBegin\nShape "sphere"')
+        m = np.array(list(got.contents.output_rgb_from_sensor_rgb), np.float64).reshape(3, 3)
+        lib.shm_pbrt_free(got)
+        return m
+    base = matrix()
+    assert np.allclose(base, render.SRGB_FROM_XYZ, atol=2e-3)  # IEC 61966-2-1, up to the D65 table's white point
+    assert np.allclose(base @ np.array([0.95047, 1.0, 1.08883]), 1.0, atol=3e-3)  # D65 white -> (1, 1, 1)
+    warm = matrix('"float whitebalance" 3200')  # below 4000 K the reference takes a blackbody: a warm illuminant is balanced towards blue
+    lam = np.arange(360.0, 831.0) * 1e-9
+    t = 3200.0 * 1.4388 / 1.4380
+    planck = 1.0 / (lam ** 5 * (np.exp(6.62606957e-34 * 299792458.0 / (lam * 1.3806488e-23 * t)) - 1))
+    tb = scn.tables()
+    white = np.array([(tb[k].astype(np.float64) * planck).sum() for k in ("CIE_X", "CIE_Y", "CIE_Z")])
+    rgb = warm @ (white / white[1])
+    assert np.allclose(rgb / rgb[1], 1.0, atol=0.02), rgb  # the illuminant's own white comes out neutral
+    assert (base @ (white / white[1]))[2] < 0.4  # ... which it does not without the balance
+    # At and above 4000 K the reference's CCT -> xy polynomial reads `2.9678e6 / cct * cct` (spectrum.rs:233, 238: the square was meant to
+    # divide), so x is about 3e6 and the "balanced" matrix is far from any colour transform. Restated as written.
+    wb = matrix('"float whitebalance" 6500')
+    assert np.abs(wb - base).max() > 1.0
+    out = C.POINTER(abi.ShmPbrtScene)()
+    assert lib.shm_scene_parse_pbrt(b'Film "rgb" "string sensor" "canon_eos_5d"\nWorldBegin\nShape "sphere"', None, C.byref(out)) == -1
+    assert "Unknown sensor type" in lib.shm_last_error().decode()
