@@ -554,6 +554,21 @@ SHM_API int shm_camera_perspective(const float world_from_camera[16], float fov_
  * conventions. lens_radius / focal_distance are stored but unused, as in the reference. */
 SHM_API int shm_camera_orthographic(const float world_from_camera[16], const int32_t full_resolution[2], float lens_radius,
                             float focal_distance, ShmCamera* out, float render_from_world_out[16]);
+/* The same two constructors with the rest of what Camera::create reads (camera.rs:676-705, 848-890) and the rendering space of
+ * CameraTransform::new (camera.rs:507-523; Option "rendercoordsys"): */
+enum { SHM_RENDER_SPACE_CAMERA_WORLD = 0, SHM_RENDER_SPACE_CAMERA = 1, SHM_RENDER_SPACE_WORLD = 2 };
+typedef struct ShmCameraParams {
+    uint32_t kind;                /* SHM_CAMERA_PERSPECTIVE / SHM_CAMERA_ORTHOGRAPHIC */
+    uint32_t render_space;        /* SHM_RENDER_SPACE_* */
+    float world_from_camera[16];  /* row-major */
+    float fov_deg;                /* perspective only */
+    int32_t full_resolution[2];
+    float lens_radius, focal_distance;
+    float frame_aspect_ratio;     /* "frameaspectratio"; 0 = x / y of the film */
+    uint32_t has_screen_window;
+    float screen_window[4];       /* "screenwindow" as the file gives it: x0 x1 y0 y1 */
+} ShmCameraParams;
+SHM_API int shm_camera_create(const ShmCameraParams* params, ShmCamera* out, float render_from_world_out[16]);
 /* C entry to the C++ host mirror of the reference's integrator interface (shimmer_amd/csrc/host/integrator.hpp):
  * create_integrator(name, {maxdepth, regularize, lightsampler "uniform", spp}, scene)->render(options), integrator.rs:16-42,
  * 52-54, 120-210, 226-322. `name`: "path", "simplepath" (sample_lights / sample_bsdf are its "samplelights" / "samplebsdf") or
@@ -593,7 +608,8 @@ SHM_API void shm_ply_free(ShmPlyMesh* mesh);
 /* ---- PBRT-v4 scene front end (ABI v7) ------------------------------------------------------------------------------
  * The reference's loader (loading/tokenizer.rs, parser.rs:216-351, parser_target.rs:50-184, scene.rs:1221-2033) restated in C++ for the
  * directive set the repository's scenes use: transforms (LookAt Translate Scale Rotate Identity Transform ConcatTransform CoordinateSystem
- * CoordSysTransform ReverseOrientation), Camera (perspective / orthographic), Film (rgb), Sampler (independent), PixelFilter (box),
+ * CoordSysTransform ReverseOrientation), Camera (perspective / orthographic, incl. frameaspectratio / screenwindow), Film (rgb, whitebalance),
+ * Attribute, Option (incl. rendercoordsys), Sampler (independent), PixelFilter (box),
  * Integrator (path / simplepath / randomwalk), Option, WorldBegin, AttributeBegin / End, Material / MakeNamedMaterial / NamedMaterial
  * (diffuse conductor dielectric thindielectric coateddiffuse coatedconductor mix, "normalmap"), Texture (float / spectrum: constant scale
  * mix directionmix imagemap — with the uv / spherical / cylindrical / planar mappings), AreaLightSource (diffuse), LightSource (point,

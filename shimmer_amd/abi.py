@@ -196,6 +196,12 @@ class ShmPbrtScene(C.Structure):
                 ("output_rgb_from_sensor_rgb", C.c_float * 9)]
 
 
+class ShmCameraParams(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("render_space", C.c_uint32), ("world_from_camera", C.c_float * 16), ("fov_deg", C.c_float),
+                ("full_resolution", C.c_int32 * 2), ("lens_radius", C.c_float), ("focal_distance", C.c_float), ("frame_aspect_ratio", C.c_float),
+                ("has_screen_window", C.c_uint32), ("screen_window", C.c_float * 4)]
+
+
 class ShmLoadedImage(C.Structure):
     _fields_ = [("n_levels", C.c_uint32), ("n_channels", C.c_uint32), ("file_channels", C.c_uint32), ("has_color_space", C.c_uint32),
                 ("n_texel_floats", C.c_uint64), ("levels", C.POINTER(ShmImageLevel)), ("texels", c_float_p)]
@@ -241,6 +247,7 @@ EXPORTS = {
     "shm_look_at": (C.c_int, [c_float_p, c_float_p, c_float_p, c_float_p]),
     "shm_image_load_png": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.POINTER(ShmLoadedImage)]),
     "shm_image_free": (None, [C.POINTER(ShmLoadedImage)]),
+    "shm_camera_create": (C.c_int, [C.POINTER(ShmCameraParams), C.POINTER(ShmCamera), c_float_p]),
     "shm_render_multi": (C.c_int, [C.POINTER(ShmSceneDesc), C.POINTER(C.c_int32), C.c_int32, C.POINTER(ShmRenderParams), C.c_void_p, C.POINTER(ShmStats)]),
 }
 

@@ -292,15 +292,18 @@ int shm_tile_bounds(const int32_t pb[4], int32_t tile_w, int32_t tile_h, ShmTile
 
 // ProjectiveCameraBase::new for either projection (camera.rs:594-642); fov_deg < 0 selects Transform::orthographic(0, 1)
 static int projective_camera(const float world_from_camera[16], float fov_deg, const int32_t full_resolution[2],
-                             float lens_radius, float focal_distance, ShmCamera* out, float render_from_world_out[16]) {
-    if (!world_from_camera || !full_resolution || !out || full_resolution[0] <= 0 || full_resolution[1] <= 0)
+                             float lens_radius, float focal_distance, ShmCamera* out, float render_from_world_out[16],
+                             uint32_t render_space = SHM_RENDER_SPACE_CAMERA_WORLD, float frame_aspect_ratio = 0.0f, const float* screen_window = nullptr) {
+    if (!world_from_camera || !full_resolution || !out || full_resolution[0] <= 0 || full_resolution[1] <= 0 || render_space > SHM_RENDER_SPACE_WORLD)
         return SHM_ERR_INVALID_ARGUMENT;
     M4 wfc;
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) wfc.m[i][j] = world_from_camera[i * 4 + j];
-    // CameraTransform::new, RenderingCoordinateSystem::CameraWorld (camera.rs:507-523; main.rs:66 default)
+    // CameraTransform::new (camera.rs:507-523): CameraWorld (main.rs:66 default) keeps world axes and puts the camera at the origin, Camera
+    // renders in camera space, World in world space
     double origin[3] = {0, 0, 0}, p_camera[3];
     m4_point(wfc, origin, p_camera);
-    M4 world_from_render = m4_translate(p_camera[0], p_camera[1], p_camera[2]);
+    M4 world_from_render = render_space == SHM_RENDER_SPACE_CAMERA ? wfc
+                           : (render_space == SHM_RENDER_SPACE_WORLD ? m4_identity() : m4_translate(p_camera[0], p_camera[1], p_camera[2]));
     M4 render_from_world;
     if (!m4_inverse(world_from_render, render_from_world)) return SHM_ERR_INVALID_ARGUMENT;
     M4 render_from_camera = m4_mul(render_from_world, wfc);
@@ -315,11 +318,13 @@ static int projective_camera(const float world_from_camera[16], float fov_deg, c
     M4 screen_from_camera = m4_mul(m4_scale(inv_tan, inv_tan, 1.0), persp);
     const bool ortho = fov_deg < 0.0f;
     if (ortho) screen_from_camera = m4_identity();  // Transform::orthographic(0, 1) = scale(1, 1, 1 / (1 - 0)) * translate(0, 0, -0) (transform.rs:293-303)
-    // screen window from the aspect ratio (camera.rs:848-864)
-    double frame = (double)full_resolution[0] / (double)full_resolution[1];
+    // screen window from the aspect ratio, "frameaspectratio" or "screenwindow" (camera.rs:848-877: the file gives x0 x1 y0 y1)
+    double frame = frame_aspect_ratio > 0.0f ? (double)frame_aspect_ratio : (double)((float)full_resolution[0] / (float)full_resolution[1]);
     double sw[4];  // min.x, min.y, max.x, max.y
     if (frame > 1.0) { sw[0] = -frame; sw[1] = -1.0; sw[2] = frame; sw[3] = 1.0; }
     else { sw[0] = -1.0; sw[1] = -1.0 / frame; sw[2] = 1.0; sw[3] = 1.0 / frame; }
+    if (screen_window) { sw[0] = screen_window[0]; sw[1] = screen_window[2]; sw[2] = screen_window[1]; sw[3] = screen_window[3]; }
+    if (!(sw[2] > sw[0]) || !(sw[3] > sw[1])) return SHM_ERR_INVALID_ARGUMENT;
     // ProjectiveCameraBase::new (camera.rs:612-634)
     M4 ndc_from_screen = m4_mul(m4_scale(1.0 / (sw[2] - sw[0]), 1.0 / (sw[3] - sw[1]), 1.0), m4_translate(-sw[0], -sw[3], 0.0));
     M4 raster_from_ndc = m4_scale((double)full_resolution[0], -(double)full_resolution[1], 1.0);
@@ -393,6 +398,13 @@ int shm_camera_perspective(const float world_from_camera[16], float fov_deg, con
 int shm_camera_orthographic(const float world_from_camera[16], const int32_t full_resolution[2], float lens_radius,
                             float focal_distance, ShmCamera* out, float render_from_world_out[16]) {
     return projective_camera(world_from_camera, -1.0f, full_resolution, lens_radius, focal_distance, out, render_from_world_out);
+}
+
+int shm_camera_create(const ShmCameraParams* p, ShmCamera* out, float render_from_world_out[16]) {
+    if (!p || (p->kind != SHM_CAMERA_PERSPECTIVE && p->kind != SHM_CAMERA_ORTHOGRAPHIC)) return SHM_ERR_INVALID_ARGUMENT;
+    if (p->kind == SHM_CAMERA_PERSPECTIVE && !(p->fov_deg > 0.0f)) return SHM_ERR_INVALID_ARGUMENT;
+    return projective_camera(p->world_from_camera, p->kind == SHM_CAMERA_PERSPECTIVE ? p->fov_deg : -1.0f, p->full_resolution, p->lens_radius, p->focal_distance, out,
+                             render_from_world_out, p->render_space, p->frame_aspect_ratio, p->has_screen_window ? p->screen_window : nullptr);
 }
 
 int shm_film_get_image(const ShmFilmPixel* film, uint64_t n_pixels, const float m[9], int write_fp16, float* rgb_out) {

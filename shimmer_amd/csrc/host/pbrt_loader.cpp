@@ -197,6 +197,7 @@ public:
         std::string integrator = "path", filename = "shimmer.pfm", sampler = "independent";
         int seed = 0;
         float white_balance = 0.0f;
+        uint32_t render_space = SHM_RENDER_SPACE_CAMERA_WORLD;
         bool disable_pixel_jitter = false, disable_wavelength_jitter = false, force_diffuse = false, disable_texture_filtering = false;
     } settings_;
 
@@ -882,14 +883,21 @@ private:
         const Xf world_from_camera = xf_inverse(camera_from_world_);
         float wfc[16], rfw[16];
         memcpy(wfc, world_from_camera.m.m, sizeof(wfc));
-        const int32_t res[2] = {xres, yres};
         const float lens = camera_params_.one_float("lensradius", 0.0f), focal = camera_params_.one_float("focaldistance", 1e6f);
-        if (camera_params_.find("screenwindow") || camera_params_.find("frameaspectratio")) fail("screenwindow / frameaspectratio overrides are not supported", SHM_ERR_UNSUPPORTED);
-        int rc;
-        if (camera_type_ == "perspective") rc = shm_camera_perspective(wfc, camera_params_.one_float("fov", 90.0f), res, lens, focal, &a_->camera, rfw);
-        else if (camera_type_ == "orthographic") rc = shm_camera_orthographic(wfc, res, lens, focal, &a_->camera, rfw);
-        else fail(tk.where(line) + ": camera \"" + camera_type_ + "\" is not supported (perspective, orthographic)", SHM_ERR_UNSUPPORTED);
-        if (rc != SHM_OK) fail("camera construction failed");
+        if (camera_type_ != "perspective" && camera_type_ != "orthographic")
+            fail(tk.where(line) + ": camera \"" + camera_type_ + "\" is not supported (perspective, orthographic)", SHM_ERR_UNSUPPORTED);
+        ShmCameraParams cp;
+        memset(&cp, 0, sizeof(cp));
+        cp.kind = camera_type_ == "perspective" ? SHM_CAMERA_PERSPECTIVE : SHM_CAMERA_ORTHOGRAPHIC;
+        cp.render_space = settings_.render_space;
+        memcpy(cp.world_from_camera, wfc, sizeof(wfc));
+        cp.fov_deg = camera_params_.one_float("fov", 90.0f);
+        cp.full_resolution[0] = xres; cp.full_resolution[1] = yres;
+        cp.lens_radius = lens; cp.focal_distance = focal;
+        cp.frame_aspect_ratio = camera_params_.one_float("frameaspectratio", 0.0f);
+        const std::vector<float> sw = camera_params_.floats("screenwindow");
+        if (sw.size() == 4) { cp.has_screen_window = 1; memcpy(cp.screen_window, sw.data(), 16); }  // (any other count: the reference warns and ignores it)
+        if (shm_camera_create(&cp, &a_->camera, rfw) != SHM_OK) fail(tk.where(line) + ": camera construction failed (fov, screen window or transform)");
         a_->camera.shutter_open = shutter_open;
         a_->camera.shutter_close = shutter_close;
         a_->have_camera = true;
@@ -937,7 +945,13 @@ private:
                 else if (p.name == "disablewavelengthjitter") settings_.disable_wavelength_jitter = !p.b.empty() && p.b[0];
                 else if (p.name == "forcediffuse") settings_.force_diffuse = !p.b.empty() && p.b[0];
                 else if (p.name == "disabletexturefiltering") settings_.disable_texture_filtering = !p.b.empty() && p.b[0];
-                else if (p.name == "rendercoordsys") { if (p.s.empty() || p.s[0] != "cameraworld") fail(tk.where(t.line) + ": only the cameraworld rendering space is supported", SHM_ERR_UNSUPPORTED); }
+                else if (p.name == "rendercoordsys") {  // scene.rs:1411-1431
+                    const std::string v = p.s.empty() ? "" : p.s[0];
+                    if (v == "cameraworld") settings_.render_space = SHM_RENDER_SPACE_CAMERA_WORLD;
+                    else if (v == "camera") settings_.render_space = SHM_RENDER_SPACE_CAMERA;
+                    else if (v == "world") settings_.render_space = SHM_RENDER_SPACE_WORLD;
+                    else fail(tk.where(t.line) + ": Unknown rendering coordinate system " + v);
+                }
             }
         } else if (d == "Camera") {
             need_world(t, tk, false);

@@ -499,3 +499,59 @@ def test_film_output_matrix_and_white_balance(lib):
     out = C.POINTER(abi.ShmPbrtScene)()
     assert lib.shm_scene_parse_pbrt(b'Film "rgb" "string sensor" "canon_eos_5d"\nWorldBegin\nShape "sphere"', None, C.byref(out)) == -1
     assert "Unknown sensor type" in lib.shm_last_error().decode()
+
+
+def test_camera_screen_window_aspect_and_render_space(lib):
+    """The rest of Camera::create (camera.rs:676-705, 848-890: "frameaspectratio", "screenwindow" as x0 x1 y0 y1) and Option "rendercoordsys"
+    (scene.rs:1411-1431 -> CameraTransform::new, camera.rs:507-523): the three rendering spaces place the same scene differently and render
+    the same picture."""
+    body = """
+    LookAt 1 2 6  0 0.5 0  0 1 0
+    Camera "perspective" "float fov" 40 {cam}
+    Film "rgb" "integer xresolution" 32 "integer yresolution" 24
+    Sampler "independent" "integer pixelsamples" 16
+    WorldBegin
+    AttributeBegin
+      AreaLightSource "diffuse" "blackbody L" 6000 "float scale" 8
+      Translate 0 4 0
+      Shape "sphere" "float radius" 0.7
+    AttributeEnd
+    Material "diffuse" "float reflectance" 0.6
+    Shape "sphere" "float radius" 1
+    Shape "trianglemesh" "point3 P" [ -5 -1 -5  5 -1 -5  5 -1 5  -5 -1 5 ] "integer indices" [ 0 2 1 0 3 2 ]
+    """
+    def scene(option="", cam=""):
+        return load(lib, (f'Option "string rendercoordsys" "{option}"\n' if option else "") + body.format(cam=cam))
+    imgs, cams = {}, {}
+    for space in ("cameraworld", "camera", "world"):
+        got = scene(space)
+        d = got.contents.desc
+        cams[space] = np.array(list(d.camera.render_from_camera), np.float64).reshape(4, 4)
+        o = oracle_py.Oracle(d)
+        film, _ = o.render(got.contents.params, n_threads=8)
+        o.close()
+        imgs[space] = film["rgb_sum"] / film["weight_sum"][..., None]
+        centre = np.array(list(d.spheres[1].render_from_object), np.float64).reshape(4, 4)[:3, 3]
+        if space == "world":
+            assert np.allclose(centre, 0.0, atol=1e-6) and np.allclose(cams[space][:3, 3], [1, 2, 6], atol=1e-5)
+        elif space == "camera":
+            assert np.allclose(cams[space], np.eye(4), atol=1e-6) and np.linalg.norm(centre) == pytest.approx(np.sqrt(1 + 4 + 36), rel=1e-5) and centre[2] > 6
+        else:
+            assert np.allclose(cams[space][:3, 3], 0.0, atol=1e-6) and np.allclose(centre, [-1, -2, -6], atol=1e-5)
+        lib.shm_pbrt_free(got)
+    ref = imgs["cameraworld"]
+    for space in ("camera", "world"):  # the same picture up to Monte-Carlo noise and float rounding of the different coordinates
+        assert abs(imgs[space].mean() - ref.mean()) < 0.03 * ref.mean() and np.abs(imgs[space] - ref).mean() < 0.25 * ref.mean()
+    # screen window: half the default extent in x (the film is 4:3 -> default x in [-4/3, 4/3]) doubles the magnification in x only
+    base = scene()
+    zoom = scene(cam='"float screenwindow" [ -0.6666667 0.6666667 -1 1 ]')
+    wide = scene(cam='"float frameaspectratio" 2')
+    bx = np.array(list(base.contents.desc.camera.dx_camera))
+    zx, zy = np.array(list(zoom.contents.desc.camera.dx_camera)), np.array(list(zoom.contents.desc.camera.dy_camera))
+    assert np.allclose(zx, bx / 2, rtol=1e-5) and np.allclose(zy, np.array(list(base.contents.desc.camera.dy_camera)), rtol=1e-5)
+    wx = np.array(list(wide.contents.desc.camera.dx_camera))
+    assert np.allclose(wx, bx * (2.0 / (32.0 / 24.0)), rtol=1e-5)  # frame 2: screen x in [-2, 2]
+    for g in (base, zoom, wide):
+        lib.shm_pbrt_free(g)
+    out = C.POINTER(abi.ShmPbrtScene)()
+    assert lib.shm_scene_parse_pbrt(b'Option "string rendercoordsys" "object"\nWorldBegin\nShape "sphere"', None, C.byref(out)) == -1
