@@ -319,7 +319,7 @@ static int projective_camera(const float world_from_camera[16], float fov_deg, c
     const bool ortho = fov_deg < 0.0f;
     if (ortho) screen_from_camera = m4_identity();  // Transform::orthographic(0, 1) = scale(1, 1, 1 / (1 - 0)) * translate(0, 0, -0) (transform.rs:293-303)
     // screen window from the aspect ratio, "frameaspectratio" or "screenwindow" (camera.rs:848-877: the file gives x0 x1 y0 y1)
-    double frame = frame_aspect_ratio > 0.0f ? (double)frame_aspect_ratio : (double)((float)full_resolution[0] / (float)full_resolution[1]);
+    double frame = frame_aspect_ratio > 0.0f ? (double)frame_aspect_ratio : (double)full_resolution[0] / (double)full_resolution[1];
     double sw[4];  // min.x, min.y, max.x, max.y
     if (frame > 1.0) { sw[0] = -frame; sw[1] = -1.0; sw[2] = frame; sw[3] = 1.0; }
     else { sw[0] = -1.0; sw[1] = -1.0 / frame; sw[2] = 1.0; sw[3] = 1.0 / frame; }
