@@ -186,7 +186,8 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                 }
             }
             if (go) {
-                const float4* np = reinterpret_cast<const float4*>(node_base + ((size_t)cur << 5));
+                // (a 32-bit byte offset on the uniform base: one shift and the scalar-base addressing mode; wf_trace_prepare checks the tree fits 4 GiB)
+                const float4* np = reinterpret_cast<const float4*>(node_base + (uint32_t)(cur << 5));
                 float4 na = np[0], nb = np[1];
                 visited = true;
                 // Bounds3f::intersect_p_cached (bounding_box.rs:520-563), signs held as lane masks
@@ -218,7 +219,7 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                     state = ST_LEAF;
                 } else {
                     uint32_t axis = (meta >> 16) & 0xffu;
-                    bool neg = (axis == 0) ? negx : ((axis == 1) ? negy : negz);
+                    bool neg = ((axis == 0) ? inv_dir.x : ((axis == 1) ? inv_dir.y : inv_dir.z)) < 0.0f;  // dir_is_neg[axis], from the component itself
                     uint32_t far_child = neg ? cur + 1 : offset;   // aggregate.rs:119-127
                     uint32_t near_child = neg ? offset : cur + 1;
                     if (sp < K3_LDS_N) st_lds[sp * WAVE] = far_child;
@@ -364,6 +365,7 @@ __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x;
 }  // namespace
 
 int wf_trace_prepare(ShmScene* s) {
+    if (s->flat.nodes.size() > (size_t)1 << 27) { shm_err() = "more than 2^27 BVH nodes (the traversal kernels address the node array with 32-bit byte offsets)"; return SHM_ERR_UNSUPPORTED; }
     const bool tri_only = !s->flat.has_spheres;
     for (int any = 0; any < 2; ++any) {
         const int lds = tri_only ? (any ? K3Shape<true, true>::LDS : K3Shape<false, true>::LDS) : K3Shape<false, false>::LDS;
