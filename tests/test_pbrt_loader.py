@@ -555,3 +555,18 @@ def test_camera_screen_window_aspect_and_render_space(lib):
         lib.shm_pbrt_free(g)
     out = C.POINTER(abi.ShmPbrtScene)()
     assert lib.shm_scene_parse_pbrt(b'Option "string rendercoordsys" "object"\nWorldBegin\nShape "sphere"', None, C.byref(out)) == -1
+
+
+def test_example_scene_files_load(lib):
+    """examples/scenes/*.pbrt (what examples/render_pbrt.c is pointed at) load and are valid scenes."""
+    from pathlib import Path
+    for f in sorted((Path(__file__).resolve().parents[1] / "examples" / "scenes").glob("*.pbrt")):
+        out = C.POINTER(abi.ShmPbrtScene)()
+        abi.check(lib, lib.shm_scene_load_pbrt(str(f).encode(), C.byref(out)), f.name)
+        s = out.contents
+        s.params.samples_per_pixel = 1
+        o = oracle_py.Oracle(s.desc)
+        film, _ = o.render(s.params, n_threads=8)
+        o.close()
+        assert np.isfinite(film["rgb_sum"]).all() and film["rgb_sum"].sum() > 0, f.name
+        lib.shm_pbrt_free(out)
