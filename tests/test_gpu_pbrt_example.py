@@ -112,3 +112,24 @@ def test_png_textured_pbrt_scene_renders_bit_exact(gpu_lib, tmp_path, filter):
             assert st[k] == ost[k], k
     finally:
         gpu_lib.shm_pbrt_free(out)
+
+
+def test_example_scene_files_render_bit_exact(gpu_lib):
+    """examples/scenes/*.pbrt through the loader and the HIP path at a few samples: the oracle's film, bit for bit."""
+    for f in sorted((ROOT / "examples" / "scenes").glob("*.pbrt")):
+        out = C.POINTER(abi.ShmPbrtScene)()
+        abi.check(gpu_lib, gpu_lib.shm_scene_load_pbrt(str(f).encode(), C.byref(out)), f.name)
+        try:
+            s = out.contents
+            s.params.samples_per_pixel = 3
+            rr = render.Renderer(gpu_lib, s.desc, device=0)
+            film, st = rr.render(s.params)
+            rr.close()
+            o = oracle_py.Oracle(s.desc)
+            want, ost = o.render(s.params, n_threads=8)
+            o.close()
+            assert np.array_equal(film.view(np.uint64), want.view(np.uint64)), f.name
+            for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+                assert st[k] == ost[k], (f.name, k)
+        finally:
+            gpu_lib.shm_pbrt_free(out)
