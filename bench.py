@@ -5,11 +5,16 @@
          256 spp, maxdepth 5. A step = one whole ImageTileIntegrator::render of that frame (all spp-waves over all 8x8 tiles).
   N > 1  the scaling configuration (configs[4], "C5"): the same scene at 3840x2160, 1024 spp, tiles sharded across the N GPUs
          inside the library (shm_render_sharded: C++ tile sharding, no collective while rendering, RCCL gather of the film rows
-         to rank 0 inside the timed region). Launched by the driver through torch.distributed.run (one process per GPU);
-         torch.distributed is the control plane only (unique-id broadcast, barrier, max-over-ranks time).
+         to rank 0 inside the timed region). One process per GPU, started EITHER by `python -m torch.distributed.run ... bench.py
+         --gpus N` (the driver's way: RANK / LOCAL_RANK / WORLD_SIZE come from the environment) OR by a plain `python bench.py --gpus N`:
+         the parent then starts N fresh children itself before making any GPU call (shimmer_amd/launch.py), relays rank 0's JSON line
+         and exits non-zero if any child does.
+A rank process imports NO torch: it maps one HIP runtime and one RCCL, the ones libshimmer_hip.so is linked against (/opt/rocm). The
+128-byte RCCL id travels from rank 0 to the others through a directory of files; the barrier either side of the timed region, the
+max-over-ranks clock and the counters run through the library's own collectives (shm_dist_barrier / _allreduce_f64 / _allgather_f64).
 Scene arrays are resident in HBM before the timed region. --width/--height/--spp override either default.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--spp S] [--res R] [--no-cpu-baseline] [--no-side]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--spp S] [--res R] [--no-cpu-baseline] [--no-side] [--no-live-pmc]
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -30,19 +35,104 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def pmc_profile(args):
-    """Counters of the K2 kernel per launch from the committed rocprofv3 PMC passes of THIS configuration
-    (tools/profile_gpu.sh -> profiles/traffic_*.json): HBM traffic = 2 x FETCH_SIZE (the gfx950 correction of
-    MI355X_MICROARCH.md section HBM) + WRITE_SIZE, in bytes, and (when the pass was collected) the mean number of active lanes
-    per VALU instruction. None when no profile of this configuration is committed."""
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"))
+K2_NAME = "k_trace3<closest>"
+
+
+def _k2_counters_from_db(db):
+    """Per-dispatch means of every counter of the closest-hit traversal kernel in one rocprofv3 rocpd database."""
+    import re
+    import sqlite3
+    cur = sqlite3.connect(db).cursor()
+    acc, disp = {}, set()
+    for name, counter, value, d in cur.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
+        m = re.search(r"k_trace3<(\w+)(?:, (\w+))?>", name)
+        if not m or m.group(1) != "false":  # first template argument: ANY
+            continue
+        acc[counter] = acc.get(counter, 0.0) + float(value)
+        disp.add(d)
+    n = max(1, len(disp))
+    return {k: v / n for k, v in acc.items()}, len(disp)
+
+
+def live_pmc(args):
+    """Collects the dominant kernel's hardware counters IN THIS RUN: one child process per counter set — `rocprofv3 --pmc <set> -- python3
+    bench.py --pmc-child ...` renders one frame of the same configuration — started before this process makes any GPU call. Separate
+    passes, no trace domain beside --pmc (MI355X_MICROARCH.md "rocprofv3 PMC slots"). Returns {counter: mean per K2 launch} or None."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out, t0 = {}, time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="shm_pmc_")
+    try:
+        child = [sys.executable, str(Path(__file__).resolve()), "--pmc-child", "--spp", str(args.spp), "--res", str(args.res), "--n", str(args.n),
+                 "--max-depth", str(args.max_depth), "--seed", str(args.seed), "--steps", "1", "--warmup", "0"]
+        for i, counters in enumerate(PMC_PASSES):
+            d = os.path.join(tmp, f"pass{i}")
+            cmd = [exe, "--pmc", *counters, "-d", d, "-o", "pmc", "--"] + child
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            r = subprocess.run(cmd, env=env, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.pmc_timeout)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, f"pass {counters[0]}: rc {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"
+            vals, n = _k2_counters_from_db(dbs[0])
+            if not n:
+                return None, f"pass {counters[0]}: no {K2_NAME} dispatch in the database"
+            out.update(vals)
+            out["dispatches"] = n
+        out["collect_s"] = time.perf_counter() - t0
+        return out, "live: rocprofv3 --pmc passes of this run"
+    except Exception as e:  # reporting only
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def committed_pmc(args):
+    """Fallback: the committed rocprofv3 PMC passes of THIS configuration (tools/profile_gpu.sh -> profiles/traffic_*.json)."""
     f = ROOT / "profiles" / f"traffic_res{args.res}_spp{args.spp}_n{args.n}_depth{args.max_depth}.json"
     if not f.exists() or args.width or args.height:
-        return None, None
-    t = json.loads(f.read_text()).get("k_trace3<closest>")
+        return None
+    t = json.loads(f.read_text()).get(K2_NAME)
     if not t:
-        return None, None
-    traffic = 2.0 * t.get("FETCH_SIZE_bytes_per_dispatch_raw", 0.0) + t.get("WRITE_SIZE_bytes_per_dispatch_raw", 0.0)
-    return traffic, t.get("valu_lanes_active")
+        return None
+    c = {"FETCH_SIZE": t.get("FETCH_SIZE_bytes_per_dispatch_raw", 0.0) / 1024.0, "WRITE_SIZE": t.get("WRITE_SIZE_bytes_per_dispatch_raw", 0.0) / 1024.0}
+    if t.get("valu_lanes_active"):
+        c["lanes"] = t["valu_lanes_active"]
+    for k in ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):
+        if k in t:
+            c[k] = t[k]
+    return c
+
+
+def counter_blocks(c, avg_launch_ms):
+    """HBM traffic per launch (2 x FETCH_SIZE — the gfx950 correction of MI355X_MICROARCH.md section HBM — + WRITE_SIZE, KiB units) and the
+    VALU-issue picture of the same kernel."""
+    if not c:
+        return None, None, None
+    traffic = (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0 if "FETCH_SIZE" in c else None
+    lanes = c.get("lanes")
+    if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU"):
+        lanes = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
+    valu = None
+    if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
+        n_simd, n_xcd = 256 * 4, 8
+        cycles = c["GRBM_GUI_ACTIVE"] / n_xcd                       # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        busy = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (n_simd * cycles)   # quad-cycles of VALU issue per SIMD over the kernel's cycles
+        valu = {"kernel": "k_trace3<closest>", "valu_busy_frac": busy, "lanes_per_valu_inst": lanes, "lane_throughput_frac": busy * lanes / 64.0 if lanes else None,
+                "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "active_inst_valu_quadcycles_per_launch": c["SQ_ACTIVE_INST_VALU"],
+                "gpu_cycles_per_launch": cycles, "effective_clock_GHz": cycles / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms else None,
+                "definitions": "valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): SQ_ACTIVE_INST_* count quad-cycles "
+                               "(MI355X_MICROARCH.md, 's_memtime tick vs SQ PMC units') and one wave64 VALU instruction is taken to occupy its SIMD's issue "
+                               "port for one quad-cycle (4 clocks; SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 in this kernel). The guide's 2-clock wave64 "
+                               "v_fma_f32 rate would halve the fraction: read it as +-2x. lanes_per_valu_inst = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; "
+                               "lane_throughput_frac = busy x lanes / 64"}
+    return traffic, lanes, valu
 
 
 def cpu_baseline(sc, params_full, host_lib, budget_s=15.0):
@@ -136,7 +226,10 @@ def side_results(lib, args, render, scenes, headline_scene, log):
     return out
 
 
-def main():
+_STORE = None  # this rank's control-channel store (so that main() can publish a failure)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -150,42 +243,86 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the side configurations (coated S3, C4, C2, textured Cornell)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not collect the dominant kernel's counters in this run (falls back to the committed profile)")
+    ap.add_argument("--pmc-timeout", type=float, default=240.0, help="seconds per live counter pass")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: the frame a live counter pass profiles (no baseline, no side runs, prints nothing)")
     ap.add_argument("--coated", action="store_true", help="S3 with a CoatedDiffuse object (LayeredBxDF, SURVEY 8f-1) instead of the "
                     "headline diffuse one: a side measurement, not the BASELINE config")
     ap.add_argument("--shard-of", type=int, default=0, help="development: render only the tiles rank 0 of N would own (no gather), "
                     "to estimate the per-rank time of an N-GPU run on one GPU")
     ap.add_argument("--shard-rank", type=int, default=0, help="development: which rank's tiles --shard-of renders")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL communicator + shm_render_sharded path even with one rank")
-    args = ap.parse_args()
+    ap.add_argument("--launch", action="store_true", help="go through the self-launcher even for N = 1 (one fresh child process)")
+    ap.add_argument("--launch-timeout", type=float, default=0.0, help="seconds the launcher waits for its ranks (0 = no limit)")
+    ap.add_argument("--init-timeout", type=float, default=600.0, help="seconds a rank waits for the id exchange + ncclCommInitRank before it gives up")
+    ap.add_argument("--dry-run", action="store_true", help="control plane only (no GPU, no library render call): launcher, environment, id exchange, "
+                    "barrier and max-reduce through the store; used by the CPU tests")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="with --dry-run: this rank exits 7 after the id exchange")
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not in_rank and (args.gpus > 1 or args.launch):
+        # the parent of a plain `python bench.py --gpus N`: N fresh children before any GPU call; it relays rank 0's line
+        from shimmer_amd import launch
+        log(f"[bench] self-launch: {args.gpus} rank process(es), one per GPU (no torch.distributed.run above us)")
+        argv = [sys.executable, str(Path(__file__).resolve())] + [a for a in sys.argv[1:] if a != "--launch"]
+        sys.exit(launch.spawn_ranks(argv, args.gpus, timeout_s=args.launch_timeout or None))
+    try:
+        rank_main(args)
+    except BaseException as e:  # a failing rank tells its peers through the store before it dies, so that nobody waits for it
+        clean_exit = isinstance(e, SystemExit) and e.code in (0, None)
+        if _STORE is not None and not clean_exit:
+            _STORE.fail(f"{type(e).__name__}: {e}")
+        raise
+
+
+def rank_main(args):
+    global _STORE
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
     c5 = world > 1 and not (args.width or args.height)
     if c5:
         args.width, args.height = 3840, 2160
     if not args.spp:
         args.spp = 1024 if world > 1 else 256
+    use_dist = world > 1 or args.force_dist
+    from shimmer_amd import launch
+    store = None
+    if use_dist or args.dry_run:
+        store = _STORE = launch.store_from_env(rank, world, timeout_s=args.init_timeout)
+
+    if args.dry_run:
+        return dry_run(args, rank, local_rank, world, store)
+
+    headline = world == 1 and not (args.coated or args.shard_of or args.force_dist or args.width or args.height or args.pmc_child)
+    counters, counters_src = None, "none"
+    if headline and not args.no_live_pmc:
+        # BEFORE this process touches the GPU: the counter passes are child processes under rocprofv3
+        counters, counters_src = live_pmc(args)
+        log(f"[bench] live counters: {counters_src}" + (f" ({counters['collect_s']:.0f} s)" if counters else ""))
+    if counters is None and world == 1:
+        c = committed_pmc(args)
+        if c:
+            counters, counters_src = c, f"committed profile profiles/traffic_res{args.res}_spp{args.spp}_n{args.n}_depth{args.max_depth}.json" + \
+                (f" (live collection failed: {counters_src})" if counters_src not in ("none",) else "")
 
     import numpy as np
-    import torch
-    import torch.distributed as dist
     from shimmer_amd import abi, scenes, render
 
     lib = abi.load_library()
-    if lib.shm_device_count() < 1 or not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if "torch" in sys.modules:
+        raise SystemExit("bench.py must not import torch: the rank process maps ONE HIP runtime and ONE RCCL (the library's)")
+    if lib.shm_device_count() <= local_rank:
+        raise SystemExit(f"bench.py needs HIP device {local_rank}: the render path has no CPU fallback ({lib.shm_device_count()} visible)")
+
+    def device_sync():
+        abi.check(lib, lib.shm_device_synchronize(local_rank), "shm_device_synchronize")
 
     t0 = time.perf_counter()
     width, height = (args.width or args.res), (args.height or args.res)
@@ -198,20 +335,22 @@ def main():
         log(f"[bench] scene {sc.name}: {sc.info['n_primitives']} prims, {sc.info['n_nodes']} nodes; build {t_scene:.1f}s, upload {t_upload:.2f}s")
     params = render.make_params(seed=args.seed, spp=args.spp, max_depth=args.max_depth)
     if use_dist:
-        # the library's own RCCL communicator: rank 0 draws the unique id, torch.distributed (control plane) carries its 128 bytes
-        uid = torch.zeros(abi.SHM_DIST_ID_BYTES, dtype=torch.uint8, device=device)
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(r.dist_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
-        r.dist_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+        # the library's own RCCL communicator: rank 0 draws the unique id, the file store carries its 128 bytes; a rank that cannot get
+        # this far publishes its failure in the store (main()), and a watchdog bounds ncclCommInitRank, which waits for every rank
+        with launch.Watchdog(args.init_timeout, "id exchange + shm_dist_init (ncclCommInitRank)", store):
+            uid = store.broadcast("rccl_unique_id", r.dist_unique_id() if rank == 0 else None)
+            r.dist_init(rank, world, uid)
+    info = r.dist_info()
+    if rank == 0:
+        log(f"[bench] runtime: librccl {info['librccl_path']} (RCCL {info['rccl_version']}), libamdhip64 {info['libamdhip_path']} (HIP {info['hip_runtime_version']}); "
+            f"communicator: {info['rccl_ranks']} rank(s), world {world}, {info['rows_per_block']} tile rows per shard block")
     my_tiles = None
     if world == 1 and args.shard_of > 1:
         my_tiles = render.shard_tiles(r.n_tiles, r.tiles_per_row, args.shard_rank, args.shard_of, lib=lib)
 
     def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+        r.dist_barrier()   # drains this rank's streams, then (with a communicator) one all-reduce over RCCL: every rank arrived
+        device_sync()
 
     def step():
         if use_dist:
@@ -230,24 +369,23 @@ def main():
             acc[k] = acc.get(k, 0) + v
     barrier()
     dt = time.perf_counter() - t0
+    if args.pmc_child:
+        r.close()
+        return
     per_rank = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = r.dist_allreduce([dt], abi.SHM_REDUCE_MAX)[0]   # the slowest rank's clock
         keys = ["paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"]
-        c = torch.tensor([acc[k] for k in keys], dtype=torch.float64, device=device)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        tot = {k: float(v) for k, v in zip(keys, c.tolist())}
-        mine = torch.tensor([acc["ms_total"] / args.steps, acc["ms_gather"] / args.steps, acc["rays_closest"] + acc["rays_any"],
-                             acc["gather_bytes"] / args.steps], dtype=torch.float64, device=device)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = [{"rank": i, "render_ms": float(v[0]), "gather_ms": float(v[1]), "rays_per_step": float(v[2]) / args.steps,
-                     "gather_MB": float(v[3]) / 1e6} for i, v in enumerate(allr)]
+        tot = dict(zip(keys, r.dist_allreduce([float(acc[k]) for k in keys], abi.SHM_REDUCE_SUM)))
+        mine = [acc["ms_total"] / args.steps, acc["ms_gather"] / args.steps, float(acc["rays_closest"] + acc["rays_any"]) / args.steps,
+                acc["gather_bytes"] / args.steps / 1e6, float(info["n_my_tiles"]), float(info["rccl_device"])]
+        allr = r.dist_allgather(mine)
+        per_rank = [{"rank": i, "render_ms": v[0], "gather_ms": v[1], "rays_per_step": v[2], "gather_MB": v[3], "tiles": int(v[4]), "device": int(v[5])}
+                    for i, v in enumerate(allr)]
     else:
         tot = {k: float(v) for k, v in acc.items()}
 
+    out = None
     if rank == 0:
         rays = tot["rays_closest"] + tot["rays_any"]
         value = rays / dt / 1e6
@@ -258,7 +396,7 @@ def main():
         ms = acc["ms_trace_closest"]
         achieved = bytes_alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         launches = max(1, acc["launches_closest"])
-        traffic, lanes = pmc_profile(args) if world == 1 else (None, None)
+        traffic, lanes, valu = counter_blocks(counters, ms / launches)
         hbm_counter = traffic / (ms / launches * 1e-3) / 1e9 if traffic and ms > 0 else None
         out = {
             "metric": "Mray/s (primary+secondary) at 1024^2 256spp Ganesha; 1/2/4/8-GPU scaling",
@@ -274,9 +412,10 @@ def main():
                                       "timed region" if use_dist else "none"},
             # `achieved` is the ALGORITHMIC byte rate of the kernel (what the traversal would read if every node / primitive
             # visit came from memory), `frac` = achieved / HBM peak. The kernel's gathers are largely served by L2 / MALL, so this is NOT
-            # HBM utilisation: `hbm_counter_GBs` (PMC traffic / launch time) is, and the kernel is VALU-issue bound (`bound_note`).
-            "roofline": {"bound": "hbm", "kernel": "k_trace3<closest> (BvhAggregate::intersect)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            # HBM utilisation: `hbm_counter_GBs` (PMC traffic / launch time) is; what limits the kernel is in `roofline_valu`.
+            "roofline": {"bound": "hbm (ALGORITHMIC bytes of SURVEY 8d; the gathers are cache-served, the kernel is VALU-issue limited: roofline_valu)",
+                         "kernel": "k_trace3<closest> (BvhAggregate::intersect)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": counters_src,
                          "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS, "hbm_counter_GBs": hbm_counter,
                          "hbm_counter_frac": (hbm_counter / HBM_PEAK_GBS) if hbm_counter else None, "lanes_active": lanes,
                          "bound_note": "algorithmic-bytes rate; gathers are cache-served (L2/MALL), the kernel is bound by VALU issue at "
@@ -294,7 +433,14 @@ def main():
             "breakdown_ms_per_step": {"trace_closest": acc["ms_trace_closest"] / args.steps, "trace_any": acc["ms_trace_any"] / args.steps,
                                       "shade_generate_film": acc["ms_shade"] / args.steps, "gpu_total": acc["ms_total"] / args.steps,
                                       "film_gather": acc.get("ms_gather", 0.0) / args.steps},
+            "runtime": {"launcher": os.environ.get("SHM_LAUNCHED_BY") or ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
+                        "control_plane": "file store (128-byte id) + the library's RCCL collectives (barrier, max clock, counters)" if use_dist else "none",
+                        "torch_imported": "torch" in sys.modules, "librccl": info["librccl_path"], "rccl_version": info["rccl_version"],
+                        "libamdhip64": info["libamdhip_path"], "hip_runtime_version": info["hip_runtime_version"],
+                        "rccl_ranks": info["rccl_ranks"], "rows_per_shard_block": info["rows_per_block"]},
         }
+        if valu:
+            out["roofline_valu"] = valu
         if per_rank is not None:
             out["per_rank"] = per_rank
     if use_dist and rank == 0:
@@ -317,6 +463,8 @@ def main():
         out["nonfinite_pixels"] = int((~np.isfinite(host["rgb_sum"]).all(axis=-1)).sum())
         if out["nonfinite_pixels"] and not args.coated:
             raise SystemExit("film is not finite")
+    if use_dist:
+        r.dist_barrier()   # nobody tears its communicator down while a peer still checks the film
     r.close()
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
@@ -326,15 +474,34 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         if not args.no_side and not args.coated and not args.shard_of and (width, height) == (1024, 1024):
             out["side_results"] = side_results(lib, args, render, scenes, sc, log)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if store is not None:
+        store.finish()
     if rank == 0:
         # RCCL prints its version banner through C stdio, which is flushed at exit: flush it now so that the JSON line is the
         # last thing on stdout
         import ctypes
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
+
+
+def dry_run(args, rank, local_rank, world, store):
+    """The control plane without a GPU (CPU tests): environment, id exchange, barrier and max-reduce — through the file store, since no
+    communicator can exist here. Rank 0 prints one JSON line."""
+    fake_id = store.broadcast("rccl_unique_id", bytes((7 * i + 1) & 0xFF for i in range(128)) if rank == 0 else None)
+    if rank == args.dry_run_fail_rank:
+        log(f"[bench] dry run: rank {rank} fails on request")
+        raise SystemExit(7)
+    store.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    store.barrier()
+    dt = store.allreduce_max("dt", time.perf_counter() - t0)
+    ranks = store.allgather("who", json.dumps({"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "ppid": os.getppid(),
+                                               "torch_imported": "torch" in sys.modules, "id_ok": fake_id[:3] == bytes((1, 8, 15))}).encode())
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "max_dt_s": dt, "ranks": [json.loads(x) for x in ranks],
+                          "launcher": os.environ.get("SHM_LAUNCHED_BY") or "external"}), flush=True)
+    store.finish()
 
 
 if __name__ == "__main__":

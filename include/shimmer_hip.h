@@ -507,8 +507,9 @@ SHM_API int shm_shard_tiles(uint32_t n_tiles, uint32_t tiles_per_row, int32_t ra
                             uint32_t* idx_out, uint32_t* n_out);
 
 /* One process per GPU (the layout of `torchrun` / MPI launches): an RCCL communicator per scene. The host distributes the 128-byte
- * unique id from rank 0 to every rank by whatever control channel it has (MPI_Bcast, a TCP store, torch.distributed), then every
- * rank calls shm_dist_init (collective: ncclCommInitRank on the scene's device). */
+ * unique id from rank 0 to every rank by whatever control channel it has (MPI_Bcast, a TCP store, a file: bench.py uses a directory of
+ * files, shimmer_amd/launch.py), then every rank calls shm_dist_init (collective: ncclCommInitRank on the scene's device, then rank 0's
+ * shard plan — tile rows per block — is broadcast, so that per-process environments cannot make block ownership differ between ranks). */
 #define SHM_DIST_ID_BYTES 128
 SHM_API int shm_dist_unique_id(uint8_t id_out[SHM_DIST_ID_BYTES]);
 SHM_API int shm_dist_init(ShmScene* scene, int32_t rank, int32_t world, const uint8_t id[SHM_DIST_ID_BYTES]);
@@ -520,6 +521,31 @@ SHM_API int shm_dist_finalize(ShmScene* scene);   /* also done by shm_scene_dest
  * single-GPU render; the other ranks hold their own rows. stats (may be NULL) is this rank's. Without shm_dist_init it renders the
  * whole frame on this GPU (world = 1). */
 SHM_API int shm_render_sharded(ShmScene* scene, const ShmRenderParams* params, ShmStats* stats);
+/* Small collectives on the scene's communicator, so that a host needs NO second communication stack beside this library (bench.py runs
+ * its barrier and its max-over-ranks clock through these; the only thing the host carries itself is the 128-byte id). Host values in,
+ * host values out; they go through a 32 KB device scratch and ncclAllReduce / ncclAllGather on the render stream. Every wait polls the
+ * stream and ncclCommGetAsyncError instead of blocking: a peer that died or never arrives becomes SHM_ERR_DEVICE after SHM_DIST_TIMEOUT_S
+ * (default 900 s), and the communicator is aborted so that the other ranks' pending operations fail too. Without shm_dist_init (or with
+ * a world of 1) they are the identity. */
+enum { SHM_REDUCE_SUM = 0, SHM_REDUCE_MAX = 1, SHM_REDUCE_MIN = 2 };
+SHM_API int shm_dist_barrier(ShmScene* scene);   /* this rank's streams drained, then one all-reduce: every rank arrived */
+SHM_API int shm_dist_allreduce_f64(ShmScene* scene, double* values /* in / out */, uint32_t n /* <= 4096 */, int32_t op /* SHM_REDUCE_* */);
+SHM_API int shm_dist_allgather_f64(ShmScene* scene, const double* mine, uint32_t n, double* all_out /* world * n <= 4096, rank-major */);
+/* What this process runs on: the communicator as RCCL sees it and the shared objects the two runtimes were mapped from (a host process that
+ * imported another ROCm stack before this library would show up here). scene may be NULL (library-wide fields only). */
+typedef struct ShmDistInfo {
+    int32_t rank, world;             /* as given to shm_dist_init (0, 1 without) */
+    int32_t rccl_ranks;              /* ncclCommCount of the communicator (0 without one) */
+    int32_t rccl_device;             /* ncclCommCuDevice */
+    int32_t rccl_version;            /* ncclGetVersion: e.g. 22707 */
+    int32_t hip_runtime_version;     /* hipRuntimeGetVersion */
+    int32_t rows_per_block;          /* tile rows per shard block in use (rank 0's, broadcast at shm_dist_init) */
+    uint32_t n_my_tiles;             /* tiles this rank owns */
+    char librccl_path[256];          /* dladdr of ncclGetVersion */
+    char libamdhip_path[256];        /* dladdr of hipRuntimeGetVersion */
+} ShmDistInfo;
+SHM_API int shm_dist_info(ShmScene* scene, ShmDistInfo* out);
+SHM_API int shm_device_synchronize(int32_t device);   /* hipDeviceSynchronize on that ordinal */
 /* Test entry: sends this rank's film rows to ITSELF through the same RCCL send / recv group into a scratch film and compares
  * (exercises the RCCL transport on a one-GPU box). SHM_OK when every byte matches. */
 SHM_API int shm_dist_selftest(ShmScene* scene);

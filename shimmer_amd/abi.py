@@ -207,6 +207,17 @@ class ShmLoadedImage(C.Structure):
                 ("n_texel_floats", C.c_uint64), ("levels", C.POINTER(ShmImageLevel)), ("texels", c_float_p)]
 
 
+class ShmDistInfo(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("rccl_ranks", C.c_int32), ("rccl_device", C.c_int32), ("rccl_version", C.c_int32),
+                ("hip_runtime_version", C.c_int32), ("rows_per_block", C.c_int32), ("n_my_tiles", C.c_uint32), ("librccl_path", C.c_char * 256),
+                ("libamdhip_path", C.c_char * 256)]
+
+    def as_dict(self):
+        return {n: (getattr(self, n).decode() if n.endswith("_path") else getattr(self, n)) for n, _ in self._fields_}
+
+
+SHM_REDUCE_SUM, SHM_REDUCE_MAX, SHM_REDUCE_MIN = 0, 1, 2
+
 # Every symbol include/shimmer_hip.h declares, with its signature (tests check the .so exports all of them).
 EXPORTS = {
     "shm_scene_create": (C.c_int, [C.POINTER(ShmSceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
@@ -240,6 +251,11 @@ EXPORTS = {
     "shm_dist_finalize": (C.c_int, [C.c_void_p]),
     "shm_render_sharded": (C.c_int, [C.c_void_p, C.POINTER(ShmRenderParams), C.POINTER(ShmStats)]),
     "shm_dist_selftest": (C.c_int, [C.c_void_p]),
+    "shm_dist_barrier": (C.c_int, [C.c_void_p]),
+    "shm_dist_allreduce_f64": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_uint32, C.c_int32]),
+    "shm_dist_allgather_f64": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_double)]),
+    "shm_dist_info": (C.c_int, [C.c_void_p, C.POINTER(ShmDistInfo)]),
+    "shm_device_synchronize": (C.c_int, [C.c_int32]),
     "shm_scene_load_pbrt": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(ShmPbrtScene))]),
     "shm_scene_parse_pbrt": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.POINTER(ShmPbrtScene))]),
     "shm_pbrt_free": (None, [C.POINTER(ShmPbrtScene)]),

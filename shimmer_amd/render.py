@@ -1,8 +1,8 @@
 """Python mirror of the reference's render driver for the GPU path (src/render.rs:8-55 ->
 ImageTileIntegrator::render, src/integrator.rs:226-322): spp-wave schedule over 8x8 tiles, film read-back,
 RgbFilm::get_pixel_rgb (film.rs:720-738).  Multi-GPU: tiles are sharded across ranks (one process per GPU,
-no data-path collective while rendering); the per-rank film slabs are gathered with RCCL through
-torch.distributed (plumbing only — all arithmetic happens inside libshimmer_hip.so).
+no data-path collective while rendering) and the film rows are gathered by RCCL INSIDE libshimmer_hip.so (shm_render_sharded);
+the small collectives a host needs around it (barrier, reductions) are the library's too (Renderer.dist_*): no torch.
 """
 import ctypes as C
 import os
@@ -127,6 +127,29 @@ class Renderer:
         stats = abi.ShmStats()
         abi.check(self.lib, self.lib.shm_render_sharded(self.handle, C.byref(params), C.byref(stats)), "shm_render_sharded")
         return stats.as_dict()
+
+    def dist_barrier(self):
+        abi.check(self.lib, self.lib.shm_dist_barrier(self.handle), "shm_dist_barrier")
+
+    def dist_allreduce(self, values, op=abi.SHM_REDUCE_SUM):
+        """All-reduce of a short list of host doubles over the scene's communicator (identity without one)."""
+        buf = (C.c_double * len(values))(*[float(v) for v in values])
+        abi.check(self.lib, self.lib.shm_dist_allreduce_f64(self.handle, buf, len(values), op), "shm_dist_allreduce_f64")
+        return list(buf)
+
+    def dist_allgather(self, values):
+        """Every rank's short list of host doubles, rank-major: [[rank 0's], [rank 1's], ...]."""
+        info = self.dist_info()
+        n, world = len(values), max(1, info["world"])
+        mine = (C.c_double * n)(*[float(v) for v in values])
+        out = (C.c_double * (n * world))()
+        abi.check(self.lib, self.lib.shm_dist_allgather_f64(self.handle, mine, n, out), "shm_dist_allgather_f64")
+        return [list(out[i * n:(i + 1) * n]) for i in range(world)]
+
+    def dist_info(self):
+        info = abi.ShmDistInfo()
+        abi.check(self.lib, self.lib.shm_dist_info(self.handle, C.byref(info)), "shm_dist_info")
+        return info.as_dict()
 
     def dist_selftest(self):
         abi.check(self.lib, self.lib.shm_dist_selftest(self.handle), "shm_dist_selftest")

@@ -77,6 +77,54 @@ def test_dist_world1_rccl_render_and_loopback(gpu_lib, small_s3):
     r.close()
 
 
+def test_dist_small_collectives_world1(gpu_lib, small_s3):
+    """The collectives a host needs around shm_render_sharded (barrier, reductions, gather of per-rank figures) are the library's own:
+    with a communicator of one rank they go through ncclAllReduce / ncclAllGather and must be the identity; without one they are too."""
+    sc, p, _, _ = small_s3
+    r = render.Renderer(gpu_lib, sc.desc, device=0)
+    for with_comm in (False, True):
+        if with_comm:
+            r.dist_init(0, 1, r.dist_unique_id())
+        r.dist_barrier()
+        assert r.dist_allreduce([1.5, -2.0, 3e300], abi.SHM_REDUCE_MAX) == [1.5, -2.0, 3e300]
+        assert r.dist_allreduce([0.1, 7.0], abi.SHM_REDUCE_SUM) == [0.1, 7.0]
+        assert r.dist_allreduce([4.0], abi.SHM_REDUCE_MIN) == [4.0]
+        assert r.dist_allgather([1.0, 2.0, 3.0]) == [[1.0, 2.0, 3.0]]
+        info = r.dist_info()
+        assert info["world"] == 1 and info["rank"] == 0
+        assert info["rccl_ranks"] == (1 if with_comm else 0)
+        assert info["rccl_version"] >= 20000 and "librccl" in info["librccl_path"] and "libamdhip64" in info["libamdhip_path"]
+        if with_comm:
+            assert info["rccl_device"] == 0 and info["n_my_tiles"] == r.n_tiles and info["rows_per_block"] >= 1
+    with pytest.raises(abi.ShimmerHipError):
+        r.dist_allreduce([0.0] * 5000)  # more than the control scratch holds: reported
+    r.close()
+    abi.check(gpu_lib, gpu_lib.shm_device_synchronize(0), "shm_device_synchronize")
+    assert gpu_lib.shm_device_synchronize(99) != 0
+
+
+def test_bench_self_launcher_world1_one_runtime_stack(gpu_lib):
+    """`python bench.py --gpus 1 --launch --force-dist`: the parent starts ONE fresh rank process (no torch.distributed.run), which runs the
+    whole N > 1 code path — id through the file store, shm_dist_init, barrier / max clock / counters through the library's RCCL
+    collectives, shm_render_sharded, loop-back self test — on the HIP runtime and the RCCL the library is linked against, without torch."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SHM_STORE_DIR")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--launch", "--force-dist", "--res", "128", "--spp", "8", "--n", "24", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-side"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    rt = out["runtime"]
+    assert rt["launcher"] == "shimmer_amd.launch" and rt["torch_imported"] is False
+    assert rt["rccl_ranks"] == 1 and rt["librccl"].startswith("/opt/rocm") and rt["libamdhip64"].startswith("/opt/rocm")
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["nonfinite_pixels"] == 0
+    assert len(out["per_rank"]) == 1 and out["per_rank"][0]["tiles"] == 16 * 16 and out["per_rank"][0]["gather_MB"] == 0.0
+    assert "self-launch: 1 rank process" in r.stderr.decode() and "librccl /opt/rocm" in r.stderr.decode()
+
+
 def test_render_sharded_without_communicator_is_the_whole_frame(gpu_lib, small_s3):
     sc, p, film, _ = small_s3
     r = render.Renderer(gpu_lib, sc.desc, device=0)
