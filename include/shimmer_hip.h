@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SHM_ABI_VERSION 7
+#define SHM_ABI_VERSION 8
 
 /* The library is built with -fvisibility=hidden; only these entry points are exported. */
 #if defined(__GNUC__)
@@ -397,6 +397,15 @@ typedef struct ShmRenderParams {
     uint8_t sample_lights;        /* SimplePath "samplelights" (default true in the reference, integrator.rs:135-137) */
     uint8_t sample_bsdf;          /* SimplePath "samplebsdf"   (default true) */
     uint8_t disable_texture_filtering; /* options.disable_texture_filtering: compute_differentials leaves zeros (interaction.rs:287-295) */
+    /* ABI v8 — SHM_REFERENCE_QUIRKS. 0 (the default) = reference-exact: every deviation of the reference from PBRT-v4 that SURVEY 7
+     * lists is reproduced, and every parity test runs this way. 1 = the PBRT-v4 behaviour at the sites where the reference's produces invalid or
+     * biased values: LayeredBxDF::pdf tests the reflected sample (`rs.f != 0 && rs.pdf > 0`, bxdf.rs:1491-1506 omits it: 0/0 -> NaN film
+     * pixels in coated scenes); a radiance sample with a NaN or an infinite component is dropped before RgbFilm::add_sample (the two TODOs of
+     * integrator.rs:377-382); safe_acos is acos (math.rs:272-274 calls asin): Sphere (u, v) and SphericalMapping (which then also uses phi
+     * for t, texture.rs:972); uniform_hemisphere_pdf = 1/(2 pi) (sampling.rs:306-308 returns 1/(4 pi)); Sphere::pdf_with_context uses
+     * 2 pi and multiplies by the squared distance inside the sphere (sphere.rs:438-440, 456). */
+    uint8_t disable_reference_quirks;
+    uint8_t pad[7];
 } ShmRenderParams;
 enum {
     SHM_INTEGRATOR_PATH = 0,        /* PathIntegrator,       integrator.rs:748-963 */

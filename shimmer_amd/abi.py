@@ -10,7 +10,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 LIB_PATH = ROOT / "csrc" / "libshimmer_hip.so"
 
-SHM_ABI_VERSION = 7
+SHM_ABI_VERSION = 8
 SHM_OK = 0
 SHM_DIST_ID_BYTES = 128
 SHM_SHAPE_TRIANGLE, SHM_SHAPE_SPHERE, SHM_SHAPE_BILINEAR_PATCH, SHM_SHAPE_INSTANCE = 0, 1, 2, 3
@@ -159,7 +159,8 @@ class ShmSceneDesc(C.Structure):
 class ShmRenderParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32), ("regularize", C.c_uint8),
                 ("disable_pixel_jitter", C.c_uint8), ("disable_wavelength_jitter", C.c_uint8), ("force_diffuse", C.c_uint8),
-                ("integrator", C.c_uint8), ("sample_lights", C.c_uint8), ("sample_bsdf", C.c_uint8), ("disable_texture_filtering", C.c_uint8)]
+                ("integrator", C.c_uint8), ("sample_lights", C.c_uint8), ("sample_bsdf", C.c_uint8), ("disable_texture_filtering", C.c_uint8),
+                ("disable_reference_quirks", C.c_uint8), ("pad", C.c_uint8 * 7)]
 
 
 class ShmTile(C.Structure):

@@ -62,6 +62,7 @@ struct FlatScene {
 
     shm::SceneView view() const {
         shm::SceneView v;
+        v.quirks_off = 0;
         v.nodes = nodes.data();
         v.n_nodes = (uint32_t)nodes.size();
         v.prim_recs = prim_recs.data();

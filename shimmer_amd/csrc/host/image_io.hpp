@@ -36,7 +36,10 @@ public:
         const unsigned cmf = p_[0], flg = p_[1];
         if ((cmf & 15u) != 8u || ((cmf << 8) | flg) % 31u != 0u || (flg & 32u)) fail("PNG: not a zlib/deflate stream");
         pos_ = 2;
-        out_.reserve(size_hint);
+        // size_hint comes from an unchecked IHDR: it bounds the output (a PNG's inflated size is exactly (stride + 1) * height) but is
+        // not trusted as an allocation size — DEFLATE expands at most 1032 : 1, so a few hundred bytes cannot reserve gigabytes
+        limit_ = size_hint;
+        out_.reserve(std::min(size_hint, n_ > ((size_t)-1) / 1032 ? size_hint : n_ * 1032));
         bool last = false;
         while (!last) {
             last = bits(1) != 0;
@@ -67,6 +70,7 @@ private:
     uint32_t acc_ = 0;
     int nbits_ = 0;
     std::vector<uint8_t> out_;
+    size_t limit_ = (size_t)-1;  // the raw size the header implies: more output than that is a malformed file
     Huff lit_, dist_;
 
     unsigned bits(int need) {
@@ -111,6 +115,7 @@ private:
         pos_ += 4;
         if ((len ^ 0xffffu) != nlen) fail("PNG: stored block length mismatch");
         if (pos_ + len > n_) fail("PNG: truncated stored block");
+        if (out_.size() + len > limit_) fail("PNG: image data longer than the header's dimensions imply");
         out_.insert(out_.end(), p_ + pos_, p_ + pos_ + len);
         pos_ += len;
     }
@@ -160,7 +165,7 @@ private:
         static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
         for (;;) {
             int sym = decode(lit_);
-            if (sym < 256) out_.push_back((uint8_t)sym);
+            if (sym < 256) { if (out_.size() >= limit_) fail("PNG: image data longer than the header's dimensions imply"); out_.push_back((uint8_t)sym); }
             else if (sym == 256) return;
             else {
                 sym -= 257;
@@ -170,6 +175,7 @@ private:
                 if (ds >= 30) fail("PNG: invalid distance code");
                 const size_t dist = dbase[ds] + bits(dext[ds]);
                 if (dist > out_.size()) fail("PNG: distance beyond the start of the output");
+                if (out_.size() + len > limit_) fail("PNG: image data longer than the header's dimensions imply");
                 size_t from = out_.size() - dist;
                 for (size_t k = 0; k < len; ++k) out_.push_back(out_[from + k]);
             }

@@ -18,8 +18,10 @@
 // rendered as something else. Host-side only.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <set>
 #include <sstream>
@@ -203,17 +205,19 @@ public:
 
     void parse(const std::string& text, const std::string& name) {
         Tokenizer tk(text, name);
+        include_chain_.push_back(name);  // (an exception leaves the chain as it is: the loader object is discarded with it)
         for (;;) {
             const Token t = tk.next();
             if (t.kind == Token::END) break;
             if (t.kind != Token::WORD) fail(tk.where(t.line) + ": expected a directive");
             directive(t, tk);
         }
+        include_chain_.pop_back();
     }
     std::unique_ptr<Assembly::Built> finish() {
         if (!world_) fail("the scene description has no WorldBegin");
-        if (!stack_.empty()) fail("unmatched AttributeBegin");
-        if (object_ != 0) fail("unmatched ObjectBegin");
+        if (object_ != 0) fail("unmatched ObjectBegin" + (push_stack_.empty() ? std::string() : " from " + push_stack_.back().where));
+        if (!stack_.empty()) fail("Missing end to AttributeBegin from " + push_stack_.back().where);  // scene.rs:2013-2017
         return Assembly::build(std::move(a_));
     }
 
@@ -222,6 +226,11 @@ private:
     std::unique_ptr<Assembly> a_;
     GraphicsState gs_;
     std::vector<GraphicsState> stack_;
+    // what pushed each entry of stack_ and where (scene.rs:1190-1192 `push_stack: Vec<(u8, FileLoc)>`, 'a' attribute / 'o' object):
+    // AttributeEnd and ObjectEnd must find their own kind on top (scene.rs:1693-1712, 1929-1962)
+    struct Pushed { char kind; std::string where; };
+    std::vector<Pushed> push_stack_;
+    std::vector<std::string> include_chain_;  // files being parsed right now (Include recursion: cycles and runaway depth are errors, not a native stack overflow)
     std::map<std::string, Xf> coordinate_systems_;
     std::map<std::string, int> named_materials_;
     std::map<std::string, uint32_t> float_texture_names_;
@@ -980,11 +989,13 @@ private:
             if (ps.one_string("lightsampler", "uniform") != "uniform") fail(tk.where(t.line) + ": only the uniform light sampler exists on this path", SHM_ERR_UNSUPPORTED);
         } else if (d == "Accelerator") { read_string(tk, t); parse_params(tk); }  // the BVH of aggregate.rs is the only accelerator
         else if (d == "WorldBegin") { need_world(t, tk, false); world_begin(tk, t.line); }
-        else if (d == "AttributeBegin") { need_world(t, tk, true); stack_.push_back(gs_); }
-        else if (d == "AttributeEnd") {
-            if (stack_.empty()) fail(tk.where(t.line) + ": Unmatched attribute_end statement.");
+        else if (d == "AttributeBegin") { need_world(t, tk, true); stack_.push_back(gs_); push_stack_.push_back(Pushed{'a', tk.where(t.line)}); }
+        else if (d == "AttributeEnd") {  // scene.rs:1693-1712
+            if (push_stack_.empty() || stack_.empty()) fail(tk.where(t.line) + ": Unmatched attribute_end statement.");
+            if (push_stack_.back().kind == 'o') fail(tk.where(t.line) + ": Mismatched nesting: open ObjectBegin from " + push_stack_.back().where + " at attribute_end.");
             gs_ = stack_.back();
             stack_.pop_back();
+            push_stack_.pop_back();
         } else if (d == "Attribute") {  // scene.rs:1714-1730: default parameters for what follows of that kind, within the attribute scope
             const std::string target = read_string(tk, t);
             const Params ps = parse_params(tk);
@@ -1036,12 +1047,16 @@ private:
             if (object_ != 0) fail(tk.where(t.line) + ": ObjectBegin called inside of instance definition");
             if (a_->objects.count(name)) fail(tk.where(t.line) + ": " + name + ": trying to redefine an object instance");
             stack_.push_back(gs_);
+            push_stack_.push_back(Pushed{'o', tk.where(t.line)});
             a_->objects[name] = (uint32_t)a_->objects.size() + 1;
             object_ = a_->objects[name];
         } else if (d == "ObjectEnd") {
             if (object_ == 0) fail(tk.where(t.line) + ": ObjectEnd called outside of instance definition");
+            if (push_stack_.empty() || stack_.empty()) fail(tk.where(t.line) + ": Unmatched ObjectEnd statement.");  // scene.rs:1947-1950
+            if (push_stack_.back().kind == 'a') fail(tk.where(t.line) + ": Mismatched nesting: open AttributeBegin from " + push_stack_.back().where + " at ObjectEnd.");
             gs_ = stack_.back();
             stack_.pop_back();
+            push_stack_.pop_back();
             object_ = 0;
         } else if (d == "ObjectInstance") {
             need_world(t, tk, true);
@@ -1057,6 +1072,10 @@ private:
             a_->prims.push_back(pr);
         } else if (d == "Include") {
             const std::string fn = resolve(read_string(tk, t));
+            // the reference recurses without a limit (parser.rs:191-197); a file that includes itself would overflow the native stack here,
+            // which the try / catch at the ABI boundary cannot turn into an error code
+            if (std::find(include_chain_.begin(), include_chain_.end(), fn) != include_chain_.end()) fail(tk.where(t.line) + ": Include cycle: " + fn + " is already being parsed");
+            if (include_chain_.size() >= 64) fail(tk.where(t.line) + ": Include nesting deeper than 64 files");
             std::ifstream in(fn);
             if (!in) fail(tk.where(t.line) + ": unable to read included file " + fn);
             std::stringstream ss;
@@ -1094,6 +1113,8 @@ static int load_text(const std::string& text, const std::string& name, const std
         p.disable_texture_filtering = st.disable_texture_filtering;
         p.sample_lights = st.sample_lights;
         p.sample_bsdf = st.sample_bsdf;
+        // SHM_REFERENCE_QUIRKS (include/shimmer_hip.h ShmRenderParams::disable_reference_quirks): ON unless the host's environment says 0 / off
+        if (const char* q = getenv("SHM_REFERENCE_QUIRKS")) p.disable_reference_quirks = (!strcmp(q, "0") || !strcmp(q, "off") || !strcmp(q, "OFF")) ? 1 : 0;
         p.integrator = st.integrator == "path" ? SHM_INTEGRATOR_PATH : (st.integrator == "simplepath" ? SHM_INTEGRATOR_SIMPLE_PATH : SHM_INTEGRATOR_RANDOM_WALK);
         snprintf(scene->integrator, sizeof(scene->integrator), "%s", st.integrator.c_str());
         snprintf(scene->output_filename, sizeof(scene->output_filename), "%s", st.filename.c_str());

@@ -32,6 +32,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                 b.kind = meta & 0xffu;
                 b.max_depth = (int)((meta >> 8) & 0xfffu);
                 b.n_samples = (int)(meta >> 20);
+                b.strict = (int)sv.quirks_off;
                 b.eta = p2.x;
                 b.mf.alpha_x = p2.y;
                 b.mf.alpha_y = p2.z;

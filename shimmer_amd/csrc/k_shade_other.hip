@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(Scen
                             pdf = uniform_sphere_pdf();
                         } else {
                             wi_next = sample_uniform_hemisphere(sampler_get_2d(rng));
-                            pdf = uniform_hemisphere_pdf();
+                            pdf = uniform_hemisphere_pdf(sv.quirks_off != 0);
                             if ((flags_is_reflective(flags) && dot(wo, si.n) * dot(wi_next, si.n) < 0.0f) ||
                                 (flags_is_transmissive(flags) && dot(wo, si.n) * dot(wi_next, si.n) > 0.0f))
                                 wi_next = -wi_next;

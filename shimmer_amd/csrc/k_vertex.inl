@@ -127,7 +127,7 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
                     pa.bx0[path] = st_spec(b.r);
                     if (pa.bx1) pa.bx1[path] = st_spec(b.k);
                     pa.bx2[path] = make_float4(b.eta, b.mf.alpha_x, b.mf.alpha_y,
-                                               __uint_as_float(b.kind | ((uint32_t)b.max_depth << 8) | ((uint32_t)b.n_samples << 20)));
+                                               __uint_as_float(b.kind | ((uint32_t)b.max_depth << 8) | ((uint32_t)b.n_samples << 20)));  // (b.strict is sv.quirks_off: not carried)
                     if (pa.bx3) {
                         pa.bx3[path] = st_spec(b.albedo);
                         pa.bx4[path] = make_float4(b.mf2.alpha_x, b.mf2.alpha_y, b.thickness, b.g);

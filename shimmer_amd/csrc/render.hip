@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_film(SceneView sv, PathArrays p
     for (int s = 0; s < n_samples; ++s) {
         uint32_t slot = slot_of(p_local, (uint32_t)s, n_pix, (uint32_t)n_samples, pix_group);
         Spec L = ld_spec(pa.L[slot]);
+        if (sv.quirks_off && !spec_is_finite(L)) L = spec_const(0.0f);  // integrator.rs:377-382's TODOs, done only with the quirks switched off
         Wavelengths lambda;
         float4 a = pa.lambda[slot], c = pa.lambda_pdf[slot];
         lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
@@ -196,9 +197,10 @@ static uint64_t staging_bytes_per_path(const ShmScene* s) {
     for (int c = 0; c < N_BXDF_CLASSES; ++c) if (f.has_class[c]) b += 4;       // class queues
     return b;
 }
-static uint64_t workspace_cap(const ShmScene* s) {
-    // path state + three queues (+ auxiliary rays) (+ the staging arrays of every scene class but the lean one)
-    const uint64_t BYTES_PER_PATH = 264 + 3 * 4 + (s->flat.has_textures ? 48 : 0) + ((s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
+static uint64_t workspace_cap(const ShmScene* s, bool need_staged) {
+    // path state + three queues (+ auxiliary rays) (+ the staging arrays whenever the upcoming render is staged: every scene class but the
+    // lean one, and the lean one too under options.force_diffuse — the budget must count them BEFORE the first staged allocation)
+    const uint64_t BYTES_PER_PATH = 264 + 3 * 4 + (s->flat.has_textures ? 48 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
     uint64_t cap = max_batch_paths();
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -210,7 +212,7 @@ static uint64_t workspace_cap(const ShmScene* s) {
 }
 
 int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
-    uint64_t max_cap = workspace_cap(s);
+    uint64_t max_cap = workspace_cap(s, need_staged);
     uint64_t want = std::min<uint64_t>(std::max<uint64_t>(needed_paths, 4096), max_cap);
     // a large request takes the whole budget at once: freeing and re-allocating ~140 GB because the next call needs a few percent more
     // paths costs seconds (measured: 3.7 s per regrow at 500 M paths)
@@ -463,6 +465,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     hipLaunchKernelGGL(k_expand_tiles, dim3((n_tiles + 255) / 256), dim3(256), 0, s->stream, s->d_tiles, s->d_tile_offset, n_tiles, s->d_pixels);
 
     const int n_samples = sample_end - sample_begin;
+    s->dsv.quirks_off = params->disable_reference_quirks ? 1u : 0u;  // SHM_REFERENCE_QUIRKS: every kernel of this render takes s->dsv by value
     const bool random_walk = params->integrator == SHM_INTEGRATOR_RANDOM_WALK;
     // (the random walk keeps 32 B per depth per path beside the path state: its batches are capped at 16 Mi paths)
     const bool staged = use_staged(s, params);
@@ -624,7 +627,7 @@ int shm_render_device(ShmScene* s, const ShmRenderParams* params, const ShmTile*
     for (uint32_t t = 0; tiles && t < n_tiles; ++t)
         n_pixels += (uint64_t)std::max(0, tiles[t].x1 - tiles[t].x0) * (uint64_t)std::max(0, tiles[t].y1 - tiles[t].y0);
     HIP_TRY(hipSetDevice(s->device));
-    const int max_fuse = (int)std::min<uint64_t>(std::max<uint64_t>(64, n_pixels ? workspace_cap(s) / n_pixels : 64), 1u << 20);
+    const int max_fuse = (int)std::min<uint64_t>(std::max<uint64_t>(64, n_pixels ? workspace_cap(s, use_staged(s, params)) / n_pixels : 64), 1u << 20);
     int wave_start = 0, wave_end = 1, next_wave_size = 1;
     int pend_begin = 0, pend_end = 0;
     while (wave_start < spp) {

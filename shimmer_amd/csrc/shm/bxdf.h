@@ -228,6 +228,7 @@ struct BxDF : BaseBxDF {
     Float thickness, g;
     Spec albedo;
     int max_depth, n_samples;
+    int strict;  // ShmRenderParams::disable_reference_quirks: LayeredBxDF::pdf tests its reflected sample as PBRT-v4 does (0 = as the reference)
 };
 enum : int { MODE_RADIANCE = 0, MODE_IMPORTANCE = 1 };  // TransportMode
 
@@ -718,7 +719,9 @@ SHM_HD Float layered_pdf(const BxDF& l, V3 wo, V3 wi, int mode) {
                     uc = layered_r(rng);
                     u = layered_r2(rng);
                     BSDFSample rs;
-                    if (base_sample_f(r_i, -wos.wi, uc, u, REFLTRANS_ALL, rs, mode)) {
+                    // bxdf.rs:1491-1506 uses `rs` as soon as it exists; PBRT-v4 also requires rs.f != 0 && rs.pdf > 0 — without that a
+                    // cosine sample exactly on the horizon (rs.pdf = 0, then t_pdf = 0) makes power_heuristic 0 / 0
+                    if (base_sample_f(r_i, -wos.wi, uc, u, REFLTRANS_ALL, rs, mode) && (!l.strict || (!is_zero(rs.f) && rs.pdf > 0.0f))) {
                         if (!flags_is_non_specular(r_flags)) {
                             pdf_sum += base_pdf(t_i, -rs.wi, wi, REFLTRANS_ALL);
                         } else {

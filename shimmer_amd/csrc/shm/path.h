@@ -83,7 +83,7 @@ SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const Li
         V3 wi = sample_uniform_sphere(u);
         out.l = light.scale * spectrum_sample(light.spectrum, sv.spectrum_data, lambda);
         out.wi = wi;
-        out.pdf = uniform_hemisphere_pdf();
+        out.pdf = uniform_hemisphere_pdf(sv.quirks_off != 0);
         out.p_light_pi = p3i_exact(ctx.p() + wi * (2.0f * sv.scene_radius));
         out.p_light_n = v3s(0.0f);
         return true;
@@ -120,7 +120,7 @@ SHM_HD Float light_pdf_li(const SceneView& sv, const ShmLight& light, const Ligh
     ShapeSampleContext sctx;
     sctx.pi = ctx.pi; sctx.n = ctx.n; sctx.ns = ctx.ns;
     const PrimRec& pr = sv.prim_recs[light.primitive];
-    if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) return sphere_pdf_with_context(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], sctx, wi);
+    if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) return sphere_pdf_with_context(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], sctx, wi, sv.quirks_off != 0);
     if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) return blp_pdf_with_context(load_patch(sv, light.primitive), sctx, wi);
     return triangle_pdf_with_context(load_triangle(sv, light.primitive), sctx, wi);
 }
@@ -206,6 +206,7 @@ SHM_HD BSDF get_bsdf(const SceneView& sv, SurfaceInteraction& si, const ShmMater
     b.albedo = spec_const(0.0f);
     b.max_depth = 0;
     b.n_samples = 1;
+    b.strict = (int)sv.quirks_off;
     if (m.kind == SHM_MATERIAL_DIFFUSE) {
         b.r = clamp(tex(m.a), 0.0f, 1.0f);  // material.rs:301-311
     } else if (m.kind == SHM_MATERIAL_CONDUCTOR) {  // material.rs:456-499

@@ -151,7 +151,7 @@ SHM_HD V3 sample_uniform_hemisphere(V2 u) {
     return v3(r * cos(phi), r * sin(phi), z);
 }
 SHM_HD Float uniform_sphere_pdf() { return INV_4PI; }
-SHM_HD Float uniform_hemisphere_pdf() { return INV_4PI; }  // sampling.rs:306-308 (quirk 2)
+SHM_HD Float uniform_hemisphere_pdf(bool strict = false) { return strict ? INV_2PI : INV_4PI; }  // sampling.rs:306-308 (quirk 2: 1/(4 pi) there)
 // sampling.rs:324-339
 SHM_HD V2 sample_uniform_disk_concentric(V2 u) {
     V2 uo = 2.0f * u - v2(1.0f, 1.0f);

@@ -93,6 +93,7 @@ struct SceneView {
     // image infinite lights: per light its transform + image + the two PiecewiseConstant2D distributions, flattened into dist_data
     const struct ImageLightRec* image_lights;
     const Float* dist_data;
+    uint32_t quirks_off;  // ShmRenderParams::disable_reference_quirks of the render in flight (0 = reference-exact; set per render call)
 };
 
 // A FloatTexture tree flattened at scene creation into a post-order program: evaluating the ops in order (each into slot k of a
@@ -234,7 +235,7 @@ SHM_HD SurfaceInteraction hit_interaction_local(const SceneView& sv, const Hit& 
         qi.t_hit = h.t;
         qi.p_obj = v3(h.b0, h.b1, h.b2);
         qi.phi = h.phi;
-        return sphere_interaction(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], qi, wo);
+        return sphere_interaction(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], qi, wo, sv.quirks_off != 0);
     }
     if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) return blp_interaction(load_patch(sv, (uint32_t)h.prim), h.b0, h.b1, wo);
     TriangleData tr = load_triangle(sv, (uint32_t)h.prim);

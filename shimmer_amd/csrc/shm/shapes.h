@@ -481,12 +481,12 @@ SHM_HD bool sphere_basic_intersect(const ShmSphere& s, V3 ro, V3 rd, Float t_max
 }
 
 // shape/sphere.rs:198-271
-SHM_HD SurfaceInteraction sphere_interaction(const ShmSphere& s, const QuadricIntersection& isect, V3 wo) {
+SHM_HD SurfaceInteraction sphere_interaction(const ShmSphere& s, const QuadricIntersection& isect, V3 wo, bool strict = false) {
     V3 p_hit = isect.p_obj;
     Float phi = isect.phi;
     Float u = phi / s.phi_max;
     Float cos_theta_ = p_hit.z / s.radius;
-    Float theta = safe_acos(cos_theta_);
+    Float theta = strict ? acos(clamp(cos_theta_, -1.0f, 1.0f)) : safe_acos(cos_theta_);  // (quirk 5: safe_acos is asin in the reference)
     Float v = (theta - s.theta_z_min) / (s.theta_z_max - s.theta_z_min);
     Float z_radius = sqrt(p_hit.x * p_hit.x + p_hit.y * p_hit.y);
     Float cos_phi_ = p_hit.x / z_radius;
@@ -679,7 +679,7 @@ SHM_HD bool sphere_sample_with_context(const ShmSphere& s, const ShapeSampleCont
     return true;
 }
 // sphere.rs:424-457 (quirk 1: 2.90 and the double division are the reference's)
-SHM_HD Float sphere_pdf_with_context(const ShmSphere& s, const ShapeSampleContext& ctx, V3 wi) {
+SHM_HD Float sphere_pdf_with_context(const ShmSphere& s, const ShapeSampleContext& ctx, V3 wi, bool strict = false) {
     V3 p_center = xf_point(s.render_from_object, v3s(0.0f));
     V3 p_origin = offset_ray_origin(ctx.pi, ctx.n, p_center - ctx.p());
     if (distance_squared(p_origin, p_center) <= s.radius * s.radius) {
@@ -687,7 +687,8 @@ SHM_HD Float sphere_pdf_with_context(const ShmSphere& s, const ShapeSampleContex
         QuadricIntersection qi;
         if (!sphere_basic_intersect(s, o, wi, infinity(), qi)) return 0.0f;
         SurfaceInteraction isect = sphere_interaction(s, qi, -wi);
-        Float pdf = (1.0f / sphere_area(s)) / abs_dot(isect.n, -wi) / distance_squared(ctx.p(), isect.p());
+        Float pdf = strict ? (1.0f / sphere_area(s)) / (abs_dot(isect.n, -wi) / distance_squared(ctx.p(), isect.p()))
+                           : (1.0f / sphere_area(s)) / abs_dot(isect.n, -wi) / distance_squared(ctx.p(), isect.p());
         if (is_inf(pdf)) return 0.0f;
         return pdf;
     }
@@ -695,7 +696,7 @@ SHM_HD Float sphere_pdf_with_context(const ShmSphere& s, const ShapeSampleContex
     Float cos_theta_max = safe_sqrt(1.0f - sin2_theta_max);
     Float one_minus_cos_theta_max = 1.0f - cos_theta_max;
     if (sin2_theta_max < 0.00068523f) one_minus_cos_theta_max = sin2_theta_max / 2.0f;
-    return 1.0f / (2.90f * PI_F * one_minus_cos_theta_max);
+    return 1.0f / ((strict ? 2.0f : 2.90f) * PI_F * one_minus_cos_theta_max);
 }
 
 }  // namespace shm

@@ -24,6 +24,7 @@ struct Spec {
     SHM_HD Float operator[](int i) const { return v[i]; }
 };
 SHM_HD Spec spec_const(Float c) { Spec s; for (int i = 0; i < NSPEC; ++i) s.v[i] = c; return s; }
+SHM_HD bool spec_is_finite(const Spec& s) { return is_finite(s.v[0]) && is_finite(s.v[1]) && is_finite(s.v[2]) && is_finite(s.v[3]); }
 SHM_HD bool is_zero(const Spec& s) {
     for (int i = 0; i < NSPEC; ++i) if (s.v[i] != 0.0f) return false;
     return true;

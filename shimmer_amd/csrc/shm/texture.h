@@ -193,7 +193,7 @@ struct TexCoord2D {  // texture.rs:1048-1054
 };
 SHM_HD Float spherical_theta(V3 v) { return safe_acos(v.z); }  // vecmath/spherical.rs:16-18
 
-SHM_HD TexCoord2D texture_map(const ShmImageTexture& t, const TextureEvalContext& ctx) {
+SHM_HD TexCoord2D texture_map(const ShmImageTexture& t, const TextureEvalContext& ctx, bool strict = false) {
     TexCoord2D c;
     if (t.mapping == SHM_TEXMAP_UV) {  // texture.rs:918-935
         c.dsdx = t.su * ctx.dudx;
@@ -216,7 +216,10 @@ SHM_HD TexCoord2D texture_map(const ShmImageTexture& t, const TextureEvalContext
         c.dtdx = dot(dtdp, dpdx);
         c.dtdy = dot(dtdp, dpdy);
         V3 vec = normalize(pt - v3s(0.0f));
-        c.st = v2(spherical_theta(vec) * INV_PI, spherical_theta(vec) * INV_2PI);
+        if (strict) {  // PBRT-v4's SphericalMapping: (theta / pi, phi / 2 pi) with a real acos
+            Float phi = atan2(vec.y, vec.x);
+            c.st = v2(acos(clamp(vec.z, -1.0f, 1.0f)) * INV_PI, (phi < 0.0f ? phi + 2.0f * PI_F : phi) * INV_2PI);
+        } else c.st = v2(spherical_theta(vec) * INV_PI, spherical_theta(vec) * INV_2PI);
         return c;
     }
     if (t.mapping == SHM_TEXMAP_CYLINDRICAL) {  // texture.rs:983-1009
@@ -446,7 +449,7 @@ SHM_HD TextureView texture_view(const SceneView& sv, uint32_t texture_index) {
 // FloatImageTexture::evaluate, texture.rs:393-403
 SHM_HD_NOINLINE Float float_image_texture_evaluate(const SceneView& sv, uint32_t texture_index, const TextureEvalContext& ctx) {
     TextureView tv = texture_view(sv, texture_index);
-    TexCoord2D c = texture_map(*tv.t, ctx);
+    TexCoord2D c = texture_map(*tv.t, ctx, sv.quirks_off != 0);
     c.st.y = 1.0f - c.st.y;
     Float v = tex_filter<Float>(tv, sv.ewa_lut, c.st, v2(c.dsdx, c.dtdx), v2(c.dsdy, c.dtdy)) * tv.t->scale;
     return tv.t->invert ? max(0.0f, 1.0f - v) : v;
@@ -533,7 +536,7 @@ SHM_HD_NOINLINE Spec image_texture_evaluate(const SceneView& sv, uint32_t textur
     tv.t = &sv.image_textures[texture_index];
     tv.levels = sv.image_levels + tv.t->first_level;
     tv.texels = sv.texel_data;
-    TexCoord2D c = texture_map(*tv.t, ctx);
+    TexCoord2D c = texture_map(*tv.t, ctx, sv.quirks_off != 0);
     c.st.y = 1.0f - c.st.y;
     RGB3 rgb = tex_filter<RGB3>(tv, sv.ewa_lut, c.st, v2(c.dsdx, c.dtdx), v2(c.dsdy, c.dtdy)) * tv.t->scale;
     if (tv.t->invert) rgb = rgb3(1.0f, 1.0f, 1.0f) - rgb;

@@ -26,6 +26,7 @@ namespace wf {
         hipError_t _e = (expr);                                                                  \
         if (_e != hipSuccess) {                                                                  \
             shm_err() = std::string(#expr) + ": " + hipGetErrorString(_e);                           \
+            (void)hipGetLastError(); /* reported here: must not resurface at the next launch's LAUNCH_TRY */ \
             return SHM_ERR_DEVICE;                                                               \
         }                                                                                        \
     } while (0)

@@ -16,12 +16,13 @@ FILM_DTYPE = np.dtype([("rgb_sum", "<f8", (3,)), ("weight_sum", "<f8")])
 
 
 def make_params(seed=0, spp=4, max_depth=5, regularize=False, disable_pixel_jitter=False, disable_wavelength_jitter=False,
-                integrator="path", sample_lights=True, sample_bsdf=True, force_diffuse=False, disable_texture_filtering=False):
+                integrator="path", sample_lights=True, sample_bsdf=True, force_diffuse=False, disable_texture_filtering=False, reference_quirks=True):
     p = abi.ShmRenderParams()
     p.integrator = {"path": abi.SHM_INTEGRATOR_PATH, "simplepath": abi.SHM_INTEGRATOR_SIMPLE_PATH,
                     "randomwalk": abi.SHM_INTEGRATOR_RANDOM_WALK}[integrator]
     p.sample_lights, p.sample_bsdf = int(sample_lights), int(sample_bsdf)
     p.force_diffuse, p.disable_texture_filtering = int(force_diffuse), int(disable_texture_filtering)
+    p.disable_reference_quirks = 0 if reference_quirks else 1  # SHM_REFERENCE_QUIRKS: ON = reference-exact (the default)
     p.seed, p.samples_per_pixel, p.max_depth = seed, spp, max_depth
     p.regularize, p.disable_pixel_jitter, p.disable_wavelength_jitter = int(regularize), int(disable_pixel_jitter), int(disable_wavelength_jitter)
     return p

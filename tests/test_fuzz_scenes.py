@@ -32,7 +32,8 @@ def test_gpu_random_scene_parity(gpu_lib, seed):
     lib = gpu_lib
     sc = scenes.random_scene(lib, seed)
     regularize = bool(seed % 4 == 3)
-    p = render.make_params(seed=100 + seed, spp=6, max_depth=7, regularize=regularize)
+    # (every fourth seed with SHM_REFERENCE_QUIRKS off: sphere emitters, spherical mappings and coated materials under the PBRT-v4 variants)
+    p = render.make_params(seed=100 + seed, spp=6, max_depth=7, regularize=regularize, reference_quirks=(seed % 4 != 2))
     gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
     fg, sg = gpu.render(p)
     fo, so = orc.render(p, n_threads=os.cpu_count() or 1)

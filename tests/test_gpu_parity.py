@@ -333,6 +333,61 @@ def test_layered_pdf_zero_over_zero_is_the_references(env):
     assert np.array_equal(fg[y0:y0 + 8, x0:x0 + 8].view(np.uint64), fo[y0:y0 + 8, x0:x0 + 8].view(np.uint64))  # NaN bits included
 
 
+def test_reference_quirks_off_no_nan_and_still_bit_exact(env):
+    """SHM_REFERENCE_QUIRKS off (ShmRenderParams::disable_reference_quirks = 1): the coated S3 tile whose pixel (714, 268) the reference
+    poisons (previous test) renders finite at every one of its 128 samples, and the HIP path still equals the oracle bit for bit — the
+    switch lives in the shared arithmetic, both sides take it from the render parameters."""
+    lib, oracle_py, render, scenes = env
+    from shimmer_amd import scene as scn
+    sc = scenes.ganesha_proxy(lib, 1024, 1024, coated=True)
+    x0, y0 = 714 & ~7, 268 & ~7
+    tiles, n = scn.tiles_for(lib, (x0, y0, x0 + 8, y0 + 8))
+    gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+    sel = np.array([i for i in range(gpu.n_tiles) if (gpu.tiles[i].x0, gpu.tiles[i].y0) == (x0, y0)])
+    films = {}
+    for quirks in (True, False):
+        p = render.make_params(seed=0, spp=128, max_depth=5, reference_quirks=quirks)
+        fo, so = orc.render(p, n_threads=os.cpu_count() or 1, tiles=tiles, n_tiles=n)
+        gpu.clear()
+        sg = gpu.render_waves(p, tile_indices=sel)
+        fg = gpu.read_film()
+        assert np.array_equal(fg[y0:y0 + 8, x0:x0 + 8].view(np.uint64), fo[y0:y0 + 8, x0:x0 + 8].view(np.uint64))
+        for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+            assert sg[k] == so[k], k
+        films[quirks] = fg[y0:y0 + 8, x0:x0 + 8]["rgb_sum"]
+    assert not np.isfinite(films[True]).all() and np.isfinite(films[False]).all()
+    gpu.close(); orc.close()
+
+
+@pytest.mark.parametrize("name", ["S1_sphere_light", "three_spheres_environment", "S2_cornell_textured", "S2_cornell_coated", "instanced"])
+def test_render_parity_with_reference_quirks_off(env, name):
+    """Every site the switch touches (sphere (u, v) through acos, SphericalMapping, LayeredBxDF::pdf's guard, the dropped non-finite
+    samples) through the wavefront pipeline == the scalar oracle, bit for bit, with the quirks off as with them on."""
+    lib, oracle_py, render, scenes = env
+    sc, spp, depth = SCENES[name](scenes, lib)
+    gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+    p = render.make_params(seed=3, spp=spp, max_depth=depth, reference_quirks=False)
+    fg, sg = gpu.render(p)
+    fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
+    assert np.array_equal(fg, fo) and np.isfinite(fg["rgb_sum"]).all()
+    for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+        assert sg[k] == so[k], k
+    gpu.close(); orc.close()
+
+
+@pytest.mark.parametrize("integrator", ["simplepath", "randomwalk"])
+def test_other_integrators_with_reference_quirks_off(env, integrator):
+    """uniform_hemisphere_pdf (1/(2 pi) with the quirks off) is reached by SimplePath's uniform sampling and the uniform sky's sample_li."""
+    lib, oracle_py, render, scenes = env
+    sc = scenes.three_spheres(lib, 48, 32, camera=(0.75, 0.5, 9.0))
+    gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+    p = render.make_params(seed=4, spp=8, max_depth=4, integrator=integrator, sample_lights=False, sample_bsdf=False, reference_quirks=False)
+    fg, _ = gpu.render(p)
+    fo, _ = orc.render(p, n_threads=os.cpu_count() or 1)
+    assert np.array_equal(fg, fo) and np.isfinite(fg["rgb_sum"]).all()
+    gpu.close(); orc.close()
+
+
 def test_no_silent_fallback(env):
     """The product never routes through the oracle: libshimmer_hip.so exports no orc_* symbol, and a Renderer holds a
     device film pointer."""

@@ -294,6 +294,12 @@ def test_defaults_materials_textures_instances(lib, tmp_path):
     ('WorldBegin\nImport "other.pbrt"', -2, "Import"),
     ('WorldBegin\nNamedMaterial "nope"', -1, "named material not found"),
     ('WorldBegin\nAttributeEnd', -1, "Unmatched"),
+    # the graphics-state stack remembers what pushed each entry (scene.rs:1190-1192, 1693-1712, 1929-1962)
+    ('WorldBegin\nObjectBegin "a"\nAttributeEnd\nObjectEnd', -1, "<string>:3: Mismatched nesting: open ObjectBegin from <string>:2 at attribute_end"),
+    ('WorldBegin\nObjectBegin "a"\nAttributeBegin\nShape "sphere"\nObjectEnd', -1, "<string>:5: Mismatched nesting: open AttributeBegin from <string>:3 at ObjectEnd"),
+    ('WorldBegin\nAttributeBegin\nShape "sphere"', -1, "Missing end to AttributeBegin from <string>:2"),
+    ('WorldBegin\nObjectBegin "a"\nShape "sphere"', -1, "unmatched ObjectBegin from <string>:2"),
+    ('WorldBegin\nShape "sphere"\nObjectEnd', -1, "ObjectEnd called outside"),
     ('WorldBegin\nMakeNamedMedium "fog"', -2, "media"),
     ('WorldBegin\nShape "curve"', -2, "not supported"),
     ('Integrator "bdpt"\nWorldBegin', -1, "Unknown integrator"),
@@ -305,6 +311,27 @@ def test_errors_are_codes_with_line_numbers(lib, text, code, needle):
     rc = lib.shm_scene_parse_pbrt(text.encode(), None, C.byref(out))
     assert rc == code and not out
     assert needle in lib.shm_last_error().decode(), lib.shm_last_error()
+
+
+def test_include_cycles_and_depth_are_errors_not_stack_overflows(lib, tmp_path):
+    """parser.rs:191-197 recurses into included files without a limit; a cycle must come back as an error code through the ABI."""
+    (tmp_path / "a.pbrt").write_text('WorldBegin\nInclude "b.pbrt"\n')
+    (tmp_path / "b.pbrt").write_text('Shape "sphere"\nInclude "a.pbrt"\n')
+    out = C.POINTER(abi.ShmPbrtScene)()
+    assert lib.shm_scene_load_pbrt(str(tmp_path / "a.pbrt").encode(), C.byref(out)) == -1 and not out
+    assert "Include cycle" in lib.shm_last_error().decode() and "b.pbrt:2" in lib.shm_last_error().decode()
+    (tmp_path / "self.pbrt").write_text('WorldBegin\nShape "sphere"\nInclude "self.pbrt"\n')
+    assert lib.shm_scene_load_pbrt(str(tmp_path / "self.pbrt").encode(), C.byref(out)) == -1 and "Include cycle" in lib.shm_last_error().decode()
+    for i in range(70):  # a chain without a cycle, deeper than any scene nests files
+        (tmp_path / f"c{i}.pbrt").write_text(('WorldBegin\nShape "sphere"\n' if i == 0 else '') + f'Include "c{i + 1}.pbrt"\n')
+    (tmp_path / "c70.pbrt").write_text('Shape "sphere"\n')
+    assert lib.shm_scene_load_pbrt(str(tmp_path / "c0.pbrt").encode(), C.byref(out)) == -1 and "deeper than 64" in lib.shm_last_error().decode()
+    # an ordinary nested include still loads, and the same file may be included twice in sequence (not a cycle)
+    (tmp_path / "top.pbrt").write_text('WorldBegin\nInclude "leaf.pbrt"\nTranslate 3 0 0\nInclude "leaf.pbrt"\n')
+    (tmp_path / "leaf.pbrt").write_text('Shape "sphere"\n')
+    abi.check(lib, lib.shm_scene_load_pbrt(str(tmp_path / "top.pbrt").encode(), C.byref(out)), "shm_scene_load_pbrt")
+    assert out.contents.desc.n_primitives == 2
+    lib.shm_pbrt_free(out)
 
 
 def test_load_from_file_and_look_at_blackbody_helpers(lib, tmp_path):
