@@ -672,6 +672,15 @@ SHM_API int shm_scene_load_pbrt(const char* path, ShmPbrtScene** out);
 /* The same from a string; base_dir (may be NULL) resolves Include and plymesh file names. */
 SHM_API int shm_scene_parse_pbrt(const char* text, const char* base_dir, ShmPbrtScene** out);
 SHM_API void shm_pbrt_free(ShmPbrtScene* scene);
+/* Test entries (the front end's own tokenizer and parameter-list parser, exposed so that the reference's in-source vectors —
+ * loading/tokenizer.rs:126-260, token.rs:218-290, param.rs:214-260, parser.rs:656-870 — can be replayed against them):
+ * shm_pbrt_tokenize writes every token as <kind letter><token text as the reference's Token holds it, quotes kept><NUL>; kinds: D a
+ * directive name (Token::is_directive), W another bare word, S a quoted string (Token::is_quote), B a bracket, Q an opening quote without
+ * its partner (the rest of the input, as tokenizer.rs yields it; the loader proper reports it as an error, as the reference's parser does).
+ * shm_pbrt_parse_params parses a parameter list (`"type name" value | [ values ]` ...) and writes it as JSON:
+ * [{"type", "name", "floats", "ints", "bools", "strings"}] (ParsedParameter, paramdict.rs). */
+SHM_API int shm_pbrt_tokenize(const char* text, char* out, uint64_t capacity, uint32_t* n_tokens);
+SHM_API int shm_pbrt_parse_params(const char* text, char* out_json, uint64_t capacity);
 /* Two pieces of the front end the scene generators of this repository share with the loader, so that both hand the library bit-identical
  * inputs: DenselySampledSpectrum::new(BlackbodySpectrum::new(T)) at 360..=830 nm (spectra/spectrum.rs:430-489) and the world_from_camera
  * matrix of Transform::look_at (transform.rs:270-303), both in f32 as the reference computes them. */

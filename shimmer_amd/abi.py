@@ -260,6 +260,8 @@ EXPORTS = {
     "shm_scene_load_pbrt": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(ShmPbrtScene))]),
     "shm_scene_parse_pbrt": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.POINTER(ShmPbrtScene))]),
     "shm_pbrt_free": (None, [C.POINTER(ShmPbrtScene)]),
+    "shm_pbrt_tokenize": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, c_u32_p]),
+    "shm_pbrt_parse_params": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64]),
     "shm_blackbody_dense": (C.c_int, [C.c_float, c_float_p]),
     "shm_look_at": (C.c_int, [c_float_p, c_float_p, c_float_p, c_float_p]),
     "shm_image_load_png": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.POINTER(ShmLoadedImage)]),

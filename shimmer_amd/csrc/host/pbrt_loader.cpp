@@ -35,27 +35,45 @@ namespace pbrt {
 
 // ---- tokens (loading/tokenizer.rs): words, "quoted strings", [ ], # comments -----------------------------------------------------------
 struct Token {
-    enum Kind { END, WORD, STRING, LBRACKET, RBRACKET } kind = END;
-    std::string text;
+    // BAD_QUOTE: an opening quote without its partner — the reference's tokenizer hands the rest of the input over as one token
+    // (tokenizer.rs:98-107; tests single_quote, single_quote_with_spaces, just_quote) and its parser rejects it (token.rs is_valid / unquote)
+    enum Kind { END, WORD, STRING, LBRACKET, RBRACKET, BAD_QUOTE } kind = END;
+    std::string text;  // STRING: without the quotes; BAD_QUOTE: with the opening one
     int line = 0;
+    // the token as the reference's Token holds it (quotes kept): what shm_pbrt_tokenize reports
+    std::string raw() const { return kind == LBRACKET ? "[" : kind == RBRACKET ? "]" : kind == STRING ? "\"" + text + "\"" : text; }
 };
+// token.rs:112-170 Directive::from_str — the directive set of parser.rs:373-506 (Token::is_directive)
+static bool is_directive_name(const std::string& w) {
+    static const std::set<std::string> k = {"Identity", "Translate", "Scale", "Rotate", "LookAt", "CoordinateSystem", "CoordSysTransform", "Transform", "ConcatTransform",
+        "TransformTimes", "ActiveTransform", "Include", "Import", "Option", "Camera", "Sampler", "ColorSpace", "Film", "Integrator", "Accelerator", "MakeNamedMedium",
+        "MediumInterface", "WorldBegin", "AttributeBegin", "AttributeEnd", "Attribute", "Shape", "ReverseOrientation", "ObjectBegin", "ObjectEnd", "ObjectInstance",
+        "LightSource", "AreaLightSource", "Material", "Texture", "MakeNamedMaterial", "NamedMaterial", "PixelFilter"};
+    return k.count(w) != 0;
+}
 class Tokenizer {
 public:
     Tokenizer(const std::string& s, const std::string& name) : s_(s), name_(name) {}
     Token next() {
         if (has_peek_) { has_peek_ = false; return peek_; }
-        return scan();
+        return checked(scan());
     }
     const Token& peek() {
-        if (!has_peek_) { peek_ = scan(); has_peek_ = true; }
+        if (!has_peek_) { peek_ = checked(scan()); has_peek_ = true; }
         return peek_;
     }
+    Token next_raw() { return scan(); }  // the token stream as the reference's Tokenizer yields it (shm_pbrt_tokenize)
     std::string where(int line) const { return name_ + ":" + std::to_string(line); }
 
 private:
+    Token checked(Token t) {
+        if (t.kind == Token::BAD_QUOTE) fail(where(t.line) + ": unterminated string");
+        return t;
+    }
+    static bool is_space(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; }  // tokenizer.rs:92
     Token scan() {
         for (;;) {
-            while (i_ < s_.size() && isspace((unsigned char)s_[i_])) { if (s_[i_] == '\n') ++line_; ++i_; }
+            while (i_ < s_.size() && is_space(s_[i_])) { if (s_[i_] == '\n') ++line_; ++i_; }
             if (i_ < s_.size() && s_[i_] == '#') { while (i_ < s_.size() && s_[i_] != '\n') ++i_; continue; }
             break;
         }
@@ -65,17 +83,17 @@ private:
         const char c = s_[i_];
         if (c == '[') { ++i_; t.kind = Token::LBRACKET; return t; }
         if (c == ']') { ++i_; t.kind = Token::RBRACKET; return t; }
-        if (c == '"') {
+        if (c == '"') {  // tokenizer.rs:93-102: everything up to the next quote, line breaks included
             size_t j = i_ + 1;
-            while (j < s_.size() && s_[j] != '"') { if (s_[j] == '\n') fail(where(line_) + ": unterminated string"); ++j; }
-            if (j >= s_.size()) fail(where(line_) + ": unterminated string");
+            while (j < s_.size() && s_[j] != '"') { if (s_[j] == '\n') ++line_; ++j; }
+            if (j >= s_.size()) { t.kind = Token::BAD_QUOTE; t.text = s_.substr(i_); i_ = s_.size(); return t; }
             t.kind = Token::STRING;
             t.text = s_.substr(i_ + 1, j - i_ - 1);
             i_ = j + 1;
             return t;
         }
-        size_t j = i_;
-        while (j < s_.size() && !isspace((unsigned char)s_[j]) && s_[j] != '[' && s_[j] != ']' && s_[j] != '"' && s_[j] != '#') ++j;
+        size_t j = i_;  // tokenizer.rs:108-116: a word ends at white space, a quote or a bracket ('#' only starts a comment between tokens)
+        while (j < s_.size() && !is_space(s_[j]) && s_[j] != '[' && s_[j] != ']' && s_[j] != '"') ++j;
         t.kind = Token::WORD;
         t.text = s_.substr(i_, j - i_);
         i_ = j;
@@ -134,6 +152,8 @@ static Params parse_params(Tokenizer& tk) {
             tk.next();
             while (tk.peek().kind != Token::RBRACKET) {
                 if (tk.peek().kind == Token::END) fail(tk.where(decl.line) + ": unterminated parameter list");
+                // parser.rs:603-606: a directive before the closing bracket is an UnexpectedToken, not a value
+                if (tk.peek().kind == Token::WORD && is_directive_name(tk.peek().text)) fail(tk.where(tk.peek().line) + ": unexpected directive " + tk.peek().text + " inside [ ]: missing closing bracket");
                 vals.push_back(tk.next());
             }
             tk.next();
@@ -149,6 +169,7 @@ static Params parse_params(Tokenizer& tk) {
             else if (p.type == "spectrum" && v.kind == Token::STRING) p.s.push_back(v.text);
             else p.f.push_back(parse_float(v, tk));
         }
+        if (ps.find(p.name)) fail(tk.where(decl.line) + ": duplicated parameter name \"" + p.name + "\"");  // param.rs:133-139 ParamList::add
         ps.v.push_back(p);
     }
     return ps;
@@ -1081,7 +1102,7 @@ private:
             std::stringstream ss;
             ss << in.rdbuf();
             parse(ss.str(), fn);
-        } else if (d == "Import") fail(tk.where(t.line) + ": Import is not supported (use Include)", SHM_ERR_UNSUPPORTED);
+        } else if (d == "Import") { const std::string fn = read_string(tk, t); fail(tk.where(t.line) + ": Import \"" + fn + "\" is not supported (todo!() in the reference: use Include)", SHM_ERR_UNSUPPORTED); }
         else if (d == "MakeNamedMedium" || d == "MediumInterface") fail(tk.where(t.line) + ": participating media are todo!() in the reference and not supported", SHM_ERR_UNSUPPORTED);
         else fail(tk.where(t.line) + ": unknown directive \"" + d + "\"");
     }
@@ -1154,6 +1175,76 @@ int shm_scene_load_pbrt(const char* path, ShmPbrtScene** out) {
     std::string p(path);
     const size_t slash = p.find_last_of('/');
     return pbrt::load_text(ss.str(), p, slash == std::string::npos ? std::string(".") : p.substr(0, slash), out);
+}
+
+// ---- test entries: the product's own tokenizer and parameter-list parser, so that the reference's in-source vectors for them
+// (loading/tokenizer.rs:126-260, token.rs:218-290, param.rs:214-260, parser.rs:656-870) can be replayed against this code ----
+int shm_pbrt_tokenize(const char* text, char* out, uint64_t capacity, uint32_t* n_tokens) {
+    if (!text || !out || !n_tokens) return SHM_ERR_INVALID_ARGUMENT;
+    try {
+        const std::string s(text);
+        pbrt::Tokenizer tk(s, "<string>");
+        uint64_t used = 0;
+        uint32_t n = 0;
+        for (;;) {
+            const pbrt::Token t = tk.next_raw();
+            if (t.kind == pbrt::Token::END) break;
+            // kind letter, then the token as the reference's Token holds it, then NUL
+            const char kind = t.kind == pbrt::Token::WORD ? (pbrt::is_directive_name(t.text) ? 'D' : 'W') : t.kind == pbrt::Token::STRING ? 'S'
+                              : t.kind == pbrt::Token::BAD_QUOTE ? 'Q' : 'B';
+            const std::string raw = t.raw();
+            if (used + raw.size() + 2 > capacity) { shm_set_last_error("shm_pbrt_tokenize: output buffer too small"); return SHM_ERR_INVALID_ARGUMENT; }
+            out[used++] = kind;
+            memcpy(out + used, raw.data(), raw.size());
+            used += raw.size();
+            out[used++] = 0;
+            ++n;
+        }
+        *n_tokens = n;
+        return SHM_OK;
+    } catch (const std::exception& e) {
+        shm_set_last_error(e.what());
+        return SHM_ERR_INVALID_ARGUMENT;
+    }
+}
+
+int shm_pbrt_parse_params(const char* text, char* out_json, uint64_t capacity) {
+    if (!text || !out_json || capacity == 0) return SHM_ERR_INVALID_ARGUMENT;
+    try {
+        const std::string s(text);
+        pbrt::Tokenizer tk(s, "<string>");
+        const pbrt::Params ps = pbrt::parse_params(tk);
+        if (tk.peek().kind != pbrt::Token::END) pbrt::fail(tk.where(tk.peek().line) + ": trailing tokens after the parameter list");
+        std::ostringstream o;
+        o << "[";
+        for (size_t k = 0; k < ps.v.size(); ++k) {
+            const pbrt::Param& p = ps.v[k];
+            o << (k ? "," : "") << "{\"type\":\"" << p.type << "\",\"name\":\"" << p.name << "\",\"floats\":[";
+            for (size_t i = 0; i < p.f.size(); ++i) { char b[40]; snprintf(b, sizeof(b), "%.9g", (double)p.f[i]); o << (i ? "," : "") << b; }
+            o << "],\"ints\":[";
+            for (size_t i = 0; i < p.i.size(); ++i) o << (i ? "," : "") << p.i[i];
+            o << "],\"bools\":[";
+            for (size_t i = 0; i < p.b.size(); ++i) o << (i ? "," : "") << (p.b[i] ? "true" : "false");
+            o << "],\"strings\":[";
+            for (size_t i = 0; i < p.s.size(); ++i) {
+                o << (i ? "," : "") << "\"";
+                for (char c : p.s[i]) { if (c == '"' || c == '\\') o << '\\'; if (c == '\n') o << "\\n"; else o << c; }
+                o << "\"";
+            }
+            o << "]}";
+        }
+        o << "]";
+        const std::string j = o.str();
+        if (j.size() + 1 > capacity) { shm_set_last_error("shm_pbrt_parse_params: output buffer too small"); return SHM_ERR_INVALID_ARGUMENT; }
+        memcpy(out_json, j.c_str(), j.size() + 1);
+        return SHM_OK;
+    } catch (const pbrt::LoadError& e) {
+        shm_set_last_error(e.what());
+        return e.code;
+    } catch (const std::exception& e) {
+        shm_set_last_error(e.what());
+        return SHM_ERR_INTERNAL;
+    }
 }
 
 void shm_pbrt_free(ShmPbrtScene* scene) {

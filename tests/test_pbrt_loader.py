@@ -466,8 +466,8 @@ def test_rgb_spectra_png_textures_normal_map_and_environment_light(lib, tmp_path
 
 def test_attribute_directive_sets_defaults_in_scope(lib):
     """Attribute "target" params (scene.rs:1714-1730 + ParameterDictionary::new_with_unowned, paramdict.rs:440-455): defaults for the shapes /
-    lights / materials / textures that follow inside the attribute scope; a directive's own parameter wins; a repeated name resolves to its last
-    value."""
+    lights / materials / textures that follow inside the attribute scope; a directive's own parameter wins; a name repeated by a later Attribute
+    resolves to the later value; a name repeated within ONE directive is the reference's DuplicatedParamName error (param.rs:133-139)."""
     text = """
     Camera "perspective"
     WorldBegin
@@ -477,7 +477,8 @@ def test_attribute_directive_sets_defaults_in_scope(lib):
       Attribute "light" "float scale" 3
       Material "diffuse"
       Shape "sphere"
-      Material "diffuse" "float reflectance" 0.75 "float reflectance" 0.5
+      Attribute "material" "float reflectance" 0.75
+      Material "diffuse"
       Shape "sphere" "float radius" 0.5
       LightSource "point" "float scale" 1
       LightSource "point"
@@ -488,7 +489,7 @@ def test_attribute_directive_sets_defaults_in_scope(lib):
     got = load(lib, text)
     try:
         d = got.contents.desc
-        assert [d.materials[i].a.c for i in range(d.n_materials)] == [0.5, 0.25, 0.5, 0.5]  # default slot, attribute, last repeated value, out of scope
+        assert [d.materials[i].a.c for i in range(d.n_materials)] == [0.5, 0.25, 0.75, 0.5]  # default slot, attribute, the later attribute, out of scope
         assert sorted(d.spheres[i].radius for i in range(d.n_spheres)) == [0.5, 1.0, 2.0]
         assert d.lights[1].scale == pytest.approx(3.0 * d.lights[0].scale, rel=1e-6)
     finally:
@@ -496,6 +497,8 @@ def test_attribute_directive_sets_defaults_in_scope(lib):
     out = C.POINTER(abi.ShmPbrtScene)()
     assert lib.shm_scene_parse_pbrt(b'WorldBegin\nAttribute "camera" "float fov" 3\nShape "sphere"', None, C.byref(out)) == -1
     assert "Unknown attribute target camera" in lib.shm_last_error().decode()
+    assert lib.shm_scene_parse_pbrt(b'WorldBegin\nMaterial "diffuse" "float reflectance" 0.75 "float reflectance" 0.5\nShape "sphere"', None, C.byref(out)) == -1
+    assert '<string>:2: duplicated parameter name "reflectance"' in lib.shm_last_error().decode()
 
 
 def test_film_output_matrix_and_white_balance(lib):
