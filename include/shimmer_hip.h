@@ -576,6 +576,10 @@ SHM_API int shm_device_count(void);
  * nodes_out capacity 2*n-1; prim_order_out[n] receives, per leaf-order slot, the input primitive index. */
 SHM_API int shm_bvh_build(const float* prim_bounds, uint32_t n, int split_method, ShmBvhNode* nodes_out,
                   uint32_t* n_nodes_out, uint32_t* prim_order_out);
+/* Test entry: the Bounds3f operations the builder is made of (union, union_point, surface_area, volume, max_dimension; bounding_box.rs:394-446),
+ * for the reference's own vectors (bounding_box.rs:699-733, 950-995). a, b: {min xyz, max xyz}. out[16]: union(a, b) min, max | union_point(a, p)
+ * min, max | surface_area(a), volume(a), max_dimension(a), 0. */
+SHM_API int shm_bounds3_probe(const float a[6], const float b[6], const float p[3], float out[16]);
 /* Tile::tile (tile.rs:21-104). tiles_out capacity ceil(w/tw)*ceil(h/th); returns the count via n_out. */
 SHM_API int shm_tile_bounds(const int32_t pixel_bounds[4], int32_t tile_w, int32_t tile_h, ShmTile* tiles_out,
                     uint32_t* n_out);

@@ -579,6 +579,11 @@ float orc_fn_next_float_up(float v) { return next_float_up(v); }
 float orc_fn_next_float_down(float v) { return next_float_down(v); }
 float orc_fn_gamma(int n) { return gamma(n); }
 float orc_fn_difference_of_products(float a, float b, float c, float d) { return difference_of_products(a, b, c, d); }
+float orc_fn_lerp(float t, float a, float b) { return shm::lerp(t, a, b); }   // math.rs:246-248
+// fast_polynomial::poly(x, [c0, c1, c2]) = c0 + c1 x + c2 x^2 as the path evaluates it: rgb_sigmoid's polynomial is poly(lambda, [c2, c1, c0])
+// (color.rs:359), i.e. the sigmoid's argument; recovered here through the sigmoid's inverse-free form x / (2 sqrt(1 + x^2)) is not needed:
+// the polynomial itself is exposed
+float orc_fn_poly3(float x, float c0, float c1, float c2) { return shm::poly3(x, c0, c1, c2); }
 float orc_fn_sin(float x) { return shm::sin(x); }
 float orc_fn_cos(float x) { return shm::cos(x); }
 float orc_fn_asin(float x) { return shm::asin(x); }

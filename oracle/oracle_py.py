@@ -51,6 +51,8 @@ def load():
         fn.restype, fn.argtypes = F, [F, F]
     lib.orc_fn_gamma.restype, lib.orc_fn_gamma.argtypes = F, [C.c_int]
     lib.orc_fn_difference_of_products.restype, lib.orc_fn_difference_of_products.argtypes = F, [F, F, F, F]
+    lib.orc_fn_lerp.restype, lib.orc_fn_lerp.argtypes = F, [F, F, F]
+    lib.orc_fn_poly3.restype, lib.orc_fn_poly3.argtypes = F, [F, F, F, F]
     lib.orc_fn_fresnel_complex.restype, lib.orc_fn_fresnel_complex.argtypes = F, [F, F, F]
     lib.orc_fn_dot.restype, lib.orc_fn_dot.argtypes = F, [FP, FP]
     lib.orc_fn_cross.restype, lib.orc_fn_cross.argtypes = None, [FP, FP, FP]

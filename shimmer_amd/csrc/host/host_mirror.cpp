@@ -214,6 +214,23 @@ void m4_point(const M4& a, const double p[3], double out[3]) {
 
 extern "C" {
 
+// Test entry: the Bounds3f operations BvhAggregate::build_recursive is made of (bounding_box.rs: union :432-446, union_point :417-430,
+// surface_area :394-397, volume :399-402, max_dimension :404-415), exactly the helpers the builder above calls, so that the reference's own
+// vectors for them (bounding_box.rs:699-733, 950-995) can be replayed. out[16]: union(a, b) min, max | union_point(a, p) min, max |
+// surface_area(a), volume(a), max_dimension(a), 0.
+int shm_bounds3_probe(const float a[6], const float b[6], const float p[3], float out[16]) {
+    if (!a || !b || !p || !out) return SHM_ERR_INVALID_ARGUMENT;
+    B3 ba, bb;
+    for (int k = 0; k < 3; ++k) { ba.mn[k] = a[k]; ba.mx[k] = a[3 + k]; bb.mn[k] = b[k]; bb.mx[k] = b[3 + k]; }
+    const B3 u = b3_union(ba, bb), up = b3_union_point(ba, p);
+    for (int k = 0; k < 3; ++k) { out[k] = u.mn[k]; out[3 + k] = u.mx[k]; out[6 + k] = up.mn[k]; out[9 + k] = up.mx[k]; }
+    out[12] = b3_surface_area(ba);
+    out[13] = (ba.mx[0] - ba.mn[0]) * (ba.mx[1] - ba.mn[1]) * (ba.mx[2] - ba.mn[2]);
+    out[14] = (float)b3_max_dimension(ba);
+    out[15] = 0.0f;
+    return SHM_OK;
+}
+
 int shm_bvh_build(const float* prim_bounds, uint32_t n, int split_method, ShmBvhNode* nodes_out,
                   uint32_t* n_nodes_out, uint32_t* prim_order_out) {
     if (!prim_bounds || n == 0 || !nodes_out || !n_nodes_out || !prim_order_out || split_method < 0 || split_method > 1)

@@ -115,6 +115,7 @@ struct Param {
     std::vector<std::string> s;
     std::vector<bool> b;
     int line = 0;
+    int color_space = -1;  // ParsedParameter::color_space (paramdict.rs): the graphics state's colour space when the parameter was read
 };
 struct Params {
     std::vector<Param> v;
@@ -179,6 +180,7 @@ static Params parse_params(Tokenizer& tk) {
 struct GraphicsState {
     Xf ctm = xf_identity();
     bool reverse_orientation = false;
+    int color_space = CS_SRGB;   // scene.rs:1119, 1561-1564: the ColorSpace directive's, part of the attribute state
     int material = 0;            // index into Assembly::materials
     Assembly::Emission area_light;
     Params shape_attributes, light_attributes, material_attributes, texture_attributes;  // Attribute "target" ... (scene.rs:1714-1730)
@@ -199,17 +201,15 @@ public:
         memset(&a_->film, 0, sizeof(a_->film));
         // BasicSceneBuilder::new (scene.rs:1221-1304): the default material is "diffuse" with default parameters
         gs_.material = make_material("diffuse", Params(), 0);
-        // RgbColorSpace::SRGB's coefficient table (rgb_to_spectra.rs:27-31 reads rgbtospec/srgb.spec from the working directory): an explicit
-        // file first, then the reference's own location (beside the scene, then the working directory), then the table tools/gen_rgb2spec.py
-        // leaves beside this library
-        if (const char* e = getenv("SHM_RGB2SPEC_SRGB")) a_->rgb2spec_search.push_back(e);
-        if (!base_dir.empty()) a_->rgb2spec_search.push_back(base_dir + "/rgbtospec/srgb.spec");
-        a_->rgb2spec_search.push_back("rgbtospec/srgb.spec");
+        // A colour space's coefficient table (rgb_to_spectra.rs:27-45 reads rgbtospec/<name>.spec from the working directory): an explicit
+        // file first ($SHM_RGB2SPEC_<NAME>), then the reference's own location (beside the scene, then the working directory), then the table
+        // tools/gen_rgb2spec.py leaves beside this library (Assembly::need_color_space)
+        a_->scene_dir = base_dir;
         Dl_info info;
         if (dladdr(reinterpret_cast<const void*>(&shm_set_last_error), &info) && info.dli_fname) {
             std::string lib(info.dli_fname);
             const size_t slash = lib.find_last_of('/');
-            a_->rgb2spec_search.push_back((slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/../data/rgb2spec_srgb_res64.spec");
+            a_->lib_data_dir = (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/../data";
         }
         settings_.spp = 4;
         settings_.max_depth = 5;
@@ -224,6 +224,13 @@ public:
         bool disable_pixel_jitter = false, disable_wavelength_jitter = false, force_diffuse = false, disable_texture_filtering = false;
     } settings_;
 
+    // a directive's parameter list, each parameter stamped with the colour space in effect (ParameterDictionary::new(params,
+    // graphics_state.color_space), scene.rs:1573-1654; Attribute stamps its own at declaration, scene.rs:1725-1729)
+    Params read_params(Tokenizer& tk) {
+        Params ps = parse_params(tk);
+        for (Param& p : ps.v) p.color_space = gs_.color_space;
+        return ps;
+    }
     void parse(const std::string& text, const std::string& name) {
         Tokenizer tk(text, name);
         include_chain_.push_back(name);  // (an exception leaves the chain as it is: the loader object is discarded with it)
@@ -235,6 +242,7 @@ public:
         }
         include_chain_.pop_back();
     }
+    int film_color_space() const { return film_color_space_; }
     std::unique_ptr<Assembly::Built> finish() {
         if (!world_) fail("the scene description has no WorldBegin");
         if (object_ != 0) fail("unmatched ObjectBegin" + (push_stack_.empty() ? std::string() : " from " + push_stack_.back().where));
@@ -275,6 +283,7 @@ private:
     // pre-world entities (scene.rs:1578-1660): kept until WorldBegin, where the camera transform is known
     Params film_params_, camera_params_, filter_params_;
     std::string camera_type_ = "perspective", film_type_ = "rgb", filter_type_ = "box";
+    int film_color_space_ = CS_SRGB;  // the colour space in effect at the Film directive (scene.rs:95): RgbFilm's output matrix uses its rgb_from_xyz
     Xf camera_from_world_ = xf_identity();
     Xf render_from_world_ = xf_identity();
 
@@ -301,9 +310,10 @@ private:
         key << p.type;
         for (float x : p.f) key << ' ' << x;
         for (const std::string& x : p.s) key << ' ' << x;
+        if (p.type == "rgb") key << " cs" << (p.color_space >= 0 ? p.color_space : 0);  // the same numbers in another colour space are another spectrum
         v.key = key.str();
         if (p.type == "float") { if (p.f.empty()) fail(tk.where(p.line) + ": empty float"); v.kind = SpectrumValue::CONSTANT; v.c = p.f[0]; }
-        else if (p.type == "rgb") { if (p.f.size() != 3) fail(tk.where(p.line) + ": rgb needs three values"); v.kind = SpectrumValue::RGB; memcpy(v.rgb, p.f.data(), 12); }
+        else if (p.type == "rgb") { if (p.f.size() != 3) fail(tk.where(p.line) + ": rgb needs three values"); v.kind = SpectrumValue::RGB; memcpy(v.rgb, p.f.data(), 12); v.color_space = p.color_space >= 0 ? p.color_space : CS_SRGB; }
         else if (p.type == "blackbody") { if (p.f.empty()) fail(tk.where(p.line) + ": blackbody needs a temperature"); v.kind = SpectrumValue::DENSE; v.dense = blackbody_dense(p.f[0]); }
         else if (p.type == "spectrum" && !p.f.empty()) {
             if (p.f.size() % 2) fail(tk.where(p.line) + ": Found odd number of values for " + p.name);
@@ -797,9 +807,9 @@ private:
         float scale = ps.one_float("scale", 1.0f);
         if (type == "point") {
             l.kind = SHM_LIGHT_POINT;
-            SpectrumValue d65;
+            SpectrumValue d65;  // light.rs:433: the dictionary's colour space illuminant when "I" is absent
             d65.kind = SpectrumValue::DENSE;
-            d65.dense = illuminant_d65_dense();
+            d65.dense = illuminant_dense(gs_.color_space);
             const Param* ip = ps.find("I");
             const std::vector<float> dense = a_->dense_of(ip ? spectrum_of(*ip, tk) : d65);
             scale /= spectrum_to_photometric(dense);
@@ -822,7 +832,7 @@ private:
             if (image.nc < 3) fail(tk.where(line) + ": Infinite image light sources must have RGB channels");
             if (image.res[0] != image.res[1]) fail(tk.where(line) + ": " + file + ": image resolution is non-square; it's unlikely that it is an equal-area environment map (light.rs:918-923)");
             a_->need_color_space();
-            scale /= spectrum_to_photometric(a_->cs_illuminant);
+            scale /= spectrum_to_photometric(a_->cs_illuminant());  // the IMAGE's colour space (light.rs:178-188): sRGB for every RGB PNG
             const float e_v = ps.one_float("illuminance", -1.0f);
             if (e_v > 0.0f) {  // light.rs:191-221: the upper hemisphere's illuminance of the map
                 float lum[3];
@@ -859,9 +869,9 @@ private:
         } else if (type == "infinite") {
             if (ps.find("portal")) fail(tk.where(line) + ": portal infinite lights are todo!() in the reference", SHM_ERR_UNSUPPORTED);
             l.kind = SHM_LIGHT_UNIFORM_INFINITE;
-            SpectrumValue d65;
+            SpectrumValue d65;  // light.rs:114, 141-145: color_space.illuminant
             d65.kind = SpectrumValue::DENSE;
-            d65.dense = illuminant_d65_dense();
+            d65.dense = illuminant_dense(gs_.color_space);
             const Param* lp = ps.find("L");
             const std::vector<float> dense = a_->dense_of(lp ? spectrum_of(*lp, tk) : d65);
             scale /= spectrum_to_photometric(dense);
@@ -966,9 +976,14 @@ private:
             if (it != coordinate_systems_.end()) gs_.ctm = it->second;  // (the reference only warns when the name is unknown)
         } else if (d == "ReverseOrientation") gs_.reverse_orientation = !gs_.reverse_orientation;
         else if (d == "TransformTimes" || d == "ActiveTransform") fail(tk.where(t.line) + ": animated transforms are not supported", SHM_ERR_UNSUPPORTED);
-        else if (d == "ColorSpace") { if (read_string(tk, t) != "srgb") fail(tk.where(t.line) + ": only the srgb colour space is supported", SHM_ERR_UNSUPPORTED); }
+        else if (d == "ColorSpace") {  // scene.rs:1561-1564: RgbColorSpace::get_named(n.into()) — srgb / rec2020 / aces2065-1, any case (colorspace.rs:123-132)
+            const std::string n = read_string(tk, t);
+            const int cs = color_space_from_name(n);
+            if (cs < 0) fail(tk.where(t.line) + ": Unknown color space: " + n);
+            gs_.color_space = cs;
+        }
         else if (d == "Option") {  // options.rs / scene.rs:1375-1454
-            const Params ps = parse_params(tk);
+            const Params ps = read_params(tk);
             for (const Param& p : ps.v) {
                 if (p.name == "seed") settings_.seed = p.i.empty() ? 0 : p.i[0];
                 else if (p.name == "disablepixeljitter") settings_.disable_pixel_jitter = !p.b.empty() && p.b[0];
@@ -986,29 +1001,29 @@ private:
         } else if (d == "Camera") {
             need_world(t, tk, false);
             camera_type_ = read_string(tk, t);
-            camera_params_ = parse_params(tk);
+            camera_params_ = read_params(tk);
             camera_from_world_ = gs_.ctm;                       // scene.rs:1614-1637
             coordinate_systems_["camera"] = xf_inverse(gs_.ctm);
-        } else if (d == "Film") { need_world(t, tk, false); film_type_ = read_string(tk, t); film_params_ = parse_params(tk); }
-        else if (d == "PixelFilter") { need_world(t, tk, false); filter_type_ = read_string(tk, t); filter_params_ = parse_params(tk); }
+        } else if (d == "Film") { need_world(t, tk, false); film_type_ = read_string(tk, t); film_params_ = read_params(tk); film_color_space_ = gs_.color_space; }  // scene.rs:95: film.parameters.color_space
+        else if (d == "PixelFilter") { need_world(t, tk, false); filter_type_ = read_string(tk, t); filter_params_ = read_params(tk); }
         else if (d == "Sampler") {
             need_world(t, tk, false);
             settings_.sampler = read_string(tk, t);
-            const Params ps = parse_params(tk);
+            const Params ps = read_params(tk);
             if (settings_.sampler != "independent") fail(tk.where(t.line) + ": sampler \"" + settings_.sampler + "\" is not supported (independent)", SHM_ERR_UNSUPPORTED);
             settings_.spp = ps.one_int("pixelsamples", 4);
             settings_.seed = ps.one_int("seed", settings_.seed);
         } else if (d == "Integrator") {
             need_world(t, tk, false);
             settings_.integrator = read_string(tk, t);
-            const Params ps = parse_params(tk);
+            const Params ps = read_params(tk);
             if (settings_.integrator != "path" && settings_.integrator != "simplepath" && settings_.integrator != "randomwalk") fail(tk.where(t.line) + ": Unknown integrator " + settings_.integrator);
             settings_.max_depth = ps.one_int("maxdepth", 5);
             settings_.regularize = ps.one_bool("regularize", false);
             settings_.sample_lights = ps.one_bool("samplelights", true);
             settings_.sample_bsdf = ps.one_bool("samplebsdf", true);
             if (ps.one_string("lightsampler", "uniform") != "uniform") fail(tk.where(t.line) + ": only the uniform light sampler exists on this path", SHM_ERR_UNSUPPORTED);
-        } else if (d == "Accelerator") { read_string(tk, t); parse_params(tk); }  // the BVH of aggregate.rs is the only accelerator
+        } else if (d == "Accelerator") { read_string(tk, t); read_params(tk); }  // the BVH of aggregate.rs is the only accelerator
         else if (d == "WorldBegin") { need_world(t, tk, false); world_begin(tk, t.line); }
         else if (d == "AttributeBegin") { need_world(t, tk, true); stack_.push_back(gs_); push_stack_.push_back(Pushed{'a', tk.where(t.line)}); }
         else if (d == "AttributeEnd") {  // scene.rs:1693-1712
@@ -1019,18 +1034,18 @@ private:
             push_stack_.pop_back();
         } else if (d == "Attribute") {  // scene.rs:1714-1730: default parameters for what follows of that kind, within the attribute scope
             const std::string target = read_string(tk, t);
-            const Params ps = parse_params(tk);
+            const Params ps = read_params(tk);
             Params* dst = target == "shape" ? &gs_.shape_attributes : target == "light" ? &gs_.light_attributes : target == "material" ? &gs_.material_attributes
                           : target == "texture" ? &gs_.texture_attributes : nullptr;
             if (target == "medium") fail(tk.where(t.line) + ": participating media are todo!() in the reference and not supported", SHM_ERR_UNSUPPORTED);
             if (!dst) fail(tk.where(t.line) + ": Unknown attribute target " + target);
             dst->v.insert(dst->v.end(), ps.v.begin(), ps.v.end());
         }
-        else if (d == "Material") { need_world(t, tk, true); const std::string ty = read_string(tk, t); const Params ps = with_attributes(parse_params(tk), gs_.material_attributes); gs_.material = make_material(ty, ps, &tk); }
+        else if (d == "Material") { need_world(t, tk, true); const std::string ty = read_string(tk, t); const Params ps = with_attributes(read_params(tk), gs_.material_attributes); gs_.material = make_material(ty, ps, &tk); }
         else if (d == "MakeNamedMaterial") {
             need_world(t, tk, true);
             const std::string name = read_string(tk, t);
-            const Params ps = with_attributes(parse_params(tk), gs_.material_attributes);
+            const Params ps = with_attributes(read_params(tk), gs_.material_attributes);
             if (named_materials_.count(name)) fail(tk.where(t.line) + ": named material \"" + name + "\" redefined");
             const std::string ty = ps.one_string("type", "");
             if (ty.empty()) fail(tk.where(t.line) + ": MakeNamedMaterial \"" + name + "\" has no \"string type\"");
@@ -1044,24 +1059,24 @@ private:
         } else if (d == "Texture") {
             need_world(t, tk, true);
             const std::string name = read_string(tk, t), ty = read_string(tk, t), cls = read_string(tk, t);
-            texture(name, ty, cls, with_attributes(parse_params(tk), gs_.texture_attributes), tk, t.line);
+            texture(name, ty, cls, with_attributes(read_params(tk), gs_.texture_attributes), tk, t.line);
         } else if (d == "AreaLightSource") {
             need_world(t, tk, true);
             const std::string ty = read_string(tk, t);
-            const Params ps = with_attributes(parse_params(tk), gs_.light_attributes);
+            const Params ps = with_attributes(read_params(tk), gs_.light_attributes);
             if (ty != "diffuse") fail(tk.where(t.line) + ": area light \"" + ty + "\" unknown (diffuse)");
             if (!ps.one_string("filename", "").empty()) fail(tk.where(t.line) + ": image area lights are todo!() in the reference", SHM_ERR_UNSUPPORTED);
             Assembly::Emission em;
             em.on = true;
             const Param* lp = ps.find("L");
             if (lp) em.L = spectrum_of(*lp, tk);
-            else { em.L.kind = SpectrumValue::DENSE; em.L.dense = illuminant_d65_dense(); em.L.key = "StdIllum-D65"; }  // light.rs:592-596
+            else { em.L.kind = SpectrumValue::DENSE; em.L.dense = illuminant_dense(gs_.color_space); em.L.key = color_space_def(gs_.color_space).aces_d60 ? "illum-acesD60" : "StdIllum-D65"; }  // light.rs:592-596: color_space.illuminant
             em.scale = ps.one_float("scale", 1.0f);
             em.power = ps.one_float("power", -1.0f);
             em.two_sided = ps.one_bool("twosided", false);
             gs_.area_light = em;
-        } else if (d == "LightSource") { need_world(t, tk, true); const std::string ty = read_string(tk, t); light_source(ty, with_attributes(parse_params(tk), gs_.light_attributes), tk, t.line); }
-        else if (d == "Shape") { need_world(t, tk, true); const std::string ty = read_string(tk, t); shape(ty, with_attributes(parse_params(tk), gs_.shape_attributes), tk, t.line); }
+        } else if (d == "LightSource") { need_world(t, tk, true); const std::string ty = read_string(tk, t); light_source(ty, with_attributes(read_params(tk), gs_.light_attributes), tk, t.line); }
+        else if (d == "Shape") { need_world(t, tk, true); const std::string ty = read_string(tk, t); shape(ty, with_attributes(read_params(tk), gs_.shape_attributes), tk, t.line); }
         else if (d == "ObjectBegin") {  // scene.rs:1904-1982
             need_world(t, tk, true);
             const std::string name = read_string(tk, t);
@@ -1139,7 +1154,7 @@ static int load_text(const std::string& text, const std::string& name, const std
         p.integrator = st.integrator == "path" ? SHM_INTEGRATOR_PATH : (st.integrator == "simplepath" ? SHM_INTEGRATOR_SIMPLE_PATH : SHM_INTEGRATOR_RANDOM_WALK);
         snprintf(scene->integrator, sizeof(scene->integrator), "%s", st.integrator.c_str());
         snprintf(scene->output_filename, sizeof(scene->output_filename), "%s", st.filename.c_str());
-        Assembly::film_output_matrix(st.white_balance, scene->output_rgb_from_sensor_rgb);
+        Assembly::film_output_matrix(st.white_balance, scene->output_rgb_from_sensor_rgb, loader.film_color_space());
         Holder* h = new Holder();
         h->built = std::move(built);
         scene->owner = h;

@@ -98,6 +98,44 @@ inline std::vector<float> illuminant_d65_dense() {
     return piecewise_to_dense(lam, val);
 }
 
+// Spectrum::get_named_spectrum(IllumAcesD60): from_interleaved(ACES_ILLUM_D60, normalize = true) (named_spectrum.rs:58-62), densely sampled
+inline std::vector<float> illuminant_aces_d60_dense() {
+    std::vector<float> lam, val;
+    from_interleaved(PBRT_TABLE(ACES_ILLUM_D60), lam, val);
+    std::vector<float> dense = piecewise_to_dense(lam, val);
+    const std::vector<float> y = PBRT_TABLE(CIE_Y);
+    float integral = 0.0f;
+    for (int i = 0; i < 471; ++i) integral += dense[i] * y[i];
+    const std::vector<float> yi = PBRT_TABLE(CIE_Y_INTEGRAL);
+    const float k = yi[0] / integral;
+    for (float& v : val) v *= k;
+    return piecewise_to_dense(lam, val);
+}
+// The named colour spaces (colorspace.rs:117-164: NamedColorSpace, SRGB / REC_2020 / ACES2065_1 with their primaries, illuminant and Gamut) and
+// where each one's rgb2spec coefficient table comes from (rgb_to_spectra.rs:27-45: rgbtospec/srgb.spec, rec2020.spec, aces2065_1.spec)
+enum ColorSpaceId : int { CS_SRGB = 0, CS_REC2020 = 1, CS_ACES2065_1 = 2, N_COLOR_SPACES = 3 };
+struct ColorSpaceDef {
+    const char* name;        // the ColorSpace directive's argument (matched case-insensitively, colorspace.rs:125-131)
+    const char* spec_file;   // the reference's file name under rgbtospec/
+    const char* env;         // explicit override
+    const char* generated;   // what tools/gen_rgb2spec.py writes into shimmer_amd/data/
+    float xy[3][2];          // r, g, b primaries
+    bool aces_d60;           // illuminant: ACES D60 instead of D65
+};
+inline const ColorSpaceDef& color_space_def(int cs) {
+    static const ColorSpaceDef k[N_COLOR_SPACES] = {
+        {"srgb", "srgb.spec", "SHM_RGB2SPEC_SRGB", "rgb2spec_srgb_res64.spec", {{0.64f, 0.33f}, {0.3f, 0.6f}, {0.15f, 0.06f}}, false},
+        {"rec2020", "rec2020.spec", "SHM_RGB2SPEC_REC2020", "rgb2spec_rec2020_res64.spec", {{0.708f, 0.292f}, {0.170f, 0.797f}, {0.131f, 0.046f}}, false},
+        {"aces2065-1", "aces2065_1.spec", "SHM_RGB2SPEC_ACES2065_1", "rgb2spec_aces2065_1_res64.spec", {{0.7347f, 0.2653f}, {0.0f, 1.0f}, {0.0001f, -0.077f}}, true}};
+    return k[cs];
+}
+inline int color_space_from_name(std::string n) {
+    for (char& c : n) c = (char)tolower((unsigned char)c);
+    for (int cs = 0; cs < N_COLOR_SPACES; ++cs) if (n == color_space_def(cs).name) return cs;
+    return -1;
+}
+inline std::vector<float> illuminant_dense(int cs) { return color_space_def(cs).aces_d60 ? illuminant_aces_d60_dense() : illuminant_d65_dense(); }
+
 // A spectrum value as parsed, before it is bound to a use (material slot: kept in its own kind; light: densely sampled)
 struct SpectrumValue {
     enum Kind { NONE, CONSTANT, PIECEWISE, DENSE, RGB, TEXTURE } kind = NONE;
@@ -105,6 +143,7 @@ struct SpectrumValue {
     std::vector<float> lam, val;   // PIECEWISE
     std::vector<float> dense;      // DENSE (blackbody)
     float rgb[3] = {0, 0, 0};
+    int color_space = CS_SRGB;     // RGB: the colour space the value is given in (the parameter's: paramdict.rs:615-620)
     std::string texture;           // TEXTURE: name of a spectrum texture
     std::string key;               // identity for pooling (one table per distinct emission spectrum)
 };
@@ -170,62 +209,72 @@ public:
     std::vector<float> texels;
     std::vector<ShmImageInfiniteLight> image_lights;
     std::vector<float> ewa_lut = PBRT_TABLE(MIP_FILTER_LUT);
-    Rgb2SpecTable rgb2spec;
-    std::vector<float> cs_illuminant;       // RgbColorSpace::SRGB.illuminant: StdIllum-D65, densely sampled (colorspace.rs:139, 65)
-    std::vector<std::string> rgb2spec_search;  // where the table is looked for, in order
-    // RgbColorSpace::SRGB's coefficient table, loaded the first time something needs it
-    void need_color_space() {
-        if (rgb2spec.res) return;
+    Rgb2SpecTable rgb2spec_tables[N_COLOR_SPACES];    // per named colour space, loaded the first time something needs it
+    std::vector<float> cs_illuminants[N_COLOR_SPACES];  // RgbColorSpace::illuminant, densely sampled (colorspace.rs:63-65): StdIllum-D65 / ACES D60
+    uint32_t cs_illuminant_offsets[N_COLOR_SPACES] = {~0u, ~0u, ~0u};
+    // what the DEVICE gets (ShmSceneDesc::color_space): the table and illuminant of RGB IMAGES — always sRGB, the colour space read_png gives
+    // every RGB file (image.rs:1262-1270); "rgb" PARAMETERS are converted on the host with their own colour space's table
+    const Rgb2SpecTable& rgb2spec() const { return rgb2spec_tables[CS_SRGB]; }
+    const std::vector<float>& cs_illuminant() const { return cs_illuminants[CS_SRGB]; }
+    std::string scene_dir, lib_data_dir;    // where the tables are looked for: <scene dir>/rgbtospec, ./rgbtospec (the reference's place), then beside this library
+    void need_color_space(int cs = CS_SRGB) {
+        Rgb2SpecTable& t = rgb2spec_tables[cs];
+        if (t.res) return;
+        const ColorSpaceDef& def = color_space_def(cs);
+        std::vector<std::string> search;
+        if (const char* e = getenv(def.env)) search.push_back(e);
+        if (!scene_dir.empty()) search.push_back(scene_dir + "/rgbtospec/" + def.spec_file);
+        search.push_back(std::string("rgbtospec/") + def.spec_file);
+        if (!lib_data_dir.empty()) search.push_back(lib_data_dir + "/" + def.generated);
         std::string tried;
-        for (const std::string& p : rgb2spec_search) {
+        for (const std::string& p : search) {
             if (p.empty()) continue;
-            if (rgb2spec_load(p, rgb2spec)) break;
+            if (rgb2spec_load(p, t)) break;
             tried += (tried.empty() ? "" : ", ") + p;
         }
-        if (!rgb2spec.res)
-            fail("\"rgb\" values and RGB images need the sRGB rgb2spec coefficient table (the reference loads rgbtospec/srgb.spec, rgb_to_spectra.rs:27-31); not found in: " +
-                     tried + " — set SHM_RGB2SPEC_SRGB or run tools/gen_rgb2spec.py", SHM_ERR_UNSUPPORTED);
-        cs_illuminant = illuminant_d65_dense();
+        if (!t.res)
+            fail(std::string("\"rgb\" values and RGB images need the ") + def.name + " rgb2spec coefficient table (the reference loads rgbtospec/" + def.spec_file +
+                     ", rgb_to_spectra.rs:27-45); not found in: " + tried + " — set " + def.env + " or run tools/gen_rgb2spec.py", SHM_ERR_UNSUPPORTED);
+        cs_illuminants[cs] = illuminant_dense(cs);
     }
     // RgbColorSpace::to_rgb_coeffs (colorspace.rs:95-98 -> rgb_to_spectra.rs:16-25 -> RGB2Spec::fetch)
-    void rgb_coeffs(const float rgb[3], float out[3]) {
-        need_color_space();
+    void rgb_coeffs(const float rgb[3], float out[3], int cs = CS_SRGB) {
+        need_color_space(cs);
         shm::SceneView sv;
         memset(&sv, 0, sizeof(sv));
-        sv.rgb2spec_res = rgb2spec.res;
-        sv.rgb2spec_scale = rgb2spec.scale.data();
-        sv.rgb2spec_data = rgb2spec.data.data();
+        sv.rgb2spec_res = rgb2spec_tables[cs].res;
+        sv.rgb2spec_scale = rgb2spec_tables[cs].scale.data();
+        sv.rgb2spec_data = rgb2spec_tables[cs].data.data();
         shm::rgb2spec_fetch(sv, shm::rgb3(rgb[0], rgb[1], rgb[2]), out);
     }
     // RgbAlbedoSpectrum / RgbUnboundedSpectrum / RgbIlluminantSpectrum::new (spectrum.rs:502-509, 536-547, 574-588)
-    ShmSpectrum spec_rgb(const float rgb[3], SpectrumType type) {
+    ShmSpectrum spec_rgb(const float rgb[3], SpectrumType type, int cs = CS_SRGB) {
         if (rgb[0] < 0.0f || rgb[1] < 0.0f || rgb[2] < 0.0f) fail("RGB parameter has negative component");  // paramdict.rs:628-633
         ShmSpectrum s;
         memset(&s, 0, sizeof(s));
         if (type == SPECTRUM_ALBEDO) {
             if (rgb[0] > 1.0f || rgb[1] > 1.0f || rgb[2] > 1.0f) fail("RGB parameter has component value > 1.0");  // paramdict.rs:641-646
             s.kind = SHM_SPECTRUM_RGB_ALBEDO;
-            rgb_coeffs(rgb, s.rgb_c);
+            rgb_coeffs(rgb, s.rgb_c, cs);
             return s;
         }
         const float m = std::max(std::max(rgb[0], rgb[1]), rgb[2]);
         const float scale = 2.0f * m;
         const float scaled[3] = {scale != 0.0f ? rgb[0] / scale : 0.0f, scale != 0.0f ? rgb[1] / scale : 0.0f, scale != 0.0f ? rgb[2] / scale : 0.0f};
-        rgb_coeffs(scaled, s.rgb_c);
+        rgb_coeffs(scaled, s.rgb_c, cs);
         s.c = scale;
         if (type == SPECTRUM_UNBOUNDED) { s.kind = SHM_SPECTRUM_RGB_UNBOUNDED; return s; }
-        s.kind = SHM_SPECTRUM_RGB_ILLUMINANT;
-        if (cs_illuminant_offset == ~0u) cs_illuminant_offset = pool(cs_illuminant);
-        s.offset = cs_illuminant_offset;
+        s.kind = SHM_SPECTRUM_RGB_ILLUMINANT;  // times the colour space's illuminant, which the spectrum carries (pooled once per colour space)
+        if (cs_illuminant_offsets[cs] == ~0u) cs_illuminant_offsets[cs] = pool(cs_illuminants[cs]);
+        s.offset = cs_illuminant_offsets[cs];
         s.n = 471;
         s.lambda_min = 360;
         return s;
     }
-    uint32_t cs_illuminant_offset = ~0u;
     // ---- RgbFilm::new's output matrix (film.rs:482-545, 767-850; colorspace.rs:38-72; color.rs:392-416; spectrum.rs:215-262) ----
     // xyz_from_rgb of sRGB as RgbColorSpace::new builds it from the primaries and W = XYZ::from_spectrum(D65): rgb * diag(rgb^-1 W). The
     // reference's 3x3 algebra is compensated f32; here f64, rounded once at the end.
-    static void srgb_matrices(const std::vector<float>& d65_dense, double xyz_from_rgb[3][3], double rgb_from_xyz[3][3], double white_xy[2]) {
+    static void cs_matrices(int cs, const std::vector<float>& d65_dense, double xyz_from_rgb[3][3], double rgb_from_xyz[3][3], double white_xy[2]) {
         const std::vector<float> bx = PBRT_TABLE(CIE_X), by = PBRT_TABLE(CIE_Y), bz = PBRT_TABLE(CIE_Z), yi = PBRT_TABLE(CIE_Y_INTEGRAL);
         const std::vector<float>* bars[3] = {&bx, &by, &bz};
         double w[3];
@@ -236,7 +285,7 @@ public:
         }
         white_xy[0] = w[0] / (w[0] + w[1] + w[2]);
         white_xy[1] = w[1] / (w[0] + w[1] + w[2]);
-        const float xy[3][2] = {{0.64f, 0.33f}, {0.3f, 0.6f}, {0.15f, 0.06f}};
+        const float (*xy)[2] = color_space_def(cs).xy;  // XYZ::from_xy_y_default of each primary (color.rs:242-252): (x / y, 1, (1 - x - y) / y)
         double m[3][3], inv[3][3];
         for (int j = 0; j < 3; ++j) { m[0][j] = xy[j][0] * 1.0f / xy[j][1]; m[1][j] = 1.0; m[2][j] = (1.0f - xy[j][0] - xy[j][1]) * 1.0f / xy[j][1]; }
         invert3(m, inv);
@@ -270,15 +319,15 @@ public:
     }
     // film.rs:524: output_rgb_from_sensor_rgb = color_space.rgb_from_xyz * sensor.xyz_from_sensor_rgb, the sensor's matrix being the von Kries
     // white balance (color.rs:404-416) from the "whitebalance" illuminant's white to the colour space's, or the identity without one
-    static void film_output_matrix(float white_balance_temp, float out9[9]) {
-        const std::vector<float> d65 = illuminant_d65_dense();
+    static void film_output_matrix(float white_balance_temp, float out9[9], int cs = CS_SRGB) {
+        const std::vector<float> d65 = illuminant_dense(cs);  // the film colour space's illuminant (D65, or ACES D60)
         double xyz_from_rgb[3][3], rgb_from_xyz[3][3], target_xy[2];
-        srgb_matrices(d65, xyz_from_rgb, rgb_from_xyz, target_xy);
+        cs_matrices(cs, d65, xyz_from_rgb, rgb_from_xyz, target_xy);
         double sensor[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
         if (white_balance_temp != 0.0f) {
             const std::vector<float> illum = d_illuminant_dense(white_balance_temp);
             double dummy1[3][3], dummy2[3][3], src_xy[2];
-            srgb_matrices(illum, dummy1, dummy2, src_xy);  // (only its XYZ::from_spectrum(illum).xy() part is used)
+            cs_matrices(cs, illum, dummy1, dummy2, src_xy);  // (only its XYZ::from_spectrum(illum).xy() part is used)
             static const double lms_from_xyz[3][3] = {{0.8951, 0.2664, -0.1614}, {-0.7502, 1.7135, 0.0367}, {0.0389, -0.0685, 1.0296}};
             static const double xyz_from_lms[3][3] = {{0.986993, -0.147054, 0.159963}, {0.432305, 0.51836, 0.0492912}, {-0.00852866, 0.0400428, 0.968487}};
             auto from_xy = [](const double xy[2], double xyz[3]) { xyz[0] = xy[0] / xy[1]; xyz[1] = 1.0; xyz[2] = (1.0 - xy[0] - xy[1]) / xy[1]; };
@@ -308,7 +357,7 @@ public:
         const std::vector<float> yi = PBRT_TABLE(CIE_Y_INTEGRAL);
         for (int k = 0; k < 3; ++k) {
             float acc = 0.0f;
-            for (int i = 0; i < 471; ++i) acc += (*bars[k])[i] * cs_illuminant[i];
+            for (int i = 0; i < 471; ++i) acc += (*bars[k])[i] * cs_illuminants[CS_SRGB][i];
             w[k] = acc / yi[0];
         }
         const float xy[3][2] = {{0.64f, 0.33f}, {0.3f, 0.6f}, {0.15f, 0.06f}};
@@ -322,8 +371,8 @@ public:
         for (int k = 0; k < 3; ++k) lum[k] = (float)(inv[k][0] * w[0] + inv[k][1] * w[1] + inv[k][2] * w[2]);
     }
     // Spectrum::get of an RGB-derived spectrum at the 471 integer wavelengths (DenselySampledSpectrum::new of it: lights)
-    std::vector<float> rgb_dense(const float rgb[3], SpectrumType type) {
-        ShmSpectrum s = spec_rgb(rgb, type);
+    std::vector<float> rgb_dense(const float rgb[3], SpectrumType type, int cs = CS_SRGB) {
+        ShmSpectrum s = spec_rgb(rgb, type, cs);
         std::vector<float> d(471);
         for (int l = 360; l <= 830; ++l) d[l - 360] = shm::spectrum_get(s, spec.data(), (float)l);
         return d;
@@ -372,7 +421,7 @@ public:
                 if (it == spectrum_texture_names.end()) fail("Couldn't find spectrum texture named \"" + v.texture + "\"");
                 return it->second;
             }
-            case SpectrumValue::RGB: return spec_rgb(v.rgb, type);
+            case SpectrumValue::RGB: return spec_rgb(v.rgb, type, v.color_space);
             default: fail("missing spectrum");
         }
     }
@@ -382,7 +431,7 @@ public:
             case SpectrumValue::CONSTANT: return std::vector<float>(471, v.c);
             case SpectrumValue::PIECEWISE: return piecewise_to_dense(v.lam, v.val);
             case SpectrumValue::DENSE: return v.dense;
-            case SpectrumValue::RGB: return rgb_dense(v.rgb, type);
+            case SpectrumValue::RGB: return rgb_dense(v.rgb, type, v.color_space);
             default: fail("a light's spectrum cannot be a texture");
         }
     }
@@ -643,11 +692,11 @@ public:
         d.n_texel_floats = a.texels.size(); d.texel_data = a.texels.data();
         d.n_image_lights = (uint32_t)a.image_lights.size(); d.image_lights = a.image_lights.data();
         if (!a.image_textures.empty() || !a.image_lights.empty()) d.ewa_filter_lut = a.ewa_lut.data();
-        if (a.rgb2spec.res) {  // ShmColorSpace (only when something asked for it: RGB images, image lights)
-            d.color_space.rgb2spec_res = a.rgb2spec.res;
-            d.color_space.rgb2spec_scale = a.rgb2spec.scale.data();
-            d.color_space.rgb2spec_data = a.rgb2spec.data.data();
-            d.color_space.illuminant = a.cs_illuminant.data();
+        if (a.rgb2spec().res) {  // ShmColorSpace (only when something asked for it: RGB images, image lights — the sRGB table, see rgb2spec())
+            d.color_space.rgb2spec_res = a.rgb2spec().res;
+            d.color_space.rgb2spec_scale = a.rgb2spec().scale.data();
+            d.color_space.rgb2spec_data = a.rgb2spec().data.data();
+            d.color_space.illuminant = a.cs_illuminant().data();
         }
         out->owner = std::move(self_owned);
         return out;

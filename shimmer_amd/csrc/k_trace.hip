@@ -32,6 +32,16 @@ enum : uint32_t { ST_IDLE = 0, ST_NODE = 1, ST_LEAF = 2, ST_DONE = 3 };
 // workgroup needs LDS_N KiB of the CU's 160: the four entry points below trade stack levels in LDS for resident waves as far as their registers
 // allow — closest-hit: 72 VGPRs = 7 waves, 22 levels; any-hit: 64 VGPRs = 8 waves, 19 levels; the instantiations with quadrics / patches /
 // instances need > 120 VGPRs (3-4 waves) and keep 26 levels. Deeper levels go to the HBM spill (a BVH of 4.3 M triangles is 32 deep).
+// v_cndmask with the per-ray sign held as a 64-bit lane mask in a SCALAR register pair (one bit per lane, rebuilt by three ballots whenever
+// a lane takes a new ray): the select costs one VALU instruction and no compare, and — unlike a `bool` per lane, which the compiler keeps
+// as such a mask too but has to merge at every control-flow join (3 SALU instructions per mask per join: profiles/r03_k_trace3_isa_before.txt
+// counts 123 SALU in the refill section alone) — a wave-uniform integer needs no merging at all.
+__device__ __forceinline__ Float sel_mask(unsigned long long mask, Float if_clear, Float if_set) {
+    Float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
+
 template <bool ANY, bool TRI_ONLY, int LDS_N>
 __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
                                             uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
@@ -40,10 +50,15 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                                             DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
                                             int refill_min, int leaf_min, int queue_parts) {
     constexpr int K3_LDS_N = LDS_N;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
     __shared__ uint32_t lds_stack[(TRACE_BLOCK / WAVE) * K3_LDS_N * WAVE];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave_in_block = threadIdx.x / WAVE;
-    uint32_t* const st_lds = lds_stack + wave_in_block * K3_LDS_N * WAVE + lane;
+    // The per-lane stack, levels [0, LDS_N) in LDS as [level][lane]. `top` is the LDS address of the next free level and is the only
+    // stack register: a push stores at it and adds one level, a pop subtracts and loads; it keeps counting past the LDS window, where
+    // the level lives in the per-lane HBM spill instead (level - LDS_N), so "empty" and "beyond LDS" are two compares against constants.
+    lds_u32* const st_base = (lds_u32*)lds_stack + wave_in_block * K3_LDS_N * WAVE + lane;
+    lds_u32* top = st_base;
     // (wave-uniform base; the lane offset is added where a spill level is touched — rare — instead of living in two VGPRs)
     uint32_t* const st_spill_wave = spill + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE;
     const uint32_t n = n_ptr ? *n_ptr : n_direct;
@@ -56,18 +71,20 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
 
     uint32_t state = ST_IDLE;
     bool exhausted = false;  // wave-uniform
-    uint32_t w_next = 0, w_end = 0;  // wave-uniform private range of the queue
+    uint32_t w_next = 0, w_end = 0;  // wave-uniform private range of the queue (scalar registers: readfirstlane of the claimed base)
     // chunk size: large enough that the single head word sees few atomics (it saturates near 88 dequeues/us,
     // MI355X_MICROARCH.md "dequeue"), small enough that the last chunks balance across the resident waves
     const uint32_t n_waves = gridDim.x * (TRACE_BLOCK / WAVE);
     uint32_t chunk = n / (n_waves * 8u);
     chunk = chunk < 64u ? 64u : (chunk > (uint32_t)K3_CHUNK_MAX ? (uint32_t)K3_CHUNK_MAX : chunk);
     chunk = (chunk + 63u) & ~63u;
-    bool want_pop = false;
     uint32_t path = 0;
     V3 ro = v3s(0.0f), inv_dir = v3s(0.0f);
     V3 rd_full = v3s(0.0f);  // the direction itself is only kept for non-triangle shapes (TRI_ONLY = false)
-    bool negx = false, negy = false, negz = false;
+    // dir_is_neg (aggregate.rs:76-81) twice: as three wave-wide lane masks in scalar registers for the slab test's selects (sel_mask), and
+    // as three bits of one VGPR for the near / far child choice, where the axis varies per lane
+    unsigned long long m_negx = 0ull, m_negy = 0ull, m_negz = 0ull;
+    uint32_t sgn = 0;
     RayShear rs;
     rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
     Float t_max = 0.0f;
@@ -79,9 +96,22 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
     Float t_outer = 0.0f;
     bool inst_hit = false;
     constexpr uint32_t INST_SENTINEL = 0xffffffffu;  // stack entry that marks the way back out of an instance
-    int sp = 0;
     uint32_t cur = 0;
     uint32_t leaf_off = 0, leaf_n = 0;
+
+    auto set_ray = [&](V3 o, V3 d) {  // aggregate.rs:76-81 + the ray-constant part of the triangle test
+        ro = o;
+        inv_dir = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        sgn = (inv_dir.x < 0.0f ? 1u : 0u) | (inv_dir.y < 0.0f ? 2u : 0u) | (inv_dir.z < 0.0f ? 4u : 0u);
+        rs = ray_shear(d);
+        if (!TRI_ONLY) rd_full = d;
+    };
+    auto push = [&](uint32_t v) {
+        // two different store flavours, so that the compiler cannot merge them into one flat_store of a selected pointer
+        if (top < st_base + K3_LDS_N * WAVE) *top = v;
+        else st_spill_wave[(size_t)(top - (st_base + K3_LDS_N * WAVE)) + lane] = v;
+        top += WAVE;
+    };
 
     // Stack storage by level: [0, K3_LDS_N) in LDS, anything deeper in the per-lane HBM spill. (The first version kept
     // the LDS window at levels 6..31 and spilled the bottom levels: those are written at the start of every ray and again
@@ -97,16 +127,16 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
     uint32_t parts_left = n_parts;
     for (;;) {
         // ---- refill idle lanes from the wave-private chunk [w_next, w_end); one atomic per `chunk` rays ----
-        unsigned long long idle = __ballot(state == ST_IDLE);
+        const unsigned long long idle = __ballot(state == ST_IDLE);
         if (idle != 0ull) {
-            int n_idle = __popcll(idle);
+            const int n_idle = __popcll(idle);
             if (!exhausted && (n_idle >= refill_min || idle == ~0ull)) {
                 while (w_next >= w_end && !exhausted) {
                     const uint32_t p_begin = part * part_size;
                     const uint32_t p_end = (p_begin < n) ? ((n - p_begin < part_size) ? n : p_begin + part_size) : p_begin;
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(head + part * 32u, chunk);
-                    base = __shfl(base, 0);
+                    base = __builtin_amdgcn_readfirstlane(base);
                     if (base < p_end - p_begin) {
                         w_next = p_begin + base;
                         w_end = (p_end - w_next < chunk) ? p_end : w_next + chunk;
@@ -116,35 +146,30 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                     }
                 }
                 if (!exhausted) {
-                    uint32_t take = min((uint32_t)n_idle, w_end - w_next);
+                    const uint32_t take = min((uint32_t)n_idle, w_end - w_next);
                     if (state == ST_IDLE) {
                         // idle lanes below this one (v_mbcnt: no 64-bit lane mask to keep in registers)
-                        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                         if (rank < take) {
-                            uint32_t qi = w_next + rank;
+                            const uint32_t qi = w_next + rank;
                             path = queue ? queue[qi] : qi;
                             const float4* rp = reinterpret_cast<const float4*>(rays + path);
-                            float4 r0 = rp[0], r1 = rp[1];
-                            ro = v3(r0.x, r0.y, r0.z);
-                            V3 rd = v3(r0.w, r1.x, r1.y);
+                            const float4 r0 = rp[0], r1 = rp[1];
+                            set_ray(v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y));
                             t_max = r1.z;
-                            inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);  // aggregate.rs:76-81
-                            negx = inv_dir.x < 0.0f;
-                            negy = inv_dir.y < 0.0f;
-                            negz = inv_dir.z < 0.0f;
-                            rs = ray_shear(rd);
-                            if (!TRI_ONLY) rd_full = rd;
                             hit_prim = -1;
                             hit_inst = -1;
                             inst_slot = -1;
-                            sp = 0;
+                            top = st_base;
                             cur = 0;
-                            want_pop = false;
                             state = ST_NODE;
                         }
                     }
                     w_next += take;
                     w_rays += take;
+                    m_negx = __ballot((sgn & 1u) != 0u);
+                    m_negy = __ballot((sgn & 2u) != 0u);
+                    m_negz = __ballot((sgn & 4u) != 0u);
                 }
             }
             if (__ballot(state != ST_IDLE) == 0ull) {
@@ -152,88 +177,51 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                 continue;  // private chunk was empty: fetch the next one
             }
         }
-        // ---- one uniform node step ----
-        bool visited = false;
-        if (state == ST_NODE) {
-            bool go = true;
-            if (want_pop) {
-                want_pop = false;
-                if (sp == 0) { state = ST_DONE; go = false; }
-                else {
-                    sp--;
-                    // two different load flavours, so that the compiler cannot merge them into one flat_load of a selected
-                    // pointer (which waits on both the LDS and the vector-memory counter)
-                    if (sp < K3_LDS_N) cur = st_lds[sp * WAVE];
-                    else cur = __builtin_nontemporal_load(st_spill_wave + (size_t)(sp - K3_LDS_N) * WAVE + lane);
-                    if (!TRI_ONLY && cur == INST_SENTINEL) {
-                        // the instanced aggregate is exhausted: back to the ray of the enclosing tree (primitive.rs:158-171 returns);
-                        // t_max is the hit found inside (in the instance's parameterisation, as the reference keeps it) or what it was
-                        const float4* rp = reinterpret_cast<const float4*>(rays + path);
-                        float4 r0 = rp[0], r1 = rp[1];
-                        ro = v3(r0.x, r0.y, r0.z);
-                        V3 rd = v3(r0.w, r1.x, r1.y);
-                        inv_dir = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                        negx = inv_dir.x < 0.0f;
-                        negy = inv_dir.y < 0.0f;
-                        negz = inv_dir.z < 0.0f;
-                        rs = ray_shear(rd);
-                        rd_full = rd;
-                        if (!inst_hit) t_max = t_outer;
-                        inst_slot = -1;
-                        want_pop = true;
-                        go = false;
-                    }
-                }
-            }
-            if (go) {
-                // (a 32-bit byte offset on the uniform base: one shift and the scalar-base addressing mode; wf_trace_prepare checks the tree fits 4 GiB)
-                const float4* np = reinterpret_cast<const float4*>(node_base + (uint32_t)(cur << 5));
-                float4 na = np[0], nb = np[1];
-                visited = true;
-                // Bounds3f::intersect_p_cached (bounding_box.rs:520-563), signs held as lane masks
-                const Float g = 1.0f + 2.0f * gamma(3);
-                Float t0 = ((negx ? na.w : na.x) - ro.x) * inv_dir.x;
-                Float t1 = ((negx ? na.x : na.w) - ro.x) * inv_dir.x;
-                Float ty0 = ((negy ? nb.x : na.y) - ro.y) * inv_dir.y;
-                Float ty1 = ((negy ? na.y : nb.x) - ro.y) * inv_dir.y;
-                t1 *= g;
-                ty1 *= g;
-                bool hit_box = !(t0 > ty1 || ty0 > t1);
-                if (ty0 > t0) t0 = ty0;
-                if (ty1 < t1) t1 = ty1;
-                Float tz0 = ((negz ? nb.y : na.z) - ro.z) * inv_dir.z;
-                Float tz1 = ((negz ? na.z : nb.y) - ro.z) * inv_dir.z;
-                tz1 *= g;
-                hit_box = hit_box && !(t0 > tz1 || tz0 > t1);
-                if (tz0 > t0) t0 = tz0;
-                if (tz1 < t1) t1 = tz1;
-                hit_box = hit_box && (t0 < t_max) && (t1 > 0.0f);
-                uint32_t offset = __float_as_uint(nb.z);
-                uint32_t meta = __float_as_uint(nb.w);
-                uint32_t n_prims = meta & 0xffffu;
-                if (!hit_box) {
-                    want_pop = true;
-                } else if (n_prims > 0) {
-                    leaf_off = offset;
-                    leaf_n = n_prims;
-                    state = ST_LEAF;
-                } else {
-                    uint32_t axis = (meta >> 16) & 0xffu;
-                    bool neg = ((axis == 0) ? inv_dir.x : ((axis == 1) ? inv_dir.y : inv_dir.z)) < 0.0f;  // dir_is_neg[axis], from the component itself
-                    uint32_t far_child = neg ? cur + 1 : offset;   // aggregate.rs:119-127
-                    uint32_t near_child = neg ? offset : cur + 1;
-                    if (sp < K3_LDS_N) st_lds[sp * WAVE] = far_child;
-                    else st_spill_wave[(size_t)(sp - K3_LDS_N) * WAVE + lane] = far_child;
-                    sp++;
-                    cur = near_child;
-                }
+        // ---- one uniform node step: every lane with a node tests it (aggregate.rs:92-97) ----
+        bool need_pop = false;  // this step's outcome: the lane wants the next node from its stack (a miss, or a finished leaf below)
+        const bool at_node = state == ST_NODE;
+        w_nodes += (unsigned long long)__popcll(__ballot(at_node));  // (counted here: the compare's own lane mask, nothing to rebuild after the branch)
+        if (at_node) {
+            // (a 32-bit byte offset on the uniform base: one shift and the scalar-base addressing mode; wf_trace_prepare checks the tree fits 4 GiB)
+            const float4* np = reinterpret_cast<const float4*>(node_base + (uint32_t)(cur << 5));
+            const float4 na = np[0], nb = np[1];
+            // Bounds3f::intersect_p_cached (bounding_box.rs:520-563), the near / far plane of each axis chosen by the ray's sign masks
+            const Float g = 1.0f + 2.0f * gamma(3);
+            Float t0 = (sel_mask(m_negx, na.x, na.w) - ro.x) * inv_dir.x;
+            Float t1 = (sel_mask(m_negx, na.w, na.x) - ro.x) * inv_dir.x;
+            const Float ty0 = (sel_mask(m_negy, na.y, nb.x) - ro.y) * inv_dir.y;
+            Float ty1 = (sel_mask(m_negy, nb.x, na.y) - ro.y) * inv_dir.y;
+            t1 *= g;
+            ty1 *= g;
+            bool hit_box = !(t0 > ty1 || ty0 > t1);
+            if (ty0 > t0) t0 = ty0;
+            if (ty1 < t1) t1 = ty1;
+            const Float tz0 = (sel_mask(m_negz, na.z, nb.y) - ro.z) * inv_dir.z;
+            Float tz1 = (sel_mask(m_negz, nb.y, na.z) - ro.z) * inv_dir.z;
+            tz1 *= g;
+            hit_box = hit_box && !(t0 > tz1 || tz0 > t1);
+            if (tz0 > t0) t0 = tz0;
+            if (tz1 < t1) t1 = tz1;
+            hit_box = hit_box && (t0 < t_max) && (t1 > 0.0f);
+            const uint32_t offset = __float_as_uint(nb.z);
+            const uint32_t meta = __float_as_uint(nb.w);
+            const uint32_t n_prims = meta & 0xffffu;
+            // the three outcomes as selects, not branches: almost every step has lanes on each of them
+            const bool is_leaf = hit_box && n_prims != 0u;
+            need_pop = !hit_box;
+            leaf_off = is_leaf ? offset : leaf_off;
+            leaf_n = is_leaf ? n_prims : leaf_n;
+            state = is_leaf ? (uint32_t)ST_LEAF : state;
+            if (hit_box && n_prims == 0u) {
+                const bool neg = ((sgn >> ((meta >> 16) & 0xffu)) & 1u) != 0u;  // dir_is_neg[axis]
+                push(neg ? cur + 1 : offset);                                  // aggregate.rs:119-127: the far child waits, untested
+                cur = neg ? offset : cur + 1;
             }
         }
-        w_nodes += (unsigned long long)__popcll(__ballot(visited));
         // ---- postponed leaf phase ----
-        unsigned long long leaf_mask = __ballot(state == ST_LEAF);
+        const unsigned long long leaf_mask = __ballot(state == ST_LEAF);
         if (leaf_mask != 0ull) {
-            unsigned long long node_mask = __ballot(state == ST_NODE);
+            const unsigned long long node_mask = __ballot(state == ST_NODE && !need_pop);
             if (__popcll(leaf_mask) >= leaf_min || node_mask == 0ull) {
                 if (state == ST_LEAF) {
                     bool found_any = false;
@@ -249,22 +237,14 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                             // the ray into the instance's space — apply_ray_inverse for intersect, the FORWARD apply_ray for
                             // intersect_predicate, as the reference writes them — and go on in the instanced aggregate's tree.
                             const ShmInstance& in = sv.instances[__float_as_uint(q2.y) & PRIM_INDEX_MASK];
-                            if (sp < K3_LDS_N) st_lds[sp * WAVE] = INST_SENTINEL;
-                            else st_spill_wave[(size_t)(sp - K3_LDS_N) * WAVE + lane] = INST_SENTINEL;
-                            sp++;
+                            push(INST_SENTINEL);
                             t_outer = t_max;
                             inst_slot = (int32_t)slot;
                             inst_hit = false;
                             Ray r;
                             if (ANY) { Ray w; w.o = ro; w.d = rd_full; r = xf_ray(in.render_from_primitive, w); }
                             else r = xf_ray_inverse(in.primitive_from_render, ro, rd_full, t_max);
-                            ro = r.o;
-                            rd_full = r.d;
-                            inv_dir = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-                            negx = inv_dir.x < 0.0f;
-                            negy = inv_dir.y < 0.0f;
-                            negz = inv_dir.z < 0.0f;
-                            rs = ray_shear(r.d);
+                            set_ray(r.o, r.d);
                             cur = in.root_node;
                             entered = true;
                             break;
@@ -281,9 +261,12 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                                                 ld3(sv.patches[__float_as_uint(q2.y) & PRIM_INDEX_MASK].p11), bi);
                             if (got) { hit_prim = (int32_t)slot; t_max = bi.t; hit_b0 = bi.u; hit_b1 = bi.v; hit_b2 = 0.0f; hit_phi = 0.0f; }
                         } else {
+                            // (the precomputed degeneracy flag is applied to the RESULT: tested first, the compiler fetched the flag word,
+                            // waited, and only then fetched the vertices — two dependent round trips per leaf; degenerate triangles are rare
+                            // and the test itself has no side effect)
                             TriangleIntersection ti;
-                            got = !(__float_as_uint(q2.y) & PRIM_DEGENERATE_BIT) &&
-                                  intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
+                            got = intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
+                            got = got && !(__float_as_uint(q2.y) & PRIM_DEGENERATE_BIT);
                             if (got) { hit_prim = (int32_t)slot; t_max = ti.t; hit_b0 = ti.b0; hit_b1 = ti.b1; hit_b2 = ti.b2; hit_phi = 0.0f; }
                         }
                         if (got) {
@@ -292,16 +275,52 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                         }
                     }
                     if (!TRI_ONLY && entered) {
-                        state = ST_NODE;
-                        want_pop = false;
+                        state = ST_NODE;  // goes on at the instance's root
                     } else if (ANY && found_any) {
                         state = ST_DONE;
                     } else {
                         state = ST_NODE;
-                        want_pop = true;
+                        need_pop = true;
+                    }
+                }
+                if (!TRI_ONLY) {  // a lane may have entered an instance: its ray, and with it its signs, changed
+                    m_negx = __ballot((sgn & 1u) != 0u);
+                    m_negy = __ballot((sgn & 2u) != 0u);
+                    m_negz = __ballot((sgn & 4u) != 0u);
+                }
+            }
+        }
+        // ---- pop: a lane that missed its box, or is through with a leaf, takes the next node from its stack (aggregate.rs:129-135) ----
+        // (for TRI_ONLY = false the loop runs again for the rare lane that pops the marker of an instance it has finished)
+        while (__ballot(need_pop) != 0ull) {
+            bool again = false;
+            if (need_pop) {
+                need_pop = false;
+                if (top == st_base) state = ST_DONE;
+                else {
+                    top -= WAVE;
+                    // two different load flavours, so that the compiler cannot merge them into one flat_load of a selected
+                    // pointer (which waits on both the LDS and the vector-memory counter)
+                    if (top < st_base + K3_LDS_N * WAVE) cur = *top;
+                    else cur = __builtin_nontemporal_load(st_spill_wave + (size_t)(top - (st_base + K3_LDS_N * WAVE)) + lane);
+                    if (!TRI_ONLY && cur == INST_SENTINEL) {
+                        // the instanced aggregate is exhausted: back to the ray of the enclosing tree (primitive.rs:158-171 returns);
+                        // t_max is the hit found inside (in the instance's parameterisation, as the reference keeps it) or what it was
+                        const float4* rp = reinterpret_cast<const float4*>(rays + path);
+                        const float4 r0 = rp[0], r1 = rp[1];
+                        set_ray(v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y));
+                        if (!inst_hit) t_max = t_outer;
+                        inst_slot = -1;
+                        again = true;
                     }
                 }
             }
+            if (TRI_ONLY) break;
+            if (__ballot(again) == 0ull) break;
+            need_pop = again;
+            m_negx = __ballot((sgn & 1u) != 0u);
+            m_negy = __ballot((sgn & 2u) != 0u);
+            m_negz = __ballot((sgn & 4u) != 0u);
         }
         // ---- retire finished rays ----
         if (state == ST_DONE) {

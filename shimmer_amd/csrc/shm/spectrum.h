@@ -115,8 +115,10 @@ SHM_HD int find_interval(int size, Pred pred) {
 // RgbSigmoidPolynomial::get, color.rs:353-383: s(poly(lambda, [c2, c1, c0])). `poly` is the fast_polynomial 0.1.0 crate (source
 // not vendored: parity unpinned at that boundary); a three-coefficient Estrin / Horner evaluation with FMAs is
 // fma(x^2, c0, fma(x, c1, c2)), which is what is done here.
+// fast_polynomial::poly(x, [k0, k1, k2]) = k0 + k1 x + k2 x^2 (math.rs:563-570 pins poly(2, [1, 2, 3]) = 17), in the order defined above
+SHM_HD Float poly3(Float x, Float k0, Float k1, Float k2) { return fma(x * x, k2, fma(x, k1, k0)); }
 SHM_HD Float rgb_sigmoid(const Float c[3], Float lambda) {
-    Float x = fma(lambda * lambda, c[0], fma(lambda, c[1], c[2]));
+    Float x = poly3(lambda, c[2], c[1], c[0]);
     if (is_inf(x)) return x > 0.0f ? 1.0f : 0.0f;
     return 0.5f + x / (2.0f * sqrt(1.0f + x * x));
 }

@@ -29,10 +29,13 @@ def test_cpu_suite_under_asan_and_ubsan():
     subprocess.run(["make", "-C", str(ROOT / "oracle"), "asan"], check=True, capture_output=True)
     env = dict(os.environ, LD_PRELOAD=libasan + (" " + libstdcxx if libstdcxx and Path(libstdcxx).exists() else ""), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1",
                ORACLE_LIB=str(ROOT / "oracle" / "_build" / "liboracle_asan.so"), SHM_LIB=str(ROOT / "oracle" / "_build" / "libhostmirror_asan.so"),
-               SHM_HOST_ONLY="1", SHM_RGB2SPEC_SRGB=str(ROOT / "shimmer_amd" / "data" / "rgb2spec_srgb_res64.spec"))  # (the loader's default is beside the PRODUCT library)
+               SHM_HOST_ONLY="1",  # (the loader's default place for the tables is beside the PRODUCT library: name them for this build)
+               SHM_RGB2SPEC_SRGB=str(ROOT / "shimmer_amd" / "data" / "rgb2spec_srgb_res64.spec"),
+               SHM_RGB2SPEC_REC2020=str(ROOT / "shimmer_amd" / "data" / "rgb2spec_rec2020_res64.spec"),
+               SHM_RGB2SPEC_ACES2065_1=str(ROOT / "shimmer_amd" / "data" / "rgb2spec_aces2065_1_res64.spec"))
     # everything that runs without a device entry point (those live in shimmer_hip.hip, which only hipcc builds)
     files = ["test_oracle_golden.py", "test_textures.py", "test_image_light.py", "test_instancing.py", "test_ply.py", "test_layered.py",
-             "test_bilinear_patch.py", "test_spectra.py", "test_fuzz_scenes.py", "test_golden_films.py", "test_oracle_render.py", "test_host_mirror.py", "test_pbrt_loader.py", "test_leaf_golden.py", "test_image_io.py"]
+             "test_bilinear_patch.py", "test_spectra.py", "test_color_spaces.py", "test_reference_loader_vectors.py", "test_bvh_independent.py", "test_quirks_switch.py", "test_fuzz_scenes.py", "test_golden_films.py", "test_oracle_render.py", "test_host_mirror.py", "test_pbrt_loader.py", "test_leaf_golden.py", "test_image_io.py"]
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "not gpu", "-p", "no:cacheprovider",
            "-k", "not exports_every_declared and not no_device and not integrator_mirror_errors"] + [str(ROOT / "tests" / f) for f in files]
     r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=1500)

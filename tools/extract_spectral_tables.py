@@ -18,7 +18,7 @@ COLOR = Path("/root/reference/src/color.rs")    # SRGB_TO_LINEAR_LUT: the 256 ta
 OUT = Path(__file__).resolve().parents[1] / "shimmer_amd" / "data" / "spectral_tables.npz"
 WANT = {
     "cie.rs": ["CIE_LAMBDA", "CIE_X", "CIE_Y", "CIE_Z"],
-    "named_spectrum.rs": ["CIE_ILLUM_D6500", "GLASS_BK7_ETA_SAMPLES", "GLASS_BAF10_ETA_SAMPLES", "GLASS_F11_ETA_SAMPLES",
+    "named_spectrum.rs": ["CIE_ILLUM_D6500", "ACES_ILLUM_D60", "GLASS_BK7_ETA_SAMPLES", "GLASS_BAF10_ETA_SAMPLES", "GLASS_F11_ETA_SAMPLES",
                           "CU_ETA_SAMPLES", "CU_K_SAMPLES", "AU_ETA_SAMPLES", "AU_K_SAMPLES", "AG_ETA_SAMPLES",
                           "AG_K_SAMPLES", "AL_ETA_SAMPLES", "AL_K_SAMPLES", "CIE_S_LAMBDA", "CIE_S0", "CIE_S1", "CIE_S2"],
 }
