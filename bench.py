@@ -124,14 +124,21 @@ def counter_blocks(c, avg_launch_ms):
         n_simd, n_xcd = 256 * 4, 8
         cycles = c["GRBM_GUI_ACTIVE"] / n_xcd                       # GRBM_GUI_ACTIVE is summed over the 8 XCDs
         busy = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (n_simd * cycles)   # quad-cycles of VALU issue per SIMD over the kernel's cycles
-        valu = {"kernel": "k_trace3<closest>", "valu_busy_frac": busy, "lanes_per_valu_inst": lanes, "lane_throughput_frac": busy * lanes / 64.0 if lanes else None,
+        # measured issue rates (tools/ubench/valu_rate.hip -> profiles/r03_valu_issue_rates.txt, >= 2 waves per SIMD): v_add / v_mul / v_fma /
+        # v_add_u32 / v_mov 2.4 clocks per wave64 instruction; v_cndmask (SGPR mask) / v_cmp -> SGPR / v_pk_* / v_lshl_add / v_max 4.2; v_rcp 8.2
+        valu = {"kernel": "k_trace3<closest>", "valu_busy_frac": busy, "valu_busy_frac_if_all_2p4_clock_ops": busy * 2.4 / 4.0,
+                "lanes_per_valu_inst": lanes, "lane_throughput_frac": busy * lanes / 64.0 if lanes else None,
                 "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "active_inst_valu_quadcycles_per_launch": c["SQ_ACTIVE_INST_VALU"],
                 "gpu_cycles_per_launch": cycles, "effective_clock_GHz": cycles / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms else None,
+                "issue_rate_assumed_clocks_per_inst": 4.0, "issue_rate_measured_clocks_per_inst": {"simple f32 / int (add, mul, fma, mov)": 2.4,
+                                                                                                     "select / compare-to-SGPR / packed / 3-operand": 4.2, "rcp": 8.2},
                 "definitions": "valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): SQ_ACTIVE_INST_* count quad-cycles "
-                               "(MI355X_MICROARCH.md, 's_memtime tick vs SQ PMC units') and one wave64 VALU instruction is taken to occupy its SIMD's issue "
-                               "port for one quad-cycle (4 clocks; SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 in this kernel). The guide's 2-clock wave64 "
-                               "v_fma_f32 rate would halve the fraction: read it as +-2x. lanes_per_valu_inst = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; "
-                               "lane_throughput_frac = busy x lanes / 64"}
+                               "(MI355X_MICROARCH.md, 's_memtime tick vs SQ PMC units'); the counter charges every VALU instruction one quad-cycle "
+                               "(SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 in this kernel), so the fraction prices each at 4 clocks. Measured on this "
+                               "part (profiles/r03_valu_issue_rates.txt) a wave64 instruction holds the SIMD 2.4 clocks (add / mul / fma / mov) or 4.2 "
+                               "(v_cndmask with an SGPR mask, v_cmp to an SGPR pair, packed f32, three-operand integer): the slab test is mostly the second "
+                               "kind, so the port's true busy fraction lies between valu_busy_frac_if_all_2p4_clock_ops and valu_busy_frac. "
+                               "lanes_per_valu_inst = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; lane_throughput_frac = busy x lanes / 64"}
     return traffic, lanes, valu
 
 

@@ -21,73 +21,22 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters, int shadow_parity) {
     const uint32_t n = qs->n_active[cur];
-    __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK], s_work[SHADE_CHUNK];
-    __shared__ uint32_t s_cnt[3], s_base[2];
+    __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
+    __shared__ uint32_t s_cnt[2], s_base[2];
     for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
-      if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; }
+      if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
       __syncthreads();
-      // ---- pass A: split the chunk. An escaped ray (integrator.rs:776-794) only meets the infinite lights — nothing at all in a scene without
-      // them — while a hit runs the whole vertex; left interleaved as K2 wrote them, a quarter of the lanes of the headline frame sat out the
-      // vertex code (48 of 64 lanes per VALU instruction, profiles/r02_final_spp256.txt). The hits are compacted into an LDS work list and
-      // worked through with full waves in pass B; the misses are finished here.
       for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
         const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
-        bool is_hit = false;
-        uint32_t path = 0;
-        if (i < n) {
-            path = q_cur[i];
-            const int32_t prim = pa.hit[path].prim;
-            is_hit = prim >= 0;
-            if (!is_hit && sv.n_infinite_lights != 0u) {
-                const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
-                const float4 r0 = rp[0], r1 = rp[1];
-                const V3 ray_d = v3(r0.w, r1.x, r1.y);
-                const Spec beta = ld_spec(pa.beta[path]);
-                Wavelengths lambda;
-                const float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
-                lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
-                lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
-                const uint32_t fl = pa.flags[path];
-                const int depth = (int)(fl & 0xffu);
-                const bool specular_bounce = (fl >> 8) & 1u;
-                Spec Lacc = ld_spec(pa.L[path]);  // L += term per light, each added in turn as the reference does
-                for (uint32_t q = 0; q < sv.n_infinite_lights; ++q) {
-                    const ShmLight& light = sv.lights[sv.infinite_lights[q]];
-                    const Spec le = infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda);
-                    if (depth == 0 || specular_bounce) {
-                        Lacc = Lacc + beta * le;
-                    } else {
-                        LightSampleContext c;
-                        const float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path];
-                        c.pi.x = iv2(c0.x, c0.w); c.pi.y = iv2(c0.y, c1.x); c.pi.z = iv2(c0.z, c1.y);
-                        c.n = v3(c1.z, c1.w, c2.x);
-                        c.ns = v3(c2.y, c2.z, c2.w);
-                        const Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, c, ray_d);
-                        const Float w_b = power_heuristic(1, pa.pb_eta[path].x, 1, p_l);
-                        Lacc = Lacc + beta * w_b * le;
-                    }
-                }
-                pa.L[path] = st_spec(Lacc);
-            }
-        }
-        const uint32_t w = queue_push_slot(&s_cnt[2], is_hit);
-        if (is_hit) s_work[w] = path;
-      }
-      __syncthreads();
-      const uint32_t n_work = s_cnt[2];
-      // ---- pass B: one whole path vertex per entry of the work list ----
-      for (uint32_t j0 = 0; j0 < n_work; j0 += SHADE2_BLOCK) {
-        const uint32_t j = j0 + threadIdx.x;
-        bool active = j < n_work;
+        bool active = i < n;
         bool push_next = false, push_shadow = false;
         uint32_t path = 0;
         if (active) {
-            path = s_work[j];
+            path = q_cur[i];
             const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
             float4 h0 = hp[0], h1 = hp[1];
             Hit hit;
             hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
-            __builtin_assume(hit.prim >= 0);
             const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
             float4 r0 = rp[0], r1 = rp[1];
             V3 ray_d = v3(r0.w, r1.x, r1.y);
@@ -119,7 +68,20 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                 c.ns = v3(c2.y, c2.z, c2.w);
                 return c;
             };
-            {
+            if (hit.prim < 0) {
+                // integrator.rs:776-794: escaped ray, infinite lights
+                for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
+                    const ShmLight& light = sv.lights[sv.infinite_lights[k]];
+                    Spec le = infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda);
+                    if (depth == 0 || specular_bounce) {
+                        add_l(beta * le);
+                    } else {
+                        Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
+                        Float w_b = power_heuristic(1, p_b, 1, p_l);
+                        add_l(beta * w_b * le);
+                    }
+                }
+            } else {
                 SurfaceInteraction si = hit_interaction<TRI_ONLY>(sv, hit, -ray_d);
                 const ShmPrimitive prim = sv.primitives[hit.prim];
                 // integrator.rs:798-813: emission at the hit

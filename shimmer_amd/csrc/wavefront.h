@@ -186,7 +186,7 @@ struct ShmScene {
     uint32_t* d_spill3_any = nullptr;  // the any-hit kernel may run concurrently with the closest-hit one (second stream)
     hipStream_t stream2 = nullptr;
     uint64_t overlap_paths = 96ull << 20;  // batches below this many paths run K3(b) beside K2(b+1) (SHM_OVERLAP_PATHS; 0 = never)
-    int refill_min = 16;
+    int refill_min = 24;           // idle lanes before a wave refills (SHM_REFILL_MIN; r03 sweep on the rewritten kernel: 8 / 16 / 24 = 354 / 348 / 346 ms per frame)
     uint32_t pix_group = 1024;      // path-slot order [tile][sample][pixel in tile] (SHM_PIX_GROUP; >= n_pix: sample-major)
     int queue_parts = 8;           // k_trace3 queue partitions, one per XCD with stealing (SHM_QUEUE_PARTS: 1 or 8)
     uint32_t* d_heads3 = nullptr;  // [2 (closest, any)][8 partitions][32 dwords: one 128-B line per head word]

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(1024) k_rate(float* out, unsigned long long* c
 #define OP_LSHL(k) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(r##k) : "v"(p##k));
 #define OP_MAX(k) asm volatile("v_max_f32 %0, %0, %1" : "+v"(r##k) : "v"(p##k));
 #define OP_RCP(k) asm volatile("v_rcp_f32 %0, %0" : "+v"(r##k));
-#define OP_SAND(k) asm volatile("s_and_b64 %0, %0, %1" : "+s"(s0) : "s"(s1));
+#define OP_SAND(k) asm volatile("s_and_b64 %0, %0, %1" : "+s"(s0) : "s"(s1) : "scc");  // (SCC declared: without it the loop's own compare was clobbered and the kernel never ended)
         if (KIND == FMA) { REP64(OP_FMA) }
         else if (KIND == ADD) { REP64(OP_ADD) }
         else if (KIND == MUL) { REP64(OP_MUL) }
@@ -74,7 +74,8 @@ static void run(int waves_per_simd, int iters, float* d_out, unsigned long long*
     hipEventRecord(e0);
     hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(block), 0, 0, d_out, d_cyc, iters, 1.0f);
     hipEventRecord(e1);
-    hipDeviceSynchronize();
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("%s: %s\n", kNames[KIND], hipGetErrorString(e)); exit(1); }
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> c((size_t)grid * block / 64);
@@ -90,10 +91,10 @@ static void run(int waves_per_simd, int iters, float* d_out, unsigned long long*
 }
 
 int main() {
+    setvbuf(stdout, NULL, _IONBF, 0);  // every line as it is measured (run it under `timeout`: a first version never returned on the GPU box)
     float* d_out; unsigned long long* d_cyc;
-    hipMalloc(&d_out, 256 * 1024 * sizeof(float));
-    hipMalloc(&d_cyc, 256 * 16 * 8);
-    const int iters = 4096;
+    if (hipMalloc(&d_out, 256 * 1024 * sizeof(float)) != hipSuccess || hipMalloc(&d_cyc, 256 * 16 * 8) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+    const int iters = 512;
     for (int w : {1, 2, 4}) {
         run<FMA>(w, iters, d_out, d_cyc); run<ADD>(w, iters, d_out, d_cyc); run<MUL>(w, iters, d_out, d_cyc); run<CNDMASK_SGPR>(w, iters, d_out, d_cyc);
         run<CMP_SGPR>(w, iters, d_out, d_cyc); run<PK_MUL>(w, iters, d_out, d_cyc); run<PK_ADD>(w, iters, d_out, d_cyc); run<MOV>(w, iters, d_out, d_cyc);
