@@ -344,9 +344,22 @@ def rank_main(args):
     if use_dist:
         # the library's own RCCL communicator: rank 0 draws the unique id, the file store carries its 128 bytes; a rank that cannot get
         # this far publishes its failure in the store (main()), and a watchdog bounds ncclCommInitRank, which waits for every rank
-        with launch.Watchdog(args.init_timeout, "id exchange + shm_dist_init (ncclCommInitRank)", store):
-            uid = store.broadcast("rccl_unique_id", r.dist_unique_id() if rank == 0 else None)
-            r.dist_init(rank, world, uid)
+        # (RCCL prints its version banner through C stdio on stdout when the communicator is made: stdout belongs to the ONE JSON line, so
+        #  file descriptor 1 points at stderr while the communicator is being set up)
+        import ctypes
+        libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            with launch.Watchdog(args.init_timeout, "id exchange + shm_dist_init (ncclCommInitRank)", store):
+                uid = store.broadcast("rccl_unique_id", r.dist_unique_id() if rank == 0 else None)
+                r.dist_init(rank, world, uid)
+                r.dist_barrier()  # the first collective, still with the banner going to stderr
+        finally:
+            libc.fflush(None)
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     info = r.dist_info()
     if rank == 0:
         log(f"[bench] runtime: librccl {info['librccl_path']} (RCCL {info['rccl_version']}), libamdhip64 {info['libamdhip_path']} (HIP {info['hip_runtime_version']}); "

@@ -288,6 +288,7 @@ void shm_scene_destroy(ShmScene* s) {
     if (s->d_pixels) hipFree(s->d_pixels);
     for (hipEvent_t e : s->events) hipEventDestroy(e);
     if (s->stream2) hipStreamDestroy(s->stream2);
+    for (hipStream_t st : s->stream_cls) if (st) hipStreamDestroy(st);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
 }
@@ -312,6 +313,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
     if (hipStreamCreate(&s->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; return fail(SHM_ERR_DEVICE); }
     if (hipStreamCreate(&s->stream2) != hipSuccess) { g_err = "hipStreamCreate failed"; return fail(SHM_ERR_DEVICE); }
+    for (hipStream_t& st : s->stream_cls) if (hipStreamCreate(&st) != hipSuccess) { g_err = "hipStreamCreate failed"; return fail(SHM_ERR_DEVICE); }
     if (const char* e = getenv("SHM_OVERLAP_PATHS")) { long long v2 = atoll(e); if (v2 >= 0) s->overlap_paths = (uint64_t)v2; }
 
     const shm_host::FlatScene& f = s->flat;
@@ -368,6 +370,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     // Tuning knobs (development): defaults are the measured optimum on S3
     if (const char* e = getenv("SHM_PIX_GROUP")) { long long v2 = atoll(e); if (v2 >= 1) s->pix_group = (uint32_t)std::min<long long>(v2, 0x7fffffffll); }
     if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
+    if (const char* e = getenv("SHM_CONCURRENT_SCATTER")) s->concurrent_scatter = atoi(e) != 0;
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = v2; }
     if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) s->trace3_per_cu_override = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
@@ -535,11 +538,38 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     // class the scene holds, each over its own material-sorted queue
                     const bool has_tex = s->flat.has_textures;
                     rc = has_tex ? wf_launch_vertex_tex(s, sa) : (tri_only ? wf_launch_vertex_tri(s, sa) : wf_launch_vertex_gen(s, sa));
-                    if (rc == SHM_OK && s->flat.has_class[CLASS_DIFFUSE]) rc = wf_launch_scatter_diffuse(s, sa, tri_only, has_tex);
-                    if (rc == SHM_OK && s->flat.has_class[CLASS_CONDUCTOR]) rc = wf_launch_scatter_conductor(s, sa, tri_only, has_tex);
-                    if (rc == SHM_OK && s->flat.has_class[CLASS_DIELECTRIC]) rc = wf_launch_scatter_dielectric(s, sa, tri_only, has_tex);
-                    if (rc == SHM_OK && s->flat.has_class[CLASS_LAYERED])
-                        rc = has_tex ? wf_launch_scatter_layered_tex(s, sa) : (tri_only ? wf_launch_scatter_layered_tri(s, sa) : wf_launch_scatter_layered_gen(s, sa));
+                    // The classes' scatter kernels are independent of each other (own queue each, disjoint paths, wave-aggregated atomics on the
+                    // shared next / shadow queues): the first runs on the render stream, the others beside it on their own streams, and the render
+                    // stream waits for them. With large queues each fills the device and they simply share it; in the late bounces of deep paths
+                    // (profiles/r03_c4_per_bounce.txt: 1-3 M rays per bounce, four shading launches of 0.4-0.6 ms each) they overlap.
+                    int n_cls = 0;
+                    for (int c = 0; c < N_BXDF_CLASSES; ++c) n_cls += s->flat.has_class[c] ? 1 : 0;
+                    hipEvent_t vertex_done = nullptr;
+                    if (s->concurrent_scatter && n_cls > 1) { vertex_done = ev.get(); hipEventRecord(vertex_done, s->stream); }  // (before the first class's launch)
+                    std::vector<hipEvent_t> side_done;
+                    int k_cls = 0;
+                    auto scatter_on = [&](int cls, auto&& launch) {
+                        if (rc != SHM_OK || !s->flat.has_class[cls]) return;
+                        ShadeArgs sc = sa;
+                        const bool side = k_cls > 0 && vertex_done != nullptr;
+                        if (side) {
+                            sc.stream = s->stream_cls[k_cls - 1];
+                            hipStreamWaitEvent(sc.stream, vertex_done, 0);
+                        }
+                        rc = launch(sc);
+                        if (side && rc == SHM_OK) {
+                            hipEvent_t done = ev.get();
+                            hipEventRecord(done, sc.stream);
+                            side_done.push_back(done);
+                        }
+                        ++k_cls;
+                    };
+                    scatter_on(CLASS_DIFFUSE, [&](const ShadeArgs& x) { return wf_launch_scatter_diffuse(s, x, tri_only, has_tex); });
+                    scatter_on(CLASS_CONDUCTOR, [&](const ShadeArgs& x) { return wf_launch_scatter_conductor(s, x, tri_only, has_tex); });
+                    scatter_on(CLASS_DIELECTRIC, [&](const ShadeArgs& x) { return wf_launch_scatter_dielectric(s, x, tri_only, has_tex); });
+                    scatter_on(CLASS_LAYERED, [&](const ShadeArgs& x) {
+                        return has_tex ? wf_launch_scatter_layered_tex(s, x) : (tri_only ? wf_launch_scatter_layered_tri(s, x) : wf_launch_scatter_layered_gen(s, x)); });
+                    for (hipEvent_t e : side_done) hipStreamWaitEvent(s->stream, e, 0);
                 }
                 else if (random_walk) rc = wf_launch_shade_randomwalk(s, sa, cap_eff);
                 else if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH) rc = wf_launch_shade_simple(s, sa);
