@@ -540,12 +540,13 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     rc = has_tex ? wf_launch_vertex_tex(s, sa) : (tri_only ? wf_launch_vertex_tri(s, sa) : wf_launch_vertex_gen(s, sa));
                     // The classes' scatter kernels are independent of each other (own queue each, disjoint paths, wave-aggregated atomics on the
                     // shared next / shadow queues): the first runs on the render stream, the others beside it on their own streams, and the render
-                    // stream waits for them. With large queues each fills the device and they simply share it; in the late bounces of deep paths
-                    // (profiles/r03_c4_per_bounce.txt: 1-3 M rays per bounce, four shading launches of 0.4-0.6 ms each) they overlap.
+                    // stream waits for them — for small batches only (the same threshold as the K3 / K2 overlap above), where the launches are
+                    // tail-dominated: textured Cornell 512^2 x 64 1 376 -> 1 486 Mray/s. With large queues each kernel fills the device by itself and
+                    // sharing it costs (coated S3 at 256 spp 1 944 -> 1 864), and C4's late bounces did not gain (2 044 either way).
                     int n_cls = 0;
                     for (int c = 0; c < N_BXDF_CLASSES; ++c) n_cls += s->flat.has_class[c] ? 1 : 0;
                     hipEvent_t vertex_done = nullptr;
-                    if (s->concurrent_scatter && n_cls > 1) { vertex_done = ev.get(); hipEventRecord(vertex_done, s->stream); }  // (before the first class's launch)
+                    if (s->concurrent_scatter && overlap && n_cls > 1) { vertex_done = ev.get(); hipEventRecord(vertex_done, s->stream); }  // (before the first class's launch)
                     std::vector<hipEvent_t> side_done;
                     int k_cls = 0;
                     auto scatter_on = [&](int cls, auto&& launch) {

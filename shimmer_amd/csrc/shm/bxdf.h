@@ -432,7 +432,12 @@ SHM_HD uint32_t base_flags(const BaseBxDF& b) {
 #ifndef SHM_BASE_BXDF_CALL
 #define SHM_BASE_BXDF_CALL SHM_HD
 #endif
-SHM_BASE_BXDF_CALL Spec base_f(const BaseBxDF& b, V3 wo, V3 wi, int mode = MODE_RADIANCE) {
+// As real calls the dispatchers take the interface BY VALUE and return their result by value: aggregates of up to 64 bytes travel in registers
+// under the AMDGPU calling convention (BaseBxDF is 48 B, a BSDFSample with its flag 48 B), while a `const BaseBxDF&` or a `BSDFSample&` has to
+// live in scratch memory — which is what round 2's layered scatter kernel did at every one of its ~30 call sites (416-464 B of scratch per
+// lane, 7 GB written per launch: profiles/r02_staged_S3c.txt). The reference-shaped signatures below are inline wrappers.
+struct BSDFSampleOpt { BSDFSample s; uint32_t ok; };
+SHM_BASE_BXDF_CALL Spec base_f_v(BaseBxDF b, V3 wo, V3 wi, int mode) {
     switch (b.kind) {
         case SHM_MATERIAL_DIFFUSE: return diffuse_f(b, wo, wi);
         case SHM_MATERIAL_CONDUCTOR: return conductor_f(b, wo, wi);
@@ -440,15 +445,20 @@ SHM_BASE_BXDF_CALL Spec base_f(const BaseBxDF& b, V3 wo, V3 wi, int mode = MODE_
         default: return spec_const(0.0f);
     }
 }
-SHM_BASE_BXDF_CALL bool base_sample_f(const BaseBxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out, int mode = MODE_RADIANCE) {
+SHM_BASE_BXDF_CALL BSDFSampleOpt base_sample_f_v(BaseBxDF b, V3 wo, Float uc, V2 u, uint32_t sample_flags, int mode) {
+    BSDFSampleOpt r;
+    r.s = bsdf_sample(spec_const(0.0f), v3s(0.0f), 0.0f, 0u);
+    bool ok;
     switch (b.kind) {
-        case SHM_MATERIAL_DIFFUSE: return diffuse_sample_f(b, wo, u, sample_flags, out);
-        case SHM_MATERIAL_CONDUCTOR: return conductor_sample_f(b, wo, u, sample_flags, out);
-        case SHM_MATERIAL_DIELECTRIC: return dielectric_sample_f(b, wo, uc, u, sample_flags, out, mode);
-        default: return thin_dielectric_sample_f(b, wo, uc, sample_flags, out);
+        case SHM_MATERIAL_DIFFUSE: ok = diffuse_sample_f(b, wo, u, sample_flags, r.s); break;
+        case SHM_MATERIAL_CONDUCTOR: ok = conductor_sample_f(b, wo, u, sample_flags, r.s); break;
+        case SHM_MATERIAL_DIELECTRIC: ok = dielectric_sample_f(b, wo, uc, u, sample_flags, r.s, mode); break;
+        default: ok = thin_dielectric_sample_f(b, wo, uc, sample_flags, r.s); break;
     }
+    r.ok = ok ? 1u : 0u;
+    return r;
 }
-SHM_BASE_BXDF_CALL Float base_pdf(const BaseBxDF& b, V3 wo, V3 wi, uint32_t sample_flags) {
+SHM_BASE_BXDF_CALL Float base_pdf_v(BaseBxDF b, V3 wo, V3 wi, uint32_t sample_flags) {
     switch (b.kind) {
         case SHM_MATERIAL_DIFFUSE: return diffuse_pdf(b, wo, wi, sample_flags);
         case SHM_MATERIAL_CONDUCTOR: return conductor_pdf(b, wo, wi, sample_flags);
@@ -456,6 +466,13 @@ SHM_BASE_BXDF_CALL Float base_pdf(const BaseBxDF& b, V3 wo, V3 wi, uint32_t samp
         default: return 0.0f;
     }
 }
+SHM_HD Spec base_f(const BaseBxDF& b, V3 wo, V3 wi, int mode = MODE_RADIANCE) { return base_f_v(b, wo, wi, mode); }
+SHM_HD bool base_sample_f(const BaseBxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out, int mode = MODE_RADIANCE) {
+    const BSDFSampleOpt r = base_sample_f_v(b, wo, uc, u, sample_flags, mode);
+    if (r.ok) out = r.s;   // (a failed sample leaves `out` as it was, as the by-reference form did)
+    return r.ok != 0u;
+}
+SHM_HD Float base_pdf(const BaseBxDF& b, V3 wo, V3 wi, uint32_t sample_flags) { return base_pdf_v(b, wo, wi, sample_flags); }
 
 // ---- Henyey-Greenstein, scattering.rs:231-260; HGPhaseFunction, media.rs:8-40 (p == pdf) ----
 SHM_HD Float henyey_greenstein(Float cos_theta, Float g) {
