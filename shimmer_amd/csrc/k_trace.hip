@@ -48,7 +48,7 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                                             ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
                                             float4* __restrict__ L, const float4* __restrict__ contrib,
                                             DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
-                                            int refill_min, int leaf_min, int queue_parts) {
+                                            int refill_min, int leaf_min, int queue_parts, int rays_per_lane) {
     constexpr int K3_LDS_N = LDS_N;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     __shared__ uint32_t lds_stack[(TRACE_BLOCK / WAVE) * K3_LDS_N * WAVE];
@@ -62,6 +62,16 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
     // (wave-uniform base; the lane offset is added where a spill level is touched — rare — instead of living in two VGPRs)
     uint32_t* const st_spill_wave = spill + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE;
     const uint32_t n = n_ptr ? *n_ptr : n_direct;
+    // A small queue is traced by a part of the persistent grid: with only a ray or two per resident lane a launch is all ramp — every wave
+    // takes one 64-ray chunk, the rays end at different times, and most iterations run with a few lanes. The first blocks of the grid
+    // (dispatched breadth first over the CUs) take all the rays, the others return at once; a launch of more than rays_per_lane x the
+    // grid's lanes is unchanged. It pays where rays are short (Cornell box, 16 nodes per ray: 16.8 -> 16.1 ms per frame at 4 rays per lane)
+    // and not where one ray is a long dependent chain (C4's late bounces, 71 nodes per ray, want every wave they can get: larger values
+    // cost there) — profiles/r03_trace_rays_per_lane_sweep.txt.
+    const uint32_t per_block = (uint32_t)TRACE_BLOCK * (uint32_t)(rays_per_lane > 0 ? rays_per_lane : 1);
+    const uint32_t blocks_wanted = rays_per_lane > 0 ? (n + per_block - 1u) / per_block : gridDim.x;
+    const uint32_t active_blocks = blocks_wanted < 64u ? (gridDim.x < 64u ? gridDim.x : 64u) : (blocks_wanted < gridDim.x ? blocks_wanted : gridDim.x);
+    if (blockIdx.x >= active_blocks) return;
     const char* __restrict__ node_base = reinterpret_cast<const char*>(sv.nodes);
     const char* __restrict__ prim_base = reinterpret_cast<const char*>(sv.prim_recs);
     // visit counters: rays and node visits are counted per wave in scalar registers (one popcount of the lanes that took the step), only the
@@ -74,7 +84,7 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
     uint32_t w_next = 0, w_end = 0;  // wave-uniform private range of the queue (scalar registers: readfirstlane of the claimed base)
     // chunk size: large enough that the single head word sees few atomics (it saturates near 88 dequeues/us,
     // MI355X_MICROARCH.md "dequeue"), small enough that the last chunks balance across the resident waves
-    const uint32_t n_waves = gridDim.x * (TRACE_BLOCK / WAVE);
+    const uint32_t n_waves = active_blocks * (TRACE_BLOCK / WAVE);
     uint32_t chunk = n / (n_waves * 8u);
     chunk = chunk < 64u ? 64u : (chunk > (uint32_t)K3_CHUNK_MAX ? (uint32_t)K3_CHUNK_MAX : chunk);
     chunk = (chunk + 63u) & ~63u;
@@ -358,8 +368,8 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
 #define K3_PARAMS SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_direct, uint32_t* head,                    \
                   const ShmRay* __restrict__ rays, ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out, float4* __restrict__ L,                 \
                   const float4* __restrict__ contrib, DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels, int refill_min, int leaf_min, \
-                  int queue_parts
-#define K3_ARGS sv, queue, n_ptr, n_direct, head, rays, hits, occluded_out, L, contrib, counters, spill, spill_levels, refill_min, leaf_min, queue_parts
+                  int queue_parts, int rays_per_lane
+#define K3_ARGS sv, queue, n_ptr, n_direct, head, rays, hits, occluded_out, L, contrib, counters, spill, spill_levels, refill_min, leaf_min, queue_parts, rays_per_lane
 template <bool ANY, bool TRI_ONLY> struct K3Shape;  // {LDS levels, workgroups per CU} of each entry point
 template <> struct K3Shape<false, true> { static constexpr int LDS = 22, PER_CU = 7; };
 template <> struct K3Shape<true, true> { static constexpr int LDS = 19, PER_CU = 8; };
@@ -410,7 +420,7 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
     const bool tri_only = !s->flat.has_spheres;
 #define TRACE_LAUNCH(ANY, TRI)                                                                                                                   \
     hipLaunchKernelGGL((k_trace3<ANY, TRI>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
-                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], s->refill_min, leaf_min, s->queue_parts)
+                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], s->refill_min, leaf_min, s->queue_parts, s->trace_rays_per_lane)
     if (any) { if (tri_only) TRACE_LAUNCH(true, true); else TRACE_LAUNCH(true, false); }
     else { if (tri_only) TRACE_LAUNCH(false, true); else TRACE_LAUNCH(false, false); }
 #undef TRACE_LAUNCH

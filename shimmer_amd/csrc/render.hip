@@ -370,6 +370,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     // Tuning knobs (development): defaults are the measured optimum on S3
     if (const char* e = getenv("SHM_PIX_GROUP")) { long long v2 = atoll(e); if (v2 >= 1) s->pix_group = (uint32_t)std::min<long long>(v2, 0x7fffffffll); }
     if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
+    if (const char* e = getenv("SHM_TRACE_RAYS_PER_LANE")) { int v2 = atoi(e); if (v2 >= 0 && v2 <= 4096) s->trace_rays_per_lane = v2; }
     if (const char* e = getenv("SHM_CONCURRENT_SCATTER")) s->concurrent_scatter = atoi(e) != 0;
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = v2; }
     if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) s->trace3_per_cu_override = v2; }

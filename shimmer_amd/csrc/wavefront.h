@@ -189,6 +189,8 @@ struct ShmScene {
     hipStream_t stream_cls[3] = {nullptr, nullptr, nullptr};  // staged shading: the scatter kernels of the 2nd .. 4th BxDF class of a bounce run beside the first one's
     uint64_t overlap_paths = 96ull << 20;  // batches below this many paths run K3(b) beside K2(b+1) (SHM_OVERLAP_PATHS; 0 = never)
     int refill_min = 24;           // idle lanes before a wave refills (SHM_REFILL_MIN; r03 sweep on the rewritten kernel: 8 / 16 / 24 = 354 / 348 / 346 ms per frame)
+    int trace_rays_per_lane = 4;   // a traversal launch uses as much of its persistent grid as gives each resident lane about this many rays (SHM_TRACE_RAYS_PER_LANE; 0 = always
+                                   // the whole grid). profiles/r03_trace_rays_per_lane_sweep.txt: C2 16.8 / 16.1 / 15.8 / 15.8 / 16.5 ms at 0 / 4 / 8 / 16 / 32, C4's K2 276.7 / 276.8 / 282 / 307 / 362
     uint32_t pix_group = 1024;      // path-slot order [tile][sample][pixel in tile] (SHM_PIX_GROUP; >= n_pix: sample-major)
     int queue_parts = 8;           // k_trace3 queue partitions, one per XCD with stealing (SHM_QUEUE_PARTS: 1 or 8)
     uint32_t* d_heads3 = nullptr;  // [2 (closest, any)][8 partitions][32 dwords: one 128-B line per head word]
