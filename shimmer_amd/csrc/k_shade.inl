@@ -19,8 +19,8 @@ namespace {
 template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ONLY = false>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
-                                                     DeviceCounters* counters, int shadow_parity) {
-    const uint32_t n = qs->n_active[cur];
+                                                     DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in) {
+    const uint32_t n = n_in ? *n_in : qs->n_active[cur];  // (n_in: the lean diversion's queue, whose count is not n_active)
     __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
     __shared__ uint32_t s_cnt[2], s_base[2];
     for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
@@ -251,6 +251,12 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
 #define WF_SHADE_LAUNCH(KERNEL)                                                                                                              \
     do {                                                                                                                                     \
         hipLaunchKernelGGL(KERNEL, dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], s->d_q_active[a.cur ^ 1], \
-                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity);                                        \
+                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)nullptr);              \
         LAUNCH_TRY("k_shade");                                                                                                               \
+    } while (0)
+#define WF_SHADE_LAUNCH_DIVERTED(KERNEL)                                                                                                     \
+    do {                                                                                                                                     \
+        hipLaunchKernelGGL(KERNEL, dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_lean, s->d_q_active[a.cur ^ 1],       \
+                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)&s->d_qs->n_lean);      \
+        LAUNCH_TRY("k_shade (diverted)");                                                                                                    \
     } while (0)

@@ -344,8 +344,10 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                 }
             } else {
                 float4* hp = reinterpret_cast<float4*>(hits + path);
-                hp[0] = make_float4(__int_as_float(hit_prim), hit_prim >= 0 ? t_max : 0.0f, hit_b0, hit_b1);
-                hp[1] = make_float4(hit_b2, TRI_ONLY ? 0.0f : hit_phi, TRI_ONLY ? 0.0f : __int_as_float(hit_inst + 1), 0.0f);
+                // (a miss is all zeros behind prim = -1: the lane's registers still hold its previous ray's barycentrics)
+                const bool found = hit_prim >= 0;
+                hp[0] = make_float4(__int_as_float(hit_prim), found ? t_max : 0.0f, found ? hit_b0 : 0.0f, found ? hit_b1 : 0.0f);
+                hp[1] = make_float4(found ? hit_b2 : 0.0f, (TRI_ONLY || !found) ? 0.0f : hit_phi, (TRI_ONLY || !found) ? 0.0f : __int_as_float(hit_inst + 1), 0.0f);
             }
             state = ST_IDLE;
         }
@@ -420,7 +422,7 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
     const bool tri_only = !s->flat.has_spheres;
 #define TRACE_LAUNCH(ANY, TRI)                                                                                                                   \
     hipLaunchKernelGGL((k_trace3<ANY, TRI>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
-                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], s->refill_min, leaf_min, s->queue_parts, s->trace_rays_per_lane)
+                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane)
     if (any) { if (tri_only) TRACE_LAUNCH(true, true); else TRACE_LAUNCH(true, false); }
     else { if (tri_only) TRACE_LAUNCH(false, true); else TRACE_LAUNCH(false, false); }
 #undef TRACE_LAUNCH

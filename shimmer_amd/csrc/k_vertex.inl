@@ -16,17 +16,23 @@ namespace {
 // works through the chunk in that order, so that the 64 lanes of a wave mostly evaluate ONE material. Paths are independent and every later
 // queue is order-agnostic: films and counters do not change.
 constexpr int VERTEX_SORT_BINS = 64;
+// q_lean (may be null): the lean diversion. A hit on a plain DiffuseMaterial in a triangle-only scene without textures is not worked on here at all:
+// the path goes to q_lean and the FUSED kernel (k_shade.inl's all-diffuse instantiation) runs its whole vertex — for that class the staged pair
+// only adds the parameter block's traffic (headline frame staged: 130 -> 165 ms). Everything else — escaped rays, the other
+// materials, MixMaterial (resolved in get_bsdf) — stays on the staged path.
+constexpr int N_VERTEX_QUEUES = N_BXDF_CLASSES + 1;
 template <bool TRI_ONLY, bool HAS_TEX, bool SORT>
 __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArrays& pa, const uint32_t* __restrict__ q_cur, uint32_t* q_s0, uint32_t* q_s1,
-                                            uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, const ShmRenderParams& params) {
+                                            uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, const ShmRenderParams& params, uint32_t* q_lean) {
     const uint32_t n = qs->n_active[cur];
-    __shared__ uint32_t s_q[N_BXDF_CLASSES][SHADE_CHUNK];
-    __shared__ uint32_t s_cnt[N_BXDF_CLASSES], s_base[N_BXDF_CLASSES];
+    const bool divert = TRI_ONLY && !HAS_TEX && q_lean != nullptr;
+    __shared__ uint32_t s_q[(TRI_ONLY && !HAS_TEX) ? N_VERTEX_QUEUES : N_BXDF_CLASSES][SHADE_CHUNK];  // (the fifth queue only where the diversion can happen)
+    __shared__ uint32_t s_cnt[N_VERTEX_QUEUES], s_base[N_VERTEX_QUEUES];
     __shared__ uint32_t s_sorted[SORT ? SHADE_CHUNK : 1];
     __shared__ uint32_t s_bin[SORT ? VERTEX_SORT_BINS + 1 : 1];
-    uint32_t* const q_out[N_BXDF_CLASSES] = {q_s0, q_s1, q_s2, q_s3};
+    uint32_t* const q_out[N_VERTEX_QUEUES] = {q_s0, q_s1, q_s2, q_s3, q_lean};
     for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
-      if (threadIdx.x < N_BXDF_CLASSES) s_cnt[threadIdx.x] = 0;
+      if (threadIdx.x < N_VERTEX_QUEUES) s_cnt[threadIdx.x] = 0;
       if (SORT) {
           auto key_of = [&](uint32_t path) -> uint32_t {
               const int prim = __float_as_int(reinterpret_cast<const float*>(pa.hit + path)[0]);
@@ -105,6 +111,8 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
                     const ShmLight& light = sv.lights[sv.infinite_lights[li]];
                     emit(infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda), light);
                 }
+            } else if (divert && sv.materials[sv.primitives[hit.prim].material].kind == SHM_MATERIAL_DIFFUSE) {
+                push_class = N_BXDF_CLASSES;  // the fused kernel takes this vertex from its start (emission included)
             } else {
                 SurfaceInteraction si = hit_interaction<TRI_ONLY>(sv, hit, -ray_d);
                 const ShmPrimitive prim = sv.primitives[hit.prim];
@@ -155,7 +163,8 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
         }
         // stage the class queues of this chunk in LDS (wave-aggregated LDS atomics), material-sorted by construction
 #pragma unroll
-        for (int c = 0; c < N_BXDF_CLASSES; ++c) {
+        for (int c = 0; c < N_VERTEX_QUEUES; ++c) {
+            if (c == N_BXDF_CLASSES && !divert) break;
             const bool mine = push_class == c;
             uint32_t slot = queue_push_slot(&s_cnt[c], mine);
             if (mine) s_q[c][slot] = path;
@@ -163,25 +172,28 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
       }
       __syncthreads();
       if (threadIdx.x < N_BXDF_CLASSES) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&qs->n_scatter[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+      if (threadIdx.x == N_BXDF_CLASSES) s_base[N_BXDF_CLASSES] = s_cnt[N_BXDF_CLASSES] ? atomicAdd(&qs->n_lean, s_cnt[N_BXDF_CLASSES]) : 0u;
       __syncthreads();
 #pragma unroll
-      for (int c = 0; c < N_BXDF_CLASSES; ++c)
+      for (int c = 0; c < N_VERTEX_QUEUES; ++c) {
+          if (c == N_BXDF_CLASSES && !divert) break;
           for (uint32_t j = threadIdx.x; j < s_cnt[c]; j += SHADE2_BLOCK) q_out[c][s_base[c] + j] = s_q[c][j];
+      }
       __syncthreads();
     }
 }
 
 template <bool TRI_ONLY, bool HAS_TEX, bool SORT = false>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_vertex(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* q_s0, uint32_t* q_s1,
-                                                                     uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, ShmRenderParams params) {
-    vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params);
+                                                                     uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, ShmRenderParams params, uint32_t* q_lean) {
+    vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params, q_lean);
 }
 // three waves per SIMD (<= 168 VGPRs): the triangle-only instantiation needs 159 and is bound by the latency of its gathers
 template <bool TRI_ONLY, bool HAS_TEX, bool SORT = false>
 __global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_vertex_w3(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur,
                                                                                                         uint32_t* q_s0, uint32_t* q_s1, uint32_t* q_s2, uint32_t* q_s3,
-                                                                                                        QueueState* qs, int cur, ShmRenderParams params) {
-    vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params);
+                                                                                                        QueueState* qs, int cur, ShmRenderParams params, uint32_t* q_lean) {
+    vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params, q_lean);
 }
 
 }  // namespace
@@ -196,12 +208,14 @@ static inline bool wf_vertex_sort(const ShmScene* s) {
 #define WF_VERTEX_LAUNCH_W3(TRI, TEX, SORT)                                                                                                    \
     do {                                                                                                                                       \
         hipLaunchKernelGGL((k_vertex_w3<TRI, TEX, SORT>), dim3(a.blocks * 3 / 2), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], \
-                           s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params);              \
+                           s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params,               \
+                           (a.params.force_diffuse == 0 && s->lean_divert) ? s->d_q_lean : (uint32_t*)nullptr);                                 \
         LAUNCH_TRY("k_vertex_w3");                                                                                                             \
     } while (0)
 #define WF_VERTEX_LAUNCH(TRI, TEX, SORT)                                                                                                       \
     do {                                                                                                                                       \
         hipLaunchKernelGGL((k_vertex<TRI, TEX, SORT>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur],          \
-                           s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params);              \
+                           s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params,               \
+                           (a.params.force_diffuse == 0 && s->lean_divert) ? s->d_q_lean : (uint32_t*)nullptr);                                 \
         LAUNCH_TRY("k_vertex");                                                                                                                \
     } while (0)

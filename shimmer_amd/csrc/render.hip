@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
         qs->n_shadow[0] = 0;
         qs->n_shadow[1] = 0;
         qs->n_scatter[0] = qs->n_scatter[1] = qs->n_scatter[2] = qs->n_scatter[3] = 0;
+    qs->n_lean = 0;
     }
 }
 
@@ -105,6 +106,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
 __global__ void k_next_bounce(QueueState* qs, int cur, int next_shadow_parity) {
     qs->n_active[cur] = 0;
     qs->n_scatter[0] = qs->n_scatter[1] = qs->n_scatter[2] = qs->n_scatter[3] = 0;
+    qs->n_lean = 0;
     qs->n_shadow[next_shadow_parity] = 0;  // the one the NEXT shade launch fills; this bounce's count stays for its K3
 }
 // ---------------------------------------------------------------------------------------------
@@ -195,6 +197,7 @@ static uint64_t staging_bytes_per_path(const ShmScene* s) {
     if (f.has_spheres || f.has_textures) b += 16;                              // siwo (the textured kernels are the general ones)
     if (f.has_textures) b += 48;                                               // dd0..2
     for (int c = 0; c < N_BXDF_CLASSES; ++c) if (f.has_class[c]) b += 4;       // class queues
+    if (s->lean_divert) b += 4;                                                // the lean diversion's queue
     return b;
 }
 static uint64_t workspace_cap(const ShmScene* s, bool need_staged) {
@@ -242,6 +245,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
     if (s->flat.has_textures) { WS(aux0, float4); WS(aux1, float4); WS(aux2, float4); }
     s->pa.bx0 = s->pa.bx1 = s->pa.bx2 = s->pa.bx3 = s->pa.bx4 = s->pa.fr = s->pa.siwo = s->pa.dd0 = s->pa.dd1 = s->pa.dd2 = nullptr;
     for (int c = 0; c < N_BXDF_CLASSES; ++c) s->d_q_scatter[c] = nullptr;
+    s->d_q_lean = nullptr;
     s->ws_staged = false;
     if (need_staged) {
         const shm_host::FlatScene& f = s->flat;
@@ -252,6 +256,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
         if (f.has_textures) { WS(dd0, float4); WS(dd1, float4); WS(dd2, float4); }
         for (int c = 0; c < N_BXDF_CLASSES; ++c)
             if (f.has_class[c] && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_scatter[c])) != SHM_OK) return rc;
+        if (s->lean_divert && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_lean)) != SHM_OK) return rc;
         s->ws_staged = true;
     }
 #undef WS
@@ -370,9 +375,13 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     // Tuning knobs (development): defaults are the measured optimum on S3
     if (const char* e = getenv("SHM_PIX_GROUP")) { long long v2 = atoll(e); if (v2 >= 1) s->pix_group = (uint32_t)std::min<long long>(v2, 0x7fffffffll); }
     if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
+    // the lean diversion (k_vertex.inl): triangle-only scenes without textures that hold plain diffuse materials BESIDE other classes
+    s->lean_divert = !s->flat.has_spheres && !s->flat.has_textures && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s);
+    if (const char* e = getenv("SHM_LEAN_DIVERT")) s->lean_divert = s->lean_divert && atoi(e) != 0;
     if (const char* e = getenv("SHM_TRACE_RAYS_PER_LANE")) { int v2 = atoi(e); if (v2 >= 0 && v2 <= 4096) s->trace_rays_per_lane = v2; }
     if (const char* e = getenv("SHM_CONCURRENT_SCATTER")) s->concurrent_scatter = atoi(e) != 0;
-    if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = v2; }
+    if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = s->refill_min_any = v2; }
+    if (const char* e = getenv("SHM_REFILL_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) s->trace3_per_cu_override = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
@@ -539,6 +548,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     // class the scene holds, each over its own material-sorted queue
                     const bool has_tex = s->flat.has_textures;
                     rc = has_tex ? wf_launch_vertex_tex(s, sa) : (tri_only ? wf_launch_vertex_tri(s, sa) : wf_launch_vertex_gen(s, sa));
+                    // the hits k_vertex diverted (plain diffuse materials): their whole vertex in the fused kernel
+                    if (rc == SHM_OK && s->lean_divert && s->d_q_lean && params->force_diffuse == 0) rc = wf_launch_shade_lean_diverted(s, sa);
                     // The classes' scatter kernels are independent of each other (own queue each, disjoint paths, wave-aggregated atomics on the
                     // shared next / shadow queues): the first runs on the render stream, the others beside it on their own streams, and the render
                     // stream waits for them — for small batches only (the same threshold as the K3 / K2 overlap above), where the launches are

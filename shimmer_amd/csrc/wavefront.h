@@ -59,6 +59,8 @@ struct QueueState {
     uint32_t n_shadow[2];   // entries in q_shadow, double-buffered by bounce parity: K3 of bounce b may still be reading its count
                             // while the counters of bounce b+1 are recycled (K3(b) overlaps K2(b+1) on a second stream)
     uint32_t n_scatter[4];  // staged shading: entries in q_scatter[class], filled by k_vertex, drained by k_scatter<class>
+    uint32_t n_lean;        // staged shading with the lean diversion: hits on plain DiffuseMaterial, which k_vertex hands to the fused kernel whole
+    uint32_t pad;
 };
 
 // Path state, structure of arrays (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
@@ -163,6 +165,8 @@ struct ShmScene {
     uint32_t* d_q_active[2] = {nullptr, nullptr};
     uint32_t* d_q_shadow = nullptr;
     uint32_t* d_q_scatter[4] = {nullptr, nullptr, nullptr, nullptr};  // staged shading: one queue per BxDF class present in the scene
+    uint32_t* d_q_lean = nullptr;  // the lean diversion's queue (triangle-only scenes without textures that hold plain diffuse materials beside others)
+    bool lean_divert = false;      // SHM_LEAN_DIVERT=0 switches it off (A/B)
     bool staged = false;           // the scene class runs k_vertex -> k_scatter<class> (everything but all-diffuse triangle scenes without textures)
     bool ws_staged = false;        // the workspace holds the staging arrays
     QueueState* d_qs = nullptr;
@@ -188,6 +192,7 @@ struct ShmScene {
     bool concurrent_scatter = true;  // SHM_CONCURRENT_SCATTER=0: everything on the render stream (A/B)
     hipStream_t stream_cls[3] = {nullptr, nullptr, nullptr};  // staged shading: the scatter kernels of the 2nd .. 4th BxDF class of a bounce run beside the first one's
     uint64_t overlap_paths = 96ull << 20;  // batches below this many paths run K3(b) beside K2(b+1) (SHM_OVERLAP_PATHS; 0 = never)
+    int refill_min_any = 24;       // the any-hit kernel's threshold (SHM_REFILL_MIN_ANY)
     int refill_min = 24;           // idle lanes before a wave refills (SHM_REFILL_MIN; r03 sweep on the rewritten kernel: 8 / 16 / 24 = 354 / 348 / 346 ms per frame)
     int trace_rays_per_lane = 4;   // a traversal launch uses as much of its persistent grid as gives each resident lane about this many rays (SHM_TRACE_RAYS_PER_LANE; 0 = always
                                    // the whole grid). profiles/r03_trace_rays_per_lane_sweep.txt: C2 16.8 / 16.1 / 15.8 / 15.8 / 16.5 ms at 0 / 4 / 8 / 16 / 32, C4's K2 276.7 / 276.8 / 282 / 307 / 362
@@ -229,6 +234,7 @@ struct ShadeArgs {
     int blocks;
 };
 WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a);  // the fused kernel: all-diffuse triangle scenes without textures
+WF_INTERNAL int wf_launch_shade_lean_diverted(ShmScene* s, const ShadeArgs& a);  // the same kernel over q_lean, in a scene the staged pipeline renders
 // staged shading (k_vertex_*.hip, k_scatter_*.hip): the hit half of a vertex (interaction, emission + MIS, get_bsdf with its texture
 // evaluation -> BxDF parameter block, pushed to the queue of its BxDF class), then per class the scattering half (NEE, sample_f, RR)
 WF_INTERNAL int wf_launch_vertex_tri(ShmScene* s, const ShadeArgs& a);

@@ -107,6 +107,13 @@ def test_trace_edge_cases(env):
         assert np.array_equal(hg.view(np.uint8), ho.view(np.uint8))
     one, _ = gpu.trace(rays[:1])
     assert one["prim"][0] >= 0
+    # more rays than the lanes a small launch uses (a small queue takes part of the persistent grid: 4 rays per resident lane), hits and misses
+    # mixed: every lane traces several rays in turn, and the record of a miss must not carry the barycentrics of the hit the lane found before it
+    big = _rays(sc, 60000, 7, toward_centre=0.3)
+    hg, sg = gpu.trace(big)
+    ho, so = orc.trace(big)
+    assert 0.05 < (ho["prim"] < 0).mean() < 0.95
+    assert np.array_equal(hg.view(np.uint8), ho.view(np.uint8)) and sg["nodes_closest"] == so["nodes_closest"] and sg["tris_closest"] == so["tris_closest"]
     gpu.close()
     orc.close()
 
