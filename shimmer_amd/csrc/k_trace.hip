@@ -42,6 +42,10 @@ __device__ __forceinline__ Float sel_mask(unsigned long long mask, Float if_clea
     return r;
 }
 
+// One-instruction max / min of three (IEEE maxNum / minNum; used only where no operand can be a NaN, see the slab test).
+__device__ __forceinline__ Float vmax3(Float a, Float b, Float c) { Float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ Float vmin3(Float a, Float b, Float c) { Float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 template <bool ANY, bool TRI_ONLY, int LDS_N>
 __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
                                             uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
@@ -94,6 +98,10 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
     // dir_is_neg (aggregate.rs:76-81) twice: as three wave-wide lane masks in scalar registers for the slab test's selects (sel_mask), and
     // as three bits of one VGPR for the near / far child choice, where the axis varies per lane
     unsigned long long m_negx = 0ull, m_negy = 0ull, m_negz = 0ull;
+    // ... and the lanes whose ray is not "regular" (bit 3 of sgn): a non-finite origin, or a direction component that is 0, infinite or so small
+    // that its reciprocal overflows. Only such a ray can turn a slab distance into a NaN ((plane - o) * (1 / d) = 0 * inf, inf * 0, inf - inf),
+    // and only with NaNs does the reference's compare-and-select chain differ from max3 / min3 — see the slab test.
+    unsigned long long m_irregular = 0ull;
     uint32_t sgn = 0;
     RayShear rs;
     rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
@@ -112,7 +120,9 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
     auto set_ray = [&](V3 o, V3 d) {  // aggregate.rs:76-81 + the ray-constant part of the triangle test
         ro = o;
         inv_dir = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        sgn = (inv_dir.x < 0.0f ? 1u : 0u) | (inv_dir.y < 0.0f ? 2u : 0u) | (inv_dir.z < 0.0f ? 4u : 0u);
+        const bool regular = is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(inv_dir.x) && is_finite(inv_dir.y) && is_finite(inv_dir.z) &&
+                             inv_dir.x != 0.0f && inv_dir.y != 0.0f && inv_dir.z != 0.0f;
+        sgn = (inv_dir.x < 0.0f ? 1u : 0u) | (inv_dir.y < 0.0f ? 2u : 0u) | (inv_dir.z < 0.0f ? 4u : 0u) | (regular ? 0u : 8u);
         rs = ray_shear(d);
         if (!TRI_ONLY) rd_full = d;
     };
@@ -123,6 +133,8 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
         top += WAVE;
     };
 
+    // (Measured and rejected, round 3: the newest stack entry in a register, so that a pop starts its node fetch without waiting for the LDS read
+    // — no gain in the any-hit kernel, 78.4 -> 79.6 ms per frame, and one register too many for the closest-hit kernel at eight waves.)
     // Stack storage by level: [0, K3_LDS_N) in LDS, anything deeper in the per-lane HBM spill. (The first version kept
     // the LDS window at levels 6..31 and spilled the bottom levels: those are written at the start of every ray and again
     // whenever the traversal comes back near the root, and as HBM stores they made WRITE_SIZE 7x the algorithmic hit writes
@@ -180,6 +192,7 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                     m_negx = __ballot((sgn & 1u) != 0u);
                     m_negy = __ballot((sgn & 2u) != 0u);
                     m_negz = __ballot((sgn & 4u) != 0u);
+                    m_irregular = __ballot((sgn & 8u) != 0u);
                 }
             }
             if (__ballot(state != ST_IDLE) == 0ull) {
@@ -197,22 +210,35 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
             const float4 na = np[0], nb = np[1];
             // Bounds3f::intersect_p_cached (bounding_box.rs:520-563), the near / far plane of each axis chosen by the ray's sign masks
             const Float g = 1.0f + 2.0f * gamma(3);
-            Float t0 = (sel_mask(m_negx, na.x, na.w) - ro.x) * inv_dir.x;
-            Float t1 = (sel_mask(m_negx, na.w, na.x) - ro.x) * inv_dir.x;
+            const Float tx0 = (sel_mask(m_negx, na.x, na.w) - ro.x) * inv_dir.x;
+            Float tx1 = (sel_mask(m_negx, na.w, na.x) - ro.x) * inv_dir.x;
             const Float ty0 = (sel_mask(m_negy, na.y, nb.x) - ro.y) * inv_dir.y;
             Float ty1 = (sel_mask(m_negy, nb.x, na.y) - ro.y) * inv_dir.y;
-            t1 *= g;
-            ty1 *= g;
-            bool hit_box = !(t0 > ty1 || ty0 > t1);
-            if (ty0 > t0) t0 = ty0;
-            if (ty1 < t1) t1 = ty1;
             const Float tz0 = (sel_mask(m_negz, na.z, nb.y) - ro.z) * inv_dir.z;
             Float tz1 = (sel_mask(m_negz, nb.y, na.z) - ro.z) * inv_dir.z;
+            tx1 *= g;
+            ty1 *= g;
             tz1 *= g;
-            hit_box = hit_box && !(t0 > tz1 || tz0 > t1);
-            if (tz0 > t0) t0 = tz0;
-            if (tz1 < t1) t1 = tz1;
-            hit_box = hit_box && (t0 < t_max) && (t1 > 0.0f);
+            bool hit_box;
+            if (m_irregular == 0ull) {
+                // Every ray of the wave is regular: no slab distance is a NaN (the node bounds are finite: shm_bvh_build refuses others), and then
+                // the reference's chain — !(tx0 > ty1 || ty0 > tx1), t0 = max, t1 = min, !(t0 > tz1 || tz0 > t1), ..., t0 < t_max, t1 > 0 — is
+                // max3(near) <= min3(far) && max3 < t_max && min3 > 0: the chain tests every near_i against every far_j of ANOTHER axis; the same-axis
+                // pairs hold by construction (near_i <= far_i before the * g; a far_i that * g pushed below near_i is negative, and then t1 > 0
+                // fails on both sides). Two instructions and three compares instead of ten compares and four selects.
+                const Float t0 = vmax3(tx0, ty0, tz0), t1 = vmin3(tx1, ty1, tz1);
+                hit_box = (t0 <= t1) && (t0 < t_max) && (t1 > 0.0f);
+            } else {
+                // bounding_box.rs:520-563 statement for statement (a lane may hold NaNs: comparisons with them are false, the selects keep them)
+                Float t0 = tx0, t1 = tx1;
+                hit_box = !(t0 > ty1 || ty0 > t1);
+                if (ty0 > t0) t0 = ty0;
+                if (ty1 < t1) t1 = ty1;
+                hit_box = hit_box && !(t0 > tz1 || tz0 > t1);
+                if (tz0 > t0) t0 = tz0;
+                if (tz1 < t1) t1 = tz1;
+                hit_box = hit_box && (t0 < t_max) && (t1 > 0.0f);
+            }
             const uint32_t offset = __float_as_uint(nb.z);
             const uint32_t meta = __float_as_uint(nb.w);
             const uint32_t n_prims = meta & 0xffffu;
@@ -297,6 +323,7 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                     m_negx = __ballot((sgn & 1u) != 0u);
                     m_negy = __ballot((sgn & 2u) != 0u);
                     m_negz = __ballot((sgn & 4u) != 0u);
+                    m_irregular = __ballot((sgn & 8u) != 0u);
                 }
             }
         }
@@ -331,6 +358,7 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
             m_negx = __ballot((sgn & 1u) != 0u);
             m_negy = __ballot((sgn & 2u) != 0u);
             m_negz = __ballot((sgn & 4u) != 0u);
+            m_irregular = __ballot((sgn & 8u) != 0u);
         }
         // ---- retire finished rays ----
         if (state == ST_DONE) {
@@ -373,14 +401,17 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                   int queue_parts, int rays_per_lane
 #define K3_ARGS sv, queue, n_ptr, n_direct, head, rays, hits, occluded_out, L, contrib, counters, spill, spill_levels, refill_min, leaf_min, queue_parts, rays_per_lane
 template <bool ANY, bool TRI_ONLY> struct K3Shape;  // {LDS levels, workgroups per CU} of each entry point
-template <> struct K3Shape<false, true> { static constexpr int LDS = 22, PER_CU = 7; };
+#ifndef K3_CLOSEST_WAVES
+#define K3_CLOSEST_WAVES 8
+#endif
+template <> struct K3Shape<false, true> { static constexpr int LDS = (K3_CLOSEST_WAVES == 8 ? 19 : 22), PER_CU = K3_CLOSEST_WAVES; };
 template <> struct K3Shape<true, true> { static constexpr int LDS = 19, PER_CU = 8; };
 template <> struct K3Shape<false, false> { static constexpr int LDS = 26, PER_CU = 4; };
 template <> struct K3Shape<true, false> { static constexpr int LDS = 26, PER_CU = 4; };
 template <bool ANY, bool TRI_ONLY>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(K3_PARAMS);
 template <>
-__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7))) k_trace3<false, true>(K3_PARAMS) {
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K3_CLOSEST_WAVES, K3_CLOSEST_WAVES))) k_trace3<false, true>(K3_PARAMS) {
     trace3_body<false, true, K3Shape<false, true>::LDS>(K3_ARGS);
 }
 template <>
