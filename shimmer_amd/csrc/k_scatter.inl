@@ -8,64 +8,134 @@
 
 namespace {
 
+// Deferred next-event estimation of the LayeredBxDF class. In a CoatedDiffuse / CoatedConductor vertex the expensive part of NEE is LayeredBxDF::f
+// and ::pdf (two random walks through the coating) — and only the lanes whose light sample is usable run them: a third of a wave on the coated S3
+// (the others wait for them). NEE feeds nothing else of the vertex: its result is the deferred shadow ray's contribution. So a lane with a usable light
+// sample only DEPOSITS a job in its wave's LDS buffer — {path, wo, wi, L, p_l, beta, flags}; the BxDF is re-read from the parameter block — and goes on
+// with sample_f; when 64 jobs have gathered (and at the end of the chunk) the wave evaluates them with every lane busy. Same arithmetic per path, same
+// sampler dimensions: films are bit-identical. Wave-private buffer, wave-uniform count: no barrier, no atomics.
+// (timing experiments only — never set in the product build: bit 0 drops the deferred NEE jobs, 1 the pdf after sample_f, 2 light sampling, 3 sample_f)
+#ifndef SHM_EXP_SKIP
+#define SHM_EXP_SKIP 0
+#endif
+constexpr int NEE_JOB_WORDS = 17;
+constexpr int NEE_JOB_CAP = 2 * WAVE;  // at most 63 waiting + 64 new
+
 template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
 __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArrays& pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                              uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, const ShmRenderParams& params, int shadow_parity) {
     const uint32_t n = qs->n_scatter[CLASS];
+    constexpr bool LAYERED = CLASS == CLASS_LAYERED;
+    constexpr uint32_t ROUNDS = SHADE_CHUNK / SHADE2_BLOCK;
     __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
     __shared__ uint32_t s_cnt[2], s_base[2];
+    __shared__ uint32_t s_jobs[LAYERED ? (SHADE2_BLOCK / WAVE) * NEE_JOB_WORDS * NEE_JOB_CAP : 1];
+    uint32_t* const jobs = s_jobs + (LAYERED ? (threadIdx.x / WAVE) * (NEE_JOB_WORDS * NEE_JOB_CAP) : 0);
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    // options.force_diffuse replaces the BxDF by a DiffuseBxDF (its f is a constant): nothing worth deferring, NEE stays inline
+    const bool defer = LAYERED && params.force_diffuse == 0;
+    uint32_t n_jobs = 0;  // wave-uniform
+    // the BxDF and the shading frame as k_vertex left them in the parameter block (c2 = PathArrays::ctx2[path]: n.z and the shading normal)
+    auto build_bsdf = [&](uint32_t path, const float4& c2, BSDF& bsdf, V3& ns) {
+        BxDF& b = bsdf.bxdf;
+        const float4 p2 = pa.bx2[path];
+        const uint32_t meta = __float_as_uint(p2.w);
+        b.kind = meta & 0xffu;
+        b.max_depth = (int)((meta >> 8) & 0xfffu);
+        b.n_samples = (int)(meta >> 20);
+        b.strict = (int)sv.quirks_off;
+        b.eta = p2.x;
+        b.mf.alpha_x = p2.y;
+        b.mf.alpha_y = p2.z;
+        b.r = ld_spec(pa.bx0[path]);
+        b.k = (CLASS == CLASS_CONDUCTOR || CLASS == CLASS_LAYERED) ? ld_spec(pa.bx1[path]) : spec_const(0.0f);
+        if (CLASS == CLASS_LAYERED) {
+            b.albedo = ld_spec(pa.bx3[path]);
+            const float4 p4 = pa.bx4[path];
+            b.mf2.alpha_x = p4.x; b.mf2.alpha_y = p4.y; b.thickness = p4.z; b.g = p4.w;
+        } else {
+            b.albedo = spec_const(0.0f);
+            b.mf2.alpha_x = 0.0f; b.mf2.alpha_y = 0.0f; b.thickness = 0.0f; b.g = 0.0f;
+        }
+        // the class is a property of the queue: the dispatch inside bxdf_f / bxdf_pdf / bxdf_sample_f folds to this class's code
+        // (plus DiffuseBxDF, which options.force_diffuse substitutes below)
+        if (CLASS == CLASS_DIFFUSE) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIFFUSE);
+        if (CLASS == CLASS_CONDUCTOR) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_CONDUCTOR);
+        if (CLASS == CLASS_DIELECTRIC) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIELECTRIC || bsdf.bxdf.kind == SHM_MATERIAL_THIN_DIELECTRIC);
+        if (CLASS == CLASS_LAYERED) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_COATED_DIFFUSE || bsdf.bxdf.kind == SHM_MATERIAL_COATED_CONDUCTOR);
+        const float4 f = pa.fr[path];
+        ns = v3(c2.y, c2.z, c2.w);
+        // Frame::from_xz (frame.rs:14-17): y = z cross x
+        bsdf.shading_frame.x = v3(f.x, f.y, f.z);
+        bsdf.shading_frame.z = ns;
+        bsdf.shading_frame.y = cross(ns, bsdf.shading_frame.x);
+    };
     for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
       if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
       __syncthreads();
-      for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+      for (uint32_t k = 0; k < ROUNDS || (LAYERED && n_jobs > 0u);) {
+        if (LAYERED && (n_jobs >= (uint32_t)WAVE || k == ROUNDS)) {
+            // ---- a full wave of deferred NEE jobs (the newest ones; at the end of the chunk whatever is left) ----
+            const uint32_t take = n_jobs < (uint32_t)WAVE ? n_jobs : (uint32_t)WAVE;
+            const uint32_t first = n_jobs - take;
+            n_jobs = first;
+            bool push_shadow = false;
+            uint32_t path = 0;
+            if (lane < take && !(SHM_EXP_SKIP & 1)) {
+                const uint32_t* jw = jobs + first + lane;
+                path = jw[0];
+                BSDF bsdf;
+                V3 ns;
+                build_bsdf(path, pa.ctx2[path], bsdf, ns);
+                const uint32_t jf = jw[16 * NEE_JOB_CAP];
+                if (jf & 2u) bxdf_regularize(bsdf.bxdf);
+                const V3 si_wo = v3(__uint_as_float(jw[1 * NEE_JOB_CAP]), __uint_as_float(jw[2 * NEE_JOB_CAP]), __uint_as_float(jw[3 * NEE_JOB_CAP]));
+                const V3 wi = v3(__uint_as_float(jw[4 * NEE_JOB_CAP]), __uint_as_float(jw[5 * NEE_JOB_CAP]), __uint_as_float(jw[6 * NEE_JOB_CAP]));
+                // integrator.rs:924-962, from the BSDF's f on
+                Spec f = bsdf_f(bsdf, si_wo, wi) * abs_dot(wi, ns);
+                if (!is_zero(f)) {
+                    Spec l, beta;
+                    for (int c = 0; c < 4; ++c) { l.v[c] = __uint_as_float(jw[(7 + c) * NEE_JOB_CAP]); beta.v[c] = __uint_as_float(jw[(12 + c) * NEE_JOB_CAP]); }
+                    const Float p_l = __uint_as_float(jw[11 * NEE_JOB_CAP]);
+                    Spec ld;
+                    if (jf & 1u) {
+                        ld = l * f / p_l;
+                    } else {
+                        Float pb2 = bsdf_pdf(bsdf, si_wo, wi, REFLTRANS_ALL);
+                        Float w_l = power_heuristic(1, p_l, 1, pb2);
+                        ld = w_l * l * f / p_l;
+                    }
+                    pa.shadow_contrib[path] = st_spec(beta * ld);
+                    push_shadow = true;
+                }
+            }
+            uint32_t s2 = queue_push_slot(&s_cnt[1], push_shadow);
+            if (push_shadow) s_shadow[s2] = path;
+            continue;
+        }
         const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
+        ++k;
         bool push_next = false, push_shadow = false;
         uint32_t path = 0;
+        // a deferred NEE job of this lane (LAYERED): deposited below, where the wave has reconverged
+        bool dep = false;
+        V3 j_wo = v3s(0.0f), j_wi = v3s(0.0f);
+        Spec j_l = spec_const(0.0f), j_beta = spec_const(0.0f);
+        Float j_pl = 0.0f;
+        uint32_t j_flags = 0u;
         if (i < n) {
             path = q_cur[i];
             // ---- the vertex as k_vertex left it ----
             BSDF bsdf;
-            {
-                BxDF& b = bsdf.bxdf;
-                const float4 p2 = pa.bx2[path];
-                const uint32_t meta = __float_as_uint(p2.w);
-                b.kind = meta & 0xffu;
-                b.max_depth = (int)((meta >> 8) & 0xfffu);
-                b.n_samples = (int)(meta >> 20);
-                b.strict = (int)sv.quirks_off;
-                b.eta = p2.x;
-                b.mf.alpha_x = p2.y;
-                b.mf.alpha_y = p2.z;
-                b.r = ld_spec(pa.bx0[path]);
-                b.k = (CLASS == CLASS_CONDUCTOR || CLASS == CLASS_LAYERED) ? ld_spec(pa.bx1[path]) : spec_const(0.0f);
-                if (CLASS == CLASS_LAYERED) {
-                    b.albedo = ld_spec(pa.bx3[path]);
-                    const float4 p4 = pa.bx4[path];
-                    b.mf2.alpha_x = p4.x; b.mf2.alpha_y = p4.y; b.thickness = p4.z; b.g = p4.w;
-                } else {
-                    b.albedo = spec_const(0.0f);
-                    b.mf2.alpha_x = 0.0f; b.mf2.alpha_y = 0.0f; b.thickness = 0.0f; b.g = 0.0f;
-                }
-            }
-            // the class is a property of the queue: the dispatch inside bxdf_f / bxdf_pdf / bxdf_sample_f folds to this class's code
-            // (plus DiffuseBxDF, which options.force_diffuse substitutes below)
-            if (CLASS == CLASS_DIFFUSE) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIFFUSE);
-            if (CLASS == CLASS_CONDUCTOR) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_CONDUCTOR);
-            if (CLASS == CLASS_DIELECTRIC) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIELECTRIC || bsdf.bxdf.kind == SHM_MATERIAL_THIN_DIELECTRIC);
-            if (CLASS == CLASS_LAYERED) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_COATED_DIFFUSE || bsdf.bxdf.kind == SHM_MATERIAL_COATED_CONDUCTOR);
             P3i si_pi;
             V3 si_n, ns;
             {
-                const float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path], f = pa.fr[path];
+                const float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path];
                 si_pi.x = iv2(c0.x, c0.w);
                 si_pi.y = iv2(c0.y, c1.x);
                 si_pi.z = iv2(c0.z, c1.y);
                 si_n = v3(c1.z, c1.w, c2.x);
-                ns = v3(c2.y, c2.z, c2.w);
-                // Frame::from_xz (frame.rs:14-17): y = z cross x
-                bsdf.shading_frame.x = v3(f.x, f.y, f.z);
-                bsdf.shading_frame.z = ns;
-                bsdf.shading_frame.y = cross(ns, bsdf.shading_frame.x);
+                build_bsdf(path, c2, bsdf, ns);
             }
             const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
             const float4 r0 = rp[0], r1 = rp[1];
@@ -107,7 +177,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
             depth += 1;
             // integrator.rs:837-841 + 897-963: next-event estimation; the visibility test is deferred to K3
             const uint32_t bf = bsdf_flags(bsdf);
-            if (flags_is_non_specular(bf)) {
+            if (flags_is_non_specular(bf) && !(SHM_EXP_SKIP & 4)) {
                 LightSampleContext ctx;
                 ctx.pi = si_pi; ctx.n = si_n; ctx.ns = ns;
                 if (flags_is_reflective(bf) && !flags_is_transmissive(bf)) ctx.pi = p3i_exact(offset_ray_origin(si_pi, si_n, si_wo));
@@ -121,6 +191,28 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                     LightLiSample ls;
                     if (light_sample_li<TRI_ONLY, HAS_TEX>(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
                         V3 wi = ls.wi;
+                        // (LayeredBxDF::f is zero when wo and wi lie on opposite sides of the shading plane — shm/bxdf.h, layered_f — or wo in it,
+                        //  bsdf.rs:48: half of the usable light samples on the coated S3; nothing to evaluate, nothing to queue)
+                        const bool f_may_be_nonzero = !LAYERED || [&] {
+                            const V3 wo_l = bsdf.shading_frame.to_local(si_wo), wi_l = bsdf.shading_frame.to_local(wi);
+                            return wo_l.z != 0.0f && same_hemisphere(wo_l, wi_l);
+                        }();
+                        if (defer && !f_may_be_nonzero) {
+                        } else if (defer) {
+                            // the shadow ray does not depend on the BSDF: written now (K3 only reads it if the job queues the path)
+                            Ray sr = spawn_ray_to_both_offset(si_pi, si_n, ls.p_light_pi, ls.p_light_n);
+                            ShmRay s;
+                            s.o[0] = sr.o.x; s.o[1] = sr.o.y; s.o[2] = sr.o.z;
+                            s.d[0] = sr.d.x; s.d[1] = sr.d.y; s.d[2] = sr.d.z;
+                            s.t_max = 1.0f - 0.0001f;  // 1 - SHADOW_EPSILON, integrator.rs:66,115
+                            s.pad = 0.0f;
+                            pa.shadow_ray[path] = s;
+                            dep = true;
+                            j_wo = si_wo; j_wi = wi; j_l = ls.l; j_beta = beta;
+                            j_pl = p_sel * ls.pdf;
+                            j_flags = (light_is_delta(light) ? 1u : 0u) | ((params.regularize && any_non_specular_bounces) ? 2u : 0u);
+                        } else {
+                        if (LAYERED) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIFFUSE);  // (force_diffuse: see `defer`)
                         Spec f = bsdf_f(bsdf, si_wo, wi) * abs_dot(wi, ns);
                         if (!is_zero(f)) {
                             Ray sr = spawn_ray_to_both_offset(si_pi, si_n, ls.p_light_pi, ls.p_light_n);
@@ -142,6 +234,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                             pa.shadow_contrib[path] = st_spec(beta * ld);
                             push_shadow = true;
                         }
+                        }
                     }
                 }
             }
@@ -149,12 +242,12 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
             Float u = sampler_get_1d(rng);
             V2 u2 = sampler_get_2d(rng);
             BSDFSample bs;
-            if (!bsdf_sample_f(bsdf, wo, u, u2, REFLTRANS_ALL, bs)) {
+            if ((SHM_EXP_SKIP & 8) || !bsdf_sample_f(bsdf, wo, u, u2, REFLTRANS_ALL, bs)) {
                 alive = false;
             } else {
                 // integrator.rs:859-872
                 beta = beta * (bs.f * abs_dot(bs.wi, ns) / bs.pdf);
-                p_b = bs.pdf_is_proportional ? bsdf_pdf(bsdf, wo, bs.wi, REFLTRANS_ALL) : bs.pdf;
+                p_b = (bs.pdf_is_proportional && !(SHM_EXP_SKIP & 2)) ? bsdf_pdf(bsdf, wo, bs.wi, REFLTRANS_ALL) : bs.pdf;
                 specular_bounce = flags_is_specular(bs.flags);
                 any_non_specular_bounces |= !specular_bounce;
                 if (flags_is_transmissive(bs.flags)) eta_scale *= sqr(bs.eta);
@@ -191,6 +284,21 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                     pa.flags[path] = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9) | aux_bit;
                     push_next = true;
                 }
+            }
+        }
+        if (LAYERED) {
+            const unsigned long long m = __ballot(dep);
+            if (m != 0ull) {
+                if (dep) {
+                    uint32_t* jw = jobs + n_jobs + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    jw[0] = path;
+                    jw[1 * NEE_JOB_CAP] = __float_as_uint(j_wo.x); jw[2 * NEE_JOB_CAP] = __float_as_uint(j_wo.y); jw[3 * NEE_JOB_CAP] = __float_as_uint(j_wo.z);
+                    jw[4 * NEE_JOB_CAP] = __float_as_uint(j_wi.x); jw[5 * NEE_JOB_CAP] = __float_as_uint(j_wi.y); jw[6 * NEE_JOB_CAP] = __float_as_uint(j_wi.z);
+                    for (int c = 0; c < 4; ++c) { jw[(7 + c) * NEE_JOB_CAP] = __float_as_uint(j_l.v[c]); jw[(12 + c) * NEE_JOB_CAP] = __float_as_uint(j_beta.v[c]); }
+                    jw[11 * NEE_JOB_CAP] = __float_as_uint(j_pl);
+                    jw[16 * NEE_JOB_CAP] = j_flags;
+                }
+                n_jobs = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_jobs + (uint32_t)__popcll(m)));
             }
         }
         // stage the queue entries of this chunk in LDS (wave-aggregated LDS atomics)

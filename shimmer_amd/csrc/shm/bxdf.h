@@ -531,6 +531,11 @@ SHM_HD bool sample_unusable(const BSDFSample& s) { return is_zero(s.f) || s.pdf 
 // LayeredBxDF::f, bxdf.rs:941-1218
 SHM_HD Spec layered_f(const BxDF& l, V3 wo, V3 wi, int mode) {
     Spec f = spec_const(0.0f);
+    // wo and wi on opposite sides: the walk would have to LEAVE through the bottom interface, and the first thing every sample does for that is
+    // bottom.sample_f(wi, .., TRANSMISSION) (bxdf.rs:1004-1012) — which a DiffuseBxDF / ConductorBxDF refuses (no transmission lobe): every
+    // sample `continue`s, the sum stays 0 and 0 / n_samples is returned. Known from the two z signs alone, so the (local, unobservable) generator
+    // and the top interface's sample are not even started; the GPU's deferred NEE uses the same test before it queues an evaluation.
+    if (!same_hemisphere(wo, wi)) return f;
     if (wo.z < 0.0f) { wo = -wo; wi = -wi; }  // TWO_SIDED
     const bool entered_top = true;            // TWO_SIDED || wo.z > 0
     const BaseBxDF top = layered_top(l), bottom = layered_bottom(l);
