@@ -14,7 +14,7 @@ namespace {
 // sample only DEPOSITS a job in its wave's LDS buffer — {path, wo, wi, L, p_l, beta, flags}; the BxDF is re-read from the parameter block — and goes on
 // with sample_f; when 64 jobs have gathered (and at the end of the chunk) the wave evaluates them with every lane busy. Same arithmetic per path, same
 // sampler dimensions: films are bit-identical. Wave-private buffer, wave-uniform count: no barrier, no atomics.
-// (timing experiments only — never set in the product build: bit 0 drops the deferred NEE jobs, 1 the pdf after sample_f, 2 light sampling, 3 sample_f)
+// (timing experiments only — never set in the product build: bit 0 drops the deferred NEE jobs, 1 the pdf after sample_f, 2 light sampling, 3 sample_f; bit 4 evaluates NEE inline)
 #ifndef SHM_EXP_SKIP
 #define SHM_EXP_SKIP 0
 #endif
@@ -33,7 +33,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
     uint32_t* const jobs = s_jobs + (LAYERED ? (threadIdx.x / WAVE) * (NEE_JOB_WORDS * NEE_JOB_CAP) : 0);
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     // options.force_diffuse replaces the BxDF by a DiffuseBxDF (its f is a constant): nothing worth deferring, NEE stays inline
-    const bool defer = LAYERED && params.force_diffuse == 0;
+    const bool defer = LAYERED && params.force_diffuse == 0 && !(SHM_EXP_SKIP & 16);
     uint32_t n_jobs = 0;  // wave-uniform
     // the BxDF and the shading frame as k_vertex left them in the parameter block (c2 = PathArrays::ctx2[path]: n.z and the shading normal)
     auto build_bsdf = [&](uint32_t path, const float4& c2, BSDF& bsdf, V3& ns) {
@@ -212,7 +212,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                             j_pl = p_sel * ls.pdf;
                             j_flags = (light_is_delta(light) ? 1u : 0u) | ((params.regularize && any_non_specular_bounces) ? 2u : 0u);
                         } else {
-                        if (LAYERED) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIFFUSE);  // (force_diffuse: see `defer`)
+                        if (LAYERED && !(SHM_EXP_SKIP & 16)) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIFFUSE);  // (force_diffuse: see `defer`)
                         Spec f = bsdf_f(bsdf, si_wo, wi) * abs_dot(wi, ns);
                         if (!is_zero(f)) {
                             Ray sr = spawn_ray_to_both_offset(si_pi, si_n, ls.p_light_pi, ls.p_light_n);

@@ -509,7 +509,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_any, ev_shade;
     bool used_overlap = false;
     HIP_TRY(hipEventRecord(e_begin, s->stream));
-    const int shade_blocks = s->n_cu * 4;
+    static const int shade_per_cu = [] { const char* e = getenv("SHM_SHADE_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 16) ? v : 4; }();
+    const int shade_blocks = s->n_cu * shade_per_cu;
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += pix_per_batch) {
         uint32_t n_pix = (uint32_t)std::min<uint64_t>(pix_per_batch, n_pixels - p0);
         uint32_t total = n_pix * (uint32_t)n_samples;
