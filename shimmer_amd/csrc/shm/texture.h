@@ -343,12 +343,19 @@ template <typename T> struct TexelOps;
 template <> struct TexelOps<RGB3> {
     static SHM_HD RGB3 zero() { return rgb3(0.0f, 0.0f, 0.0f); }
     static SHM_HD RGB3 texel(const TextureView& tv, int level, int x, int y) { return tex_texel(tv, level, x, y); }
+    // the same value from a texel's address (tex_texel / tex_channel with the coordinates already remapped; outside the image: black)
+    static SHM_HD RGB3 from_channels(const Float* p, int n_channels, bool inside_image) {
+        if (!inside_image) return rgb3(0.0f, 0.0f, 0.0f);
+        if (n_channels == 3) return rgb3(p[0], p[1], p[2]);
+        return rgb3(p[0], p[0], p[0]);
+    }
     static SHM_HD RGB3 bilerp(const TextureView& tv, int level, V2 st) { return tex_bilerp(tv, level, st); }
     static SHM_HD RGB3 lerp(Float t, RGB3 a, RGB3 b) { return lerp_rgb(t, a, b); }
 };
 template <> struct TexelOps<Float> {
     static SHM_HD Float zero() { return 0.0f; }
     static SHM_HD Float texel(const TextureView& tv, int level, int x, int y) { return tex_channel(tv, level, x, y, 0); }
+    static SHM_HD Float from_channels(const Float* p, int, bool inside_image) { return inside_image ? p[0] : 0.0f; }
     static SHM_HD Float bilerp(const TextureView& tv, int level, V2 st) {
         if (tv.t->n_channels == 1) return tex_bilerp_channel(tv, level, st, 0);
         // ImageChannelValues::average, image.rs:275-277
@@ -385,17 +392,27 @@ SHM_HD T tex_ewa(const TextureView& tv, const Float* lut, int level, V2 st, V2 d
     int t1 = float_to_i32(floor(st.y + 2.0f * inv_det * v_sqrt));
     T sum = TexelOps<T>::zero();
     Float sum_wts = 0.0f;
+    // The level's and the texture's fields are read once, and a texel of the ellipse's bounding box is FETCHED whether or not it lies inside the
+    // ellipse (its address is valid either way: remap_pixel_coords wraps, clamps or blacks it out): with the load inside the `r2 < 1` branch a
+    // wave made one dependent memory round trip per texel. What is accumulated, and in which order, is unchanged.
+    const int lw = l.width, lh = l.height, nc = (int)tv.t->n_channels;
+    const uint32_t wrap = tv.t->wrap;
+    const Float* const level_texels = tv.texels + l.texel_offset;
     for (int it = t0; it <= t1; ++it) {
         Float tt = (Float)it - st.y;
         for (int is = s0; is <= s1; ++is) {
             Float ss = (Float)is - st.x;
             Float r2 = a * sqr(ss) + b * ss * tt + c * sqr(tt);
+            int x = is, y = it;
+            const bool inside_image = remap_pixel_coords(x, y, lw, lh, wrap);
+            const Float* tp = level_texels + (inside_image ? (uint32_t)(nc * (y * lw + x)) : 0u);
+            const T texel = TexelOps<T>::from_channels(tp, nc, inside_image);
+            int index = float_to_i32(r2 * (Float)MIP_FILTER_LUT_SIZE);  // `as usize` saturates at 0 for negatives
+            if (index < 0) index = 0;
+            if (index > MIP_FILTER_LUT_SIZE - 1) index = MIP_FILTER_LUT_SIZE - 1;
+            const Float weight = lut[index];
             if (r2 < 1.0f) {
-                int index = float_to_i32(r2 * (Float)MIP_FILTER_LUT_SIZE);  // `as usize` saturates at 0 for negatives
-                if (index < 0) index = 0;
-                if (index > MIP_FILTER_LUT_SIZE - 1) index = MIP_FILTER_LUT_SIZE - 1;
-                Float weight = lut[index];
-                sum = sum + TexelOps<T>::texel(tv, level, is, it) * weight;
+                sum = sum + texel * weight;
                 sum_wts += weight;
             }
         }
