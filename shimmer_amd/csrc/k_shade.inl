@@ -5,6 +5,16 @@
 
 namespace {
 
+// Three waves per SIMD (<= 168 VGPRs) for the fused kernel: it waits for its gathers more than half of its cycles. Path state that is only needed at
+// one place (beta, p_b, eta_scale) is loaded THERE instead of being held across the vertex, which brings the kernel from 205 to 191 VGPRs at two waves
+// and to 19 spilled ones at three: shade 128.7 -> 121.6 ms per headline frame (three waves with the early loads: 45 spilled, 130.8 ms; two waves with
+// the late loads: 133.1 ms — the extra loads are exposed latency there). The grid is 3 workgroups per CU (6 is the same; 4 leaves a quarter of the
+// chunks to a second round: 154.7 ms).
+#ifndef K_SHADE_LEAN_WAVES
+#define K_SHADE_LEAN_WAVES 3
+#endif
+#define K_SHADE_LEAN_ATTR __attribute__((amdgpu_waves_per_eu(K_SHADE_LEAN_WAVES, K_SHADE_LEAN_WAVES)))
+
 // ---------------------------------------------------------------------------------------------
 // K4+K5: one path vertex (integrator.rs:772-892 for the vertex found by K2).
 // ---------------------------------------------------------------------------------------------
@@ -17,7 +27,7 @@ namespace {
 //   DIFFUSE_ONLY = true is the instantiation for scenes whose materials are all DiffuseMaterial (the headline scene class): the
 //   conductor / dielectric BxDFs and the material dispatch are compiled out of it.
 template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ONLY = false>
-__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
+__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in) {
     const uint32_t n = n_in ? *n_in : qs->n_active[cur];  // (n_in: the lean diversion's queue, whose count is not n_active)
@@ -42,7 +52,9 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
             V3 ray_d = v3(r0.w, r1.x, r1.y);
             // L is only touched by a vertex that adds emission (most do not): loaded and stored inside add_l
             auto add_l = [&](const Spec& c) { pa.L[path] = st_spec(ld_spec(pa.L[path]) + c); };
-            Spec beta = ld_spec(pa.beta[path]);
+            // (beta is read where it is used — emission, the NEE contribution, the throughput update — instead of being held across the vertex)
+            auto load_beta = [&]() { return ld_spec(pa.beta[path]); };
+            Spec beta;
             Wavelengths lambda;
             float4 pdf_in;
             {
@@ -55,8 +67,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
             int depth = (int)(fl & 0xffu);
             bool specular_bounce = (fl >> 8) & 1u;
             bool any_non_specular_bounces = (fl >> 9) & 1u;
-            float2 pe = pa.pb_eta[path];
-            Float p_b = pe.x, eta_scale = pe.y;
+            // (p_b is only read by the MIS weight of an emitter that was hit, eta_scale after sample_f: loaded there, not held across the vertex)
+            Float p_b = 0.0f, eta_scale = 0.0f;
             // the previous vertex's context is only needed for the MIS weight of an emitter that was hit
             auto load_prev_ctx = [&]() {
                 LightSampleContext c;
@@ -74,11 +86,11 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                     const ShmLight& light = sv.lights[sv.infinite_lights[k]];
                     Spec le = infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda);
                     if (depth == 0 || specular_bounce) {
-                        add_l(beta * le);
+                        add_l(load_beta() * le);
                     } else {
                         Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
-                        Float w_b = power_heuristic(1, p_b, 1, p_l);
-                        add_l(beta * w_b * le);
+                        Float w_b = power_heuristic(1, pa.pb_eta[path].x, 1, p_l);
+                        add_l(load_beta() * w_b * le);
                     }
                 }
             } else {
@@ -90,11 +102,11 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                     Spec le = area_light_l(sv, light, si.n, -ray_d, lambda);
                     if (!is_zero(le)) {
                         if (depth == 0 || specular_bounce) {
-                            add_l(beta * le);
+                            add_l(load_beta() * le);
                         } else {
                             Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
-                            Float w_l = power_heuristic(1, p_b, 1, p_l);
-                            add_l(beta * w_l * le);
+                            Float w_l = power_heuristic(1, pa.pb_eta[path].x, 1, p_l);
+                            add_l(load_beta() * w_l * le);
                         }
                     }
                 }
@@ -168,7 +180,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                                     s.t_max = 1.0f - 0.0001f;  // 1 - SHADOW_EPSILON, integrator.rs:66,115
                                     s.pad = 0.0f;
                                     pa.shadow_ray[path] = s;
-                                    pa.shadow_contrib[path] = st_spec(beta * ld);
+                                    pa.shadow_contrib[path] = st_spec(load_beta() * ld);
                                     push_shadow = true;
                                 }
                             }
@@ -183,10 +195,11 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                         alive = false;
                     } else {
                         // integrator.rs:859-872
-                        beta = beta * (bs.f * abs_dot(bs.wi, si.shading.n) / bs.pdf);
+                        beta = load_beta() * (bs.f * abs_dot(bs.wi, si.shading.n) / bs.pdf);
                         p_b = bs.pdf_is_proportional ? bsdf_pdf(bsdf, wo, bs.wi, REFLTRANS_ALL) : bs.pdf;
                         specular_bounce = flags_is_specular(bs.flags);
                         any_non_specular_bounces |= !specular_bounce;
+                        eta_scale = pa.pb_eta[path].y;
                         if (flags_is_transmissive(bs.flags)) eta_scale *= sqr(bs.eta);
                         LightSampleContext nctx = light_ctx_from(si);
                         V3 no = offset_ray_origin(si.pi, si.n, bs.wi);  // integrator.rs:875 -> interaction.rs:68-75
@@ -223,7 +236,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
                     }
                 }
                 // terminate_secondary may have changed the pdfs (material.rs:609-619): written back only then
-                if (lambda.pdf[1] != pdf_in.y || lambda.pdf[2] != pdf_in.z || lambda.pdf[3] != pdf_in.w || lambda.pdf[0] != pdf_in.x)
+                // (only DielectricMaterial terminates wavelengths: nothing to write back in the all-diffuse instantiation)
+                if (!DIFFUSE_ONLY && (lambda.pdf[1] != pdf_in.y || lambda.pdf[2] != pdf_in.z || lambda.pdf[3] != pdf_in.w || lambda.pdf[0] != pdf_in.x))
                     pa.lambda_pdf[path] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
             }
         }
@@ -250,13 +264,13 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade(SceneView s
 
 #define WF_SHADE_LAUNCH(KERNEL)                                                                                                              \
     do {                                                                                                                                     \
-        hipLaunchKernelGGL(KERNEL, dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], s->d_q_active[a.cur ^ 1], \
+        hipLaunchKernelGGL(KERNEL, dim3(s->n_cu * K_SHADE_LEAN_WAVES), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], s->d_q_active[a.cur ^ 1], \
                            s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)nullptr);              \
         LAUNCH_TRY("k_shade");                                                                                                               \
     } while (0)
 #define WF_SHADE_LAUNCH_DIVERTED(KERNEL)                                                                                                     \
     do {                                                                                                                                     \
-        hipLaunchKernelGGL(KERNEL, dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_lean, s->d_q_active[a.cur ^ 1],       \
+        hipLaunchKernelGGL(KERNEL, dim3(s->n_cu * K_SHADE_LEAN_WAVES), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_lean, s->d_q_active[a.cur ^ 1], \
                            s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)&s->d_qs->n_lean);      \
         LAUNCH_TRY("k_shade (diverted)");                                                                                                    \
     } while (0)
