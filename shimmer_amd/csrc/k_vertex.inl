@@ -30,6 +30,7 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
     __shared__ uint32_t s_cnt[N_VERTEX_QUEUES], s_base[N_VERTEX_QUEUES];
     __shared__ uint32_t s_sorted[SORT ? SHADE_CHUNK : 1];
     __shared__ uint32_t s_bin[SORT ? VERTEX_SORT_BINS + 1 : 1];
+    __shared__ uint8_t s_sorted_key[SORT ? SHADE_CHUNK : 4];  // the sort key (material, 64 = escaped) of each sorted entry: the diversion test needs nothing else
     uint32_t* const q_out[N_VERTEX_QUEUES] = {q_s0, q_s1, q_s2, q_s3, q_lean};
     for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
       if (threadIdx.x < N_VERTEX_QUEUES) s_cnt[threadIdx.x] = 0;
@@ -42,9 +43,20 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
           };
           if (threadIdx.x <= VERTEX_SORT_BINS) s_bin[threadIdx.x] = 0;
           __syncthreads();
+          // (the counting pass keeps each entry's path and key in registers for the scatter pass: the q -> hit -> primitive -> material chain of
+          //  dependent gathers is walked once per entry, not twice)
+          uint32_t my_path[SHADE_CHUNK / SHADE2_BLOCK];
+          uint32_t my_keys = 0u, my_keys_hi = 0u;  // 8 keys of 7 bits (0..64)
+#pragma unroll
           for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
               const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
-              if (i < n) atomicAdd(&s_bin[key_of(q_cur[i])], 1u);
+              my_path[k] = 0u;
+              if (i < n) {
+                  my_path[k] = q_cur[i];
+                  const uint32_t key = key_of(my_path[k]);
+                  if (k < 4) my_keys |= key << (8u * k); else my_keys_hi |= key << (8u * (k - 4u));
+                  atomicAdd(&s_bin[key], 1u);
+              }
           }
           __syncthreads();
           if (threadIdx.x == 0) {  // exclusive prefix over 65 bins: the bins become cursors
@@ -52,9 +64,11 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
               for (int b = 0; b <= VERTEX_SORT_BINS; ++b) { const uint32_t c = s_bin[b]; s_bin[b] = acc; acc += c; }
           }
           __syncthreads();
+#pragma unroll
           for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
               const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
-              if (i < n) { const uint32_t path = q_cur[i]; s_sorted[atomicAdd(&s_bin[key_of(path)], 1u)] = path; }
+              const uint32_t key = ((k < 4 ? my_keys >> (8u * k) : my_keys_hi >> (8u * (k - 4u)))) & 0xffu;
+              if (i < n) { const uint32_t slot = atomicAdd(&s_bin[key], 1u); s_sorted[slot] = my_path[k]; s_sorted_key[slot] = (uint8_t)key; }
           }
       }
       __syncthreads();
@@ -62,7 +76,18 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
         const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
         int push_class = -1;
         uint32_t path = 0;
-        if (i < n) {
+        // a plain-diffuse hit that the fused kernel takes over is recognised by its sort key alone (the material index, when it is below the last,
+        // shared bin): no hit record, no primitive record for it
+        bool diverted_by_key = false;
+        if (SORT && divert && i < n) {
+            const uint32_t key = s_sorted_key[k * SHADE2_BLOCK + threadIdx.x];
+            if (key < (uint32_t)VERTEX_SORT_BINS - 1u && sv.materials[key].kind == SHM_MATERIAL_DIFFUSE) {
+                diverted_by_key = true;
+                path = s_sorted[k * SHADE2_BLOCK + threadIdx.x];
+                push_class = N_BXDF_CLASSES;
+            }
+        }
+        if (i < n && !diverted_by_key) {
             path = SORT ? s_sorted[k * SHADE2_BLOCK + threadIdx.x] : q_cur[i];
             const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
             float4 h0 = hp[0], h1 = hp[1];
