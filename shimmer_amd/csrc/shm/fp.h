@@ -27,11 +27,7 @@
 #include <hip/hip_runtime.h>
 #define SHM_HD __host__ __device__ inline
 // large leaf routines that are called from many sites (image texture filtering): a real call keeps code size and compile time bounded
-#if defined(SHM_EXP_INLINE_TEX) && SHM_EXP_INLINE_TEX  // (timing experiment only, tools/exp_variants.sh)
-#define SHM_HD_NOINLINE __host__ __device__ inline
-#else
 #define SHM_HD_NOINLINE __host__ __device__ inline __attribute__((noinline))
-#endif
 #else
 #define SHM_HD inline
 #define SHM_HD_NOINLINE inline
