@@ -38,6 +38,7 @@ struct FlatScene {
     float scene_radius = 0.0f;
     bool has_spheres = false;  // any non-triangle shape (sphere or bilinear patch): selects k_trace3<.., TRI_ONLY = false>
     bool has_layered = false;  // any Coated* material: selects the k_shade instantiation that carries LayeredBxDF
+    bool has_rough_dielectric = false;  // a DielectricMaterial whose roughness is not the constant 0 (the specular / rough split of its scatter kernels)
     bool has_class[4] = {false, false, false, false};  // BxDF classes present in the material table (staged shading launches one scatter
                                                        // kernel per class): 0 diffuse, 1 conductor, 2 dielectric / thin dielectric, 3 coated
     bool diffuse_only = true;  // every material is a DiffuseMaterial: selects the k_shade instantiation with the other BxDFs compiled out
@@ -520,6 +521,9 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         else if (m.kind == SHM_MATERIAL_CONDUCTOR) out.has_class[1] = true;
         else if (m.kind == SHM_MATERIAL_DIELECTRIC || m.kind == SHM_MATERIAL_THIN_DIELECTRIC) out.has_class[2] = true;
         else if (m.kind == SHM_MATERIAL_COATED_DIFFUSE || m.kind == SHM_MATERIAL_COATED_CONDUCTOR) out.has_class[3] = true;
+        if (m.kind == SHM_MATERIAL_DIELECTRIC && (m.u_roughness != 0.0f || m.v_roughness != 0.0f || m.float_tex[SHM_FLOATSLOT_U_ROUGHNESS] != 0u ||
+                                                  m.float_tex[SHM_FLOATSLOT_V_ROUGHNESS] != 0u))
+            out.has_rough_dielectric = true;
         for (int k = 0; k < 8; ++k)
             if (m.float_tex[k] != 0u) {
                 if (m.float_tex[k] > d->n_float_textures) { err = "material float texture index out of range"; return SHM_ERR_INVALID_ARGUMENT; }

@@ -21,7 +21,11 @@ namespace {
 constexpr int NEE_JOB_WORDS = 17;
 constexpr int NEE_JOB_CAP = 2 * WAVE;  // at most 63 waiting + 64 new
 
-template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
+// SUB (the dielectric class only): 0 = every entry of the class queue; 1 = only the entries whose BxDF is specular — a ThinDielectricBxDF, or a DielectricBxDF that
+// is index-matched or effectively smooth — with next-event estimation and the rough-interface code compiled OUT (a specular BSDF has no NEE, integrator.rs:837):
+// the kernel then needs a fraction of the registers and runs four waves per SIMD instead of two; 2 = only the others. Kernels 1 and 2 walk the same queue and
+// each skips the other's entries (decided from the parameter block alone, so only without options.force_diffuse / regularize, which change the BxDF here).
+template <int CLASS, bool TRI_ONLY, bool HAS_TEX, int SUB = 0>
 __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArrays& pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                              uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, const ShmRenderParams& params, int shadow_parity) {
     const uint32_t n = qs->n_scatter[CLASS];
@@ -123,8 +127,16 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
         Spec j_l = spec_const(0.0f), j_beta = spec_const(0.0f);
         Float j_pl = 0.0f;
         uint32_t j_flags = 0u;
-        if (i < n) {
+        bool mine = i < n;
+        if (mine) {
             path = q_cur[i];
+            if (SUB != 0) {
+                const float4 p2 = pa.bx2[path];
+                const bool specular = (__float_as_uint(p2.w) & 0xffu) == SHM_MATERIAL_THIN_DIELECTRIC || p2.x == 1.0f || (p2.y < 1e-3f && p2.z < 1e-3f);
+                mine = specular == (SUB == 1);
+            }
+        }
+        if (mine) {
             // ---- the vertex as k_vertex left it ----
             BSDF bsdf;
             P3i si_pi;
@@ -136,6 +148,8 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                 si_pi.z = iv2(c0.z, c1.y);
                 si_n = v3(c1.z, c1.w, c2.x);
                 build_bsdf(path, c2, bsdf, ns);
+                // (SUB == 1: the specular branches never read the roughness; as constants they fold TrowbridgeReitz::effectively_smooth and with it the rough code away)
+                if (SUB == 1) { bsdf.bxdf.mf.alpha_x = 0.0f; bsdf.bxdf.mf.alpha_y = 0.0f; }
             }
             const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
             const float4 r0 = rp[0], r1 = rp[1];
@@ -177,7 +191,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
             depth += 1;
             // integrator.rs:837-841 + 897-963: next-event estimation; the visibility test is deferred to K3
             const uint32_t bf = bsdf_flags(bsdf);
-            if (flags_is_non_specular(bf) && !(SHM_EXP_SKIP & 4)) {
+            if (SUB != 1 && flags_is_non_specular(bf) && !(SHM_EXP_SKIP & 4)) {
                 LightSampleContext ctx;
                 ctx.pi = si_pi; ctx.n = si_n; ctx.ns = ns;
                 if (flags_is_reflective(bf) && !flags_is_transmissive(bf)) ctx.pi = p3i_exact(offset_ray_origin(si_pi, si_n, si_wo));
@@ -328,6 +342,19 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_scatter(SceneView
                                                                       int shadow_parity) {
     scatter_body<CLASS, TRI_ONLY, HAS_TEX>(sv, pa, q_cur, q_next, q_shadow, qs, cur, params, shadow_parity);
 }
+// the specular half of the dielectric class at four waves per SIMD (SUB = 1), and the rest of the class (SUB = 2) as before
+template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
+__global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_scatter_specular(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur,
+                                                                                                             uint32_t* __restrict__ q_next, uint32_t* __restrict__ q_shadow,
+                                                                                                             QueueState* qs, int cur, ShmRenderParams params, int shadow_parity) {
+    scatter_body<CLASS, TRI_ONLY, HAS_TEX, 1>(sv, pa, q_cur, q_next, q_shadow, qs, cur, params, shadow_parity);
+}
+template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
+__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_scatter_nonspecular(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
+                                                                                  uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
+                                                                                  int shadow_parity) {
+    scatter_body<CLASS, TRI_ONLY, HAS_TEX, 2>(sv, pa, q_cur, q_next, q_shadow, qs, cur, params, shadow_parity);
+}
 // one wave per SIMD and the whole 512-entry unified register file: no spills, less latency hiding (see above)
 template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
 __global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) k_scatter_w1(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur,
@@ -343,6 +370,12 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_
         hipLaunchKernelGGL((k_scatter<CLASS, TRI, TEX>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_scatter[CLASS], \
                            s->d_q_active[a.cur ^ 1], s->d_q_shadow, s->d_qs, a.cur, a.params, a.shadow_parity);                                \
         LAUNCH_TRY("k_scatter");                                                                                                                \
+    } while (0)
+#define WF_SCATTER_LAUNCH_SUB(KERNEL, BLOCKS, CLASS, TRI, TEX)                                                                                   \
+    do {                                                                                                                                        \
+        hipLaunchKernelGGL((KERNEL<CLASS, TRI, TEX>), dim3(BLOCKS), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_scatter[CLASS],         \
+                           s->d_q_active[a.cur ^ 1], s->d_q_shadow, s->d_qs, a.cur, a.params, a.shadow_parity);                                \
+        LAUNCH_TRY(#KERNEL);                                                                                                                    \
     } while (0)
 #define WF_SCATTER_LAUNCH_W1(CLASS, TRI, TEX)                                                                                                   \
     do {                                                                                                                                        \
