@@ -250,8 +250,9 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
             state = is_leaf ? (uint32_t)ST_LEAF : state;
             if (hit_box && n_prims == 0u) {
                 const bool neg = ((sgn >> ((meta >> 16) & 0xffu)) & 1u) != 0u;  // dir_is_neg[axis]
-                push(neg ? cur + 1 : offset);                                  // aggregate.rs:119-127: the far child waits, untested
-                cur = neg ? offset : cur + 1;
+                // (device layout: the children are the pair {offset, offset + 1} — the reference's cur + 1 and second_child_offset; render.hip, upload)
+                push(neg ? offset : offset + 1u);                              // aggregate.rs:119-127: the far child waits, untested
+                cur = neg ? offset + 1u : offset;
             }
         }
         // ---- postponed leaf phase ----
@@ -427,7 +428,7 @@ __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x;
 }  // namespace
 
 int wf_trace_prepare(ShmScene* s) {
-    if (s->flat.nodes.size() > (size_t)1 << 27) { shm_err() = "more than 2^27 BVH nodes (the traversal kernels address the node array with 32-bit byte offsets)"; return SHM_ERR_UNSUPPORTED; }
+    if (s->flat.nodes.size() + s->flat.instances.size() + 2 > (size_t)1 << 27) { shm_err() = "more than 2^27 BVH nodes (the traversal kernels address the node array with 32-bit byte offsets)"; return SHM_ERR_UNSUPPORTED; }
     const bool tri_only = !s->flat.has_spheres;
     for (int any = 0; any < 2; ++any) {
         const int lds = tri_only ? (any ? K3Shape<true, true>::LDS : K3Shape<false, true>::LDS) : K3Shape<false, false>::LDS;

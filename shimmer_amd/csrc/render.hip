@@ -323,7 +323,54 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
 
     const shm_host::FlatScene& f = s->flat;
     SceneView v = f.view();  // scalars + host pointers; pointers replaced below
-    if ((rc = dev_upload(s, f.nodes, &v.nodes)) != SHM_OK) return fail(rc);
+    // The DEVICE copy of the tree is laid out by sibling pairs (the ABI's array and the oracle's stay in the reference's depth-first order,
+    // aggregate.rs:425-467): the two children of a node share one 64-byte block, the block of a node's first child's children follows. Depth first, a
+    // node's second child lies behind its sibling's whole subtree, and the fetch that a pop starts — the head of a dependent chain — misses; here it
+    // shares the block its sibling brought in. Same nodes, same visit order, same counters: an interior node's `offset` is its first child's index, the
+    // second child is offset + 1 (k_trace.hip).
+    std::vector<ShmBvhNode> pair_nodes;
+    std::vector<ShmInstance> pair_instances = f.instances;
+    {
+        const std::vector<ShmBvhNode>& dn = f.nodes;
+        std::vector<uint32_t> new_index(dn.size(), 0xffffffffu);
+        std::vector<uint32_t> roots{0u};
+        for (const ShmInstance& in : f.instances) roots.push_back(in.root_node);
+        std::sort(roots.begin(), roots.end());
+        roots.erase(std::unique(roots.begin(), roots.end()), roots.end());
+        uint32_t next = 0;
+        std::vector<uint32_t> stack;
+        for (uint32_t r : roots) {
+            if (r >= dn.size()) { g_err = "instance root node out of range"; return fail(SHM_ERR_INVALID_ARGUMENT); }
+            new_index[r] = next;  // (a root sits alone in its block: the odd slot stays a zeroed, never-visited record)
+            next += 2;
+            stack.assign(1, r);
+            while (!stack.empty()) {
+                const uint32_t o = stack.back();
+                stack.pop_back();
+                if (dn[o].n_prims != 0) continue;
+                const uint32_t c0 = o + 1u, c1 = dn[o].offset;
+                if (c0 >= dn.size() || c1 >= dn.size() || new_index[c0] != 0xffffffffu || new_index[c1] != 0xffffffffu) {
+                    g_err = "BVH node array is not a depth-first tree"; return fail(SHM_ERR_INVALID_ARGUMENT);
+                }
+                new_index[c0] = next;
+                new_index[c1] = next + 1u;
+                next += 2;
+                stack.push_back(c1);
+                stack.push_back(c0);
+            }
+        }
+        ShmBvhNode zero;
+        memset(&zero, 0, sizeof(zero));
+        pair_nodes.assign(next, zero);
+        for (size_t o = 0; o < dn.size(); ++o) {
+            if (new_index[o] == 0xffffffffu) continue;  // (not reachable from any root)
+            ShmBvhNode n = dn[o];
+            if (n.n_prims == 0) n.offset = new_index[o + 1];
+            pair_nodes[new_index[o]] = n;
+        }
+        for (ShmInstance& in : pair_instances) in.root_node = new_index[in.root_node];
+    }
+    if ((rc = dev_upload(s, pair_nodes, &v.nodes)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.prim_recs, &v.prim_recs)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.primitives, &v.primitives)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.mesh_flags, &v.mesh_flags)) != SHM_OK) return fail(rc);
@@ -350,7 +397,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if ((rc = dev_upload(s, f.rgb2spec_data, &v.rgb2spec_data)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.cs_illuminant, &v.cs_illuminant)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ewa_lut, &v.ewa_lut)) != SHM_OK) return fail(rc);
-    if ((rc = dev_upload(s, f.instances, &v.instances)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, pair_instances, &v.instances)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.float_textures, &v.float_textures)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ftex_ranges, &v.ftex_ranges)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ftex_ops, &v.ftex_ops)) != SHM_OK) return fail(rc);
