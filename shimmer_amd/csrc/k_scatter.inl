@@ -181,12 +181,12 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                 rng.inc = (h << 1u) | 1u;
             }
             // options.force_diffuse (interaction.rs:256-275) draws inside get_bsdf, i.e. before anything else of this half
-            if (params.force_diffuse) {
+            if (SUB == 0 && params.force_diffuse) {  // (the SUB kernels are only launched without it, and without regularize)
                 Float uc = sampler_get_1d(rng);
                 V2 u2f = sampler_get_2d(rng);
                 bsdf_force_diffuse(bsdf, si_wo, uc, u2f);
             }
-            if (params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
+            if (SUB == 0 && params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
             bool alive = true;
             depth += 1;
             // integrator.rs:837-841 + 897-963: next-event estimation; the visibility test is deferred to K3
