@@ -21,8 +21,8 @@ namespace {
 constexpr int NEE_JOB_WORDS = 17;
 constexpr int NEE_JOB_CAP = 2 * WAVE;  // at most 63 waiting + 64 new
 
-// SUB (the dielectric class only): 0 = every entry of the class queue; 1 = only the entries whose BxDF is specular — a ThinDielectricBxDF, or a DielectricBxDF that
-// is index-matched or effectively smooth — with next-event estimation and the rough-interface code compiled OUT (a specular BSDF has no NEE, integrator.rs:837):
+// SUB (the dielectric class only): 0 = every entry of the class queue; 1 = only the entries whose BxDF is specular — a ThinDielectricBxDF, or a DielectricBxDF whose
+// distribution is effectively smooth — with next-event estimation and the rough-interface code compiled OUT (a specular BSDF has no NEE, integrator.rs:837):
 // the kernel then needs a fraction of the registers and runs four waves per SIMD instead of two; 2 = only the others. Kernels 1 and 2 walk the same queue and
 // each skips the other's entries (decided from the parameter block alone, so only without options.force_diffuse / regularize, which change the BxDF here).
 template <int CLASS, bool TRI_ONLY, bool HAS_TEX, int SUB = 0>
@@ -132,7 +132,9 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
             path = q_cur[i];
             if (SUB != 0) {
                 const float4 p2 = pa.bx2[path];
-                const bool specular = (__float_as_uint(p2.w) & 0xffu) == SHM_MATERIAL_THIN_DIELECTRIC || p2.x == 1.0f || (p2.y < 1e-3f && p2.z < 1e-3f);
+                // (what BxDF::flags calls SPECULAR, bxdf.rs:541-551 / 812-814: an index-matched interface with a rough distribution is GLOSSY — its NEE finds f = 0,
+                //  but draws its three sampler dimensions — and stays with the general kernel)
+                const bool specular = (__float_as_uint(p2.w) & 0xffu) == SHM_MATERIAL_THIN_DIELECTRIC || (p2.y < 1e-3f && p2.z < 1e-3f);
                 mine = specular == (SUB == 1);
             }
         }

@@ -2,7 +2,7 @@
 #include "k_scatter.inl"
 
 // Without options.force_diffuse / regularize (which change the BxDF inside the scatter half) the class queue is worked through by TWO kernels: the specular
-// entries — smooth or index-matched DielectricBxDF, ThinDielectricBxDF: no NEE, no microfacet code — at four waves per SIMD, and the rough ones (launched only if the
+// entries — smooth DielectricBxDF, ThinDielectricBxDF: no NEE, no microfacet code — at four waves per SIMD, and the rough ones (launched only if the
 // material table holds a dielectric that can be rough) by the general kernel; each skips the other's entries.
 int wf_launch_scatter_dielectric(ShmScene* s, const ShadeArgs& a, bool tri_only, bool has_tex) {
     static const bool split_off = [] { const char* e = getenv("SHM_SPECULAR_SPLIT"); return e && atoi(e) == 0; }();

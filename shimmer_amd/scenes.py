@@ -96,7 +96,7 @@ def test_image(size=64, channels=3, seed=7):
 
 
 def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=False, patch_skew=0.0, textured=False,
-                texture_filter=None, textured_coated_ceiling=True):
+                texture_filter=None, textured_coated_ceiling=True, glass=False):
     """S2 (config C2): 5 walls x 2 + 2 boxes x 5 faces x 2 + light 2 = 32 triangles.
     coated=True: the tall box becomes CoatedConductor (rough interface, Cu), the short one CoatedDiffuse with a scattering
     medium between the interfaces, the floor CoatedDiffuse with a smooth interface (SURVEY §8f-1 materials)."""
@@ -112,12 +112,18 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=Fal
         tall_m = b.material_coated_conductor(interface_roughness=0.05, conductor_roughness=0.2, thickness=0.02)
         short_m = b.material_coated_diffuse(reflectance=_two_point_spectrum(b, 0.1, 0.7), roughness=0.1, thickness=0.05, albedo=0.6, g=0.3)
         floor_m = b.material_coated_diffuse(reflectance=0.6, roughness=0.0, eta=b.spectrum_named("glass-BK7"))
+    if glass:  # every kind of dielectric interface in one scene: smooth + dispersive, rough, index-matched, thin (the specular / rough scatter kernels)
+        tall_m = b.material_dielectric(b.spectrum_named("glass-BK7"))
+        short_m = b.material_dielectric(1.5, roughness=0.3)
+        floor_m = b.material_mix(white, b.material_dielectric(1.0, roughness=0.2), 0.7)
     if mix:  # MixMaterial (material.rs:1288-1330): a plain two-way mix, and a nested one whose leaves include a coated material
         gold = b.material_conductor(b.spectrum_named("metal-Au-eta"), b.spectrum_named("metal-Au-k"), roughness=0.3)
         short_m = b.material_mix(white, gold, 0.5)
         tall_m = b.material_mix(b.material_mix(red, green, 0.3), b.material_coated_diffuse(reflectance=0.7, roughness=0.1), 0.6)
         floor_m = b.material_mix(white, black, 0.0)  # amount <= 0: always the first
     ceil_m, back_m, left_m, right_m = white, white, red, green
+    if glass:
+        left_m = b.material_mix(red, b.material_dielectric(1.33, thin=True), 0.5)
     if textured:
         # SpectrumImageTexture on every wall, one combination of mapping / filter / wrap / spectrum type each; the
         # tall box is a mirror and the short one glass so that specular reflection AND transmission differentials reach textures
@@ -203,7 +209,7 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=Fal
     else:
         p, vi = _quad((-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (0.3, 1.98, 0.3), (-0.3, 1.98, 0.3))
         b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=20.0)
-    return _finish(b, lib, name="S2 cornell box" + (" (coated)" if coated else "") + (" (mix)" if mix else "") + (" (patches)" if patches else "") + (" (textured)" if textured else ""))
+    return _finish(b, lib, name="S2 cornell box" + (" (coated)" if coated else "") + (" (mix)" if mix else "") + (" (patches)" if patches else "") + (" (textured)" if textured else "") + (" (glass)" if glass else ""))
 
 
 def _hash3(ix, iy, iz, seed):
