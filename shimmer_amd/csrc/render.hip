@@ -587,12 +587,23 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         // K3 of bounce b runs on a second stream beside K2 of bounce b+1 — they are independent: K3 reads the shadow buffers and
         // adds into L, K2 reads the extension rays and writes hit records — and the next shade launch waits for both. Large
         // batches (the 1-GPU headline frame) keep everything on one stream, so each kernel has the device to itself.
-        const bool overlap = s->overlap_paths > 0 && (uint64_t)total < s->overlap_paths && params->max_depth > 0;
+        const bool overlap_batch = s->overlap_paths > 0 && (uint64_t)total < s->overlap_paths && params->max_depth > 0;
+        // ... and, whatever the batch size, the LATE bounces of a deep render: from bounce `late_overlap_bounce` on the queues hold a few percent of the paths
+        // (C4: 7 % at bounce 6, 1 % at 12) and every launch is a tail (profiles/r03_c4_per_bounce.txt): K3 beside the next K2, the class scatter kernels beside each other.
+        // C4 frame 541 -> 522 ms at 6 (524-528 at 10, 528-534 at 16, 530 at 4; SHM_LATE_OVERLAP_BOUNCE, 0 = off)
+        static const int late_overlap_bounce = [] { const char* e = getenv("SHM_LATE_OVERLAP_BOUNCE"); const int v = e ? atoi(e) : 6; return v >= 1 ? v : 1 << 30; }();
+        bool overlap = overlap_batch;
         hipStream_t any_stream = overlap ? s->stream2 : s->stream;
         used_overlap = used_overlap || overlap;
         hipEvent_t k3_done = nullptr;
         for (int bounce = 0; bounce <= params->max_depth; ++bounce) {
             const int sh = bounce & 1;
+            if (!overlap && s->overlap_paths > 0 && bounce >= late_overlap_bounce) {
+                // (the switch is safe at a bounce boundary: everything so far was ordered on the render stream)
+                overlap = true;
+                any_stream = s->stream2;
+                used_overlap = true;
+            }
             hipEvent_t a = ev.get(), b = ev.get();
             hipEventRecord(a, s->stream);
             if ((rc = wf_launch_trace(s, false, s->stream, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr)) != SHM_OK) return rc;
