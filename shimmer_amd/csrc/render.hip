@@ -620,21 +620,21 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     // class the scene holds, each over its own material-sorted queue
                     const bool has_tex = s->flat.has_textures;
                     rc = has_tex ? wf_launch_vertex_tex(s, sa) : (tri_only ? wf_launch_vertex_tri(s, sa) : wf_launch_vertex_gen(s, sa));
-                    // the hits k_vertex diverted (plain diffuse materials): their whole vertex in the fused kernel
-                    if (rc == SHM_OK && s->lean_divert && s->d_q_lean && params->force_diffuse == 0) rc = wf_launch_shade_lean_diverted(s, sa);
+                    // the hits k_vertex diverted (plain diffuse materials): their whole vertex in the fused kernel — the first member of the group below
+                    const bool lean_too = s->lean_divert && s->d_q_lean && params->force_diffuse == 0;
                     // The classes' scatter kernels are independent of each other (own queue each, disjoint paths, wave-aggregated atomics on the
                     // shared next / shadow queues): the first runs on the render stream, the others beside it on their own streams, and the render
                     // stream waits for them — for small batches only (the same threshold as the K3 / K2 overlap above), where the launches are
                     // tail-dominated: textured Cornell 512^2 x 64 1 376 -> 1 486 Mray/s. With large queues each kernel fills the device by itself and
                     // sharing it costs (coated S3 at 256 spp 1 944 -> 1 864), and C4's late bounces did not gain (2 044 either way).
-                    int n_cls = 0;
+                    int n_cls = lean_too ? 1 : 0;
                     for (int c = 0; c < N_BXDF_CLASSES; ++c) n_cls += s->flat.has_class[c] ? 1 : 0;
                     hipEvent_t vertex_done = nullptr;
                     if (s->concurrent_scatter && overlap && n_cls > 1) { vertex_done = ev.get(); hipEventRecord(vertex_done, s->stream); }  // (before the first class's launch)
                     std::vector<hipEvent_t> side_done;
                     int k_cls = 0;
                     auto scatter_on = [&](int cls, auto&& launch) {
-                        if (rc != SHM_OK || !s->flat.has_class[cls]) return;
+                        if (rc != SHM_OK || !(cls < 0 ? lean_too : s->flat.has_class[cls])) return;
                         ShadeArgs sc = sa;
                         const bool side = k_cls > 0 && vertex_done != nullptr;
                         if (side) {
@@ -649,6 +649,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                         }
                         ++k_cls;
                     };
+                    scatter_on(-1, [&](const ShadeArgs& x) { return wf_launch_shade_lean_diverted(s, x); });
                     scatter_on(CLASS_DIFFUSE, [&](const ShadeArgs& x) { return wf_launch_scatter_diffuse(s, x, tri_only, has_tex); });
                     scatter_on(CLASS_CONDUCTOR, [&](const ShadeArgs& x) { return wf_launch_scatter_conductor(s, x, tri_only, has_tex); });
                     scatter_on(CLASS_DIELECTRIC, [&](const ShadeArgs& x) { return wf_launch_scatter_dielectric(s, x, tri_only, has_tex); });

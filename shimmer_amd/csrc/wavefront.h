@@ -190,7 +190,7 @@ struct ShmScene {
     uint32_t* d_spill3_any = nullptr;  // the any-hit kernel may run concurrently with the closest-hit one (second stream)
     hipStream_t stream2 = nullptr;
     bool concurrent_scatter = true;  // SHM_CONCURRENT_SCATTER=0: everything on the render stream (A/B)
-    hipStream_t stream_cls[3] = {nullptr, nullptr, nullptr};  // staged shading: the scatter kernels of the 2nd .. 4th BxDF class of a bounce run beside the first one's
+    hipStream_t stream_cls[4] = {nullptr, nullptr, nullptr, nullptr};  // staged shading: the scatter kernels of the 2nd .. 4th BxDF class of a bounce run beside the first one's
     uint64_t overlap_paths = 96ull << 20;  // batches below this many paths run K3(b) beside K2(b+1) (SHM_OVERLAP_PATHS; 0 = never)
     int refill_min_any = 24;       // the any-hit kernel's threshold (SHM_REFILL_MIN_ANY)
     int refill_min = 24;           // idle lanes before a wave refills (SHM_REFILL_MIN; r03 sweep on the rewritten kernel: 8 / 16 / 24 = 354 / 348 / 346 ms per frame)
