@@ -615,7 +615,12 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 hipEventRecord(s0, s->stream);
                 const ShadeArgs sa{s->stream, cur, *params, sh, shade_blocks};
                 const bool tri_only = !s->flat.has_spheres;
-                if (staged) {
+                // the late bounces of a deep render in a triangle scene without textures or coated materials: ONE fused launch instead of the staged four or five
+                // (C4 frame, same box: 522-528 ms staged throughout; 510-512 from bounce 6, 511-513 from 8, 512-513 from 10, 514-517 from 14; 0 = off)
+                static const int tail_fused_bounce = [] { const char* e = getenv("SHM_TAIL_FUSED_BOUNCE"); const int v = e ? atoi(e) : 8; return v >= 1 ? v : 1 << 30; }();
+                if (staged && bounce >= tail_fused_bounce && tri_only && !s->flat.has_textures && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0) {
+                    rc = wf_launch_shade_tail(s, sa);
+                } else if (staged) {
                     // hit half (interaction, emission, get_bsdf -> parameter block, class queues), then one scattering kernel per BxDF
                     // class the scene holds, each over its own material-sorted queue
                     const bool has_tex = s->flat.has_textures;

@@ -234,7 +234,8 @@ struct ShadeArgs {
     int blocks;
 };
 WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a);  // the fused kernel: all-diffuse triangle scenes without textures
-WF_INTERNAL int wf_launch_shade_lean_diverted(ShmScene* s, const ShadeArgs& a);  // the same kernel over q_lean, in a scene the staged pipeline renders
+WF_INTERNAL int wf_launch_shade_lean_diverted(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_shade_tail(ShmScene* s, const ShadeArgs& a);  // fused, every material class but the coated ones: late bounces of deep renders (k_shade_tail.hip)  // the same kernel over q_lean, in a scene the staged pipeline renders
 // staged shading (k_vertex_*.hip, k_scatter_*.hip): the hit half of a vertex (interaction, emission + MIS, get_bsdf with its texture
 // evaluation -> BxDF parameter block, pushed to the queue of its BxDF class), then per class the scattering half (NEE, sample_f, RR)
 WF_INTERNAL int wf_launch_vertex_tri(ShmScene* s, const ShadeArgs& a);
