@@ -47,7 +47,7 @@ SCENES = {
     "S3_small_coated": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, coated=True), 4, 5),
     "S2_cornell_patches": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, patches=True), 8, 5),  # BilinearPatch: rectangle light + curved patch
     "S2_cornell_patches_skewed": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, patches=True, patch_skew=2e-3), 4, 5),  # area-sampled patch light
-    "S2_cornell_glass": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, glass=True), 8, 8),  # smooth / rough / index-matched dielectrics: k_scatter_specular + k_scatter_nonspecular
+    "S2_cornell_glass": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, glass=True), 8, 14),  # smooth / rough / index-matched / thin dielectrics: k_scatter_specular + k_scatter_nonspecular, late-bounce overlap (6) and the fused tail launch (8)
     "S2_cornell_mix": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, mix=True), 8, 5),  # MixMaterial, nested, with a coated leaf
     # image textures (every mapping / filter / wrap / spectrum type), ray differentials through a mirror and glass
     "S2_cornell_textured": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, textured=True), 8, 6),
