@@ -638,7 +638,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     // ... and at any batch size where the diverted fused kernel (latency-bound, three waves per SIMD) has the LayeredBxDF class's scatter kernel
                     // (issue-bound, two) to run beside: complementary bounds (coated S3 at 256 spp: see DESIGN.md section 6)
                     static const int concurrent_big = [] { const char* e = getenv("SHM_CONCURRENT_BIG"); return e ? atoi(e) : 1; }();
-                    const bool group_big = concurrent_big != 0 && lean_too && s->flat.has_class[CLASS_LAYERED];
+                    const bool group_big = (concurrent_big == 1 && lean_too && s->flat.has_class[CLASS_LAYERED]) || concurrent_big == 2;  // (2: every staged scene — experiment)
                     if (s->concurrent_scatter && (overlap || group_big) && n_cls > 1) { vertex_done = ev.get(); hipEventRecord(vertex_done, s->stream); }  // (before the first class's launch)
                     std::vector<hipEvent_t> side_done;
                     int k_cls = 0;
