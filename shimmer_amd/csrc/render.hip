@@ -587,7 +587,10 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         // K3 of bounce b runs on a second stream beside K2 of bounce b+1 — they are independent: K3 reads the shadow buffers and
         // adds into L, K2 reads the extension rays and writes hit records — and the next shade launch waits for both. Large
         // batches (the 1-GPU headline frame) keep everything on one stream, so each kernel has the device to itself.
-        const bool overlap_batch = s->overlap_paths > 0 && (uint64_t)total < s->overlap_paths && params->max_depth > 0;
+        // (a scene shaded by the diverted fused kernel AND the LayeredBxDF scatter kernel runs in this mode at any batch size: its any-hit share is large and its
+        //  two shading kernels are bound differently — coated S3 at 256 spp 447 -> 437.5 ms; the headline frame is indifferent, C4 loses 1 %)
+        const bool mixed_lean_layered = staged && s->lean_divert && s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0;
+        const bool overlap_batch = s->overlap_paths > 0 && ((uint64_t)total < s->overlap_paths || mixed_lean_layered) && params->max_depth > 0;
         // ... and, whatever the batch size, the LATE bounces of a deep render: from bounce `late_overlap_bounce` on the queues hold a few percent of the paths
         // (C4: 7 % at bounce 6, 1 % at 12) and every launch is a tail (profiles/r03_c4_per_bounce.txt): K3 beside the next K2, the class scatter kernels beside each other.
         // C4 frame 541 -> 522 ms at 6 (524-528 at 10, 528-534 at 16, 530 at 4; SHM_LATE_OVERLAP_BOUNCE, 0 = off)
