@@ -29,6 +29,9 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0  # MI355X_MICROARCH.md: measured-achievable copy rate
+# FETCH_SIZE -> bytes: the guide's gfx950 correction (x2) is calibrated there for wide coalesced streams; tools/ubench/gather_fetch.hip measures it for
+# this kernel's pattern (random pairs of 16-B loads from 32-B records of an array far larger than the 256 MiB Infinity Cache): profiles/r04_gather_fetch.txt
+FETCH_FACTOR = 2.0
 
 
 def log(*a):
@@ -36,7 +39,13 @@ def log(*a):
 
 
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
-              ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"))
+              ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"),
+              ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_ANY"))
+# measured on this part (tools/ubench/valu_rate.hip -> profiles/r03_valu_issue_rates.txt, >= 2 waves per SIMD): clocks a SIMD is held per wave64 VALU
+# instruction. The cheapest class prices the CEILING (no instruction mix can issue faster); the counter's own pricing is one quad-cycle = 4 clocks.
+VALU_CLOCKS_BEST = 2.4     # v_add / v_mul / v_fma / v_add_u32 / v_mov
+VALU_CLOCKS_COUNTER = 4.0  # what SQ_ACTIVE_INST_VALU charges; v_cndmask (SGPR mask) / v_cmp -> SGPR / v_max3 measure 4.2
+N_SIMD, N_XCD = 256 * 4, 8
 K2_NAME = "k_trace3<closest>"
 
 
@@ -111,34 +120,38 @@ def committed_pmc(args):
 
 
 def counter_blocks(c, avg_launch_ms):
-    """HBM traffic per launch (2 x FETCH_SIZE — the gfx950 correction of MI355X_MICROARCH.md section HBM — + WRITE_SIZE, KiB units) and the
-    VALU-issue picture of the same kernel."""
+    """From the dominant kernel's counters (means per launch): HBM traffic (2 x FETCH_SIZE — the gfx950 correction of MI355X_MICROARCH.md
+    section HBM, calibrated for THIS access pattern by tools/ubench/gather_fetch.hip — + WRITE_SIZE, KiB units), lanes per VALU instruction,
+    and the VALU-issue roofline: lane-operations per second against what 1024 SIMDs x 64 lanes can issue."""
     if not c:
         return None, None, None
-    traffic = (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0 if "FETCH_SIZE" in c else None
+    traffic = (FETCH_FACTOR * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0 if "FETCH_SIZE" in c else None
     lanes = c.get("lanes")
     if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU"):
         lanes = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
     valu = None
-    if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
-        n_simd, n_xcd = 256 * 4, 8
-        cycles = c["GRBM_GUI_ACTIVE"] / n_xcd                       # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-        busy = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (n_simd * cycles)   # quad-cycles of VALU issue per SIMD over the kernel's cycles
-        # measured issue rates (tools/ubench/valu_rate.hip -> profiles/r03_valu_issue_rates.txt, >= 2 waves per SIMD): v_add / v_mul / v_fma /
-        # v_add_u32 / v_mov 2.4 clocks per wave64 instruction; v_cndmask (SGPR mask) / v_cmp -> SGPR / v_pk_* / v_lshl_add / v_max 4.2; v_rcp 8.2
-        valu = {"kernel": "k_trace3<closest>", "valu_busy_frac": busy, "valu_busy_frac_if_all_2p4_clock_ops": busy * 2.4 / 4.0,
-                "lanes_per_valu_inst": lanes, "lane_throughput_frac": busy * lanes / 64.0 if lanes else None,
-                "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "active_inst_valu_quadcycles_per_launch": c["SQ_ACTIVE_INST_VALU"],
-                "gpu_cycles_per_launch": cycles, "effective_clock_GHz": cycles / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms else None,
-                "issue_rate_assumed_clocks_per_inst": 4.0, "issue_rate_measured_clocks_per_inst": {"simple f32 / int (add, mul, fma, mov)": 2.4,
-                                                                                                     "select / compare-to-SGPR / packed / 3-operand": 4.2, "rcp": 8.2},
-                "definitions": "valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): SQ_ACTIVE_INST_* count quad-cycles "
-                               "(MI355X_MICROARCH.md, 's_memtime tick vs SQ PMC units'); the counter charges every VALU instruction one quad-cycle "
-                               "(SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 in this kernel), so the fraction prices each at 4 clocks. Measured on this "
-                               "part (profiles/r03_valu_issue_rates.txt) a wave64 instruction holds the SIMD 2.4 clocks (add / mul / fma / mov) or 4.2 "
-                               "(v_cndmask with an SGPR mask, v_cmp to an SGPR pair, packed f32, three-operand integer): the slab test is mostly the second "
-                               "kind, so the port's true busy fraction lies between valu_busy_frac_if_all_2p4_clock_ops and valu_busy_frac. "
-                               "lanes_per_valu_inst = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; lane_throughput_frac = busy x lanes / 64"}
+    if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE") and lanes and avg_launch_ms:
+        cycles = c["GRBM_GUI_ACTIVE"] / N_XCD                       # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        clock_hz = cycles / (avg_launch_ms * 1e-3)
+        n_inst = c.get("SQ_INSTS_VALU") or c["SQ_ACTIVE_INST_VALU"]  # (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 in this kernel: one quad-cycle each)
+        lane_ops = n_inst * lanes                                   # = SQ_THREAD_CYCLES_VALU when every instruction is charged one quad-cycle
+        achieved = lane_ops / (avg_launch_ms * 1e-3)                # lane-operations per second
+        peak = N_SIMD * 64 * clock_hz / VALU_CLOCKS_BEST            # every SIMD issuing a full-width 2.4-clock instruction back to back
+        busy4 = VALU_CLOCKS_COUNTER * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cycles)
+        valu = {"kernel": "k_trace<closest>", "achieved_lane_ops_per_s": achieved, "peak_lane_ops_per_s": peak, "frac": achieved / peak,
+                "frac_at_counter_pricing_4_clocks": achieved / (N_SIMD * 64 * clock_hz / VALU_CLOCKS_COUNTER),
+                "valu_busy_frac_at_4_clocks": busy4, "valu_busy_frac_at_2p4_clocks": busy4 * VALU_CLOCKS_BEST / VALU_CLOCKS_COUNTER,
+                "lanes_per_valu_inst": lanes, "valu_insts_per_launch": n_inst, "gpu_cycles_per_launch": cycles, "effective_clock_GHz": clock_hz / 1e9,
+                "issue_rate_measured_clocks_per_inst": {"simple f32 / int (add, mul, fma, mov)": 2.4, "select / compare-to-SGPR / packed / 3-operand": 4.2, "rcp": 8.2},
+                "wait_frac": (c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAIT_INST_ANY") and c.get("SQ_WAVE_CYCLES") else None,
+                "salu_busy_frac_at_4_clocks": (4.0 * c["SQ_ACTIVE_INST_SCA"] / (N_SIMD * cycles)) if c.get("SQ_ACTIVE_INST_SCA") else None,
+                "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
+                "definitions": "achieved = SQ_INSTS_VALU x (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) / launch time = active-lane VALU operations per second; "
+                               "peak = 1024 SIMDs x 64 lanes x measured clock (GRBM_GUI_ACTIVE / 8 XCDs / launch time) / 2.4 clocks — the fastest rate a SIMD issues "
+                               "wave64 VALU instructions at (profiles/r03_valu_issue_rates.txt), so no instruction mix can exceed it; the slab test is mostly 4.2-clock "
+                               "selects and compares, for which frac_at_counter_pricing_4_clocks is the closer figure. frac = lane occupancy x issue-slot occupancy: "
+                               "lanes_per_valu_inst / 64 x valu_busy_frac. wait_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (a wave's cycles spent waiting on a "
+                               "dependent gather); SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, 's_memtime tick vs SQ PMC units')"}
     return traffic, lanes, valu
 
 
@@ -430,20 +443,33 @@ def rank_main(args):
                        "rays_per_step": rays / args.steps, "paths_per_step": tot["paths"] / args.steps,
                        "film_gather": "RCCL ncclSend/ncclRecv of each rank's film rows into rank 0's device film, inside the library and inside the "
                                       "timed region" if use_dist else "none"},
-            # `achieved` is the ALGORITHMIC byte rate of the kernel (what the traversal would read if every node / primitive
-            # visit came from memory), `frac` = achieved / HBM peak. The kernel's gathers are largely served by L2 / MALL, so this is NOT
-            # HBM utilisation: `hbm_counter_GBs` (PMC traffic / launch time) is; what limits the kernel is in `roofline_valu`.
-            "roofline": {"bound": "hbm (ALGORITHMIC bytes of SURVEY 8d; the gathers are cache-served, the kernel is VALU-issue limited: roofline_valu)",
-                         "kernel": "k_trace3<closest> (BvhAggregate::intersect)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": counters_src,
-                         "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS, "hbm_counter_GBs": hbm_counter,
-                         "hbm_counter_frac": (hbm_counter / HBM_PEAK_GBS) if hbm_counter else None, "lanes_active": lanes,
-                         "bound_note": "algorithmic-bytes rate; gathers are cache-served (L2/MALL), the kernel is bound by VALU issue at "
-                                       "partial lane occupancy — see hbm_counter_* for real HBM utilisation",
-                         "bytes_per_launch": bytes_alg / launches, "avg_launch_ms": ms / launches, "launches": launches,
-                         "nodes_per_ray": acc["nodes_closest"] / max(1, acc["rays_closest"]),
-                         "prims_per_ray": acc["tris_closest"] / max(1, acc["rays_closest"]),
-                         "closest_Mray_s_in_kernel": acc["rays_closest"] / (ms * 1e-3) / 1e6 if ms > 0 else 0.0},
+            # The primary roofline is the ceiling that BINDS the dominant kernel: VALU issue (lane-operations per second against what the
+            # SIMDs can issue; frac <= 1 by construction). SURVEY §8(d)'s algorithmic-bytes figure — which counts every node visit as 32 B
+            # from memory although four in five are cache hits, and therefore exceeds the HBM peak — is kept as roofline_hbm_algorithmic;
+            # what HBM really carries (PMC traffic / launch time) is roofline_hbm_counter.
+            "roofline": {"bound": "valu-issue", "kernel": "k_trace<closest> (BvhAggregate::intersect)",
+                         "achieved": (valu["achieved_lane_ops_per_s"] / 1e12) if valu else None, "peak": (valu["peak_lane_ops_per_s"] / 1e12) if valu else None,
+                         "unit": "Tlane-op/s", "frac": valu["frac"] if valu else None,
+                         "frac_at_counter_pricing_4_clocks": valu["frac_at_counter_pricing_4_clocks"] if valu else None,
+                         "traffic": traffic, "traffic_source": counters_src, "lanes_active": lanes,
+                         "wait_frac": valu["wait_frac"] if valu else None, "salu_busy_frac": valu["salu_busy_frac_at_4_clocks"] if valu else None,
+                         "valu_busy_frac": valu["valu_busy_frac_at_4_clocks"] if valu else None,
+                         "avg_launch_ms": ms / launches, "launches": launches,
+                         "bound_note": "lane-operations per second of the closest-hit traversal kernel over 1024 SIMDs x 64 lanes x clock / 2.4 clocks per "
+                                       "instruction (the measured best issue rate); the gathers are L2 / MALL-served (roofline_hbm_counter), so HBM is not "
+                                       "the ceiling; see roofline_valu for every term" if valu else
+                                       "no hardware counters available in this run (rocprofv3 missing and no committed profile of this configuration): "
+                                       "see roofline_hbm_algorithmic"},
+            "roofline_hbm_algorithmic": {"bound": "hbm (SURVEY 8d ALGORITHMIC bytes; cache-served, saturated: may exceed 1)",
+                                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                         "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS, "bytes_per_launch": bytes_alg / launches,
+                                         "nodes_per_ray": acc["nodes_closest"] / max(1, acc["rays_closest"]),
+                                         "prims_per_ray": acc["tris_closest"] / max(1, acc["rays_closest"]),
+                                         "closest_Mray_s_in_kernel": acc["rays_closest"] / (ms * 1e-3) / 1e6 if ms > 0 else 0.0},
+            "roofline_hbm_counter": {"bound": "hbm (PMC traffic: FETCH_FACTOR x FETCH_SIZE + WRITE_SIZE per launch / launch time)", "traffic": traffic,
+                                     "fetch_factor": FETCH_FACTOR, "achieved": hbm_counter, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": (hbm_counter / HBM_PEAK_GBS) if hbm_counter else None,
+                                     "traffic_over_algorithmic": (traffic / (bytes_alg / launches)) if traffic else None},
             # the second traversal kernel, same accounting (informational; `roofline` above is the dominant kernel)
             "roofline_any_hit": {"kernel": "k_trace3<any> (BvhAggregate::intersect_predicate)",
                                  "achieved": ((32.0 * acc["nodes_any"] + 48.0 * acc["tris_any"] + 48.0 * acc["rays_any"]) / (acc["ms_trace_any"] * 1e-3) / 1e9)
@@ -461,6 +487,8 @@ def rank_main(args):
         }
         if valu:
             out["roofline_valu"] = valu
+            if not (0.0 < valu["frac"] <= 1.0):
+                raise SystemExit(f"roofline.frac = {valu['frac']} is not a fraction of a ceiling")
         if per_rank is not None:
             out["per_rank"] = per_rank
     if use_dist and rank == 0:

@@ -675,6 +675,12 @@ void orc_fn_layered_f_pdf(int kind, const float* p, const int* ip, const float* 
     out6[4] = bxdf_pdf(b, ld3(wo), ld3(wi), REFLTRANS_ALL);
     out6[5] = (float)bxdf_flags(b);
 }
+// LayeredBxDF::f with the whole walk evaluated (no opposite-hemisphere early-out): what the shortcut of shm/bxdf.h must equal
+void orc_fn_layered_f_full(int kind, const float* p, const int* ip, const float* wo, const float* wi, float* out4) {
+    BxDF b = make_layered(kind, p, ip);
+    Spec f = layered_f<false>(b, ld3(wo), ld3(wi), MODE_RADIANCE);
+    for (int i = 0; i < 4; ++i) out4[i] = f.v[i];
+}
 int orc_fn_layered_sample_f(int kind, const float* p, const int* ip, const float* wo, float uc, const float* u, float* out10) {
     BxDF b = make_layered(kind, p, ip);
     BSDFSample bs;

@@ -211,7 +211,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                         //  bsdf.rs:48: half of the usable light samples on the coated S3; nothing to evaluate, nothing to queue)
                         const bool f_may_be_nonzero = !LAYERED || [&] {
                             const V3 wo_l = bsdf.shading_frame.to_local(si_wo), wi_l = bsdf.shading_frame.to_local(wi);
-                            return wo_l.z != 0.0f && same_hemisphere(wo_l, wi_l);
+                            return wo_l.z != 0.0f && (layered_bottom_transmits(bsdf.bxdf.kind) || same_hemisphere(wo_l, wi_l));
                         }();
                         if (defer && !f_may_be_nonzero) {
                         } else if (defer) {

@@ -342,6 +342,8 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
         static const int layout = [] { const char* e = getenv("SHM_NODE_LAYOUT"); return e ? atoi(e) : 1; }();  // 0: the first child's block next; 1: the larger child's (default)
         for (uint32_t r : roots) {
             if (r >= dn.size()) { g_err = "instance root node out of range"; return fail(SHM_ERR_INVALID_ARGUMENT); }
+            // (a root inside another root's tree — an instanced SUB-tree — would get two device indices: named, not mis-traversed)
+            if (new_index[r] != 0xffffffffu) { g_err = "an instance's root node lies inside another tree of the node array (instanced sub-trees are not supported: give the object its own tree)"; return fail(SHM_ERR_INVALID_ARGUMENT); }
             new_index[r] = next;  // (a root sits alone in its block: the odd slot stays a zeroed, never-visited record)
             next += 2;
             stack.assign(1, r);

@@ -528,14 +528,20 @@ SHM_HD Float layered_tr(Float dz, V3 w) {
 }
 SHM_HD bool sample_unusable(const BSDFSample& s) { return is_zero(s.f) || s.pdf == 0.0f || s.wi.z == 0.0f; }
 
-// LayeredBxDF::f, bxdf.rs:941-1218
+// Whether the BOTTOM interface of a LayeredBxDF kind can transmit. The two layered materials the reference has (CoatedDiffuse, CoatedConductor:
+// material.rs:917-963, 1189-1256) put a DiffuseBxDF / ConductorBxDF there — reflection only. The opposite-hemisphere shortcut of layered_f and the
+// deferred NEE's matching skip (k_scatter.inl) are valid ONLY under this; a future layered kind with a transmissive bottom must return true here.
+SHM_HD constexpr bool layered_bottom_transmits(uint32_t kind) { return !(kind == SHM_MATERIAL_COATED_DIFFUSE || kind == SHM_MATERIAL_COATED_CONDUCTOR); }
+
+// LayeredBxDF::f, bxdf.rs:941-1218. SHORTCUT = false evaluates the walk without the opposite-hemisphere early-out (tests compare the two).
+template <bool SHORTCUT = true>
 SHM_HD Spec layered_f(const BxDF& l, V3 wo, V3 wi, int mode) {
     Spec f = spec_const(0.0f);
     // wo and wi on opposite sides: the walk would have to LEAVE through the bottom interface, and the first thing every sample does for that is
     // bottom.sample_f(wi, .., TRANSMISSION) (bxdf.rs:1004-1012) — which a DiffuseBxDF / ConductorBxDF refuses (no transmission lobe): every
     // sample `continue`s, the sum stays 0 and 0 / n_samples is returned. Known from the two z signs alone, so the (local, unobservable) generator
     // and the top interface's sample are not even started; the GPU's deferred NEE uses the same test before it queues an evaluation.
-    if (!same_hemisphere(wo, wi)) return f;
+    if (SHORTCUT && !layered_bottom_transmits(l.kind) && !same_hemisphere(wo, wi)) return f;
     if (wo.z < 0.0f) { wo = -wo; wi = -wi; }  // TWO_SIDED
     const bool entered_top = true;            // TWO_SIDED || wo.z > 0
     const BaseBxDF top = layered_top(l), bottom = layered_bottom(l);

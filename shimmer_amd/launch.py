@@ -105,7 +105,10 @@ def store_from_env(rank, world, timeout_s=600.0):
     if not d:
         port = os.environ.get("MASTER_PORT", "0")
         run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
-        d = os.path.join(tempfile.gettempdir(), f"shm_store_{os.getuid()}_{port}_{os.getppid()}_{run}")
+        # (one directory per ATTEMPT: with --max-restarts the agent re-spawns its workers under the same port / pid / run id, and a new attempt
+        #  must not read the dead attempt's rccl_unique_id, failed.* notes or barrier keys)
+        attempt = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+        d = os.path.join(tempfile.gettempdir(), f"shm_store_{os.getuid()}_{port}_{os.getppid()}_{run}_a{attempt}")
     return FileStore(d, rank, world, timeout_s)
 
 

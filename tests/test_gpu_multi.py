@@ -161,6 +161,66 @@ def test_c5_shaped_shard_matches_oracle(gpu_lib, rank):
     assert (film["weight_sum"][owned] == 1.0).all() and (film["weight_sum"][~owned] == 0.0).all()
 
 
+def test_c5_frame_at_full_size(gpu_lib):
+    """BASELINE.json configs[4] ITSELF on one GPU: S3 (4 305 626 primitives) at 3840 x 2160, 1024 spp, maxdepth 5 — 8.49 G paths — through the
+    path an 8-GPU run takes per rank: shm_dist_init (RCCL communicator, here of one rank) + shm_render_sharded. Size-independent properties
+    (every pixel 1024 samples, finite, nothing gathered with one rank, run-to-run identity of film and counters, the send / recv loop-back),
+    a 16 x 16 block on the object at all 1024 samples against the oracle — film and visit counters bit for bit —, and rank 3 of 8's REAL
+    tile set on the real scene at 64 spp: owned pixels complete, the others untouched, a 1-in-97 sample of its tiles equal to the oracle's."""
+    from shimmer_amd import scene as scn
+    W, H, SPP = 3840, 2160, 1024
+    sc = scenes.ganesha_proxy(gpu_lib, W, H)
+    assert sc.info["n_primitives"] == 4305626
+    p = render.make_params(seed=0, spp=SPP, max_depth=5)
+    r = render.Renderer(gpu_lib, sc.desc, device=0)
+    assert r.n_tiles == 129600 and r.tiles_per_row == 480
+    r.dist_init(0, 1, r.dist_unique_id())
+    s1 = r.render_sharded(p)
+    f1 = r.read_film()
+    s2 = r.render_sharded(p)
+    assert np.array_equal(r.read_film(), f1)
+    keys = ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any")
+    for k in keys:
+        assert s1[k] == s2[k], k
+    assert s1["paths"] == W * H * SPP and s1["gather_bytes"] == 0
+    assert (f1["weight_sum"] == float(SPP)).all() and np.isfinite(f1["rgb_sum"]).all() and (f1["rgb_sum"] >= 0).all()
+    assert s1["rays_closest"] >= s1["paths"] and 0 < s1["rays_any"] <= s1["rays_closest"] and s1["rays_closest"] + s1["rays_any"] > 30_000_000_000
+    r.dist_selftest()  # the film rows through the ncclSend / ncclRecv group, looped back, every byte compared
+    # a 16 x 16 block in the object's silhouette (the 1024^2 headline test's block, scaled to this frame)
+    x0, y0 = 1912, 928
+    tiles, n = scn.tiles_for(gpu_lib, (x0, y0, x0 + 16, y0 + 16))
+    orc = oracle_py.Oracle(sc.desc)
+    fo, so = orc.render(p, n_threads=os.cpu_count() or 1, tiles=tiles, n_tiles=n)
+    assert np.array_equal(f1[y0:y0 + 16, x0:x0 + 16], fo[y0:y0 + 16, x0:x0 + 16])
+    assert so["nodes_closest"] / so["rays_closest"] > 20  # the block is on the object, not on a wall
+    sel = np.array([i for i in range(r.n_tiles) if (lambda t: t.x0 >= x0 and t.x1 <= x0 + 16 and t.y0 >= y0 and t.y1 <= y0 + 16)(r.tiles[i])])
+    assert len(sel) == n == 4
+    r.clear()
+    sb = r.render_device(p, tile_indices=sel)
+    for k in keys:
+        assert sb[k] == so[k], k
+    # rank 3 of 8: its real tile set of this frame, 64 spp
+    mine = render.shard_tiles(r.n_tiles, r.tiles_per_row, 3, 8, lib=gpu_lib)
+    p64 = render.make_params(seed=0, spp=64, max_depth=5)
+    r.clear()
+    s3 = r.render_device(p64, mine)
+    f3 = r.read_film()
+    assert s3["paths"] == len(mine) * 64 * 64
+    owned = np.zeros((H, W), bool)
+    for i in mine:
+        t = r.tiles[int(i)]
+        owned[t.y0:t.y1, t.x0:t.x1] = True
+    assert (f3["weight_sum"][owned] == 64.0).all() and (f3["weight_sum"][~owned] == 0.0).all() and np.isfinite(f3["rgb_sum"]).all()
+    sample = mine[::97]
+    sub = (abi.ShmTile * len(sample))(*[r.tiles[int(i)] for i in sample])
+    fs, _ = orc.render(p64, n_threads=os.cpu_count() or 1, tiles=sub, n_tiles=len(sample))
+    for i in sample:
+        t = r.tiles[int(i)]
+        assert np.array_equal(f3[t.y0:t.y1, t.x0:t.x1], fs[t.y0:t.y1, t.x0:t.x1]), int(i)
+    orc.close()
+    r.close()
+
+
 def _nccl_world1_worker(rank, port, out_path):
     # a fresh process that imports torch FIRST (torch ships its own HIP runtime: it must be the one the process initialises)
     import sys

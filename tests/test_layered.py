@@ -188,6 +188,32 @@ def test_energy_and_sampling_consistency(orc, name):
         assert np.all(albedo_s >= albedo_f - 0.03)  # the specular reflection adds energy f() cannot see
 
 
+@pytest.mark.parametrize("name", ["coated_diffuse", "coated_conductor"])
+def test_opposite_hemisphere_shortcut_equals_the_full_walk(orc, name):
+    """layered_f returns 0 for wo / wi on opposite sides before it starts its walk (valid while the bottom interface cannot transmit:
+    layered_bottom_transmits, shm/bxdf.h); the full walk (bxdf.rs:965-1218 without the early-out) gives the same bits, both hemispheres."""
+    kind = COATED_DIFFUSE if name == "coated_diffuse" else COATED_CONDUCTOR
+    rng = np.random.default_rng(11)
+    orc.orc_fn_layered_f_full.restype = None
+    n_opposite = 0
+    for rough in (0.0, 0.3):
+        for albedo in (0.0, 0.6):
+            p = params(r=0.6, k=2.5, albedo=albedo, ax=rough, ax2=rough, thickness=0.02, g=0.3)
+            i = ip(10, 2)
+            for _ in range(60):
+                wo = unit(rng.uniform(0, math.pi), rng.uniform(0, 2 * math.pi))
+                wi = unit(rng.uniform(0, math.pi), rng.uniform(0, 2 * math.pi))
+                f, _, _ = f_pdf(orc, kind, p, i, wo, wi)
+                out = (C.c_float * 4)()
+                orc.orc_fn_layered_f_full(kind, p, i, fa(*wo), fa(*wi), out)
+                full = np.array(out[:], np.float32)
+                assert f.tobytes() == full.tobytes(), (wo, wi, f, full)
+                if wo[2] * wi[2] < 0:
+                    n_opposite += 1
+                    assert not f.any()
+    assert n_opposite > 100
+
+
 def test_coated_scene_renders_deterministically(lib):
     """The oracle's whole-path render of the coated Cornell box: finite, brighter than black, identical run to run and
     for any thread count (no entropy anywhere on the path)."""

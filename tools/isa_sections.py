@@ -8,8 +8,9 @@ branches), BRANCH (s_cbranch*, s_branch), VMEM (global_* / buffer_* / scratch_* 
 The counts are STATIC (instructions in the code object per section); one loop iteration executes the refill test, at most one pop, one node
 step, one leaf-mark / push, and — when enough lanes wait — the leaf phase, so per-iteration dynamic counts are the sums of the sections on
 that path, not of all of them.
-    python tools/isa_sections.py [out.txt]
+    python tools/isa_sections.py [-o out.txt]
 """
+import argparse
 import re
 import subprocess
 import sys
@@ -58,6 +59,9 @@ def classify(op):
 
 
 def main():
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    ap.add_argument("-o", "--out", help="also write the census to this file")
+    args = ap.parse_args()  # (flags are parsed before anything is written: `--help` once became an output path)
     src = (CSRC / "k_trace.hip").read_text().splitlines()
     secs = sections_of(src)
     with tempfile.TemporaryDirectory() as tmp:
@@ -103,8 +107,8 @@ def main():
             top = sorted(ops.get(name, {}).items(), key=lambda kv: -kv[1])[:14]
             lines_out.append(f"  {name}: " + ", ".join(f"{k} x{v}" for k, v in top))
     text = "\n".join(lines_out) + "\n"
-    if len(sys.argv) > 1:
-        Path(sys.argv[1]).write_text(text)
+    if args.out:
+        Path(args.out).write_text(text)
     print(text)
 
 
