@@ -143,15 +143,16 @@ def counter_blocks(c, avg_launch_ms):
                 "valu_busy_frac_at_4_clocks": busy4, "valu_busy_frac_at_2p4_clocks": busy4 * VALU_CLOCKS_BEST / VALU_CLOCKS_COUNTER,
                 "lanes_per_valu_inst": lanes, "valu_insts_per_launch": n_inst, "gpu_cycles_per_launch": cycles, "effective_clock_GHz": clock_hz / 1e9,
                 "issue_rate_measured_clocks_per_inst": {"simple f32 / int (add, mul, fma, mov)": 2.4, "select / compare-to-SGPR / packed / 3-operand": 4.2, "rcp": 8.2},
-                "wait_frac": (c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAIT_INST_ANY") and c.get("SQ_WAVE_CYCLES") else None,
+                "wait_frac": (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAIT_ANY") and c.get("SQ_WAVE_CYCLES") else None,
+                "wait_inst_frac": (c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAIT_INST_ANY") and c.get("SQ_WAVE_CYCLES") else None,
                 "salu_busy_frac_at_4_clocks": (4.0 * c["SQ_ACTIVE_INST_SCA"] / (N_SIMD * cycles)) if c.get("SQ_ACTIVE_INST_SCA") else None,
                 "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
                 "definitions": "achieved = SQ_INSTS_VALU x (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) / launch time = active-lane VALU operations per second; "
                                "peak = 1024 SIMDs x 64 lanes x measured clock (GRBM_GUI_ACTIVE / 8 XCDs / launch time) / 2.4 clocks — the fastest rate a SIMD issues "
                                "wave64 VALU instructions at (profiles/r03_valu_issue_rates.txt), so no instruction mix can exceed it; the slab test is mostly 4.2-clock "
                                "selects and compares, for which frac_at_counter_pricing_4_clocks is the closer figure. frac = lane occupancy x issue-slot occupancy: "
-                               "lanes_per_valu_inst / 64 x valu_busy_frac. wait_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (a wave's cycles spent waiting on a "
-                               "dependent gather); SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, 's_memtime tick vs SQ PMC units')"}
+                               "lanes_per_valu_inst / 64 x valu_busy_frac. wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (the share of a wave's resident cycles it spends waiting — mostly on "
+                               "its dependent gathers), wait_inst_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (waiting for an instruction to issue); SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, 's_memtime tick vs SQ PMC units')"}
     return traffic, lanes, valu
 
 

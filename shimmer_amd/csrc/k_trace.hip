@@ -239,7 +239,7 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                 if (tz1 < t1) t1 = tz1;
                 hit_box = hit_box && (t0 < t_max) && (t1 > 0.0f);
             }
-            const uint32_t offset = __float_as_uint(nb.z);
+            const uint32_t offset = __float_as_uint(nb.z) & LINK_INDEX_MASK;  // (the device record's link word, wavefront.h: first child / first primitive)
             const uint32_t meta = __float_as_uint(nb.w);
             const uint32_t n_prims = meta & 0xffffu;
             // the three outcomes as selects, not branches: almost every step has lanes on each of them
@@ -424,19 +424,357 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3<false, false>(K3_PARAMS)
 template <>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3<true, false>(K3_PARAMS) { trace3_body<true, false, K3Shape<true, false>::LDS>(K3_ARGS); }
 
+// ---------------------------------------------------------------------------------------------
+// k_trace5: the BOTH-CHILDREN step (round 4), for scenes made of triangles only. Same algorithm, node for node — the reference tests both children of
+// every interior node it enters exactly once too (aggregate.rs:110-135: the near child next, the far child when it is popped) — but a step starts from a
+// node that is already known to be hit, fetches the 64-byte block of its two children (sibling pairs share one block on the device, render.hip) and runs
+// both slab tests at once. A ray's chain of dependent fetches is half as long (S3: 28-33 block fetches instead of 56-67 node fetches per ray), and the
+// stack sees a quarter of the traffic: a far child is only pushed when the ray can hit its box at all (7-8 pushes per ray instead of 28-33).
+//  * What makes the early test of the far child exact: the slab distances depend on the ray and the box only; the one thing that changes until the
+//    reference would have tested it is t_max (a closer hit found in between). So the step evaluates everything but `t0 < t_max` and the stack entry
+//    carries t0 — {link word, t0}, 8 bytes — for that compare to be made at the pop, against the t_max of THAT moment (t0 may be a NaN for an
+//    irregular ray: the compare is false then, as in the reference's chain). A far child that fails the t_max-independent part is never pushed: the
+//    reference would pop it, test it and drop it — one node visit, counted here at the step. Hits, tie order and both visit counters equal the oracle's
+//    (tools/sim/pair_step_sim.cpp is the scalar model of this body; tests/test_gpu_parity.py compares the kernels themselves).
+//  * any-hit: t_max never changes, so the far child's whole test is known at the step and no t0 is needed; but a ray ends at its first hit and the
+//    reference never visits what is still on its stack then — a far child that already failed ("phantom") must count only if the traversal gets back to
+//    it. Phantoms are not pushed: a lane counts those above its newest stack entry in a register, an entry carries the count of those below it in its
+//    second word, and a pop adds what it passes. Same totals as the reference's loop for every ray (same sim, ANY mode).
+//  * a lane's whole state is ONE register: `cur` is the link word of the node it goes on from (interior: fetch its children; leaf: bit 31, pending triangle
+//    test) or one of three values no link word can take (axis 3): idle, pop pending, done.
+//  * closest-hit writes the hit record when it FINDS a closer hit (1.3 stores per hit ray) instead of carrying prim / b0 / b1 / b2 in registers until the
+//    ray retires; t is t_max itself; a miss is written at retirement.
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t { CUR_IDLE = 0x7fffffffu, CUR_POP = 0x7ffffffeu, CUR_DONE = 0x7ffffffdu, CUR_FIRST_SPECIAL = 0x60000000u };
+
+template <bool ANY, int LDS_N>
+__device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
+                                            uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
+                                            ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
+                                            float4* __restrict__ L, const float4* __restrict__ contrib,
+                                            DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
+                                            int refill_min, int leaf_min, int queue_parts, int rays_per_lane, const uint32_t* __restrict__ big_leaf_n) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) u32x2 lds_u2;
+    __shared__ u32x2 lds_stack5[(TRACE_BLOCK / WAVE) * LDS_N * WAVE];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave_in_block = threadIdx.x / WAVE;
+    // the per-lane stack of {link word, t0 | phantom count} entries: levels [0, LDS_N) in LDS as [level][lane], deeper ones in the per-lane HBM spill
+    lds_u2* const st_base = (lds_u2*)lds_stack5 + wave_in_block * LDS_N * WAVE + lane;
+    lds_u2* top = st_base;
+    u32x2* const st_spill_wave = reinterpret_cast<u32x2*>(spill) + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE;
+    const uint32_t n = n_ptr ? *n_ptr : n_direct;
+    // (a small queue is traced by a part of the persistent grid: see trace3_body)
+    const uint32_t per_block = (uint32_t)TRACE_BLOCK * (uint32_t)(rays_per_lane > 0 ? rays_per_lane : 1);
+    const uint32_t blocks_wanted = rays_per_lane > 0 ? (n + per_block - 1u) / per_block : gridDim.x;
+    const uint32_t active_blocks = blocks_wanted < 64u ? (gridDim.x < 64u ? gridDim.x : 64u) : (blocks_wanted < gridDim.x ? blocks_wanted : gridDim.x);
+    if (blockIdx.x >= active_blocks) return;
+    const char* __restrict__ node_base = reinterpret_cast<const char*>(sv.nodes);
+    const char* __restrict__ prim_base = reinterpret_cast<const char*>(sv.prim_recs);
+    // the root's record (wave-uniform: scalar registers for the whole kernel): a new ray tests it where it is taken from the queue
+    auto uniform4 = [](float4 v) {  // (readfirstlane: the compiler cannot prove a global load uniform, and eight VGPRs held for the refill path would spill)
+        return make_float4(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.x))), __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.y))),
+                           __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.z))), __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.w))));
+    };
+    const float4 root_a = uniform4(reinterpret_cast<const float4*>(node_base)[0]), root_b = uniform4(reinterpret_cast<const float4*>(node_base)[1]);
+    unsigned long long w_nodes = 0, w_rays = 0, w_prims = 0;  // closest-hit: all three per wave in scalar registers
+    uint32_t c_nodes = 0, ph_top = 0;                         // any-hit: node visits per lane (phantoms make the increments differ), phantoms above the top entry
+
+    bool exhausted = false;          // wave-uniform
+    uint32_t w_next = 0, w_end = 0;  // wave-uniform private range of the queue
+    const uint32_t n_waves = active_blocks * (TRACE_BLOCK / WAVE);
+    uint32_t chunk = n / (n_waves * 8u);
+    chunk = chunk < 64u ? 64u : (chunk > (uint32_t)K3_CHUNK_MAX ? (uint32_t)K3_CHUNK_MAX : chunk);
+    chunk = (chunk + 63u) & ~63u;
+    uint32_t path = 0;
+    V3 ro = v3s(0.0f), inv_dir = v3s(0.0f);
+    unsigned long long m_negx = 0ull, m_negy = 0ull, m_negz = 0ull, m_irregular = 0ull;  // see trace3_body
+    uint32_t sgn = 0;  // bits 0-2: dir_is_neg, bit 3: irregular ray, bit 4: a hit has been found (closest: its record is in `hits` already)
+    RayShear rs;
+    rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
+    Float t_max = 0.0f;
+    uint32_t cur = CUR_IDLE;
+
+    // Bounds3f::intersect_p_cached (bounding_box.rs:520-563) without its `t0 < t_max`: the t_max-independent part of the verdict, and t0
+    auto slab = [&](const float4 na, const float4 nb, Float& t0_out) -> bool {
+        const Float g = 1.0f + 2.0f * gamma(3);
+        const Float tx0 = (sel_mask(m_negx, na.x, na.w) - ro.x) * inv_dir.x;
+        Float tx1 = (sel_mask(m_negx, na.w, na.x) - ro.x) * inv_dir.x;
+        const Float ty0 = (sel_mask(m_negy, na.y, nb.x) - ro.y) * inv_dir.y;
+        Float ty1 = (sel_mask(m_negy, nb.x, na.y) - ro.y) * inv_dir.y;
+        const Float tz0 = (sel_mask(m_negz, na.z, nb.y) - ro.z) * inv_dir.z;
+        Float tz1 = (sel_mask(m_negz, nb.y, na.z) - ro.z) * inv_dir.z;
+        tx1 *= g;
+        ty1 *= g;
+        tz1 *= g;
+        if (m_irregular == 0ull) {
+            // every ray of the wave is regular: no slab distance is a NaN, and the reference's chain is max3(near) <= min3(far) && min3 > 0 (&& max3 < t_max);
+            // see trace3_body for why
+            const Float t0 = vmax3(tx0, ty0, tz0), t1 = vmin3(tx1, ty1, tz1);
+            t0_out = t0;
+            return (t0 <= t1) && (t1 > 0.0f);
+        }
+        // bounding_box.rs:520-563 statement for statement (a lane may hold NaNs: comparisons with them are false, the selects keep them)
+        Float t0 = tx0, t1 = tx1;
+        bool ok = !(t0 > ty1 || ty0 > t1);
+        if (ty0 > t0) t0 = ty0;
+        if (ty1 < t1) t1 = ty1;
+        ok = ok && !(t0 > tz1 || tz0 > t1);
+        if (tz0 > t0) t0 = tz0;
+        if (tz1 < t1) t1 = tz1;
+        t0_out = t0;
+        return ok && (t1 > 0.0f);
+    };
+    auto push = [&](uint32_t link, uint32_t word1) {
+        // two different store flavours, so that the compiler cannot merge them into one flat_store of a selected pointer
+        if (top < st_base + LDS_N * WAVE) *top = u32x2{link, word1};
+        else st_spill_wave[(size_t)(top - (st_base + LDS_N * WAVE)) + lane] = u32x2{link, word1};
+        top += WAVE;
+    };
+
+    const uint32_t n_parts = (uint32_t)queue_parts;
+    const uint32_t part_size = ((n + n_parts * 64u - 1u) / (n_parts * 64u)) * 64u;
+    uint32_t part = (n_parts > 1u) ? (__builtin_amdgcn_s_getreg(6164 /* HW_REG_XCC_ID, bits [3:0] */) & (n_parts - 1u)) : 0u;
+    uint32_t parts_left = n_parts;
+    for (;;) {
+        // ---- refill idle lanes from the wave-private chunk [w_next, w_end); one atomic per `chunk` rays ----
+        const unsigned long long idle = __ballot(cur == CUR_IDLE);
+        if (idle != 0ull) {
+            const int n_idle = __popcll(idle);
+            if (!exhausted && (n_idle >= refill_min || idle == ~0ull)) {
+                while (w_next >= w_end && !exhausted) {
+                    const uint32_t p_begin = part * part_size;
+                    const uint32_t p_end = (p_begin < n) ? ((n - p_begin < part_size) ? n : p_begin + part_size) : p_begin;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(head + part * 32u, chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base < p_end - p_begin) {
+                        w_next = p_begin + base;
+                        w_end = (p_end - w_next < chunk) ? p_end : w_next + chunk;
+                    } else {
+                        part = (part + 1u == n_parts) ? 0u : part + 1u;
+                        if (--parts_left == 0u) exhausted = true;
+                    }
+                }
+                if (!exhausted) {
+                    const uint32_t take = min((uint32_t)n_idle, w_end - w_next);
+                    if (cur == CUR_IDLE) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                        if (rank < take) {
+                            const uint32_t qi = w_next + rank;
+                            path = queue ? queue[qi] : qi;
+                            const float4* rp = reinterpret_cast<const float4*>(rays + path);
+                            const float4 r0 = rp[0], r1 = rp[1];
+                            // aggregate.rs:76-81 + the ray-constant part of the triangle test
+                            const V3 o = v3(r0.x, r0.y, r0.z), d = v3(r0.w, r1.x, r1.y);
+                            ro = o;
+                            inv_dir = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                            const bool regular = is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(inv_dir.x) && is_finite(inv_dir.y) && is_finite(inv_dir.z) &&
+                                                 inv_dir.x != 0.0f && inv_dir.y != 0.0f && inv_dir.z != 0.0f;
+                            sgn = (inv_dir.x < 0.0f ? 1u : 0u) | (inv_dir.y < 0.0f ? 2u : 0u) | (inv_dir.z < 0.0f ? 4u : 0u) | (regular ? 0u : 8u);
+                            rs = ray_shear(d);
+                            t_max = r1.z;
+                            top = st_base;
+                            if (ANY) ph_top = 0u;
+                            // the root (aggregate.rs:92-97, first iteration), by the reference's own chain: once per ray, and this lane's sign masks do not exist yet
+                            {
+                                const Float g = 1.0f + 2.0f * gamma(3);
+                                const bool nx = (sgn & 1u) != 0u, ny = (sgn & 2u) != 0u, nz = (sgn & 4u) != 0u;
+                                Float t0 = ((nx ? root_a.w : root_a.x) - ro.x) * inv_dir.x;
+                                Float t1 = ((nx ? root_a.x : root_a.w) - ro.x) * inv_dir.x;
+                                const Float ty0 = ((ny ? root_b.x : root_a.y) - ro.y) * inv_dir.y;
+                                Float ty1 = ((ny ? root_a.y : root_b.x) - ro.y) * inv_dir.y;
+                                t1 *= g;
+                                ty1 *= g;
+                                bool ok = !(t0 > ty1 || ty0 > t1);
+                                if (ty0 > t0) t0 = ty0;
+                                if (ty1 < t1) t1 = ty1;
+                                const Float tz0 = ((nz ? root_b.y : root_a.z) - ro.z) * inv_dir.z;
+                                Float tz1 = ((nz ? root_a.z : root_b.y) - ro.z) * inv_dir.z;
+                                tz1 *= g;
+                                ok = ok && !(t0 > tz1 || tz0 > t1);
+                                if (tz0 > t0) t0 = tz0;
+                                if (tz1 < t1) t1 = tz1;
+                                ok = ok && (t0 < t_max) && (t1 > 0.0f);
+                                cur = ok ? __float_as_uint(root_b.z) : (uint32_t)CUR_POP;  // (a miss pops the empty stack: done, retired below)
+                                if (ANY) c_nodes += 1u;
+                            }
+                        }
+                    }
+                    w_next += take;
+                    w_rays += take;
+                    if (!ANY) w_nodes += take;
+                    m_negx = __ballot((sgn & 1u) != 0u);
+                    m_negy = __ballot((sgn & 2u) != 0u);
+                    m_negz = __ballot((sgn & 4u) != 0u);
+                    m_irregular = __ballot((sgn & 8u) != 0u);
+                }
+            }
+            if (__ballot(cur != CUR_IDLE) == 0ull) {
+                if (exhausted) break;
+                continue;  // private chunk was empty: fetch the next one
+            }
+        }
+        // ---- one uniform step: every lane that stands on an interior node fetches the block of its two children and tests both (aggregate.rs:92-135) ----
+        const bool at_node = cur < (uint32_t)CUR_FIRST_SPECIAL;
+        if (!ANY) w_nodes += 2ull * (unsigned long long)__popcll(__ballot(at_node));
+        if (at_node) {
+            // near child first (aggregate.rs:119-127: dir_is_neg[axis] picks it); pairs start at even indices, so the sibling's record is at byte offset ^ 32
+            const uint32_t neg = (sgn >> (cur >> LINK_AXIS_SHIFT)) & 1u;
+            const uint32_t off_near = (cur << 5) | (neg << 5);  // (cur << 5 drops the axis bits; a 32-bit byte offset on the uniform base)
+            const float4* pn = reinterpret_cast<const float4*>(node_base + off_near);
+            const float4* pf = reinterpret_cast<const float4*>(node_base + (off_near ^ 32u));
+            const float4 na = pn[0], nb = pn[1], fa = pf[0], fb = pf[1];
+            Float t0n, t0f;
+            const bool pre_n = slab(na, nb, t0n), pre_f = slab(fa, fb, t0f);
+            const bool hit_n = pre_n && (t0n < t_max), hit_f = pre_f && (t0f < t_max);
+            const uint32_t link_n = __float_as_uint(nb.z), link_f = __float_as_uint(fb.z);
+            if (ANY) {
+                // t_max is fixed: the far child's verdict is final now. Visits: the near child now; the far child now if the traversal turns to it at
+                // once (the near child missed: the reference's very next pop), at its pop if it is pushed, and as a phantom otherwise
+                c_nodes += hit_n ? 1u : 2u;
+                if (hit_n && hit_f) { push(link_f, ph_top); ph_top = 0u; }
+                else if (hit_n) ph_top += 1u;
+            } else {
+                if (hit_n && pre_f) push(link_f, __float_as_uint(t0f));  // aggregate.rs:119-127: the far child waits; what is left of its test is `t0 < t_max`
+            }
+            cur = hit_n ? link_n : (hit_f ? link_f : (uint32_t)CUR_POP);
+        }
+        // ---- postponed leaf phase: lanes standing on a leaf wait until enough of them do (or nothing else can run) ----
+        const unsigned long long leaf_mask = __ballot((int32_t)cur < 0);
+        if (leaf_mask != 0ull) {
+            const unsigned long long node_mask = __ballot(cur < (uint32_t)CUR_FIRST_SPECIAL);
+            if (__popcll(leaf_mask) >= leaf_min || node_mask == 0ull) {
+                // the primitives of a leaf one after the other, in a loop the WAVE steps through (its trip count is the longest pending leaf — almost always
+                // 1): the lanes whose leaf has an i-th primitive test it, and the primitive tests are counted per wave where the loop's own condition is
+                const bool on_leaf = (int32_t)cur < 0;
+                const uint32_t leaf_off = cur & LINK_INDEX_MASK;
+                uint32_t leaf_n = on_leaf ? ((cur >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX) : 0u;
+                if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[leaf_off];
+                for (uint32_t i = 0;; ++i) {
+                    const unsigned long long testing = __ballot(i < leaf_n);
+                    if (testing == 0ull) break;
+                    w_prims += (unsigned long long)__popcll(testing);
+                    if (i < leaf_n) {
+                        const uint32_t slot = leaf_off + i;
+                        const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * 48u);
+                        const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+                        // (the precomputed degeneracy flag is applied to the RESULT, see trace3_body)
+                        TriangleIntersection ti;
+                        bool got = intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
+                        got = got && !(__float_as_uint(q2.y) & PRIM_DEGENERATE_BIT);
+                        if (got) {
+                            sgn |= 16u;
+                            if (ANY) leaf_n = 0u;  // intersect_predicate returns at its first hit (aggregate.rs:160-166)
+                            else {
+                                t_max = ti.t;  // aggregate.rs:105-109 shrinks the ray to the hit
+                                float4* hp = reinterpret_cast<float4*>(hits + path);
+                                hp[0] = make_float4(__int_as_float((int32_t)slot), ti.t, ti.b0, ti.b1);
+                                hp[1] = make_float4(ti.b2, 0.0f, 0.0f, 0.0f);
+                            }
+                        }
+                    }
+                }
+                if (on_leaf) cur = (ANY && (sgn & 16u) != 0u) ? (uint32_t)CUR_DONE : (uint32_t)CUR_POP;
+            }
+        }
+        // ---- pop: a lane whose two children both missed, or that is through with a leaf, takes the next node from its stack (aggregate.rs:129-135) ----
+#ifndef K5_POP_ROUNDS
+#define K5_POP_ROUNDS 1
+#endif
+        for (int round = 0; round < (ANY ? 1 : K5_POP_ROUNDS); ++round) {  // (closest-hit: a culled entry costs no fetch; further rounds let its lane try the next one at once)
+            if (__ballot(cur == CUR_POP) == 0ull) break;
+            if (cur == CUR_POP) {
+                if (ANY) { c_nodes += ph_top; ph_top = 0u; }  // the phantoms above the newest entry: popped, tested, dropped, one after the other
+                if (top == st_base) cur = CUR_DONE;
+                else {
+                    top -= WAVE;
+                    u32x2 e;
+                    // two different load flavours, so that the compiler cannot merge them into one flat_load of a selected pointer
+                    if (top < st_base + LDS_N * WAVE) e = *top;
+                    else e = __builtin_nontemporal_load(st_spill_wave + (size_t)(top - (st_base + LDS_N * WAVE)) + lane);
+                    if (ANY) { c_nodes += 1u; ph_top = e.y; cur = e.x; }
+                    else if (__uint_as_float(e.y) < t_max) cur = e.x;  // the rest of the far child's test, against the t_max of now
+                    // (else: culled without a fetch; the lane pops again in the next iteration)
+                }
+            }
+        }
+        // ---- retire finished rays ----
+        if (cur == CUR_DONE) {
+            const bool found = (sgn & 16u) != 0u;
+            if (ANY) {
+                if (occluded_out) occluded_out[path] = found ? 1 : 0;
+                if (L && !found) {
+                    float4 l = L[path], c = contrib[path];
+                    l.x += c.x; l.y += c.y; l.z += c.z; l.w += c.w;
+                    L[path] = l;
+                }
+            } else if (!found) {
+                float4* hp = reinterpret_cast<float4*>(hits + path);  // a miss is all zeros behind prim = -1
+                hp[0] = make_float4(__int_as_float(-1), 0.0f, 0.0f, 0.0f);
+                hp[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            cur = CUR_IDLE;
+        }
+    }
+    if (ANY) {
+        unsigned long long wn = c_nodes;
+        for (int off = 32; off > 0; off >>= 1) wn += __shfl_down(wn, off);
+        w_nodes = wn;
+    }
+    if (lane == 0 && w_rays) {
+        if (ANY) {
+            atomicAdd(&counters->rays_any, w_rays);
+            atomicAdd(&counters->nodes_any, w_nodes);
+            atomicAdd(&counters->tris_any, w_prims);
+        } else {
+            atomicAdd(&counters->rays_closest, w_rays);
+            atomicAdd(&counters->nodes_closest, w_nodes);
+            atomicAdd(&counters->tris_closest, w_prims);
+        }
+    }
+}
+
+#ifndef K5_CLOSEST_WAVES
+#define K5_CLOSEST_WAVES 8
+#endif
+#ifndef K5_ANY_WAVES
+#define K5_ANY_WAVES 8
+#endif
+// {LDS levels of 8-byte entries, workgroups per CU}: 256 lanes x 8 B = 2 KiB per level and workgroup; 9 levels x 8 workgroups = 144 of the CU's 160 KiB
+// (S3: 98.5 % of the pushes land below level 9, 99.95 % below 12 — tools/sim/run_pair_sim.py; the rest goes to the HBM spill)
+#ifndef K5_LDS_AT_8
+#define K5_LDS_AT_8 9
+#endif
+template <int WAVES> struct K5Shape { static constexpr int LDS = (WAVES >= 8 ? K5_LDS_AT_8 : (WAVES == 7 ? 11 : (WAVES == 6 ? 13 : 15))), PER_CU = WAVES; };
+#define K5_PARAMS K3_PARAMS, const uint32_t* __restrict__ big_leaf_n
+#define K5_ARGS K3_ARGS, big_leaf_n
+template <bool ANY>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace5(K5_PARAMS);
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_CLOSEST_WAVES, K5_CLOSEST_WAVES))) k_trace5<false>(K5_PARAMS) {
+    trace5_body<false, K5Shape<K5_CLOSEST_WAVES>::LDS>(K5_ARGS);
+}
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_ANY_WAVES, K5_ANY_WAVES))) k_trace5<true>(K5_PARAMS) {
+    trace5_body<true, K5Shape<K5_ANY_WAVES>::LDS>(K5_ARGS);
+}
+
 __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x; i < 8 * 32; i += blockDim.x) heads[i] = 0; }
 }  // namespace
 
 int wf_trace_prepare(ShmScene* s) {
     if (s->flat.nodes.size() + s->flat.instances.size() + 2 > (size_t)1 << 27) { shm_err() = "more than 2^27 BVH nodes (the traversal kernels address the node array with 32-bit byte offsets)"; return SHM_ERR_UNSUPPORTED; }
     const bool tri_only = !s->flat.has_spheres;
+    const bool pair = tri_only && s->trace_pair;  // k_trace5 (8-byte stack entries)
     for (int any = 0; any < 2; ++any) {
-        const int lds = tri_only ? (any ? K3Shape<true, true>::LDS : K3Shape<false, true>::LDS) : K3Shape<false, false>::LDS;
+        int lds = tri_only ? (any ? K3Shape<true, true>::LDS : K3Shape<false, true>::LDS) : K3Shape<false, false>::LDS;
         int per_cu = tri_only ? (any ? K3Shape<true, true>::PER_CU : K3Shape<false, true>::PER_CU) : K3Shape<false, false>::PER_CU;
+        if (pair) { lds = any ? K5Shape<K5_ANY_WAVES>::LDS : K5Shape<K5_CLOSEST_WAVES>::LDS; per_cu = any ? K5Shape<K5_ANY_WAVES>::PER_CU : K5Shape<K5_CLOSEST_WAVES>::PER_CU; }
         if (s->trace3_per_cu_override > 0) per_cu = std::min(per_cu, s->trace3_per_cu_override);
         s->trace3_blocks[any] = s->n_cu * per_cu;
         s->spill3_levels[any] = std::max(0, (int)s->flat.max_leaf_depth + 1 - lds) + 1;
-        const size_t words = (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[any] * WAVE;
+        const size_t words = (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[any] * WAVE * (pair ? 2u : 1u);
         void* d = nullptr;
         if (hipMalloc(&d, words * sizeof(uint32_t)) != hipSuccess) { shm_err() = "hipMalloc of the traversal stack spill failed"; return SHM_ERR_OUT_OF_MEMORY; }
         s->allocs.push_back(d);
@@ -455,9 +793,14 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
 #define TRACE_LAUNCH(ANY, TRI)                                                                                                                   \
     hipLaunchKernelGGL((k_trace3<ANY, TRI>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
                        hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane)
-    if (any) { if (tri_only) TRACE_LAUNCH(true, true); else TRACE_LAUNCH(true, false); }
+#define TRACE5_LAUNCH(ANY)                                                                                                                    \
+    hipLaunchKernelGGL((k_trace5<ANY>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,  \
+                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, s->d_big_leaf_n)
+    if (tri_only && s->trace_pair) { if (any) TRACE5_LAUNCH(true); else TRACE5_LAUNCH(false); }
+    else if (any) { if (tri_only) TRACE_LAUNCH(true, true); else TRACE_LAUNCH(true, false); }
     else { if (tri_only) TRACE_LAUNCH(false, true); else TRACE_LAUNCH(false, false); }
+#undef TRACE5_LAUNCH
 #undef TRACE_LAUNCH
-    LAUNCH_TRY(any ? "k_trace3<any>" : "k_trace3<closest>");
+    LAUNCH_TRY(any ? "k_trace<any>" : "k_trace<closest>");
     return SHM_OK;
 }

@@ -329,6 +329,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     // shares the block its sibling brought in. Same nodes, same visit order, same counters: an interior node's `offset` is its first child's index, the
     // second child is offset + 1 (k_trace.hip). Headline frame: K2 136.0 -> 133.5 ms, K3 81.0 -> 77.8 ms (of which the larger-child-next order: 0.5 %).
     std::vector<ShmBvhNode> pair_nodes;
+    std::vector<uint32_t> big_leaf_n;
     std::vector<ShmInstance> pair_instances = f.instances;
     {
         const std::vector<ShmBvhNode>& dn = f.nodes;
@@ -374,15 +375,25 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
         ShmBvhNode zero;
         memset(&zero, 0, sizeof(zero));
         pair_nodes.assign(next, zero);
+        if (next > LINK_INDEX_MASK || f.prim_recs.size() > LINK_INDEX_MASK) { g_err = "more than 2^27 BVH nodes or primitives (the device link word holds 27-bit indices)"; return fail(SHM_ERR_UNSUPPORTED); }
         for (size_t o = 0; o < dn.size(); ++o) {
             if (new_index[o] == 0xffffffffu) continue;  // (not reachable from any root)
             ShmBvhNode n = dn[o];
-            if (n.n_prims == 0) n.offset = new_index[o + 1];
+            // the link word (wavefront.h): where a traversal goes on from this node
+            if (n.n_prims == 0) n.offset = ((uint32_t)n.axis << LINK_AXIS_SHIFT) | new_index[o + 1];
+            else {
+                if (n.n_prims >= LINK_COUNT_MAX) {
+                    if (big_leaf_n.empty()) big_leaf_n.assign(f.prim_recs.size(), 0u);
+                    big_leaf_n[n.offset] = n.n_prims;
+                }
+                n.offset = LINK_LEAF | (std::min<uint32_t>(n.n_prims, LINK_COUNT_MAX) << LINK_COUNT_SHIFT) | n.offset;
+            }
             pair_nodes[new_index[o]] = n;
         }
         for (ShmInstance& in : pair_instances) in.root_node = new_index[in.root_node];
     }
     if ((rc = dev_upload(s, pair_nodes, &v.nodes)) != SHM_OK) return fail(rc);
+    if (!big_leaf_n.empty()) { const uint32_t* d = nullptr; if ((rc = dev_upload(s, big_leaf_n, &d)) != SHM_OK) return fail(rc); s->d_big_leaf_n = const_cast<uint32_t*>(d); }
     if ((rc = dev_upload(s, f.prim_recs, &v.prim_recs)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.primitives, &v.primitives)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.mesh_flags, &v.mesh_flags)) != SHM_OK) return fail(rc);
@@ -447,6 +458,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) s->trace3_per_cu_override = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
+    if (const char* e = getenv("SHM_TRACE_PAIR")) s->trace_pair = atoi(e) != 0;
     if ((rc = wf_trace_prepare(s)) != SHM_OK) return fail(rc);
     DBG("scene: %u nodes, depth %u, trace blocks %d / %d, spill levels %d / %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->trace3_blocks[0], s->trace3_blocks[1],
         s->spill3_levels[0], s->spill3_levels[1]);

@@ -49,6 +49,13 @@ constexpr int WAVE = 64;
 constexpr int TRACE_BLOCK = 256;  // 4 waves per workgroup
 constexpr int SHADE_BLOCK = 128;
 
+// The DEVICE copy of a BVH node (render.hip lays the tree out by sibling pairs and rewrites `offset` into a link word; the ABI's array and the
+// oracle's keep the reference's fields): everything a traversal step needs to go on from a node without reading it again —
+//   interior  axis << 29 | index of the first child (the second is + 1; pairs start at even indices, so (index << 5) ^ 32 is the sibling's byte offset)
+//   leaf      1 << 31 | min(n_prims, 15) << 27 | offset of its first primitive record (a count of 15 means: read ShmScene::d_big_leaf_n[offset])
+// `n_prims` and `axis` stay where they were for the kernels that read them (k_trace3).
+constexpr uint32_t LINK_LEAF = 0x80000000u, LINK_INDEX_MASK = 0x07ffffffu, LINK_COUNT_SHIFT = 27u, LINK_COUNT_MAX = 15u, LINK_AXIS_SHIFT = 29u;
+
 struct DeviceCounters {
     unsigned long long rays_closest, rays_any, nodes_closest, tris_closest, nodes_any, tris_any, paths;
 };
@@ -185,6 +192,8 @@ struct ShmScene {
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
     int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
     uint32_t* d_spill3 = nullptr;
+    uint32_t* d_big_leaf_n = nullptr;  // n_prims by first primitive slot, only in scenes with a leaf of >= 15 primitives (the link word holds smaller counts)
+    bool trace_pair = true;          // triangle-only scenes: the both-children step (k_trace5) instead of the one-node step (k_trace3); SHM_TRACE_PAIR=0 for A/B
     float4* d_rw = nullptr;          // RandomWalk: (le, f cos) per depth per path, 2 * (max_depth + 1) * capacity float4
     size_t rw_floats4 = 0;
     uint32_t* d_spill3_any = nullptr;  // the any-hit kernel may run concurrently with the closest-hit one (second stream)

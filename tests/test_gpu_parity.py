@@ -78,11 +78,61 @@ def test_trace_bitwise_parity(env, name):
         assert sg["nodes_closest"] == so["nodes_closest"] and sg["tris_closest"] == so["tris_closest"] and sg["rays_closest"] == 30000
         ag, s2 = gpu.trace(rays, any_hit=True)
         ao, s3 = orc.trace(rays, any_hit=True)
-        # any-hit: identical occlusion flags and primitive tests; the tuned kernel tests both children at the parent, so it
-        # may count node visits the reference never makes after its early exit
+        # any-hit: identical occlusion flags, primitive tests AND node visits — the pair-step kernel tests both children at the parent, and counts a
+        # far child only if the reference's loop would have reached it before its early exit (phantom counts, k_trace.hip)
         assert np.array_equal(ag, ao) and s2["nodes_any"] == s3["nodes_any"] and s2["tris_any"] == s3["tris_any"]
     gpu.close()
     orc.close()
+
+
+def _stacked_leaf_scene(scenes, lib, copies):
+    """The Cornell box plus `copies` coincident triangles (identical centroids: BvhAggregate::new leaves them in ONE leaf, aggregate.rs:345-356) —
+    a leaf of more primitives than the device link word's count field holds (15)."""
+    from shimmer_amd.scene import SceneBuilder
+    b = SceneBuilder()
+    b.set_film(32, 32)
+    rfw = b.set_camera_look_at(lib, (0, 1, 3.4), (0, 1, 0), (0, 1, 0), 39.0)
+    white = b.material_diffuse(0.75)
+    room_p, room_vi = scenes._merge([scenes._box((-1, 0, -1), (1, 2, 1), faces="xXyYz")])
+    b.add_mesh(scenes._to_render(room_p, rfw), room_vi, white)
+    tri = np.array([[-0.4, 0.6, 0.0], [0.4, 0.6, 0.1], [0.0, 1.4, -0.1]], np.float32)
+    p = np.concatenate([tri] * copies)
+    vi = np.arange(3 * copies, dtype=np.uint32).reshape(-1, 3)
+    b.add_mesh(scenes._to_render(p, rfw), vi, white)
+    pl, vil = scenes._quad((-0.3, 1.99, -0.3), (0.3, 1.99, -0.3), (0.3, 1.99, 0.3), (-0.3, 1.99, 0.3))
+    from shimmer_amd.scene import blackbody_dense
+    b.add_mesh(scenes._to_render(pl, rfw), vil, b.material_diffuse(0.0), emission=blackbody_dense(6500.0), emission_scale=10.0)
+    return scenes._finish(b, lib, name=f"stacked leaf x{copies}")
+
+
+@pytest.mark.parametrize("pair", ["1", "0"])
+def test_trace_both_step_kinds(env, monkeypatch, pair):
+    """Triangle-only scenes are traced by the both-children step (k_trace5, the default) or by the one-node step (k_trace3, SHM_TRACE_PAIR=0, the
+    kernel the scenes with quadrics / patches / instances use): hit records, occlusion flags and all four visit counters equal the oracle's under
+    either, on a deep tree (S3 proxy, stack spill exercised with depth beyond the LDS levels), a shallow one, and a tree with leaves of 1, 14, 15, 16
+    and 40 coincident triangles (the link word's count field saturates at 15: ShmScene::d_big_leaf_n)."""
+    lib, oracle_py, render, scenes = env
+    monkeypatch.setenv("SHM_TRACE_PAIR", pair)
+    cases = [scenes.ganesha_proxy(lib, 64, 64, n=96), scenes.cornell_box(lib, 32, 32)] + [_stacked_leaf_scene(scenes, lib, c) for c in (14, 15, 16, 40)]
+    for sc in cases:
+        gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+        for seed, tmax, aim in ((5, np.inf, 0.5), (6, 2.5, 0.9)):
+            rays = _rays(sc, 40000, seed, tmax, toward_centre=aim)
+            hg, sg = gpu.trace(rays)
+            ho, so = orc.trace(rays)
+            assert np.array_equal(hg.view(np.uint8), ho.view(np.uint8)), sc.name
+            assert sg["nodes_closest"] == so["nodes_closest"] and sg["tris_closest"] == so["tris_closest"], sc.name
+            ag, s2 = gpu.trace(rays, any_hit=True)
+            ao, s3 = orc.trace(rays, any_hit=True)
+            assert np.array_equal(ag, ao) and s2["nodes_any"] == s3["nodes_any"] and s2["tris_any"] == s3["tris_any"], sc.name
+        p = render.make_params(seed=2, spp=4, max_depth=5)
+        fg, st = gpu.render(p)
+        fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
+        assert np.array_equal(fg, fo), sc.name
+        for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+            assert st[k] == so[k], (sc.name, k)
+        gpu.close()
+        orc.close()
 
 
 def test_trace_edge_cases(env):
