@@ -46,7 +46,7 @@ PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
 VALU_CLOCKS_BEST = 2.4     # v_add / v_mul / v_fma / v_add_u32 / v_mov
 VALU_CLOCKS_COUNTER = 4.0  # what SQ_ACTIVE_INST_VALU charges; v_cndmask (SGPR mask) / v_cmp -> SGPR / v_max3 measure 4.2
 N_SIMD, N_XCD = 256 * 4, 8
-K2_NAME = "k_trace3<closest>"
+K2_NAME = "k_trace<closest>"  # k_trace5<false> (triangle scenes: the both-children step) or k_trace3<false, *>
 
 
 def _k2_counters_from_db(db):
@@ -56,7 +56,7 @@ def _k2_counters_from_db(db):
     cur = sqlite3.connect(db).cursor()
     acc, disp = {}, set()
     for name, counter, value, d in cur.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
-        m = re.search(r"k_trace3<(\w+)(?:, (\w+))?>", name)
+        m = re.search(r"k_trace\d<(\w+)(?:, (\w+))?>", name)
         if not m or m.group(1) != "false":  # first template argument: ANY
             continue
         acc[counter] = acc.get(counter, 0.0) + float(value)
@@ -107,7 +107,8 @@ def committed_pmc(args):
     f = ROOT / "profiles" / f"traffic_res{args.res}_spp{args.spp}_n{args.n}_depth{args.max_depth}.json"
     if not f.exists() or args.width or args.height:
         return None
-    t = json.loads(f.read_text()).get(K2_NAME)
+    j = json.loads(f.read_text())
+    t = j.get("k_trace5<closest>") or j.get("k_trace3<closest>")
     if not t:
         return None
     c = {"FETCH_SIZE": t.get("FETCH_SIZE_bytes_per_dispatch_raw", 0.0) / 1024.0, "WRITE_SIZE": t.get("WRITE_SIZE_bytes_per_dispatch_raw", 0.0) / 1024.0}
@@ -472,7 +473,7 @@ def rank_main(args):
                                      "frac": (hbm_counter / HBM_PEAK_GBS) if hbm_counter else None,
                                      "traffic_over_algorithmic": (traffic / (bytes_alg / launches)) if traffic else None},
             # the second traversal kernel, same accounting (informational; `roofline` above is the dominant kernel)
-            "roofline_any_hit": {"kernel": "k_trace3<any> (BvhAggregate::intersect_predicate)",
+            "roofline_any_hit": {"kernel": "k_trace<any> (BvhAggregate::intersect_predicate)",
                                  "achieved": ((32.0 * acc["nodes_any"] + 48.0 * acc["tris_any"] + 48.0 * acc["rays_any"]) / (acc["ms_trace_any"] * 1e-3) / 1e9)
                                  if acc["ms_trace_any"] > 0 else 0.0, "unit": "GB/s",
                                  "nodes_per_ray": acc["nodes_any"] / max(1, acc["rays_any"]), "prims_per_ray": acc["tris_any"] / max(1, acc["rays_any"]),

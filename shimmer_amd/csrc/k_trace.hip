@@ -504,17 +504,18 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         Float ty1 = (sel_mask(m_negy, nb.x, na.y) - ro.y) * inv_dir.y;
         const Float tz0 = (sel_mask(m_negz, na.z, nb.y) - ro.z) * inv_dir.z;
         Float tz1 = (sel_mask(m_negz, nb.y, na.z) - ro.z) * inv_dir.z;
+        if (m_irregular == 0ull) {
+            // every ray of the wave is regular: no slab distance is a NaN, and the reference's chain is max3(near) <= min3(far * g) && min3 > 0 (&& max3 < t_max);
+            // see trace3_body for why. One product instead of three: g > 1 and rounding is monotonic, so min3(a g, b g, c g) = min3(a, b, c) g bit for bit
+            // (the far distances are not NaNs here), and its sign is the sign of min3(a, b, c).
+            const Float t0 = vmax3(tx0, ty0, tz0), t1 = vmin3(tx1, ty1, tz1);
+            t0_out = t0;
+            return (t0 <= t1 * g) && (t1 > 0.0f);
+        }
+        // bounding_box.rs:520-563 statement for statement (a lane may hold NaNs: comparisons with them are false, the selects keep them)
         tx1 *= g;
         ty1 *= g;
         tz1 *= g;
-        if (m_irregular == 0ull) {
-            // every ray of the wave is regular: no slab distance is a NaN, and the reference's chain is max3(near) <= min3(far) && min3 > 0 (&& max3 < t_max);
-            // see trace3_body for why
-            const Float t0 = vmax3(tx0, ty0, tz0), t1 = vmin3(tx1, ty1, tz1);
-            t0_out = t0;
-            return (t0 <= t1) && (t1 > 0.0f);
-        }
-        // bounding_box.rs:520-563 statement for statement (a lane may hold NaNs: comparisons with them are false, the selects keep them)
         Float t0 = tx0, t1 = tx1;
         bool ok = !(t0 > ty1 || ty0 > t1);
         if (ty0 > t0) t0 = ty0;
@@ -739,7 +740,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
 #define K5_CLOSEST_WAVES 8
 #endif
 #ifndef K5_ANY_WAVES
-#define K5_ANY_WAVES 8
+#define K5_ANY_WAVES 7  // (r04 sweep: 8 waves x 9 levels 65.5 ms of any-hit launches per headline frame, 7 waves x 11 levels 62.8)
 #endif
 // {LDS levels of 8-byte entries, workgroups per CU}: 256 lanes x 8 B = 2 KiB per level and workgroup; 9 levels x 8 workgroups = 144 of the CU's 160 KiB
 // (S3: 98.5 % of the pushes land below level 9, 99.95 % below 12 — tools/sim/run_pair_sim.py; the rest goes to the HBM spill)

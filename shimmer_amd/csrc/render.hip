@@ -453,12 +453,15 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (f.nodes.size() < 4096) s->trace_rays_per_lane = 8;
     if (const char* e = getenv("SHM_TRACE_RAYS_PER_LANE")) { int v2 = atoi(e); if (v2 >= 0 && v2 <= 4096) s->trace_rays_per_lane = v2; }
     if (const char* e = getenv("SHM_CONCURRENT_SCATTER")) s->concurrent_scatter = atoi(e) != 0;
+    if (const char* e = getenv("SHM_TRACE_PAIR")) s->trace_pair = atoi(e) != 0;
+    // the both-children kernels set a ray up with the root test and six IEEE divisions (200 VALU instructions): they refill when 40 lanes are idle, so that
+    // the set-up runs at 40 lanes instead of 24 (r04 sweep on the headline frame, closest / any ms: 24: 97.4 / 62.3, 40: 96.5 / 60.9, 48: 102.1 / 63.5, 56: 119.1 / 78.1)
+    if (!s->flat.has_spheres && s->trace_pair) s->refill_min = s->refill_min_any = 40;
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_REFILL_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) s->trace3_per_cu_override = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
-    if (const char* e = getenv("SHM_TRACE_PAIR")) s->trace_pair = atoi(e) != 0;
     if ((rc = wf_trace_prepare(s)) != SHM_OK) return fail(rc);
     DBG("scene: %u nodes, depth %u, trace blocks %d / %d, spill levels %d / %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->trace3_blocks[0], s->trace3_blocks[1],
         s->spill3_levels[0], s->spill3_levels[1]);

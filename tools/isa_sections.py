@@ -24,13 +24,19 @@ FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-con
         "-fno-gpu-flush-denormals-to-zero -Wno-unused-result -Wno-unused-value -gline-tables-only".split()
 
 
-def sections_of(src_lines):
-    """Line ranges of trace3_body's sections, found by the comments that open them (so the census follows the source as it changes)."""
-    marks = [("setup", "template <bool ANY, bool TRI_ONLY, int LDS_N>"), ("refill", "// ---- refill idle lanes"),
-             ("node_step (load + slab test)", "// ---- one uniform node step"), ("leaf-mark / push", "// the three outcomes as selects"),
-             ("leaf_phase", "// ---- postponed leaf phase"), ("pop", "// ---- pop: a lane that missed"),
-             ("retire", "// ---- retire finished rays"), ("epilogue", "unsigned long long w_prims = c_prims;"), ("end", "#define K3_PARAMS")]
-    out, pos = [], 0
+MARKS3 = [("setup", "template <bool ANY, bool TRI_ONLY, int LDS_N>"), ("refill", "// ---- refill idle lanes"),
+          ("node_step (load + slab test)", "// ---- one uniform node step"), ("leaf-mark / push", "// the three outcomes as selects"),
+          ("leaf_phase", "// ---- postponed leaf phase"), ("pop", "// ---- pop: a lane that missed"),
+          ("retire", "// ---- retire finished rays"), ("epilogue", "unsigned long long w_prims = c_prims;"), ("end", "#define K3_PARAMS")]
+MARKS5 = [("setup", "template <bool ANY, int LDS_N>"), ("refill (+ root test)", "// ---- refill idle lanes"),
+          ("pair_step (2 x (load + slab test) + push)", "// ---- one uniform step: every lane that stands"),
+          ("leaf_phase", "// ---- postponed leaf phase: lanes standing"), ("pop", "// ---- pop: a lane whose two children"),
+          ("retire", "// ---- retire finished rays"), ("epilogue", "unsigned long long wn = c_nodes;"), ("end", "#ifndef K5_CLOSEST_WAVES")]
+
+
+def sections_of(src_lines, marks, first_line=0):
+    """Line ranges of a traversal body's sections, found by the comments that open them (so the census follows the source as it changes)."""
+    out, pos = [], first_line
     for name, needle in marks:
         for i in range(pos, len(src_lines)):
             if needle in src_lines[i]:
@@ -63,7 +69,8 @@ def main():
     ap.add_argument("-o", "--out", help="also write the census to this file")
     args = ap.parse_args()  # (flags are parsed before anything is written: `--help` once became an output path)
     src = (CSRC / "k_trace.hip").read_text().splitlines()
-    secs = sections_of(src)
+    secs3 = sections_of(src, MARKS3)
+    secs5 = sections_of(src, MARKS5, secs3[-1][2])
     with tempfile.TemporaryDirectory() as tmp:
         subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-x", "hip", "-c", str(CSRC / "k_trace.hip"), "-I", str(CSRC), "-o", f"{tmp}/k.o", "-save-temps"],
                               cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -73,8 +80,9 @@ def main():
         m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
         if m:
             files[int(m.group(1))] = m.group(3) or m.group(2)
-    lines_out = [f"# static instruction census of the traversal kernels by section of trace3_body (tools/isa_sections.py; hipcc {' '.join(FLAGS[:3])} ...)"]
-    for label, want in (("k_trace3<closest, TRI_ONLY>", "k_trace3ILb0ELb1EE"), ("k_trace3<any, TRI_ONLY>", "k_trace3ILb1ELb1EE")):
+    lines_out = [f"# static instruction census of the traversal kernels by section of trace5_body / trace3_body (tools/isa_sections.py; hipcc {' '.join(FLAGS[:3])} ...)"]
+    for label, want, secs in (("k_trace5<closest> (both-children step)", "k_trace5ILb0EE", secs5), ("k_trace5<any>", "k_trace5ILb1EE", secs5),
+                              ("k_trace3<closest, TRI_ONLY> (one-node step)", "k_trace3ILb0ELb1EE", secs3), ("k_trace3<any, TRI_ONLY>", "k_trace3ILb1ELb1EE", secs3)):
         start = next(i for i, l in enumerate(asm) if re.match(r"^_ZN.*" + want + r".*:", l))
         end = next(i for i in range(start, len(asm)) if asm[i].strip().startswith(".Lfunc_end"))
         counts = defaultdict(lambda: defaultdict(int))
@@ -103,7 +111,7 @@ def main():
                 tot[k] += v
             lines_out.append(f"{name:34s} {c.get('VALU', 0):5d} {c.get('SALU', 0):5d} {c.get('BRANCH', 0):6d} {c.get('VMEM', 0):5d} {c.get('LDS', 0):4d} {c.get('WAIT', 0):5d}   k_trace.hip:{a}-{b}")
         lines_out.append(f"{'total':34s} {tot['VALU']:5d} {tot['SALU']:5d} {tot['BRANCH']:6d} {tot['VMEM']:5d} {tot['LDS']:4d} {tot['WAIT']:5d}")
-        for name in ("refill", "node_step (load + slab test)", "leaf-mark / push", "pop"):
+        for name in [n for n, _, _ in secs if n not in ("setup", "epilogue", "retire")]:
             top = sorted(ops.get(name, {}).items(), key=lambda kv: -kv[1])[:14]
             lines_out.append(f"  {name}: " + ", ".join(f"{k} x{v}" for k, v in top))
     text = "\n".join(lines_out) + "\n"
