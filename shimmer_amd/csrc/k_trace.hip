@@ -445,6 +445,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3<true, false>(K3_PARAMS) 
 //  * closest-hit writes the hit record when it FINDS a closer hit (1.3 stores per hit ray) instead of carrying prim / b0 / b1 / b2 in registers until the
 //    ray retires; t is t_max itself; a miss is written at retirement.
 // ---------------------------------------------------------------------------------------------
+#ifdef K5_CENSUS
+// development build (-DK5_CENSUS): per-phase lane census of the closest-hit kernel, printed by wf_trace_census() at scene destruction
+__device__ unsigned long long g_census[16];
+#define CENSUS(i, v) do { if (!ANY) c_census[i] += (unsigned long long)(v); } while (0)
+#else
+#define CENSUS(i, v) do { } while (0)
+#endif
 enum : uint32_t { CUR_IDLE = 0x7fffffffu, CUR_POP = 0x7ffffffeu, CUR_DONE = 0x7ffffffdu, CUR_FIRST_SPECIAL = 0x60000000u };
 
 template <bool ANY, int LDS_N>
@@ -479,6 +486,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     const float4 root_a = uniform4(reinterpret_cast<const float4*>(node_base)[0]), root_b = uniform4(reinterpret_cast<const float4*>(node_base)[1]);
     unsigned long long w_nodes = 0, w_rays = 0, w_prims = 0;  // closest-hit: all three per wave in scalar registers
     uint32_t c_nodes = 0, ph_top = 0;                         // any-hit: node visits per lane (phantoms make the increments differ), phantoms above the top entry
+#ifdef K5_CENSUS
+    unsigned long long c_census[16] = {0};
+#endif
 
     bool exhausted = false;          // wave-uniform
     uint32_t w_next = 0, w_end = 0;  // wave-uniform private range of the queue
@@ -605,6 +615,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                     w_next += take;
                     w_rays += take;
                     if (!ANY) w_nodes += take;
+                    CENSUS(11, 1); CENSUS(12, take);
                     m_negx = __ballot((sgn & 1u) != 0u);
                     m_negy = __ballot((sgn & 2u) != 0u);
                     m_negz = __ballot((sgn & 4u) != 0u);
@@ -619,6 +630,8 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         // ---- one uniform step: every lane that stands on an interior node fetches the block of its two children and tests both (aggregate.rs:92-135) ----
         const bool at_node = cur < (uint32_t)CUR_FIRST_SPECIAL;
         if (!ANY) w_nodes += 2ull * (unsigned long long)__popcll(__ballot(at_node));
+        CENSUS(0, 1); CENSUS(1, __popcll(__ballot(at_node))); CENSUS(2, __popcll(__ballot((int32_t)cur < 0))); CENSUS(3, __popcll(__ballot(cur == CUR_IDLE)));
+        CENSUS(4, __popcll(__ballot(cur == CUR_POP))); CENSUS(10, __ballot(at_node) != 0ull ? 1 : 0);
         if (at_node) {
             // near child first (aggregate.rs:119-127: dir_is_neg[axis] picks it); pairs start at even indices, so the sibling's record is at byte offset ^ 32
             const uint32_t neg = (sgn >> (cur >> LINK_AXIS_SHIFT)) & 1u;
@@ -646,37 +659,37 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         if (leaf_mask != 0ull) {
             const unsigned long long node_mask = __ballot(cur < (uint32_t)CUR_FIRST_SPECIAL);
             if (__popcll(leaf_mask) >= leaf_min || node_mask == 0ull) {
-                // the primitives of a leaf one after the other, in a loop the WAVE steps through (its trip count is the longest pending leaf — almost always
-                // 1): the lanes whose leaf has an i-th primitive test it, and the primitive tests are counted per wave where the loop's own condition is
+                // ONE primitive per lane and phase: a leaf of several primitives (coincident centroids, aggregate.rs:345-356: the room's quads) stays pending with
+                // its link word advanced to the next one — same primitives, same order, same t_max updates as the reference's inner loop, but every round of
+                // triangle tests runs with all the pending lanes (as an inner loop, the second rounds ran for the few lanes on such leaves: 0.62 extra rounds
+                // per phase, 13 % of the kernel's instructions on the headline frame)
                 const bool on_leaf = (int32_t)cur < 0;
-                const uint32_t leaf_off = cur & LINK_INDEX_MASK;
-                uint32_t leaf_n = on_leaf ? ((cur >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX) : 0u;
-                if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[leaf_off];
-                for (uint32_t i = 0;; ++i) {
-                    const unsigned long long testing = __ballot(i < leaf_n);
-                    if (testing == 0ull) break;
-                    w_prims += (unsigned long long)__popcll(testing);
-                    if (i < leaf_n) {
-                        const uint32_t slot = leaf_off + i;
-                        const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * 48u);
-                        const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
-                        // (the precomputed degeneracy flag is applied to the RESULT, see trace3_body)
-                        TriangleIntersection ti;
-                        bool got = intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
-                        got = got && !(__float_as_uint(q2.y) & PRIM_DEGENERATE_BIT);
-                        if (got) {
-                            sgn |= 16u;
-                            if (ANY) leaf_n = 0u;  // intersect_predicate returns at its first hit (aggregate.rs:160-166)
-                            else {
-                                t_max = ti.t;  // aggregate.rs:105-109 shrinks the ray to the hit
-                                float4* hp = reinterpret_cast<float4*>(hits + path);
-                                hp[0] = make_float4(__int_as_float((int32_t)slot), ti.t, ti.b0, ti.b1);
-                                hp[1] = make_float4(ti.b2, 0.0f, 0.0f, 0.0f);
-                            }
+                w_prims += (unsigned long long)__popcll(__ballot(on_leaf));
+                CENSUS(5, 1); CENSUS(6, 1); CENSUS(7, __popcll(__ballot(on_leaf)));
+                if (on_leaf) {
+                    const uint32_t slot = cur & LINK_INDEX_MASK;
+                    uint32_t leaf_n = (cur >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX;
+                    if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[slot];  // (rare: 15 or more primitives in one leaf; the table holds the count from each slot on)
+                    const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * 48u);
+                    const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+                    // (the precomputed degeneracy flag is applied to the RESULT, see trace3_body)
+                    TriangleIntersection ti;
+                    bool got = intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
+                    got = got && !(__float_as_uint(q2.y) & PRIM_DEGENERATE_BIT);
+                    if (got) {
+                        sgn |= 16u;
+                        if (!ANY) {
+                            t_max = ti.t;  // aggregate.rs:105-109 shrinks the ray to the hit
+                            float4* hp = reinterpret_cast<float4*>(hits + path);
+                            hp[0] = make_float4(__int_as_float((int32_t)slot), ti.t, ti.b0, ti.b1);
+                            hp[1] = make_float4(ti.b2, 0.0f, 0.0f, 0.0f);
                         }
                     }
+                    leaf_n -= 1u;
+                    if (ANY && got) cur = CUR_DONE;  // intersect_predicate returns at its first hit (aggregate.rs:160-166)
+                    else if (leaf_n == 0u) cur = CUR_POP;
+                    else cur = LINK_LEAF | ((leaf_n < LINK_COUNT_MAX ? leaf_n : LINK_COUNT_MAX) << LINK_COUNT_SHIFT) | (slot + 1u);
                 }
-                if (on_leaf) cur = (ANY && (sgn & 16u) != 0u) ? (uint32_t)CUR_DONE : (uint32_t)CUR_POP;
             }
         }
         // ---- pop: a lane whose two children both missed, or that is through with a leaf, takes the next node from its stack (aggregate.rs:129-135) ----
@@ -685,6 +698,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
 #endif
         for (int round = 0; round < (ANY ? 1 : K5_POP_ROUNDS); ++round) {  // (closest-hit: a culled entry costs no fetch; further rounds let its lane try the next one at once)
             if (__ballot(cur == CUR_POP) == 0ull) break;
+            CENSUS(8, 1); CENSUS(9, __popcll(__ballot(cur == CUR_POP)));
             if (cur == CUR_POP) {
                 if (ANY) { c_nodes += ph_top; ph_top = 0u; }  // the phantoms above the newest entry: popped, tested, dropped, one after the other
                 if (top == st_base) cur = CUR_DONE;
@@ -718,6 +732,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
             cur = CUR_IDLE;
         }
     }
+#ifdef K5_CENSUS
+    if (!ANY && lane == 0) for (int i = 0; i < 16; ++i) if (c_census[i]) atomicAdd(&g_census[i], c_census[i]);
+#endif
     if (ANY) {
         unsigned long long wn = c_nodes;
         for (int off = 32; off > 0; off >>= 1) wn += __shfl_down(wn, off);
@@ -763,6 +780,18 @@ __global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_e
 
 __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x; i < 8 * 32; i += blockDim.x) heads[i] = 0; }
 }  // namespace
+
+void wf_trace_census() {
+#ifdef K5_CENSUS
+    unsigned long long c[16];
+    if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_census), sizeof(c)) != hipSuccess || !c[0]) return;
+    const double it = (double)c[0];
+    fprintf(stderr, "[k5 census, closest-hit] wave iterations %.3e | lanes per iteration: at a node %.1f, on a pending leaf %.1f, idle %.1f, pop pending %.1f | iterations with a node step %.3f\n"
+                    "  leaf phases %.3e (one per %.2f iterations), primitive rounds %.3e at %.1f lanes | pop rounds %.3e at %.1f lanes | refills %.3e at %.1f rays\n",
+            it, c[1] / it, c[2] / it, c[3] / it, c[4] / it, c[10] / it, (double)c[5], it / (double)c[5], (double)c[6], (double)c[7] / (double)c[6], (double)c[8], (double)c[9] / (double)c[8],
+            (double)c[11], (double)c[12] / (double)c[11]);
+#endif
+}
 
 int wf_trace_prepare(ShmScene* s) {
     if (s->flat.nodes.size() + s->flat.instances.size() + 2 > (size_t)1 << 27) { shm_err() = "more than 2^27 BVH nodes (the traversal kernels address the node array with 32-bit byte offsets)"; return SHM_ERR_UNSUPPORTED; }

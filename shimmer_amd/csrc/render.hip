@@ -284,6 +284,7 @@ int shm_device_count(void) {
 void shm_scene_destroy(ShmScene* s) {
     if (!s) return;
     hipSetDevice(s->device);
+    wf_trace_census();  // (prints in -DK5_CENSUS development builds only)
     wf_dist_release(s);
     for (void* p : s->allocs) hipFree(p);
     for (void* p : s->ws_allocs) hipFree(p);
@@ -384,7 +385,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
             else {
                 if (n.n_prims >= LINK_COUNT_MAX) {
                     if (big_leaf_n.empty()) big_leaf_n.assign(f.prim_recs.size(), 0u);
-                    big_leaf_n[n.offset] = n.n_prims;
+                    for (uint32_t j = 0; j < n.n_prims; ++j) big_leaf_n[n.offset + j] = n.n_prims - j;  // (the primitives left from each slot on: k_trace5 takes one per phase)
                 }
                 n.offset = LINK_LEAF | (std::min<uint32_t>(n.n_prims, LINK_COUNT_MAX) << LINK_COUNT_SHIFT) | n.offset;
             }

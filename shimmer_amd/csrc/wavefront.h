@@ -52,7 +52,7 @@ constexpr int SHADE_BLOCK = 128;
 // The DEVICE copy of a BVH node (render.hip lays the tree out by sibling pairs and rewrites `offset` into a link word; the ABI's array and the
 // oracle's keep the reference's fields): everything a traversal step needs to go on from a node without reading it again —
 //   interior  axis << 29 | index of the first child (the second is + 1; pairs start at even indices, so (index << 5) ^ 32 is the sibling's byte offset)
-//   leaf      1 << 31 | min(n_prims, 15) << 27 | offset of its first primitive record (a count of 15 means: read ShmScene::d_big_leaf_n[offset])
+//   leaf      1 << 31 | min(n_prims, 15) << 27 | offset of its first primitive record (a count of 15 means: read ShmScene::d_big_leaf_n[offset], the primitives left from that slot on)
 // `n_prims` and `axis` stay where they were for the kernels that read them (k_trace3).
 constexpr uint32_t LINK_LEAF = 0x80000000u, LINK_INDEX_MASK = 0x07ffffffu, LINK_COUNT_SHIFT = 27u, LINK_COUNT_MAX = 15u, LINK_AXIS_SHIFT = 29u;
 
@@ -231,6 +231,7 @@ struct EventPool {
 // ---- launchers exported by the kernel translation units (hidden visibility: library-internal) ----
 #define WF_INTERNAL __attribute__((visibility("hidden")))
 // k_trace.hip: BvhAggregate::intersect (any = false) / intersect_predicate (any = true) over a queue of path slots
+WF_INTERNAL void wf_trace_census();  // k_trace.hip: prints the per-phase lane census of a -DK5_CENSUS development build (a no-op otherwise)
 WF_INTERNAL int wf_trace_prepare(ShmScene* s);  // grid sizes + stack spill buffers of the two traversal kernels (at scene creation)
 WF_INTERNAL int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct,
                                 const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib);
