@@ -239,6 +239,13 @@ def side_results(lib, args, render, scenes, headline_scene, log):
             C.memmove(C.byref(headline_scene.desc.materials[0]), C.byref(saved), C.sizeof(saved))
         sc = scenes.crown_proxy(lib, 1000, 1400)
         timed("C4_crown_proxy_1000x1400_spp256_depth32", sc.desc, 256, 32, sc.info["n_primitives"])
+        c4 = out["C4_crown_proxy_1000x1400_spp256_depth32"]
+        try:  # "mean path length; queue occupancy" — one more, UNTIMED render of the same frame in a child process with SHM_DEBUG=1: the library reads its queue counters back after every bounce
+            import subprocess
+            r = subprocess.run([sys.executable, str(ROOT / "tools" / "c4_bounces.py"), "--json"], capture_output=True, text=True, timeout=300)
+            c4.update(json.loads(r.stdout.strip().splitlines()[-1]))
+        except Exception as e:  # reporting only
+            c4["per_bounce_error"] = f"{type(e).__name__}: {e}"
         sc = scenes.cornell_box(lib, 512, 512)
         timed("C2_cornell_512x512_spp64", sc.desc, 64, 5, sc.info["n_primitives"])
         sc = scenes.cornell_box(lib, 512, 512, textured=True)
