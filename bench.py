@@ -49,20 +49,27 @@ N_SIMD, N_XCD = 256 * 4, 8
 K2_NAME = "k_trace<closest>"  # k_trace5<false> (triangle scenes: the both-children step) or k_trace3<false, *>
 
 
-def _k2_counters_from_db(db):
-    """Per-dispatch means of every counter of the closest-hit traversal kernel in one rocprofv3 rocpd database."""
+def _counters_from_db(db, want):
+    """Per-dispatch means of every counter of one kernel in a rocprofv3 rocpd database, and its mean duration there. `want`: "closest" — the
+    closest-hit traversal kernel (k_trace5<false> / k_trace3<false, *>) — or "shade" — the fused shading kernel of the headline scene class."""
     import re
     import sqlite3
     cur = sqlite3.connect(db).cursor()
-    acc, disp = {}, set()
-    for name, counter, value, d in cur.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
-        m = re.search(r"k_trace\d<(\w+)(?:, (\w+))?>", name)
-        if not m or m.group(1) != "false":  # first template argument: ANY
+    acc, disp = {}, {}
+    for name, counter, value, d, dur in cur.execute("select kernel_name, counter_name, value, dispatch_id, duration from counters_collection"):
+        if want == "closest":
+            m = re.search(r"k_trace\d<(\w+)(?:, (\w+))?>", name)
+            if not m or m.group(1) != "false":  # first template argument: ANY
+                continue
+        elif not re.search(r"k_shade<false, true, false, true>", name):
             continue
         acc[counter] = acc.get(counter, 0.0) + float(value)
-        disp.add(d)
+        disp[d] = float(dur)
     n = max(1, len(disp))
-    return {k: v / n for k, v in acc.items()}, len(disp)
+    out = {k: v / n for k, v in acc.items()}
+    if disp:
+        out["_duration_ms"] = sum(disp.values()) / len(disp) / 1e6
+    return out, len(disp)
 
 
 def live_pmc(args):
@@ -89,11 +96,15 @@ def live_pmc(args):
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return None, f"pass {counters[0]}: rc {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"
-            vals, n = _k2_counters_from_db(dbs[0])
+            vals, n = _counters_from_db(dbs[0], "closest")
             if not n:
                 return None, f"pass {counters[0]}: no {K2_NAME} dispatch in the database"
             out.update(vals)
             out["dispatches"] = n
+            sv, sn = _counters_from_db(dbs[0], "shade")  # (the frame's longest kernel since round 4: the same accounting, informational)
+            if sn:
+                out.setdefault("_shade", {}).update(sv)
+                out["_shade"]["dispatches"] = sn
         out["collect_s"] = time.perf_counter() - t0
         return out, "live: rocprofv3 --pmc passes of this run"
     except Exception as e:  # reporting only
@@ -494,6 +505,17 @@ def rank_main(args):
                         "libamdhip64": info["libamdhip_path"], "hip_runtime_version": info["hip_runtime_version"],
                         "rccl_ranks": info["rccl_ranks"], "rows_per_shard_block": info["rows_per_block"]},
         }
+        if counters and counters.get("_shade"):
+            sh = counters["_shade"]
+            st, _, sv = counter_blocks(sh, sh.get("_duration_ms"))
+            if sv:
+                sv["kernel"] = "k_shade<false, true, false, true> (the fused vertex kernel of all-diffuse triangle scenes: integrator.rs:772-892)"
+                out["roofline_shade"] = {"bound": "valu-issue / gather latency at three waves per SIMD (informational: the frame's longest kernel)", "kernel": sv["kernel"],
+                                         "avg_launch_ms_under_the_counter_pass": sh.get("_duration_ms"), "launches_per_step": sh.get("dispatches"),
+                                         "achieved": sv["achieved_lane_ops_per_s"] / 1e12, "peak": sv["peak_lane_ops_per_s"] / 1e12, "unit": "Tlane-op/s", "frac": sv["frac"],
+                                         "frac_at_counter_pricing_4_clocks": sv["frac_at_counter_pricing_4_clocks"], "lanes_active": sv["lanes_per_valu_inst"],
+                                         "valu_busy_frac": sv["valu_busy_frac_at_4_clocks"], "wait_frac": sv["wait_frac"], "traffic": st,
+                                         "hbm_counter_GBs": (st / (sh["_duration_ms"] * 1e-3) / 1e9) if st and sh.get("_duration_ms") else None}
         if valu:
             out["roofline_valu"] = valu
             if not (0.0 < valu["frac"] <= 1.0):

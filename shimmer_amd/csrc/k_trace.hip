@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3<true, false>(K3_PARAMS) 
 #ifdef K5_CENSUS
 // development build (-DK5_CENSUS): per-phase lane census of the closest-hit kernel, printed by wf_trace_census() at scene destruction
 __device__ unsigned long long g_census[16];
-#define CENSUS(i, v) do { if (!ANY) c_census[i] += (unsigned long long)(v); } while (0)
+#define CENSUS(i, v) do { if (ANY == (K5_CENSUS == 2)) c_census[i] += (unsigned long long)(v); } while (0)  // -DK5_CENSUS=1: closest-hit, =2: any-hit
 #else
 #define CENSUS(i, v) do { } while (0)
 #endif
@@ -733,7 +733,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         }
     }
 #ifdef K5_CENSUS
-    if (!ANY && lane == 0) for (int i = 0; i < 16; ++i) if (c_census[i]) atomicAdd(&g_census[i], c_census[i]);
+    if (ANY == (K5_CENSUS == 2) && lane == 0) for (int i = 0; i < 16; ++i) if (c_census[i]) atomicAdd(&g_census[i], c_census[i]);
 #endif
     if (ANY) {
         unsigned long long wn = c_nodes;
@@ -786,9 +786,9 @@ void wf_trace_census() {
     unsigned long long c[16];
     if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_census), sizeof(c)) != hipSuccess || !c[0]) return;
     const double it = (double)c[0];
-    fprintf(stderr, "[k5 census, closest-hit] wave iterations %.3e | lanes per iteration: at a node %.1f, on a pending leaf %.1f, idle %.1f, pop pending %.1f | iterations with a node step %.3f\n"
+    fprintf(stderr, "[k5 census, %s] wave iterations %.3e | lanes per iteration: at a node %.1f, on a pending leaf %.1f, idle %.1f, pop pending %.1f | iterations with a node step %.3f\n"
                     "  leaf phases %.3e (one per %.2f iterations), primitive rounds %.3e at %.1f lanes | pop rounds %.3e at %.1f lanes | refills %.3e at %.1f rays\n",
-            it, c[1] / it, c[2] / it, c[3] / it, c[4] / it, c[10] / it, (double)c[5], it / (double)c[5], (double)c[6], (double)c[7] / (double)c[6], (double)c[8], (double)c[9] / (double)c[8],
+            K5_CENSUS == 2 ? "any-hit" : "closest-hit", it, c[1] / it, c[2] / it, c[3] / it, c[4] / it, c[10] / it, (double)c[5], it / (double)c[5], (double)c[6], (double)c[7] / (double)c[6], (double)c[8], (double)c[9] / (double)c[8],
             (double)c[11], (double)c[12] / (double)c[11]);
 #endif
 }

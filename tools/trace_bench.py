@@ -32,8 +32,12 @@ def camera_rays():
     p = np.stack([px, py, np.zeros_like(px), np.ones_like(px)], 1) @ m.T
     d = p[:, :3] / p[:, 3:4]
     d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # camera space -> render space (PerspectiveCamera::generate_ray, camera.rs:1003-1028: render_from_camera; the pinhole sits at its origin)
+    rfc = np.array(list(cam.render_from_camera), np.float64).reshape(4, 4)
+    d = d @ rfc[:3, :3].T
+    o = np.tile(rfc[:3, 3], (d.shape[0], 1))
     rays = np.zeros((d.shape[0], 8), np.float32)
-    rays[:, 3:6] = d
+    rays[:, :3], rays[:, 3:6] = o, d
     rays[:, 6] = np.inf
     return rays
 
@@ -81,10 +85,24 @@ def report(name, rays, repeat=5):
     gb = (32 * nodes + 48 * tris + 48 * n) / 1e9
     print(f"{name:28s} n={n:8d} {ms:8.3f} ms  {n/ms/1e3:8.1f} Mray/s  nodes/ray {nodes/n:6.1f} prims/ray {tris/n:5.2f}  alg {gb/ms*1e3:7.0f} GB/s ({gb/ms*1e3/80:5.1f}% of 8 TB/s)  hit {float((hits['prim']>=0).mean()):.2f}", flush=True)
 
+def survey_8d_rays():
+    """origins uniform in the scene's bounding sphere x 1.5, directions uniform on the sphere, seed 42 — the incoherent batch."""
+    g = np.random.default_rng(42)
+    b = sc.info["bounds"]
+    lo, hi = b[:, :3].min(0), b[:, 3:].max(0)
+    c, rad = (lo + hi) / 2, np.linalg.norm(hi - lo) / 2 * 1.5
+    o = g.normal(size=(N, 3)); o /= np.linalg.norm(o, axis=1, keepdims=True)
+    o = c + o * (rad * g.random((N, 1)) ** (1.0 / 3.0))
+    d = g.normal(size=(N, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((N, 8), np.float32)
+    rays[:, :3], rays[:, 3:6], rays[:, 6] = o, d, np.inf
+    return rays
+
 cfg = {k: os.environ.get(k) for k in ("SHM_REFILL_MIN", "SHM_LEAF_MIN", "SHM_TRACE3_BLOCKS_PER_CU")}
 print("config:", cfg, flush=True)
 cam = camera_rays()
 report("camera (tile order)", cam)
+report("SURVEY 8d incoherent", survey_8d_rays())
 b1 = bounce_rays(cam)
 report("bounce-1 (path order)", b1)
 report("bounce-1 shuffled", b1[rng.permutation(b1.shape[0])])
