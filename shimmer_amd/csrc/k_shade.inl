@@ -26,20 +26,23 @@ namespace {
 //   get_bsdf filters the MIP pyramids. One general instantiation <true, false, true>.
 //   DIFFUSE_ONLY = true is the instantiation for scenes whose materials are all DiffuseMaterial (the headline scene class): the
 //   conductor / dielectric BxDFs and the material dispatch are compiled out of it.
-template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ONLY = false>
+//   EMIT_INLINE = false (the lean instantiation): emission at the hit (integrator.rs:798-813) is not evaluated here — a vertex that hit an emitter deposits what
+//   the evaluation needs of the state this kernel is about to overwrite (PathArrays::e_*) and its path in q_emit; k_emit_jobs below works the list off after the launch.
+template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ONLY = false, bool EMIT_INLINE = true>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
-                                                     DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in) {
+                                                     DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in, uint32_t* __restrict__ q_emit) {
     const uint32_t n = n_in ? *n_in : qs->n_active[cur];  // (n_in: the lean diversion's queue, whose count is not n_active)
     __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
-    __shared__ uint32_t s_cnt[2], s_base[2];
+    __shared__ uint32_t s_emit[EMIT_INLINE ? 1 : SHADE_CHUNK];
+    __shared__ uint32_t s_cnt[3], s_base[3];
     for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
-      if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+      if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; }
       __syncthreads();
       for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
         const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
         bool active = i < n;
-        bool push_next = false, push_shadow = false;
+        bool push_next = false, push_shadow = false, push_emit = false;
         uint32_t path = 0;
         if (active) {
             path = q_cur[i];
@@ -97,7 +100,16 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                 SurfaceInteraction si = hit_interaction<TRI_ONLY>(sv, hit, -ray_d);
                 const ShmPrimitive prim = sv.primitives[hit.prim];
                 // integrator.rs:798-813: emission at the hit
-                if (prim.area_light >= 0) {
+                if (!EMIT_INLINE && prim.area_light >= 0) {
+                    // the hit is on an emitter (rare): its `L += beta * Le` — with the MIS weight's inverted light sampling — is k_emit_jobs's, after this launch; what
+                    // it needs of the state this vertex overwrites goes to the side arrays now
+                    pa.e_ray[path] = make_float4(ray_d.x, ray_d.y, ray_d.z, pa.pb_eta[path].x);
+                    pa.e_beta[path] = pa.beta[path];
+                    pa.e_flags[path] = fl;
+                    if (!(depth == 0 || specular_bounce)) { pa.e_ctx0[path] = pa.ctx0[path]; pa.e_ctx1[path] = pa.ctx1[path]; pa.e_ctx2[path] = pa.ctx2[path]; }
+                    push_emit = true;
+                }
+                if (EMIT_INLINE && prim.area_light >= 0) {
                     const ShmLight& light = sv.lights[prim.area_light];
                     Spec le = area_light_l(sv, light, si.n, -ray_d, lambda);
                     if (!is_zero(le)) {
@@ -246,31 +258,95 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
         if (push_next) s_next[s1] = path;
         uint32_t s2 = queue_push_slot(&s_cnt[1], push_shadow);
         if (push_shadow) s_shadow[s2] = path;
+        if (!EMIT_INLINE) {
+            uint32_t s3 = queue_push_slot(&s_cnt[2], push_emit);
+            if (push_emit) s_emit[s3] = path;
+        }
       }
       __syncthreads();
       if (threadIdx.x == 0) {
           s_base[0] = s_cnt[0] ? atomicAdd(&qs->n_active[cur ^ 1], s_cnt[0]) : 0u;
           s_base[1] = s_cnt[1] ? atomicAdd(&qs->n_shadow[shadow_parity], s_cnt[1]) : 0u;
+          s_base[2] = (!EMIT_INLINE && s_cnt[2]) ? atomicAdd(&qs->n_emit, s_cnt[2]) : 0u;
       }
       __syncthreads();
       for (uint32_t j = threadIdx.x; j < s_cnt[0]; j += SHADE2_BLOCK) q_next[s_base[0] + j] = s_next[j];
       for (uint32_t j = threadIdx.x; j < s_cnt[1]; j += SHADE2_BLOCK) q_shadow[s_base[1] + j] = s_shadow[j];
+      if (!EMIT_INLINE) for (uint32_t j = threadIdx.x; j < s_cnt[2]; j += SHADE2_BLOCK) q_emit[s_base[2] + j] = s_emit[j];
       __syncthreads();
     }
     (void)counters;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Emission at the hit (integrator.rs:798-813: `L += beta * Le`, MIS-weighted against the light sampler after a non-specular bounce) for the vertices the fused
+// kernel deferred. Hitting an emitter is rare (S3's window: two triangles), but the branch — `light_pdf_li` inverts the spherical-triangle sampling — sat in the middle
+// of the vertex kernel and cost EVERY vertex registers: without it the kernel takes 8.8 ms less per headline frame (timing variant SHM_SHADE_SKIP=8). The few paths
+// of q_emit are worked off here with dense lanes, from the hit record (K2's, untouched), the wavelengths, and the e_* copies of what the vertex kernel overwrote. Same
+// functions, same operands, same order as the inline branch; `L` receives the sum at the same place in the path's sequence (after the previous bounce's shadow
+// contribution, before this bounce's: the launcher puts this kernel between k_shade and K3).
+// ---------------------------------------------------------------------------------------------
+template <bool TRI_ONLY, bool HAS_TEX>
+__global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_emit, const QueueState* qs) {
+    const uint32_t n = qs->n_emit;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t path = q_emit[i];
+        const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
+        const float4 h0 = hp[0], h1 = hp[1];
+        Hit hit;
+        hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
+        const float4 er = pa.e_ray[path];
+        const V3 ray_d = v3(er.x, er.y, er.z);
+        Wavelengths lambda;
+        {
+            const float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+            lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
+            lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
+        }
+        const uint32_t fl = pa.e_flags[path];
+        const int depth = (int)(fl & 0xffu);
+        const bool specular_bounce = (fl >> 8) & 1u;
+        const SurfaceInteraction si = hit_interaction<TRI_ONLY>(sv, hit, -ray_d);
+        const ShmPrimitive prim = sv.primitives[hit.prim];
+        const ShmLight& light = sv.lights[prim.area_light];
+        const Spec le = area_light_l(sv, light, si.n, -ray_d, lambda);
+        if (!is_zero(le)) {
+            auto add_l = [&](const Spec& c) { pa.L[path] = st_spec(ld_spec(pa.L[path]) + c); };
+            auto load_beta = [&]() { return ld_spec(pa.e_beta[path]); };
+            if (depth == 0 || specular_bounce) {
+                add_l(load_beta() * le);
+            } else {
+                LightSampleContext c;
+                const float4 c0 = pa.e_ctx0[path], c1 = pa.e_ctx1[path], c2 = pa.e_ctx2[path];
+                c.pi.x = iv2(c0.x, c0.w);
+                c.pi.y = iv2(c0.y, c1.x);
+                c.pi.z = iv2(c0.z, c1.y);
+                c.n = v3(c1.z, c1.w, c2.x);
+                c.ns = v3(c2.y, c2.z, c2.w);
+                const Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, c, ray_d);
+                const Float w_l = power_heuristic(1, er.w, 1, p_l);
+                add_l(load_beta() * w_l * le);
+            }
+        }
+    }
+}
 }  // namespace
 
 
+#define WF_EMIT_JOBS_LAUNCH()                                                                                                                \
+    do {                                                                                                                                     \
+        hipLaunchKernelGGL((k_emit_jobs<true, false>), dim3(s->n_cu * 4), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_emit, s->d_qs); \
+        LAUNCH_TRY("k_emit_jobs");                                                                                                           \
+    } while (0)
 #define WF_SHADE_LAUNCH(KERNEL)                                                                                                              \
     do {                                                                                                                                     \
         hipLaunchKernelGGL(KERNEL, dim3(s->n_cu * K_SHADE_LEAN_WAVES), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], s->d_q_active[a.cur ^ 1], \
-                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)nullptr);              \
+                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)nullptr, s->d_q_emit); \
         LAUNCH_TRY("k_shade");                                                                                                               \
     } while (0)
 #define WF_SHADE_LAUNCH_DIVERTED(KERNEL)                                                                                                     \
     do {                                                                                                                                     \
         hipLaunchKernelGGL(KERNEL, dim3(s->n_cu * K_SHADE_LEAN_WAVES), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_lean, s->d_q_active[a.cur ^ 1], \
-                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)&s->d_qs->n_lean);      \
+                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)&s->d_qs->n_lean, s->d_q_emit); \
         LAUNCH_TRY("k_shade (diverted)");                                                                                                    \
     } while (0)

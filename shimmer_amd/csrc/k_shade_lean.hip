@@ -4,12 +4,14 @@
 #include "k_shade.inl"
 
 int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a) {
-    WF_SHADE_LAUNCH((k_shade<false, true, false, true>));
+    WF_SHADE_LAUNCH((k_shade<false, true, false, true, false>));
+    WF_EMIT_JOBS_LAUNCH();  // emission of the vertices that hit an emitter, before K3 adds this bounce's shadow contributions (k_shade.inl)
     return SHM_OK;
 }
 // The same kernel over the queue k_vertex diverted plain-diffuse hits to (a scene that also holds other materials): for those vertices the
 // fused kernel beats the staged pair — no parameter block to write and read back ("staged shading").
 int wf_launch_shade_lean_diverted(ShmScene* s, const ShadeArgs& a) {
-    WF_SHADE_LAUNCH_DIVERTED((k_shade<false, true, false, true>));
+    WF_SHADE_LAUNCH_DIVERTED((k_shade<false, true, false, true, false>));
+    WF_EMIT_JOBS_LAUNCH();
     return SHM_OK;
 }

@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
         qs->n_shadow[0] = 0;
         qs->n_shadow[1] = 0;
         qs->n_scatter[0] = qs->n_scatter[1] = qs->n_scatter[2] = qs->n_scatter[3] = 0;
+        qs->n_emit = 0;
     qs->n_lean = 0;
     }
 }
@@ -107,6 +108,7 @@ __global__ void k_next_bounce(QueueState* qs, int cur, int next_shadow_parity) {
     qs->n_active[cur] = 0;
     qs->n_scatter[0] = qs->n_scatter[1] = qs->n_scatter[2] = qs->n_scatter[3] = 0;
     qs->n_lean = 0;
+    qs->n_emit = 0;
     qs->n_shadow[next_shadow_parity] = 0;  // the one the NEXT shade launch fills; this bounce's count stays for its K3
 }
 // ---------------------------------------------------------------------------------------------
@@ -200,10 +202,11 @@ static uint64_t staging_bytes_per_path(const ShmScene* s) {
     if (s->lean_divert) b += 4;                                                // the lean diversion's queue
     return b;
 }
+static bool uses_fused_kernel(const ShmScene* s) { return scene_is_lean(s) || s->lean_divert; }  // k_shade<lean>: deferred emitter hits (PathArrays::e_*)
 static uint64_t workspace_cap(const ShmScene* s, bool need_staged) {
     // path state + three queues (+ auxiliary rays) (+ the staging arrays whenever the upcoming render is staged: every scene class but the
     // lean one, and the lean one too under options.force_diffuse — the budget must count them BEFORE the first staged allocation)
-    const uint64_t BYTES_PER_PATH = 264 + 3 * 4 + (s->flat.has_textures ? 48 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
+    const uint64_t BYTES_PER_PATH = 264 + 3 * 4 + (s->flat.has_textures ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
     uint64_t cap = max_batch_paths();
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -241,6 +244,13 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
     WS(ray, ShmRay); WS(hit, ShmHit); WS(shadow_ray, ShmRay); WS(shadow_contrib, float4); WS(L, float4); WS(beta, float4);
     WS(lambda, float4); WS(lambda_pdf, float4); WS(ctx0, float4); WS(ctx1, float4); WS(ctx2, float4); WS(pb_eta, float2);
     WS(rng, uint2); WS(pixel, uint32_t); WS(flags, uint32_t);
+    s->pa.e_ray = s->pa.e_beta = s->pa.e_ctx0 = s->pa.e_ctx1 = s->pa.e_ctx2 = nullptr;
+    s->pa.e_flags = nullptr;
+    s->d_q_emit = nullptr;
+    if (uses_fused_kernel(s)) {
+        WS(e_ray, float4); WS(e_beta, float4); WS(e_ctx0, float4); WS(e_ctx1, float4); WS(e_ctx2, float4); WS(e_flags, uint32_t);
+        if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_emit)) != SHM_OK) return rc;
+    }
     s->pa.aux0 = s->pa.aux1 = s->pa.aux2 = nullptr;
     if (s->flat.has_textures) { WS(aux0, float4); WS(aux1, float4); WS(aux2, float4); }
     s->pa.bx0 = s->pa.bx1 = s->pa.bx2 = s->pa.bx3 = s->pa.bx4 = s->pa.fr = s->pa.siwo = s->pa.dd0 = s->pa.dd1 = s->pa.dd2 = nullptr;

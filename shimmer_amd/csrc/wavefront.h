@@ -67,7 +67,7 @@ struct QueueState {
                             // while the counters of bounce b+1 are recycled (K3(b) overlaps K2(b+1) on a second stream)
     uint32_t n_scatter[4];  // staged shading: entries in q_scatter[class], filled by k_vertex, drained by k_scatter<class>
     uint32_t n_lean;        // staged shading with the lean diversion: hits on plain DiffuseMaterial, which k_vertex hands to the fused kernel whole
-    uint32_t pad;
+    uint32_t n_emit;        // the fused kernel's deferred emitter hits (q_emit), worked off by k_emit_jobs after it
 };
 
 // Path state, structure of arrays (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
@@ -105,6 +105,14 @@ struct PathArrays {
     float4* dd0;            // dpdx.xyz, dpdy.x
     float4* dd1;            // dpdy.yz, dndx.xy
     float4* dd2;            // dndx.z, dndy.xyz
+    // scenes whose vertices (or some of them: the lean diversion) run the fused kernel: what emission at the hit needs of the state that kernel overwrites,
+    // written for the rare vertex that hit an emitter and read back by k_emit_jobs (k_shade.inl)
+    float4* e_ray;          // ray.d.xyz, p_b
+    float4* e_beta;
+    float4* e_ctx0;         // prev_intr_ctx as ctx0..2 (only written when the MIS weight needs it)
+    float4* e_ctx1;
+    float4* e_ctx2;
+    uint32_t* e_flags;      // the path's flags word at the hit (depth, specular_bounce)
 };
 enum : int { CLASS_DIFFUSE = 0, CLASS_CONDUCTOR = 1, CLASS_DIELECTRIC = 2, CLASS_LAYERED = 3, N_BXDF_CLASSES = 4 };
 __host__ __device__ inline int bxdf_class_of(uint32_t kind) {
@@ -192,6 +200,7 @@ struct ShmScene {
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
     int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
     uint32_t* d_spill3 = nullptr;
+    uint32_t* d_q_emit = nullptr;      // paths of the current fused-kernel launch that hit an emitter (k_emit_jobs)
     uint32_t* d_big_leaf_n = nullptr;  // n_prims by first primitive slot, only in scenes with a leaf of >= 15 primitives (the link word holds smaller counts)
     bool trace_pair = true;          // triangle-only scenes: the both-children step (k_trace5) instead of the one-node step (k_trace3); SHM_TRACE_PAIR=0 for A/B
     float4* d_rw = nullptr;          // RandomWalk: (le, f cos) per depth per path, 2 * (max_depth + 1) * capacity float4
