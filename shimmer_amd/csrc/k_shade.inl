@@ -14,6 +14,9 @@ namespace {
 #define K_SHADE_LEAN_WAVES 3
 #endif
 #define K_SHADE_LEAN_ATTR __attribute__((amdgpu_waves_per_eu(K_SHADE_LEAN_WAVES, K_SHADE_LEAN_WAVES)))
+#ifndef K_SHADE_NEE_LAST
+#define K_SHADE_NEE_LAST 1  // next-event estimation evaluated at the end of the vertex (0: where the reference's text has it: A/B)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // K4+K5: one path vertex (integrator.rs:772-892 for the vertex found by K2).
@@ -158,20 +161,30 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                 if (alive) {
                     depth += 1;
                     if (!forced) load_rng();
-                    // integrator.rs:837-841 + 897-963: next-event estimation; the visibility test is deferred to K3
-                    if (flags_is_non_specular(bsdf_flags(bsdf))) {
+                    // integrator.rs:837-841 + 897-963: next-event estimation; the visibility test is deferred to K3. The sampler dimensions are drawn HERE, in the
+                    // reference's order (light choice, light sample, then the BSDF sample's three, then Russian roulette's) — the evaluation itself runs as the LAST
+                    // thing of the vertex (K_SHADE_NEE_LAST): the light sample is the register-hungriest island of the kernel (82 VGPRs on its own), and at the end only
+                    // its own inputs are live beside it, not everything the BSDF sampling, Russian roulette and the spawned ray still need. Independent computations:
+                    // every value is what it was.
+                    const bool do_nee = flags_is_non_specular(bsdf_flags(bsdf));
+                    Float nee_u = 0.0f;
+                    V2 nee_u_light = v2(0.0f, 0.0f);
+                    if (do_nee) {
+                        nee_u = sampler_get_1d(rng);
+                        nee_u_light = sampler_get_2d(rng);
+                    }
+                    const Spec beta_at_vertex = load_beta();  // (the throughput BEFORE this vertex's update: what weighs the light's contribution)
+                    auto next_event_estimation = [&]() {
                         LightSampleContext ctx = light_ctx_from(si);
                         uint32_t bf = bsdf_flags(bsdf);
                         if (flags_is_reflective(bf) && !flags_is_transmissive(bf)) ctx.pi = p3i_exact(offset_ray_origin(si.pi, si.n, si.wo));
                         else if (flags_is_transmissive(bf) && !flags_is_reflective(bf)) ctx.pi = p3i_exact(offset_ray_origin(si.pi, si.n, -si.wo));
-                        Float u = sampler_get_1d(rng);
                         Float p_sel = 0.0f;
-                        int li = light_sampler_sample(sv, u, p_sel);
-                        V2 u_light = sampler_get_2d(rng);
+                        int li = light_sampler_sample(sv, nee_u, p_sel);
                         if (li >= 0) {
                             const ShmLight& light = sv.lights[li];
                             LightLiSample ls;
-                            if (light_sample_li<TRI_ONLY, HAS_TEX>(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
+                            if (light_sample_li<TRI_ONLY, HAS_TEX>(sv, light, ctx, nee_u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
                                 V3 wo = si.wo;
                                 V3 wi = ls.wi;
                                 Spec f = bsdf_f(bsdf, wo, wi) * abs_dot(wi, si.shading.n);
@@ -192,12 +205,13 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                                     s.t_max = 1.0f - 0.0001f;  // 1 - SHADOW_EPSILON, integrator.rs:66,115
                                     s.pad = 0.0f;
                                     pa.shadow_ray[path] = s;
-                                    pa.shadow_contrib[path] = st_spec(load_beta() * ld);
+                                    pa.shadow_contrib[path] = st_spec(beta_at_vertex * ld);
                                     push_shadow = true;
                                 }
                             }
                         }
-                    }
+                    };
+                    if (!K_SHADE_NEE_LAST && do_nee) next_event_estimation();
                     // integrator.rs:843-857: sample the BSDF
                     V3 wo = -ray_d;
                     Float u = sampler_get_1d(rng);
@@ -207,7 +221,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                         alive = false;
                     } else {
                         // integrator.rs:859-872
-                        beta = load_beta() * (bs.f * abs_dot(bs.wi, si.shading.n) / bs.pdf);
+                        beta = beta_at_vertex * (bs.f * abs_dot(bs.wi, si.shading.n) / bs.pdf);
                         p_b = bs.pdf_is_proportional ? bsdf_pdf(bsdf, wo, bs.wi, REFLTRANS_ALL) : bs.pdf;
                         specular_bounce = flags_is_specular(bs.flags);
                         any_non_specular_bounces |= !specular_bounce;
@@ -246,6 +260,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                             push_next = true;
                         }
                     }
+                    if (K_SHADE_NEE_LAST && do_nee) next_event_estimation();
                 }
                 // terminate_secondary may have changed the pdfs (material.rs:609-619): written back only then
                 // (only DielectricMaterial terminates wavelengths: nothing to write back in the all-diffuse instantiation)
