@@ -206,7 +206,8 @@ static bool uses_fused_kernel(const ShmScene* s) { return scene_is_lean(s) || s-
 static uint64_t workspace_cap(const ShmScene* s, bool need_staged) {
     // path state + three queues (+ auxiliary rays) (+ the staging arrays whenever the upcoming render is staged: every scene class but the
     // lean one, and the lean one too under options.force_diffuse — the budget must count them BEFORE the first staged allocation)
-    const uint64_t BYTES_PER_PATH = 264 + 3 * 4 + (s->flat.has_textures ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
+    // (ray 32, hit 32, shadow_ray 32, shadow_contrib 16, L 16, beta 16, lambda 16, lambda_pdf 16, ctx0..2 48, pb_eta 8, rng 8, pixel 4, flags 4 = 248)
+    const uint64_t BYTES_PER_PATH = 248 + 3 * 4 + (s->flat.has_textures ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
     uint64_t cap = max_batch_paths();
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -222,11 +223,17 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
     uint64_t want = std::min<uint64_t>(std::max<uint64_t>(needed_paths, 4096), max_cap);
     // a large request takes the whole budget at once: freeing and re-allocating ~140 GB because the next call needs a few percent more
     // paths costs seconds (measured: 3.7 s per regrow at 500 M paths)
+    need_staged = need_staged || s->ws_staged || !scene_is_lean(s);
+    // (what decides is whether THIS render fits: the budget below moves by a few paths from call to call — the free-memory reading, the per-path estimate — and a
+    //  workspace that already holds the render must not be freed and re-allocated for it: 7 s per frame at 150 GB)
+    if (s->ws_staged || !need_staged) {
+        if (s->capacity >= want) return SHM_OK;
+        // a render that is batched anyway (it needs more than the budget): a workspace within 10 % of the budget is the budget
+        if (needed_paths > max_cap && s->capacity * 10ull >= max_cap * 9ull) return SHM_OK;
+    }
     if (want > max_cap / 8) want = max_cap;
     want = (want + 4095ull) & ~4095ull;
     if (want > 0xfffff000ull) want = 0xfffff000ull;
-    need_staged = need_staged || s->ws_staged || !scene_is_lean(s);
-    if (s->capacity >= want && (s->ws_staged || !need_staged)) return SHM_OK;
     want = std::max<uint64_t>(want, s->capacity);
     for (void* p : s->ws_allocs) hipFree(p);
     s->ws_allocs.clear();
@@ -274,7 +281,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
     if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_active[1])) != SHM_OK) return rc;
     if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_shadow)) != SHM_OK) return rc;
     s->capacity = cap;
-    DBG("workspace: %u paths (%.2f GB)", cap, (double)cap * 276.0 / 1e9);
+    DBG("workspace: %u paths", cap);
     return SHM_OK;
 }
 }  // namespace
