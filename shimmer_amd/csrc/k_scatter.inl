@@ -18,6 +18,9 @@ namespace {
 #ifndef SHM_EXP_SKIP
 #define SHM_EXP_SKIP 0
 #endif
+#ifndef K_SCATTER_NEE_LAST
+#define K_SCATTER_NEE_LAST 1  // (0: next-event estimation evaluated where the reference's text has it: A/B)
+#endif
 constexpr int NEE_JOB_WORDS = 17;
 constexpr int NEE_JOB_CAP = 2 * WAVE;  // at most 63 waiting + 64 new
 
@@ -191,17 +194,27 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
             if (SUB == 0 && params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
             bool alive = true;
             depth += 1;
-            // integrator.rs:837-841 + 897-963: next-event estimation; the visibility test is deferred to K3
+            // integrator.rs:837-841 + 897-963: next-event estimation; the visibility test is deferred to K3. The sampler dimensions are drawn here, in the reference's
+            // order; for every class but the layered one the evaluation runs as the LAST thing of the vertex (as in the fused kernel, k_shade.inl: the light sample is
+            // the register-hungriest island, and at the end only its own inputs are live beside it). The layered class keeps it first: its sample_f walk is the
+            // hungrier part, and NEE leaves only a deferred job behind.
             const uint32_t bf = bsdf_flags(bsdf);
-            if (SUB != 1 && flags_is_non_specular(bf) && !(SHM_EXP_SKIP & 4)) {
+            const bool do_nee = SUB != 1 && flags_is_non_specular(bf) && !(SHM_EXP_SKIP & 4);
+            Float nee_u = 0.0f;
+            V2 nee_u_light = v2(0.0f, 0.0f);
+            if (do_nee) {
+                nee_u = sampler_get_1d(rng);
+                nee_u_light = sampler_get_2d(rng);
+            }
+            const Spec beta_at_vertex = beta;  // (the throughput before this vertex's update: what weighs the light's contribution)
+            auto next_event_estimation = [&]() {
                 LightSampleContext ctx;
                 ctx.pi = si_pi; ctx.n = si_n; ctx.ns = ns;
                 if (flags_is_reflective(bf) && !flags_is_transmissive(bf)) ctx.pi = p3i_exact(offset_ray_origin(si_pi, si_n, si_wo));
                 else if (flags_is_transmissive(bf) && !flags_is_reflective(bf)) ctx.pi = p3i_exact(offset_ray_origin(si_pi, si_n, -si_wo));
-                Float u = sampler_get_1d(rng);
                 Float p_sel = 0.0f;
-                int li = light_sampler_sample(sv, u, p_sel);
-                V2 u_light = sampler_get_2d(rng);
+                int li = light_sampler_sample(sv, nee_u, p_sel);
+                const V2 u_light = nee_u_light;
                 if (li >= 0) {
                     const ShmLight& light = sv.lights[li];
                     LightLiSample ls;
@@ -224,7 +237,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                             s.pad = 0.0f;
                             pa.shadow_ray[path] = s;
                             dep = true;
-                            j_wo = si_wo; j_wi = wi; j_l = ls.l; j_beta = beta;
+                            j_wo = si_wo; j_wi = wi; j_l = ls.l; j_beta = beta_at_vertex;
                             j_pl = p_sel * ls.pdf;
                             j_flags = (light_is_delta(light) ? 1u : 0u) | ((params.regularize && any_non_specular_bounces) ? 2u : 0u);
                         } else {
@@ -247,13 +260,15 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                             s.t_max = 1.0f - 0.0001f;  // 1 - SHADOW_EPSILON, integrator.rs:66,115
                             s.pad = 0.0f;
                             pa.shadow_ray[path] = s;
-                            pa.shadow_contrib[path] = st_spec(beta * ld);
+                            pa.shadow_contrib[path] = st_spec(beta_at_vertex * ld);
                             push_shadow = true;
                         }
                         }
                     }
                 }
-            }
+            };
+            constexpr bool NEE_LAST = !LAYERED && K_SCATTER_NEE_LAST;
+            if (!NEE_LAST && do_nee) next_event_estimation();
             // integrator.rs:843-857: sample the BSDF
             Float u = sampler_get_1d(rng);
             V2 u2 = sampler_get_2d(rng);
@@ -301,6 +316,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                     push_next = true;
                 }
             }
+            if (NEE_LAST && do_nee) next_event_estimation();
         }
         if (LAYERED) {
             const unsigned long long m = __ballot(dep);
