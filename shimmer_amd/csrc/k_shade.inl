@@ -90,6 +90,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                 // integrator.rs:776-794: escaped ray, infinite lights
                 for (uint32_t k = 0; k < sv.n_infinite_lights; ++k) {
                     const ShmLight& light = sv.lights[sv.infinite_lights[k]];
+                    // (flatten_scene lists only the infinite kinds here: light_pdf_li's area-light half — the inverted triangle sampling — folds away)
+                    __builtin_assume(light.kind != SHM_LIGHT_DIFFUSE_AREA);
                     Spec le = infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda);
                     if (depth == 0 || specular_bounce) {
                         add_l(load_beta() * le);

@@ -134,6 +134,8 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
                 // integrator.rs:776-794: escaped ray, infinite lights
                 for (uint32_t li = 0; li < sv.n_infinite_lights; ++li) {
                     const ShmLight& light = sv.lights[sv.infinite_lights[li]];
+                    // (flatten_scene lists only the infinite kinds here: light_pdf_li's area-light half — the inverted triangle sampling — folds away)
+                    __builtin_assume(light.kind != SHM_LIGHT_DIFFUSE_AREA);
                     emit(infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda), light);
                 }
             } else if (divert && sv.materials[sv.primitives[hit.prim].material].kind == SHM_MATERIAL_DIFFUSE) {
