@@ -14,6 +14,11 @@ namespace {
 #define K_SHADE_LEAN_WAVES 3
 #endif
 #define K_SHADE_LEAN_ATTR __attribute__((amdgpu_waves_per_eu(K_SHADE_LEAN_WAVES, K_SHADE_LEAN_WAVES)))
+// timing / register experiments only (tools/exp_variants.sh k_shade_lean SHM_SHADE_SKIP <bits>; results are wrong by design): 1 = no next-event estimation,
+// 4 = no BSDF sampling (paths end), 16 = no bump_map / get_bsdf beyond the reflectance
+#ifndef SHM_SHADE_SKIP
+#define SHM_SHADE_SKIP 0
+#endif
 #ifndef K_SHADE_NEE_LAST
 #define K_SHADE_NEE_LAST 1  // next-event estimation evaluated at the end of the vertex (0: where the reference's text has it: A/B)
 #endif
@@ -168,7 +173,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                     // thing of the vertex (K_SHADE_NEE_LAST): the light sample is the register-hungriest island of the kernel (82 VGPRs on its own), and at the end only
                     // its own inputs are live beside it, not everything the BSDF sampling, Russian roulette and the spawned ray still need. Independent computations:
                     // every value is what it was.
-                    const bool do_nee = flags_is_non_specular(bsdf_flags(bsdf));
+                    const bool do_nee = !(SHM_SHADE_SKIP & 1) && flags_is_non_specular(bsdf_flags(bsdf));
                     Float nee_u = 0.0f;
                     V2 nee_u_light = v2(0.0f, 0.0f);
                     if (do_nee) {
@@ -219,7 +224,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                     Float u = sampler_get_1d(rng);
                     V2 u2 = sampler_get_2d(rng);
                     BSDFSample bs;
-                    if (!bsdf_sample_f(bsdf, wo, u, u2, REFLTRANS_ALL, bs)) {
+                    if ((SHM_SHADE_SKIP & 4) || !bsdf_sample_f(bsdf, wo, u, u2, REFLTRANS_ALL, bs)) {
                         alive = false;
                     } else {
                         // integrator.rs:859-872
