@@ -48,6 +48,10 @@ SCENES = {
     "S2_cornell_patches": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, patches=True), 8, 5),  # BilinearPatch: rectangle light + curved patch
     "S2_cornell_patches_skewed": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, patches=True, patch_skew=2e-3), 4, 5),  # area-sampled patch light
     "S2_cornell_glass": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, glass=True), 8, 14),  # smooth / rough / index-matched / thin dielectrics: k_scatter_specular + k_scatter_nonspecular, late-bounce overlap (6) and the fused tail launch (8)
+    # emission at a vertex whose path goes on (a reflecting, two-sided emitter): the fused kernel defers it to k_emit_jobs — alone (all-diffuse scene) and as the
+    # diverted kernel of a scene with coated materials
+    "S2_cornell_reflecting_emitter": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, emitter_reflects=True), 8, 5),
+    "S2_cornell_coated_reflecting_emitter": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, coated=True, emitter_reflects=True), 6, 5),
     "S2_cornell_mix": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, mix=True), 8, 5),  # MixMaterial, nested, with a coated leaf
     # image textures (every mapping / filter / wrap / spectrum type), ray differentials through a mirror and glass
     "S2_cornell_textured": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, textured=True), 8, 6),
@@ -364,6 +368,26 @@ def test_c4_frame_at_full_size(env):
         assert sb[k] == so[k], k
     assert so["rays_closest"] / so["paths"] > 3.0  # the block is on the glass: long specular chains
     gpu.close()
+
+
+def test_workspace_is_not_reallocated_between_equal_renders(env):
+    """A frame large enough to take the whole workspace budget (64 M paths: more than an eighth of it) rendered three times: the second and third render find
+    the workspace of the first. Round 4 found the opposite — the per-path estimate of the budget was 16 bytes high, the budget crept from call to call, and every
+    frame of a coated scene freed and re-allocated 150 GB (7 s against 0.1 s of rendering). Wall-clock, with a generous bound: allocation takes seconds."""
+    import time
+    lib, oracle_py, render, scenes = env
+    sc = scenes.ganesha_proxy(lib, 1024, 1024, n=24, coated=True)
+    p = render.make_params(seed=0, spp=64, max_depth=5)
+    gpu = render.Renderer(lib, sc.desc, 0)
+    times = []
+    for _ in range(3):
+        gpu.clear()
+        t0 = time.perf_counter()
+        st = gpu.render_device(p)
+        times.append(time.perf_counter() - t0)
+    gpu.close()
+    assert st["paths"] == 1024 * 1024 * 64
+    assert times[1] < 1.5 and times[2] < 1.5, times  # (the first one allocates: several seconds)
 
 
 def test_layered_pdf_zero_over_zero_is_the_references(env):
