@@ -61,7 +61,7 @@ def _counters_from_db(db, want):
             m = re.search(r"k_trace\d<(\w+)(?:, (\w+))?>", name)
             if not m or m.group(1) != "false":  # first template argument: ANY
                 continue
-        elif not re.search(r"k_shade<false, true, false, true>", name):
+        elif not re.search(r"k_shade<false, true, false, true\b", name):
             continue
         acc[counter] = acc.get(counter, 0.0) + float(value)
         disp[d] = float(dur)
