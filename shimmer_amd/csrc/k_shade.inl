@@ -37,9 +37,12 @@ namespace {
 //   EMIT_INLINE = false (the lean instantiation): emission at the hit (integrator.rs:798-813) is not evaluated here — a vertex that hit an emitter deposits what
 //   the evaluation needs of the state this kernel is about to overwrite (PathArrays::e_*) and its path in q_emit; k_emit_jobs below works the list off after the launch.
 template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ONLY = false, bool EMIT_INLINE = true>
-__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
+__global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneView sv_global, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
-                                                     DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in, uint32_t* __restrict__ q_emit) {
+                                                     DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in, uint32_t* __restrict__ q_emit,
+                                                     LdsTables lds_tables) {
+    __shared__ uint4 s_tables[(EMIT_INLINE ? 16 : LDS_TABLE_BUDGET) / 16];  // (the lean instantiation stages the material / light / spectrum tables: wavefront.h)
+    const SceneView sv = EMIT_INLINE ? sv_global : stage_scene_tables(sv_global, lds_tables, s_tables);
     const uint32_t n = n_in ? *n_in : qs->n_active[cur];  // (n_in: the lean diversion's queue, whose count is not n_active)
     __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
     __shared__ uint32_t s_emit[EMIT_INLINE ? 1 : SHADE_CHUNK];
@@ -363,12 +366,12 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathAr
 #define WF_SHADE_LAUNCH(KERNEL)                                                                                                              \
     do {                                                                                                                                     \
         hipLaunchKernelGGL(KERNEL, dim3(s->n_cu * K_SHADE_LEAN_WAVES), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], s->d_q_active[a.cur ^ 1], \
-                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)nullptr, s->d_q_emit); \
+                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)nullptr, s->d_q_emit, s->lds_tables); \
         LAUNCH_TRY("k_shade");                                                                                                               \
     } while (0)
 #define WF_SHADE_LAUNCH_DIVERTED(KERNEL)                                                                                                     \
     do {                                                                                                                                     \
         hipLaunchKernelGGL(KERNEL, dim3(s->n_cu * K_SHADE_LEAN_WAVES), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_lean, s->d_q_active[a.cur ^ 1], \
-                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)&s->d_qs->n_lean, s->d_q_emit); \
+                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)&s->d_qs->n_lean, s->d_q_emit, s->lds_tables); \
         LAUNCH_TRY("k_shade (diverted)");                                                                                                    \
     } while (0)

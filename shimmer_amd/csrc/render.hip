@@ -149,7 +149,7 @@ namespace {
 
 template <typename T>
 int dev_upload(ShmScene* s, const std::vector<T>& v, const T** out) {
-    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    size_t bytes = (std::max<size_t>(v.size(), 1) * sizeof(T) + 15u) & ~(size_t)15u;  // (whole 16-byte groups: the LDS staging of the small tables copies uint4s)
     void* d = nullptr;
     HIP_TRY(hipMalloc(&d, bytes));
     s->allocs.push_back(d);
@@ -472,6 +472,18 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_TRACE_RAYS_PER_LANE")) { int v2 = atoi(e); if (v2 >= 0 && v2 <= 4096) s->trace_rays_per_lane = v2; }
     if (const char* e = getenv("SHM_CONCURRENT_SCATTER")) s->concurrent_scatter = atoi(e) != 0;
     if (const char* e = getenv("SHM_TRACE_PAIR")) s->trace_pair = atoi(e) != 0;
+    {   // the small tables the shading kernels stage in LDS (wavefront.h, stage_scene_tables): all three or — when they do not fit the budget — the ones that do, smallest first
+        auto pad16 = [](size_t b) { return (uint32_t)((b + 15u) & ~(size_t)15u); };  // (dev_upload allocates whole 16-byte groups)
+        const uint32_t mb = pad16(f.materials.size() * sizeof(ShmMaterial)), lb = pad16(f.lights.size() * sizeof(ShmLight)), sb = pad16(f.spectrum_data.size() * sizeof(float));
+        const bool whole_m = true, whole_l = true, whole_s = true;
+        uint32_t left = LDS_TABLE_BUDGET;
+        const char* e = getenv("SHM_LDS_TABLES");
+        if (!(e && atoi(e) == 0)) {
+            if (whole_l && lb && lb <= left) { s->lds_tables.lights_bytes = lb; left -= lb; }
+            if (whole_m && mb && mb <= left) { s->lds_tables.materials_bytes = mb; left -= mb; }
+            if (whole_s && sb && sb <= left) { s->lds_tables.spectrum_bytes = sb; left -= sb; }
+        }
+    }
     // the both-children kernels set a ray up with the root test and six IEEE divisions (200 VALU instructions): they refill when 40 lanes are idle, so that
     // the set-up runs at 40 lanes instead of 24 (r04 sweep on the headline frame, closest / any ms: 24: 97.4 / 62.3, 40: 96.5 / 60.9, 48: 102.1 / 63.5, 56: 119.1 / 78.1)
     if (!s->flat.has_spheres && s->trace_pair) s->refill_min = s->refill_min_any = 40;

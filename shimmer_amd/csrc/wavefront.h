@@ -133,6 +133,34 @@ __device__ __forceinline__ void st_aux(const PathArrays& pa, uint32_t path, cons
     pa.aux2[path] = make_float4(x.ry_o.z, x.ry_d.x, x.ry_d.y, x.ry_d.z);
 }
 
+// ---- small scene tables staged in LDS --------------------------------------------------------------------------------------------------
+// The material table, the light table and the spectrum pool are tens of bytes to a few KB, and every vertex reaches them at the END of a chain of dependent
+// gathers (hit -> primitive -> material -> spectrum samples; light -> spectrum samples): from L2 each link costs a vector-memory round trip. A workgroup copies them
+// into LDS once and the kernel goes on with a SceneView whose pointers name the copies — generic pointers into the LDS aperture: the shared leaf code (shm/*.h,
+// compiled for the oracle too) reads them through the same flat loads as before, at LDS latency. Same bytes: results cannot change. `LdsTables` says what fits
+// (host side: wf_lds_tables); a scene whose tables exceed the budget runs with the global pointers (bytes = 0).
+constexpr uint32_t LDS_TABLE_BUDGET = 12 * 1024;
+struct LdsTables {
+    uint32_t materials_bytes, lights_bytes, spectrum_bytes;  // each a multiple of 16; all 0: nothing staged
+};
+__device__ __forceinline__ SceneView stage_scene_tables(const SceneView& sv, const LdsTables t, uint4* lds) {
+    SceneView out = sv;
+    const uint32_t total = t.materials_bytes + t.lights_bytes + t.spectrum_bytes;
+    if (total == 0u) return out;
+    const uint32_t n_m = t.materials_bytes / 16u, n_l = t.lights_bytes / 16u, n_s = t.spectrum_bytes / 16u;
+    const uint4* gm = reinterpret_cast<const uint4*>(sv.materials);
+    const uint4* gl = reinterpret_cast<const uint4*>(sv.lights);
+    const uint4* gs = reinterpret_cast<const uint4*>(sv.spectrum_data);
+    for (uint32_t i = threadIdx.x; i < n_m; i += blockDim.x) lds[i] = gm[i];
+    for (uint32_t i = threadIdx.x; i < n_l; i += blockDim.x) lds[n_m + i] = gl[i];
+    for (uint32_t i = threadIdx.x; i < n_s; i += blockDim.x) lds[n_m + n_l + i] = gs[i];
+    __syncthreads();
+    if (n_m) out.materials = reinterpret_cast<const ShmMaterial*>(lds);
+    if (n_l) out.lights = reinterpret_cast<const ShmLight*>(lds + n_m);
+    if (n_s) out.spectrum_data = reinterpret_cast<const Float*>(lds + n_m + n_l);
+    return out;
+}
+
 __device__ __forceinline__ uint32_t wave_lane() { return __lane_id(); }
 
 // Wave-aggregated append: one atomic per wave, lanes get consecutive slots.
@@ -200,6 +228,7 @@ struct ShmScene {
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
     int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
     uint32_t* d_spill3 = nullptr;
+    LdsTables lds_tables = {0, 0, 0};  // what of the material / light / spectrum tables the shading kernels stage in LDS (render.hip: at scene creation; SHM_LDS_TABLES=0: nothing)
     uint32_t* d_q_emit = nullptr;      // paths of the current fused-kernel launch that hit an emitter (k_emit_jobs)
     uint32_t* d_big_leaf_n = nullptr;  // n_prims by first primitive slot, only in scenes with a leaf of >= 15 primitives (the link word holds smaller counts)
     bool trace_pair = true;          // triangle-only scenes: the both-children step (k_trace5) instead of the one-node step (k_trace3); SHM_TRACE_PAIR=0 for A/B

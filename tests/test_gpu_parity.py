@@ -109,6 +109,18 @@ def _stacked_leaf_scene(scenes, lib, copies):
     return scenes._finish(b, lib, name=f"stacked leaf x{copies}")
 
 
+def _tiny_tree_scene(scenes, lib, n_tris):
+    """A tree of one node (n_tris = 1: the root IS a leaf) or three (two triangles): the smallest inputs of the traversal kernels' root handling."""
+    from shimmer_amd.scene import SceneBuilder, blackbody_dense
+    b = SceneBuilder()
+    b.set_film(16, 16)
+    rfw = b.set_camera_look_at(lib, (0, 0, 4), (0, 0, 0), (0, 1, 0), 40.0)
+    p = np.array([[-1, -1, 0], [1, -1, 0.2], [0, 1, -0.1], [0.5, 0.5, 1.0], [1.5, 0.6, 1.1], [0.9, 1.5, 0.8]], np.float32)[: 3 * n_tris]
+    vi = np.arange(3 * n_tris, dtype=np.uint32).reshape(-1, 3)
+    b.add_mesh(scenes._to_render(p, rfw), vi, b.material_diffuse(0.5), emission=blackbody_dense(6500.0), emission_scale=5.0, two_sided=True)
+    return scenes._finish(b, lib, name=f"{n_tris} triangle(s)")
+
+
 @pytest.mark.parametrize("pair", ["1", "0"])
 def test_trace_both_step_kinds(env, monkeypatch, pair):
     """Triangle-only scenes are traced by the both-children step (k_trace5, the default) or by the one-node step (k_trace3, SHM_TRACE_PAIR=0, the
@@ -117,7 +129,8 @@ def test_trace_both_step_kinds(env, monkeypatch, pair):
     and 40 coincident triangles (the link word's count field saturates at 15: ShmScene::d_big_leaf_n)."""
     lib, oracle_py, render, scenes = env
     monkeypatch.setenv("SHM_TRACE_PAIR", pair)
-    cases = [scenes.ganesha_proxy(lib, 64, 64, n=96), scenes.cornell_box(lib, 32, 32)] + [_stacked_leaf_scene(scenes, lib, c) for c in (14, 15, 16, 40)]
+    cases = [scenes.ganesha_proxy(lib, 64, 64, n=96), scenes.cornell_box(lib, 32, 32)] + [_stacked_leaf_scene(scenes, lib, c) for c in (14, 15, 16, 40)] + \
+            [_tiny_tree_scene(scenes, lib, 1), _tiny_tree_scene(scenes, lib, 2)]
     for sc in cases:
         gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
         for seed, tmax, aim in ((5, np.inf, 0.5), (6, 2.5, 0.9)):
