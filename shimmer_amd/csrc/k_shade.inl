@@ -41,8 +41,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in, uint32_t* __restrict__ q_emit,
                                                      LdsTables lds_tables) {
-    __shared__ uint4 s_tables[(EMIT_INLINE ? 16 : LDS_TABLE_BUDGET) / 16];  // (the lean instantiation stages the material / light / spectrum tables: wavefront.h)
-    const SceneView sv = EMIT_INLINE ? sv_global : stage_scene_tables(sv_global, lds_tables, s_tables);
+    __shared__ uint4 s_tables[LDS_TABLE_BUDGET / 16];  // the small scene tables, staged once per workgroup (wavefront.h, stage_scene_tables)
+    const SceneView sv = stage_scene_tables(sv_global, lds_tables, s_tables);
     const uint32_t n = n_in ? *n_in : qs->n_active[cur];  // (n_in: the lean diversion's queue, whose count is not n_active)
     __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
     __shared__ uint32_t s_emit[EMIT_INLINE ? 1 : SHADE_CHUNK];

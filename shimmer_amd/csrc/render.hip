@@ -218,6 +218,25 @@ static uint64_t workspace_cap(const ShmScene* s, bool need_staged) {
     return std::max<uint64_t>(cap, 4096);
 }
 
+}  // namespace
+// Which of the small scene tables a kernel with `budget` bytes of LDS to spare stages there (wavefront.h, stage_scene_tables): greedily, in the enum's order.
+LdsTables wf_lds_tables(const ShmScene* s, uint32_t budget) {
+    LdsTables t = {};
+    const char* e = getenv("SHM_LDS_TABLES");
+    if (e && atoi(e) == 0) return t;
+    const shm_host::FlatScene& f = s->flat;
+    auto pad16 = [](size_t b) { return (size_t)((b + 15u) & ~(size_t)15u); };  // (dev_upload allocates whole 16-byte groups)
+    const size_t want[N_LDS_TABLES] = {
+        pad16(f.lights.size() * sizeof(ShmLight)), pad16(f.materials.size() * sizeof(ShmMaterial)), pad16(f.spectrum_data.size() * sizeof(float)),
+        pad16(f.image_textures.size() * sizeof(ShmImageTexture)), pad16(f.image_levels.size() * sizeof(ShmImageLevel)), pad16(f.float_textures.size() * sizeof(ShmFloatTexture)),
+        pad16(f.ftex_ranges.size() * sizeof(shm::FloatTexRange)), pad16(f.ftex_ops.size() * sizeof(shm::FloatTexOp)), pad16(f.spectrum_textures.size() * sizeof(ShmSpectrumTexture)),
+        pad16(f.stex_ranges.size() * sizeof(shm::FloatTexRange)), pad16(f.stex_ops.size() * sizeof(shm::FloatTexOp)), pad16(f.ewa_lut.size() * sizeof(float))};
+    size_t left = budget;
+    for (int k = 0; k < N_LDS_TABLES; ++k)
+        if (want[k] && want[k] <= left) { t.bytes[k] = (uint32_t)want[k]; left -= want[k]; }
+    return t;
+}
+namespace {
 int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
     uint64_t max_cap = workspace_cap(s, need_staged);
     uint64_t want = std::min<uint64_t>(std::max<uint64_t>(needed_paths, 4096), max_cap);
@@ -472,18 +491,8 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_TRACE_RAYS_PER_LANE")) { int v2 = atoi(e); if (v2 >= 0 && v2 <= 4096) s->trace_rays_per_lane = v2; }
     if (const char* e = getenv("SHM_CONCURRENT_SCATTER")) s->concurrent_scatter = atoi(e) != 0;
     if (const char* e = getenv("SHM_TRACE_PAIR")) s->trace_pair = atoi(e) != 0;
-    {   // the small tables the shading kernels stage in LDS (wavefront.h, stage_scene_tables): all three or — when they do not fit the budget — the ones that do, smallest first
-        auto pad16 = [](size_t b) { return (uint32_t)((b + 15u) & ~(size_t)15u); };  // (dev_upload allocates whole 16-byte groups)
-        const uint32_t mb = pad16(f.materials.size() * sizeof(ShmMaterial)), lb = pad16(f.lights.size() * sizeof(ShmLight)), sb = pad16(f.spectrum_data.size() * sizeof(float));
-        const bool whole_m = true, whole_l = true, whole_s = true;
-        uint32_t left = LDS_TABLE_BUDGET;
-        const char* e = getenv("SHM_LDS_TABLES");
-        if (!(e && atoi(e) == 0)) {
-            if (whole_l && lb && lb <= left) { s->lds_tables.lights_bytes = lb; left -= lb; }
-            if (whole_m && mb && mb <= left) { s->lds_tables.materials_bytes = mb; left -= mb; }
-            if (whole_s && sb && sb <= left) { s->lds_tables.spectrum_bytes = sb; left -= sb; }
-        }
-    }
+    s->lds_tables = wf_lds_tables(s, LDS_TABLE_BUDGET);
+    s->lds_tables_small = wf_lds_tables(s, LDS_TABLE_BUDGET_SMALL);
     // the both-children kernels set a ray up with the root test and six IEEE divisions (200 VALU instructions): they refill when 40 lanes are idle, so that
     // the set-up runs at 40 lanes instead of 24 (r04 sweep on the headline frame, closest / any ms: 24: 97.4 / 62.3, 40: 96.5 / 60.9, 48: 102.1 / 63.5, 56: 119.1 / 78.1)
     if (!s->flat.has_spheres && s->trace_pair) s->refill_min = s->refill_min_any = 40;

@@ -139,25 +139,42 @@ __device__ __forceinline__ void st_aux(const PathArrays& pa, uint32_t path, cons
 // into LDS once and the kernel goes on with a SceneView whose pointers name the copies — generic pointers into the LDS aperture: the shared leaf code (shm/*.h,
 // compiled for the oracle too) reads them through the same flat loads as before, at LDS latency. Same bytes: results cannot change. `LdsTables` says what fits
 // (host side: wf_lds_tables); a scene whose tables exceed the budget runs with the global pointers (bytes = 0).
-constexpr uint32_t LDS_TABLE_BUDGET = 12 * 1024;
+constexpr uint32_t LDS_TABLE_BUDGET = 12 * 1024, LDS_TABLE_BUDGET_SMALL = 1536;
+// the tables a kernel may stage, hottest and smallest first (the host fills a kernel's budget greedily in this order: wf_lds_tables, render.hip)
+enum : int { LT_LIGHTS, LT_MATERIALS, LT_SPECTRUM, LT_IMAGE_TEXTURES, LT_IMAGE_LEVELS, LT_FLOAT_TEXTURES, LT_FTEX_RANGES, LT_FTEX_OPS, LT_SPECTRUM_TEXTURES,
+              LT_STEX_RANGES, LT_STEX_OPS, LT_EWA_LUT, N_LDS_TABLES };
 struct LdsTables {
-    uint32_t materials_bytes, lights_bytes, spectrum_bytes;  // each a multiple of 16; all 0: nothing staged
+    uint32_t bytes[N_LDS_TABLES];  // each a multiple of 16 (dev_upload allocates whole 16-byte groups); 0: that table stays in global memory
 };
-__device__ __forceinline__ SceneView stage_scene_tables(const SceneView& sv, const LdsTables t, uint4* lds) {
+__device__ __forceinline__ SceneView stage_scene_tables(const SceneView& sv, const LdsTables& t, uint4* lds) {
     SceneView out = sv;
-    const uint32_t total = t.materials_bytes + t.lights_bytes + t.spectrum_bytes;
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < N_LDS_TABLES; ++k) total += t.bytes[k];
     if (total == 0u) return out;
-    const uint32_t n_m = t.materials_bytes / 16u, n_l = t.lights_bytes / 16u, n_s = t.spectrum_bytes / 16u;
-    const uint4* gm = reinterpret_cast<const uint4*>(sv.materials);
-    const uint4* gl = reinterpret_cast<const uint4*>(sv.lights);
-    const uint4* gs = reinterpret_cast<const uint4*>(sv.spectrum_data);
-    for (uint32_t i = threadIdx.x; i < n_m; i += blockDim.x) lds[i] = gm[i];
-    for (uint32_t i = threadIdx.x; i < n_l; i += blockDim.x) lds[n_m + i] = gl[i];
-    for (uint32_t i = threadIdx.x; i < n_s; i += blockDim.x) lds[n_m + n_l + i] = gs[i];
+    uint32_t at = 0;  // in uint4s
+#define SHM_STAGE_TABLE(K, FIELD, TYPE)                                                                \
+    if (t.bytes[K]) {                                                                                  \
+        const uint32_t n = t.bytes[K] / 16u;                                                           \
+        const uint4* g = reinterpret_cast<const uint4*>(sv.FIELD);                                     \
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds[at + i] = g[i];                     \
+        out.FIELD = reinterpret_cast<const TYPE*>(lds + at);                                           \
+        at += n;                                                                                       \
+    }
+    SHM_STAGE_TABLE(LT_LIGHTS, lights, ShmLight)
+    SHM_STAGE_TABLE(LT_MATERIALS, materials, ShmMaterial)
+    SHM_STAGE_TABLE(LT_SPECTRUM, spectrum_data, Float)
+    SHM_STAGE_TABLE(LT_IMAGE_TEXTURES, image_textures, ShmImageTexture)
+    SHM_STAGE_TABLE(LT_IMAGE_LEVELS, image_levels, ShmImageLevel)
+    SHM_STAGE_TABLE(LT_FLOAT_TEXTURES, float_textures, ShmFloatTexture)
+    SHM_STAGE_TABLE(LT_FTEX_RANGES, ftex_ranges, FloatTexRange)
+    SHM_STAGE_TABLE(LT_FTEX_OPS, ftex_ops, FloatTexOp)
+    SHM_STAGE_TABLE(LT_SPECTRUM_TEXTURES, spectrum_textures, ShmSpectrumTexture)
+    SHM_STAGE_TABLE(LT_STEX_RANGES, stex_ranges, FloatTexRange)
+    SHM_STAGE_TABLE(LT_STEX_OPS, stex_ops, FloatTexOp)
+    SHM_STAGE_TABLE(LT_EWA_LUT, ewa_lut, Float)
+#undef SHM_STAGE_TABLE
     __syncthreads();
-    if (n_m) out.materials = reinterpret_cast<const ShmMaterial*>(lds);
-    if (n_l) out.lights = reinterpret_cast<const ShmLight*>(lds + n_m);
-    if (n_s) out.spectrum_data = reinterpret_cast<const Float*>(lds + n_m + n_l);
     return out;
 }
 
@@ -228,7 +245,8 @@ struct ShmScene {
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
     int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
     uint32_t* d_spill3 = nullptr;
-    LdsTables lds_tables = {0, 0, 0};  // what of the material / light / spectrum tables the shading kernels stage in LDS (render.hip: at scene creation; SHM_LDS_TABLES=0: nothing)
+    LdsTables lds_tables = {};        // the small tables the shading kernels stage in LDS within the full budget (render.hip: wf_lds_tables; SHM_LDS_TABLES=0: nothing)
+    LdsTables lds_tables_small = {};  // ... within the 1.5 KB the material-sorted triangle vertex kernel has to spare
     uint32_t* d_q_emit = nullptr;      // paths of the current fused-kernel launch that hit an emitter (k_emit_jobs)
     uint32_t* d_big_leaf_n = nullptr;  // n_prims by first primitive slot, only in scenes with a leaf of >= 15 primitives (the link word holds smaller counts)
     bool trace_pair = true;          // triangle-only scenes: the both-children step (k_trace5) instead of the one-node step (k_trace3); SHM_TRACE_PAIR=0 for A/B
@@ -269,6 +287,7 @@ struct EventPool {
 // ---- launchers exported by the kernel translation units (hidden visibility: library-internal) ----
 #define WF_INTERNAL __attribute__((visibility("hidden")))
 // k_trace.hip: BvhAggregate::intersect (any = false) / intersect_predicate (any = true) over a queue of path slots
+WF_INTERNAL LdsTables wf_lds_tables(const ShmScene* s, uint32_t budget);  // render.hip: which small tables fit `budget` bytes of LDS
 WF_INTERNAL void wf_trace_census();  // k_trace.hip: prints the per-phase lane census of a -DK5_CENSUS development build (a no-op otherwise)
 WF_INTERNAL int wf_trace_prepare(ShmScene* s);  // grid sizes + stack spill buffers of the two traversal kernels (at scene creation)
 WF_INTERNAL int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct,
