@@ -383,6 +383,24 @@ def test_c4_frame_at_full_size(env):
     gpu.close()
 
 
+def test_instance_root_inside_another_tree_is_rejected(env):
+    """An instance whose root node lies INSIDE the top-level tree (an instanced sub-tree) would get two device indices in the sibling-pair re-layout of the node array:
+    scene creation names it instead of traversing something else (advisor, round 3). Whatever layer refuses it first, it is refused with a message, on the GPU path."""
+    lib, oracle_py, render, scenes = env
+    sc = scenes.instanced_scene(lib, 16, 16, n_instances=2)
+    assert sc.desc.n_instances >= 1 and sc.desc.n_nodes > 3
+    saved = sc.desc.instances[0].root_node
+    try:
+        sc.desc.instances[0].root_node = 1  # the first child of the top-level root: not a tree of its own
+        with pytest.raises(Exception) as ei:
+            render.Renderer(lib, sc.desc, 0).close()
+        assert "instance" in str(ei.value).lower() or "tree" in str(ei.value).lower() or "unsupported" in str(ei.value).lower(), str(ei.value)
+    finally:
+        sc.desc.instances[0].root_node = saved
+    r = render.Renderer(lib, sc.desc, 0)  # (and the untouched description still loads)
+    r.close()
+
+
 def test_workspace_is_not_reallocated_between_equal_renders(env):
     """A frame large enough to take the whole workspace budget (64 M paths: more than an eighth of it) rendered three times: the second and third render find
     the workspace of the first. Round 4 found the opposite — the per-path estimate of the budget was 16 bytes high, the budget crept from call to call, and every
