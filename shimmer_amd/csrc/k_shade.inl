@@ -40,7 +40,7 @@ template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ON
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneView sv_global, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in, uint32_t* __restrict__ q_emit,
-                                                     LdsTables lds_tables) {
+                                                     LdsTables lds_tables, int first_bounce) {
     __shared__ uint4 s_tables[LDS_TABLE_BUDGET / 16];  // the small scene tables, staged once per workgroup (wavefront.h, stage_scene_tables)
     const SceneView sv = stage_scene_tables(sv_global, lds_tables, s_tables);
     const uint32_t n = n_in ? *n_in : qs->n_active[cur];  // (n_in: the lean diversion's queue, whose count is not n_active)
@@ -56,7 +56,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
         bool push_next = false, push_shadow = false, push_emit = false;
         uint32_t path = 0;
         if (active) {
-            path = q_cur[i];
+            // first_bounce (wave-uniform; the lean instantiation only): k_generate left the constants out — the queue is the identity, beta = 1, p_b = eta_scale = 1, flags = 0
+            path = first_bounce ? i : q_cur[i];
             const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
             float4 h0 = hp[0], h1 = hp[1];
             Hit hit;
@@ -67,7 +68,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
             // L is only touched by a vertex that adds emission (most do not): loaded and stored inside add_l
             auto add_l = [&](const Spec& c) { pa.L[path] = st_spec(ld_spec(pa.L[path]) + c); };
             // (beta is read where it is used — emission, the NEE contribution, the throughput update — instead of being held across the vertex)
-            auto load_beta = [&]() { return ld_spec(pa.beta[path]); };
+            auto load_beta = [&]() { return first_bounce ? spec_const(1.0f) : ld_spec(pa.beta[path]); };
+            auto load_pb_eta = [&]() { return first_bounce ? make_float2(1.0f, 1.0f) : pa.pb_eta[path]; };
             Spec beta;
             Wavelengths lambda;
             float4 pdf_in;
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                 lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
                 lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
             }
-            uint32_t fl = pa.flags[path];
+            uint32_t fl = first_bounce ? 0u : pa.flags[path];
             int depth = (int)(fl & 0xffu);
             bool specular_bounce = (fl >> 8) & 1u;
             bool any_non_specular_bounces = (fl >> 9) & 1u;
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                         add_l(load_beta() * le);
                     } else {
                         Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
-                        Float w_b = power_heuristic(1, pa.pb_eta[path].x, 1, p_l);
+                        Float w_b = power_heuristic(1, load_pb_eta().x, 1, p_l);
                         add_l(load_beta() * w_b * le);
                     }
                 }
@@ -116,8 +118,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                 if (!EMIT_INLINE && prim.area_light >= 0) {
                     // the hit is on an emitter (rare): its `L += beta * Le` — with the MIS weight's inverted light sampling — is k_emit_jobs's, after this launch; what
                     // it needs of the state this vertex overwrites goes to the side arrays now
-                    pa.e_ray[path] = make_float4(ray_d.x, ray_d.y, ray_d.z, pa.pb_eta[path].x);
-                    pa.e_beta[path] = pa.beta[path];
+                    pa.e_ray[path] = make_float4(ray_d.x, ray_d.y, ray_d.z, load_pb_eta().x);
+                    pa.e_beta[path] = st_spec(load_beta());
                     pa.e_flags[path] = fl;
                     if (!(depth == 0 || specular_bounce)) { pa.e_ctx0[path] = pa.ctx0[path]; pa.e_ctx1[path] = pa.ctx1[path]; pa.e_ctx2[path] = pa.ctx2[path]; }
                     push_emit = true;
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                             add_l(load_beta() * le);
                         } else {
                             Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
-                            Float w_l = power_heuristic(1, pa.pb_eta[path].x, 1, p_l);
+                            Float w_l = power_heuristic(1, load_pb_eta().x, 1, p_l);
                             add_l(load_beta() * w_l * le);
                         }
                     }
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                         p_b = bs.pdf_is_proportional ? bsdf_pdf(bsdf, wo, bs.wi, REFLTRANS_ALL) : bs.pdf;
                         specular_bounce = flags_is_specular(bs.flags);
                         any_non_specular_bounces |= !specular_bounce;
-                        eta_scale = pa.pb_eta[path].y;
+                        eta_scale = load_pb_eta().y;
                         if (flags_is_transmissive(bs.flags)) eta_scale *= sqr(bs.eta);
                         LightSampleContext nctx = light_ctx_from(si);
                         V3 no = offset_ray_origin(si.pi, si.n, bs.wi);  // integrator.rs:875 -> interaction.rs:68-75
@@ -366,12 +368,12 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathAr
 #define WF_SHADE_LAUNCH(KERNEL)                                                                                                              \
     do {                                                                                                                                     \
         hipLaunchKernelGGL(KERNEL, dim3(s->n_cu * K_SHADE_LEAN_WAVES), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], s->d_q_active[a.cur ^ 1], \
-                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)nullptr, s->d_q_emit, s->lds_tables); \
+                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)nullptr, s->d_q_emit, s->lds_tables, a.first_bounce); \
         LAUNCH_TRY("k_shade");                                                                                                               \
     } while (0)
 #define WF_SHADE_LAUNCH_DIVERTED(KERNEL)                                                                                                     \
     do {                                                                                                                                     \
         hipLaunchKernelGGL(KERNEL, dim3(s->n_cu * K_SHADE_LEAN_WAVES), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_lean, s->d_q_active[a.cur ^ 1], \
-                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)&s->d_qs->n_lean, s->d_q_emit, s->lds_tables); \
+                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)&s->d_qs->n_lean, s->d_q_emit, s->lds_tables, 0); \
         LAUNCH_TRY("k_shade (diverted)");                                                                                                    \
     } while (0)

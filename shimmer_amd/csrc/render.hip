@@ -53,7 +53,7 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t p_local, uint32_t s_local, 
 
 // HAS_TEX: scenes that bind image textures carry the camera ray's auxiliary rays (a compile-time switch: with a run-time pointer the
 // auxiliary-ray record lived in scratch memory, 52 B of stores per path, in every scene)
-template <bool HAS_TEX>
+template <bool HAS_TEX, bool LEAN = false>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArrays pa, const uint32_t* pixels, uint32_t n_pix,
                                                         int sample_begin, int n_samples, ShmRenderParams params,
                                                         uint32_t* q_active, QueueState* qs, uint32_t pix_group) {
@@ -83,15 +83,19 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
     ray.pad = 0.0f;
     pa.ray[slot] = ray;
     pa.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    // LEAN (the fused kernel shades bounce 0 and knows it is bounce 0): the constants — beta = 1, p_b = eta_scale = 1, flags = 0, the identity queue — are not
+    // written here nor read there (ShadeArgs::first_bounce): 32 of 124 bytes per path
+    if (!LEAN) pa.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     pa.lambda[slot] = make_float4(lambda.lambda[0], lambda.lambda[1], lambda.lambda[2], lambda.lambda[3]);
     pa.lambda_pdf[slot] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
     // (ctx0..2, the previous vertex's LightSampleContext, are first read at depth >= 1, after k_shade has written them)
-    pa.pb_eta[slot] = make_float2(1.0f, 1.0f);
+    if (!LEAN) pa.pb_eta[slot] = make_float2(1.0f, 1.0f);
     pa.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
     pa.pixel[slot] = pix;
-    pa.flags[slot] = has_tex ? (1u << 10) : 0u;  // camera rays always carry auxiliary rays (camera.rs:1070-1078)
-    q_active[slot] = slot;  // first bounce: identity queue
+    if (!LEAN) {
+        pa.flags[slot] = has_tex ? (1u << 10) : 0u;  // camera rays always carry auxiliary rays (camera.rs:1070-1078)
+        q_active[slot] = slot;  // first bounce: identity queue
+    }
     if (slot == 0) {
         qs->n_active[0] = total;
         qs->n_active[1] = 0;
@@ -631,8 +635,14 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         uint32_t n_pix = (uint32_t)std::min<uint64_t>(pix_per_batch, n_pixels - p0);
         uint32_t total = n_pix * (uint32_t)n_samples;
         const uint32_t* pixels = s->d_pixels + p0;
+        // the fused kernel's own scene class under the path integrator: bounce 0 runs on known constants (k_generate<., LEAN>, ShadeArgs::first_bounce; SHM_LEAN_FIRST_BOUNCE=0: A/B)
+        static const bool lean_first_on = [] { const char* e = getenv("SHM_LEAN_FIRST_BOUNCE"); return !(e && atoi(e) == 0); }();
+        const bool lean_first = lean_first_on && !staged && !random_walk && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && !s->pa.aux0;
         if (s->pa.aux0)
             hipLaunchKernelGGL(k_generate<true>, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
+                               sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs, s->pix_group);
+        else if (lean_first)
+            hipLaunchKernelGGL((k_generate<false, true>), dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
                                sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs, s->pix_group);
         else
             hipLaunchKernelGGL(k_generate<false>, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
@@ -665,14 +675,16 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
             }
             hipEvent_t a = ev.get(), b = ev.get();
             hipEventRecord(a, s->stream);
-            if ((rc = wf_launch_trace(s, false, s->stream, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr)) != SHM_OK) return rc;
+            const bool first_lean = lean_first && bounce == 0;  // (the identity queue was not written: K2 takes slot = queue index, k_shade knows the constants)
+            if ((rc = first_lean ? wf_launch_trace(s, false, s->stream, nullptr, nullptr, total, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr)
+                                 : wf_launch_trace(s, false, s->stream, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr)) != SHM_OK) return rc;
             hipEventRecord(b, s->stream);
             ev_closest.push_back({a, b});
             if (overlap && k3_done) hipStreamWaitEvent(s->stream, k3_done, 0);  // shade(b) touches L and refills the shadow buffers
             {
                 hipEvent_t s0 = ev.get(), s1 = ev.get();
                 hipEventRecord(s0, s->stream);
-                const ShadeArgs sa{s->stream, cur, *params, sh, shade_blocks};
+                const ShadeArgs sa{s->stream, cur, *params, sh, shade_blocks, first_lean ? 1 : 0};
                 const bool tri_only = !s->flat.has_spheres;
                 // the late bounces of a deep render in a triangle scene without textures or coated materials: ONE fused launch instead of the staged four or five
                 // (C4 frame, same box: 522-528 ms staged throughout; 510-512 from bounce 6, 511-513 from 8, 512-513 from 10, 514-517 from 14; 0 = off)

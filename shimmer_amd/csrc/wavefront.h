@@ -300,6 +300,7 @@ struct ShadeArgs {
     ShmRenderParams params;
     int shadow_parity;
     int blocks;
+    int first_bounce = 0;  // 1: bounce 0 of a render whose k_generate left the constants out (beta = 1, p_b = eta_scale = 1, flags = 0, the identity queue): the fused kernel knows them
 };
 WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a);  // the fused kernel: all-diffuse triangle scenes without textures
 WF_INTERNAL int wf_launch_shade_lean_diverted(ShmScene* s, const ShadeArgs& a);
