@@ -636,7 +636,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         uint32_t total = n_pix * (uint32_t)n_samples;
         const uint32_t* pixels = s->d_pixels + p0;
         // the fused kernel's own scene class under the path integrator: bounce 0 runs on known constants (k_generate<., LEAN>, ShadeArgs::first_bounce; SHM_LEAN_FIRST_BOUNCE=0: A/B)
-        static const bool lean_first_on = [] { const char* e = getenv("SHM_LEAN_FIRST_BOUNCE"); return !(e && atoi(e) == 0); }();
+        const bool lean_first_on = [] { const char* e = getenv("SHM_LEAN_FIRST_BOUNCE"); return !(e && atoi(e) == 0); }();  // (read per render: the tests flip it)
         const bool lean_first = lean_first_on && !staged && !random_walk && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && !s->pa.aux0;
         if (s->pa.aux0)
             hipLaunchKernelGGL(k_generate<true>, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,

@@ -401,6 +401,28 @@ def test_instance_root_inside_another_tree_is_rejected(env):
     r.close()
 
 
+@pytest.mark.parametrize("switch", ["SHM_LDS_TABLES", "SHM_LEAN_FIRST_BOUNCE", "SHM_TRACE_PAIR", "SHM_LEAN_DIVERT"])
+def test_ab_switches_change_no_result(env, monkeypatch, switch):
+    """The round-4 optimisations each have an A/B switch read at scene creation / first launch; switched off, the films and the counters are the same bits:
+    the small scene tables staged in LDS, bounce 0 on known constants, the both-children traversal step, the lean diversion (its fused kernel defers emitter hits)."""
+    lib, oracle_py, render, scenes = env
+    cases = [(scenes.ganesha_proxy(lib, 64, 64, n=32), 6, 5), (scenes.cornell_box(lib, 48, 48, coated=True, emitter_reflects=True), 6, 5),
+             (scenes.cornell_box(lib, 40, 40, textured=True), 4, 6)]
+    for sc, spp, depth in cases:
+        p = render.make_params(seed=9, spp=spp, max_depth=depth)
+        monkeypatch.delenv(switch, raising=False)
+        g = render.Renderer(lib, sc.desc, 0)
+        f_on, s_on = g.render(p)
+        g.close()
+        monkeypatch.setenv(switch, "0")
+        g = render.Renderer(lib, sc.desc, 0)
+        f_off, s_off = g.render(p)
+        g.close()
+        assert np.array_equal(f_on, f_off), (switch, sc.name)
+        for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+            assert s_on[k] == s_off[k], (switch, sc.name, k)
+
+
 def test_workspace_is_not_reallocated_between_equal_renders(env):
     """A frame large enough to take the whole workspace budget (64 M paths: more than an eighth of it) rendered three times: the second and third render find
     the workspace of the first. Round 4 found the opposite — the per-path estimate of the budget was 16 bytes high, the budget crept from call to call, and every
