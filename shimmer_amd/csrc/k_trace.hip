@@ -1,6 +1,8 @@
 // k_trace.hip — K2 / K3: BVH traversal of the gfx950 wavefront path tracer (see wavefront.h).
-//   aggregate.rs:71-139    BvhAggregate::intersect           -> k_trace3<false, TRI_ONLY> (persistent waves, LDS stack)
-//   aggregate.rs:141-203   BvhAggregate::intersect_predicate -> k_trace3<true, TRI_ONLY>
+//   aggregate.rs:71-139    BvhAggregate::intersect           -> k_trace5<false> (triangle scenes: the both-children step, round 4) / k_trace3<false, TRI_ONLY>
+//   aggregate.rs:141-203   BvhAggregate::intersect_predicate -> k_trace5<true> / k_trace3<true, TRI_ONLY>
+// Two bodies, one algorithm (the reference's, node for node): trace3_body tests ONE node per step — the kernel of scenes with quadrics / patches / instances,
+// and the A/B partner of the other (SHM_TRACE_PAIR=0) —, trace5_body further down tests BOTH children of a node that is known to be hit.
 #include "wavefront.h"
 
 namespace {
