@@ -549,6 +549,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     const uint32_t part_size = ((n + n_parts * 64u - 1u) / (n_parts * 64u)) * 64u;
     uint32_t part = (n_parts > 1u) ? (__builtin_amdgcn_s_getreg(6164 /* HW_REG_XCC_ID, bits [3:0] */) & (n_parts - 1u)) : 0u;
     uint32_t parts_left = n_parts;
+#ifdef K5_CENSUS
+    const unsigned long long t_loop0 = __builtin_readcyclecounter();
+#endif
     for (;;) {
         // ---- refill idle lanes from the wave-private chunk [w_next, w_end); one atomic per `chunk` rays ----
         const unsigned long long idle = __ballot(cur == CUR_IDLE);
@@ -570,6 +573,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                     }
                 }
                 if (!exhausted) {
+#ifdef K5_CENSUS
+                    const unsigned long long t_refill0 = __builtin_readcyclecounter();
+#endif
                     const uint32_t take = min((uint32_t)n_idle, w_end - w_next);
                     if (cur == CUR_IDLE) {
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
@@ -622,6 +628,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                     m_negy = __ballot((sgn & 2u) != 0u);
                     m_negz = __ballot((sgn & 4u) != 0u);
                     m_irregular = __ballot((sgn & 8u) != 0u);
+#ifdef K5_CENSUS
+                    CENSUS(13, __builtin_readcyclecounter() - t_refill0);  // (the ballots above consume the loaded rays: the refill's memory wait is inside)
+#endif
                 }
             }
             if (__ballot(cur != CUR_IDLE) == 0ull) {
@@ -735,6 +744,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         }
     }
 #ifdef K5_CENSUS
+    CENSUS(14, __builtin_readcyclecounter() - t_loop0);
     if (ANY == (K5_CENSUS == 2) && lane == 0) for (int i = 0; i < 16; ++i) if (c_census[i]) atomicAdd(&g_census[i], c_census[i]);
 #endif
     if (ANY) {
@@ -792,6 +802,7 @@ void wf_trace_census() {
                     "  leaf phases %.3e (one per %.2f iterations), primitive rounds %.3e at %.1f lanes | pop rounds %.3e at %.1f lanes | refills %.3e at %.1f rays\n",
             K5_CENSUS == 2 ? "any-hit" : "closest-hit", it, c[1] / it, c[2] / it, c[3] / it, c[4] / it, c[10] / it, (double)c[5], it / (double)c[5], (double)c[6], (double)c[7] / (double)c[6], (double)c[8], (double)c[9] / (double)c[8],
             (double)c[11], (double)c[12] / (double)c[11]);
+    fprintf(stderr, "  s_memtime ticks: in refills %.3e of %.3e wave-loop ticks = %.1f %% (%.0f ticks per refill)\n", (double)c[13], (double)c[14], 100.0 * (double)c[13] / (double)c[14], (double)c[13] / (double)c[11]);
 #endif
 }
 
