@@ -762,7 +762,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 hipStreamSynchronize(s->stream);
                 hipStreamSynchronize(any_stream);
                 hipMemcpy(&q, s->d_qs, sizeof(q), hipMemcpyDeviceToHost);
-                DBG("bounce %d: traced %u, next %u, shadow %u", bounce, q.n_active[cur], q.n_active[cur ^ 1], q.n_shadow[sh]);
+                DBG("bounce %d: traced %u, next %u, shadow %u, emitter hits deferred %u, diverted %u", bounce, q.n_active[cur], q.n_active[cur ^ 1], q.n_shadow[sh], q.n_emit, q.n_lean);
             }
             hipLaunchKernelGGL(k_next_bounce, dim3(1), dim3(1), 0, s->stream, s->d_qs, cur, sh ^ 1);
             cur ^= 1;
