@@ -690,6 +690,25 @@ int orc_fn_layered_sample_f(int kind, const float* p, const int* ip, const float
     out10[9] = bs.pdf_is_proportional ? 1.0f : 0.0f;
     return 1;
 }
+// LayeredBxDF::sample_f through the resumable form the staged layered kernel runs (layered_sample_begin + layered_sample_step, shm/bxdf.h), `steps_per_pass`
+// steps at a time with the walk's state copied between passes as the kernel's job buffer does; returns the number of steps taken in *n_steps
+int orc_fn_layered_sample_f_steps(int kind, const float* p, const int* ip, const float* wo, float uc, const float* u, int steps_per_pass, float* out10, int* n_steps) {
+    BxDF b = make_layered(kind, p, ip);
+    BSDFSample bs;
+    LayeredWalk k;
+    *n_steps = 0;
+    int status = layered_sample_begin(b, ld3(wo), uc, v2(u[0], u[1]), MODE_RADIANCE, bs, k);
+    while (status == WALK_CONTINUES) {
+        LayeredWalk resumed = k;  // (a deposit and a reload)
+        for (int s = 0; s < steps_per_pass && status == WALK_CONTINUES; ++s) { status = layered_sample_step(b, MODE_RADIANCE, resumed, bs); ++*n_steps; }
+        k = resumed;
+    }
+    if (status == WALK_FAILED) return 0;
+    for (int i = 0; i < 4; ++i) out10[i] = bs.f.v[i];
+    out10[4] = bs.wi.x; out10[5] = bs.wi.y; out10[6] = bs.wi.z; out10[7] = bs.pdf; out10[8] = (float)bs.flags;
+    out10[9] = bs.pdf_is_proportional ? 1.0f : 0.0f;
+    return 1;
+}
 float orc_fn_henyey_greenstein(float cos_theta, float g) { return henyey_greenstein(cos_theta, g); }
 void orc_fn_sample_henyey_greenstein(const float* wo, float g, const float* u, float* out4) {
     Float pdf;

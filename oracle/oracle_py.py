@@ -69,6 +69,7 @@ def load():
     IP = C.POINTER(C.c_int)
     lib.orc_fn_layered_f_pdf.restype, lib.orc_fn_layered_f_pdf.argtypes = None, [C.c_int, FP, IP, FP, FP, FP]
     lib.orc_fn_layered_sample_f.restype, lib.orc_fn_layered_sample_f.argtypes = C.c_int, [C.c_int, FP, IP, FP, F, FP, FP]
+    lib.orc_fn_layered_sample_f_steps.restype, lib.orc_fn_layered_sample_f_steps.argtypes = C.c_int, [C.c_int, FP, IP, FP, F, FP, C.c_int, FP, IP]
     lib.orc_fn_henyey_greenstein.restype, lib.orc_fn_henyey_greenstein.argtypes = F, [F, F]
     lib.orc_fn_sample_henyey_greenstein.restype, lib.orc_fn_sample_henyey_greenstein.argtypes = None, [FP, F, FP, FP]
     lib.orc_fn_sample_exponential.restype, lib.orc_fn_sample_exponential.argtypes = F, [F, F]

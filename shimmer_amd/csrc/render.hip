@@ -325,6 +325,7 @@ void shm_scene_destroy(ShmScene* s) {
     if (!s) return;
     hipSetDevice(s->device);
     wf_trace_census();  // (prints in -DK5_CENSUS development builds only)
+    wf_layered_census();  // (-DLJ_CENSUS)
     wf_dist_release(s);
     for (void* p : s->allocs) hipFree(p);
     for (void* p : s->ws_allocs) hipFree(p);
@@ -636,6 +637,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         uint32_t total = n_pix * (uint32_t)n_samples;
         const uint32_t* pixels = s->d_pixels + p0;
         // the fused kernel's own scene class under the path integrator: bounce 0 runs on known constants (k_generate<., LEAN>, ShadeArgs::first_bounce; SHM_LEAN_FIRST_BOUNCE=0: A/B)
+        const bool layered_staged = [] { const char* e = getenv("SHM_LAYERED_STAGED"); return !(e && atoi(e) == 0); }();  // (the LayeredBxDF class as dense per-wave stages; read per render: the tests flip it)
         const bool lean_first_on = [] { const char* e = getenv("SHM_LEAN_FIRST_BOUNCE"); return !(e && atoi(e) == 0); }();  // (read per render: the tests flip it)
         const bool lean_first = lean_first_on && !staged && !random_walk && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && !s->pa.aux0;
         if (s->pa.aux0)
@@ -734,6 +736,9 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     scatter_on(CLASS_CONDUCTOR, [&](const ShadeArgs& x) { return wf_launch_scatter_conductor(s, x, tri_only, has_tex); });
                     scatter_on(CLASS_DIELECTRIC, [&](const ShadeArgs& x) { return wf_launch_scatter_dielectric(s, x, tri_only, has_tex); });
                     scatter_on(CLASS_LAYERED, [&](const ShadeArgs& x) {
+                        // (options.force_diffuse replaces the BxDF inside this half: the one-pass kernel has that code)
+                        if (params->force_diffuse == 0 && layered_staged)
+                            return has_tex ? wf_launch_scatter_layered_staged_tex(s, x) : (tri_only ? wf_launch_scatter_layered_staged_tri(s, x) : wf_launch_scatter_layered_staged_gen(s, x));
                         return has_tex ? wf_launch_scatter_layered_tex(s, x) : (tri_only ? wf_launch_scatter_layered_tri(s, x) : wf_launch_scatter_layered_gen(s, x)); });
                     for (hipEvent_t e : side_done) hipStreamWaitEvent(s->stream, e, 0);
                 }

@@ -436,8 +436,12 @@ SHM_HD uint32_t base_flags(const BaseBxDF& b) {
 // under the AMDGPU calling convention (BaseBxDF is 48 B, a BSDFSample with its flag 48 B), while a `const BaseBxDF&` or a `BSDFSample&` has to
 // live in scratch memory — which is what round 2's layered scatter kernel did at every one of its ~30 call sites (416-464 B of scratch per
 // lane, 7 GB written per launch: profiles/r02_staged_S3c.txt). The reference-shaped signatures below are inline wrappers.
+// Behind the interface (12 registers) and wo (3) every further argument is a SCALAR: clang hands an aggregate that no longer fits the first 16
+// argument registers over through the stack (round 4 found one scratch_store_dwordx3 + scratch_load_dwordx3 of `wi` around each of these calls),
+// scalars always travel in registers.
 struct BSDFSampleOpt { BSDFSample s; uint32_t ok; };
-SHM_BASE_BXDF_CALL Spec base_f_v(BaseBxDF b, V3 wo, V3 wi, int mode) {
+SHM_BASE_BXDF_CALL Spec base_f_v(BaseBxDF b, V3 wo, Float wi_x, Float wi_y, Float wi_z, int mode) {
+    const V3 wi = v3(wi_x, wi_y, wi_z);
     switch (b.kind) {
         case SHM_MATERIAL_DIFFUSE: return diffuse_f(b, wo, wi);
         case SHM_MATERIAL_CONDUCTOR: return conductor_f(b, wo, wi);
@@ -445,7 +449,8 @@ SHM_BASE_BXDF_CALL Spec base_f_v(BaseBxDF b, V3 wo, V3 wi, int mode) {
         default: return spec_const(0.0f);
     }
 }
-SHM_BASE_BXDF_CALL BSDFSampleOpt base_sample_f_v(BaseBxDF b, V3 wo, Float uc, V2 u, uint32_t sample_flags, int mode) {
+SHM_BASE_BXDF_CALL BSDFSampleOpt base_sample_f_v(BaseBxDF b, V3 wo, Float uc, Float u_x, Float u_y, uint32_t sample_flags, int mode) {
+    const V2 u = v2(u_x, u_y);
     BSDFSampleOpt r;
     r.s = bsdf_sample(spec_const(0.0f), v3s(0.0f), 0.0f, 0u);
     bool ok;
@@ -458,7 +463,8 @@ SHM_BASE_BXDF_CALL BSDFSampleOpt base_sample_f_v(BaseBxDF b, V3 wo, Float uc, V2
     r.ok = ok ? 1u : 0u;
     return r;
 }
-SHM_BASE_BXDF_CALL Float base_pdf_v(BaseBxDF b, V3 wo, V3 wi, uint32_t sample_flags) {
+SHM_BASE_BXDF_CALL Float base_pdf_v(BaseBxDF b, V3 wo, Float wi_x, Float wi_y, Float wi_z, uint32_t sample_flags) {
+    const V3 wi = v3(wi_x, wi_y, wi_z);
     switch (b.kind) {
         case SHM_MATERIAL_DIFFUSE: return diffuse_pdf(b, wo, wi, sample_flags);
         case SHM_MATERIAL_CONDUCTOR: return conductor_pdf(b, wo, wi, sample_flags);
@@ -466,13 +472,13 @@ SHM_BASE_BXDF_CALL Float base_pdf_v(BaseBxDF b, V3 wo, V3 wi, uint32_t sample_fl
         default: return 0.0f;
     }
 }
-SHM_HD Spec base_f(const BaseBxDF& b, V3 wo, V3 wi, int mode = MODE_RADIANCE) { return base_f_v(b, wo, wi, mode); }
+SHM_HD Spec base_f(const BaseBxDF& b, V3 wo, V3 wi, int mode = MODE_RADIANCE) { return base_f_v(b, wo, wi.x, wi.y, wi.z, mode); }
 SHM_HD bool base_sample_f(const BaseBxDF& b, V3 wo, Float uc, V2 u, uint32_t sample_flags, BSDFSample& out, int mode = MODE_RADIANCE) {
-    const BSDFSampleOpt r = base_sample_f_v(b, wo, uc, u, sample_flags, mode);
+    const BSDFSampleOpt r = base_sample_f_v(b, wo, uc, u.x, u.y, sample_flags, mode);
     if (r.ok) out = r.s;   // (a failed sample leaves `out` as it was, as the by-reference form did)
     return r.ok != 0u;
 }
-SHM_HD Float base_pdf(const BaseBxDF& b, V3 wo, V3 wi, uint32_t sample_flags) { return base_pdf_v(b, wo, wi, sample_flags); }
+SHM_HD Float base_pdf(const BaseBxDF& b, V3 wo, V3 wi, uint32_t sample_flags) { return base_pdf_v(b, wo, wi.x, wi.y, wi.z, sample_flags); }
 
 // ---- Henyey-Greenstein, scattering.rs:231-260; HGPhaseFunction, media.rs:8-40 (p == pdf) ----
 SHM_HD Float henyey_greenstein(Float cos_theta, Float g) {
@@ -716,6 +722,99 @@ SHM_HD bool layered_sample_f(const BxDF& l, V3 wo, Float uc, V2 u, int mode, BSD
         f = f * abs_cos_theta(s2.wi);
     }
     return false;
+}
+
+// LayeredBxDF::sample_f as a RESUMABLE walk: `layered_sample_begin` is everything layered_sample_f does before its loop, `layered_sample_step` one iteration of
+// the loop — the same statements in the same order, with the loop's locals in a struct. The staged layered kernel (k_scatter_layered.inl) advances 64 deposited
+// walks per wave two steps at a time instead of letting every lane wait for the longest walk of its wave; tests/test_layered.py holds begin + steps bitwise equal
+// to layered_sample_f (which stays the oracle's text).
+struct LayeredWalk {
+    V3 w;
+    Spec f;
+    Float pdf, z;
+    Float wo_z;  // of the flipped wo (> 0 unless wo.z is NaN): all that same_hemisphere(wo, w) reads of it
+    int depth;
+    bool specular_path, flip_wi;
+    Rng rng;
+};
+enum : int { WALK_FAILED = 0, WALK_DONE = 1, WALK_CONTINUES = 2 };
+SHM_HD int layered_sample_begin(const BxDF& l, V3 wo, Float uc, V2 u, int mode, BSDFSample& out, LayeredWalk& k) {
+    bool flip_wi = false;
+    if (wo.z < 0.0f) { wo = -wo; flip_wi = true; }  // TWO_SIDED
+    const BaseBxDF top = layered_top(l);             // (entered_top is always true)
+    BSDFSample bs;
+    if (!base_sample_f(top, wo, uc, u, REFLTRANS_ALL, bs, mode)) return WALK_FAILED;
+    if (sample_unusable(bs)) return WALK_FAILED;
+    if (flags_is_reflective(bs.flags)) {
+        if (flip_wi) bs.wi = -bs.wi;
+        bs.pdf_is_proportional = true;
+        out = bs;
+        return WALK_DONE;
+    }
+    k.w = bs.wi;
+    k.specular_path = flags_is_specular(bs.flags);
+    k.rng = layered_rng(hash_f32(hash_f32(hash_f32(0x5eed0002ULL, uc), u.x), u.y), hash_v3(0ULL, wo));
+    k.f = bs.f * abs_cos_theta(bs.wi);
+    k.pdf = bs.pdf;
+    k.z = l.thickness;
+    k.wo_z = wo.z;
+    k.depth = 0;
+    k.flip_wi = flip_wi;
+    return WALK_CONTINUES;
+}
+SHM_HD int layered_sample_step(const BxDF& l, int mode, LayeredWalk& k, BSDFSample& out) {
+    if (!(k.depth < l.max_depth)) return WALK_FAILED;  // (the loop's condition; the function's last statement)
+    const int depth = k.depth++;
+    Float rr_beta = max_component_value(k.f) / k.pdf;
+    if (depth > 3 && rr_beta < 0.25f) {
+        Float q = max(0.0f, 1.0f - rr_beta);
+        if (layered_r(k.rng) < q) return WALK_FAILED;
+        k.pdf *= 1.0f - q;
+    }
+    if (k.w.z == 0.0f) return WALK_FAILED;
+    if (!is_zero(l.albedo)) {
+        const Float sigma_t = 1.0f;
+        Float dz = sample_exponential(layered_r(k.rng), sigma_t / abs_cos_theta(k.w));
+        Float zp = (k.w.z > 0.0f) ? (k.z + dz) : (k.z - dz);
+        if (zp == k.z) return WALK_FAILED;
+        if (0.0f < zp && zp < l.thickness) {
+            V2 up = layered_r2(k.rng);
+            Float ps_pdf;
+            V3 ps_wi = sample_henyey_greenstein(-k.w, l.g, up, ps_pdf);
+            if (ps_pdf == 0.0f || ps_wi.z == 0.0f) return WALK_FAILED;
+            k.f = k.f * (l.albedo * ps_pdf);
+            k.pdf *= ps_pdf;
+            k.specular_path = false;
+            k.w = ps_wi;
+            k.z = zp;
+            return WALK_CONTINUES;
+        }
+        k.z = clamp(zp, 0.0f, l.thickness);
+    } else {
+        k.z = (k.z == l.thickness) ? 0.0f : l.thickness;
+        k.f = k.f * layered_tr(l.thickness, k.w);
+    }
+    const BaseBxDF iface = (k.z == 0.0f) ? layered_bottom(l) : layered_top(l);
+    Float uc2 = layered_r(k.rng);
+    V2 u2 = layered_r2(k.rng);
+    BSDFSample s2;
+    if (!base_sample_f(iface, -k.w, uc2, u2, REFLTRANS_ALL, s2, mode)) return WALK_FAILED;
+    if (sample_unusable(s2)) return WALK_FAILED;
+    k.f = k.f * s2.f;
+    k.pdf *= s2.pdf;
+    k.specular_path = k.specular_path && flags_is_specular(s2.flags);
+    k.w = s2.wi;
+    if (flags_is_transmissive(s2.flags)) {
+        uint32_t flags = (k.wo_z * k.w.z > 0.0f) ? BXDF_REFLECTION : BXDF_TRANSMISSION;  // same_hemisphere(wo, w)
+        flags |= k.specular_path ? BXDF_SPECULAR : BXDF_GLOSSY;
+        V3 w = k.w;
+        if (k.flip_wi) w = -w;
+        out = bsdf_sample(k.f, w, k.pdf, flags, 1.0f);
+        out.pdf_is_proportional = true;
+        return WALK_DONE;
+    }
+    k.f = k.f * abs_cos_theta(s2.wi);
+    return WALK_CONTINUES;
 }
 
 // LayeredBxDF::pdf, bxdf.rs:1406-1575 (sample_flags must be ALL there: assert)

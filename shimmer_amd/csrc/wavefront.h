@@ -290,6 +290,7 @@ struct EventPool {
 // k_trace.hip: BvhAggregate::intersect (any = false) / intersect_predicate (any = true) over a queue of path slots
 WF_INTERNAL LdsTables wf_lds_tables(const ShmScene* s, uint32_t budget);  // render.hip: which small tables fit `budget` bytes of LDS
 WF_INTERNAL void wf_trace_census();  // k_trace.hip: prints the per-phase lane census of a -DK5_CENSUS development build (a no-op otherwise)
+WF_INTERNAL void wf_layered_census();  // k_scatter_layered_staged_tri.hip: the same for a -DLJ_CENSUS build of the staged LayeredBxDF kernel
 WF_INTERNAL int wf_trace_prepare(ShmScene* s);  // grid sizes + stack spill buffers of the two traversal kernels (at scene creation)
 WF_INTERNAL int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct,
                                 const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib);
@@ -316,6 +317,10 @@ WF_INTERNAL int wf_launch_scatter_dielectric(ShmScene* s, const ShadeArgs& a, bo
 WF_INTERNAL int wf_launch_scatter_layered_tri(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_scatter_layered_gen(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_scatter_layered_tex(ShmScene* s, const ShadeArgs& a);
+// the same class as dense per-wave stages (k_scatter_layered.inl): every render but options.force_diffuse; SHM_LAYERED_STAGED=0 for A/B
+WF_INTERNAL int wf_launch_scatter_layered_staged_tri(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_scatter_layered_staged_gen(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_scatter_layered_staged_tex(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_simple(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_randomwalk(ShmScene* s, const ShadeArgs& a, uint32_t cap_eff);
 WF_INTERNAL int wf_launch_fold_randomwalk(ShmScene* s, hipStream_t stream, uint32_t cap_eff, uint32_t total);

@@ -214,6 +214,36 @@ def test_opposite_hemisphere_shortcut_equals_the_full_walk(orc, name):
     assert n_opposite > 100
 
 
+@pytest.mark.parametrize("name", ["coated_diffuse", "coated_conductor"])
+def test_resumable_walk_equals_sample_f(orc, name):
+    """layered_sample_begin + layered_sample_step (shm/bxdf.h: what the staged layered kernel runs, one or two steps per pass with the walk's state going through a
+    job buffer in between) against the monolithic layered_sample_f (bxdf.rs:1220-1404), bit for bit: smooth and rough interfaces, with and without a medium,
+    both sides of the surface, walks of every length up to max_depth."""
+    kind = COATED_DIFFUSE if name == "coated_diffuse" else COATED_CONDUCTOR
+    rng = np.random.default_rng(5)
+    lengths, outcomes = set(), [0, 0]
+    for rough in (0.0, 0.25):
+        for albedo in (0.0, 0.7):
+            for max_depth in (10, 3, 0):
+                p = params(r=0.8, k=2.5, albedo=albedo, ax=rough, ax2=rough, thickness=0.05, g=0.4)
+                i = ip(max_depth, 1)
+                for _ in range(150):
+                    wo = unit(rng.uniform(0, math.pi), rng.uniform(0, 2 * math.pi))
+                    uc, u = rng.uniform(), rng.uniform(size=2)
+                    want = sample_f(orc, kind, p, i, wo, uc, u)
+                    for per_pass in (1, 2, 64):
+                        out, n = (C.c_float * 10)(), C.c_int(0)
+                        ok = orc.orc_fn_layered_sample_f_steps(kind, p, i, fa(*wo), float(uc), fa(*u), per_pass, out, C.byref(n))
+                        assert bool(ok) == (want is not None), (wo, uc, u)
+                        if ok:
+                            o = np.array(out[:], np.float32)
+                            assert o[:4].tobytes() == want["f"].tobytes() and o[4:7].tobytes() == want["wi"].tobytes()
+                            assert o[7].tobytes() == want["pdf"].tobytes() and int(o[8]) == want["flags"] and bool(o[9]) == want["proportional"]
+                    lengths.add(n.value)
+                    outcomes[1 if want is not None else 0] += 1
+    assert {0, 2, 4}.issubset(lengths) and max(lengths) >= 8 and min(outcomes) > 200, (lengths, outcomes)
+
+
 def test_coated_scene_renders_deterministically(lib):
     """The oracle's whole-path render of the coated Cornell box: finite, brighter than black, identical run to run and
     for any thread count (no entropy anywhere on the path)."""
