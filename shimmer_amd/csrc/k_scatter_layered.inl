@@ -429,6 +429,9 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
             }
         }
         LJ_TALLY(17, dep_nee);
+#ifdef LJ_CENSUS
+        { const unsigned long long _d = __ballot(dep_nee); if (lane == 0) { if (_d == 0ull) atomicAdd(&g_lj_census[18], 1ull); if (__popcll(_d) <= 8) atomicAdd(&g_lj_census[19], 1ull); } }
+#endif
         LJ_TICK1(0);
     }
     push_flush(push_next, q_next, lane);

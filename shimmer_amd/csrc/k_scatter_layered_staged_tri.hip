@@ -21,5 +21,6 @@ void wf_layered_census() {
                 (double)c[k * 3 + 2] / (double)c[k * 3], 100.0 * (double)c[k * 3 + 2] / ticks);
     fprintf(stderr, "[layered census] A: vertices %.3e -> walks %.3e, reflected at the top %.3e, NEE jobs %.3e | B: jobs in %.3e -> go on %.3e, left %.3e | N: queued %.3e\n", (double)c[1], (double)c[15],
             (double)c[16], (double)c[17], (double)c[4], (double)c[12], (double)c[13], (double)c[14]);
+    fprintf(stderr, "[layered census] A rounds without a single NEE job %.3e, with at most 8: %.3e (of %.3e)\n", (double)c[18], (double)c[19], (double)c[0]);
 #endif
 }
