@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                                                      DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in, uint32_t* __restrict__ q_emit,
                                                      LdsTables lds_tables, int first_bounce) {
     __shared__ uint4 s_tables[LDS_TABLE_BUDGET / 16];  // the small scene tables, staged once per workgroup (wavefront.h, stage_scene_tables)
-    const SceneView sv = stage_scene_tables(sv_global, lds_tables, s_tables);
+    __shared__ uint4 s_view[HAS_TEX ? SCENE_VIEW_UINT4S : 1];  // with textures: the view itself, for the texture evaluators that are real calls (shm/texture.h)
+    const SceneView sv = stage_scene_tables_tex<HAS_TEX>(sv_global, lds_tables, s_tables, s_view);
     const uint32_t n = n_in ? *n_in : qs->n_active[cur];  // (n_in: the lean diversion's queue, whose count is not n_active)
     __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
     __shared__ uint32_t s_emit[EMIT_INLINE ? 1 : SHADE_CHUNK];

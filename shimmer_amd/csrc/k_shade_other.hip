@@ -22,6 +22,8 @@ __device__ BSDF get_bsdf_general(const SceneView& sv, const PathArrays& pa, uint
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur,
                                                                            uint32_t* __restrict__ q_next, uint32_t* __restrict__ q_shadow,
                                                                            QueueState* qs, int cur, ShmRenderParams params, int shadow_parity) {
+    __shared__ uint4 s_view[SCENE_VIEW_UINT4S];  // the texture evaluators that are real calls read the scene through the workgroup's copy (shm/texture.h)
+    attach_call_copy(sv, s_view);
     const uint32_t n = qs->n_active[cur];
     const bool sample_lights = params.sample_lights != 0, sample_bsdf = params.sample_bsdf != 0;
     __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
@@ -186,6 +188,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(Scen
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_randomwalk(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur,
                                                                                uint32_t* __restrict__ q_next, QueueState* qs, int cur,
                                                                                ShmRenderParams params, float4* __restrict__ rw, uint32_t capacity) {
+    __shared__ uint4 s_view[SCENE_VIEW_UINT4S];  // the texture evaluators that are real calls read the scene through the workgroup's copy (shm/texture.h)
+    attach_call_copy(sv, s_view);
     const uint32_t n = qs->n_active[cur];
     __shared__ uint32_t s_next[SHADE_CHUNK];
     __shared__ uint32_t s_cnt, s_base;

@@ -215,7 +215,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_vertex(SceneView 
                                                                      uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, ShmRenderParams params, uint32_t* q_lean,
                                                                      LdsTables lds_tables) {
     __shared__ uint4 s_tables[LDS_TABLE_BUDGET / 16];  // the small scene tables, staged once per workgroup (wavefront.h, stage_scene_tables)
-    const SceneView sv = stage_scene_tables(sv_global, lds_tables, s_tables);
+    __shared__ uint4 s_view[HAS_TEX ? SCENE_VIEW_UINT4S : 1];  // ... and, with textures, the view itself: what the texture evaluators that are real calls read the scene through
+    const SceneView sv = stage_scene_tables_tex<HAS_TEX>(sv_global, lds_tables, s_tables, s_view);
     vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params, q_lean);
 }
 // three waves per SIMD (<= 168 VGPRs): the triangle-only instantiation needs 159 and is bound by the latency of its gathers
@@ -226,7 +227,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_
                                                                                                         LdsTables lds_tables) {
     // (three workgroups of this kernel share a CU's 160 KB with 41-51 KB each of sort bins and queues: 1.5 KB are left for tables — the material table of most scenes)
     __shared__ uint4 s_tables[LDS_TABLE_BUDGET_SMALL / 16];
-    const SceneView sv = stage_scene_tables(sv_global, lds_tables, s_tables);
+    __shared__ uint4 s_view[HAS_TEX ? SCENE_VIEW_UINT4S : 1];
+    const SceneView sv = stage_scene_tables_tex<HAS_TEX>(sv_global, lds_tables, s_tables, s_view);
     vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params, q_lean);
 }
 

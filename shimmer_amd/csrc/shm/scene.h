@@ -94,6 +94,9 @@ struct SceneView {
     const struct ImageLightRec* image_lights;
     const Float* dist_data;
     uint32_t quirks_off;  // ShmRenderParams::disable_reference_quirks of the render in flight (0 = reference-exact; set per render call)
+    // device only: the workgroup's copy of this object in LDS, which the texture evaluators that are real calls read the scene through (shm/texture.h,
+    // SHM_SV_FOR_CALL; set by stage_scene_tables_tex in the kernels that evaluate textures, never read on the host)
+    const SceneView* call_copy;
 };
 
 // A FloatTexture tree flattened at scene creation into a post-order program: evaluating the ops in order (each into slot k of a

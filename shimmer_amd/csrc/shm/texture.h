@@ -187,6 +187,35 @@ SHM_HD TextureEvalContext tex_ctx_from(const SurfaceInteraction& si, const Diffe
     c.dudx = df.dudx; c.dudy = df.dudy; c.dvdx = df.dvdx; c.dvdy = df.dvdy;
     return c;
 }
+// ---- the calling form of the four texture evaluators that are REAL calls on the device (SHM_HD_NOINLINE below) ----
+// A `const SceneView&` / `const TextureEvalContext&` / `const Wavelengths&` handed to a real call has to live in memory: the kernel's SceneView (≈ 90
+// registers' worth of pointers) became a per-lane stack object, every pointer of it — in the callees AND in the kernel's own inlined code, since an escaped
+// object is not promoted to registers at all — was read back from scratch in front of the gather it addresses, and the context (18 floats) and the wavelengths
+// (8) were stored and re-read around every call (round 4: 1 240 B of scratch per lane in k_vertex<textured> with no register spilled). The `_v` forms take
+// the scene as a POINTER TO THE WORKGROUP'S COPY IN LDS (SceneView::call_copy, set by stage_scene_tables_tex; the host passes the object's own address) and
+// the context and the wavelengths as scalars (clang passes scalars in registers however many there are; an aggregate beyond the 16th argument register
+// goes through the stack). Same statements, same values.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SHM_SV_FOR_CALL(sv) ((sv).call_copy)
+#else
+#define SHM_SV_FOR_CALL(sv) (&(sv))
+#endif
+#define SHM_TEXCTX_PARAMS Float c_px, Float c_py, Float c_pz, Float c_dpdx_x, Float c_dpdx_y, Float c_dpdx_z, Float c_dpdy_x, Float c_dpdy_y, Float c_dpdy_z, \
+                          Float c_nx, Float c_ny, Float c_nz, Float c_u, Float c_v, Float c_dudx, Float c_dudy, Float c_dvdx, Float c_dvdy
+#define SHM_TEXCTX_ARGS(c) (c).p.x, (c).p.y, (c).p.z, (c).dpdx.x, (c).dpdx.y, (c).dpdx.z, (c).dpdy.x, (c).dpdy.y, (c).dpdy.z, \
+                           (c).n.x, (c).n.y, (c).n.z, (c).uv.x, (c).uv.y, (c).dudx, (c).dudy, (c).dvdx, (c).dvdy
+#define SHM_TEXCTX_FROM_PARAMS(name)                                                                                                         \
+    TextureEvalContext name;                                                                                                                 \
+    name.p = v3(c_px, c_py, c_pz); name.dpdx = v3(c_dpdx_x, c_dpdx_y, c_dpdx_z); name.dpdy = v3(c_dpdy_x, c_dpdy_y, c_dpdy_z);               \
+    name.n = v3(c_nx, c_ny, c_nz); name.uv = v2(c_u, c_v); name.dudx = c_dudx; name.dudy = c_dudy; name.dvdx = c_dvdx; name.dvdy = c_dvdy
+#define SHM_LAMBDA_PARAMS Float l_0, Float l_1, Float l_2, Float l_3, Float l_p0, Float l_p1, Float l_p2, Float l_p3
+#define SHM_LAMBDA_ARGS(l) (l).lambda[0], (l).lambda[1], (l).lambda[2], (l).lambda[3], (l).pdf[0], (l).pdf[1], (l).pdf[2], (l).pdf[3]
+#define SHM_LAMBDA_FROM_PARAMS(name)                                                                     \
+    Wavelengths name;                                                                                    \
+    name.lambda[0] = l_0; name.lambda[1] = l_1; name.lambda[2] = l_2; name.lambda[3] = l_3;              \
+    name.pdf[0] = l_p0; name.pdf[1] = l_p1; name.pdf[2] = l_p2; name.pdf[3] = l_p3
+static_assert(NSPEC == 4, "the scalar calling form of the texture evaluators spells out four wavelengths");
+
 struct TexCoord2D {  // texture.rs:1048-1054
     V2 st;
     Float dsdx, dsdy, dtdx, dtdy;
@@ -464,16 +493,30 @@ SHM_HD TextureView texture_view(const SceneView& sv, uint32_t texture_index) {
     return tv;
 }
 // FloatImageTexture::evaluate, texture.rs:393-403
-SHM_HD_NOINLINE Float float_image_texture_evaluate(const SceneView& sv, uint32_t texture_index, const TextureEvalContext& ctx) {
+SHM_HD_NOINLINE Float float_image_texture_evaluate_v(const SceneView* svp, uint32_t texture_index, SHM_TEXCTX_PARAMS) {
+    const SceneView& sv = *svp;
+    SHM_TEXCTX_FROM_PARAMS(ctx);
     TextureView tv = texture_view(sv, texture_index);
     TexCoord2D c = texture_map(*tv.t, ctx, sv.quirks_off != 0);
     c.st.y = 1.0f - c.st.y;
     Float v = tex_filter<Float>(tv, sv.ewa_lut, c.st, v2(c.dsdx, c.dtdx), v2(c.dsdy, c.dtdy)) * tv.t->scale;
     return tv.t->invert ? max(0.0f, 1.0f - v) : v;
 }
+SHM_HD Float float_image_texture_evaluate(const SceneView& sv, uint32_t texture_index, const TextureEvalContext& ctx) {
+    return float_image_texture_evaluate_v(SHM_SV_FOR_CALL(sv), texture_index, SHM_TEXCTX_ARGS(ctx));
+}
 // FloatTexture::evaluate (texture.rs:142-152): the node's post-order program (scene.h FloatTexOp), children before parents
-SHM_HD_NOINLINE Float float_texture_evaluate(const SceneView& sv, uint32_t index, const TextureEvalContext& ctx) {
+SHM_HD_NOINLINE Float float_texture_evaluate_v(const SceneView* svp, uint32_t index, SHM_TEXCTX_PARAMS) {
+    const SceneView& sv = *svp;
+    SHM_TEXCTX_FROM_PARAMS(ctx);
     const FloatTexRange r = sv.ftex_ranges[index];
+    if (r.count == 1u) {
+        // a program of one op is a leaf (the combining kinds have children before them): evaluated without the value array, which — indexed at run time —
+        // lives in scratch memory on the device (a store and a dependent load around the one value)
+        const ShmFloatTexture& t = sv.float_textures[sv.ftex_ops[r.first].node];
+        if (t.kind == SHM_FLOATTEX_CONSTANT) return t.value;
+        if (t.kind == SHM_FLOATTEX_IMAGE) return float_image_texture_evaluate(sv, t.image, ctx);
+    }
     Float vals[FTEX_MAX_OPS];
     for (uint32_t k = 0; k < r.count; ++k) {
         const FloatTexOp op = sv.ftex_ops[r.first + k];
@@ -500,6 +543,9 @@ SHM_HD_NOINLINE Float float_texture_evaluate(const SceneView& sv, uint32_t index
         vals[k] = v;
     }
     return vals[r.count - 1];
+}
+SHM_HD Float float_texture_evaluate(const SceneView& sv, uint32_t index, const TextureEvalContext& ctx) {
+    return float_texture_evaluate_v(SHM_SV_FOR_CALL(sv), index, SHM_TEXCTX_ARGS(ctx));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -548,7 +594,10 @@ SHM_HD void rgb2spec_fetch(const SceneView& sv, RGB3 rgb_in, Float out[3]) {
 }
 
 // SpectrumImageTexture::evaluate, texture.rs:777-808
-SHM_HD_NOINLINE Spec image_texture_evaluate(const SceneView& sv, uint32_t texture_index, const TextureEvalContext& ctx, const Wavelengths& lambda) {
+SHM_HD_NOINLINE Spec image_texture_evaluate_v(const SceneView* svp, uint32_t texture_index, SHM_TEXCTX_PARAMS, SHM_LAMBDA_PARAMS) {
+    const SceneView& sv = *svp;
+    SHM_TEXCTX_FROM_PARAMS(ctx);
+    SHM_LAMBDA_FROM_PARAMS(lambda);
     TextureView tv;
     tv.t = &sv.image_textures[texture_index];
     tv.levels = sv.image_levels + tv.t->first_level;
@@ -577,6 +626,9 @@ SHM_HD_NOINLINE Spec image_texture_evaluate(const SceneView& sv, uint32_t textur
     for (int i = 0; i < NSPEC; ++i) s.v[i] = scale * rgb_sigmoid(coeff, lambda.lambda[i]);
     if (tv.t->spectrum_type == SHM_SPECTRUM_TYPE_UNBOUNDED) return s;
     return s * dense_table_sample(sv.cs_illuminant, lambda);  // spectrum.rs:600-606
+}
+SHM_HD Spec image_texture_evaluate(const SceneView& sv, uint32_t texture_index, const TextureEvalContext& ctx, const Wavelengths& lambda) {
+    return image_texture_evaluate_v(SHM_SV_FOR_CALL(sv), texture_index, SHM_TEXCTX_ARGS(ctx), SHM_LAMBDA_ARGS(lambda));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -715,8 +767,16 @@ SHM_HD void normal_map_texture(const SceneView& sv, uint32_t texture_index, cons
 
 // A composite SpectrumTexture tree (scale / mix / directionmix over spectrum and image leaves), texture.rs:573-581, 628-645,
 // 810-828, as a post-order program like the float ones
-SHM_HD_NOINLINE Spec spectrum_texture_node_evaluate(const SceneView& sv, uint32_t index, const TextureEvalContext& ctx, const Wavelengths& lambda) {
+SHM_HD_NOINLINE Spec spectrum_texture_node_evaluate_v(const SceneView* svp, uint32_t index, SHM_TEXCTX_PARAMS, SHM_LAMBDA_PARAMS) {
+    const SceneView& sv = *svp;
+    SHM_TEXCTX_FROM_PARAMS(ctx);
+    SHM_LAMBDA_FROM_PARAMS(lambda);
     const FloatTexRange r = sv.stex_ranges[index];
+    if (r.count == 1u) {  // a single leaf: no value array (float_texture_evaluate_v)
+        const ShmSpectrumTexture& t = sv.spectrum_textures[sv.stex_ops[r.first].node];
+        if (t.kind == SHM_SPECTEX_LEAF)
+            return (t.leaf.kind == SHM_SPECTRUM_IMAGE_TEXTURE) ? image_texture_evaluate(sv, t.leaf.offset, ctx, lambda) : spectrum_sample(t.leaf, sv.spectrum_data, lambda);
+    }
     Spec vals[STEX_MAX_OPS];
     for (uint32_t k = 0; k < r.count; ++k) {
         const FloatTexOp op = sv.stex_ops[r.first + k];
@@ -742,6 +802,9 @@ SHM_HD_NOINLINE Spec spectrum_texture_node_evaluate(const SceneView& sv, uint32_
         vals[k] = v;
     }
     return vals[r.count - 1];
+}
+SHM_HD Spec spectrum_texture_node_evaluate(const SceneView& sv, uint32_t index, const TextureEvalContext& ctx, const Wavelengths& lambda) {
+    return spectrum_texture_node_evaluate_v(SHM_SV_FOR_CALL(sv), index, SHM_TEXCTX_ARGS(ctx), SHM_LAMBDA_ARGS(lambda));
 }
 
 // SpectrumTexture::evaluate for a material slot: a constant spectrum texture samples its spectrum (texture.rs:509-513), an image

@@ -179,6 +179,22 @@ __device__ __forceinline__ SceneView stage_scene_tables(const SceneView& sv, con
     return out;
 }
 
+// ... and for the kernels that evaluate textures: the staged view itself copied to LDS once per workgroup, for the evaluators that are real calls (shm/texture.h)
+constexpr uint32_t SCENE_VIEW_UINT4S = (sizeof(SceneView) + 15) / 16;
+__device__ __forceinline__ void attach_call_copy(SceneView& sv, uint4* slot) {
+    SceneView* call_copy = reinterpret_cast<SceneView*>(slot);
+    sv.call_copy = call_copy;
+    if (threadIdx.x == 0) *call_copy = sv;
+    __syncthreads();
+}
+// (HAS_TEX = false: the plain staging; `slot` is a one-element dummy then)
+template <bool HAS_TEX>
+__device__ __forceinline__ SceneView stage_scene_tables_tex(const SceneView& sv, const LdsTables& t, uint4* lds, uint4* slot) {
+    SceneView out = stage_scene_tables(sv, t, lds);
+    if (HAS_TEX) attach_call_copy(out, slot);
+    return out;
+}
+
 __device__ __forceinline__ uint32_t wave_lane() { return __lane_id(); }
 
 // Wave-aggregated append: one atomic per wave, lanes get consecutive slots.
