@@ -188,12 +188,14 @@ def cpu_baseline(sc, params_full, host_lib, budget_s=15.0):
         _, st = orc.render(p, n_threads=cores, tiles=sub, n_tiles=len(idx))
         return len(idx), st["rays_closest"] + st["rays_any"], time.perf_counter() - t0
 
-    # probe: 1 and 5 spp on every 61st tile (61 is coprime with the tiles per row: no column aliasing) sizes the sample to ~budget_s
+    # probe: 16 and 64 spp on every 61st tile (61 is coprime with the tiles per row: no column aliasing) sizes the sample to ~budget_s. (Round 4: the probe
+    # used to be 1 and 5 spp — 0.03 s on 256 threads, all start-up cost: the difference was noise and the "sample" became the whole frame, 97 s.)
     run(61, 1)  # thread start-up, page faults
-    n_probe, _, t0 = run(61, 1)
-    _, rays1, t1 = run(61, 5)
+    n_probe, _, t0 = run(61, 16)
+    _, rays1, t1 = run(61, 64)
     full = params_full.samples_per_pixel
-    per_tile_spp = max((t1 - t0) / 4.0, 1e-5) / n_probe           # seconds per tile per spp (fixed per-call cost cancels)
+    # seconds per tile per spp: the difference (the fixed per-call cost cancels), but never less than 0.7 x the plain rate of the larger probe
+    per_tile_spp = max((t1 - t0) / 48.0, 0.7 * t1 / 64.0, 1e-5) / n_probe
     want_tiles = budget_s / (per_tile_spp * full)
     stride = int(max(1, min(n_tiles, round(n_tiles / max(want_tiles, 1.0)))))
     while stride > 1 and stride % 2 == 0 and ((orc.width + 7) // 8) % 2 == 0:
