@@ -137,7 +137,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
             jw[8 * LJ_CAP] = __float_as_uint(k.pdf);
             jw[9 * LJ_CAP] = __float_as_uint(k.z);
             jw[10 * LJ_CAP] = __float_as_uint(k.wo_z);
-            jw[11 * LJ_CAP] = (uint32_t)k.depth | ((uint32_t)k.specular_path << 8) | ((uint32_t)k.flip_wi << 9) | ((uint32_t)regularized << 10);
+            jw[11 * LJ_CAP] = (uint32_t)k.depth | ((uint32_t)k.specular_path << 12) | ((uint32_t)k.flip_wi << 13) | ((uint32_t)regularized << 14);  // (depth <= max_depth < 4096: 12 bits, as in bx2)
             jw[12 * LJ_CAP] = (uint32_t)k.rng.state; jw[13 * LJ_CAP] = (uint32_t)(k.rng.state >> 32);
             jw[14 * LJ_CAP] = (uint32_t)k.rng.inc; jw[15 * LJ_CAP] = (uint32_t)(k.rng.inc >> 32);
         }
@@ -251,10 +251,10 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                 k.z = __uint_as_float(jw[9 * LJ_CAP]);
                 k.wo_z = __uint_as_float(jw[10 * LJ_CAP]);
                 const uint32_t meta = jw[11 * LJ_CAP];
-                k.depth = (int)(meta & 0xffu);
-                k.specular_path = (meta >> 8) & 1u;
-                k.flip_wi = (meta >> 9) & 1u;
-                regularized = (meta >> 10) & 1u;
+                k.depth = (int)(meta & 0xfffu);
+                k.specular_path = (meta >> 12) & 1u;
+                k.flip_wi = (meta >> 13) & 1u;
+                regularized = (meta >> 14) & 1u;
                 k.rng.state = (uint64_t)jw[12 * LJ_CAP] | ((uint64_t)jw[13 * LJ_CAP] << 32);
                 k.rng.inc = (uint64_t)jw[14 * LJ_CAP] | ((uint64_t)jw[15 * LJ_CAP] << 32);
                 BxDF b;

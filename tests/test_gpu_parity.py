@@ -121,6 +121,37 @@ def _tiny_tree_scene(scenes, lib, n_tris):
     return scenes._finish(b, lib, name=f"{n_tris} triangle(s)")
 
 
+def _deep_walk_scene(scenes, lib):
+    """A coated floor whose coating is a thick, almost lossless scattering medium under an area light: LayeredBxDF walks of hundreds of steps (max_depth 1000)."""
+    from shimmer_amd.scene import SceneBuilder, blackbody_dense
+    b = SceneBuilder()
+    b.set_film(40, 40)
+    rfw = b.set_camera_look_at(lib, (0, 2.5, 4), (0, 0, 0), (0, 1, 0), 40.0)
+    floor = np.array([[-2, 0, -2], [2, 0, -2], [2, 0, 2], [-2, 0, 2]], np.float32)
+    lamp = np.array([[-0.7, 3, -0.7], [0.7, 3, -0.7], [0.7, 3, 0.7], [-0.7, 3, 0.7]], np.float32)
+    quad = np.array([[0, 2, 1], [0, 3, 2]], np.uint32)
+    m = b.material_coated_diffuse(reflectance=0.99, roughness=0.1, thickness=5.0, albedo=0.9999, g=0.2, max_depth=1000)
+    b.add_mesh(scenes._to_render(floor, rfw), quad, m)
+    b.add_mesh(scenes._to_render(lamp, rfw), quad[:, ::-1].copy(), b.material_diffuse(0.0), emission=blackbody_dense(6500.0), emission_scale=8.0)
+    return scenes._finish(b, lib, name="deep layered walks")
+
+
+def test_layered_walks_of_hundreds_of_steps(env):
+    """The staged LayeredBxDF kernel (k_scatter_layered.inl) carries a walk's depth through its job buffer; walks longer than 255 steps (a thick, almost lossless
+    medium, max_depth 1000: about one walk in 300 here) must come out as the oracle's one-piece layered_sample_f has them — film and counters bit for bit."""
+    lib, oracle_py, render, scenes = env
+    sc = _deep_walk_scene(scenes, lib)
+    p = render.make_params(seed=4, spp=8, max_depth=4)
+    gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+    fg, sg = gpu.render(p)
+    fo, so = orc.render(p)
+    gpu.close(); orc.close()
+    assert np.array_equal(fg.view(np.uint64), fo.view(np.uint64))
+    for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+        assert sg[k] == so[k], k
+    assert sg["rays_any"] > 1000  # (next-event estimation ran: the f and pdf walks too)
+
+
 @pytest.mark.parametrize("pair", ["1", "0"])
 def test_trace_both_step_kinds(env, monkeypatch, pair):
     """Triangle-only scenes are traced by the both-children step (k_trace5, the default) or by the one-node step (k_trace3, SHM_TRACE_PAIR=0, the
