@@ -737,7 +737,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     scatter_on(CLASS_DIELECTRIC, [&](const ShadeArgs& x) { return wf_launch_scatter_dielectric(s, x, tri_only, has_tex); });
                     scatter_on(CLASS_LAYERED, [&](const ShadeArgs& x) {
                         // (options.force_diffuse replaces the BxDF inside this half: the one-pass kernel has that code)
-                        if (params->force_diffuse == 0 && layered_staged)
+                        if (params->force_diffuse == 0 && layered_staged && s->capacity < (1u << 30))  // (its jobs carry two flag bits above the path index)
                             return has_tex ? wf_launch_scatter_layered_staged_tex(s, x) : (tri_only ? wf_launch_scatter_layered_staged_tri(s, x) : wf_launch_scatter_layered_staged_gen(s, x));
                         return has_tex ? wf_launch_scatter_layered_tex(s, x) : (tri_only ? wf_launch_scatter_layered_tri(s, x) : wf_launch_scatter_layered_gen(s, x)); });
                     for (hipEvent_t e : side_done) hipStreamWaitEvent(s->stream, e, 0);
