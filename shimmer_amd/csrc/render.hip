@@ -232,6 +232,7 @@ LdsTables wf_lds_tables(const ShmScene* s, uint32_t budget) {
     auto pad16 = [](size_t b) { return (size_t)((b + 15u) & ~(size_t)15u); };  // (dev_upload allocates whole 16-byte groups)
     const size_t want[N_LDS_TABLES] = {
         pad16(f.mesh_flags.size() * sizeof(uint32_t)), pad16(f.lights.size() * sizeof(ShmLight)), pad16(f.materials.size() * sizeof(ShmMaterial)), pad16(f.spectrum_data.size() * sizeof(float)),
+        pad16(f.rgb2spec_scale.size() * sizeof(float)),
         pad16(f.image_textures.size() * sizeof(ShmImageTexture)), pad16(f.image_levels.size() * sizeof(ShmImageLevel)), pad16(f.float_textures.size() * sizeof(ShmFloatTexture)),
         pad16(f.ftex_ranges.size() * sizeof(shm::FloatTexRange)), pad16(f.ftex_ops.size() * sizeof(shm::FloatTexOp)), pad16(f.spectrum_textures.size() * sizeof(ShmSpectrumTexture)),
         pad16(f.stex_ranges.size() * sizeof(shm::FloatTexRange)), pad16(f.stex_ops.size() * sizeof(shm::FloatTexOp)), pad16(f.ewa_lut.size() * sizeof(float))};
