@@ -163,22 +163,22 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
             // builds its interaction in object space and maps it back (sphere.rs:254-270, primitive.rs:165-170), so it is carried
             V3 si_wo = wo;
             if (!TRI_ONLY) { const float4 w4 = pa.siwo[path]; si_wo = v3(w4.x, w4.y, w4.z); }
-            Spec beta = ld_spec(pa.beta[path]);
+            Spec beta = ld_spec(pa.rec[path].beta);
             Wavelengths lambda;
             {
-                const float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                const float4 a = pa.rec[path].lambda, b = pa.lambda_pdf[path];
                 lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
                 lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
             }
-            const uint32_t fl = pa.flags[path];
+            const uint32_t fl = pa.rec[path].flags;
             int depth = (int)(fl & 0xffu);
             bool specular_bounce = (fl >> 8) & 1u;
             bool any_non_specular_bounces = (fl >> 9) & 1u;
-            Float p_b, eta_scale = pa.pb_eta[path].y;
+            Float p_b, eta_scale = pa.rec[path].pb_eta.y;
             Rng rng;
             {
-                const uint32_t pix = pa.pixel[path];
-                const uint2 rs = pa.rng[path];
+                const uint32_t pix = pa.rec[path].pixel;
+                const uint2 rs = pa.rec[path].rng;
                 rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
                 // inc is a pure function of (pixel, seed): re-derived instead of stored
                 uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
@@ -299,10 +299,10 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                     nr.t_max = infinity();
                     nr.pad = 0.0f;
                     pa.ray[path] = nr;
-                    pa.beta[path] = st_spec(beta);
-                    pa.pb_eta[path] = make_float2(p_b, eta_scale);
+                    pa.rec[path].beta = st_spec(beta);
+                    pa.rec[path].pb_eta = make_float2(p_b, eta_scale);
                     // (ctx0..2 already hold this vertex's context: the next vertex's prev_intr_ctx)
-                    pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                    pa.rec[path].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
                     uint32_t aux_bit = 0u;
                     if (HAS_TEX && CLASS != CLASS_DIFFUSE && (fl & (1u << 10)) &&
                         (bs.flags == BXDF_SPECULAR_REFLECTION || bs.flags == BXDF_SPECULAR_TRANSMISSION)) {
@@ -312,7 +312,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                                                                  v3(d2.y, d2.z, d2.w), ld_aux(pa, path), bs.wi, bs.flags, bs.eta);
                         if (na.has) { st_aux(pa, path, na); aux_bit = 1u << 10; }
                     }
-                    pa.flags[path] = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9) | aux_bit;
+                    pa.rec[path].flags = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9) | aux_bit;
                     push_next = true;
                 }
             }

@@ -92,8 +92,8 @@ __device__ __forceinline__ void layered_bsdf_of(const SceneView& sv, const PathA
 }
 __device__ __forceinline__ Rng path_sampler(const PathArrays& pa, uint32_t path, const ShmRenderParams& params) {
     Rng rng;
-    const uint32_t pix = pa.pixel[path];
-    const uint2 rs = pa.rng[path];
+    const uint32_t pix = pa.rec[path].pixel;
+    const uint2 rs = pa.rec[path].rng;
     rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
     // inc is a pure function of (pixel, seed): re-derived instead of stored
     uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
@@ -178,12 +178,12 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                 const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
                 const float4 r0 = rp[0], r1 = rp[1];
                 const V3 wo = -v3(r0.w, r1.x, r1.y);  // li()'s wo = -ray.d (integrator.rs:844)
-                Spec beta = ld_spec(pa.beta[path]);
-                const uint32_t fl = pa.flags[path];
+                Spec beta = ld_spec(pa.rec[path].beta);
+                const uint32_t fl = pa.rec[path].flags;
                 const int depth = (int)(fl & 0xffu) + 1;
                 bool any_non_specular_bounces = (fl >> 9) & 1u;
                 if (params.regularize && any_non_specular_bounces) bxdf_regularize(bsdf.bxdf);
-                Float eta_scale = pa.pb_eta[path].y;
+                Float eta_scale = pa.rec[path].pb_eta.y;
                 Rng rng = path_sampler(pa, path, params);  // (stage A left the state behind this vertex's seven dimensions)
                 bs.wi = bsdf.shading_frame.from_local(bs.wi);  // bsdf.rs:80
                 // integrator.rs:859-872
@@ -220,11 +220,11 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                         if (na.has) { st_aux(pa, path, na); aux_bit = 1u << 10; }
                     }
                     pa.ray[path] = nr;
-                    pa.beta[path] = st_spec(beta);
-                    pa.pb_eta[path] = make_float2(p_b, eta_scale);
+                    pa.rec[path].beta = st_spec(beta);
+                    pa.rec[path].pb_eta = make_float2(p_b, eta_scale);
                     // (ctx0..2 already hold this vertex's context: the next vertex's prev_intr_ctx)
-                    pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
-                    pa.flags[path] = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9) | aux_bit;
+                    pa.rec[path].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                    pa.rec[path].flags = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9) | aux_bit;
                 }
             }
             push_begin(push_next, &qs->n_active[cur ^ 1], alive, path, lane);
@@ -344,7 +344,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                 // intr.wo, what sample_ld and get_bsdf use: bitwise -ray.d for a top-level triangle; a quadric or an instanced primitive carries its own (k_scatter.inl)
                 si_wo = wo;
                 if (!TRI_ONLY) { const float4 w4 = pa.siwo[path]; si_wo = v3(w4.x, w4.y, w4.z); }
-                regularized = params.regularize && ((pa.flags[path] >> 9) & 1u);
+                regularized = params.regularize && ((pa.rec[path].flags >> 9) & 1u);
                 Rng rng = path_sampler(pa, path, params);
                 if (regularized) bxdf_regularize(bsdf.bxdf);
                 bf = bsdf_flags(bsdf);
@@ -357,7 +357,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                 // integrator.rs:843-857: sample the BSDF — here BSDF::sample_f's entry (bsdf.rs:60-74) and the top interface's sample
                 const Float u = sampler_get_1d(rng);
                 const V2 u2 = sampler_get_2d(rng);
-                pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));  // stage C draws Russian roulette from here
+                pa.rec[path].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));  // stage C draws Russian roulette from here
                 const V3 wo_l = bsdf.shading_frame.to_local(wo);
                 if (!(wo_l.z == 0.0f || !((bf & REFLTRANS_ALL) != 0u))) status = layered_sample_begin(bsdf.bxdf, wo_l, u, u2, MODE_RADIANCE, bs, k);
             }
@@ -380,7 +380,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
             const V3 si_n = v3(c1.z, c1.w, c2.x), ns = v3(c2.y, c2.z, c2.w);
             Wavelengths lambda;
             {
-                const float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                const float4 a = pa.rec[path].lambda, b = pa.lambda_pdf[path];
                 lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
                 lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
             }
@@ -424,7 +424,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                 jw[4 * LJ_CAP] = __float_as_uint(j_wi.x); jw[5 * LJ_CAP] = __float_as_uint(j_wi.y); jw[6 * LJ_CAP] = __float_as_uint(j_wi.z);
                 jw[7 * LJ_CAP] = __float_as_uint(j_pl);
                 // the throughput before this vertex's update (stage C has not run for this path): what weighs the light's contribution
-                const float4 b4 = pa.beta[path];
+                const float4 b4 = pa.rec[path].beta;
                 jw[8 * LJ_CAP] = __float_as_uint(b4.x); jw[9 * LJ_CAP] = __float_as_uint(b4.y); jw[10 * LJ_CAP] = __float_as_uint(b4.z); jw[11 * LJ_CAP] = __float_as_uint(b4.w);
             }
         }

@@ -69,18 +69,18 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
             // L is only touched by a vertex that adds emission (most do not): loaded and stored inside add_l
             auto add_l = [&](const Spec& c) { pa.L[path] = st_spec(ld_spec(pa.L[path]) + c); };
             // (beta is read where it is used — emission, the NEE contribution, the throughput update — instead of being held across the vertex)
-            auto load_beta = [&]() { return first_bounce ? spec_const(1.0f) : ld_spec(pa.beta[path]); };
-            auto load_pb_eta = [&]() { return first_bounce ? make_float2(1.0f, 1.0f) : pa.pb_eta[path]; };
+            auto load_beta = [&]() { return first_bounce ? spec_const(1.0f) : ld_spec(pa.rec[path].beta); };
+            auto load_pb_eta = [&]() { return first_bounce ? make_float2(1.0f, 1.0f) : pa.rec[path].pb_eta; };
             Spec beta;
             Wavelengths lambda;
             float4 pdf_in;
             {
-                float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                float4 a = pa.rec[path].lambda, b = pa.lambda_pdf[path];
                 pdf_in = b;
                 lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
                 lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
             }
-            uint32_t fl = first_bounce ? 0u : pa.flags[path];
+            uint32_t fl = first_bounce ? 0u : pa.rec[path].flags;
             int depth = (int)(fl & 0xffu);
             bool specular_bounce = (fl >> 8) & 1u;
             bool any_non_specular_bounces = (fl >> 9) & 1u;
@@ -152,8 +152,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                 if (DIFFUSE_ONLY) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIFFUSE);
                 Rng rng;
                 auto load_rng = [&]() {
-                    uint32_t pix = pa.pixel[path];
-                    uint2 rs = pa.rng[path];
+                    uint32_t pix = pa.rec[path].pixel;
+                    uint2 rs = pa.rec[path].rng;
                     rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
                     // inc is a pure function of (pixel, seed): re-derive instead of storing 8 more bytes per path
                     uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
@@ -258,18 +258,18 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                             nr.t_max = infinity();
                             nr.pad = 0.0f;
                             pa.ray[path] = nr;
-                            pa.beta[path] = st_spec(beta);
-                            pa.pb_eta[path] = make_float2(p_b, eta_scale);
+                            pa.rec[path].beta = st_spec(beta);
+                            pa.rec[path].pb_eta = make_float2(p_b, eta_scale);
                             pa.ctx0[path] = make_float4(nctx.pi.x.low, nctx.pi.y.low, nctx.pi.z.low, nctx.pi.x.high);
                             pa.ctx1[path] = make_float4(nctx.pi.y.high, nctx.pi.z.high, nctx.n.x, nctx.n.y);
                             pa.ctx2[path] = make_float4(nctx.n.z, nctx.ns.x, nctx.ns.y, nctx.ns.z);
-                            pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                            pa.rec[path].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
                             uint32_t aux_bit = 0u;
                             if (HAS_TEX) {  // spawn_ray_with_differentials, interaction.rs:430-514
                                 AuxRays na = spawn_ray_differentials(si, df, aux, bs.wi, bs.flags, bs.eta);
                                 if (na.has) { st_aux(pa, path, na); aux_bit = 1u << 10; }
                             }
-                            pa.flags[path] = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9) | aux_bit;
+                            pa.rec[path].flags = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9) | aux_bit;
                             push_next = true;
                         }
                     }
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathAr
         const V3 ray_d = v3(er.x, er.y, er.z);
         Wavelengths lambda;
         {
-            const float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+            const float4 a = pa.rec[path].lambda, b = pa.lambda_pdf[path];
             lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
             lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
         }

@@ -45,16 +45,16 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(Scen
             float4 r0 = rp[0], r1 = rp[1];
             V3 ray_d = v3(r0.w, r1.x, r1.y);
             auto add_l = [&](const Spec& c) { pa.L[path] = st_spec(ld_spec(pa.L[path]) + c); };
-            Spec beta = ld_spec(pa.beta[path]);
+            Spec beta = ld_spec(pa.rec[path].beta);
             Wavelengths lambda;
             float4 pdf_in;
             {
-                float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                float4 a = pa.rec[path].lambda, b = pa.lambda_pdf[path];
                 pdf_in = b;
                 lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
                 lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
             }
-            uint32_t fl = pa.flags[path];
+            uint32_t fl = pa.rec[path].flags;
             int depth = (int)(fl & 0xffu);
             // k_generate leaves flags = 0: the reference starts with specular_bounce = true (integrator.rs:601), so bit 8 holds its
             // negation here ("the last bounce was NOT specular")
@@ -76,8 +76,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(Scen
                     depth += 1;
                     BSDF bsdf = get_bsdf_general(sv, pa, path, fl, si, sv.materials[prim.material], lambda, params);
                     V3 wo = -ray_d;
-                    uint32_t pix = pa.pixel[path];
-                    uint2 rs = pa.rng[path];
+                    uint32_t pix = pa.rec[path].pixel;
+                    uint2 rs = pa.rec[path].rng;
                     Rng rng;
                     rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
                     {
@@ -152,9 +152,9 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_simple(Scen
                         nr.t_max = infinity();
                         nr.pad = 0.0f;
                         pa.ray[path] = nr;
-                        pa.beta[path] = st_spec(beta);
-                        pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
-                        pa.flags[path] = (uint32_t)depth | ((specular_bounce ? 0u : 1u) << 8);
+                        pa.rec[path].beta = st_spec(beta);
+                        pa.rec[path].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                        pa.rec[path].flags = (uint32_t)depth | ((specular_bounce ? 0u : 1u) << 8);
                         push_next = true;
                     }
                     if (lambda.pdf[1] != pdf_in.y || lambda.pdf[2] != pdf_in.z || lambda.pdf[3] != pdf_in.w || lambda.pdf[0] != pdf_in.x)
@@ -212,12 +212,12 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_randomwalk(
             Wavelengths lambda;
             float4 pdf_in;
             {
-                float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                float4 a = pa.rec[path].lambda, b = pa.lambda_pdf[path];
                 pdf_in = b;
                 lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
                 lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
             }
-            const uint32_t fl = pa.flags[path];
+            const uint32_t fl = pa.rec[path].flags;
             const int depth = (int)(fl & 0xffu);
             float4* rec = rw + (size_t)(2 * depth) * capacity + path;  // le at 2*depth, f cos at 2*depth + 1
             Spec le = spec_const(0.0f);
@@ -235,8 +235,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_randomwalk(
                 rec[0] = st_spec(le);
                 if (depth != params.max_depth) {
                     BSDF bsdf = get_bsdf_general(sv, pa, path, fl, si, sv.materials[prim.material], lambda, params);
-                    uint32_t pix = pa.pixel[path];
-                    uint2 rs = pa.rng[path];
+                    uint32_t pix = pa.rec[path].pixel;
+                    uint2 rs = pa.rec[path].rng;
                     Rng rng;
                     rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
                     {
@@ -260,8 +260,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_randomwalk(
                         nr.t_max = infinity();
                         nr.pad = 0.0f;
                         pa.ray[path] = nr;
-                        pa.rng[path] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
-                        pa.flags[path] = (uint32_t)(depth + 1);
+                        pa.rec[path].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                        pa.rec[path].flags = (uint32_t)(depth + 1);
                         push_next = true;
                     }
                     if (lambda.pdf[1] != pdf_in.y || lambda.pdf[2] != pdf_in.z || lambda.pdf[3] != pdf_in.w || lambda.pdf[0] != pdf_in.x)
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_shade_randomwalk(
 __global__ void __launch_bounds__(SHADE_BLOCK) k_fold_randomwalk(PathArrays pa, const float4* __restrict__ rw, uint32_t capacity, uint32_t total) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= total) return;
-    int t = (int)(pa.flags[slot] & 0xffu);
+    int t = (int)(pa.rec[slot].flags & 0xffu);
     Spec l = ld_spec(rw[(size_t)(2 * t) * capacity + slot]);
     for (int k = t - 1; k >= 0; --k) {
         Spec le = ld_spec(rw[(size_t)(2 * k) * capacity + slot]);

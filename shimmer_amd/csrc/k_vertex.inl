@@ -100,12 +100,12 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
             Wavelengths lambda;
             float4 pdf_in;
             {
-                float4 a = pa.lambda[path], b = pa.lambda_pdf[path];
+                float4 a = pa.rec[path].lambda, b = pa.lambda_pdf[path];
                 pdf_in = b;
                 lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
                 lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
             }
-            const uint32_t fl = pa.flags[path];
+            const uint32_t fl = pa.rec[path].flags;
             const int depth = (int)(fl & 0xffu);
             const bool specular_bounce = (fl >> 8) & 1u;
             // beta, p_b and the previous vertex's context are only needed when something is emitted towards the path
@@ -120,11 +120,11 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
                 return c;
             };
             auto emit = [&](const Spec& le, const ShmLight& light) {  // integrator.rs:779-792 / 802-812
-                Spec beta = ld_spec(pa.beta[path]);
+                Spec beta = ld_spec(pa.rec[path].beta);
                 if (depth == 0 || specular_bounce) {
                     add_l(beta * le);
                 } else {
-                    Float p_b = pa.pb_eta[path].x;
+                    Float p_b = pa.rec[path].pb_eta.x;
                     Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
                     Float w = power_heuristic(1, p_b, 1, p_l);
                     add_l(beta * w * le);

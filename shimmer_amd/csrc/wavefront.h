@@ -70,23 +70,33 @@ struct QueueState {
     uint32_t n_emit;        // the fused kernel's deferred emitter hits (q_emit), worked off by k_emit_jobs after it
 };
 
-// Path state, structure of arrays (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
+// The part of a path's state that EVERY vertex reads (and rewrites), as one 64-byte record. As six separate arrays (rounds 1-4) a vertex touched six cache lines for
+// these 56 bytes — harmless while every path of a line is alive, but paths die (Russian roulette, escapes) and the survivors stay where they are: at bounce 4 of the
+// headline frame one path in ten is left, a 128-byte line serves one of them, and the fused kernel fetched 666 bytes per vertex against 108 at bounce 0
+// (rocprofv3 FETCH_SIZE per dispatch). One record: one half line per vertex whatever the survival.
+struct alignas(64) PathRec {
+    float4 beta;
+    float4 lambda;     // (the film reads its own copy, PathArrays::lambda)
+    float2 pb_eta;     // p_b, eta_scale
+    uint2 rng;         // PCG32 state (inc is re-derived from pixel + seed)
+    uint32_t pixel;    // x | y << 16 (absolute pixel coordinates, < 65536)
+    uint32_t flags;    // depth | specular_bounce << 8 | any_non_specular << 9 | ray has auxiliary rays << 10
+    uint32_t pad[2];
+};
+static_assert(sizeof(PathRec) == 64, "PathRec is one half cache line");
+// Path state (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
 struct PathArrays {
     ShmRay* ray;            // 32 B: o, d, t_max — input of K2
     ShmHit* hit;            // 32 B: output of K2
     ShmRay* shadow_ray;     // 32 B: input of K3
     float4* shadow_contrib; // beta * Ld, added to L by K3 when unoccluded
     float4* L;
-    float4* beta;
-    float4* lambda;
+    PathRec* rec;           // 64 B: beta, lambda, p_b / eta_scale, sampler state, pixel, flags — what every vertex reads of its path, in ONE half line (below)
+    float4* lambda;         // the film's copy of the wavelengths (written once by k_generate; the shading kernels read PathRec::lambda)
     float4* lambda_pdf;
     float4* ctx0;           // prev_intr_ctx: pi.low.xyz, pi.high.x
     float4* ctx1;           //                pi.high.yz, n.xy
     float4* ctx2;           //                n.z, ns.xyz
-    float2* pb_eta;         // p_b, eta_scale
-    uint2* rng;             // PCG32 state (inc is re-derived from pixel+seed)
-    uint32_t* pixel;        // x | y << 16 (absolute pixel coordinates, < 65536)
-    uint32_t* flags;        // depth | specular_bounce << 8 | any_non_specular << 9 | ray has auxiliary rays << 10
     // scenes with image textures only (null otherwise): the ray's AuxiliaryRays (ray.rs:104-135)
     float4* aux0;           // rx_origin.xyz, rx_direction.x
     float4* aux1;           // rx_direction.yz, ry_origin.xy
