@@ -94,10 +94,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
     if (!LEAN) pa.rec[slot].pb_eta = make_float2(1.0f, 1.0f);
     pa.rec[slot].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
     pa.rec[slot].pixel = pix;
-    if (!LEAN) {
-        pa.rec[slot].flags = has_tex ? (1u << 10) : 0u;  // camera rays always carry auxiliary rays (camera.rs:1070-1078)
-        q_active[slot] = slot;  // first bounce: identity queue
-    }
+    pa.rec[slot].flags = has_tex ? (1u << 10) : 0u;  // camera rays always carry auxiliary rays (camera.rs:1070-1078); (LEAN: not read at bounce 0, but it completes the record's first sector)
+    if (!LEAN) q_active[slot] = slot;  // first bounce: identity queue
     if (slot == 0) {
         qs->n_active[0] = total;
         qs->n_active[1] = 0;

@@ -75,12 +75,14 @@ struct QueueState {
 // headline frame one path in ten is left, a 128-byte line serves one of them, and the fused kernel fetched 666 bytes per vertex against 108 at bounce 0
 // (rocprofv3 FETCH_SIZE per dispatch). One record: one half line per vertex whatever the survival.
 struct alignas(64) PathRec {
-    float4 beta;
+    // first 32-byte sector: what k_generate writes (all of it, so that a new path costs one full sector, not two partial ones) and bounce 0 reads
     float4 lambda;     // (the film reads its own copy, PathArrays::lambda)
-    float2 pb_eta;     // p_b, eta_scale
     uint2 rng;         // PCG32 state (inc is re-derived from pixel + seed)
     uint32_t pixel;    // x | y << 16 (absolute pixel coordinates, < 65536)
     uint32_t flags;    // depth | specular_bounce << 8 | any_non_specular << 9 | ray has auxiliary rays << 10
+    // second sector: written by the first vertex (a new path's constants — beta = 1, p_b = eta_scale = 1 — are not stored where the consumer knows them: k_generate<LEAN>)
+    float4 beta;
+    float2 pb_eta;     // p_b, eta_scale
     uint32_t pad[2];
 };
 static_assert(sizeof(PathRec) == 64, "PathRec is one half cache line");
