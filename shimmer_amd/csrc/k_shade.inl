@@ -73,9 +73,13 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
             auto load_pb_eta = [&]() { return first_bounce ? make_float2(1.0f, 1.0f) : pa.rec[path].pb_eta; };
             Spec beta;
             Wavelengths lambda;
-            float4 pdf_in;
+            float4 pdf_in, lambda4_in;
+            uint32_t pix_in = 0u;
             {
-                float4 a = pa.rec[path].lambda, b = pa.lambda_pdf[path];
+                // (bounce 0 on known constants: k_generate<LEAN> leaves no record — the wavelengths are in the film's array, sampler state and pixel in rng0 / pixel0 —
+                //  and this vertex writes the path's first one, whole)
+                float4 a = first_bounce ? pa.lambda[path] : pa.rec[path].lambda, b = pa.lambda_pdf[path];
+                lambda4_in = a;
                 pdf_in = b;
                 lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
                 lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
@@ -152,8 +156,9 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                 if (DIFFUSE_ONLY) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIFFUSE);
                 Rng rng;
                 auto load_rng = [&]() {
-                    uint32_t pix = pa.rec[path].pixel;
-                    uint2 rs = pa.rec[path].rng;
+                    uint32_t pix = first_bounce ? pa.pixel0[path] : pa.rec[path].pixel;
+                    uint2 rs = first_bounce ? pa.rng0[path] : pa.rec[path].rng;
+                    pix_in = pix;
                     rng.state = (uint64_t)rs.x | ((uint64_t)rs.y << 32);
                     // inc is a pure function of (pixel, seed): re-derive instead of storing 8 more bytes per path
                     uint64_t h = mix_bits(((uint64_t)(pix & 0xffffu) << 32) | (uint64_t)(pix >> 16));
@@ -264,6 +269,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                             pa.ctx1[path] = make_float4(nctx.pi.y.high, nctx.pi.z.high, nctx.n.x, nctx.n.y);
                             pa.ctx2[path] = make_float4(nctx.n.z, nctx.ns.x, nctx.ns.y, nctx.ns.z);
                             pa.rec[path].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                            if (first_bounce) { pa.rec[path].lambda = lambda4_in; pa.rec[path].pixel = pix_in; }  // the record's first sector, complete
                             uint32_t aux_bit = 0u;
                             if (HAS_TEX) {  // spawn_ray_with_differentials, interaction.rs:430-514
                                 AuxRays na = spawn_ray_differentials(si, df, aux, bs.wi, bs.flags, bs.eta);
@@ -327,7 +333,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathAr
         const V3 ray_d = v3(er.x, er.y, er.z);
         Wavelengths lambda;
         {
-            const float4 a = pa.rec[path].lambda, b = pa.lambda_pdf[path];
+            const float4 a = pa.lambda[path], b = pa.lambda_pdf[path];  // (the film's copy: valid from k_generate on, also for a bounce-0 hit whose record does not exist yet)
             lambda.lambda[0] = a.x; lambda.lambda[1] = a.y; lambda.lambda[2] = a.z; lambda.lambda[3] = a.w;
             lambda.pdf[0] = b.x; lambda.pdf[1] = b.y; lambda.pdf[2] = b.z; lambda.pdf[3] = b.w;
         }

@@ -85,16 +85,26 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
     pa.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     // LEAN (the fused kernel shades bounce 0 and knows it is bounce 0): the constants — beta = 1, p_b = eta_scale = 1, flags = 0, the identity queue — are not
     // written here nor read there (ShadeArgs::first_bounce): 32 of 124 bytes per path
-    if (!LEAN) pa.rec[slot].beta = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     const float4 lambda4 = make_float4(lambda.lambda[0], lambda.lambda[1], lambda.lambda[2], lambda.lambda[3]);
-    pa.rec[slot].lambda = lambda4;
     pa.lambda[slot] = lambda4;  // (the film's copy: k_film reads wavelengths and pdfs of every sample, and a 64-byte record for 16 of its bytes would triple that)
     pa.lambda_pdf[slot] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
     // (ctx0..2, the previous vertex's LightSampleContext, are first read at depth >= 1, after k_shade has written them)
-    if (!LEAN) pa.rec[slot].pb_eta = make_float2(1.0f, 1.0f);
-    pa.rec[slot].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
-    pa.rec[slot].pixel = pix;
-    pa.rec[slot].flags = has_tex ? (1u << 10) : 0u;  // camera rays always carry auxiliary rays (camera.rs:1070-1078); (LEAN: not read at bounce 0, but it completes the record's first sector)
+    if (LEAN) {
+        // no record: the fused kernel's bounce 0 reads these three arrays and writes the path's first record whole (one full 64-byte store instead of this kernel's
+        // partial sectors: k_generate 10.5 -> 6 ms per headline frame)
+        pa.rng0[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+        pa.pixel0[slot] = pix;
+    } else {
+        PathRec r;
+        r.lambda = lambda4;
+        r.rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+        r.pixel = pix;
+        r.flags = has_tex ? (1u << 10) : 0u;  // camera rays always carry auxiliary rays (camera.rs:1070-1078)
+        r.beta = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        r.pb_eta = make_float2(1.0f, 1.0f);
+        r.pad[0] = 0u; r.pad[1] = 0u;
+        pa.rec[slot] = r;
+    }
     if (!LEAN) q_active[slot] = slot;  // first bounce: identity queue
     if (slot == 0) {
         qs->n_active[0] = total;
@@ -211,7 +221,7 @@ static uint64_t workspace_cap(const ShmScene* s, bool need_staged) {
     // path state + three queues (+ auxiliary rays) (+ the staging arrays whenever the upcoming render is staged: every scene class but the
     // lean one, and the lean one too under options.force_diffuse — the budget must count them BEFORE the first staged allocation)
     // (ray 32, hit 32, shadow_ray 32, shadow_contrib 16, L 16, the PathRec 64, lambda 16, lambda_pdf 16, ctx0..2 48 = 272)
-    const uint64_t BYTES_PER_PATH = 272 + 3 * 4 + (s->flat.has_textures ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
+    const uint64_t BYTES_PER_PATH = 272 + (scene_is_lean(s) ? 12 : 0) + 3 * 4 + (s->flat.has_textures ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
     uint64_t cap = max_batch_paths();
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -274,6 +284,8 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
 #define WS(field, type) if ((rc = ws_alloc((size_t)cap * sizeof(type), (void**)&s->pa.field)) != SHM_OK) return rc
     WS(ray, ShmRay); WS(hit, ShmHit); WS(shadow_ray, ShmRay); WS(shadow_contrib, float4); WS(L, float4); WS(rec, PathRec);
     WS(lambda, float4); WS(lambda_pdf, float4); WS(ctx0, float4); WS(ctx1, float4); WS(ctx2, float4);
+    s->pa.rng0 = nullptr; s->pa.pixel0 = nullptr;
+    if (scene_is_lean(s)) { WS(rng0, uint2); WS(pixel0, uint32_t); }
     s->pa.e_ray = s->pa.e_beta = s->pa.e_ctx0 = s->pa.e_ctx1 = s->pa.e_ctx2 = nullptr;
     s->pa.e_flags = nullptr;
     s->d_q_emit = nullptr;

@@ -95,6 +95,8 @@ struct PathArrays {
     float4* L;
     PathRec* rec;           // 64 B: beta, lambda, p_b / eta_scale, sampler state, pixel, flags — what every vertex reads of its path, in ONE half line (below)
     float4* lambda;         // the film's copy of the wavelengths (written once by k_generate; the shading kernels read PathRec::lambda)
+    uint2* rng0;            // all-diffuse triangle scenes (bounce 0 on known constants): what k_generate<LEAN> leaves INSTEAD of a record — the sampler state ...
+    uint32_t* pixel0;       // ... and the pixel; the fused kernel's bounce 0 reads them (and `lambda`) and writes the path's first record whole
     float4* lambda_pdf;
     float4* ctx0;           // prev_intr_ctx: pi.low.xyz, pi.high.x
     float4* ctx1;           //                pi.high.yz, n.xy
