@@ -45,7 +45,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
     // the BxDF and the shading frame as k_vertex left them in the parameter block (c2 = PathArrays::ctx2[path]: n.z and the shading normal)
     auto build_bsdf = [&](uint32_t path, const float4& c2, BSDF& bsdf, V3& ns) {
         BxDF& b = bsdf.bxdf;
-        const float4 p2 = pa.bx2[path];
+        const float4 p2 = pa.bx[path].bx2;
         const uint32_t meta = __float_as_uint(p2.w);
         b.kind = meta & 0xffu;
         b.max_depth = (int)((meta >> 8) & 0xfffu);
@@ -54,11 +54,11 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
         b.eta = p2.x;
         b.mf.alpha_x = p2.y;
         b.mf.alpha_y = p2.z;
-        b.r = ld_spec(pa.bx0[path]);
-        b.k = (CLASS == CLASS_CONDUCTOR || CLASS == CLASS_LAYERED) ? ld_spec(pa.bx1[path]) : spec_const(0.0f);
+        b.r = ld_spec(pa.bx[path].bx0);
+        b.k = (CLASS == CLASS_CONDUCTOR || CLASS == CLASS_LAYERED) ? ld_spec(pa.bx[path].bx1) : spec_const(0.0f);
         if (CLASS == CLASS_LAYERED) {
-            b.albedo = ld_spec(pa.bx3[path]);
-            const float4 p4 = pa.bx4[path];
+            b.albedo = ld_spec(pa.bx[path].bx3);
+            const float4 p4 = pa.bx[path].bx4;
             b.mf2.alpha_x = p4.x; b.mf2.alpha_y = p4.y; b.thickness = p4.z; b.g = p4.w;
         } else {
             b.albedo = spec_const(0.0f);
@@ -70,7 +70,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
         if (CLASS == CLASS_CONDUCTOR) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_CONDUCTOR);
         if (CLASS == CLASS_DIELECTRIC) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_DIELECTRIC || bsdf.bxdf.kind == SHM_MATERIAL_THIN_DIELECTRIC);
         if (CLASS == CLASS_LAYERED) __builtin_assume(bsdf.bxdf.kind == SHM_MATERIAL_COATED_DIFFUSE || bsdf.bxdf.kind == SHM_MATERIAL_COATED_CONDUCTOR);
-        const float4 f = pa.fr[path];
+        const float4 f = pa.bx[path].fr;
         ns = v3(c2.y, c2.z, c2.w);
         // Frame::from_xz (frame.rs:14-17): y = z cross x
         bsdf.shading_frame.x = v3(f.x, f.y, f.z);
@@ -134,7 +134,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
         if (mine) {
             path = q_cur[i];
             if (SUB != 0) {
-                const float4 p2 = pa.bx2[path];
+                const float4 p2 = pa.bx[path].bx2;
                 // (what BxDF::flags calls SPECULAR, bxdf.rs:541-551 / 812-814: an index-matched interface with a rough distribution is GLOSSY — its NEE finds f = 0,
                 //  but draws its three sampler dimensions — and stays with the general kernel)
                 const bool specular = (__float_as_uint(p2.w) & 0xffu) == SHM_MATERIAL_THIN_DIELECTRIC || (p2.y < 1e-3f && p2.z < 1e-3f);
@@ -162,7 +162,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
             // intr.wo, what sample_ld and get_bsdf use: bitwise -ray.d for a top-level triangle; a quadric or an instanced primitive
             // builds its interaction in object space and maps it back (sphere.rs:254-270, primitive.rs:165-170), so it is carried
             V3 si_wo = wo;
-            if (!TRI_ONLY) { const float4 w4 = pa.siwo[path]; si_wo = v3(w4.x, w4.y, w4.z); }
+            if (!TRI_ONLY) { const float4 w4 = pa.bx[path].siwo; si_wo = v3(w4.x, w4.y, w4.z); }
             Spec beta = ld_spec(pa.rec[path].beta);
             Wavelengths lambda;
             {

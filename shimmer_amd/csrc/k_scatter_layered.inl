@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t deposit_slot(uint32_t& n, bool dep) {
 
 // the BxDF as k_vertex left it in the parameter block (without the shading frame: the walks run in the local frame)
 __device__ __forceinline__ void layered_bxdf_of(const SceneView& sv, const PathArrays& pa, uint32_t path, BxDF& b) {
-    const float4 p2 = pa.bx2[path];
+    const float4 p2 = pa.bx[path].bx2;
     const uint32_t meta = __float_as_uint(p2.w);
     b.kind = meta & 0xffu;
     b.max_depth = (int)((meta >> 8) & 0xfffu);
@@ -74,16 +74,16 @@ __device__ __forceinline__ void layered_bxdf_of(const SceneView& sv, const PathA
     b.eta = p2.x;
     b.mf.alpha_x = p2.y;
     b.mf.alpha_y = p2.z;
-    b.r = ld_spec(pa.bx0[path]);
-    b.k = ld_spec(pa.bx1[path]);
-    b.albedo = ld_spec(pa.bx3[path]);
-    const float4 p4 = pa.bx4[path];
+    b.r = ld_spec(pa.bx[path].bx0);
+    b.k = ld_spec(pa.bx[path].bx1);
+    b.albedo = ld_spec(pa.bx[path].bx3);
+    const float4 p4 = pa.bx[path].bx4;
     b.mf2.alpha_x = p4.x; b.mf2.alpha_y = p4.y; b.thickness = p4.z; b.g = p4.w;
     __builtin_assume(b.kind == SHM_MATERIAL_COATED_DIFFUSE || b.kind == SHM_MATERIAL_COATED_CONDUCTOR);  // the class is a property of the queue
 }
 __device__ __forceinline__ void layered_bsdf_of(const SceneView& sv, const PathArrays& pa, uint32_t path, const float4& c2, BSDF& bsdf, V3& ns) {
     layered_bxdf_of(sv, pa, path, bsdf.bxdf);
-    const float4 f = pa.fr[path];
+    const float4 f = pa.bx[path].fr;
     ns = v3(c2.y, c2.z, c2.w);
     // Frame::from_xz (frame.rs:14-17): y = z cross x
     bsdf.shading_frame.x = v3(f.x, f.y, f.z);
@@ -213,7 +213,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                     if (HAS_TEX && (fl & (1u << 10)) && (bs.flags == BXDF_SPECULAR_REFLECTION || bs.flags == BXDF_SPECULAR_TRANSMISSION)) {
                         // spawn_ray_with_differentials, interaction.rs:430-514 (only specular bounces carry differentials on)
                         V3 si_wo = wo;
-                        if (!TRI_ONLY) { const float4 w4 = pa.siwo[path]; si_wo = v3(w4.x, w4.y, w4.z); }
+                        if (!TRI_ONLY) { const float4 w4 = pa.bx[path].siwo; si_wo = v3(w4.x, w4.y, w4.z); }
                         const float4 d0 = pa.dd0[path], d1 = pa.dd1[path], d2 = pa.dd2[path];
                         AuxRays na = spawn_ray_differentials_pre(si_pi.mid(), si_wo, ns, v3(d0.x, d0.y, d0.z), v3(d0.w, d1.x, d1.y), v3(d1.z, d1.w, d2.x),
                                                                  v3(d2.y, d2.z, d2.w), ld_aux(pa, path), bs.wi, bs.flags, bs.eta);
@@ -343,7 +343,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                 const V3 wo = -v3(r0.w, r1.x, r1.y);  // li()'s wo = -ray.d (integrator.rs:844)
                 // intr.wo, what sample_ld and get_bsdf use: bitwise -ray.d for a top-level triangle; a quadric or an instanced primitive carries its own (k_scatter.inl)
                 si_wo = wo;
-                if (!TRI_ONLY) { const float4 w4 = pa.siwo[path]; si_wo = v3(w4.x, w4.y, w4.z); }
+                if (!TRI_ONLY) { const float4 w4 = pa.bx[path].siwo; si_wo = v3(w4.x, w4.y, w4.z); }
                 regularized = params.regularize && ((pa.rec[path].flags >> 9) & 1u);
                 Rng rng = path_sampler(pa, path, params);
                 if (regularized) bxdf_regularize(bsdf.bxdf);

@@ -159,17 +159,17 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
                 BSDF bsdf = get_bsdf<HAS_TEX>(sv, si, sv.materials[prim.material], lambda, &df);
                 if (depth != params.max_depth) {  // integrator.rs:830-834
                     const BxDF& b = bsdf.bxdf;
-                    pa.bx0[path] = st_spec(b.r);
-                    if (pa.bx1) pa.bx1[path] = st_spec(b.k);
-                    pa.bx2[path] = make_float4(b.eta, b.mf.alpha_x, b.mf.alpha_y,
+                    pa.bx[path].bx0 = st_spec(b.r);
+                    pa.bx[path].bx1 = st_spec(b.k);  // (the same 32-byte sector as fr)
+                    pa.bx[path].bx2 = make_float4(b.eta, b.mf.alpha_x, b.mf.alpha_y,
                                                __uint_as_float(b.kind | ((uint32_t)b.max_depth << 8) | ((uint32_t)b.n_samples << 20)));  // (b.strict is sv.quirks_off: not carried)
-                    if (pa.bx3) {
-                        pa.bx3[path] = st_spec(b.albedo);
-                        pa.bx4[path] = make_float4(b.mf2.alpha_x, b.mf2.alpha_y, b.thickness, b.g);
+                    if (pa.has_layered) {
+                        pa.bx[path].bx3 = st_spec(b.albedo);
+                        pa.bx[path].bx4 = make_float4(b.mf2.alpha_x, b.mf2.alpha_y, b.thickness, b.g);
                     }
                     const V3 fx = bsdf.shading_frame.x;
-                    pa.fr[path] = make_float4(fx.x, fx.y, fx.z, 0.0f);
-                    if (!TRI_ONLY) pa.siwo[path] = make_float4(si.wo.x, si.wo.y, si.wo.z, 0.0f);  // differs from -ray.d for quadrics / instances
+                    pa.bx[path].fr = make_float4(fx.x, fx.y, fx.z, 0.0f);
+                    if (!TRI_ONLY) pa.bx[path].siwo = make_float4(si.wo.x, si.wo.y, si.wo.z, 0.0f);  // differs from -ray.d for quadrics / instances
                     // this vertex's LightSampleContext (light.rs:1001-1009): the scatter half's geometry, and the next vertex's prev_intr_ctx
                     pa.ctx0[path] = make_float4(si.pi.x.low, si.pi.y.low, si.pi.z.low, si.pi.x.high);
                     pa.ctx1[path] = make_float4(si.pi.y.high, si.pi.z.high, si.n.x, si.n.y);

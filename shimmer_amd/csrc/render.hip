@@ -207,10 +207,7 @@ static bool use_staged(const ShmScene* s, const ShmRenderParams* params) {
 }
 static uint64_t staging_bytes_per_path(const ShmScene* s) {
     const shm_host::FlatScene& f = s->flat;
-    uint64_t b = 16 * 3;  // bx0, bx2, fr
-    if (f.has_class[CLASS_CONDUCTOR] || f.has_class[CLASS_LAYERED]) b += 16;  // bx1
-    if (f.has_class[CLASS_LAYERED]) b += 32;                                   // bx3, bx4
-    if (f.has_spheres || f.has_textures) b += 16;                              // siwo (the textured kernels are the general ones)
+    uint64_t b = 128;  // the parameter block, one BxRec per path
     if (f.has_textures) b += 48;                                               // dd0..2
     for (int c = 0; c < N_BXDF_CLASSES; ++c) if (f.has_class[c]) b += 4;       // class queues
     if (s->lean_divert) b += 4;                                                // the lean diversion's queue
@@ -295,16 +292,15 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
     }
     s->pa.aux0 = s->pa.aux1 = s->pa.aux2 = nullptr;
     if (s->flat.has_textures) { WS(aux0, float4); WS(aux1, float4); WS(aux2, float4); }
-    s->pa.bx0 = s->pa.bx1 = s->pa.bx2 = s->pa.bx3 = s->pa.bx4 = s->pa.fr = s->pa.siwo = s->pa.dd0 = s->pa.dd1 = s->pa.dd2 = nullptr;
+    s->pa.bx = nullptr;
+    s->pa.has_layered = s->flat.has_class[CLASS_LAYERED] ? 1u : 0u;
+    s->pa.dd0 = s->pa.dd1 = s->pa.dd2 = nullptr;
     for (int c = 0; c < N_BXDF_CLASSES; ++c) s->d_q_scatter[c] = nullptr;
     s->d_q_lean = nullptr;
     s->ws_staged = false;
     if (need_staged) {
         const shm_host::FlatScene& f = s->flat;
-        WS(bx0, float4); WS(bx2, float4); WS(fr, float4);
-        if (f.has_class[CLASS_CONDUCTOR] || f.has_class[CLASS_LAYERED]) WS(bx1, float4);
-        if (f.has_class[CLASS_LAYERED]) { WS(bx3, float4); WS(bx4, float4); }
-        if (f.has_spheres || f.has_textures) WS(siwo, float4);  // every instantiation with TRI_ONLY = false writes it
+        WS(bx, BxRec);
         if (f.has_textures) { WS(dd0, float4); WS(dd1, float4); WS(dd2, float4); }
         for (int c = 0; c < N_BXDF_CLASSES; ++c)
             if (f.has_class[c] && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_scatter[c])) != SHM_OK) return rc;

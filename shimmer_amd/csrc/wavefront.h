@@ -86,6 +86,20 @@ struct alignas(64) PathRec {
     uint32_t pad[2];
 };
 static_assert(sizeof(PathRec) == 64, "PathRec is one half cache line");
+// Staged shading's parameter block — what get_bsdf left at a vertex, written by k_vertex and read by the scatter kernel of the vertex's BxDF class (the layered one
+// reads it in each of its stages) — as one 128-byte record, ordered so that a class reads whole 32-byte sectors: {bx0, bx2 | fr, bx1} for diffuse / conductor /
+// dielectric, + {bx3, bx4} for the coated ones, + {siwo} in scenes with quadrics, patches or instances. Six separate arrays before (PathRec, above, for the why).
+struct alignas(128) BxRec {
+    float4 bx0;   // r[4]: reflectance (Diffuse, CoatedDiffuse) / conductor eta (Conductor, CoatedConductor)
+    float4 bx2;   // eta, alpha_x, alpha_y, kind | max_depth << 8 | n_samples << 20 (as bits)
+    float4 fr;    // shading frame x = normalize(dpdus) (y = z cross x is recomputed; z = ns lives in ctx2)
+    float4 bx1;   // k[4]: conductor absorption
+    float4 bx3;   // albedo[4]                         (coated materials)
+    float4 bx4;   // alpha_x2, alpha_y2, thickness, g  (coated materials)
+    float4 siwo;  // intr.wo (scenes with non-triangle shapes or instances only: elsewhere it is -ray.d bit for bit)
+    float4 pad;
+};
+static_assert(sizeof(BxRec) == 128, "BxRec is one cache line");
 // Path state (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
 struct PathArrays {
     ShmRay* ray;            // 32 B: o, d, t_max — input of K2
@@ -108,13 +122,8 @@ struct PathArrays {
     // staged shading (k_vertex -> k_scatter<class>; null when the scene runs the fused kernel): the BxDF parameter block get_bsdf
     // left at this vertex and the x axis of its shading frame. The rest of the vertex geometry (pi, n, ns) is ctx0..2, which
     // k_vertex overwrites with THIS vertex's LightSampleContext once the previous one has served the emitter MIS weight.
-    float4* bx0;            // r[4]: reflectance (Diffuse, CoatedDiffuse) / conductor eta (Conductor, CoatedConductor)
-    float4* bx1;            // k[4]: conductor absorption (scenes with conductors or coated materials)
-    float4* bx2;            // eta, alpha_x, alpha_y, kind | max_depth << 8 | n_samples << 20 (as bits)
-    float4* bx3;            // albedo[4]                         (scenes with coated materials)
-    float4* bx4;            // alpha_x2, alpha_y2, thickness, g  (scenes with coated materials)
-    float4* fr;             // shading frame x = normalize(dpdus) (y = z cross x is recomputed; z = ns lives in ctx2)
-    float4* siwo;           // intr.wo (scenes with non-triangle shapes or instances only: elsewhere it is -ray.d bit for bit)
+    BxRec* bx;              // 128 B: the parameter block as ONE record per path (above)
+    uint32_t has_layered;   // the scene holds coated materials: k_vertex writes the record's third sector (bx3, bx4)
     // scenes with image textures only: what Igehy's specular differentials need beside the auxiliary rays (interaction.rs:430-514)
     float4* dd0;            // dpdx.xyz, dpdy.x
     float4* dd1;            // dpdy.yz, dndx.xy
