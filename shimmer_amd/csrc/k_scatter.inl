@@ -93,7 +93,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                 path = jw[0];
                 BSDF bsdf;
                 V3 ns;
-                build_bsdf(path, pa.ctx2[path], bsdf, ns);
+                build_bsdf(path, pa.ctx[path].c2, bsdf, ns);
                 const uint32_t jf = jw[16 * NEE_JOB_CAP];
                 if (jf & 2u) bxdf_regularize(bsdf.bxdf);
                 const V3 si_wo = v3(__uint_as_float(jw[1 * NEE_JOB_CAP]), __uint_as_float(jw[2 * NEE_JOB_CAP]), __uint_as_float(jw[3 * NEE_JOB_CAP]));
@@ -147,7 +147,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
             P3i si_pi;
             V3 si_n, ns;
             {
-                const float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path];
+                const float4 c0 = pa.ctx[path].c0, c1 = pa.ctx[path].c1, c2 = pa.ctx[path].c2;
                 si_pi.x = iv2(c0.x, c0.w);
                 si_pi.y = iv2(c0.y, c1.x);
                 si_pi.z = iv2(c0.z, c1.y);

@@ -166,7 +166,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                 bs.flags = jw[9 * LJ_CAP];
                 bs.eta = 1.0f;  // (a walk that leaves carries 1; a reflection at the top interface is not transmissive, its eta is never read)
                 bs.pdf_is_proportional = true;
-                const float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path];
+                const float4 c0 = pa.ctx[path].c0, c1 = pa.ctx[path].c1, c2 = pa.ctx[path].c2;
                 P3i si_pi;
                 si_pi.x = iv2(c0.x, c0.w);
                 si_pi.y = iv2(c0.y, c1.x);
@@ -287,7 +287,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                 path = w0 & LJ_PATH_MASK;
                 BSDF bsdf;
                 V3 ns;
-                layered_bsdf_of(sv, pa, path, pa.ctx2[path], bsdf, ns);
+                layered_bsdf_of(sv, pa, path, pa.ctx[path].c2, bsdf, ns);
                 if (w0 & 0x80000000u) bxdf_regularize(bsdf.bxdf);
                 const Spec l = ld_spec(pa.shadow_contrib[path]);  // (the light's radiance, parked by stage A where this job leaves its result)
                 const V3 si_wo = v3(__uint_as_float(jw[1 * LJ_CAP]), __uint_as_float(jw[2 * LJ_CAP]), __uint_as_float(jw[3 * LJ_CAP]));
@@ -337,7 +337,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                 path = q_cur[i];
                 BSDF bsdf;
                 V3 ns;
-                layered_bsdf_of(sv, pa, path, pa.ctx2[path], bsdf, ns);
+                layered_bsdf_of(sv, pa, path, pa.ctx[path].c2, bsdf, ns);
                 const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
                 const float4 r0 = rp[0], r1 = rp[1];
                 const V3 wo = -v3(r0.w, r1.x, r1.y);  // li()'s wo = -ray.d (integrator.rs:844)
@@ -372,7 +372,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
         Float j_pl = 0.0f;
         uint32_t j_flags = 0u;
         if (do_nee) {
-            const float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path];
+            const float4 c0 = pa.ctx[path].c0, c1 = pa.ctx[path].c1, c2 = pa.ctx[path].c2;
             P3i si_pi;
             si_pi.x = iv2(c0.x, c0.w);
             si_pi.y = iv2(c0.y, c1.x);

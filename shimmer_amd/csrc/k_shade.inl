@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
             // the previous vertex's context is only needed for the MIS weight of an emitter that was hit
             auto load_prev_ctx = [&]() {
                 LightSampleContext c;
-                float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path];
+                float4 c0 = pa.ctx[path].c0, c1 = pa.ctx[path].c1, c2 = pa.ctx[path].c2;
                 c.pi.x = iv2(c0.x, c0.w);
                 c.pi.y = iv2(c0.y, c1.x);
                 c.pi.z = iv2(c0.z, c1.y);
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                     pa.e_ray[path] = make_float4(ray_d.x, ray_d.y, ray_d.z, load_pb_eta().x);
                     pa.e_beta[path] = st_spec(load_beta());
                     pa.e_flags[path] = fl;
-                    if (!(depth == 0 || specular_bounce)) { pa.e_ctx0[path] = pa.ctx0[path]; pa.e_ctx1[path] = pa.ctx1[path]; pa.e_ctx2[path] = pa.ctx2[path]; }
+                    if (!(depth == 0 || specular_bounce)) { pa.e_ctx0[path] = pa.ctx[path].c0; pa.e_ctx1[path] = pa.ctx[path].c1; pa.e_ctx2[path] = pa.ctx[path].c2; }
                     push_emit = true;
                 }
                 if (EMIT_INLINE && prim.area_light >= 0) {
@@ -265,9 +265,9 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                             pa.ray[path] = nr;
                             pa.rec[path].beta = st_spec(beta);
                             pa.rec[path].pb_eta = make_float2(p_b, eta_scale);
-                            pa.ctx0[path] = make_float4(nctx.pi.x.low, nctx.pi.y.low, nctx.pi.z.low, nctx.pi.x.high);
-                            pa.ctx1[path] = make_float4(nctx.pi.y.high, nctx.pi.z.high, nctx.n.x, nctx.n.y);
-                            pa.ctx2[path] = make_float4(nctx.n.z, nctx.ns.x, nctx.ns.y, nctx.ns.z);
+                            pa.ctx[path].c0 = make_float4(nctx.pi.x.low, nctx.pi.y.low, nctx.pi.z.low, nctx.pi.x.high);
+                            pa.ctx[path].c1 = make_float4(nctx.pi.y.high, nctx.pi.z.high, nctx.n.x, nctx.n.y);
+                            pa.ctx[path].c2 = make_float4(nctx.n.z, nctx.ns.x, nctx.ns.y, nctx.ns.z);
                             pa.rec[path].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
                             if (first_bounce) { pa.rec[path].lambda = lambda4_in; pa.rec[path].pixel = pix_in; }  // the record's first sector, complete
                             uint32_t aux_bit = 0u;

@@ -111,7 +111,7 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
             // beta, p_b and the previous vertex's context are only needed when something is emitted towards the path
             auto load_prev_ctx = [&]() {
                 LightSampleContext c;
-                float4 c0 = pa.ctx0[path], c1 = pa.ctx1[path], c2 = pa.ctx2[path];
+                float4 c0 = pa.ctx[path].c0, c1 = pa.ctx[path].c1, c2 = pa.ctx[path].c2;
                 c.pi.x = iv2(c0.x, c0.w);
                 c.pi.y = iv2(c0.y, c1.x);
                 c.pi.z = iv2(c0.z, c1.y);
@@ -171,9 +171,9 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
                     pa.bx[path].fr = make_float4(fx.x, fx.y, fx.z, 0.0f);
                     if (!TRI_ONLY) pa.bx[path].siwo = make_float4(si.wo.x, si.wo.y, si.wo.z, 0.0f);  // differs from -ray.d for quadrics / instances
                     // this vertex's LightSampleContext (light.rs:1001-1009): the scatter half's geometry, and the next vertex's prev_intr_ctx
-                    pa.ctx0[path] = make_float4(si.pi.x.low, si.pi.y.low, si.pi.z.low, si.pi.x.high);
-                    pa.ctx1[path] = make_float4(si.pi.y.high, si.pi.z.high, si.n.x, si.n.y);
-                    pa.ctx2[path] = make_float4(si.n.z, si.shading.n.x, si.shading.n.y, si.shading.n.z);
+                    pa.ctx[path].c0 = make_float4(si.pi.x.low, si.pi.y.low, si.pi.z.low, si.pi.x.high);
+                    pa.ctx[path].c1 = make_float4(si.pi.y.high, si.pi.z.high, si.n.x, si.n.y);
+                    pa.ctx[path].c2 = make_float4(si.n.z, si.shading.n.x, si.shading.n.y, si.shading.n.z);
                     if (HAS_TEX) {  // the surface part of spawn_ray_with_differentials (interaction.rs:436-440)
                         V3 dndx = si.shading.dndu * df.dudx + si.shading.dndv * df.dvdx;
                         V3 dndy = si.shading.dndu * df.dudy + si.shading.dndv * df.dvdy;

@@ -217,8 +217,8 @@ static bool uses_fused_kernel(const ShmScene* s) { return scene_is_lean(s) || s-
 static uint64_t workspace_cap(const ShmScene* s, bool need_staged) {
     // path state + three queues (+ auxiliary rays) (+ the staging arrays whenever the upcoming render is staged: every scene class but the
     // lean one, and the lean one too under options.force_diffuse — the budget must count them BEFORE the first staged allocation)
-    // (ray 32, hit 32, shadow_ray 32, shadow_contrib 16, L 16, the PathRec 64, lambda 16, lambda_pdf 16, ctx0..2 48 = 272)
-    const uint64_t BYTES_PER_PATH = 272 + (scene_is_lean(s) ? 12 : 0) + 3 * 4 + (s->flat.has_textures ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
+    // (ray 32, hit 32, shadow_ray 32, shadow_contrib 16, L 16, the PathRec 64, lambda 16, lambda_pdf 16, the CtxRec 64 = 288)
+    const uint64_t BYTES_PER_PATH = 288 + (scene_is_lean(s) ? 12 : 0) + 3 * 4 + (s->flat.has_textures ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
     uint64_t cap = max_batch_paths();
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -280,7 +280,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
     int rc;
 #define WS(field, type) if ((rc = ws_alloc((size_t)cap * sizeof(type), (void**)&s->pa.field)) != SHM_OK) return rc
     WS(ray, ShmRay); WS(hit, ShmHit); WS(shadow_ray, ShmRay); WS(shadow_contrib, float4); WS(L, float4); WS(rec, PathRec);
-    WS(lambda, float4); WS(lambda_pdf, float4); WS(ctx0, float4); WS(ctx1, float4); WS(ctx2, float4);
+    WS(lambda, float4); WS(lambda_pdf, float4); WS(ctx, CtxRec);
     s->pa.rng0 = nullptr; s->pa.pixel0 = nullptr;
     if (scene_is_lean(s)) { WS(rng0, uint2); WS(pixel0, uint32_t); }
     s->pa.e_ray = s->pa.e_beta = s->pa.e_ctx0 = s->pa.e_ctx1 = s->pa.e_ctx2 = nullptr;

@@ -100,6 +100,8 @@ struct alignas(128) BxRec {
     float4 pad;
 };
 static_assert(sizeof(BxRec) == 128, "BxRec is one cache line");
+// A vertex's LightSampleContext (light.rs:1001-1009): the scatter half's geometry and the next vertex's prev_intr_ctx, one record
+struct alignas(64) CtxRec { float4 c0, c1, c2, pad; };
 // Path state (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
 struct PathArrays {
     ShmRay* ray;            // 32 B: o, d, t_max — input of K2
@@ -112,9 +114,7 @@ struct PathArrays {
     uint2* rng0;            // all-diffuse triangle scenes (bounce 0 on known constants): what k_generate<LEAN> leaves INSTEAD of a record — the sampler state ...
     uint32_t* pixel0;       // ... and the pixel; the fused kernel's bounce 0 reads them (and `lambda`) and writes the path's first record whole
     float4* lambda_pdf;
-    float4* ctx0;           // prev_intr_ctx: pi.low.xyz, pi.high.x
-    float4* ctx1;           //                pi.high.yz, n.xy
-    float4* ctx2;           //                n.z, ns.xyz
+    CtxRec* ctx;            // 64 B: prev_intr_ctx — c0 = pi.low.xyz, pi.high.x; c1 = pi.high.yz, n.xy; c2 = n.z, ns.xyz (one record: three arrays before)
     // scenes with image textures only (null otherwise): the ray's AuxiliaryRays (ray.rs:104-135)
     float4* aux0;           // rx_origin.xyz, rx_direction.x
     float4* aux1;           // rx_direction.yz, ry_origin.xy
