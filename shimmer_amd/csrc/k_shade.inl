@@ -40,7 +40,11 @@ template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ON
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneView sv_global, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in, uint32_t* __restrict__ q_emit,
-                                                     LdsTables lds_tables, int first_bounce) {
+                                                     LdsTables lds_tables, int bounce_flags) {
+    // bit 0: bounce 0 on known constants (ShadeArgs::first_bounce); bit 1: the scene runs this kernel alone (all-diffuse triangles, no diversion), and what the vertex leaves
+    // for the MIS weight of an emitter hit at the NEXT vertex is its hit record — primitive + barycentrics, 16 bytes — instead of its LightSampleContext (48): hitting an
+    // emitter is rare, and k_emit_jobs rebuilds the context from the record with the very code that built it here (triangle_interaction depends on nothing else)
+    const bool first_bounce = (bounce_flags & 1) != 0, ctx_as_hit = (bounce_flags & 2) != 0;
     __shared__ uint4 s_tables[LDS_TABLE_BUDGET / 16];  // the small scene tables, staged once per workgroup (wavefront.h, stage_scene_tables)
     __shared__ uint4 s_view[HAS_TEX ? SCENE_VIEW_UINT4S : 1];  // with textures: the view itself, for the texture evaluators that are real calls (shm/texture.h)
     const SceneView sv = stage_scene_tables_tex<HAS_TEX>(sv_global, lds_tables, s_tables, s_view);
@@ -126,7 +130,10 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                     pa.e_ray[path] = make_float4(ray_d.x, ray_d.y, ray_d.z, load_pb_eta().x);
                     pa.e_beta[path] = st_spec(load_beta());
                     pa.e_flags[path] = fl;
-                    if (!(depth == 0 || specular_bounce)) { pa.e_ctx0[path] = pa.ctx[path].c0; pa.e_ctx1[path] = pa.ctx[path].c1; pa.e_ctx2[path] = pa.ctx[path].c2; }
+                    if (!(depth == 0 || specular_bounce)) {
+                        pa.e_ctx0[path] = pa.ctx[path].c0;
+                        if (!ctx_as_hit) { pa.e_ctx1[path] = pa.ctx[path].c1; pa.e_ctx2[path] = pa.ctx[path].c2; }
+                    }
                     push_emit = true;
                 }
                 if (EMIT_INLINE && prim.area_light >= 0) {
@@ -265,9 +272,13 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                             pa.ray[path] = nr;
                             pa.rec[path].beta = st_spec(beta);
                             pa.rec[path].pb_eta = make_float2(p_b, eta_scale);
-                            pa.ctx[path].c0 = make_float4(nctx.pi.x.low, nctx.pi.y.low, nctx.pi.z.low, nctx.pi.x.high);
-                            pa.ctx[path].c1 = make_float4(nctx.pi.y.high, nctx.pi.z.high, nctx.n.x, nctx.n.y);
-                            pa.ctx[path].c2 = make_float4(nctx.n.z, nctx.ns.x, nctx.ns.y, nctx.ns.z);
+                            if (ctx_as_hit) {
+                                pa.ctx[path].c0 = make_float4(__int_as_float(hit.prim), hit.b0, hit.b1, hit.b2);
+                            } else {
+                                pa.ctx[path].c0 = make_float4(nctx.pi.x.low, nctx.pi.y.low, nctx.pi.z.low, nctx.pi.x.high);
+                                pa.ctx[path].c1 = make_float4(nctx.pi.y.high, nctx.pi.z.high, nctx.n.x, nctx.n.y);
+                                pa.ctx[path].c2 = make_float4(nctx.n.z, nctx.ns.x, nctx.ns.y, nctx.ns.z);
+                            }
                             pa.rec[path].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
                             if (first_bounce) { pa.rec[path].lambda = lambda4_in; pa.rec[path].pixel = pix_in; }  // the record's first sector, complete
                             uint32_t aux_bit = 0u;
@@ -321,7 +332,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
 // contribution, before this bounce's: the launcher puts this kernel between k_shade and K3).
 // ---------------------------------------------------------------------------------------------
 template <bool TRI_ONLY, bool HAS_TEX>
-__global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_emit, const QueueState* qs) {
+__global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_emit, const QueueState* qs, int ctx_as_hit) {
     const uint32_t n = qs->n_emit;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t path = q_emit[i];
@@ -351,12 +362,24 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathAr
                 add_l(load_beta() * le);
             } else {
                 LightSampleContext c;
-                const float4 c0 = pa.e_ctx0[path], c1 = pa.e_ctx1[path], c2 = pa.e_ctx2[path];
-                c.pi.x = iv2(c0.x, c0.w);
-                c.pi.y = iv2(c0.y, c1.x);
-                c.pi.z = iv2(c0.z, c1.y);
-                c.n = v3(c1.z, c1.w, c2.x);
-                c.ns = v3(c2.y, c2.z, c2.w);
+                const float4 c0 = pa.e_ctx0[path];
+                if (ctx_as_hit) {
+                    // the previous vertex left its hit record: its context is light_ctx_from(its interaction) — the same function of the same inputs as when it was shaded
+                    Hit ph;
+                    ph.prim = __float_as_int(c0.x); ph.t = 0.0f; ph.b0 = c0.y; ph.b1 = c0.z; ph.b2 = c0.w; ph.phi = 0.0f; ph.inst = -1;
+                    // (get_bsdf belongs to it: a material with a displacement — the reference's constant one included — resets the shading geometry, interaction.rs:223-245)
+                    SurfaceInteraction sp = hit_interaction<TRI_ONLY>(sv, ph, v3s(0.0f));
+                    Wavelengths lw = lambda;
+                    (void)get_bsdf<HAS_TEX>(sv, sp, sv.materials[sv.primitives[ph.prim].material], lw);
+                    c = light_ctx_from(sp);
+                } else {
+                    const float4 c1 = pa.e_ctx1[path], c2 = pa.e_ctx2[path];
+                    c.pi.x = iv2(c0.x, c0.w);
+                    c.pi.y = iv2(c0.y, c1.x);
+                    c.pi.z = iv2(c0.z, c1.y);
+                    c.n = v3(c1.z, c1.w, c2.x);
+                    c.ns = v3(c2.y, c2.z, c2.w);
+                }
                 const Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, c, ray_d);
                 const Float w_l = power_heuristic(1, er.w, 1, p_l);
                 add_l(load_beta() * w_l * le);
@@ -367,15 +390,15 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathAr
 }  // namespace
 
 
-#define WF_EMIT_JOBS_LAUNCH()                                                                                                                \
+#define WF_EMIT_JOBS_LAUNCH(CTX_AS_HIT)                                                                                                      \
     do {                                                                                                                                     \
-        hipLaunchKernelGGL((k_emit_jobs<true, false>), dim3(s->n_cu * 4), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_emit, s->d_qs); \
+        hipLaunchKernelGGL((k_emit_jobs<true, false>), dim3(s->n_cu * 4), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_emit, s->d_qs, (CTX_AS_HIT)); \
         LAUNCH_TRY("k_emit_jobs");                                                                                                           \
     } while (0)
 #define WF_SHADE_LAUNCH(KERNEL)                                                                                                              \
     do {                                                                                                                                     \
         hipLaunchKernelGGL(KERNEL, dim3(s->n_cu * K_SHADE_LEAN_WAVES), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], s->d_q_active[a.cur ^ 1], \
-                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)nullptr, s->d_q_emit, s->lds_tables, a.first_bounce); \
+                           s->d_q_shadow, s->d_qs, a.cur, a.params, s->d_counters, a.shadow_parity, (const uint32_t*)nullptr, s->d_q_emit, s->lds_tables, a.first_bounce | (CTX_AS_HIT_FLAG)); \
         LAUNCH_TRY("k_shade");                                                                                                               \
     } while (0)
 #define WF_SHADE_LAUNCH_DIVERTED(KERNEL)                                                                                                     \

@@ -4,14 +4,19 @@
 #include "k_shade.inl"
 
 int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a) {
+    // the scene runs this kernel alone: a vertex leaves its hit record, not its LightSampleContext, for the next vertex's emitter MIS weight (k_shade.inl; SHM_CTX_AS_HIT=0: A/B)
+    const char* e = getenv("SHM_CTX_AS_HIT");
+    const int ctx_as_hit = (e && atoi(e) == 0) ? 0 : 1;
+#define CTX_AS_HIT_FLAG (ctx_as_hit << 1)
     WF_SHADE_LAUNCH((k_shade<false, true, false, true, false>));
-    WF_EMIT_JOBS_LAUNCH();  // emission of the vertices that hit an emitter, before K3 adds this bounce's shadow contributions (k_shade.inl)
+#undef CTX_AS_HIT_FLAG
+    WF_EMIT_JOBS_LAUNCH(ctx_as_hit);  // emission of the vertices that hit an emitter, before K3 adds this bounce's shadow contributions (k_shade.inl)
     return SHM_OK;
 }
 // The same kernel over the queue k_vertex diverted plain-diffuse hits to (a scene that also holds other materials): for those vertices the
 // fused kernel beats the staged pair — no parameter block to write and read back ("staged shading").
 int wf_launch_shade_lean_diverted(ShmScene* s, const ShadeArgs& a) {
     WF_SHADE_LAUNCH_DIVERTED((k_shade<false, true, false, true, false>));
-    WF_EMIT_JOBS_LAUNCH();
+    WF_EMIT_JOBS_LAUNCH(0);
     return SHM_OK;
 }

@@ -7,6 +7,8 @@
 #include "k_shade.inl"
 
 int wf_launch_shade_tail(ShmScene* s, const ShadeArgs& a) {
+#define CTX_AS_HIT_FLAG 0  // (the tail kernel follows staged bounces: the vertex context stays the LightSampleContext)
     WF_SHADE_LAUNCH((k_shade<false, true, false, false>));
+#undef CTX_AS_HIT_FLAG
     return SHM_OK;
 }
