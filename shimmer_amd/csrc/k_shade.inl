@@ -63,10 +63,14 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
         if (active) {
             // first_bounce (wave-uniform; the lean instantiation only): k_generate left the constants out — the queue is the identity, beta = 1, p_b = eta_scale = 1, flags = 0
             path = first_bounce ? i : q_cur[i];
-            const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
-            float4 h0 = hp[0], h1 = hp[1];
             Hit hit;
-            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
+            if (TRI_ONLY) {
+                hit = load_hit_tri(pa, path);
+            } else {
+                const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
+                float4 h0 = hp[0], h1 = hp[1];
+                hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
+            }
             const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
             float4 r0 = rp[0], r1 = rp[1];
             V3 ray_d = v3(r0.w, r1.x, r1.y);
@@ -336,10 +340,14 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathAr
     const uint32_t n = qs->n_emit;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t path = q_emit[i];
-        const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
-        const float4 h0 = hp[0], h1 = hp[1];
         Hit hit;
-        hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
+        if (TRI_ONLY) {
+            hit = load_hit_tri(pa, path);
+        } else {
+            const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
+            const float4 h0 = hp[0], h1 = hp[1];
+            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
+        }
         const float4 er = pa.e_ray[path];
         const V3 ray_d = v3(er.x, er.y, er.z);
         Wavelengths lambda;

@@ -54,7 +54,7 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                                             ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
                                             float4* __restrict__ L, const float4* __restrict__ contrib,
                                             DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
-                                            int refill_min, int leaf_min, int queue_parts, int rays_per_lane) {
+                                            int refill_min, int leaf_min, int queue_parts, int rays_per_lane, int hit16) {
     constexpr int K3_LDS_N = LDS_N;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     __shared__ uint32_t lds_stack[(TRACE_BLOCK / WAVE) * K3_LDS_N * WAVE];
@@ -374,11 +374,16 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                     L[path] = l;
                 }
             } else {
-                float4* hp = reinterpret_cast<float4*>(hits + path);
                 // (a miss is all zeros behind prim = -1: the lane's registers still hold its previous ray's barycentrics)
                 const bool found = hit_prim >= 0;
-                hp[0] = make_float4(__int_as_float(hit_prim), found ? t_max : 0.0f, found ? hit_b0 : 0.0f, found ? hit_b1 : 0.0f);
-                hp[1] = make_float4(found ? hit_b2 : 0.0f, (TRI_ONLY || !found) ? 0.0f : hit_phi, (TRI_ONLY || !found) ? 0.0f : __int_as_float(hit_inst + 1), 0.0f);
+                if (TRI_ONLY && hit16) {
+                    // the render's own hit array in a triangle scene: {primitive, b0, b1, b2}, 16 bytes — nothing downstream reads a triangle hit's t (wavefront.h, PathArrays::hit16)
+                    reinterpret_cast<float4*>(hits)[path] = make_float4(__int_as_float(hit_prim), found ? hit_b0 : 0.0f, found ? hit_b1 : 0.0f, found ? hit_b2 : 0.0f);
+                } else {
+                    float4* hp = reinterpret_cast<float4*>(hits + path);
+                    hp[0] = make_float4(__int_as_float(hit_prim), found ? t_max : 0.0f, found ? hit_b0 : 0.0f, found ? hit_b1 : 0.0f);
+                    hp[1] = make_float4(found ? hit_b2 : 0.0f, (TRI_ONLY || !found) ? 0.0f : hit_phi, (TRI_ONLY || !found) ? 0.0f : __int_as_float(hit_inst + 1), 0.0f);
+                }
             }
             state = ST_IDLE;
         }
@@ -401,8 +406,8 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
 #define K3_PARAMS SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_direct, uint32_t* head,                    \
                   const ShmRay* __restrict__ rays, ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out, float4* __restrict__ L,                 \
                   const float4* __restrict__ contrib, DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels, int refill_min, int leaf_min, \
-                  int queue_parts, int rays_per_lane
-#define K3_ARGS sv, queue, n_ptr, n_direct, head, rays, hits, occluded_out, L, contrib, counters, spill, spill_levels, refill_min, leaf_min, queue_parts, rays_per_lane
+                  int queue_parts, int rays_per_lane, int hit16
+#define K3_ARGS sv, queue, n_ptr, n_direct, head, rays, hits, occluded_out, L, contrib, counters, spill, spill_levels, refill_min, leaf_min, queue_parts, rays_per_lane, hit16
 template <bool ANY, bool TRI_ONLY> struct K3Shape;  // {LDS levels, workgroups per CU} of each entry point
 #ifndef K3_CLOSEST_WAVES
 #define K3_CLOSEST_WAVES 8
@@ -462,7 +467,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                                             ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
                                             float4* __restrict__ L, const float4* __restrict__ contrib,
                                             DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
-                                            int refill_min, int leaf_min, int queue_parts, int rays_per_lane, const uint32_t* __restrict__ big_leaf_n) {
+                                            int refill_min, int leaf_min, int queue_parts, int rays_per_lane, int hit16, const uint32_t* __restrict__ big_leaf_n) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) u32x2 lds_u2;
     __shared__ u32x2 lds_stack5[(TRACE_BLOCK / WAVE) * LDS_N * WAVE];
@@ -691,9 +696,13 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                         sgn |= 16u;
                         if (!ANY) {
                             t_max = ti.t;  // aggregate.rs:105-109 shrinks the ray to the hit
-                            float4* hp = reinterpret_cast<float4*>(hits + path);
-                            hp[0] = make_float4(__int_as_float((int32_t)slot), ti.t, ti.b0, ti.b1);
-                            hp[1] = make_float4(ti.b2, 0.0f, 0.0f, 0.0f);
+                            if (hit16) {
+                                reinterpret_cast<float4*>(hits)[path] = make_float4(__int_as_float((int32_t)slot), ti.b0, ti.b1, ti.b2);
+                            } else {
+                                float4* hp = reinterpret_cast<float4*>(hits + path);
+                                hp[0] = make_float4(__int_as_float((int32_t)slot), ti.t, ti.b0, ti.b1);
+                                hp[1] = make_float4(ti.b2, 0.0f, 0.0f, 0.0f);
+                            }
                         }
                     }
                     leaf_n -= 1u;
@@ -736,9 +745,13 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                     L[path] = l;
                 }
             } else if (!found) {
-                float4* hp = reinterpret_cast<float4*>(hits + path);  // a miss is all zeros behind prim = -1
-                hp[0] = make_float4(__int_as_float(-1), 0.0f, 0.0f, 0.0f);
-                hp[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (hit16) {
+                    reinterpret_cast<float4*>(hits)[path] = make_float4(__int_as_float(-1), 0.0f, 0.0f, 0.0f);
+                } else {
+                    float4* hp = reinterpret_cast<float4*>(hits + path);  // a miss is all zeros behind prim = -1
+                    hp[0] = make_float4(__int_as_float(-1), 0.0f, 0.0f, 0.0f);
+                    hp[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
             }
             cur = CUR_IDLE;
         }
@@ -827,7 +840,7 @@ int wf_trace_prepare(ShmScene* s) {
 }
 
 int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, const ShmRay* rays,
-                    ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib) {
+                    ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib, int hit16) {
     uint32_t* heads = s->d_heads3 + (any ? 8 * 32 : 0);
     uint32_t* spill = any ? s->d_spill3_any : s->d_spill3;
     hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, stream, heads);
@@ -835,10 +848,10 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
     const bool tri_only = !s->flat.has_spheres;
 #define TRACE_LAUNCH(ANY, TRI)                                                                                                                   \
     hipLaunchKernelGGL((k_trace3<ANY, TRI>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
-                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane)
+                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16)
 #define TRACE5_LAUNCH(ANY)                                                                                                                    \
     hipLaunchKernelGGL((k_trace5<ANY>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,  \
-                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, s->d_big_leaf_n)
+                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n)
     if (tri_only && s->trace_pair) { if (any) TRACE5_LAUNCH(true); else TRACE5_LAUNCH(false); }
     else if (any) { if (tri_only) TRACE_LAUNCH(true, true); else TRACE_LAUNCH(true, false); }
     else { if (tri_only) TRACE_LAUNCH(false, true); else TRACE_LAUNCH(false, false); }

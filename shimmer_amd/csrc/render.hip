@@ -648,6 +648,10 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         const bool layered_staged = [] { const char* e = getenv("SHM_LAYERED_STAGED"); return !(e && atoi(e) == 0); }();  // (the LayeredBxDF class as dense per-wave stages; read per render: the tests flip it)
         const bool lean_first_on = [] { const char* e = getenv("SHM_LEAN_FIRST_BOUNCE"); return !(e && atoi(e) == 0); }();  // (read per render: the tests flip it)
         const bool lean_first = lean_first_on && !staged && !random_walk && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && !s->pa.aux0;
+        // triangle scenes without textures under the path integrator: every kernel that reads the render's hit array is a TRI_ONLY one, and none reads a triangle hit's t —
+        // the closest-hit launches write {primitive, b0, b1, b2}, 16 bytes per path instead of the 32-byte ShmHit (SHM_HIT16=0: A/B)
+        s->pa.hit16 = (!s->flat.has_spheres && !s->flat.has_textures && params->integrator == SHM_INTEGRATOR_PATH && !random_walk &&
+                       [] { const char* e = getenv("SHM_HIT16"); return !(e && atoi(e) == 0); }()) ? 1u : 0u;
         if (s->pa.aux0)
             hipLaunchKernelGGL(k_generate<true>, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
                                sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs, s->pix_group);
@@ -686,8 +690,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
             hipEvent_t a = ev.get(), b = ev.get();
             hipEventRecord(a, s->stream);
             const bool first_lean = lean_first && bounce == 0;  // (the identity queue was not written: K2 takes slot = queue index, k_shade knows the constants)
-            if ((rc = first_lean ? wf_launch_trace(s, false, s->stream, nullptr, nullptr, total, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr)
-                                 : wf_launch_trace(s, false, s->stream, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr)) != SHM_OK) return rc;
+            if ((rc = first_lean ? wf_launch_trace(s, false, s->stream, nullptr, nullptr, total, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr, (int)s->pa.hit16)
+                                 : wf_launch_trace(s, false, s->stream, s->d_q_active[cur], &s->d_qs->n_active[cur], 0, s->pa.ray, s->pa.hit, nullptr, nullptr, nullptr, (int)s->pa.hit16)) != SHM_OK) return rc;
             hipEventRecord(b, s->stream);
             ev_closest.push_back({a, b});
             if (overlap && k3_done) hipStreamWaitEvent(s->stream, k3_done, 0);  // shade(b) touches L and refills the shadow buffers

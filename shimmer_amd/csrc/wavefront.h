@@ -105,7 +105,8 @@ struct alignas(64) CtxRec { float4 c0, c1, c2, pad; };
 // Path state (DESIGN.md §"Data layout in HBM"). All arrays have `capacity` entries.
 struct PathArrays {
     ShmRay* ray;            // 32 B: o, d, t_max — input of K2
-    ShmHit* hit;            // 32 B: output of K2
+    ShmHit* hit;            // 32 B: output of K2 — or, with hit16, 16 B per path in the same allocation: {primitive, b0, b1, b2} as one float4
+    uint32_t hit16;         // set per render: a triangle scene without textures under the path integrator (every consumer is a TRI_ONLY kernel, none reads a triangle hit's t)
     ShmRay* shadow_ray;     // 32 B: input of K3
     float4* shadow_contrib; // beta * Ld, added to L by K3 when unoccluded
     float4* L;
@@ -217,6 +218,20 @@ __device__ __forceinline__ SceneView stage_scene_tables_tex(const SceneView& sv,
     SceneView out = stage_scene_tables(sv, t, lds);
     if (HAS_TEX) attach_call_copy(out, slot);
     return out;
+}
+
+// a path's hit record as the TRI_ONLY shading kernels read it: the 32-byte ShmHit, or the compact form the render's own traversal launches write (PathArrays::hit16)
+__device__ __forceinline__ Hit load_hit_tri(const PathArrays& pa, uint32_t path) {
+    Hit hit;
+    if (pa.hit16) {
+        const float4 h = reinterpret_cast<const float4*>(pa.hit)[path];
+        hit.prim = __float_as_int(h.x); hit.t = 0.0f; hit.b0 = h.y; hit.b1 = h.z; hit.b2 = h.w; hit.phi = 0.0f; hit.inst = -1;
+    } else {
+        const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
+        const float4 h0 = hp[0], h1 = hp[1];
+        hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
+    }
+    return hit;
 }
 
 __device__ __forceinline__ uint32_t wave_lane() { return __lane_id(); }
@@ -333,7 +348,7 @@ WF_INTERNAL void wf_trace_census();  // k_trace.hip: prints the per-phase lane c
 WF_INTERNAL void wf_layered_census();  // k_scatter_layered_staged_tri.hip: the same for a -DLJ_CENSUS build of the staged LayeredBxDF kernel
 WF_INTERNAL int wf_trace_prepare(ShmScene* s);  // grid sizes + stack spill buffers of the two traversal kernels (at scene creation)
 WF_INTERNAL int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct,
-                                const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib);
+                                const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib, int hit16 = 0);
 // shading of one path vertex of PathIntegrator::li for every entry of q_active[cur]
 struct ShadeArgs {
     hipStream_t stream;

@@ -432,12 +432,13 @@ def test_instance_root_inside_another_tree_is_rejected(env):
     r.close()
 
 
-@pytest.mark.parametrize("switch", ["SHM_LDS_TABLES", "SHM_LEAN_FIRST_BOUNCE", "SHM_TRACE_PAIR", "SHM_LEAN_DIVERT", "SHM_LAYERED_STAGED", "SHM_CTX_AS_HIT"])
+@pytest.mark.parametrize("switch", ["SHM_LDS_TABLES", "SHM_LEAN_FIRST_BOUNCE", "SHM_TRACE_PAIR", "SHM_LEAN_DIVERT", "SHM_LAYERED_STAGED", "SHM_CTX_AS_HIT", "SHM_HIT16"])
 def test_ab_switches_change_no_result(env, monkeypatch, switch):
     """The round-4 optimisations each have an A/B switch read at scene creation / first launch; switched off, the films and the counters are the same bits:
     the small scene tables staged in LDS, bounce 0 on known constants, the both-children traversal step, the lean diversion (its fused kernel defers emitter hits),
     the LayeredBxDF class as dense per-wave stages (k_scatter_layered.inl; off: one pass per vertex, k_scatter<CLASS_LAYERED>), the fused kernel's vertex leaving its hit
-    record instead of its LightSampleContext for the next vertex's emitter MIS weight (all-diffuse triangle scenes; k_emit_jobs rebuilds the context)."""
+    record instead of its LightSampleContext for the next vertex's emitter MIS weight (all-diffuse triangle scenes; k_emit_jobs rebuilds the context), the render's own
+    hit array as 16-byte records in triangle scenes."""
     lib, oracle_py, render, scenes = env
     cases = [(scenes.ganesha_proxy(lib, 64, 64, n=32), 6, 5), (scenes.cornell_box(lib, 48, 48, coated=True, emitter_reflects=True), 6, 5),
              (scenes.cornell_box(lib, 40, 40, textured=True), 4, 6)]
