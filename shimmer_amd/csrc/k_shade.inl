@@ -44,7 +44,9 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
     // bit 0: bounce 0 on known constants (ShadeArgs::first_bounce); bit 1: the scene runs this kernel alone (all-diffuse triangles, no diversion), and what the vertex leaves
     // for the MIS weight of an emitter hit at the NEXT vertex is its hit record — primitive + barycentrics, 16 bytes — instead of its LightSampleContext (48): hitting an
     // emitter is rare, and k_emit_jobs rebuilds the context from the record with the very code that built it here (triangle_interaction depends on nothing else)
-    const bool first_bounce = (bounce_flags & 1) != 0, ctx_as_hit = (bounce_flags & 2) != 0;
+    // bit 2 (with bit 1): the hit array is double-buffered by bounce parity (16-byte records, the two halves of the ShmHit allocation): the previous vertex's record is still
+    // there (PathArrays::hit_prev) and nothing at all is written for the next vertex
+    const bool first_bounce = (bounce_flags & 1) != 0, ctx_as_hit = (bounce_flags & 2) != 0, hit_kept = (bounce_flags & 4) != 0;
     __shared__ uint4 s_tables[LDS_TABLE_BUDGET / 16];  // the small scene tables, staged once per workgroup (wavefront.h, stage_scene_tables)
     __shared__ uint4 s_view[HAS_TEX ? SCENE_VIEW_UINT4S : 1];  // with textures: the view itself, for the texture evaluators that are real calls (shm/texture.h)
     const SceneView sv = stage_scene_tables_tex<HAS_TEX>(sv_global, lds_tables, s_tables, s_view);
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                     pa.e_beta[path] = st_spec(load_beta());
                     pa.e_flags[path] = fl;
                     if (!(depth == 0 || specular_bounce)) {
-                        pa.e_ctx0[path] = pa.ctx[path].c0;
+                        pa.e_ctx0[path] = hit_kept ? pa.hit_prev[path] : pa.ctx[path].c0;
                         if (!ctx_as_hit) { pa.e_ctx1[path] = pa.ctx[path].c1; pa.e_ctx2[path] = pa.ctx[path].c2; }
                     }
                     push_emit = true;
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                             pa.rec[path].beta = st_spec(beta);
                             pa.rec[path].pb_eta = make_float2(p_b, eta_scale);
                             if (ctx_as_hit) {
-                                pa.ctx[path].c0 = make_float4(__int_as_float(hit.prim), hit.b0, hit.b1, hit.b2);
+                                if (!hit_kept) pa.ctx[path].c0 = make_float4(__int_as_float(hit.prim), hit.b0, hit.b1, hit.b2);
                             } else {
                                 pa.ctx[path].c0 = make_float4(nctx.pi.x.low, nctx.pi.y.low, nctx.pi.z.low, nctx.pi.x.high);
                                 pa.ctx[path].c1 = make_float4(nctx.pi.y.high, nctx.pi.z.high, nctx.n.x, nctx.n.y);

@@ -679,7 +679,17 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         hipStream_t any_stream = overlap ? s->stream2 : s->stream;
         used_overlap = used_overlap || overlap;
         hipEvent_t k3_done = nullptr;
+        // all-diffuse triangle scenes with 16-byte hit records: the records are double-buffered by bounce parity in the two halves of the ShmHit allocation, so that the
+        // previous vertex's record — all the next vertex's emitter MIS weight needs (k_shade.inl, k_emit_jobs) — is still there and no vertex writes anything for it
+        ShmHit* const hit_base = s->pa.hit;
+        struct HitRestore { ShmScene* sc; ShmHit* base; ~HitRestore() { sc->pa.hit = base; sc->pa.hit_prev = nullptr; } } hit_restore{s, hit_base};
+        const bool hit_kept = s->pa.hit16 && scene_is_lean(s) && !staged && !random_walk;
         for (int bounce = 0; bounce <= params->max_depth; ++bounce) {
+            if (hit_kept) {
+                float4* const h16 = reinterpret_cast<float4*>(hit_base);
+                s->pa.hit = reinterpret_cast<ShmHit*>(h16 + (size_t)(bounce & 1) * s->capacity);
+                s->pa.hit_prev = h16 + (size_t)((bounce + 1) & 1) * s->capacity;
+            }
             const int sh = bounce & 1;
             if (!overlap && s->overlap_paths > 0 && bounce >= late_overlap_bounce) {
                 // (the switch is safe at a bounce boundary: everything so far was ordered on the render stream)
@@ -698,7 +708,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
             {
                 hipEvent_t s0 = ev.get(), s1 = ev.get();
                 hipEventRecord(s0, s->stream);
-                const ShadeArgs sa{s->stream, cur, *params, sh, shade_blocks, first_lean ? 1 : 0};
+                const ShadeArgs sa{s->stream, cur, *params, sh, shade_blocks, first_lean ? 1 : 0, hit_kept ? 1 : 0};
                 const bool tri_only = !s->flat.has_spheres;
                 // the late bounces of a deep render in a triangle scene without textures or coated materials: ONE fused launch instead of the staged four or five
                 // (C4 frame, same box: 522-528 ms staged throughout; 510-512 from bounce 6, 511-513 from 8, 512-513 from 10, 514-517 from 14; 0 = off)

@@ -106,6 +106,7 @@ struct alignas(64) CtxRec { float4 c0, c1, c2, pad; };
 struct PathArrays {
     ShmRay* ray;            // 32 B: o, d, t_max — input of K2
     ShmHit* hit;            // 32 B: output of K2 — or, with hit16, 16 B per path in the same allocation: {primitive, b0, b1, b2} as one float4
+    const float4* hit_prev; // hit16 renders of an all-diffuse triangle scene: the 16-byte records are double-buffered by bounce parity in the two halves of `hit`; this is the previous bounce's
     uint32_t hit16;         // set per render: a triangle scene without textures under the path integrator (every consumer is a TRI_ONLY kernel, none reads a triangle hit's t)
     ShmRay* shadow_ray;     // 32 B: input of K3
     float4* shadow_contrib; // beta * Ld, added to L by K3 when unoccluded
@@ -357,6 +358,7 @@ struct ShadeArgs {
     int shadow_parity;
     int blocks;
     int first_bounce = 0;  // 1: bounce 0 of a render whose k_generate left the constants out (beta = 1, p_b = eta_scale = 1, flags = 0, the identity queue): the fused kernel knows them
+    int hit_kept = 0;      // 1: the hit records are double-buffered by bounce parity (PathArrays::hit_prev is the previous bounce's): the fused kernel leaves nothing for the next vertex
 };
 WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a);  // the fused kernel: all-diffuse triangle scenes without textures
 WF_INTERNAL int wf_launch_shade_lean_diverted(ShmScene* s, const ShadeArgs& a);
