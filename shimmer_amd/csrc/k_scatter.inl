@@ -2,7 +2,7 @@
 // over the class queue k_vertex filled: next-event estimation (light sample, BSDF f and pdf, deferred shadow ray), BSDF::sample_f, the
 // throughput update, Russian roulette and the spawned ray. A wave of k_scatter<CLASS_DIELECTRIC> only ever runs dielectric code, one of
 // k_scatter<CLASS_LAYERED> only the LayeredBxDF random walks: the queues are sorted by material class by construction.
-// The BSDF is rebuilt from the parameter block (PathArrays::bx*, fr, ctx0..2) exactly as get_bsdf left it.
+// The BSDF is rebuilt from the parameter block (PathArrays::bx — one BxRec — and ctx — one CtxRec) exactly as get_bsdf left it.
 #pragma once
 #include "wavefront.h"
 
@@ -42,7 +42,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
     // options.force_diffuse replaces the BxDF by a DiffuseBxDF (its f is a constant): nothing worth deferring, NEE stays inline
     const bool defer = LAYERED && params.force_diffuse == 0 && !(SHM_EXP_SKIP & 16);
     uint32_t n_jobs = 0;  // wave-uniform
-    // the BxDF and the shading frame as k_vertex left them in the parameter block (c2 = PathArrays::ctx2[path]: n.z and the shading normal)
+    // the BxDF and the shading frame as k_vertex left them in the parameter block (c2 = PathArrays::ctx[path].c2: n.z and the shading normal)
     auto build_bsdf = [&](uint32_t path, const float4& c2, BSDF& bsdf, V3& ns) {
         BxDF& b = bsdf.bxdf;
         const float4 p2 = pa.bx[path].bx2;
@@ -301,7 +301,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                     pa.ray[path] = nr;
                     pa.rec[path].beta = st_spec(beta);
                     pa.rec[path].pb_eta = make_float2(p_b, eta_scale);
-                    // (ctx0..2 already hold this vertex's context: the next vertex's prev_intr_ctx)
+                    // (the CtxRec already holds this vertex's context: the next vertex's prev_intr_ctx)
                     pa.rec[path].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
                     uint32_t aux_bit = 0u;
                     if (HAS_TEX && CLASS != CLASS_DIFFUSE && (fl & (1u << 10)) &&

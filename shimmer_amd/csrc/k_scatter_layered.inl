@@ -222,7 +222,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
                     pa.ray[path] = nr;
                     pa.rec[path].beta = st_spec(beta);
                     pa.rec[path].pb_eta = make_float2(p_b, eta_scale);
-                    // (ctx0..2 already hold this vertex's context: the next vertex's prev_intr_ctx)
+                    // (the CtxRec already holds this vertex's context: the next vertex's prev_intr_ctx)
                     pa.rec[path].rng = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
                     pa.rec[path].flags = (uint32_t)depth | ((uint32_t)specular_bounce << 8) | ((uint32_t)any_non_specular_bounces << 9) | aux_bit;
                 }

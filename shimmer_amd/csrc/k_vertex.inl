@@ -1,7 +1,7 @@
 // k_vertex.inl — staged shading, first half of a path vertex (integrator.rs:772-834 for the vertex K2 found): escaped rays and
 // infinite lights, the interaction, emission with its MIS weight, get_bsdf (compute_differentials, MixMaterial resolution, bump /
 // normal maps, every texture evaluation -> the BxDF's parameters) and the depth test. What survives is written as a parameter block
-// (PathArrays::bx*, fr, ctx0..2) and pushed to the queue of its BxDF CLASS, so that the second half (k_scatter.inl: NEE, sample_f,
+// (PathArrays::bx, one BxRec, and ctx, one CtxRec) and pushed to the queue of its BxDF CLASS, so that the second half (k_scatter.inl: NEE, sample_f,
 // Russian roulette) runs one kernel per class over material-sorted, wave-coherent queues (north star: "wavefront-sorted queues";
 // SURVEY K5). Neither half holds the other's live state: the fused kernel of round 1 spilled up to 942 VGPRs in its general
 // instantiations. The arithmetic of a path is the fused kernel's, operation for operation: films stay bit-identical.

@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
     const float4 lambda4 = make_float4(lambda.lambda[0], lambda.lambda[1], lambda.lambda[2], lambda.lambda[3]);
     pa.lambda[slot] = lambda4;  // (the film's copy: k_film reads wavelengths and pdfs of every sample, and a 64-byte record for 16 of its bytes would triple that)
     pa.lambda_pdf[slot] = make_float4(lambda.pdf[0], lambda.pdf[1], lambda.pdf[2], lambda.pdf[3]);
-    // (ctx0..2, the previous vertex's LightSampleContext, are first read at depth >= 1, after k_shade has written them)
+    // (the CtxRec, the previous vertex's LightSampleContext, is first read at depth >= 1, after k_shade has written them)
     if (LEAN) {
         // no record: the fused kernel's bounce 0 reads these three arrays and writes the path's first record whole (one full 64-byte store instead of this kernel's
         // partial sectors: k_generate 10.5 -> 6 ms per headline frame)

@@ -92,7 +92,7 @@ static_assert(sizeof(PathRec) == 64, "PathRec is one half cache line");
 struct alignas(128) BxRec {
     float4 bx0;   // r[4]: reflectance (Diffuse, CoatedDiffuse) / conductor eta (Conductor, CoatedConductor)
     float4 bx2;   // eta, alpha_x, alpha_y, kind | max_depth << 8 | n_samples << 20 (as bits)
-    float4 fr;    // shading frame x = normalize(dpdus) (y = z cross x is recomputed; z = ns lives in ctx2)
+    float4 fr;    // shading frame x = normalize(dpdus) (y = z cross x is recomputed; z = ns lives in CtxRec::c2)
     float4 bx1;   // k[4]: conductor absorption
     float4 bx3;   // albedo[4]                         (coated materials)
     float4 bx4;   // alpha_x2, alpha_y2, thickness, g  (coated materials)
@@ -122,7 +122,7 @@ struct PathArrays {
     float4* aux1;           // rx_direction.yz, ry_origin.xy
     float4* aux2;           // ry_origin.z, ry_direction.xyz
     // staged shading (k_vertex -> k_scatter<class>; null when the scene runs the fused kernel): the BxDF parameter block get_bsdf
-    // left at this vertex and the x axis of its shading frame. The rest of the vertex geometry (pi, n, ns) is ctx0..2, which
+    // left at this vertex and the x axis of its shading frame. The rest of the vertex geometry (pi, n, ns) is the CtxRec, which
     // k_vertex overwrites with THIS vertex's LightSampleContext once the previous one has served the emitter MIS weight.
     BxRec* bx;              // 128 B: the parameter block as ONE record per path (above)
     uint32_t has_layered;   // the scene holds coated materials: k_vertex writes the record's third sector (bx3, bx4)
