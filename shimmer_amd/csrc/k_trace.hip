@@ -506,6 +506,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     uint32_t path = 0;
     V3 ro = v3s(0.0f), inv_dir = v3s(0.0f);
     unsigned long long m_negx = 0ull, m_negy = 0ull, m_negz = 0ull, m_irregular = 0ull;  // see trace3_body
+    // any-hit, with the render's deferred contributions: L[path] + contrib[path], summed when the ray is TAKEN (the two loads travel with the ray's) and stored when it
+    // ends unoccluded — at the end they were a round trip the whole wave waited for in most iterations (2.4 rays end per iteration); nobody else touches L[path] meanwhile
+    float4 l_new = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t sgn = 0;  // bits 0-2: dir_is_neg, bit 3: irregular ray, bit 4: a hit has been found (closest: its record is in `hits` already)
     RayShear rs;
     rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
@@ -589,6 +592,13 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                             path = queue ? queue[qi] : qi;
                             const float4* rp = reinterpret_cast<const float4*>(rays + path);
                             const float4 r0 = rp[0], r1 = rp[1];
+#ifndef K5_L_AT_REFILL
+#define K5_L_AT_REFILL 1  // (0: L and the contribution are loaded when the ray ends: A/B)
+#endif
+                            if (ANY && K5_L_AT_REFILL && L) {
+                                const float4 l = L[path], c = contrib[path];
+                                l_new = make_float4(l.x + c.x, l.y + c.y, l.z + c.z, l.w + c.w);
+                            }
                             // aggregate.rs:76-81 + the ray-constant part of the triangle test
                             const V3 o = v3(r0.x, r0.y, r0.z), d = v3(r0.w, r1.x, r1.y);
                             ro = o;
@@ -740,9 +750,13 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
             if (ANY) {
                 if (occluded_out) occluded_out[path] = found ? 1 : 0;
                 if (L && !found) {
-                    float4 l = L[path], c = contrib[path];
-                    l.x += c.x; l.y += c.y; l.z += c.z; l.w += c.w;
-                    L[path] = l;
+                    if (K5_L_AT_REFILL) {
+                        L[path] = l_new;
+                    } else {
+                        float4 l = L[path], c = contrib[path];
+                        l.x += c.x; l.y += c.y; l.z += c.z; l.w += c.w;
+                        L[path] = l;
+                    }
                 }
             } else if (!found) {
                 if (hit16) {
