@@ -29,6 +29,7 @@ struct FlatScene {
     std::vector<float> patch_vn, patch_vuv;
     std::vector<ShmMaterial> materials;
     std::vector<ShmLight> lights;
+    std::vector<shm::PrimRec> light_prim_recs;  // per light: the emitter's record (area lights; zeros otherwise): SceneView::light_prim_recs
     std::vector<uint32_t> infinite_lights;
     std::vector<float> spectrum_data;
     std::vector<float> sensor_r, sensor_g, sensor_b;
@@ -83,6 +84,7 @@ struct FlatScene {
         v.materials = materials.data();
         v.lights = lights.data();
         v.n_lights = (uint32_t)lights.size();
+        v.light_prim_recs = light_prim_recs.empty() ? nullptr : light_prim_recs.data();
         v.infinite_lights = infinite_lights.data();
         v.n_infinite_lights = (uint32_t)infinite_lights.size();
         v.spectrum_data = spectrum_data.data();
@@ -579,6 +581,10 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         if (l.kind == SHM_LIGHT_DIFFUSE_AREA && l.primitive >= d->n_primitives) { err = "area light primitive out of range"; return SHM_ERR_INVALID_ARGUMENT; }
         if (l.kind == SHM_LIGHT_UNIFORM_INFINITE) out.infinite_lights.push_back(i);
     }
+    // the emitters' records beside the light table (same bytes as prim_recs[light.primitive]: a light sample starts from this small, cacheable / LDS-staged copy)
+    out.light_prim_recs.assign(out.lights.size(), shm::PrimRec{});
+    for (uint32_t i = 0; i < out.lights.size(); ++i)
+        if (out.lights[i].kind == SHM_LIGHT_DIFFUSE_AREA) out.light_prim_recs[i] = out.prim_recs[out.lights[i].primitive];
 
     // BVH validation + depth (explicit stack; DFS order means child0 = i+1). The top-level tree starts at node 0, the tree of every
     // instanced object at its ShmInstance::root_node; a top-level leaf holding an instance continues into that tree (one more stack

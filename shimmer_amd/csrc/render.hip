@@ -238,7 +238,7 @@ LdsTables wf_lds_tables(const ShmScene* s, uint32_t budget) {
     const shm_host::FlatScene& f = s->flat;
     auto pad16 = [](size_t b) { return (size_t)((b + 15u) & ~(size_t)15u); };  // (dev_upload allocates whole 16-byte groups)
     const size_t want[N_LDS_TABLES] = {
-        pad16(f.mesh_flags.size() * sizeof(uint32_t)), pad16(f.lights.size() * sizeof(ShmLight)), pad16(f.materials.size() * sizeof(ShmMaterial)), pad16(f.spectrum_data.size() * sizeof(float)),
+        pad16(f.mesh_flags.size() * sizeof(uint32_t)), pad16(f.lights.size() * sizeof(ShmLight)), pad16(f.light_prim_recs.size() * sizeof(shm::PrimRec)), pad16(f.materials.size() * sizeof(ShmMaterial)), pad16(f.spectrum_data.size() * sizeof(float)),
         pad16(f.rgb2spec_scale.size() * sizeof(float)),
         pad16(f.image_textures.size() * sizeof(ShmImageTexture)), pad16(f.image_levels.size() * sizeof(ShmImageLevel)), pad16(f.float_textures.size() * sizeof(ShmFloatTexture)),
         pad16(f.ftex_ranges.size() * sizeof(shm::FloatTexRange)), pad16(f.ftex_ops.size() * sizeof(shm::FloatTexOp)), pad16(f.spectrum_textures.size() * sizeof(ShmSpectrumTexture)),
@@ -458,6 +458,8 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if ((rc = dev_upload(s, f.patch_vuv, &v.patch_vuv)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.materials, &v.materials)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.lights, &v.lights)) != SHM_OK) return fail(rc);
+    v.light_prim_recs = nullptr;
+    if (!f.light_prim_recs.empty() && (rc = dev_upload(s, f.light_prim_recs, &v.light_prim_recs)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.infinite_lights, &v.infinite_lights)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.spectrum_data, &v.spectrum_data)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.sensor_r, &v.sensor_r_bar)) != SHM_OK) return fail(rc);

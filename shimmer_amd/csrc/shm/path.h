@@ -92,11 +92,11 @@ SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const Li
     ShapeSampleContext sctx;
     sctx.pi = ctx.pi; sctx.n = ctx.n; sctx.ns = ctx.ns;
     ShapeSample ss;
-    const PrimRec& pr = sv.prim_recs[light.primitive];
+    const PrimRec& pr = light_prim_rec(sv, light);
     bool ok;
     if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) ok = sphere_sample_with_context(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], sctx, u, ss);
     else if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) ok = blp_sample_with_context(load_patch(sv, light.primitive), sctx, u, ss);
-    else ok = triangle_sample_with_context(load_triangle(sv, light.primitive), sctx, u, ss);
+    else ok = triangle_sample_with_context(load_triangle_rec(sv, pr), sctx, u, ss);
     if (!ok) return false;
     if (ss.pdf == 0.0f || length_squared(ss.pi.mid() - ctx.p()) == 0.0f) return false;
     V3 wi = normalize(ss.pi.mid() - ctx.p());
@@ -119,10 +119,10 @@ SHM_HD Float light_pdf_li(const SceneView& sv, const ShmLight& light, const Ligh
     if (light.kind != SHM_LIGHT_DIFFUSE_AREA) return 0.0f;  // light.rs:470-477, 774-775
     ShapeSampleContext sctx;
     sctx.pi = ctx.pi; sctx.n = ctx.n; sctx.ns = ctx.ns;
-    const PrimRec& pr = sv.prim_recs[light.primitive];
+    const PrimRec& pr = light_prim_rec(sv, light);
     if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) return sphere_pdf_with_context(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], sctx, wi, sv.quirks_off != 0);
     if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) return blp_pdf_with_context(load_patch(sv, light.primitive), sctx, wi);
-    return triangle_pdf_with_context(load_triangle(sv, light.primitive), sctx, wi);
+    return triangle_pdf_with_context(load_triangle_rec(sv, pr), sctx, wi);
 }
 // Light::le of an infinite light for an escaped ray: UniformInfiniteLight (light.rs:795-797) or ImageInfinitelight (:900-904)
 template <bool HAS_TEX = false>

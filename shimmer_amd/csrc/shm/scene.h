@@ -62,6 +62,8 @@ struct SceneView {
     const ShmMaterial* materials;
     const ShmLight* lights;
     uint32_t n_lights;
+    const struct PrimRec* light_prim_recs;  // per light: a copy of prim_recs[light.primitive] (area lights; zeros otherwise) — small enough to sit beside the light table in LDS,
+                                           // so that a light sample does not start with a dependent fetch of the emitter's record from the 200 MB array (null: not built)
     const uint32_t* infinite_lights;  // indices into lights (integrator.rs:86-92)
     uint32_t n_infinite_lights;
     const Float* spectrum_data;
@@ -132,8 +134,7 @@ struct ImageLightRec {
 SHM_HD V3 ld3(const Float* p) { return v3(p[0], p[1], p[2]); }
 
 // Triangle::get_points + mesh attribute fetch (shape/triangle.rs:148-160, 311-320)
-SHM_HD TriangleData load_triangle(const SceneView& sv, uint32_t slot) {
-    const PrimRec& pr = sv.prim_recs[slot];
+SHM_HD TriangleData load_triangle_rec(const SceneView& sv, const PrimRec& pr) {
     TriangleData t;
     t.p0 = ld3(pr.p0);
     t.p1 = ld3(pr.p1);
@@ -157,6 +158,11 @@ SHM_HD TriangleData load_triangle(const SceneView& sv, uint32_t slot) {
         }
     }
     return t;
+}
+SHM_HD TriangleData load_triangle(const SceneView& sv, uint32_t slot) { return load_triangle_rec(sv, sv.prim_recs[slot]); }
+// the emitter's record of an area light: the per-light copy when the scene has one (same bytes)
+SHM_HD const PrimRec& light_prim_rec(const SceneView& sv, const ShmLight& light) {
+    return sv.light_prim_recs ? sv.light_prim_recs[&light - sv.lights] : sv.prim_recs[light.primitive];
 }
 
 // BilinearPatch::get_points (bilinear_patch.rs:87-98) + the constants fixed at scene creation

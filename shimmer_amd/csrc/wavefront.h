@@ -166,7 +166,7 @@ __device__ __forceinline__ void st_aux(const PathArrays& pa, uint32_t path, cons
 // (host side: wf_lds_tables); a scene whose tables exceed the budget runs with the global pointers (bytes = 0).
 constexpr uint32_t LDS_TABLE_BUDGET = 12 * 1024, LDS_TABLE_BUDGET_SMALL = 1536;
 // the tables a kernel may stage, hottest and smallest first (the host fills a kernel's budget greedily in this order: wf_lds_tables, render.hip)
-enum : int { LT_MESH_FLAGS, LT_LIGHTS, LT_MATERIALS, LT_SPECTRUM, LT_RGB2SPEC_SCALE, LT_IMAGE_TEXTURES, LT_IMAGE_LEVELS, LT_FLOAT_TEXTURES, LT_FTEX_RANGES, LT_FTEX_OPS, LT_SPECTRUM_TEXTURES,
+enum : int { LT_MESH_FLAGS, LT_LIGHTS, LT_LIGHT_PRIMS, LT_MATERIALS, LT_SPECTRUM, LT_RGB2SPEC_SCALE, LT_IMAGE_TEXTURES, LT_IMAGE_LEVELS, LT_FLOAT_TEXTURES, LT_FTEX_RANGES, LT_FTEX_OPS, LT_SPECTRUM_TEXTURES,
               LT_STEX_RANGES, LT_STEX_OPS, LT_EWA_LUT, N_LDS_TABLES };  // (rgb2spec's scale table: 64 floats, walked by a binary search of six DEPENDENT loads per lookup)
 struct LdsTables {
     uint32_t bytes[N_LDS_TABLES];  // each a multiple of 16 (dev_upload allocates whole 16-byte groups); 0: that table stays in global memory
@@ -188,6 +188,7 @@ __device__ __forceinline__ SceneView stage_scene_tables(const SceneView& sv, con
     }
     SHM_STAGE_TABLE(LT_MESH_FLAGS, mesh_flags, uint32_t)
     SHM_STAGE_TABLE(LT_LIGHTS, lights, ShmLight)
+    SHM_STAGE_TABLE(LT_LIGHT_PRIMS, light_prim_recs, PrimRec)
     SHM_STAGE_TABLE(LT_MATERIALS, materials, ShmMaterial)
     SHM_STAGE_TABLE(LT_SPECTRUM, spectrum_data, Float)
     SHM_STAGE_TABLE(LT_RGB2SPEC_SCALE, rgb2spec_scale, Float)
