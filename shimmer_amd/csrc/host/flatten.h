@@ -269,7 +269,7 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         out.patch_vuv.assign(2, 0.0f);
     }
 
-    // 48-B leaf-order records
+    // 64-B leaf-order records
     out.prim_recs.resize(d->n_primitives);
     for (uint32_t s = 0; s < d->n_primitives; ++s) {
         const ShmPrimitive& pr = d->primitives[s];
@@ -281,6 +281,8 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         if (pr.material == 0xffffffffu) { err = "primitive without a material (medium interface, skip_intersection) is not supported"; return SHM_ERR_UNSUPPORTED; }
         if (pr.material >= d->n_materials) { err = "primitive material out of range"; return SHM_ERR_INVALID_ARGUMENT; }
         if (pr.area_light >= (int32_t)d->n_lights) { err = "primitive area light out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+        rec.material = pr.material;
+        rec.area_light = pr.area_light;
         if (pr.shape_kind == SHM_SHAPE_SPHERE) {
             if (pr.shape_index >= d->n_spheres) { err = "sphere index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
             rec.kind_index = shm::PRIM_SPHERE_BIT | pr.shape_index;

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                 }
             } else {
                 SurfaceInteraction si = hit_interaction<TRI_ONLY>(sv, hit, -ray_d);
-                const ShmPrimitive prim = sv.primitives[hit.prim];
+                const PrimRec& prim = sv.prim_recs[hit.prim];  // (material and emitter ride in the record the interaction fetches anyway)
                 // integrator.rs:798-813: emission at the hit
                 if (!EMIT_INLINE && prim.area_light >= 0) {
                     // the hit is on an emitter (rare): its `L += beta * Le` — with the MIS weight's inverted light sampling — is k_emit_jobs's, after this launch; what
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathAr
         const int depth = (int)(fl & 0xffu);
         const bool specular_bounce = (fl >> 8) & 1u;
         const SurfaceInteraction si = hit_interaction<TRI_ONLY>(sv, hit, -ray_d);
-        const ShmPrimitive prim = sv.primitives[hit.prim];
+        const PrimRec& prim = sv.prim_recs[hit.prim];  // (material and emitter ride in the record the interaction fetches anyway)
         const ShmLight& light = sv.lights[prim.area_light];
         const Spec le = area_light_l(sv, light, si.n, -ray_d, lambda);
         if (!is_zero(le)) {
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathAr
                     // (get_bsdf belongs to it: a material with a displacement — the reference's constant one included — resets the shading geometry, interaction.rs:223-245)
                     SurfaceInteraction sp = hit_interaction<TRI_ONLY>(sv, ph, v3s(0.0f));
                     Wavelengths lw = lambda;
-                    (void)get_bsdf<HAS_TEX>(sv, sp, sv.materials[sv.primitives[ph.prim].material], lw);
+                    (void)get_bsdf<HAS_TEX>(sv, sp, sv.materials[sv.prim_recs[ph.prim].material], lw);
                     c = light_ctx_from(sp);
                 } else {
                     const float4 c1 = pa.e_ctx1[path], c2 = pa.e_ctx2[path];

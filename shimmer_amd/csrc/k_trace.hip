@@ -268,7 +268,7 @@ __device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t*
                     for (uint32_t i = 0; i < leaf_n; ++i) {
                         uint32_t slot = leaf_off + i;
                         c_prims++;
-                        const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * 48u);
+                        const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * sizeof(PrimRec));
                         float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
                         bool got;
                         if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_INSTANCE_BIT)) {
@@ -696,7 +696,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                     const uint32_t slot = cur & LINK_INDEX_MASK;
                     uint32_t leaf_n = (cur >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX;
                     if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[slot];  // (rare: 15 or more primitives in one leaf; the table holds the count from each slot on)
-                    const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * 48u);
+                    const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * sizeof(PrimRec));
                     const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
                     // (the precomputed degeneracy flag is applied to the RESULT, see trace3_body)
                     TriangleIntersection ti;

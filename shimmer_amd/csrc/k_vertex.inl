@@ -38,7 +38,7 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
           auto key_of = [&](uint32_t path) -> uint32_t {
               const int prim = __float_as_int((TRI_ONLY && pa.hit16) ? reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + path)[0] : reinterpret_cast<const float*>(pa.hit + path)[0]);
               if (prim < 0) return (uint32_t)VERTEX_SORT_BINS;
-              const uint32_t m = sv.primitives[prim].material;
+              const uint32_t m = sv.prim_recs[prim].material;
               return m < (uint32_t)VERTEX_SORT_BINS ? m : (uint32_t)VERTEX_SORT_BINS - 1u;
           };
           if (threadIdx.x <= VERTEX_SORT_BINS) s_bin[threadIdx.x] = 0;
@@ -142,11 +142,11 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
                     __builtin_assume(light.kind != SHM_LIGHT_DIFFUSE_AREA);
                     emit(infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda), light);
                 }
-            } else if (divert && sv.materials[sv.primitives[hit.prim].material].kind == SHM_MATERIAL_DIFFUSE) {
+            } else if (divert && sv.materials[sv.prim_recs[hit.prim].material].kind == SHM_MATERIAL_DIFFUSE) {
                 push_class = N_BXDF_CLASSES;  // the fused kernel takes this vertex from its start (emission included)
             } else {
                 SurfaceInteraction si = hit_interaction<TRI_ONLY>(sv, hit, -ray_d);
-                const ShmPrimitive prim = sv.primitives[hit.prim];
+                const PrimRec& prim = sv.prim_recs[hit.prim];  // (material and emitter ride in the record the interaction fetches anyway)
                 // integrator.rs:798-813: emission at the hit
                 if (prim.area_light >= 0) {
                     const ShmLight& light = sv.lights[prim.area_light];

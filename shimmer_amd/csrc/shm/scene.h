@@ -22,7 +22,13 @@ struct PrimRec {
     uint32_t kind_index;  // bit 31: sphere, bit 30: bilinear patch; low bits: sphere / patch index (0 for a triangle)
     uint32_t mesh;        // triangle: mesh id
     uint32_t tri;         // triangle: global triangle index
+    // ... and, filling the record to 64 bytes, the ShmPrimitive fields the shading kernels read of a hit: one aligned 64-byte fetch gives a triangle test its three vertices
+    // (48-byte records straddled a 64-byte boundary every other time) and a vertex its material and emitter as well (a second gather from `primitives` before)
+    uint32_t material;
+    int32_t area_light;
+    uint32_t pad[2];
 };
+static_assert(sizeof(PrimRec) == 64, "PrimRec is one aligned 64-byte record");
 // A bilinear patch keeps p00, p10, p01 in {p0, p1, p2}; its fourth corner and the per-patch constants live here.
 struct PatchExtra {
     Float p11[3];
@@ -38,7 +44,6 @@ constexpr uint32_t PRIM_DEGENERATE_BIT = 0x10000000u;  // a triangle whose edge 
                                                        // else): evaluated once at scene creation with the shared arithmetic, so the traversal kernel
                                                        // skips 20 instructions of every leaf test (the oracle evaluates the check itself)
 constexpr uint32_t PRIM_INDEX_MASK = 0x0fffffffu;
-static_assert(sizeof(PrimRec) == 48, "PrimRec must be 48 bytes");
 constexpr uint32_t PRIM_SPHERE_BIT = 0x80000000u;
 
 enum : uint32_t { MESH_HAS_N = 1, MESH_HAS_S = 2, MESH_HAS_UV = 4, MESH_FLIP = 8 };
