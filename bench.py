@@ -250,6 +250,12 @@ def side_results(lib, args, render, scenes, headline_scene, log):
             timed("coated_S3_1024x1024_spp256", headline_scene.desc, 256, args.max_depth, headline_scene.info["n_primitives"])
         finally:
             C.memmove(C.byref(headline_scene.desc.materials[0]), C.byref(saved), C.sizeof(saved))
+        # the headline frame with the shapes a real PBRT-v4 scene mixes into its triangles (round 5): the window emitter as ONE bilinear patch (what a quad PLY
+        # face becomes, shape/shape.rs:119-134), a sphere beside the object, the object as a TransformedPrimitive (primitive.rs:136-176)
+        for variant, name in (("patch_emitter", "S3_patch_emitter"), ("one_sphere", "S3_with_one_sphere"), ("instanced", "S3_instanced")):
+            sc = scenes.ganesha_proxy(lib, 1024, 1024, n=args.n, variant=variant)
+            timed(f"{name}_1024x1024_spp256", sc.desc, 256, args.max_depth, sc.info["n_primitives"])
+            del sc
         sc = scenes.crown_proxy(lib, 1000, 1400)
         timed("C4_crown_proxy_1000x1400_spp256_depth32", sc.desc, 256, 32, sc.info["n_primitives"])
         c4 = out["C4_crown_proxy_1000x1400_spp256_depth32"]

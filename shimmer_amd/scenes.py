@@ -10,6 +10,7 @@ and are not available offline; SURVEY §8d defines these stand-ins).
 All geometry is generated in world space and moved to render space with the camera-world translation
 (camera.rs:507-523), as TriangleMesh::new does at load time (shape/mesh.rs:43-46).
 """
+import functools
 from types import SimpleNamespace
 
 import numpy as np
@@ -246,6 +247,7 @@ def _value_noise(p, seed, octaves=3):
     return total
 
 
+@functools.lru_cache(maxsize=2)
 def cube_sphere(n, seed=1234, amplitude=0.15, shuffle_seed=99):
     """Closed genus-0 cube-sphere: 6 faces x n x n quads x 2 triangles with shared vertices (6 n^2 + 2), unit radius,
     radially displaced by value noise; triangle order randomised (seeded Fisher-Yates / permutation)."""
@@ -286,9 +288,14 @@ def cube_sphere(n, seed=1234, amplitude=0.15, shuffle_seed=99):
     return verts, tris
 
 
-def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=False):
+def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=False, variant=None):
     """S3 (configs C3/C5): n=599 gives 6*599^2*2 = 4 305 612 triangles and 2 152 808 vertices.
-    coated=True: the object is CoatedDiffuse (the material of the reference's Ganesha render, images/shimmer-ganesha-1.png)."""
+    coated=True: the object is CoatedDiffuse (the material of the reference's Ganesha render, images/shimmer-ganesha-1.png).
+    variant (round 5: the shapes a real PBRT-v4 scene mixes into its triangles; same camera, room and object):
+      "patch_emitter"  the window emitter is ONE bilinear patch — what a quad face of a PLY file becomes (shape/shape.rs:119-134, shape/mesh.rs:233-256)
+      "one_sphere"     a diffuse sphere stands on the floor beside the object (shape/sphere.rs)
+      "instanced"      the object is an object definition placed once through a TransformedPrimitive (primitive.rs:136-176)"""
+    assert variant in (None, "patch_emitter", "one_sphere", "instanced")
     b = SceneBuilder()
     b.set_film(width, height)
     rfw = b.set_camera_look_at(lib, (0.0, 0.6, 4.2), (0.0, 0.0, 0.0), (0, 1, 0), 38.0)
@@ -296,7 +303,17 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
     wall = b.material_diffuse(0.6)
     black = b.material_diffuse(0.0)
     verts, tris = cube_sphere(n)
-    b.add_mesh(_to_render(verts, rfw), tris, obj)
+    if variant == "instanced":
+        b.begin_object("object")
+        b.add_mesh(verts, tris, obj)  # object space
+        b.end_object()
+        b.add_instance("object", rfw)  # render_from_instance = render_from_world x identity (loading/scene.rs:855-866)
+    else:
+        b.add_mesh(_to_render(verts, rfw), tris, obj)
+    if variant == "one_sphere":
+        rfo = np.eye(4, dtype=np.float32)
+        rfo[:3, 3] = _to_render(np.array([[1.75, -0.8, 0.9]], np.float32), rfw)[0]
+        b.add_sphere(0.45, wall, render_from_object=rfo)
     if with_room:
         # ground (2) + open room (10: back, left, right, ceiling, front-top strip) + window emitter (2)
         p, vi = _quad((-4, -1.25, -4), (-4, -1.25, 6), (4, -1.25, 6), (4, -1.25, -4))
@@ -311,8 +328,11 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
         b.add_mesh(_to_render(room[0], rfw), room[1], wall)
         # window emitter high on the left, facing +x/-y into the room (one-sided)
         p, vi = _quad((-3.9, 1.0, -1.5), (-3.9, 3.0, -1.5), (-3.9, 3.0, 1.5), (-3.9, 1.0, 1.5))
-        b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=40.0)
-    return _finish(b, lib, name=f"S3 ganesha-proxy n={n}" + (" (coated)" if coated else ""))
+        if variant == "patch_emitter":  # p00, p10, p01, p11 (bilinear_patch.rs:87-98): the same quad, the same side emitting
+            b.add_patch_mesh(_to_render(p, rfw), [[0, 1, 3, 2]], black, emission=blackbody_dense(6500.0), emission_scale=40.0)
+        else:
+            b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=40.0)
+    return _finish(b, lib, name=f"S3 ganesha-proxy n={n}" + (" (coated)" if coated else "") + (f" [{variant}]" if variant else ""))
 
 
 def icosphere(level):
