@@ -459,15 +459,31 @@ __device__ unsigned long long g_census[16];
 #else
 #define CENSUS(i, v) do { } while (0)
 #endif
-enum : uint32_t { CUR_IDLE = 0x7fffffffu, CUR_POP = 0x7ffffffeu, CUR_DONE = 0x7ffffffdu, CUR_FIRST_SPECIAL = 0x60000000u };
+enum : uint32_t { CUR_IDLE = 0x7fffffffu, CUR_POP = 0x7ffffffeu, CUR_DONE = 0x7ffffffdu, CUR_FIRST_SPECIAL = 0x60000000u,
+                  CUR_MARKER = 0x60000000u };  // (GEN: CUR_MARKER | leaf slot of the instance — the stack entry that leads back out of it; never a lane's `cur`: slots are below 2^27)
+constexpr uint32_t SGN_RAY = 15u, SGN_HIT = 16u, SGN_HIT_INSIDE = 32u, SGN_INST_SHIFT = 6u;  // trace5_body's `sgn` word (see there)
 
-template <bool ANY, int LDS_N>
+// GEN (round 5): scenes that hold anything but top-level triangles — spheres, bilinear patches, TransformedPrimitives. The node step is shape-agnostic and unchanged, and so
+// is the triangle leaf phase, but for one select: a lane whose record turns out to be no triangle PARKS — bit 30 of its link word, "this slot's test is pending" — and the
+// wave collects such lanes as it collects pending leaves: when `other_min` of them wait (or nothing else can run), one dense round runs Sphere::intersect (sphere.rs:95-196),
+// BilinearPatch::intersect (bilinear_patch.rs:144-236) or the way into an instance (primitive.rs:158-176: a marker {CUR_MARKER | the instance's slot, t_max outside |
+// phantoms below} goes on the stack, the ray is taken into the instance's space, the instance's root is tested by the reference's chain as a refill tests the scene's;
+// popping the marker brings the outer ray back and names the instance in the hit record if the closest hit was found inside). Same primitives in the same order per ray as
+// the reference's loop; postponing a test changes nothing a ray can see (as for triangles).
+// The loop carries NO register the triangle kernel does not, and the heavy arithmetic of that round does not raise the loop's register pressure: the ray's direction is read
+// back from the ray array where it is needed (inside an instance: through the instance's matrix again), the instance's index lives in the upper bits of `sgn`, its slot in
+// the marker — and the ray state the loop keeps (origin, reciprocals, shear: 44 bytes) is WRITTEN to a per-lane save area in HBM before a quadric / patch test and read back
+// behind it, so that nothing but path, t_max, stack pointer and link word is live across ~1 000 instructions of interval arithmetic (inlined with the state live, they made
+// the loop itself spill; as real calls, the calling convention's caller-saved registers did the same). An instance's entry saves the OUTER ray state the same way: leaving is
+// three loads, not a second ray set-up. The hit record is the ABI's 32-byte ShmHit (t, phi and the instance ride along).
+template <bool ANY, bool GEN, int LDS_N>
 __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
                                             uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
                                             ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
                                             float4* __restrict__ L, const float4* __restrict__ contrib,
                                             DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
-                                            int refill_min, int leaf_min, int queue_parts, int rays_per_lane, int hit16, const uint32_t* __restrict__ big_leaf_n) {
+                                            int refill_min, int leaf_min, int queue_parts, int rays_per_lane, int hit16, const uint32_t* __restrict__ big_leaf_n,
+                                            float4* gen_save, int other_min) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) u32x2 lds_u2;
     __shared__ u32x2 lds_stack5[(TRACE_BLOCK / WAVE) * LDS_N * WAVE];
@@ -477,6 +493,8 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     lds_u2* const st_base = (lds_u2*)lds_stack5 + wave_in_block * LDS_N * WAVE + lane;
     lds_u2* top = st_base;
     u32x2* const st_spill_wave = reinterpret_cast<u32x2*>(spill) + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE;
+    // GEN: this wave's two save areas of 3 float4 per lane, [area][k][lane] (area 0: the outer ray's state while an instance is traversed; area 1: around a quadric / patch test)
+    float4* const save_wave = GEN ? gen_save + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)(6 * WAVE) : nullptr;
     const uint32_t n = n_ptr ? *n_ptr : n_direct;
     // (a small queue is traced by a part of the persistent grid: see trace3_body)
     const uint32_t per_block = (uint32_t)TRACE_BLOCK * (uint32_t)(rays_per_lane > 0 ? rays_per_lane : 1);
@@ -509,11 +527,63 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     // any-hit, with the render's deferred contributions: L[path] + contrib[path], summed when the ray is TAKEN (the two loads travel with the ray's) and stored when it
     // ends unoccluded — at the end they were a round trip the whole wave waited for in most iterations (2.4 rays end per iteration); nobody else touches L[path] meanwhile
     float4 l_new = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t sgn = 0;  // bits 0-2: dir_is_neg, bit 3: irregular ray, bit 4: a hit has been found (closest: its record is in `hits` already)
+    uint32_t sgn = 0;  // bits 0-2: dir_is_neg, bit 3: irregular ray, bit 4: a hit has been found (closest: its record is in `hits` already); GEN: bit 5: ... inside the instance
+                       // being traversed (closest-hit: t_max stays the inner one when the marker is popped, as primitive.rs:158-171 returns it), bits 6-31: that instance's index + 1
     RayShear rs;
     rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
     Float t_max = 0.0f;
     uint32_t cur = CUR_IDLE;
+
+    // aggregate.rs:76-81 + the ray-constant part of the triangle test (the upper bits of sgn — what has been found so far, the instance — belong to the path, not to the ray)
+    auto set_ray = [&](V3 o, V3 d) {
+        ro = o;
+        inv_dir = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const bool regular = is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(inv_dir.x) && is_finite(inv_dir.y) && is_finite(inv_dir.z) &&
+                             inv_dir.x != 0.0f && inv_dir.y != 0.0f && inv_dir.z != 0.0f;
+        sgn = (sgn & ~SGN_RAY) | (inv_dir.x < 0.0f ? 1u : 0u) | (inv_dir.y < 0.0f ? 2u : 0u) | (inv_dir.z < 0.0f ? 4u : 0u) | (regular ? 0u : 8u);
+        rs = ray_shear(d);
+    };
+    // a tree's root (aggregate.rs:92-97, first iteration), by the reference's own chain: once per ray and tree, and this lane's sign masks do not exist yet
+    auto root_test = [&](const float4 ra, const float4 rb) -> bool {
+        const Float g = 1.0f + 2.0f * gamma(3);
+        const bool nx = (sgn & 1u) != 0u, ny = (sgn & 2u) != 0u, nz = (sgn & 4u) != 0u;
+        Float t0 = ((nx ? ra.w : ra.x) - ro.x) * inv_dir.x;
+        Float t1 = ((nx ? ra.x : ra.w) - ro.x) * inv_dir.x;
+        const Float ty0 = ((ny ? rb.x : ra.y) - ro.y) * inv_dir.y;
+        Float ty1 = ((ny ? ra.y : rb.x) - ro.y) * inv_dir.y;
+        t1 *= g;
+        ty1 *= g;
+        bool ok = !(t0 > ty1 || ty0 > t1);
+        if (ty0 > t0) t0 = ty0;
+        if (ty1 < t1) t1 = ty1;
+        const Float tz0 = ((nz ? rb.y : ra.z) - ro.z) * inv_dir.z;
+        Float tz1 = ((nz ? ra.z : rb.y) - ro.z) * inv_dir.z;
+        tz1 *= g;
+        ok = ok && !(t0 > tz1 || tz0 > t1);
+        if (tz0 > t0) t0 = tz0;
+        if (tz1 < t1) t1 = tz1;
+        return ok && (t0 < t_max) && (t1 > 0.0f);
+    };
+
+    // GEN: the ray state the loop keeps, out to / back from one of the lane's two save areas
+    auto save_ray_state = [&](int area) {
+        float4* a = save_wave + (size_t)area * (3 * WAVE) + lane;
+        a[0] = make_float4(ro.x, ro.y, ro.z, inv_dir.x);
+        a[WAVE] = make_float4(inv_dir.y, inv_dir.z, rs.sx, rs.sy);
+        a[2 * WAVE] = make_float4(rs.sz, __int_as_float(rs.kz), __uint_as_float(sgn & SGN_RAY), 0.0f);
+    };
+    auto restore_ray_state = [&](int area) {
+        asm volatile("" ::: "memory");  // (the loads below must be loads: with the stored values forwarded, the state would be live across what lies in between)
+        const float4* a = save_wave + (size_t)area * (3 * WAVE) + lane;
+        const float4 s0 = a[0], s1 = a[WAVE], s2 = a[2 * WAVE];
+        ro = v3(s0.x, s0.y, s0.z);
+        inv_dir = v3(s0.w, s1.x, s1.y);
+        rs.sx = s1.z; rs.sy = s1.w; rs.sz = s2.x;
+        rs.kz = __float_as_int(s2.y);
+        rs.kx = rs.kz == 2 ? 0 : rs.kz + 1;
+        rs.ky = rs.kx == 2 ? 0 : rs.kx + 1;
+        sgn = (sgn & ~SGN_RAY) | __float_as_uint(s2.z);
+    };
 
     // Bounds3f::intersect_p_cached (bounding_box.rs:520-563) without its `t0 < t_max`: the t_max-independent part of the verdict, and t0
     auto slab = [&](const float4 na, const float4 nb, Float& t0_out) -> bool {
@@ -599,40 +669,14 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                                 const float4 l = L[path], c = contrib[path];
                                 l_new = make_float4(l.x + c.x, l.y + c.y, l.z + c.z, l.w + c.w);
                             }
-                            // aggregate.rs:76-81 + the ray-constant part of the triangle test
-                            const V3 o = v3(r0.x, r0.y, r0.z), d = v3(r0.w, r1.x, r1.y);
-                            ro = o;
-                            inv_dir = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                            const bool regular = is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(inv_dir.x) && is_finite(inv_dir.y) && is_finite(inv_dir.z) &&
-                                                 inv_dir.x != 0.0f && inv_dir.y != 0.0f && inv_dir.z != 0.0f;
-                            sgn = (inv_dir.x < 0.0f ? 1u : 0u) | (inv_dir.y < 0.0f ? 2u : 0u) | (inv_dir.z < 0.0f ? 4u : 0u) | (regular ? 0u : 8u);
-                            rs = ray_shear(d);
+                            sgn = 0u;
+                            set_ray(v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y));
                             t_max = r1.z;
                             top = st_base;
                             if (ANY) ph_top = 0u;
-                            // the root (aggregate.rs:92-97, first iteration), by the reference's own chain: once per ray, and this lane's sign masks do not exist yet
-                            {
-                                const Float g = 1.0f + 2.0f * gamma(3);
-                                const bool nx = (sgn & 1u) != 0u, ny = (sgn & 2u) != 0u, nz = (sgn & 4u) != 0u;
-                                Float t0 = ((nx ? root_a.w : root_a.x) - ro.x) * inv_dir.x;
-                                Float t1 = ((nx ? root_a.x : root_a.w) - ro.x) * inv_dir.x;
-                                const Float ty0 = ((ny ? root_b.x : root_a.y) - ro.y) * inv_dir.y;
-                                Float ty1 = ((ny ? root_a.y : root_b.x) - ro.y) * inv_dir.y;
-                                t1 *= g;
-                                ty1 *= g;
-                                bool ok = !(t0 > ty1 || ty0 > t1);
-                                if (ty0 > t0) t0 = ty0;
-                                if (ty1 < t1) t1 = ty1;
-                                const Float tz0 = ((nz ? root_b.y : root_a.z) - ro.z) * inv_dir.z;
-                                Float tz1 = ((nz ? root_a.z : root_b.y) - ro.z) * inv_dir.z;
-                                tz1 *= g;
-                                ok = ok && !(t0 > tz1 || tz0 > t1);
-                                if (tz0 > t0) t0 = tz0;
-                                if (tz1 < t1) t1 = tz1;
-                                ok = ok && (t0 < t_max) && (t1 > 0.0f);
-                                cur = ok ? __float_as_uint(root_b.z) : (uint32_t)CUR_POP;  // (a miss pops the empty stack: done, retired below)
-                                if (ANY) c_nodes += 1u;
-                            }
+                            // the root: tested where the ray is taken from the queue
+                            cur = root_test(root_a, root_b) ? __float_as_uint(root_b.z) : (uint32_t)CUR_POP;  // (a miss pops the empty stack: done, retired below)
+                            if (ANY) c_nodes += 1u;
                         }
                     }
                     w_next += take;
@@ -681,7 +725,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
             cur = hit_n ? link_n : (hit_f ? link_f : (uint32_t)CUR_POP);
         }
         // ---- postponed leaf phase: lanes standing on a leaf wait until enough of them do (or nothing else can run) ----
-        const unsigned long long leaf_mask = __ballot((int32_t)cur < 0);
+        constexpr uint32_t NOT_A_TRIANGLE = PRIM_SPHERE_BIT | PRIM_PATCH_BIT | PRIM_INSTANCE_BIT;
+        constexpr uint32_t LEAF_KIND = LINK_LEAF | LINK_OTHER;  // (GEN: a leaf link with bit 30 set is a parked non-triangle test, below)
+        const unsigned long long leaf_mask = GEN ? __ballot((cur & LEAF_KIND) == LINK_LEAF) : __ballot((int32_t)cur < 0);
         if (leaf_mask != 0ull) {
             const unsigned long long node_mask = __ballot(cur < (uint32_t)CUR_FIRST_SPECIAL);
             if (__popcll(leaf_mask) >= leaf_min || node_mask == 0ull) {
@@ -689,36 +735,127 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                 // its link word advanced to the next one — same primitives, same order, same t_max updates as the reference's inner loop, but every round of
                 // triangle tests runs with all the pending lanes (as an inner loop, the second rounds ran for the few lanes on such leaves: 0.62 extra rounds
                 // per phase, 13 % of the kernel's instructions on the headline frame)
-                const bool on_leaf = (int32_t)cur < 0;
-                w_prims += (unsigned long long)__popcll(__ballot(on_leaf));
+                const bool on_leaf = GEN ? ((cur & LEAF_KIND) == LINK_LEAF) : ((int32_t)cur < 0);
+                if (!GEN) w_prims += (unsigned long long)__popcll(__ballot(on_leaf));
                 CENSUS(5, 1); CENSUS(6, 1); CENSUS(7, __popcll(__ballot(on_leaf)));
+                bool tested = false;  // (GEN: the lanes whose record was a triangle; the others park)
                 if (on_leaf) {
                     const uint32_t slot = cur & LINK_INDEX_MASK;
                     uint32_t leaf_n = (cur >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX;
-                    if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[slot];  // (rare: 15 or more primitives in one leaf; the table holds the count from each slot on)
+                    if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[slot];  // (rare: 7 or more primitives in one leaf; the table holds the count from each slot on)
                     const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * sizeof(PrimRec));
                     const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
-                    // (the precomputed degeneracy flag is applied to the RESULT, see trace3_body)
+                    const uint32_t kind = __float_as_uint(q2.y);
+                    tested = !GEN || (kind & NOT_A_TRIANGLE) == 0u;
+                    // (the precomputed degeneracy flag is applied to the RESULT, see trace3_body; GEN: so is "this record is no triangle at all" — the test has no side effect)
                     TriangleIntersection ti;
                     bool got = intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
-                    got = got && !(__float_as_uint(q2.y) & PRIM_DEGENERATE_BIT);
+                    got = got && !(kind & PRIM_DEGENERATE_BIT) && tested;
                     if (got) {
-                        sgn |= 16u;
+                        sgn |= GEN ? (SGN_HIT | SGN_HIT_INSIDE) : SGN_HIT;
                         if (!ANY) {
                             t_max = ti.t;  // aggregate.rs:105-109 shrinks the ray to the hit
-                            if (hit16) {
+                            if (!GEN && hit16) {
                                 reinterpret_cast<float4*>(hits)[path] = make_float4(__int_as_float((int32_t)slot), ti.b0, ti.b1, ti.b2);
                             } else {
                                 float4* hp = reinterpret_cast<float4*>(hits + path);
                                 hp[0] = make_float4(__int_as_float((int32_t)slot), ti.t, ti.b0, ti.b1);
-                                hp[1] = make_float4(ti.b2, 0.0f, 0.0f, 0.0f);
+                                hp[1] = make_float4(ti.b2, 0.0f, 0.0f, 0.0f);  // (GEN: a hit inside an instance gets the instance's slot when the marker is popped)
                             }
                         }
                     }
                     leaf_n -= 1u;
-                    if (ANY && got) cur = CUR_DONE;  // intersect_predicate returns at its first hit (aggregate.rs:160-166)
+                    if (GEN && !tested) cur |= LINK_OTHER;  // no triangle: the lane parks on this slot until the wave runs its other tests
+                    else if (ANY && got) cur = CUR_DONE;    // intersect_predicate returns at its first hit (aggregate.rs:160-166)
                     else if (leaf_n == 0u) cur = CUR_POP;
                     else cur = LINK_LEAF | ((leaf_n < LINK_COUNT_MAX ? leaf_n : LINK_COUNT_MAX) << LINK_COUNT_SHIFT) | (slot + 1u);
+                }
+                if (GEN) w_prims += (unsigned long long)__popcll(__ballot(tested));
+            }
+        }
+        // ---- GEN: the parked non-triangle tests, run like the leaf phase — when enough lanes wait for one, or when nothing else can run ----
+        if (GEN) {
+            const unsigned long long other_mask = __ballot(cur >= LEAF_KIND);
+            if (other_mask != 0ull) {
+                const bool busy_elsewhere = __ballot(cur < (uint32_t)CUR_FIRST_SPECIAL || (cur & LEAF_KIND) == LINK_LEAF) != 0ull;
+                if (__popcll(other_mask) >= other_min || !busy_elsewhere) {
+                    w_prims += (unsigned long long)__popcll(other_mask);
+                    bool entered = false;
+                    if (cur >= LEAF_KIND) {
+                        const uint32_t slot = cur & LINK_INDEX_MASK;
+                        uint32_t leaf_n = (cur >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX;
+                        if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[slot];
+                        const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * sizeof(PrimRec));
+                        const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+                        const uint32_t kind = __float_as_uint(q2.y);
+                        // the ray's direction, read back from the ray array (the loop keeps the origin, the reciprocals and the shear); inside an instance it goes through that
+                        // instance's matrix again — the product apply_ray_inverse / apply_ray made when the instance was entered, bit for bit
+                        const float4* rp = reinterpret_cast<const float4*>(rays + path);
+                        const float4 r0 = rp[0], r1 = rp[1];
+                        V3 rd = v3(r0.w, r1.x, r1.y);
+                        if (sgn >> SGN_INST_SHIFT) {
+                            const ShmInstance& in = sv.instances[(sgn >> SGN_INST_SHIFT) - 1u];
+                            rd = xf_vector(ANY ? in.render_from_primitive : in.primitive_from_render, rd);
+                        }
+                        if (kind & PRIM_INSTANCE_BIT) {
+                            // TransformedPrimitive (primitive.rs:158-176; alone in its top-level leaf, flatten.h): the outer ray's state goes to save area 0, a marker on the
+                            // stack — with t_max as it is outside (closest-hit) or the phantoms below (any-hit) —, the ray into the instance's space — apply_ray_inverse for
+                            // intersect, the FORWARD apply_ray for intersect_predicate, as the reference writes them — and the instanced aggregate's root is tested
+                            // (BvhAggregate::intersect's first node)
+                            save_ray_state(0);
+                            if (ANY) { push((uint32_t)CUR_MARKER | slot, ph_top); ph_top = 0u; }
+                            else push((uint32_t)CUR_MARKER | slot, __float_as_uint(t_max));
+                            sgn = (sgn & (SGN_RAY | SGN_HIT)) | (((kind & PRIM_INDEX_MASK) + 1u) << SGN_INST_SHIFT);
+                            const ShmInstance& in = sv.instances[kind & PRIM_INDEX_MASK];
+                            Ray r;
+                            if (ANY) { Ray w; w.o = ro; w.d = rd; r = xf_ray(in.render_from_primitive, w); }
+                            else r = xf_ray_inverse(in.primitive_from_render, ro, rd, t_max);
+                            set_ray(r.o, r.d);
+                            const float4* rn = reinterpret_cast<const float4*>(node_base + ((size_t)in.root_node << 5));
+                            const float4 ra = rn[0], rb = rn[1];
+                            cur = root_test(ra, rb) ? __float_as_uint(rb.z) : (uint32_t)CUR_POP;  // (a miss pops the marker: back out)
+                            if (ANY) c_nodes += 1u;
+                            entered = true;
+                        } else {
+                            save_ray_state(1);  // (... and nothing of it is live across the test)
+                            bool got;
+                            Float t_hit, h0, h1, h2, h_phi;
+                            if (kind & PRIM_SPHERE_BIT) {
+                                // Sphere::intersect (sphere.rs:95-196); the hit record carries p_obj and phi
+                                QuadricIntersection qi;
+                                qi.t_hit = 0.0f; qi.p_obj = v3s(0.0f); qi.phi = 0.0f;
+                                got = sphere_basic_intersect(sv.spheres[kind & PRIM_INDEX_MASK], ro, rd, t_max, qi);
+                                t_hit = qi.t_hit; h0 = qi.p_obj.x; h1 = qi.p_obj.y; h2 = qi.p_obj.z; h_phi = qi.phi;
+                            } else {
+                                // BilinearPatch::intersect (bilinear_patch.rs:144-236): the record holds p00, p10, p01; (u, v) go in b0, b1
+                                BilinearIntersection bi;
+                                bi.t = 0.0f; bi.u = 0.0f; bi.v = 0.0f;
+                                got = blp_intersect(ro, rd, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ld3(sv.patches[kind & PRIM_INDEX_MASK].p11), bi);
+                                t_hit = bi.t; h0 = bi.u; h1 = bi.v; h2 = 0.0f; h_phi = 0.0f;
+                            }
+                            restore_ray_state(1);
+                            if (got) {
+                                sgn |= SGN_HIT | SGN_HIT_INSIDE;
+                                if (!ANY) {
+                                    t_max = t_hit;
+                                    float4* hp = reinterpret_cast<float4*>(hits + path);
+                                    hp[0] = make_float4(__int_as_float((int32_t)slot), t_hit, h0, h1);
+                                    hp[1] = make_float4(h2, h_phi, 0.0f, 0.0f);
+                                }
+                            }
+                            leaf_n -= 1u;
+                            if (ANY && got) cur = CUR_DONE;
+                            else if (leaf_n == 0u) cur = CUR_POP;
+                            else cur = LINK_LEAF | ((leaf_n < LINK_COUNT_MAX ? leaf_n : LINK_COUNT_MAX) << LINK_COUNT_SHIFT) | (slot + 1u);
+                        }
+                    }
+                    if (__ballot(entered) != 0ull) {  // a lane's ray, and with it its signs, changed
+                        if (!ANY) w_nodes += (unsigned long long)__popcll(__ballot(entered));
+                        m_negx = __ballot((sgn & 1u) != 0u);
+                        m_negy = __ballot((sgn & 2u) != 0u);
+                        m_negz = __ballot((sgn & 4u) != 0u);
+                        m_irregular = __ballot((sgn & 8u) != 0u);
+                    }
                 }
             }
         }
@@ -726,6 +863,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
 #ifndef K5_POP_ROUNDS
 #define K5_POP_ROUNDS 1
 #endif
+        bool left_instance = false;  // (GEN)
         for (int round = 0; round < (ANY ? 1 : K5_POP_ROUNDS); ++round) {  // (closest-hit: a culled entry costs no fetch; further rounds let its lane try the next one at once)
             if (__ballot(cur == CUR_POP) == 0ull) break;
             CENSUS(8, 1); CENSUS(9, __popcll(__ballot(cur == CUR_POP)));
@@ -738,15 +876,32 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                     // two different load flavours, so that the compiler cannot merge them into one flat_load of a selected pointer
                     if (top < st_base + LDS_N * WAVE) e = *top;
                     else e = __builtin_nontemporal_load(st_spill_wave + (size_t)(top - (st_base + LDS_N * WAVE)) + lane);
-                    if (ANY) { c_nodes += 1u; ph_top = e.y; cur = e.x; }
+                    if (GEN && (e.x & ~LINK_INDEX_MASK) == (uint32_t)CUR_MARKER) {
+                        // the instanced aggregate is exhausted: back to the ray of the enclosing tree (primitive.rs:158-171 returns); t_max is the hit found inside (in
+                        // the instance's parameterisation, as the reference keeps it) — its record now names the instance — or what it was. The lane pops again in the
+                        // next iteration.
+                        if (ANY) ph_top = e.y;
+                        else if (sgn & SGN_HIT_INSIDE) reinterpret_cast<int32_t*>(hits + path)[6] = (int32_t)(e.x & LINK_INDEX_MASK) + 1;
+                        else t_max = __uint_as_float(e.y);
+                        sgn &= SGN_RAY | SGN_HIT;
+                        left_instance = true;
+                    }
+                    else if (ANY) { c_nodes += 1u; ph_top = e.y; cur = e.x; }
                     else if (__uint_as_float(e.y) < t_max) cur = e.x;  // the rest of the far child's test, against the t_max of now
                     // (else: culled without a fetch; the lane pops again in the next iteration)
                 }
             }
         }
+        if (GEN && __ballot(left_instance) != 0ull) {
+            if (left_instance) restore_ray_state(0);  // the outer ray's state, as the entry left it
+            m_negx = __ballot((sgn & 1u) != 0u);
+            m_negy = __ballot((sgn & 2u) != 0u);
+            m_negz = __ballot((sgn & 4u) != 0u);
+            m_irregular = __ballot((sgn & 8u) != 0u);
+        }
         // ---- retire finished rays ----
         if (cur == CUR_DONE) {
-            const bool found = (sgn & 16u) != 0u;
+            const bool found = (sgn & SGN_HIT) != 0u;
             if (ANY) {
                 if (occluded_out) occluded_out[path] = found ? 1 : 0;
                 if (L && !found) {
@@ -759,7 +914,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                     }
                 }
             } else if (!found) {
-                if (hit16) {
+                if (!GEN && hit16) {
                     reinterpret_cast<float4*>(hits)[path] = make_float4(__int_as_float(-1), 0.0f, 0.0f, 0.0f);
                 } else {
                     float4* hp = reinterpret_cast<float4*>(hits + path);  // a miss is all zeros behind prim = -1
@@ -804,17 +959,33 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
 #define K5_LDS_AT_8 9
 #endif
 template <int WAVES> struct K5Shape { static constexpr int LDS = (WAVES >= 8 ? K5_LDS_AT_8 : (WAVES == 7 ? 11 : (WAVES == 6 ? 13 : 15))), PER_CU = WAVES; };
-#define K5_PARAMS K3_PARAMS, const uint32_t* __restrict__ big_leaf_n
-#define K5_ARGS K3_ARGS, big_leaf_n
-template <bool ANY>
+#define K5_PARAMS K3_PARAMS, const uint32_t* __restrict__ big_leaf_n, float4* gen_save, int other_min
+#define K5_ARGS K3_ARGS, big_leaf_n, gen_save, other_min
+template <bool ANY, bool GEN = false>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace5(K5_PARAMS);
 template <>
-__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_CLOSEST_WAVES, K5_CLOSEST_WAVES))) k_trace5<false>(K5_PARAMS) {
-    trace5_body<false, K5Shape<K5_CLOSEST_WAVES>::LDS>(K5_ARGS);
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_CLOSEST_WAVES, K5_CLOSEST_WAVES))) k_trace5<false, false>(K5_PARAMS) {
+    trace5_body<false, false, K5Shape<K5_CLOSEST_WAVES>::LDS>(K5_ARGS);
 }
 template <>
-__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_ANY_WAVES, K5_ANY_WAVES))) k_trace5<true>(K5_PARAMS) {
-    trace5_body<true, K5Shape<K5_ANY_WAVES>::LDS>(K5_ARGS);
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_ANY_WAVES, K5_ANY_WAVES))) k_trace5<true, false>(K5_PARAMS) {
+    trace5_body<true, false, K5Shape<K5_ANY_WAVES>::LDS>(K5_ARGS);
+}
+// scenes with spheres / bilinear patches / instances (GEN): the direction, the instance slot and the second sub-phase's live values take the closest-hit kernel past the
+// 64 registers of eight waves; seven waves (<= 72 VGPRs) cost the triangle kernel under 1 % (r04 sweep: 98.0 -> 98.7 ms)
+#ifndef K5_GEN_CLOSEST_WAVES
+#define K5_GEN_CLOSEST_WAVES 7
+#endif
+#ifndef K5_GEN_ANY_WAVES
+#define K5_GEN_ANY_WAVES 7
+#endif
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_GEN_CLOSEST_WAVES, K5_GEN_CLOSEST_WAVES))) k_trace5<false, true>(K5_PARAMS) {
+    trace5_body<false, true, K5Shape<K5_GEN_CLOSEST_WAVES>::LDS>(K5_ARGS);
+}
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_GEN_ANY_WAVES, K5_GEN_ANY_WAVES))) k_trace5<true, true>(K5_PARAMS) {
+    trace5_body<true, true, K5Shape<K5_GEN_ANY_WAVES>::LDS>(K5_ARGS);
 }
 
 __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x; i < 8 * 32; i += blockDim.x) heads[i] = 0; }
@@ -836,11 +1007,12 @@ void wf_trace_census() {
 int wf_trace_prepare(ShmScene* s) {
     if (s->flat.nodes.size() + s->flat.instances.size() + 2 > (size_t)1 << 27) { shm_err() = "more than 2^27 BVH nodes (the traversal kernels address the node array with 32-bit byte offsets)"; return SHM_ERR_UNSUPPORTED; }
     const bool tri_only = !s->flat.has_spheres;
-    const bool pair = tri_only && s->trace_pair;  // k_trace5 (8-byte stack entries)
+    const bool pair = s->trace_pair;  // k_trace5 (8-byte stack entries)
     for (int any = 0; any < 2; ++any) {
         int lds = tri_only ? (any ? K3Shape<true, true>::LDS : K3Shape<false, true>::LDS) : K3Shape<false, false>::LDS;
         int per_cu = tri_only ? (any ? K3Shape<true, true>::PER_CU : K3Shape<false, true>::PER_CU) : K3Shape<false, false>::PER_CU;
-        if (pair) { lds = any ? K5Shape<K5_ANY_WAVES>::LDS : K5Shape<K5_CLOSEST_WAVES>::LDS; per_cu = any ? K5Shape<K5_ANY_WAVES>::PER_CU : K5Shape<K5_CLOSEST_WAVES>::PER_CU; }
+        if (pair && tri_only) { lds = any ? K5Shape<K5_ANY_WAVES>::LDS : K5Shape<K5_CLOSEST_WAVES>::LDS; per_cu = any ? K5Shape<K5_ANY_WAVES>::PER_CU : K5Shape<K5_CLOSEST_WAVES>::PER_CU; }
+        if (pair && !tri_only) { lds = any ? K5Shape<K5_GEN_ANY_WAVES>::LDS : K5Shape<K5_GEN_CLOSEST_WAVES>::LDS; per_cu = any ? K5Shape<K5_GEN_ANY_WAVES>::PER_CU : K5Shape<K5_GEN_CLOSEST_WAVES>::PER_CU; }
         if (s->trace3_per_cu_override > 0) per_cu = std::min(per_cu, s->trace3_per_cu_override);
         s->trace3_blocks[any] = s->n_cu * per_cu;
         s->spill3_levels[any] = std::max(0, (int)s->flat.max_leaf_depth + 1 - lds) + 1;
@@ -849,6 +1021,13 @@ int wf_trace_prepare(ShmScene* s) {
         if (hipMalloc(&d, words * sizeof(uint32_t)) != hipSuccess) { shm_err() = "hipMalloc of the traversal stack spill failed"; return SHM_ERR_OUT_OF_MEMORY; }
         s->allocs.push_back(d);
         (any ? s->d_spill3_any : s->d_spill3) = static_cast<uint32_t*>(d);
+        if (pair && !tri_only) {  // k_trace5<., GEN>: two 48-byte ray-state save areas per resident lane
+            if (s->flat.instances.size() >= ((size_t)1 << 25)) { shm_err() = "more than 2^25 instances (the traversal kernels keep the instance index in 26 bits)"; return SHM_ERR_UNSUPPORTED; }
+            void* g = nullptr;
+            if (hipMalloc(&g, (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * 6 * WAVE * sizeof(float4)) != hipSuccess) { shm_err() = "hipMalloc of the traversal save areas failed"; return SHM_ERR_OUT_OF_MEMORY; }
+            s->allocs.push_back(g);
+            s->d_gen_save[any] = static_cast<float4*>(g);
+        }
     }
     return SHM_OK;
 }
@@ -863,10 +1042,14 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
 #define TRACE_LAUNCH(ANY, TRI)                                                                                                                   \
     hipLaunchKernelGGL((k_trace3<ANY, TRI>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
                        hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16)
-#define TRACE5_LAUNCH(ANY)                                                                                                                    \
-    hipLaunchKernelGGL((k_trace5<ANY>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,  \
-                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n)
-    if (tri_only && s->trace_pair) { if (any) TRACE5_LAUNCH(true); else TRACE5_LAUNCH(false); }
+#define TRACE5_LAUNCH(ANY, GEN)                                                                                                               \
+    hipLaunchKernelGGL((k_trace5<ANY, GEN>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,  \
+                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n, \
+                       s->d_gen_save[ANY ? 1 : 0], (ANY ? s->other_min_any : s->other_min))
+    if (s->trace_pair) {
+        if (tri_only) { if (any) TRACE5_LAUNCH(true, false); else TRACE5_LAUNCH(false, false); }
+        else { if (any) TRACE5_LAUNCH(true, true); else TRACE5_LAUNCH(false, true); }
+    }
     else if (any) { if (tri_only) TRACE_LAUNCH(true, true); else TRACE_LAUNCH(true, false); }
     else { if (tri_only) TRACE_LAUNCH(false, true); else TRACE_LAUNCH(false, false); }
 #undef TRACE5_LAUNCH

@@ -16,7 +16,7 @@ namespace {
 // works through the chunk in that order, so that the 64 lanes of a wave mostly evaluate ONE material. Paths are independent and every later
 // queue is order-agnostic: films and counters do not change.
 constexpr int VERTEX_SORT_BINS = 64;
-// q_lean (may be null): the lean diversion. A hit on a plain DiffuseMaterial in a triangle-only scene without textures is not worked on here at all:
+// q_lean (may be null): the lean diversion. A hit on a plain DiffuseMaterial in a scene without textures is not worked on here at all:
 // the path goes to q_lean and the FUSED kernel (k_shade.inl's all-diffuse instantiation) runs its whole vertex — for that class the staged pair
 // only adds the parameter block's traffic (headline frame staged: 130 -> 165 ms). Everything else — escaped rays, the other
 // materials, MixMaterial (resolved in get_bsdf) — stays on the staged path.
@@ -25,8 +25,8 @@ template <bool TRI_ONLY, bool HAS_TEX, bool SORT>
 __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArrays& pa, const uint32_t* __restrict__ q_cur, uint32_t* q_s0, uint32_t* q_s1,
                                             uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, const ShmRenderParams& params, uint32_t* q_lean) {
     const uint32_t n = qs->n_active[cur];
-    const bool divert = TRI_ONLY && !HAS_TEX && q_lean != nullptr;
-    __shared__ uint32_t s_q[(TRI_ONLY && !HAS_TEX) ? N_VERTEX_QUEUES : N_BXDF_CLASSES][SHADE_CHUNK];  // (the fifth queue only where the diversion can happen)
+    const bool divert = !HAS_TEX && q_lean != nullptr;
+    __shared__ uint32_t s_q[!HAS_TEX ? N_VERTEX_QUEUES : N_BXDF_CLASSES][SHADE_CHUNK];  // (the fifth queue only where the diversion can happen)
     __shared__ uint32_t s_cnt[N_VERTEX_QUEUES], s_base[N_VERTEX_QUEUES];
     __shared__ uint32_t s_sorted[SORT ? SHADE_CHUNK : 1];
     __shared__ uint32_t s_bin[SORT ? VERTEX_SORT_BINS + 1 : 1];

@@ -199,7 +199,8 @@ static uint64_t max_batch_paths() {
 // (one BxDF class: nothing to sort, and the parameter block would be pure traffic); options.force_diffuse always takes the staged path.
 // (Round-2 A/B against the fused general kernels of round 1, same box: coated S3 1 208 -> 1 724 Mray/s, textured Cornell 768 -> 906,
 // crown-proxy C4 1 758 -> 1 735, Cornell with patches 2 840 -> 2 634: the staged pipeline replaced them everywhere.)
-static bool scene_is_lean(const ShmScene* s) { return !s->flat.has_spheres && s->flat.diffuse_only && !s->flat.has_textures; }
+// (round 5: whatever the shapes — a scene with spheres / patches / instances runs the kernel's general-geometry instantiation, k_shade_lean_gen.hip)
+static bool scene_is_lean(const ShmScene* s) { return s->flat.diffuse_only && !s->flat.has_textures; }
 static bool use_staged(const ShmScene* s, const ShmRenderParams* params) {
     if (params->integrator != SHM_INTEGRATOR_PATH) return false;
     // (the lean class through the staged pipeline, measured: shade + generate + film 130 -> 165 ms per headline frame)
@@ -498,7 +499,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_PIX_GROUP")) { long long v2 = atoll(e); if (v2 >= 1) s->pix_group = (uint32_t)std::min<long long>(v2, 0x7fffffffll); }
     if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
     // the lean diversion (k_vertex.inl): triangle-only scenes without textures that hold plain diffuse materials BESIDE other classes
-    s->lean_divert = !s->flat.has_spheres && !s->flat.has_textures && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s);
+    s->lean_divert = !s->flat.has_textures && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s);
     if (const char* e = getenv("SHM_LEAN_DIVERT")) s->lean_divert = s->lean_divert && atoi(e) != 0;
     // a shallow tree means short rays, and short rays want fewer, fuller waves (C2's 63-node box: 15.5 -> 15.1 ms per frame at 8 rays per lane); a deep
     // tree means long dependent chains per ray, which want every wave the device has (C4: 8 costs 2 %) — profiles/r03_trace_rays_per_lane_sweep.txt
@@ -510,12 +511,14 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     s->lds_tables_small = wf_lds_tables(s, LDS_TABLE_BUDGET_SMALL);
     // the both-children kernels set a ray up with the root test and six IEEE divisions (200 VALU instructions): they refill when 40 lanes are idle, so that
     // the set-up runs at 40 lanes instead of 24 (r04 sweep on the headline frame, closest / any ms: 24: 97.4 / 62.3, 40: 96.5 / 60.9, 48: 102.1 / 63.5, 56: 119.1 / 78.1)
-    if (!s->flat.has_spheres && s->trace_pair) s->refill_min = s->refill_min_any = 40;
+    if (s->trace_pair) s->refill_min = s->refill_min_any = 40;
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_REFILL_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) s->trace3_per_cu_override = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
+    if (const char* e = getenv("SHM_OTHER_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min = s->other_min_any = v2; }
+    if (const char* e = getenv("SHM_OTHER_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min_any = v2; }
     if ((rc = wf_trace_prepare(s)) != SHM_OK) return fail(rc);
     DBG("scene: %u nodes, depth %u, trace blocks %d / %d, spill levels %d / %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->trace3_blocks[0], s->trace3_blocks[1],
         s->spill3_levels[0], s->spill3_levels[1]);
@@ -755,7 +758,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                         }
                         ++k_cls;
                     };
-                    scatter_on(-1, [&](const ShadeArgs& x) { return wf_launch_shade_lean_diverted(s, x); });
+                    scatter_on(-1, [&](const ShadeArgs& x) { return tri_only ? wf_launch_shade_lean_diverted(s, x) : wf_launch_shade_lean_gen_diverted(s, x); });
                     scatter_on(CLASS_DIFFUSE, [&](const ShadeArgs& x) { return wf_launch_scatter_diffuse(s, x, tri_only, has_tex); });
                     scatter_on(CLASS_CONDUCTOR, [&](const ShadeArgs& x) { return wf_launch_scatter_conductor(s, x, tri_only, has_tex); });
                     scatter_on(CLASS_DIELECTRIC, [&](const ShadeArgs& x) { return wf_launch_scatter_dielectric(s, x, tri_only, has_tex); });
@@ -768,7 +771,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 }
                 else if (random_walk) rc = wf_launch_shade_randomwalk(s, sa, cap_eff);
                 else if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH) rc = wf_launch_shade_simple(s, sa);
-                else rc = wf_launch_shade_lean(s, sa);
+                else rc = tri_only ? wf_launch_shade_lean(s, sa) : wf_launch_shade_lean_gen(s, sa);
                 if (rc != SHM_OK) return rc;
                 hipEventRecord(s1, s->stream);
                 ev_shade.push_back({s0, s1});

@@ -52,9 +52,10 @@ constexpr int SHADE_BLOCK = 128;
 // The DEVICE copy of a BVH node (render.hip lays the tree out by sibling pairs and rewrites `offset` into a link word; the ABI's array and the
 // oracle's keep the reference's fields): everything a traversal step needs to go on from a node without reading it again —
 //   interior  axis << 29 | index of the first child (the second is + 1; pairs start at even indices, so (index << 5) ^ 32 is the sibling's byte offset)
-//   leaf      1 << 31 | min(n_prims, 15) << 27 | offset of its first primitive record (a count of 15 means: read ShmScene::d_big_leaf_n[offset], the primitives left from that slot on)
+//   leaf      1 << 31 | min(n_prims, 7) << 27 | offset of its first primitive record (a count of 7 means: read ShmScene::d_big_leaf_n[offset], the primitives left from that slot on);
+//             bit 30 is 0 in the array and set by a traversing lane (k_trace5<., GEN>): "the record at this slot is no triangle, its test is pending"
 // `n_prims` and `axis` stay where they were for the kernels that read them (k_trace3).
-constexpr uint32_t LINK_LEAF = 0x80000000u, LINK_INDEX_MASK = 0x07ffffffu, LINK_COUNT_SHIFT = 27u, LINK_COUNT_MAX = 15u, LINK_AXIS_SHIFT = 29u;
+constexpr uint32_t LINK_LEAF = 0x80000000u, LINK_OTHER = 0x40000000u, LINK_INDEX_MASK = 0x07ffffffu, LINK_COUNT_SHIFT = 27u, LINK_COUNT_MAX = 7u, LINK_AXIS_SHIFT = 29u;
 
 struct DeviceCounters {
     unsigned long long rays_closest, rays_any, nodes_closest, tris_closest, nodes_any, tris_any, paths;
@@ -311,6 +312,8 @@ struct ShmScene {
     float4* d_rw = nullptr;          // RandomWalk: (le, f cos) per depth per path, 2 * (max_depth + 1) * capacity float4
     size_t rw_floats4 = 0;
     uint32_t* d_spill3_any = nullptr;  // the any-hit kernel may run concurrently with the closest-hit one (second stream)
+    float4* d_gen_save[2] = {nullptr, nullptr};  // k_trace5<., GEN> (scenes with spheres / patches / instances): per resident lane two 48-byte areas for the ray state (closest, any)
+    int other_min = 16, other_min_any = 16;     // ... and the parked non-triangle tests a wave collects before it runs them (SHM_OTHER_MIN, SHM_OTHER_MIN_ANY)
     hipStream_t stream2 = nullptr;
     bool concurrent_scatter = true;  // SHM_CONCURRENT_SCATTER=0: everything on the render stream (A/B)
     hipStream_t stream_cls[4] = {nullptr, nullptr, nullptr, nullptr};  // staged shading: the scatter kernels of the 2nd .. 4th BxDF class of a bounce run beside the first one's
@@ -363,6 +366,8 @@ struct ShadeArgs {
 };
 WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a);  // the fused kernel: all-diffuse triangle scenes without textures
 WF_INTERNAL int wf_launch_shade_lean_diverted(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_shade_lean_gen(ShmScene* s, const ShadeArgs& a);           // the same kernel with the quadric / patch / instance code: scenes that hold such shapes (k_shade_lean_gen.hip)
+WF_INTERNAL int wf_launch_shade_lean_gen_diverted(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_tail(ShmScene* s, const ShadeArgs& a);  // fused, every material class but the coated ones: late bounces of deep renders (k_shade_tail.hip)  // the same kernel over q_lean, in a scene the staged pipeline renders
 // staged shading (k_vertex_*.hip, k_scatter_*.hip): the hit half of a vertex (interaction, emission + MIS, get_bsdf with its texture
 // evaluation -> BxDF parameter block, pushed to the queue of its BxDF class), then per class the scattering half (NEE, sample_f, RR)

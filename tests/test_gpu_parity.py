@@ -60,6 +60,10 @@ SCENES = {
     # TransformedPrimitive instancing: two-level traversal, inverse map for intersect, the reference's forward map for the predicate
     "instanced": lambda scenes, lib: (scenes.instanced_scene(lib, 64, 48), 8, 5),
     "three_spheres_environment": lambda scenes, lib: (scenes.three_spheres(lib, 64, 48, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(32)), 8, 5),
+    # round 5: the headline scene with the shapes a real PBRT-v4 scene mixes into its triangles (bench.py's side results, small): k_trace5<., GEN> + the general fused kernel
+    "S3_small_patch_emitter": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="patch_emitter"), 6, 5),
+    "S3_small_one_sphere": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="one_sphere"), 6, 5),
+    "S3_small_instanced": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="instanced"), 6, 5),
 }
 
 
@@ -154,14 +158,18 @@ def test_layered_walks_of_hundreds_of_steps(env):
 
 @pytest.mark.parametrize("pair", ["1", "0"])
 def test_trace_both_step_kinds(env, monkeypatch, pair):
-    """Triangle-only scenes are traced by the both-children step (k_trace5, the default) or by the one-node step (k_trace3, SHM_TRACE_PAIR=0, the
-    kernel the scenes with quadrics / patches / instances use): hit records, occlusion flags and all four visit counters equal the oracle's under
-    either, on a deep tree (S3 proxy, stack spill exercised with depth beyond the LDS levels), a shallow one, and a tree with leaves of 1, 14, 15, 16
-    and 40 coincident triangles (the link word's count field saturates at 15: ShmScene::d_big_leaf_n)."""
+    """Every scene is traced by the both-children step (k_trace5 / k_trace5<., GEN>, the default) or by the one-node step (k_trace3, SHM_TRACE_PAIR=0):
+    hit records, occlusion flags and all four visit counters equal the oracle's under either, on a deep tree (S3 proxy, stack spill exercised with depth
+    beyond the LDS levels), a shallow one, a tree with leaves of 1, 6, 7, 8, 14, 16 and 40 coincident triangles (the link word's count field saturates at 7:
+    ShmScene::d_big_leaf_n), one- and three-node trees, and the scenes with spheres, bilinear patches and instances (round 5: parked non-triangle tests,
+    the marker on the stack, sub-trees of one leaf, spheres and patches INSIDE instances)."""
     lib, oracle_py, render, scenes = env
     monkeypatch.setenv("SHM_TRACE_PAIR", pair)
-    cases = [scenes.ganesha_proxy(lib, 64, 64, n=96), scenes.cornell_box(lib, 32, 32)] + [_stacked_leaf_scene(scenes, lib, c) for c in (14, 15, 16, 40)] + \
-            [_tiny_tree_scene(scenes, lib, 1), _tiny_tree_scene(scenes, lib, 2)]
+    cases = [scenes.ganesha_proxy(lib, 64, 64, n=96), scenes.cornell_box(lib, 32, 32)] + [_stacked_leaf_scene(scenes, lib, c) for c in (6, 7, 8, 14, 16, 40)] + \
+            [_tiny_tree_scene(scenes, lib, 1), _tiny_tree_scene(scenes, lib, 2)] + \
+            [scenes.instanced_scene(lib, 32, 24), scenes.three_spheres(lib, 32, 24, camera=(0.75, 0.5, 9.0)), scenes.cornell_box(lib, 32, 32, patches=True),
+             scenes.ganesha_proxy(lib, 32, 32, n=64, variant="instanced"), scenes.ganesha_proxy(lib, 32, 32, n=24, variant="patch_emitter"),
+             scenes.random_scene(lib, 3), scenes.random_scene(lib, 11)]
     for sc in cases:
         gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
         for seed, tmax, aim in ((5, np.inf, 0.5), (6, 2.5, 0.9)):
