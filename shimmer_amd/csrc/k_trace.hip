@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace3<true, false>(K3_PARAMS) 
 // ---------------------------------------------------------------------------------------------
 #ifdef K5_CENSUS
 // development build (-DK5_CENSUS): per-phase lane census of the closest-hit kernel, printed by wf_trace_census() at scene destruction
-__device__ unsigned long long g_census[16];
+__device__ unsigned long long g_census[24];
 #define CENSUS(i, v) do { if (ANY == (K5_CENSUS == 2)) c_census[i] += (unsigned long long)(v); } while (0)  // -DK5_CENSUS=1: closest-hit, =2: any-hit
 #else
 #define CENSUS(i, v) do { } while (0)
@@ -512,7 +512,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     unsigned long long w_nodes = 0, w_rays = 0, w_prims = 0;  // closest-hit: all three per wave in scalar registers
     uint32_t c_nodes = 0, ph_top = 0;                         // any-hit: node visits per lane (phantoms make the increments differ), phantoms above the top entry
 #ifdef K5_CENSUS
-    unsigned long long c_census[16] = {0};
+    unsigned long long c_census[24] = {0};
 #endif
 
     bool exhausted = false;          // wave-uniform
@@ -565,14 +565,33 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         return ok && (t0 < t_max) && (t1 > 0.0f);
     };
 
+#ifndef K5_OUTER_IN_REGS
+#define K5_OUTER_IN_REGS 0
+#endif
+    // GEN: the OUTER ray's state while an instance is traversed
+    V3 o_ro = v3s(0.0f), o_inv = v3s(0.0f);
+    Float o_sx = 0.0f, o_sy = 0.0f, o_sz = 0.0f;
+    uint32_t o_kz_sgn = 0u;  // kz | ray bits of sgn << 2
     // GEN: the ray state the loop keeps, out to / back from one of the lane's two save areas
     auto save_ray_state = [&](int area) {
+        if (K5_OUTER_IN_REGS && area == 0) {
+            o_ro = ro; o_inv = inv_dir; o_sx = rs.sx; o_sy = rs.sy; o_sz = rs.sz; o_kz_sgn = (uint32_t)rs.kz | ((sgn & SGN_RAY) << 2);
+            return;
+        }
         float4* a = save_wave + (size_t)area * (3 * WAVE) + lane;
         a[0] = make_float4(ro.x, ro.y, ro.z, inv_dir.x);
         a[WAVE] = make_float4(inv_dir.y, inv_dir.z, rs.sx, rs.sy);
         a[2 * WAVE] = make_float4(rs.sz, __int_as_float(rs.kz), __uint_as_float(sgn & SGN_RAY), 0.0f);
     };
     auto restore_ray_state = [&](int area) {
+        if (K5_OUTER_IN_REGS && area == 0) {
+            ro = o_ro; inv_dir = o_inv; rs.sx = o_sx; rs.sy = o_sy; rs.sz = o_sz;
+            rs.kz = (int)(o_kz_sgn & 3u);
+            rs.kx = rs.kz == 2 ? 0 : rs.kz + 1;
+            rs.ky = rs.kx == 2 ? 0 : rs.kx + 1;
+            sgn = (sgn & ~SGN_RAY) | (o_kz_sgn >> 2);
+            return;
+        }
         asm volatile("" ::: "memory");  // (the loads below must be loads: with the stored values forwarded, the state would be live across what lies in between)
         const float4* a = save_wave + (size_t)area * (3 * WAVE) + lane;
         const float4 s0 = a[0], s1 = a[WAVE], s2 = a[2 * WAVE];
@@ -700,7 +719,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         // ---- one uniform step: every lane that stands on an interior node fetches the block of its two children and tests both (aggregate.rs:92-135) ----
         const bool at_node = cur < (uint32_t)CUR_FIRST_SPECIAL;
         if (!ANY) w_nodes += 2ull * (unsigned long long)__popcll(__ballot(at_node));
-        CENSUS(0, 1); CENSUS(1, __popcll(__ballot(at_node))); CENSUS(2, __popcll(__ballot((int32_t)cur < 0))); CENSUS(3, __popcll(__ballot(cur == CUR_IDLE)));
+        CENSUS(0, 1); CENSUS(1, __popcll(__ballot(at_node))); CENSUS(2, __popcll(__ballot((cur & 0xC0000000u) == 0x80000000u))); CENSUS(21, __popcll(__ballot(cur >= 0xC0000000u))); CENSUS(3, __popcll(__ballot(cur == CUR_IDLE)));
         CENSUS(4, __popcll(__ballot(cur == CUR_POP))); CENSUS(10, __ballot(at_node) != 0ull ? 1 : 0);
         if (at_node) {
             // near child first (aggregate.rs:119-127: dir_is_neg[axis] picks it); pairs start at even indices, so the sibling's record is at byte offset ^ 32
@@ -727,6 +746,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         // ---- postponed leaf phase: lanes standing on a leaf wait until enough of them do (or nothing else can run) ----
         constexpr uint32_t NOT_A_TRIANGLE = PRIM_SPHERE_BIT | PRIM_PATCH_BIT | PRIM_INSTANCE_BIT;
         constexpr uint32_t LEAF_KIND = LINK_LEAF | LINK_OTHER;  // (GEN: a leaf link with bit 30 set is a parked non-triangle test, below)
+        constexpr uint32_t LINK_LEAVE = LEAF_KIND | LINK_INDEX_MASK;  // (... and this one — no slot — a lane parked on its way back out of an instance)
         const unsigned long long leaf_mask = GEN ? __ballot((cur & LEAF_KIND) == LINK_LEAF) : __ballot((int32_t)cur < 0);
         if (leaf_mask != 0ull) {
             const unsigned long long node_mask = __ballot(cur < (uint32_t)CUR_FIRST_SPECIAL);
@@ -776,13 +796,23 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         // ---- GEN: the parked non-triangle tests, run like the leaf phase — when enough lanes wait for one, or when nothing else can run ----
         if (GEN) {
             const unsigned long long other_mask = __ballot(cur >= LEAF_KIND);
-            if (other_mask != 0ull) {
+            if (__builtin_expect(other_mask != 0ull, 0)) {  // (unlikely: block frequencies are what the register allocator places its spill code by)
                 const bool busy_elsewhere = __ballot(cur < (uint32_t)CUR_FIRST_SPECIAL || (cur & LEAF_KIND) == LINK_LEAF) != 0ull;
-                if (__popcll(other_mask) >= other_min || !busy_elsewhere) {
-                    w_prims += (unsigned long long)__popcll(other_mask);
-                    bool entered = false;
-                    if (cur >= LEAF_KIND) {
-                        const uint32_t slot = cur & LINK_INDEX_MASK;
+                if (__builtin_expect(__popcll(other_mask) >= other_min || !busy_elsewhere, 0)) {
+                    w_prims += (unsigned long long)__popcll(__ballot(cur >= LEAF_KIND && cur != LINK_LEAVE));
+                    CENSUS(15, 1); CENSUS(16, __popcll(other_mask)); CENSUS(17, busy_elsewhere ? 0 : 1);
+                    bool entered = false, root_tested = false;
+                    if (cur == LINK_LEAVE) {
+                        // a lane that came back out of an instance (its marker was popped, below): the outer ray's state, as the entry left it; then it pops on
+                        restore_ray_state(0);
+                        cur = CUR_POP;
+                        entered = true;  // (its ray changed)
+                    } else if (cur >= LEAF_KIND) {
+                        uint32_t slot = cur & LINK_INDEX_MASK;
+                        // (opaque to the optimiser: a lane may have parked in THIS iteration's leaf phase, and the compiler, seeing the same address, kept the record that
+                        //  phase loaded alive for this one — 40 bytes of scratch stores per lane in EVERY leaf phase: 117 GB per 64-spp frame, K2 28 -> 42 ms on the
+                        //  triangle-only headline scene traced by this kernel)
+                        asm volatile("" : "+v"(slot));
                         uint32_t leaf_n = (cur >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX;
                         if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[slot];
                         const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * sizeof(PrimRec));
@@ -816,6 +846,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                             cur = root_test(ra, rb) ? __float_as_uint(rb.z) : (uint32_t)CUR_POP;  // (a miss pops the marker: back out)
                             if (ANY) c_nodes += 1u;
                             entered = true;
+                            root_tested = true;
                         } else {
                             save_ray_state(1);  // (... and nothing of it is live across the test)
                             bool got;
@@ -849,8 +880,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                             else cur = LINK_LEAF | ((leaf_n < LINK_COUNT_MAX ? leaf_n : LINK_COUNT_MAX) << LINK_COUNT_SHIFT) | (slot + 1u);
                         }
                     }
+                    CENSUS(18, __popcll(__ballot(entered)));
                     if (__ballot(entered) != 0ull) {  // a lane's ray, and with it its signs, changed
-                        if (!ANY) w_nodes += (unsigned long long)__popcll(__ballot(entered));
+                        if (!ANY) w_nodes += (unsigned long long)__popcll(__ballot(root_tested));
                         m_negx = __ballot((sgn & 1u) != 0u);
                         m_negy = __ballot((sgn & 2u) != 0u);
                         m_negz = __ballot((sgn & 4u) != 0u);
@@ -863,7 +895,6 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
 #ifndef K5_POP_ROUNDS
 #define K5_POP_ROUNDS 1
 #endif
-        bool left_instance = false;  // (GEN)
         for (int round = 0; round < (ANY ? 1 : K5_POP_ROUNDS); ++round) {  // (closest-hit: a culled entry costs no fetch; further rounds let its lane try the next one at once)
             if (__ballot(cur == CUR_POP) == 0ull) break;
             CENSUS(8, 1); CENSUS(9, __popcll(__ballot(cur == CUR_POP)));
@@ -884,20 +915,13 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                         else if (sgn & SGN_HIT_INSIDE) reinterpret_cast<int32_t*>(hits + path)[6] = (int32_t)(e.x & LINK_INDEX_MASK) + 1;
                         else t_max = __uint_as_float(e.y);
                         sgn &= SGN_RAY | SGN_HIT;
-                        left_instance = true;
+                        cur = LINK_LEAVE;  // parks: the outer ray's state comes back in the wave's next round of parked work (one ray leaves per three iterations: on its own, a round per leave)
                     }
                     else if (ANY) { c_nodes += 1u; ph_top = e.y; cur = e.x; }
                     else if (__uint_as_float(e.y) < t_max) cur = e.x;  // the rest of the far child's test, against the t_max of now
                     // (else: culled without a fetch; the lane pops again in the next iteration)
                 }
             }
-        }
-        if (GEN && __ballot(left_instance) != 0ull) {
-            if (left_instance) restore_ray_state(0);  // the outer ray's state, as the entry left it
-            m_negx = __ballot((sgn & 1u) != 0u);
-            m_negy = __ballot((sgn & 2u) != 0u);
-            m_negz = __ballot((sgn & 4u) != 0u);
-            m_irregular = __ballot((sgn & 8u) != 0u);
         }
         // ---- retire finished rays ----
         if (cur == CUR_DONE) {
@@ -927,7 +951,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     }
 #ifdef K5_CENSUS
     CENSUS(14, __builtin_readcyclecounter() - t_loop0);
-    if (ANY == (K5_CENSUS == 2) && lane == 0) for (int i = 0; i < 16; ++i) if (c_census[i]) atomicAdd(&g_census[i], c_census[i]);
+    if (ANY == (K5_CENSUS == 2) && lane == 0) for (int i = 0; i < 24; ++i) if (c_census[i]) atomicAdd(&g_census[i], c_census[i]);
 #endif
     if (ANY) {
         unsigned long long wn = c_nodes;
@@ -993,20 +1017,24 @@ __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x;
 
 void wf_trace_census() {
 #ifdef K5_CENSUS
-    unsigned long long c[16];
+    unsigned long long c[24];
     if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_census), sizeof(c)) != hipSuccess || !c[0]) return;
     const double it = (double)c[0];
     fprintf(stderr, "[k5 census, %s] wave iterations %.3e | lanes per iteration: at a node %.1f, on a pending leaf %.1f, idle %.1f, pop pending %.1f | iterations with a node step %.3f\n"
                     "  leaf phases %.3e (one per %.2f iterations), primitive rounds %.3e at %.1f lanes | pop rounds %.3e at %.1f lanes | refills %.3e at %.1f rays\n",
             K5_CENSUS == 2 ? "any-hit" : "closest-hit", it, c[1] / it, c[2] / it, c[3] / it, c[4] / it, c[10] / it, (double)c[5], it / (double)c[5], (double)c[6], (double)c[7] / (double)c[6], (double)c[8], (double)c[9] / (double)c[8],
             (double)c[11], (double)c[12] / (double)c[11]);
+    if (c[15]) fprintf(stderr, "  GEN: parked on a non-triangle test %.1f lanes per iteration | other phases %.3e (one per %.2f iterations) at %.1f lanes, %.1f %% of them because nothing else could run | instance entries %.3e | leave rounds %.3e at %.1f lanes\n",
+                       c[21] / it, (double)c[15], it / (double)c[15], (double)c[16] / (double)c[15], 100.0 * (double)c[17] / (double)c[15], (double)c[18], (double)c[19], c[19] ? (double)c[20] / (double)c[19] : 0.0);
     fprintf(stderr, "  s_memtime ticks: in refills %.3e of %.3e wave-loop ticks = %.1f %% (%.0f ticks per refill)\n", (double)c[13], (double)c[14], 100.0 * (double)c[13] / (double)c[14], (double)c[13] / (double)c[11]);
 #endif
 }
 
+// development: SHM_TRACE_GEN=1 traces a triangle scene with the GEN kernels (A/B of the kernels themselves on one workload; needs SHM_HIT16=0: they write 32-byte records)
+static bool trace_force_gen() { static const int v = [] { const char* e = getenv("SHM_TRACE_GEN"); return e ? atoi(e) : 0; }(); return v != 0; }
 int wf_trace_prepare(ShmScene* s) {
     if (s->flat.nodes.size() + s->flat.instances.size() + 2 > (size_t)1 << 27) { shm_err() = "more than 2^27 BVH nodes (the traversal kernels address the node array with 32-bit byte offsets)"; return SHM_ERR_UNSUPPORTED; }
-    const bool tri_only = !s->flat.has_spheres;
+    const bool tri_only = !s->flat.has_spheres && !(trace_force_gen() && s->trace_pair);
     const bool pair = s->trace_pair;  // k_trace5 (8-byte stack entries)
     for (int any = 0; any < 2; ++any) {
         int lds = tri_only ? (any ? K3Shape<true, true>::LDS : K3Shape<false, true>::LDS) : K3Shape<false, false>::LDS;
@@ -1038,7 +1066,7 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
     uint32_t* spill = any ? s->d_spill3_any : s->d_spill3;
     hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, stream, heads);
     const int leaf_min = any ? s->leaf_min_any : s->leaf_min;
-    const bool tri_only = !s->flat.has_spheres;
+    const bool tri_only = !s->flat.has_spheres && !(trace_force_gen() && s->trace_pair);
 #define TRACE_LAUNCH(ANY, TRI)                                                                                                                   \
     hipLaunchKernelGGL((k_trace3<ANY, TRI>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
                        hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16)

@@ -28,9 +28,10 @@ MARKS3 = [("setup", "template <bool ANY, bool TRI_ONLY, int LDS_N>"), ("refill",
           ("node_step (load + slab test)", "// ---- one uniform node step"), ("leaf-mark / push", "// the three outcomes as selects"),
           ("leaf_phase", "// ---- postponed leaf phase"), ("pop", "// ---- pop: a lane that missed"),
           ("retire", "// ---- retire finished rays"), ("epilogue", "unsigned long long w_prims = c_prims;"), ("end", "#define K3_PARAMS")]
-MARKS5 = [("setup", "template <bool ANY, int LDS_N>"), ("refill (+ root test)", "// ---- refill idle lanes"),
+MARKS5 = [("setup", "template <bool ANY, bool GEN, int LDS_N>"), ("refill (+ root test)", "// ---- refill idle lanes"),
           ("pair_step (2 x (load + slab test) + push)", "// ---- one uniform step: every lane that stands"),
-          ("leaf_phase", "// ---- postponed leaf phase: lanes standing"), ("pop", "// ---- pop: a lane whose two children"),
+          ("leaf_phase", "// ---- postponed leaf phase: lanes standing"), ("other_phase (GEN: sphere / patch / instance)", "// ---- GEN: the parked non-triangle tests"),
+          ("pop", "// ---- pop: a lane whose two children"),
           ("retire", "// ---- retire finished rays"), ("epilogue", "unsigned long long wn = c_nodes;"), ("end", "#ifndef K5_CLOSEST_WAVES")]
 
 
@@ -81,7 +82,8 @@ def main():
         if m:
             files[int(m.group(1))] = m.group(3) or m.group(2)
     lines_out = [f"# static instruction census of the traversal kernels by section of trace5_body / trace3_body (tools/isa_sections.py; hipcc {' '.join(FLAGS[:3])} ...)"]
-    for label, want, secs in (("k_trace5<closest> (both-children step)", "k_trace5ILb0EE", secs5), ("k_trace5<any>", "k_trace5ILb1EE", secs5),
+    for label, want, secs in (("k_trace5<closest> (both-children step)", "k_trace5ILb0ELb0EE", secs5), ("k_trace5<any>", "k_trace5ILb1ELb0EE", secs5),
+                              ("k_trace5<closest, GEN> (scenes with spheres / patches / instances)", "k_trace5ILb0ELb1EE", secs5), ("k_trace5<any, GEN>", "k_trace5ILb1ELb1EE", secs5),
                               ("k_trace3<closest, TRI_ONLY> (one-node step)", "k_trace3ILb0ELb1EE", secs3), ("k_trace3<any, TRI_ONLY>", "k_trace3ILb1ELb1EE", secs3)):
         start = next(i for i, l in enumerate(asm) if re.match(r"^_ZN.*" + want + r".*:", l))
         end = next(i for i in range(start, len(asm)) if asm[i].strip().startswith(".Lfunc_end"))

@@ -26,7 +26,10 @@ def short(name):
         t = re.search(r"k_trace\d?<(\w+)(?:, (\w+))?>", name)
         if t:
             k += "<any>" if t.group(1) == "true" else "<closest>"
-            k += "+sph" if t.group(2) == "false" else ""  # second template argument is TRI_ONLY
+            if k.startswith("k_trace5"):
+                k += "+gen" if t.group(2) == "true" else ""   # k_trace5<ANY, GEN>
+            else:
+                k += "+sph" if t.group(2) == "false" else ""  # k_trace3<ANY, TRI_ONLY>
     return k
 
 
