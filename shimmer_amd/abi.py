@@ -238,6 +238,7 @@ EXPORTS = {
     "shm_device_count": (C.c_int, []),
     "shm_bvh_build": (C.c_int, [c_float_p, C.c_uint32, C.c_int, C.POINTER(ShmBvhNode), c_u32_p, c_u32_p]),
     "shm_bounds3_probe": (C.c_int, [c_float_p, c_float_p, c_float_p, c_float_p]),
+    "shm_debug_eval_leaf": (C.c_int, [C.c_int, C.c_int, c_u32_p, C.c_uint32, c_u32_p, C.c_uint32, C.POINTER(C.c_int)]),
     "shm_tile_bounds": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(ShmTile), c_u32_p]),
     "shm_camera_perspective": (C.c_int, [c_float_p, C.c_float, C.POINTER(C.c_int32), C.c_float, C.c_float, C.POINTER(ShmCamera), c_float_p]),
     "shm_integrator_render": (C.c_int, [C.c_char_p, C.POINTER(ShmSceneDesc), C.c_int, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_int,
