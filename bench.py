@@ -296,6 +296,8 @@ def parse_args(argv=None):
     ap.add_argument("--pmc-child", action="store_true", help="internal: the frame a live counter pass profiles (no baseline, no side runs, prints nothing)")
     ap.add_argument("--coated", action="store_true", help="S3 with a CoatedDiffuse object (LayeredBxDF, SURVEY 8f-1) instead of the "
                     "headline diffuse one: a side measurement, not the BASELINE config")
+    ap.add_argument("--variant", default=None, choices=["patch_emitter", "one_sphere", "instanced"],
+                    help="development: S3 with a bilinear-patch emitter / one sphere / the object instanced (the side results' scenes) instead of the headline scene")
     ap.add_argument("--shard-of", type=int, default=0, help="development: render only the tiles rank 0 of N would own (no gather), "
                     "to estimate the per-rank time of an N-GPU run on one GPU")
     ap.add_argument("--shard-rank", type=int, default=0, help="development: which rank's tiles --shard-of renders")
@@ -348,7 +350,7 @@ def rank_main(args):
     if args.dry_run:
         return dry_run(args, rank, local_rank, world, store)
 
-    headline = world == 1 and not (args.coated or args.shard_of or args.force_dist or args.width or args.height or args.pmc_child)
+    headline = world == 1 and not (args.coated or args.variant or args.shard_of or args.force_dist or args.width or args.height or args.pmc_child)
     counters, counters_src = None, "none"
     if headline and not args.no_live_pmc:
         # BEFORE this process touches the GPU: the counter passes are child processes under rocprofv3
@@ -374,7 +376,7 @@ def rank_main(args):
 
     t0 = time.perf_counter()
     width, height = (args.width or args.res), (args.height or args.res)
-    sc = scenes.ganesha_proxy(lib, width, height, n=args.n, coated=args.coated)
+    sc = scenes.ganesha_proxy(lib, width, height, n=args.n, coated=args.coated, variant=args.variant)
     t_scene = time.perf_counter() - t0
     t0 = time.perf_counter()
     r = render.Renderer(lib, sc.desc, device=local_rank)
@@ -464,7 +466,7 @@ def rank_main(args):
             "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{'S3c coated ' if args.coated else 'S3 '}ganesha-proxy ({sc.info['n_primitives']} prims, {sc.info['n_nodes']} BVH nodes), "
+            "config": {"workload": f"{'S3c coated ' if args.coated else 'S3 '}{'[' + args.variant + '] ' if args.variant else ''}ganesha-proxy ({sc.info['n_primitives']} prims, {sc.info['n_nodes']} BVH nodes), "
                                    f"{width}x{height}, {args.spp} spp, maxdepth {args.max_depth}, path integrator"
                                    + (" [BASELINE configs[4], the multi-GPU scaling frame]" if c5 else ""),
                        "tiles": "8x8, sharded across ranks in interleaved blocks of tile rows (~16 blocks per rank) by shm_shard_tiles" if world > 1 else "8x8",
@@ -559,7 +561,7 @@ def rank_main(args):
                 out["cpu_baseline"] = cpu_baseline(sc, params, lib)
             except Exception as e:  # the baseline is reporting only; never let it hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        if not args.no_side and not args.coated and not args.shard_of and (width, height) == (1024, 1024):
+        if not args.no_side and not args.coated and not args.variant and not args.shard_of and (width, height) == (1024, 1024):
             out["side_results"] = side_results(lib, args, render, scenes, sc, log)
     if store is not None:
         store.finish()

@@ -517,6 +517,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
 
     bool exhausted = false;          // wave-uniform
     uint32_t w_next = 0, w_end = 0;  // wave-uniform private range of the queue
+    uint32_t since_other = 0u;       // GEN, wave-uniform: iterations since the wave's last round of parked work
     const uint32_t n_waves = active_blocks * (TRACE_BLOCK / WAVE);
     uint32_t chunk = n / (n_waves * 8u);
     chunk = chunk < 64u ? 64u : (chunk > (uint32_t)K3_CHUNK_MAX ? (uint32_t)K3_CHUNK_MAX : chunk);
@@ -652,9 +653,18 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     for (;;) {
         // ---- refill idle lanes from the wave-private chunk [w_next, w_end); one atomic per `chunk` rays ----
         const unsigned long long idle = __ballot(cur == CUR_IDLE);
+        if (GEN) since_other += 1u;
         if (idle != 0ull) {
             const int n_idle = __popcll(idle);
-            if (!exhausted && (n_idle >= refill_min || idle == ~0ull)) {
+            // GEN: a lane parked on a non-triangle test takes no node step either — the refill threshold counts the lanes that cannot, not only the idle ones (with one
+            // sphere in 4.3 M triangles a parked lane waits ~190 iterations for company: 4 parked + 17 idle lanes left 32 of 64 at a node, against 37 in the triangle scene)
+#ifndef K5_REFILL_COUNTS_PARKED
+#define K5_REFILL_COUNTS_PARKED 1
+#endif
+            // (... once they have waited: where parked work is frequent — every ray of an instanced object parks twice — a round comes every ~16 iterations and
+            //  early refills only break its batches: S3 instanced 171 -> 182 ms when every parked lane counted)
+            const int n_unavailable = (GEN && K5_REFILL_COUNTS_PARKED && since_other > 24u) ? n_idle + __popcll(__ballot(cur >= (LINK_LEAF | LINK_OTHER))) : n_idle;
+            if (!exhausted && (n_unavailable >= refill_min || idle == ~0ull)) {
                 while (w_next >= w_end && !exhausted) {
                     const uint32_t p_begin = part * part_size;
                     const uint32_t p_end = (p_begin < n) ? ((n - p_begin < part_size) ? n : p_begin + part_size) : p_begin;
@@ -801,6 +811,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                 if (__builtin_expect(__popcll(other_mask) >= other_min || !busy_elsewhere, 0)) {
                     w_prims += (unsigned long long)__popcll(__ballot(cur >= LEAF_KIND && cur != LINK_LEAVE));
                     CENSUS(15, 1); CENSUS(16, __popcll(other_mask)); CENSUS(17, busy_elsewhere ? 0 : 1);
+                    since_other = 0u;
                     bool entered = false, root_tested = false;
                     if (cur == LINK_LEAVE) {
                         // a lane that came back out of an instance (its marker was popped, below): the outer ray's state, as the entry left it; then it pops on

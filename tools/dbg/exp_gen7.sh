@@ -1,0 +1,4 @@
+cd /root/repo
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "trace_bitwise or both_step or edge_cases" 2>&1 | tail -2
+python tools/bench_configs.py "S3s " "S3i " "S3p " 2>&1 | tail -3
+echo "== SHM_OTHER_MIN=8 (closest) 16 (any)"; SHM_OTHER_MIN=8 SHM_OTHER_MIN_ANY=16 python tools/bench_configs.py "S3s " "S3i " "S3p " 2>&1 | tail -3
