@@ -36,7 +36,12 @@ namespace {
 //   conductor / dielectric BxDFs and the material dispatch are compiled out of it.
 //   EMIT_INLINE = false (the lean instantiation): emission at the hit (integrator.rs:798-813) is not evaluated here — a vertex that hit an emitter deposits what
 //   the evaluation needs of the state this kernel is about to overwrite (PathArrays::e_*) and its path in q_emit; k_emit_jobs below works the list off after the launch.
-template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ONLY = false, bool EMIT_INLINE = true>
+//   SORT_CHUNK = true (the tail instantiation: every material class in one kernel, late bounces of deep renders): the workgroup counting-sorts its 2048-entry chunk by the
+//   material of the primitive each path hit (as k_vertex does, k_vertex.inl) before it works through it, so that the 64 lanes of a wave mostly run ONE material's BxDF
+//   — the queue is in image order, and a wave of the unsorted kernel ran at 11.5 of 64 lanes per instruction on C4's late bounces (profiles/r04_staged_C4.txt).
+//   Paths are independent and every later queue is order-agnostic: films and counters do not change.
+constexpr int SHADE_SORT_BINS = 64;
+template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ONLY = false, bool EMIT_INLINE = true, bool SORT_CHUNK = false>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneView sv_global, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in, uint32_t* __restrict__ q_emit,
@@ -54,8 +59,44 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
     __shared__ uint32_t s_next[SHADE_CHUNK], s_shadow[SHADE_CHUNK];
     __shared__ uint32_t s_emit[EMIT_INLINE ? 1 : SHADE_CHUNK];
     __shared__ uint32_t s_cnt[3], s_base[3];
+    __shared__ uint32_t s_sorted[SORT_CHUNK ? SHADE_CHUNK : 1];
+    __shared__ uint32_t s_bin[SORT_CHUNK ? SHADE_SORT_BINS + 1 : 1];
     for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
       if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; }
+      if (SORT_CHUNK) {
+          // counting sort of the chunk's paths by the material of the primitive they hit (64 bins + one for escaped rays): each entry's path and key stay in registers
+          // between the counting and the scatter pass, so the q -> hit -> primitive -> material chain of dependent gathers is walked once
+          if (threadIdx.x <= SHADE_SORT_BINS) s_bin[threadIdx.x] = 0;
+          __syncthreads();
+          uint32_t my_path[SHADE_CHUNK / SHADE2_BLOCK];
+          uint32_t my_keys = 0u, my_keys_hi = 0u;  // 8 keys of 7 bits (0..64)
+#pragma unroll
+          for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+              const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
+              my_path[k] = 0u;
+              if (i < n) {
+                  my_path[k] = q_cur[i];
+                  const int prim = __float_as_int((TRI_ONLY && pa.hit16) ? reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + my_path[k])[0]
+                                                                        : reinterpret_cast<const float*>(pa.hit + my_path[k])[0]);
+                  uint32_t key = (uint32_t)SHADE_SORT_BINS;
+                  if (prim >= 0) { const uint32_t m = sv.prim_recs[prim].material; key = m < (uint32_t)SHADE_SORT_BINS ? m : (uint32_t)SHADE_SORT_BINS - 1u; }
+                  if (k < 4) my_keys |= key << (8u * k); else my_keys_hi |= key << (8u * (k - 4u));
+                  atomicAdd(&s_bin[key], 1u);
+              }
+          }
+          __syncthreads();
+          if (threadIdx.x == 0) {  // exclusive prefix over 65 bins: the bins become cursors
+              uint32_t acc = 0;
+              for (int b = 0; b <= SHADE_SORT_BINS; ++b) { const uint32_t c = s_bin[b]; s_bin[b] = acc; acc += c; }
+          }
+          __syncthreads();
+#pragma unroll
+          for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+              const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
+              const uint32_t key = ((k < 4 ? my_keys >> (8u * k) : my_keys_hi >> (8u * (k - 4u)))) & 0xffu;
+              if (i < n) s_sorted[atomicAdd(&s_bin[key], 1u)] = my_path[k];
+          }
+      }
       __syncthreads();
       for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
         const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
@@ -64,7 +105,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
         uint32_t path = 0;
         if (active) {
             // first_bounce (wave-uniform; the lean instantiation only): k_generate left the constants out — the queue is the identity, beta = 1, p_b = eta_scale = 1, flags = 0
-            path = first_bounce ? i : q_cur[i];
+            path = SORT_CHUNK ? s_sorted[k * SHADE2_BLOCK + threadIdx.x] : (first_bounce ? i : q_cur[i]);
             Hit hit;
             if (TRI_ONLY) {
                 hit = load_hit_tri(pa, path);

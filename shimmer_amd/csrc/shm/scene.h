@@ -171,8 +171,7 @@ SHM_HD const PrimRec& light_prim_rec(const SceneView& sv, const ShmLight& light)
 }
 
 // BilinearPatch::get_points (bilinear_patch.rs:87-98) + the constants fixed at scene creation
-SHM_HD PatchData load_patch(const SceneView& sv, uint32_t slot) {
-    const PrimRec& pr = sv.prim_recs[slot];
+SHM_HD PatchData load_patch_rec(const SceneView& sv, const PrimRec& pr) {
     const PatchExtra& px = sv.patches[pr.kind_index & PRIM_INDEX_MASK];
     PatchData pd;
     pd.p00 = ld3(pr.p0); pd.p10 = ld3(pr.p1); pd.p01 = ld3(pr.p2); pd.p11 = ld3(px.p11);
@@ -195,6 +194,8 @@ SHM_HD PatchData load_patch(const SceneView& sv, uint32_t slot) {
     }
     return pd;
 }
+
+SHM_HD PatchData load_patch(const SceneView& sv, uint32_t slot) { return load_patch_rec(sv, sv.prim_recs[slot]); }
 
 // Result of BvhAggregate::intersect reduced to identifying data (see ShmHit).
 struct Hit {

@@ -368,6 +368,7 @@ WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a);  // the f
 WF_INTERNAL int wf_launch_shade_lean_diverted(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_lean_gen(ShmScene* s, const ShadeArgs& a);           // the same kernel with the quadric / patch / instance code: scenes that hold such shapes (k_shade_lean_gen.hip)
 WF_INTERNAL int wf_launch_shade_lean_gen_diverted(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_shade_tail_sorted(ShmScene* s, const ShadeArgs& a);  // ... with material-sorted chunks (k_shade_tail_sorted.hip)
 WF_INTERNAL int wf_launch_shade_tail(ShmScene* s, const ShadeArgs& a);  // fused, every material class but the coated ones: late bounces of deep renders (k_shade_tail.hip)  // the same kernel over q_lean, in a scene the staged pipeline renders
 // staged shading (k_vertex_*.hip, k_scatter_*.hip): the hit half of a vertex (interaction, emission + MIS, get_bsdf with its texture
 // evaluation -> BxDF parameter block, pushed to the queue of its BxDF class), then per class the scattering half (NEE, sample_f, RR)
