@@ -352,8 +352,8 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
 }
 
 // two waves per SIMD (<= 256 VGPRs): every class fits without spilling except the LayeredBxDF walks (586 spilled VGPRs). Measured on the
-// coated S3 (1024^2 x 64 spp): two waves with the spills 85.6 ms of shading per frame, one wave per SIMD without them (k_scatter_w1,
-// SHM_LAYERED_WAVES=1) 99.2 ms — latency hiding beats the scratch traffic, so two waves stay the default.
+// coated S3 (1024^2 x 64 spp): two waves with the spills 85.6 ms of shading per frame, one wave per SIMD without them (the retired k_scatter_w1)
+// 99.2 ms — latency hiding beats the scratch traffic.
 template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_scatter(SceneView sv_global, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                                       uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
@@ -379,16 +379,6 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_scatter_nonspecul
     const SceneView sv = stage_scene_tables(sv_global, lds_tables, s_tables);
     scatter_body<CLASS, TRI_ONLY, HAS_TEX, 2>(sv, pa, q_cur, q_next, q_shadow, qs, cur, params, shadow_parity);
 }
-// one wave per SIMD and the whole 512-entry unified register file: no spills, less latency hiding (see above)
-template <int CLASS, bool TRI_ONLY, bool HAS_TEX>
-__global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) k_scatter_w1(SceneView sv_global, PathArrays pa, const uint32_t* __restrict__ q_cur,
-                                                                                                         uint32_t* __restrict__ q_next, uint32_t* __restrict__ q_shadow,
-                                                                                                         QueueState* qs, int cur, ShmRenderParams params, int shadow_parity, LdsTables lds_tables) {
-    __shared__ uint4 s_tables[LDS_TABLE_BUDGET / 16];  // the small scene tables (lights, spectra: next-event estimation), staged once per workgroup
-    const SceneView sv = stage_scene_tables(sv_global, lds_tables, s_tables);
-    scatter_body<CLASS, TRI_ONLY, HAS_TEX>(sv, pa, q_cur, q_next, q_shadow, qs, cur, params, shadow_parity);
-}
-
 }  // namespace
 
 #define WF_SCATTER_LAUNCH(CLASS, TRI, TEX)                                                                                                      \
@@ -403,13 +393,6 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_
                            s->d_q_active[a.cur ^ 1], s->d_q_shadow, s->d_qs, a.cur, a.params, a.shadow_parity, s->lds_tables);                                \
         LAUNCH_TRY(#KERNEL);                                                                                                                    \
     } while (0)
-#define WF_SCATTER_LAUNCH_W1(CLASS, TRI, TEX)                                                                                                   \
-    do {                                                                                                                                        \
-        hipLaunchKernelGGL((k_scatter_w1<CLASS, TRI, TEX>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_scatter[CLASS], \
-                           s->d_q_active[a.cur ^ 1], s->d_q_shadow, s->d_qs, a.cur, a.params, a.shadow_parity, s->lds_tables);                                \
-        LAUNCH_TRY("k_scatter_w1");                                                                                                             \
-    } while (0)
-static inline bool layered_two_waves() { static int v = -1; if (v < 0) { const char* e = getenv("SHM_LAYERED_WAVES"); v = (e && atoi(e) == 1) ? 0 : 1; } return v == 1; }
 // the three scene classes every BxDF class is instantiated for
 #define WF_SCATTER_DISPATCH(CLASS)                                                  \
     do {                                                                            \

@@ -56,7 +56,15 @@ __device__ __forceinline__ void push_begin(DeferredPush& d, uint32_t* counter, b
     if (d.mask != 0ull && lane == (uint32_t)(__ffsll((long long)d.mask) - 1)) d.base_v = atomicAdd(counter, (uint32_t)__popcll(d.mask));
 }
 // the slot of a depositing lane in a job buffer that holds `n` jobs (wave-uniform), and the new count
+// Jobs travel between the LANES of a wave through LDS (the job buffers) and, for a few words, through global memory (rec[path].rng, shadow_contrib[path]) with no
+// barrier: a wave runs in lockstep. What that leaves to be said is said to the COMPILER: reads of a pass are not to sink below the deposits that reuse their slots, and a
+// pass's reads are not to rise above an earlier pass's deposits (advisor, round 4). A wavefront-scope fence + wave barrier: no instruction on wave64, an ordering point.
+__device__ __forceinline__ void lj_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ uint32_t deposit_slot(uint32_t& n, bool dep) {
+    lj_wave_sync();  // (between a pass's job reads and its deposits)
     const unsigned long long m = __ballot(dep);
     const uint32_t slot = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n + (uint32_t)__popcll(m)));
@@ -146,6 +154,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
     auto usable = [](const BSDFSample& bs) { return !(is_zero(bs.f) || bs.pdf == 0.0f || bs.wi.z == 0.0f); };
 
     for (;;) {
+        lj_wave_sync();  // (before a pass consumes what an earlier one deposited)
         const bool more = next_i < n;
         if (n_epi >= (uint32_t)WAVE || (!more && n_walk == 0u && n_epi > 0u)) {
             // ---- C: a wave of sampled directions — integrator.rs:859-891 ----

@@ -5,7 +5,6 @@
 #include "k_scatter.inl"
 
 int wf_launch_scatter_layered_gen(ShmScene* s, const ShadeArgs& a) {
-    if (layered_two_waves()) WF_SCATTER_LAUNCH(CLASS_LAYERED, false,false);
-    else WF_SCATTER_LAUNCH_W1(CLASS_LAYERED, false,false);
+    WF_SCATTER_LAUNCH(CLASS_LAYERED, false,false);
     return SHM_OK;
 }

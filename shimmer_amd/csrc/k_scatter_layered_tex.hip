@@ -5,7 +5,6 @@
 #include "k_scatter.inl"
 
 int wf_launch_scatter_layered_tex(ShmScene* s, const ShadeArgs& a) {
-    if (layered_two_waves()) WF_SCATTER_LAUNCH(CLASS_LAYERED, false,true);
-    else WF_SCATTER_LAUNCH_W1(CLASS_LAYERED, false,true);
+    WF_SCATTER_LAUNCH(CLASS_LAYERED, false,true);
     return SHM_OK;
 }

@@ -5,7 +5,6 @@
 #include "k_scatter.inl"
 
 int wf_launch_scatter_layered_tri(ShmScene* s, const ShadeArgs& a) {
-    if (layered_two_waves()) WF_SCATTER_LAUNCH(CLASS_LAYERED, true,false);
-    else WF_SCATTER_LAUNCH_W1(CLASS_LAYERED, true,false);
+    WF_SCATTER_LAUNCH(CLASS_LAYERED, true,false);
     return SHM_OK;
 }

@@ -1,39 +1,31 @@
 // k_trace.hip — K2 / K3: BVH traversal of the gfx950 wavefront path tracer (see wavefront.h).
-//   aggregate.rs:71-139    BvhAggregate::intersect           -> k_trace5<false> (triangle scenes: the both-children step, round 4) / k_trace3<false, TRI_ONLY>
-//   aggregate.rs:141-203   BvhAggregate::intersect_predicate -> k_trace5<true> / k_trace3<true, TRI_ONLY>
-// Two bodies, one algorithm (the reference's, node for node): trace3_body tests ONE node per step — the kernel of scenes with quadrics / patches / instances,
-// and the A/B partner of the other (SHM_TRACE_PAIR=0) —, trace5_body further down tests BOTH children of a node that is known to be hit.
+//   aggregate.rs:71-139    BvhAggregate::intersect           -> k_trace5<false, GEN>
+//   aggregate.rs:141-203   BvhAggregate::intersect_predicate -> k_trace5<true, GEN>
+// One body (trace5_body), the reference's algorithm node for node, executed as UNIFORM steps; GEN = false for scenes made of top-level triangles only, GEN = true for
+// scenes that also hold spheres, bilinear patches or instances. (Rounds 1-4 shipped a second body beside it, the one-node step k_trace3 — test the current node, push the
+// far child untested — as the kernel of non-triangle scenes and the A/B partner of this one: retired in round 5, when the both-children step learned the other shapes
+// and measured 112-171 ms where that kernel took 228-278 on the same frames, profiles/r05_cliff_before.json beside r05_bench_final.json. What it established stays in the
+// comments below and in DESIGN.md section 4.)
 #include "wavefront.h"
 
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// K2 / K3: BVH traversal. The reference's traversal (aggregate.rs:71-203: test the current node, push the far child
-// untested, enter the near child; pop on a miss or after a leaf) executed as UNIFORM steps, because the profile of the
-// first, reference-shaped kernel (one ray per lane from root to done; profiles/r01_v1) showed ~10 of 64 lanes active per
-// VALU instruction: issue-bound by divergence, not by HBM (FETCH_SIZE is 3-6x below the algorithmic bytes).  (A variant
-// that fetched and tested both children at the parent was measured and dropped: same results, more loads, no gain.)
-//   ANY       intersect_predicate (early out, no hit record) vs intersect (closest hit)
-//   TRI_ONLY  scenes made of triangles only; otherwise the leaf phase also carries Sphere::intersect (sphere.rs:95-196)
-//  * every loop iteration is one identical step for every lane that has a node to test: [pop if requested] -> fetch the
-//    32-B record -> slab test -> push far / enter near, or mark the leaf pending, or request a pop.  No nested loops;
-//  * leaf (triangle) tests are POSTPONED: a lane that reached a leaf waits until at least `leaf_min` lanes of its wave
-//    have a pending leaf (or no lane can take a node step), then the watertight test runs for all of them at once;
-//  * finished lanes are refilled from the queue (one wave-aggregated atomic) once `refill_min` lanes are idle;
-//  * stack levels [0, LDS_N) live in LDS as [level][lane]; any deeper level goes to a per-lane HBM region laid out the
-//    same way.
+// K2 / K3: BVH traversal. The profile of the first, reference-shaped kernel (one ray per lane from root to done; profiles/r01_v1) showed ~10 of 64 lanes active per
+// VALU instruction: issue-bound by divergence, not by HBM (FETCH_SIZE is 3-6x below the algorithmic bytes). Since then:
+//  * every loop iteration is one identical step for every lane that has a node to go on from; no nested per-lane loops;
+//  * leaf (triangle) tests are POSTPONED: a lane that reached a leaf waits until at least `leaf_min` lanes of its wave have a pending leaf (or no lane can take a node
+//    step), then the watertight test runs for all of them at once;
+//  * finished lanes are refilled from the queue (one wave-aggregated atomic per chunk) once `refill_min` lanes are idle;
+//  * stack levels [0, LDS_N) live in LDS as [level][lane]; any deeper level goes to a per-lane HBM region laid out the same way (the first version kept the LDS window at
+//    levels 6..31 and spilled the BOTTOM levels — written at the start of every ray and whenever the traversal comes back near the root —: WRITE_SIZE 7x the algorithmic
+//    hit writes, profiles/r01_v4; holding them in registers through select chains was measured too: slower than LDS).
 // Node and primitive visit counts equal the reference's in both modes (it is the same algorithm, node for node).
 // ---------------------------------------------------------------------------------------------
 #ifndef K3_CHUNK_MAX
 #define K3_CHUNK_MAX 1024
 #endif
-enum : uint32_t { ST_IDLE = 0, ST_NODE = 1, ST_LEAF = 2, ST_DONE = 3 };
 
-// LDS_N = the stack levels held in LDS. Occupancy is what the kernel is most sensitive to after its instruction count (measured on the headline
-// frame: 5 / 6 / 7 waves per SIMD = 186 / 166 / 158 ms for the closest-hit launches, 6 / 8 = 95.5 / 87.0 ms for the any-hit ones), and a 256-thread
-// workgroup needs LDS_N KiB of the CU's 160: the four entry points below trade stack levels in LDS for resident waves as far as their registers
-// allow — closest-hit: 72 VGPRs = 7 waves, 22 levels; any-hit: 64 VGPRs = 8 waves, 19 levels; the instantiations with quadrics / patches /
-// instances need > 120 VGPRs (3-4 waves) and keep 26 levels. Deeper levels go to the HBM spill (a BVH of 4.3 M triangles is 32 deep).
 // v_cndmask with the per-ray sign held as a 64-bit lane mask in a SCALAR register pair (one bit per lane, rebuilt by three ballots whenever
 // a lane takes a new ray): the select costs one VALU instruction and no compare, and — unlike a `bool` per lane, which the compiler keeps
 // as such a mask too but has to merge at every control-flow join (3 SALU instructions per mask per join: profiles/r03_k_trace3_isa_before.txt
@@ -48,388 +40,11 @@ __device__ __forceinline__ Float sel_mask(unsigned long long mask, Float if_clea
 __device__ __forceinline__ Float vmax3(Float a, Float b, Float c) { Float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ Float vmin3(Float a, Float b, Float c) { Float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-template <bool ANY, bool TRI_ONLY, int LDS_N>
-__device__ __forceinline__ void trace3_body(const SceneView& sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
-                                            uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
-                                            ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
-                                            float4* __restrict__ L, const float4* __restrict__ contrib,
-                                            DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
-                                            int refill_min, int leaf_min, int queue_parts, int rays_per_lane, int hit16) {
-    constexpr int K3_LDS_N = LDS_N;
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    __shared__ uint32_t lds_stack[(TRACE_BLOCK / WAVE) * K3_LDS_N * WAVE];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wave_in_block = threadIdx.x / WAVE;
-    // The per-lane stack, levels [0, LDS_N) in LDS as [level][lane]. `top` is the LDS address of the next free level and is the only
-    // stack register: a push stores at it and adds one level, a pop subtracts and loads; it keeps counting past the LDS window, where
-    // the level lives in the per-lane HBM spill instead (level - LDS_N), so "empty" and "beyond LDS" are two compares against constants.
-    lds_u32* const st_base = (lds_u32*)lds_stack + wave_in_block * K3_LDS_N * WAVE + lane;
-    lds_u32* top = st_base;
-    // (wave-uniform base; the lane offset is added where a spill level is touched — rare — instead of living in two VGPRs)
-    uint32_t* const st_spill_wave = spill + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE;
-    const uint32_t n = n_ptr ? *n_ptr : n_direct;
-    // A small queue is traced by a part of the persistent grid: with only a ray or two per resident lane a launch is all ramp — every wave
-    // takes one 64-ray chunk, the rays end at different times, and most iterations run with a few lanes. The first blocks of the grid
-    // (dispatched breadth first over the CUs) take all the rays, the others return at once; a launch of more than rays_per_lane x the
-    // grid's lanes is unchanged. It pays where rays are short (Cornell box, 16 nodes per ray: 16.8 -> 16.1 ms per frame at 4 rays per lane)
-    // and not where one ray is a long dependent chain (C4's late bounces, 71 nodes per ray, want every wave they can get: larger values
-    // cost there) — profiles/r03_trace_rays_per_lane_sweep.txt.
-    const uint32_t per_block = (uint32_t)TRACE_BLOCK * (uint32_t)(rays_per_lane > 0 ? rays_per_lane : 1);
-    const uint32_t blocks_wanted = rays_per_lane > 0 ? (n + per_block - 1u) / per_block : gridDim.x;
-    const uint32_t active_blocks = blocks_wanted < 64u ? (gridDim.x < 64u ? gridDim.x : 64u) : (blocks_wanted < gridDim.x ? blocks_wanted : gridDim.x);
-    if (blockIdx.x >= active_blocks) return;
-    const char* __restrict__ node_base = reinterpret_cast<const char*>(sv.nodes);
-    const char* __restrict__ prim_base = reinterpret_cast<const char*>(sv.prim_recs);
-    // visit counters: rays and node visits are counted per wave in scalar registers (one popcount of the lanes that took the step), only the
-    // primitive count — a loop of per-lane length — stays per lane
-    uint32_t c_prims = 0;
-    unsigned long long w_nodes = 0, w_rays = 0;
-
-    uint32_t state = ST_IDLE;
-    bool exhausted = false;  // wave-uniform
-    uint32_t w_next = 0, w_end = 0;  // wave-uniform private range of the queue (scalar registers: readfirstlane of the claimed base)
-    // chunk size: large enough that the single head word sees few atomics (it saturates near 88 dequeues/us,
-    // MI355X_MICROARCH.md "dequeue"), small enough that the last chunks balance across the resident waves
-    const uint32_t n_waves = active_blocks * (TRACE_BLOCK / WAVE);
-    uint32_t chunk = n / (n_waves * 8u);
-    chunk = chunk < 64u ? 64u : (chunk > (uint32_t)K3_CHUNK_MAX ? (uint32_t)K3_CHUNK_MAX : chunk);
-    chunk = (chunk + 63u) & ~63u;
-    uint32_t path = 0;
-    V3 ro = v3s(0.0f), inv_dir = v3s(0.0f);
-    V3 rd_full = v3s(0.0f);  // the direction itself is only kept for non-triangle shapes (TRI_ONLY = false)
-    // dir_is_neg (aggregate.rs:76-81) twice: as three wave-wide lane masks in scalar registers for the slab test's selects (sel_mask), and
-    // as three bits of one VGPR for the near / far child choice, where the axis varies per lane
-    unsigned long long m_negx = 0ull, m_negy = 0ull, m_negz = 0ull;
-    // ... and the lanes whose ray is not "regular" (bit 3 of sgn): a non-finite origin, or a direction component that is 0, infinite or so small
-    // that its reciprocal overflows. Only such a ray can turn a slab distance into a NaN ((plane - o) * (1 / d) = 0 * inf, inf * 0, inf - inf),
-    // and only with NaNs does the reference's compare-and-select chain differ from max3 / min3 — see the slab test.
-    unsigned long long m_irregular = 0ull;
-    uint32_t sgn = 0;
-    RayShear rs;
-    rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
-    Float t_max = 0.0f;
-    int32_t hit_prim = -1;
-    Float hit_b0 = 0.0f, hit_b1 = 0.0f, hit_b2 = 0.0f, hit_phi = 0.0f;  // (the hit's t is t_max itself: aggregate.rs:105-109 shrinks the ray to it)
-    // TransformedPrimitive (TRI_ONLY = false only): the leaf slot of the instance being traversed (-1: the top-level tree), the
-    // instance the current closest hit was found through, t_max as it was outside, and whether this visit found a hit
-    int32_t inst_slot = -1, hit_inst = -1;
-    Float t_outer = 0.0f;
-    bool inst_hit = false;
-    constexpr uint32_t INST_SENTINEL = 0xffffffffu;  // stack entry that marks the way back out of an instance
-    uint32_t cur = 0;
-    uint32_t leaf_off = 0, leaf_n = 0;
-
-    auto set_ray = [&](V3 o, V3 d) {  // aggregate.rs:76-81 + the ray-constant part of the triangle test
-        ro = o;
-        inv_dir = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        const bool regular = is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(inv_dir.x) && is_finite(inv_dir.y) && is_finite(inv_dir.z) &&
-                             inv_dir.x != 0.0f && inv_dir.y != 0.0f && inv_dir.z != 0.0f;
-        sgn = (inv_dir.x < 0.0f ? 1u : 0u) | (inv_dir.y < 0.0f ? 2u : 0u) | (inv_dir.z < 0.0f ? 4u : 0u) | (regular ? 0u : 8u);
-        rs = ray_shear(d);
-        if (!TRI_ONLY) rd_full = d;
-    };
-    auto push = [&](uint32_t v) {
-        // two different store flavours, so that the compiler cannot merge them into one flat_store of a selected pointer
-        if (top < st_base + K3_LDS_N * WAVE) *top = v;
-        else st_spill_wave[(size_t)(top - (st_base + K3_LDS_N * WAVE)) + lane] = v;
-        top += WAVE;
-    };
-
-    // (Measured and rejected, round 3: the newest stack entry in a register, so that a pop starts its node fetch without waiting for the LDS read
-    // — no gain in the any-hit kernel, 78.4 -> 79.6 ms per frame, and one register too many for the closest-hit kernel at eight waves.)
-    // Stack storage by level: [0, K3_LDS_N) in LDS, anything deeper in the per-lane HBM spill. (The first version kept
-    // the LDS window at levels 6..31 and spilled the bottom levels: those are written at the start of every ray and again
-    // whenever the traversal comes back near the root, and as HBM stores they made WRITE_SIZE 7x the algorithmic hit writes
-    // — profiles/r01_v4. Holding them in registers through select chains was measured too: slower than LDS.)
-    // Queue partitions: the queue is cut into `queue_parts` contiguous ranges, each with its own head word (own 128-B
-    // line). A wave starts in the partition of the XCD it runs on — queue order is image order (pix_group), so one XCD's L2
-    // serves one image region's part of the BVH, and 8 head words see 1/8 of the atomics each (one word saturates near
-    // 88 dequeues/us: MI355X_MICROARCH.md "dequeue") — and moves on to the next partition when its own has run dry.
-    const uint32_t n_parts = (uint32_t)queue_parts;
-    const uint32_t part_size = ((n + n_parts * 64u - 1u) / (n_parts * 64u)) * 64u;
-    uint32_t part = (n_parts > 1u) ? (__builtin_amdgcn_s_getreg(6164 /* HW_REG_XCC_ID, bits [3:0] */) & (n_parts - 1u)) : 0u;
-    uint32_t parts_left = n_parts;
-    for (;;) {
-        // ---- refill idle lanes from the wave-private chunk [w_next, w_end); one atomic per `chunk` rays ----
-        const unsigned long long idle = __ballot(state == ST_IDLE);
-        if (idle != 0ull) {
-            const int n_idle = __popcll(idle);
-            if (!exhausted && (n_idle >= refill_min || idle == ~0ull)) {
-                while (w_next >= w_end && !exhausted) {
-                    const uint32_t p_begin = part * part_size;
-                    const uint32_t p_end = (p_begin < n) ? ((n - p_begin < part_size) ? n : p_begin + part_size) : p_begin;
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(head + part * 32u, chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base < p_end - p_begin) {
-                        w_next = p_begin + base;
-                        w_end = (p_end - w_next < chunk) ? p_end : w_next + chunk;
-                    } else {
-                        part = (part + 1u == n_parts) ? 0u : part + 1u;
-                        if (--parts_left == 0u) exhausted = true;
-                    }
-                }
-                if (!exhausted) {
-                    const uint32_t take = min((uint32_t)n_idle, w_end - w_next);
-                    if (state == ST_IDLE) {
-                        // idle lanes below this one (v_mbcnt: no 64-bit lane mask to keep in registers)
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                        if (rank < take) {
-                            const uint32_t qi = w_next + rank;
-                            path = queue ? queue[qi] : qi;
-                            const float4* rp = reinterpret_cast<const float4*>(rays + path);
-                            const float4 r0 = rp[0], r1 = rp[1];
-                            set_ray(v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y));
-                            t_max = r1.z;
-                            hit_prim = -1;
-                            hit_inst = -1;
-                            inst_slot = -1;
-                            top = st_base;
-                            cur = 0;
-                            state = ST_NODE;
-                        }
-                    }
-                    w_next += take;
-                    w_rays += take;
-                    m_negx = __ballot((sgn & 1u) != 0u);
-                    m_negy = __ballot((sgn & 2u) != 0u);
-                    m_negz = __ballot((sgn & 4u) != 0u);
-                    m_irregular = __ballot((sgn & 8u) != 0u);
-                }
-            }
-            if (__ballot(state != ST_IDLE) == 0ull) {
-                if (exhausted) break;
-                continue;  // private chunk was empty: fetch the next one
-            }
-        }
-        // ---- one uniform node step: every lane with a node tests it (aggregate.rs:92-97) ----
-        bool need_pop = false;  // this step's outcome: the lane wants the next node from its stack (a miss, or a finished leaf below)
-        const bool at_node = state == ST_NODE;
-        w_nodes += (unsigned long long)__popcll(__ballot(at_node));  // (counted here: the compare's own lane mask, nothing to rebuild after the branch)
-        if (at_node) {
-            // (a 32-bit byte offset on the uniform base: one shift and the scalar-base addressing mode; wf_trace_prepare checks the tree fits 4 GiB)
-            const float4* np = reinterpret_cast<const float4*>(node_base + (uint32_t)(cur << 5));
-            const float4 na = np[0], nb = np[1];
-            // Bounds3f::intersect_p_cached (bounding_box.rs:520-563), the near / far plane of each axis chosen by the ray's sign masks
-            const Float g = 1.0f + 2.0f * gamma(3);
-            const Float tx0 = (sel_mask(m_negx, na.x, na.w) - ro.x) * inv_dir.x;
-            Float tx1 = (sel_mask(m_negx, na.w, na.x) - ro.x) * inv_dir.x;
-            const Float ty0 = (sel_mask(m_negy, na.y, nb.x) - ro.y) * inv_dir.y;
-            Float ty1 = (sel_mask(m_negy, nb.x, na.y) - ro.y) * inv_dir.y;
-            const Float tz0 = (sel_mask(m_negz, na.z, nb.y) - ro.z) * inv_dir.z;
-            Float tz1 = (sel_mask(m_negz, nb.y, na.z) - ro.z) * inv_dir.z;
-            tx1 *= g;
-            ty1 *= g;
-            tz1 *= g;
-            bool hit_box;
-            if (m_irregular == 0ull) {
-                // Every ray of the wave is regular: no slab distance is a NaN (the node bounds are finite: shm_bvh_build refuses others), and then
-                // the reference's chain — !(tx0 > ty1 || ty0 > tx1), t0 = max, t1 = min, !(t0 > tz1 || tz0 > t1), ..., t0 < t_max, t1 > 0 — is
-                // max3(near) <= min3(far) && max3 < t_max && min3 > 0: the chain tests every near_i against every far_j of ANOTHER axis; the same-axis
-                // pairs hold by construction (near_i <= far_i before the * g; a far_i that * g pushed below near_i is negative, and then t1 > 0
-                // fails on both sides). Two instructions and three compares instead of ten compares and four selects.
-                const Float t0 = vmax3(tx0, ty0, tz0), t1 = vmin3(tx1, ty1, tz1);
-                hit_box = (t0 <= t1) && (t0 < t_max) && (t1 > 0.0f);
-            } else {
-                // bounding_box.rs:520-563 statement for statement (a lane may hold NaNs: comparisons with them are false, the selects keep them)
-                Float t0 = tx0, t1 = tx1;
-                hit_box = !(t0 > ty1 || ty0 > t1);
-                if (ty0 > t0) t0 = ty0;
-                if (ty1 < t1) t1 = ty1;
-                hit_box = hit_box && !(t0 > tz1 || tz0 > t1);
-                if (tz0 > t0) t0 = tz0;
-                if (tz1 < t1) t1 = tz1;
-                hit_box = hit_box && (t0 < t_max) && (t1 > 0.0f);
-            }
-            const uint32_t offset = __float_as_uint(nb.z) & LINK_INDEX_MASK;  // (the device record's link word, wavefront.h: first child / first primitive)
-            const uint32_t meta = __float_as_uint(nb.w);
-            const uint32_t n_prims = meta & 0xffffu;
-            // the three outcomes as selects, not branches: almost every step has lanes on each of them
-            const bool is_leaf = hit_box && n_prims != 0u;
-            need_pop = !hit_box;
-            leaf_off = is_leaf ? offset : leaf_off;
-            leaf_n = is_leaf ? n_prims : leaf_n;
-            state = is_leaf ? (uint32_t)ST_LEAF : state;
-            if (hit_box && n_prims == 0u) {
-                const bool neg = ((sgn >> ((meta >> 16) & 0xffu)) & 1u) != 0u;  // dir_is_neg[axis]
-                // (device layout: the children are the pair {offset, offset + 1} — the reference's cur + 1 and second_child_offset; render.hip, upload)
-                push(neg ? offset : offset + 1u);                              // aggregate.rs:119-127: the far child waits, untested
-                cur = neg ? offset + 1u : offset;
-            }
-        }
-        // ---- postponed leaf phase ----
-        const unsigned long long leaf_mask = __ballot(state == ST_LEAF);
-        if (leaf_mask != 0ull) {
-            const unsigned long long node_mask = __ballot(state == ST_NODE && !need_pop);
-            if (__popcll(leaf_mask) >= leaf_min || node_mask == 0ull) {
-                if (state == ST_LEAF) {
-                    bool found_any = false;
-                    bool entered = false;
-                    for (uint32_t i = 0; i < leaf_n; ++i) {
-                        uint32_t slot = leaf_off + i;
-                        c_prims++;
-                        const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * sizeof(PrimRec));
-                        float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
-                        bool got;
-                        if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_INSTANCE_BIT)) {
-                            // TransformedPrimitive (primitive.rs:158-176; alone in its leaf, flatten.h): leave a marker on the stack, take
-                            // the ray into the instance's space — apply_ray_inverse for intersect, the FORWARD apply_ray for
-                            // intersect_predicate, as the reference writes them — and go on in the instanced aggregate's tree.
-                            const ShmInstance& in = sv.instances[__float_as_uint(q2.y) & PRIM_INDEX_MASK];
-                            push(INST_SENTINEL);
-                            t_outer = t_max;
-                            inst_slot = (int32_t)slot;
-                            inst_hit = false;
-                            Ray r;
-                            if (ANY) { Ray w; w.o = ro; w.d = rd_full; r = xf_ray(in.render_from_primitive, w); }
-                            else r = xf_ray_inverse(in.primitive_from_render, ro, rd_full, t_max);
-                            set_ray(r.o, r.d);
-                            cur = in.root_node;
-                            entered = true;
-                            break;
-                        }
-                        if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_SPHERE_BIT)) {
-                            // Sphere::intersect (sphere.rs:95-196) through the same leaf phase; the hit record carries p_obj and phi
-                            QuadricIntersection qi;
-                            got = sphere_basic_intersect(sv.spheres[__float_as_uint(q2.y) & PRIM_INDEX_MASK], ro, rd_full, t_max, qi);
-                            if (got) { hit_prim = (int32_t)slot; t_max = qi.t_hit; hit_b0 = qi.p_obj.x; hit_b1 = qi.p_obj.y; hit_b2 = qi.p_obj.z; hit_phi = qi.phi; }
-                        } else if (!TRI_ONLY && (__float_as_uint(q2.y) & PRIM_PATCH_BIT)) {
-                            // BilinearPatch::intersect (bilinear_patch.rs:144-236): the record holds p00, p10, p01; (u, v) go in b0, b1
-                            BilinearIntersection bi;
-                            got = blp_intersect(ro, rd_full, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x),
-                                                ld3(sv.patches[__float_as_uint(q2.y) & PRIM_INDEX_MASK].p11), bi);
-                            if (got) { hit_prim = (int32_t)slot; t_max = bi.t; hit_b0 = bi.u; hit_b1 = bi.v; hit_b2 = 0.0f; hit_phi = 0.0f; }
-                        } else {
-                            // (the precomputed degeneracy flag is applied to the RESULT: tested first, the compiler fetched the flag word,
-                            // waited, and only then fetched the vertices — two dependent round trips per leaf; degenerate triangles are rare
-                            // and the test itself has no side effect)
-                            TriangleIntersection ti;
-                            got = intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
-                            got = got && !(__float_as_uint(q2.y) & PRIM_DEGENERATE_BIT);
-                            if (got) { hit_prim = (int32_t)slot; t_max = ti.t; hit_b0 = ti.b0; hit_b1 = ti.b1; hit_b2 = ti.b2; hit_phi = 0.0f; }
-                        }
-                        if (got) {
-                            if (ANY) { found_any = true; break; }
-                            if (!TRI_ONLY) { hit_inst = inst_slot; inst_hit = true; }
-                        }
-                    }
-                    if (!TRI_ONLY && entered) {
-                        state = ST_NODE;  // goes on at the instance's root
-                    } else if (ANY && found_any) {
-                        state = ST_DONE;
-                    } else {
-                        state = ST_NODE;
-                        need_pop = true;
-                    }
-                }
-                if (!TRI_ONLY) {  // a lane may have entered an instance: its ray, and with it its signs, changed
-                    m_negx = __ballot((sgn & 1u) != 0u);
-                    m_negy = __ballot((sgn & 2u) != 0u);
-                    m_negz = __ballot((sgn & 4u) != 0u);
-                    m_irregular = __ballot((sgn & 8u) != 0u);
-                }
-            }
-        }
-        // ---- pop: a lane that missed its box, or is through with a leaf, takes the next node from its stack (aggregate.rs:129-135) ----
-        // (for TRI_ONLY = false the loop runs again for the rare lane that pops the marker of an instance it has finished)
-        while (__ballot(need_pop) != 0ull) {
-            bool again = false;
-            if (need_pop) {
-                need_pop = false;
-                if (top == st_base) state = ST_DONE;
-                else {
-                    top -= WAVE;
-                    // two different load flavours, so that the compiler cannot merge them into one flat_load of a selected
-                    // pointer (which waits on both the LDS and the vector-memory counter)
-                    if (top < st_base + K3_LDS_N * WAVE) cur = *top;
-                    else cur = __builtin_nontemporal_load(st_spill_wave + (size_t)(top - (st_base + K3_LDS_N * WAVE)) + lane);
-                    if (!TRI_ONLY && cur == INST_SENTINEL) {
-                        // the instanced aggregate is exhausted: back to the ray of the enclosing tree (primitive.rs:158-171 returns);
-                        // t_max is the hit found inside (in the instance's parameterisation, as the reference keeps it) or what it was
-                        const float4* rp = reinterpret_cast<const float4*>(rays + path);
-                        const float4 r0 = rp[0], r1 = rp[1];
-                        set_ray(v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y));
-                        if (!inst_hit) t_max = t_outer;
-                        inst_slot = -1;
-                        again = true;
-                    }
-                }
-            }
-            if (TRI_ONLY) break;
-            if (__ballot(again) == 0ull) break;
-            need_pop = again;
-            m_negx = __ballot((sgn & 1u) != 0u);
-            m_negy = __ballot((sgn & 2u) != 0u);
-            m_negz = __ballot((sgn & 4u) != 0u);
-            m_irregular = __ballot((sgn & 8u) != 0u);
-        }
-        // ---- retire finished rays ----
-        if (state == ST_DONE) {
-            if (ANY) {
-                bool occl = hit_prim >= 0;
-                if (occluded_out) occluded_out[path] = occl ? 1 : 0;
-                if (L && !occl) {
-                    float4 l = L[path], c = contrib[path];
-                    l.x += c.x; l.y += c.y; l.z += c.z; l.w += c.w;
-                    L[path] = l;
-                }
-            } else {
-                // (a miss is all zeros behind prim = -1: the lane's registers still hold its previous ray's barycentrics)
-                const bool found = hit_prim >= 0;
-                if (TRI_ONLY && hit16) {
-                    // the render's own hit array in a triangle scene: {primitive, b0, b1, b2}, 16 bytes — nothing downstream reads a triangle hit's t (wavefront.h, PathArrays::hit16)
-                    reinterpret_cast<float4*>(hits)[path] = make_float4(__int_as_float(hit_prim), found ? hit_b0 : 0.0f, found ? hit_b1 : 0.0f, found ? hit_b2 : 0.0f);
-                } else {
-                    float4* hp = reinterpret_cast<float4*>(hits + path);
-                    hp[0] = make_float4(__int_as_float(hit_prim), found ? t_max : 0.0f, found ? hit_b0 : 0.0f, found ? hit_b1 : 0.0f);
-                    hp[1] = make_float4(found ? hit_b2 : 0.0f, (TRI_ONLY || !found) ? 0.0f : hit_phi, (TRI_ONLY || !found) ? 0.0f : __int_as_float(hit_inst + 1), 0.0f);
-                }
-            }
-            state = ST_IDLE;
-        }
-    }
-    unsigned long long w_prims = c_prims;
-    for (int off = 32; off > 0; off >>= 1) w_prims += __shfl_down(w_prims, off);
-    if (lane == 0 && w_rays) {
-        if (ANY) {
-            atomicAdd(&counters->rays_any, w_rays);
-            atomicAdd(&counters->nodes_any, w_nodes);
-            atomicAdd(&counters->tris_any, w_prims);
-        } else {
-            atomicAdd(&counters->rays_closest, w_rays);
-            atomicAdd(&counters->nodes_closest, w_nodes);
-            atomicAdd(&counters->tris_closest, w_prims);
-        }
-    }
-}
-
 #define K3_PARAMS SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_direct, uint32_t* head,                    \
                   const ShmRay* __restrict__ rays, ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out, float4* __restrict__ L,                 \
                   const float4* __restrict__ contrib, DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels, int refill_min, int leaf_min, \
                   int queue_parts, int rays_per_lane, int hit16
 #define K3_ARGS sv, queue, n_ptr, n_direct, head, rays, hits, occluded_out, L, contrib, counters, spill, spill_levels, refill_min, leaf_min, queue_parts, rays_per_lane, hit16
-template <bool ANY, bool TRI_ONLY> struct K3Shape;  // {LDS levels, workgroups per CU} of each entry point
-#ifndef K3_CLOSEST_WAVES
-#define K3_CLOSEST_WAVES 8
-#endif
-template <> struct K3Shape<false, true> { static constexpr int LDS = (K3_CLOSEST_WAVES == 8 ? 19 : 22), PER_CU = K3_CLOSEST_WAVES; };
-template <> struct K3Shape<true, true> { static constexpr int LDS = 19, PER_CU = 8; };
-template <> struct K3Shape<false, false> { static constexpr int LDS = 26, PER_CU = 4; };
-template <> struct K3Shape<true, false> { static constexpr int LDS = 26, PER_CU = 4; };
-template <bool ANY, bool TRI_ONLY>
-__global__ void __launch_bounds__(TRACE_BLOCK) k_trace3(K3_PARAMS);
-template <>
-__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K3_CLOSEST_WAVES, K3_CLOSEST_WAVES))) k_trace3<false, true>(K3_PARAMS) {
-    trace3_body<false, true, K3Shape<false, true>::LDS>(K3_ARGS);
-}
-template <>
-__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_trace3<true, true>(K3_PARAMS) {
-    trace3_body<true, true, K3Shape<true, true>::LDS>(K3_ARGS);
-}
-template <>
-__global__ void __launch_bounds__(TRACE_BLOCK) k_trace3<false, false>(K3_PARAMS) { trace3_body<false, false, K3Shape<false, false>::LDS>(K3_ARGS); }
-template <>
-__global__ void __launch_bounds__(TRACE_BLOCK) k_trace3<true, false>(K3_PARAMS) { trace3_body<true, false, K3Shape<true, false>::LDS>(K3_ARGS); }
 
 // ---------------------------------------------------------------------------------------------
 // k_trace5: the BOTH-CHILDREN step (round 4), for scenes made of triangles only. Same algorithm, node for node — the reference tests both children of
@@ -496,7 +111,11 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     // GEN: this wave's two save areas of 3 float4 per lane, [area][k][lane] (area 0: the outer ray's state while an instance is traversed; area 1: around a quadric / patch test)
     float4* const save_wave = GEN ? gen_save + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)(6 * WAVE) : nullptr;
     const uint32_t n = n_ptr ? *n_ptr : n_direct;
-    // (a small queue is traced by a part of the persistent grid: see trace3_body)
+    // A small queue is traced by a part of the persistent grid: with only a ray or two per resident lane a launch is all ramp — every wave takes one 64-ray chunk, the rays
+    // end at different times, and most iterations run with a few lanes. The first blocks of the grid (dispatched breadth first over the CUs) take all the rays, the others
+    // return at once; a launch of more than rays_per_lane x the grid's lanes is unchanged. It pays where rays are short (Cornell box, 16 nodes per ray: 16.8 -> 16.1 ms per
+    // frame at 4 rays per lane) and not where one ray is a long dependent chain (C4's late bounces, 71 nodes per ray, want every wave they can get: larger values cost
+    // there) — profiles/r03_trace_rays_per_lane_sweep.txt.
     const uint32_t per_block = (uint32_t)TRACE_BLOCK * (uint32_t)(rays_per_lane > 0 ? rays_per_lane : 1);
     const uint32_t blocks_wanted = rays_per_lane > 0 ? (n + per_block - 1u) / per_block : gridDim.x;
     const uint32_t active_blocks = blocks_wanted < 64u ? (gridDim.x < 64u ? gridDim.x : 64u) : (blocks_wanted < gridDim.x ? blocks_wanted : gridDim.x);
@@ -524,7 +143,11 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     chunk = (chunk + 63u) & ~63u;
     uint32_t path = 0;
     V3 ro = v3s(0.0f), inv_dir = v3s(0.0f);
-    unsigned long long m_negx = 0ull, m_negy = 0ull, m_negz = 0ull, m_irregular = 0ull;  // see trace3_body
+    // dir_is_neg (aggregate.rs:76-81) twice: as three wave-wide lane masks in scalar registers for the slab tests' selects (sel_mask), and as three bits of `sgn` for the near /
+    // far child choice, where the axis varies per lane; and the lanes whose ray is not "regular" (bit 3 of sgn): a non-finite origin, or a direction component that is 0,
+    // infinite or so small that its reciprocal overflows. Only such a ray can turn a slab distance into a NaN ((plane - o) * (1 / d) = 0 * inf, inf * 0, inf - inf), and only
+    // with NaNs does the reference's compare-and-select chain differ from max3 / min3 — see the slab test.
+    unsigned long long m_negx = 0ull, m_negy = 0ull, m_negz = 0ull, m_irregular = 0ull;
     // any-hit, with the render's deferred contributions: L[path] + contrib[path], summed when the ray is TAKEN (the two loads travel with the ray's) and stored when it
     // ends unoccluded — at the end they were a round trip the whole wave waited for in most iterations (2.4 rays end per iteration); nobody else touches L[path] meanwhile
     float4 l_new = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -615,8 +238,11 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         const Float tz0 = (sel_mask(m_negz, na.z, nb.y) - ro.z) * inv_dir.z;
         Float tz1 = (sel_mask(m_negz, nb.y, na.z) - ro.z) * inv_dir.z;
         if (m_irregular == 0ull) {
-            // every ray of the wave is regular: no slab distance is a NaN, and the reference's chain is max3(near) <= min3(far * g) && min3 > 0 (&& max3 < t_max);
-            // see trace3_body for why. One product instead of three: g > 1 and rounding is monotonic, so min3(a g, b g, c g) = min3(a, b, c) g bit for bit
+            // Every ray of the wave is regular: no slab distance is a NaN (the node bounds are finite: shm_bvh_build refuses others), and then the reference's chain —
+            // !(tx0 > ty1 || ty0 > tx1), t0 = max, t1 = min, !(t0 > tz1 || tz0 > t1), ..., t0 < t_max, t1 > 0 — is max3(near) <= min3(far * g) && min3 > 0 (&& max3 < t_max):
+            // the chain tests every near_i against every far_j of ANOTHER axis; the same-axis pairs hold by construction (near_i <= far_i before the * g; a far_i that * g
+            // pushed below near_i is negative, and then t1 > 0 fails on both sides). Two instructions and three compares instead of ten compares and four selects.
+            // One product instead of three: g > 1 and rounding is monotonic, so min3(a g, b g, c g) = min3(a, b, c) g bit for bit
             // (the far distances are not NaNs here), and its sign is the sign of min3(a, b, c).
             const Float t0 = vmax3(tx0, ty0, tz0), t1 = vmin3(tx1, ty1, tz1);
             t0_out = t0;
@@ -643,6 +269,10 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         top += WAVE;
     };
 
+    // Queue partitions: the queue is cut into `queue_parts` contiguous ranges, each with its own head word (own 128-B line). A wave starts in the partition of the XCD it
+    // runs on — queue order is image order (pix_group), so one XCD's L2 serves one image region's part of the BVH, and 8 head words see 1/8 of the atomics each (one word
+    // saturates near 88 dequeues/us: MI355X_MICROARCH.md "dequeue") — and moves on to the next partition when its own has run dry. The chunk a wave claims with one atomic
+    // is large enough that the head word sees few atomics and small enough that the last chunks balance across the resident waves.
     const uint32_t n_parts = (uint32_t)queue_parts;
     const uint32_t part_size = ((n + n_parts * 64u - 1u) / (n_parts * 64u)) * 64u;
     uint32_t part = (n_parts > 1u) ? (__builtin_amdgcn_s_getreg(6164 /* HW_REG_XCC_ID, bits [3:0] */) & (n_parts - 1u)) : 0u;
@@ -777,7 +407,8 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                     const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
                     const uint32_t kind = __float_as_uint(q2.y);
                     tested = !GEN || (kind & NOT_A_TRIANGLE) == 0u;
-                    // (the precomputed degeneracy flag is applied to the RESULT, see trace3_body; GEN: so is "this record is no triangle at all" — the test has no side effect)
+                    // (the precomputed degeneracy flag is applied to the RESULT: tested first, the compiler fetched the flag word, waited, and only then fetched the vertices — two dependent
+                    //  round trips per leaf; degenerate triangles are rare and the test itself has no side effect; GEN: so is "this record is no triangle at all" — the test has no side effect)
                     TriangleIntersection ti;
                     bool got = intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
                     got = got && !(kind & PRIM_DEGENERATE_BIT) && tested;
@@ -1045,22 +676,19 @@ void wf_trace_census() {
 static bool trace_force_gen() { static const int v = [] { const char* e = getenv("SHM_TRACE_GEN"); return e ? atoi(e) : 0; }(); return v != 0; }
 int wf_trace_prepare(ShmScene* s) {
     if (s->flat.nodes.size() + s->flat.instances.size() + 2 > (size_t)1 << 27) { shm_err() = "more than 2^27 BVH nodes (the traversal kernels address the node array with 32-bit byte offsets)"; return SHM_ERR_UNSUPPORTED; }
-    const bool tri_only = !s->flat.has_spheres && !(trace_force_gen() && s->trace_pair);
-    const bool pair = s->trace_pair;  // k_trace5 (8-byte stack entries)
+    const bool tri_only = !s->flat.has_spheres && !trace_force_gen();
     for (int any = 0; any < 2; ++any) {
-        int lds = tri_only ? (any ? K3Shape<true, true>::LDS : K3Shape<false, true>::LDS) : K3Shape<false, false>::LDS;
-        int per_cu = tri_only ? (any ? K3Shape<true, true>::PER_CU : K3Shape<false, true>::PER_CU) : K3Shape<false, false>::PER_CU;
-        if (pair && tri_only) { lds = any ? K5Shape<K5_ANY_WAVES>::LDS : K5Shape<K5_CLOSEST_WAVES>::LDS; per_cu = any ? K5Shape<K5_ANY_WAVES>::PER_CU : K5Shape<K5_CLOSEST_WAVES>::PER_CU; }
-        if (pair && !tri_only) { lds = any ? K5Shape<K5_GEN_ANY_WAVES>::LDS : K5Shape<K5_GEN_CLOSEST_WAVES>::LDS; per_cu = any ? K5Shape<K5_GEN_ANY_WAVES>::PER_CU : K5Shape<K5_GEN_CLOSEST_WAVES>::PER_CU; }
+        int lds = any ? K5Shape<K5_ANY_WAVES>::LDS : K5Shape<K5_CLOSEST_WAVES>::LDS, per_cu = any ? K5Shape<K5_ANY_WAVES>::PER_CU : K5Shape<K5_CLOSEST_WAVES>::PER_CU;
+        if (!tri_only) { lds = any ? K5Shape<K5_GEN_ANY_WAVES>::LDS : K5Shape<K5_GEN_CLOSEST_WAVES>::LDS; per_cu = any ? K5Shape<K5_GEN_ANY_WAVES>::PER_CU : K5Shape<K5_GEN_CLOSEST_WAVES>::PER_CU; }
         if (s->trace3_per_cu_override > 0) per_cu = std::min(per_cu, s->trace3_per_cu_override);
         s->trace3_blocks[any] = s->n_cu * per_cu;
         s->spill3_levels[any] = std::max(0, (int)s->flat.max_leaf_depth + 1 - lds) + 1;
-        const size_t words = (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[any] * WAVE * (pair ? 2u : 1u);
+        const size_t words = (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[any] * WAVE * 2u;  // (8-byte stack entries)
         void* d = nullptr;
         if (hipMalloc(&d, words * sizeof(uint32_t)) != hipSuccess) { shm_err() = "hipMalloc of the traversal stack spill failed"; return SHM_ERR_OUT_OF_MEMORY; }
         s->allocs.push_back(d);
         (any ? s->d_spill3_any : s->d_spill3) = static_cast<uint32_t*>(d);
-        if (pair && !tri_only) {  // k_trace5<., GEN>: two 48-byte ray-state save areas per resident lane
+        if (!tri_only) {  // k_trace5<., GEN>: two 48-byte ray-state save areas per resident lane
             if (s->flat.instances.size() >= ((size_t)1 << 25)) { shm_err() = "more than 2^25 instances (the traversal kernels keep the instance index in 26 bits)"; return SHM_ERR_UNSUPPORTED; }
             void* g = nullptr;
             if (hipMalloc(&g, (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * 6 * WAVE * sizeof(float4)) != hipSuccess) { shm_err() = "hipMalloc of the traversal save areas failed"; return SHM_ERR_OUT_OF_MEMORY; }
@@ -1077,22 +705,14 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
     uint32_t* spill = any ? s->d_spill3_any : s->d_spill3;
     hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, stream, heads);
     const int leaf_min = any ? s->leaf_min_any : s->leaf_min;
-    const bool tri_only = !s->flat.has_spheres && !(trace_force_gen() && s->trace_pair);
-#define TRACE_LAUNCH(ANY, TRI)                                                                                                                   \
-    hipLaunchKernelGGL((k_trace3<ANY, TRI>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, \
-                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16)
+    const bool tri_only = !s->flat.has_spheres && !trace_force_gen();
 #define TRACE5_LAUNCH(ANY, GEN)                                                                                                               \
     hipLaunchKernelGGL((k_trace5<ANY, GEN>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,  \
                        hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n, \
                        s->d_gen_save[ANY ? 1 : 0], (ANY ? s->other_min_any : s->other_min))
-    if (s->trace_pair) {
-        if (tri_only) { if (any) TRACE5_LAUNCH(true, false); else TRACE5_LAUNCH(false, false); }
-        else { if (any) TRACE5_LAUNCH(true, true); else TRACE5_LAUNCH(false, true); }
-    }
-    else if (any) { if (tri_only) TRACE_LAUNCH(true, true); else TRACE_LAUNCH(true, false); }
-    else { if (tri_only) TRACE_LAUNCH(false, true); else TRACE_LAUNCH(false, false); }
+    if (tri_only) { if (any) TRACE5_LAUNCH(true, false); else TRACE5_LAUNCH(false, false); }
+    else { if (any) TRACE5_LAUNCH(true, true); else TRACE5_LAUNCH(false, true); }
 #undef TRACE5_LAUNCH
-#undef TRACE_LAUNCH
     LAUNCH_TRY(any ? "k_trace<any>" : "k_trace<closest>");
     return SHM_OK;
 }

@@ -3,8 +3,8 @@
 // Replaces the tile-parallel loop of the reference (paths relative to /root/reference/src):
 //   integrator.rs:226-322  ImageTileIntegrator::render      -> shm_render / shm_render_device / shm_render_wave (host loop below)
 //   integrator.rs:326-396  evaluate_pixel_sample            -> K1 k_generate
-//   aggregate.rs:71-139    BvhAggregate::intersect          -> K2 k_trace3<false, TRI_ONLY> (persistent waves, LDS stack)
-//   aggregate.rs:141-203   BvhAggregate::intersect_predicate-> K3 k_trace3<true, TRI_ONLY>
+//   aggregate.rs:71-139    BvhAggregate::intersect          -> K2 k_trace5<false, GEN> (persistent waves, LDS stack, both children per step)
+//   aggregate.rs:141-203   BvhAggregate::intersect_predicate-> K3 k_trace5<true, GEN>
 //   integrator.rs:772-892  PathIntegrator::li loop body     -> K4+K5 k_shade<HAS_LAYERED, TRI_ONLY> (one path vertex per launch)
 //   integrator.rs:897-963  PathIntegrator::sample_ld        -> inside k_shade (shadow ray deferred to K3)
 //   film.rs:548-574        RgbFilm::add_sample              -> K6 k_film (per-pixel ordered f64 sums)
@@ -506,12 +506,8 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (f.nodes.size() < 4096) s->trace_rays_per_lane = 8;
     if (const char* e = getenv("SHM_TRACE_RAYS_PER_LANE")) { int v2 = atoi(e); if (v2 >= 0 && v2 <= 4096) s->trace_rays_per_lane = v2; }
     if (const char* e = getenv("SHM_CONCURRENT_SCATTER")) s->concurrent_scatter = atoi(e) != 0;
-    if (const char* e = getenv("SHM_TRACE_PAIR")) s->trace_pair = atoi(e) != 0;
     s->lds_tables = wf_lds_tables(s, LDS_TABLE_BUDGET);
     s->lds_tables_small = wf_lds_tables(s, LDS_TABLE_BUDGET_SMALL);
-    // the both-children kernels set a ray up with the root test and six IEEE divisions (200 VALU instructions): they refill when 40 lanes are idle, so that
-    // the set-up runs at 40 lanes instead of 24 (r04 sweep on the headline frame, closest / any ms: 24: 97.4 / 62.3, 40: 96.5 / 60.9, 48: 102.1 / 63.5, 56: 119.1 / 78.1)
-    if (s->trace_pair) s->refill_min = s->refill_min_any = 40;
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_REFILL_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) s->trace3_per_cu_override = v2; }
@@ -687,7 +683,9 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         // all-diffuse triangle scenes with 16-byte hit records: the records are double-buffered by bounce parity in the two halves of the ShmHit allocation, so that the
         // previous vertex's record — all the next vertex's emitter MIS weight needs (k_shade.inl, k_emit_jobs) — is still there and no vertex writes anything for it
         ShmHit* const hit_base = s->pa.hit;
-        struct HitRestore { ShmScene* sc; ShmHit* base; ~HitRestore() { sc->pa.hit = base; sc->pa.hit_prev = nullptr; } } hit_restore{s, hit_base};
+        // (s->pa is the scene's one PathArrays: the per-bounce overrides — hit, hit_prev — and the per-render record form, hit16, are taken back when the batch is through,
+        //  so that whoever reads s->pa.hit outside a render — the public trace entry points, dist.hip — finds the allocation's base and 32-byte records)
+        struct HitRestore { ShmScene* sc; ShmHit* base; ~HitRestore() { sc->pa.hit = base; sc->pa.hit_prev = nullptr; sc->pa.hit16 = 0u; } } hit_restore{s, hit_base};
         const bool hit_kept = s->pa.hit16 && scene_is_lean(s) && !staged && !random_walk;
         for (int bounce = 0; bounce <= params->max_depth; ++bounce) {
             if (hit_kept) {

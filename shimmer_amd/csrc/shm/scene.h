@@ -1,16 +1,19 @@
 // shm/scene.h — flat, pointer-based view of a scene as the kernels (and the CPU oracle) read it.
 //
 // Data layout in HBM (DESIGN.md §"Data layout"):
-//   nodes[]      32-B LinearBvhNode records, DFS order (aggregate.rs:425-481 narrowed from 64 B)
-//   prim_recs[]  48-B records in BVH LEAF ORDER: the three triangle vertices pre-gathered (the reference
+//   nodes[]      32-B LinearBvhNode records, DFS order (aggregate.rs:425-481 narrowed from 64 B; the device copy: sibling pairs + link words, wavefront.h)
+//   prim_recs[]  64-B ALIGNED records in BVH LEAF ORDER: the three triangle vertices pre-gathered (the reference
 //                chases Vec<Arc<Primitive>> -> Arc<Shape> -> Arc<TriangleMesh> -> Vec<usize> -> Vec<Point3f>,
-//                shape/triangle.rs:148-160) + kind/shape index + mesh id + global triangle id.
-//                A leaf's primitive_offset indexes this array directly: one 48-B read per candidate.
-//   primitives[] material / area-light ids per leaf-order slot (primitive.rs:66-130), read once per path vertex
+//                shape/triangle.rs:148-160) + kind/shape index + mesh id + global triangle id + the hit's material and emitter index.
+//                A leaf's primitive_offset indexes this array directly: three 16-B loads of one 64-byte line per candidate (a traversal reads 48 of the 64 bytes;
+//                bench.py's roofline_hbm_algorithmic keeps SURVEY 8d's 48 B per primitive tested: the survey's convention, not the record's size).
+//   primitives[] shape kind / index + material / area-light ids per leaf-order slot (primitive.rs:66-130): the ABI's array; the device reads material and emitter from the
+//                record above (flatten copies them once), `primitives[]` only where a kernel wants the shape index of a slot
 //   vi/vn/vs/vuv global per-vertex shading arrays (only read when a mesh has N/S/uv)
 //   texel_data   every MIP level of every image texture as f32, [level][row from the top][x][channel]; image_levels[] holds
 //                {width, height, offset}; the rgb2spec coefficient table (3 x res^3 x 3 floats) sits beside it
 #pragma once
+#include <assert.h>
 #include "shapes.h"
 #include "patch.h"
 #include "spectrum.h"
@@ -165,8 +168,12 @@ SHM_HD TriangleData load_triangle_rec(const SceneView& sv, const PrimRec& pr) {
     return t;
 }
 SHM_HD TriangleData load_triangle(const SceneView& sv, uint32_t slot) { return load_triangle_rec(sv, sv.prim_recs[slot]); }
-// the emitter's record of an area light: the per-light copy when the scene has one (same bytes)
+// the emitter's record of an area light: the per-light copy when the scene has one (same bytes). `light` must be an ELEMENT of the table sv.lights names — the global
+// one or its LDS-staged copy —: its position there is the index (checked on the host, where the oracle and the tests run this code; a light held by value would index garbage)
 SHM_HD const PrimRec& light_prim_rec(const SceneView& sv, const ShmLight& light) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    assert(&light >= sv.lights && &light < sv.lights + sv.n_lights);
+#endif
     return sv.light_prim_recs ? sv.light_prim_recs[&light - sv.lights] : sv.prim_recs[light.primitive];
 }
 

@@ -54,7 +54,7 @@ constexpr int SHADE_BLOCK = 128;
 //   interior  axis << 29 | index of the first child (the second is + 1; pairs start at even indices, so (index << 5) ^ 32 is the sibling's byte offset)
 //   leaf      1 << 31 | min(n_prims, 7) << 27 | offset of its first primitive record (a count of 7 means: read ShmScene::d_big_leaf_n[offset], the primitives left from that slot on);
 //             bit 30 is 0 in the array and set by a traversing lane (k_trace5<., GEN>): "the record at this slot is no triangle, its test is pending"
-// `n_prims` and `axis` stay where they were for the kernels that read them (k_trace3).
+// `n_prims` and `axis` stay where they were (no kernel reads them since the one-node-step kernels were retired: the link word holds everything).
 constexpr uint32_t LINK_LEAF = 0x80000000u, LINK_OTHER = 0x40000000u, LINK_INDEX_MASK = 0x07ffffffu, LINK_COUNT_SHIFT = 27u, LINK_COUNT_MAX = 7u, LINK_AXIS_SHIFT = 29u;
 
 struct DeviceCounters {
@@ -297,8 +297,8 @@ struct ShmScene {
     size_t tiles_capacity = 0;
     std::vector<uint64_t> tile_bitmap;  // host scratch of the disjointness check in shm_render_wave
     int n_cu = 256;
-    // tuned traversal (k_trace3)
-    int trace3_blocks[2] = {0, 0};   // persistent grid of the closest-hit [0] / any-hit [1] entry point this scene uses (k_trace.hip: K3Shape)
+    // tuned traversal (k_trace5; the field names date from the retired one-node-step kernels)
+    int trace3_blocks[2] = {0, 0};   // persistent grid of the closest-hit [0] / any-hit [1] entry point this scene uses (k_trace.hip: K5Shape)
     int spill3_levels[2] = {1, 1};   // stack levels beyond the entry point's LDS levels (HBM spill)
     int trace3_per_cu_override = 0;  // SHM_TRACE3_BLOCKS_PER_CU (development)
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
@@ -308,7 +308,6 @@ struct ShmScene {
     LdsTables lds_tables_small = {};  // ... within the 1.5 KB the material-sorted triangle vertex kernel has to spare
     uint32_t* d_q_emit = nullptr;      // paths of the current fused-kernel launch that hit an emitter (k_emit_jobs)
     uint32_t* d_big_leaf_n = nullptr;  // n_prims by first primitive slot, only in scenes with a leaf of >= 15 primitives (the link word holds smaller counts)
-    bool trace_pair = true;          // triangle-only scenes: the both-children step (k_trace5) instead of the one-node step (k_trace3); SHM_TRACE_PAIR=0 for A/B
     float4* d_rw = nullptr;          // RandomWalk: (le, f cos) per depth per path, 2 * (max_depth + 1) * capacity float4
     size_t rw_floats4 = 0;
     uint32_t* d_spill3_any = nullptr;  // the any-hit kernel may run concurrently with the closest-hit one (second stream)
@@ -318,12 +317,14 @@ struct ShmScene {
     bool concurrent_scatter = true;  // SHM_CONCURRENT_SCATTER=0: everything on the render stream (A/B)
     hipStream_t stream_cls[4] = {nullptr, nullptr, nullptr, nullptr};  // staged shading: the scatter kernels of the 2nd .. 4th BxDF class of a bounce run beside the first one's
     uint64_t overlap_paths = 96ull << 20;  // batches below this many paths run K3(b) beside K2(b+1) (SHM_OVERLAP_PATHS; 0 = never)
-    int refill_min_any = 24;       // the any-hit kernel's threshold (SHM_REFILL_MIN_ANY)
-    int refill_min = 24;           // idle lanes before a wave refills (SHM_REFILL_MIN; r03 sweep on the rewritten kernel: 8 / 16 / 24 = 354 / 348 / 346 ms per frame)
+    // idle lanes before a traversal wave refills: the kernels set a ray up with the root test and six IEEE divisions (200 VALU instructions), so that fewer, fuller refills
+    // win although a quarter of the lanes idle (r04 sweep on the headline frame, closest / any ms: 24: 97.4 / 62.3, 40: 96.5 / 60.9, 48: 102.1 / 63.5, 56: 119.1 / 78.1)
+    int refill_min_any = 40;       // the any-hit kernel's threshold (SHM_REFILL_MIN_ANY)
+    int refill_min = 40;           // (SHM_REFILL_MIN)
     int trace_rays_per_lane = 4;   // a traversal launch uses as much of its persistent grid as gives each resident lane about this many rays (SHM_TRACE_RAYS_PER_LANE; 0 = always
                                    // the whole grid). profiles/r03_trace_rays_per_lane_sweep.txt: C2 16.8 / 16.1 / 15.8 / 15.8 / 16.5 ms at 0 / 4 / 8 / 16 / 32, C4's K2 276.7 / 276.8 / 282 / 307 / 362
     uint32_t pix_group = 1024;      // path-slot order [tile][sample][pixel in tile] (SHM_PIX_GROUP; >= n_pix: sample-major)
-    int queue_parts = 8;           // k_trace3 queue partitions, one per XCD with stealing (SHM_QUEUE_PARTS: 1 or 8)
+    int queue_parts = 8;           // the traversal queue's partitions, one per XCD with stealing (SHM_QUEUE_PARTS: 1 or 8)
     uint32_t* d_heads3 = nullptr;  // [2 (closest, any)][8 partitions][32 dwords: one 128-B line per head word]
     std::vector<hipEvent_t> events;
     struct DistState* dist = nullptr;  // multi-GPU state (dist.hip): communicator, this rank's tile shard, the gather plan

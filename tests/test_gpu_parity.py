@@ -156,15 +156,16 @@ def test_layered_walks_of_hundreds_of_steps(env):
     assert sg["rays_any"] > 1000  # (next-event estimation ran: the f and pdf walks too)
 
 
-@pytest.mark.parametrize("pair", ["1", "0"])
-def test_trace_both_step_kinds(env, monkeypatch, pair):
-    """Every scene is traced by the both-children step (k_trace5 / k_trace5<., GEN>, the default) or by the one-node step (k_trace3, SHM_TRACE_PAIR=0):
-    hit records, occlusion flags and all four visit counters equal the oracle's under either, on a deep tree (S3 proxy, stack spill exercised with depth
-    beyond the LDS levels), a shallow one, a tree with leaves of 1, 6, 7, 8, 14, 16 and 40 coincident triangles (the link word's count field saturates at 7:
-    ShmScene::d_big_leaf_n), one- and three-node trees, and the scenes with spheres, bilinear patches and instances (round 5: parked non-triangle tests,
-    the marker on the stack, sub-trees of one leaf, spheres and patches INSIDE instances)."""
+@pytest.mark.parametrize("other_min", ["16", "1", "64"])
+def test_trace_tree_shapes_and_parked_tests(env, monkeypatch, other_min):
+    """The traversal kernels (k_trace5 / k_trace5<., GEN>: the both-children step) against the oracle's scalar loop — hit records, occlusion flags and all four visit
+    counters — on a deep tree (S3 proxy, stack spill exercised with depth beyond the LDS levels), a shallow one, a tree with leaves of 1, 6, 7, 8, 14, 16 and 40 coincident
+    triangles (the link word's count field saturates at 7: ShmScene::d_big_leaf_n), one- and three-node trees, and the scenes with spheres, bilinear patches and instances
+    (round 5: parked non-triangle tests, the marker on the stack, sub-trees of one leaf, spheres and patches INSIDE instances) — with the parked tests run as the default
+    batches of 16, one at a time (SHM_OTHER_MIN=1) and only when nothing else can run (64). (Until round 5 this test also ran the one-node-step kernels k_trace3 as a
+    second implementation; they are retired, the oracle is the checker.)"""
     lib, oracle_py, render, scenes = env
-    monkeypatch.setenv("SHM_TRACE_PAIR", pair)
+    monkeypatch.setenv("SHM_OTHER_MIN", other_min)
     cases = [scenes.ganesha_proxy(lib, 64, 64, n=96), scenes.cornell_box(lib, 32, 32)] + [_stacked_leaf_scene(scenes, lib, c) for c in (6, 7, 8, 14, 16, 40)] + \
             [_tiny_tree_scene(scenes, lib, 1), _tiny_tree_scene(scenes, lib, 2)] + \
             [scenes.instanced_scene(lib, 32, 24), scenes.three_spheres(lib, 32, 24, camera=(0.75, 0.5, 9.0)), scenes.cornell_box(lib, 32, 32, patches=True),
@@ -440,16 +441,18 @@ def test_instance_root_inside_another_tree_is_rejected(env):
     r.close()
 
 
-@pytest.mark.parametrize("switch", ["SHM_LDS_TABLES", "SHM_LEAN_FIRST_BOUNCE", "SHM_TRACE_PAIR", "SHM_LEAN_DIVERT", "SHM_LAYERED_STAGED", "SHM_CTX_AS_HIT", "SHM_HIT16"])
+@pytest.mark.parametrize("switch", ["SHM_LDS_TABLES", "SHM_LEAN_FIRST_BOUNCE", "SHM_LEAN_DIVERT", "SHM_LAYERED_STAGED", "SHM_CTX_AS_HIT", "SHM_HIT16", "SHM_TAIL_SORT"])
 def test_ab_switches_change_no_result(env, monkeypatch, switch):
     """The round-4 optimisations each have an A/B switch read at scene creation / first launch; switched off, the films and the counters are the same bits:
-    the small scene tables staged in LDS, bounce 0 on known constants, the both-children traversal step, the lean diversion (its fused kernel defers emitter hits),
+    the small scene tables staged in LDS, bounce 0 on known constants, the lean diversion (its fused kernel defers emitter hits),
     the LayeredBxDF class as dense per-wave stages (k_scatter_layered.inl; off: one pass per vertex, k_scatter<CLASS_LAYERED>), the fused kernel's vertex leaving its hit
     record instead of its LightSampleContext for the next vertex's emitter MIS weight (all-diffuse triangle scenes; k_emit_jobs rebuilds the context), the render's own
-    hit array as 16-byte records in triangle scenes."""
+    hit array as 16-byte records in triangle scenes, the tail kernel's material-sorted chunks (the glass Cornell box at depth 14 crosses into the tail at bounce 8)."""
     lib, oracle_py, render, scenes = env
     cases = [(scenes.ganesha_proxy(lib, 64, 64, n=32), 6, 5), (scenes.cornell_box(lib, 48, 48, coated=True, emitter_reflects=True), 6, 5),
              (scenes.cornell_box(lib, 40, 40, textured=True), 4, 6)]
+    if switch == "SHM_TAIL_SORT":
+        cases = [(scenes.cornell_box(lib, 48, 48, glass=True), 6, 14)]
     for sc, spp, depth in cases:
         p = render.make_params(seed=9, spp=spp, max_depth=depth)
         monkeypatch.delenv(switch, raising=False)

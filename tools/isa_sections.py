@@ -32,7 +32,7 @@ MARKS5 = [("setup", "template <bool ANY, bool GEN, int LDS_N>"), ("refill (+ roo
           ("pair_step (2 x (load + slab test) + push)", "// ---- one uniform step: every lane that stands"),
           ("leaf_phase", "// ---- postponed leaf phase: lanes standing"), ("other_phase (GEN: sphere / patch / instance)", "// ---- GEN: the parked non-triangle tests"),
           ("pop", "// ---- pop: a lane whose two children"),
-          ("retire", "// ---- retire finished rays"), ("epilogue", "unsigned long long wn = c_nodes;"), ("end", "#ifndef K5_CLOSEST_WAVES")]
+          ("retire", "// ---- retire finished rays"), ("epilogue", "unsigned long long wn = c_nodes;"), ("end", "#ifndef K5_CLOSEST_WAVES")]  # (MARKS3: the retired one-node-step body; profiles/r03_k_trace3_isa*.txt were made with it)
 
 
 def sections_of(src_lines, marks, first_line=0):
@@ -70,8 +70,7 @@ def main():
     ap.add_argument("-o", "--out", help="also write the census to this file")
     args = ap.parse_args()  # (flags are parsed before anything is written: `--help` once became an output path)
     src = (CSRC / "k_trace.hip").read_text().splitlines()
-    secs3 = sections_of(src, MARKS3)
-    secs5 = sections_of(src, MARKS5, secs3[-1][2])
+    secs5 = sections_of(src, MARKS5)
     with tempfile.TemporaryDirectory() as tmp:
         subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-x", "hip", "-c", str(CSRC / "k_trace.hip"), "-I", str(CSRC), "-o", f"{tmp}/k.o", "-save-temps"],
                               cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -83,8 +82,7 @@ def main():
             files[int(m.group(1))] = m.group(3) or m.group(2)
     lines_out = [f"# static instruction census of the traversal kernels by section of trace5_body / trace3_body (tools/isa_sections.py; hipcc {' '.join(FLAGS[:3])} ...)"]
     for label, want, secs in (("k_trace5<closest> (both-children step)", "k_trace5ILb0ELb0EE", secs5), ("k_trace5<any>", "k_trace5ILb1ELb0EE", secs5),
-                              ("k_trace5<closest, GEN> (scenes with spheres / patches / instances)", "k_trace5ILb0ELb1EE", secs5), ("k_trace5<any, GEN>", "k_trace5ILb1ELb1EE", secs5),
-                              ("k_trace3<closest, TRI_ONLY> (one-node step)", "k_trace3ILb0ELb1EE", secs3), ("k_trace3<any, TRI_ONLY>", "k_trace3ILb1ELb1EE", secs3)):
+                              ("k_trace5<closest, GEN> (scenes with spheres / patches / instances)", "k_trace5ILb0ELb1EE", secs5), ("k_trace5<any, GEN>", "k_trace5ILb1ELb1EE", secs5)):
         start = next(i for i, l in enumerate(asm) if re.match(r"^_ZN.*" + want + r".*:", l))
         end = next(i for i in range(start, len(asm)) if asm[i].strip().startswith(".Lfunc_end"))
         counts = defaultdict(lambda: defaultdict(int))
