@@ -66,6 +66,7 @@ struct FlatScene {
         shm::SceneView v;
         v.quirks_off = 0;
         v.call_copy = nullptr;  // (device only: set per workgroup by the kernels that evaluate textures)
+        v.inst_roots = nullptr;  // (device only)
         v.nodes = nodes.data();
         v.n_nodes = (uint32_t)nodes.size();
         v.prim_recs = prim_recs.data();

@@ -449,6 +449,32 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                         restore_ray_state(0);
                         cur = CUR_POP;
                         entered = true;  // (its ray changed)
+                    } else if (cur >= LEAF_KIND && ((cur >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX) == 0u) {
+                        // TransformedPrimitive (primitive.rs:158-176), reached straight from the node step: the link word of its leaf holds the instance's index (render.hip,
+                        // upload). ONE round trip — the ray's direction, the instance's matrix and its tree's root record are fetched side by side — then: the outer ray's
+                        // state to save area 0, a marker on the stack — with t_max as it is outside (closest-hit) or the phantoms below (any-hit) —, the ray into the
+                        // instance's space — apply_ray_inverse for intersect, the FORWARD apply_ray for intersect_predicate, as the reference writes them — and the
+                        // instanced aggregate's root tested (BvhAggregate::intersect's first node)
+                        const uint32_t idx = cur & LINK_INDEX_MASK;
+                        const ShmInstance& in = sv.instances[idx];
+                        const float4* rp = reinterpret_cast<const float4*>(rays + path);
+                        const float4 r0 = rp[0], r1 = rp[1];
+                        const float4* rn = reinterpret_cast<const float4*>(sv.inst_roots + idx);
+                        const float4 ra = rn[0], rb = rn[1];
+                        const uint32_t slot = in.pad[0];
+                        const V3 rd = v3(r0.w, r1.x, r1.y);
+                        save_ray_state(0);
+                        if (ANY) { push((uint32_t)CUR_MARKER | slot, ph_top); ph_top = 0u; }
+                        else push((uint32_t)CUR_MARKER | slot, __float_as_uint(t_max));
+                        sgn = (sgn & (SGN_RAY | SGN_HIT)) | ((idx + 1u) << SGN_INST_SHIFT);
+                        Ray r;
+                        if (ANY) { Ray w; w.o = ro; w.d = rd; r = xf_ray(in.render_from_primitive, w); }
+                        else r = xf_ray_inverse(in.primitive_from_render, ro, rd, t_max);
+                        set_ray(r.o, r.d);
+                        cur = root_test(ra, rb) ? __float_as_uint(rb.z) : (uint32_t)CUR_POP;  // (a miss pops the marker: back out)
+                        if (ANY) c_nodes += 1u;
+                        entered = true;
+                        root_tested = true;
                     } else if (cur >= LEAF_KIND) {
                         uint32_t slot = cur & LINK_INDEX_MASK;
                         // (opaque to the optimiser: a lane may have parked in THIS iteration's leaf phase, and the compiler, seeing the same address, kept the record that
@@ -469,27 +495,8 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                             const ShmInstance& in = sv.instances[(sgn >> SGN_INST_SHIFT) - 1u];
                             rd = xf_vector(ANY ? in.render_from_primitive : in.primitive_from_render, rd);
                         }
-                        if (kind & PRIM_INSTANCE_BIT) {
-                            // TransformedPrimitive (primitive.rs:158-176; alone in its top-level leaf, flatten.h): the outer ray's state goes to save area 0, a marker on the
-                            // stack — with t_max as it is outside (closest-hit) or the phantoms below (any-hit) —, the ray into the instance's space — apply_ray_inverse for
-                            // intersect, the FORWARD apply_ray for intersect_predicate, as the reference writes them — and the instanced aggregate's root is tested
-                            // (BvhAggregate::intersect's first node)
-                            save_ray_state(0);
-                            if (ANY) { push((uint32_t)CUR_MARKER | slot, ph_top); ph_top = 0u; }
-                            else push((uint32_t)CUR_MARKER | slot, __float_as_uint(t_max));
-                            sgn = (sgn & (SGN_RAY | SGN_HIT)) | (((kind & PRIM_INDEX_MASK) + 1u) << SGN_INST_SHIFT);
-                            const ShmInstance& in = sv.instances[kind & PRIM_INDEX_MASK];
-                            Ray r;
-                            if (ANY) { Ray w; w.o = ro; w.d = rd; r = xf_ray(in.render_from_primitive, w); }
-                            else r = xf_ray_inverse(in.primitive_from_render, ro, rd, t_max);
-                            set_ray(r.o, r.d);
-                            const float4* rn = reinterpret_cast<const float4*>(node_base + ((size_t)in.root_node << 5));
-                            const float4 ra = rn[0], rb = rn[1];
-                            cur = root_test(ra, rb) ? __float_as_uint(rb.z) : (uint32_t)CUR_POP;  // (a miss pops the marker: back out)
-                            if (ANY) c_nodes += 1u;
-                            entered = true;
-                            root_tested = true;
-                        } else {
+                        {
+                            // (a sphere or a bilinear patch: an instance never parks here — it is alone in its leaf, and such a leaf's link word names it, above)
                             save_ray_state(1);  // (... and nothing of it is live across the test)
                             bool got;
                             Float t_hit, h0, h1, h2, h_phi;

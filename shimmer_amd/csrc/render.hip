@@ -437,12 +437,27 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
                     if (big_leaf_n.empty()) big_leaf_n.assign(f.prim_recs.size(), 0u);
                     for (uint32_t j = 0; j < n.n_prims; ++j) big_leaf_n[n.offset + j] = n.n_prims - j;  // (the primitives left from each slot on: k_trace5 takes one per phase)
                 }
-                n.offset = LINK_LEAF | (std::min<uint32_t>(n.n_prims, LINK_COUNT_MAX) << LINK_COUNT_SHIFT) | n.offset;
+                // a leaf of ONE primitive that is no triangle is marked as such in the link word itself — a lane that reaches it parks for the wave's next round of
+                // non-triangle work straight from the node step, without the leaf phase's fetch of a record it cannot test (k_trace5<., GEN>):
+                //   an instance (always alone in its leaf, flatten.h): count 0, the INDEX of the instance in place of the slot (its slot rides in the device copy's pad[0]);
+                //   a sphere / a bilinear patch: count 1 and the slot, as a lane would have parked on it
+                const uint32_t kind1 = n.n_prims == 1 ? f.prim_recs[n.offset].kind_index : 0u;
+                if (kind1 & shm::PRIM_INSTANCE_BIT) {
+                    const uint32_t idx = kind1 & shm::PRIM_INDEX_MASK;
+                    pair_instances[idx].pad[0] = n.offset;
+                    n.offset = LINK_LEAF | LINK_OTHER | idx;
+                } else if (kind1 & (shm::PRIM_SPHERE_BIT | shm::PRIM_PATCH_BIT)) {
+                    n.offset = LINK_LEAF | LINK_OTHER | (1u << LINK_COUNT_SHIFT) | n.offset;
+                } else {
+                    n.offset = LINK_LEAF | (std::min<uint32_t>(n.n_prims, LINK_COUNT_MAX) << LINK_COUNT_SHIFT) | n.offset;
+                }
             }
             pair_nodes[new_index[o]] = n;
         }
         for (ShmInstance& in : pair_instances) in.root_node = new_index[in.root_node];
     }
+    std::vector<ShmBvhNode> inst_roots;
+    for (const ShmInstance& in : pair_instances) inst_roots.push_back(pair_nodes[in.root_node]);
     if ((rc = dev_upload(s, pair_nodes, &v.nodes)) != SHM_OK) return fail(rc);
     if (!big_leaf_n.empty()) { const uint32_t* d = nullptr; if ((rc = dev_upload(s, big_leaf_n, &d)) != SHM_OK) return fail(rc); s->d_big_leaf_n = const_cast<uint32_t*>(d); }
     if ((rc = dev_upload(s, f.prim_recs, &v.prim_recs)) != SHM_OK) return fail(rc);
@@ -474,6 +489,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if ((rc = dev_upload(s, f.cs_illuminant, &v.cs_illuminant)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ewa_lut, &v.ewa_lut)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, pair_instances, &v.instances)) != SHM_OK) return fail(rc);
+    if ((rc = dev_upload(s, inst_roots, &v.inst_roots)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.float_textures, &v.float_textures)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ftex_ranges, &v.ftex_ranges)) != SHM_OK) return fail(rc);
     if ((rc = dev_upload(s, f.ftex_ops, &v.ftex_ops)) != SHM_OK) return fail(rc);

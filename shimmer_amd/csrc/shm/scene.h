@@ -107,6 +107,9 @@ struct SceneView {
     // device only: the workgroup's copy of this object in LDS, which the texture evaluators that are real calls read the scene through (shm/texture.h,
     // SHM_SV_FOR_CALL; set by stage_scene_tables_tex in the kernels that evaluate textures, never read on the host)
     const SceneView* call_copy;
+    // device only (null on the host): per instance, a copy of the device record of its tree's root node — what the traversal kernel tests where a ray enters the instance,
+    // fetched with the instance's matrices instead of behind them (render.hip, upload)
+    const ShmBvhNode* inst_roots;
 };
 
 // A FloatTexture tree flattened at scene creation into a post-order program: evaluating the ops in order (each into slot k of a
