@@ -312,7 +312,7 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
         b.add_mesh(_to_render(verts, rfw), tris, obj)
     if variant == "one_sphere":
         rfo = np.eye(4, dtype=np.float32)
-        rfo[:3, 3] = _to_render(np.array([[1.75, -0.8, 0.9]], np.float32), rfw)[0]
+        rfo[:3, 3] = _to_render(np.array([[0.7, -0.8, 1.7]], np.float32), rfw)[0]  # (in front of the object, to the right: in the camera's view)
         b.add_sphere(0.45, wall, render_from_object=rfo)
     if with_room:
         # ground (2) + open room (10: back, left, right, ceiling, front-top strip) + window emitter (2)

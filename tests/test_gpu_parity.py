@@ -389,6 +389,42 @@ def test_headline_frame_at_full_size(env):
     gpu.close()
 
 
+@pytest.mark.parametrize("variant,crop", [("patch_emitter", (504, 440, 520, 456)), ("one_sphere", (152, 920, 168, 936)), ("instanced", (504, 440, 520, 456))])
+def test_mixed_shape_frames_at_full_size(env, variant, crop):
+    """The headline frame with the shapes a real PBRT-v4 scene mixes into its triangles (bench.py's round-5 side results: the emitter as ONE bilinear patch, a sphere
+    beside the object, the object as a TransformedPrimitive) at its own size — 4.3 M primitives, 1024 x 1024, 256 spp, one 268 M-path batch through k_trace5<., GEN> and the
+    general fused kernel: two renders identical in film and counters; every pixel 256 samples, finite; a 16 x 16 block at all 256 samples — on the object, on the sphere
+    where there is one — equal to the oracle's film bit for bit, with the block's node / primitive visit counters."""
+    lib, oracle_py, render, scenes = env
+    from shimmer_amd import scene as scn
+    sc = scenes.ganesha_proxy(lib, 1024, 1024, variant=variant)
+    p = render.make_params(seed=0, spp=256, max_depth=5)
+    gpu = render.Renderer(lib, sc.desc, 0)
+    gpu.clear()
+    s1 = gpu.render_device(p)
+    f1 = gpu.read_film()
+    gpu.clear()
+    s2 = gpu.render_device(p)
+    assert np.array_equal(f1, gpu.read_film())
+    for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+        assert s1[k] == s2[k], k
+    assert (f1["weight_sum"] == 256.0).all() and np.isfinite(f1["rgb_sum"]).all() and s1["paths"] == 1024 * 1024 * 256
+    x0, y0, x1, y1 = crop
+    tiles, n = scn.tiles_for(lib, crop)
+    orc = oracle_py.Oracle(sc.desc)
+    fo, so = orc.render(p, n_threads=os.cpu_count() or 1, tiles=tiles, n_tiles=n)
+    orc.close()
+    assert np.array_equal(f1[y0:y1, x0:x1], fo[y0:y1, x0:x1])
+    assert fo[y0:y1, x0:x1]["rgb_sum"].max() > 0
+    sel = np.array([i for i in range(gpu.n_tiles) if (lambda t: t.x0 >= x0 and t.x1 <= x1 and t.y0 >= y0 and t.y1 <= y1)(gpu.tiles[i])])
+    assert len(sel) == n == 4
+    gpu.clear()
+    sc_ = gpu.render_device(p, tile_indices=sel)
+    for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+        assert sc_[k] == so[k], k
+    gpu.close()
+
+
 def test_c4_frame_at_full_size(env):
     """BASELINE.json configs[3] at its own size — the crown proxy (64 dispersive-glass + 16 rough-gold icospheres, 410 k triangles), 1000 x 1400,
     256 spp, maxdepth 32 (358 M paths in one batch, 33 bounces through the staged vertex / per-class scatter kernels): run-to-run identity,
