@@ -25,9 +25,11 @@ CONFIGS = [
     ("C2f-ewa cornell textured, every filter ewa", lambda: scenes.cornell_box(lib, 512, 512, textured=True, texture_filter="ewa"), 64, 6),
     ("E3 spheres + environment map 512x384x64", lambda: scenes.three_spheres(lib, 512, 384, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(64)), 64, 5),
 ]
-only = sys.argv[1:] 
+only = sys.argv[1:]
+KEYS = {c[0].split()[0] for c in CONFIGS}
 for name, make, spp, depth in CONFIGS:
-    if only and not any(o in name for o in only):
+    # an argument that is a configuration's key ("S3", "S3c") selects that one; anything else is a substring of the name
+    if only and not any(name.split()[0] == o if o in KEYS else o in name for o in only):
         continue
     sc = make()
     r = render.Renderer(lib, sc.desc, 0)
