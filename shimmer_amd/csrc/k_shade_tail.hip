@@ -10,8 +10,7 @@ int wf_launch_shade_tail(ShmScene* s, const ShadeArgs& a) {
 #define CTX_AS_HIT_FLAG 0  // (the tail kernel follows staged bounces: the vertex context stays the LightSampleContext)
     // material-sorted chunks when the scene holds more than one material (k_shade_tail_sorted.hip: its own translation unit — two instantiations of the kernel in one
     // unit stop the inliner, 121 spilled VGPRs in BOTH; SHM_TAIL_SORT=0: A/B)
-    static const int sort_on = [] { const char* e = getenv("SHM_TAIL_SORT"); return e ? atoi(e) : 1; }();
-    if (sort_on && s->flat.materials.size() > 1) return wf_launch_shade_tail_sorted(s, a);
+    if (s->tail_sort && s->flat.materials.size() > 1) return wf_launch_shade_tail_sorted(s, a);
     WF_SHADE_LAUNCH((k_shade<false, true, false, false>));
 #undef CTX_AS_HIT_FLAG
     return SHM_OK;

@@ -69,7 +69,7 @@ __device__ __forceinline__ Float vmin3(Float a, Float b, Float c) { Float r; asm
 // ---------------------------------------------------------------------------------------------
 #ifdef K5_CENSUS
 // development build (-DK5_CENSUS): per-phase lane census of the closest-hit kernel, printed by wf_trace_census() at scene destruction
-__device__ unsigned long long g_census[24];
+__device__ unsigned long long g_census[32];
 #define CENSUS(i, v) do { if (ANY == (K5_CENSUS == 2)) c_census[i] += (unsigned long long)(v); } while (0)  // -DK5_CENSUS=1: closest-hit, =2: any-hit
 #else
 #define CENSUS(i, v) do { } while (0)
@@ -131,7 +131,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     unsigned long long w_nodes = 0, w_rays = 0, w_prims = 0;  // closest-hit: all three per wave in scalar registers
     uint32_t c_nodes = 0, ph_top = 0;                         // any-hit: node visits per lane (phantoms make the increments differ), phantoms above the top entry
 #ifdef K5_CENSUS
-    unsigned long long c_census[24] = {0};
+    unsigned long long c_census[32] = {0};
 #endif
 
     bool exhausted = false;          // wave-uniform
@@ -361,6 +361,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         if (!ANY) w_nodes += 2ull * (unsigned long long)__popcll(__ballot(at_node));
         CENSUS(0, 1); CENSUS(1, __popcll(__ballot(at_node))); CENSUS(2, __popcll(__ballot((cur & 0xC0000000u) == 0x80000000u))); CENSUS(21, __popcll(__ballot(cur >= 0xC0000000u))); CENSUS(3, __popcll(__ballot(cur == CUR_IDLE)));
         CENSUS(4, __popcll(__ballot(cur == CUR_POP))); CENSUS(10, __ballot(at_node) != 0ull ? 1 : 0);
+        CENSUS(22, (__ballot(at_node) != 0ull && __popcll(__ballot(at_node)) <= 8) ? 1 : 0);  // (a VALU instruction with 8 or fewer lanes on costs 4.5 x one with 9: profiles/r05_valu_exec.txt)
         if (at_node) {
             // near child first (aggregate.rs:119-127: dir_is_neg[axis] picks it); pairs start at even indices, so the sibling's record is at byte offset ^ 32
             const uint32_t neg = (sgn >> (cur >> LINK_AXIS_SHIFT)) & 1u;
@@ -397,7 +398,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                 // per phase, 13 % of the kernel's instructions on the headline frame)
                 const bool on_leaf = GEN ? ((cur & LEAF_KIND) == LINK_LEAF) : ((int32_t)cur < 0);
                 if (!GEN) w_prims += (unsigned long long)__popcll(__ballot(on_leaf));
-                CENSUS(5, 1); CENSUS(6, 1); CENSUS(7, __popcll(__ballot(on_leaf)));
+                CENSUS(5, 1); CENSUS(6, 1); CENSUS(7, __popcll(__ballot(on_leaf))); CENSUS(23, __popcll(__ballot(on_leaf)) <= 8 ? 1 : 0);
                 bool tested = false;  // (GEN: the lanes whose record was a triangle; the others park)
                 if (on_leaf) {
                     const uint32_t slot = cur & LINK_INDEX_MASK;
@@ -441,7 +442,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                 const bool busy_elsewhere = __ballot(cur < (uint32_t)CUR_FIRST_SPECIAL || (cur & LEAF_KIND) == LINK_LEAF) != 0ull;
                 if (__builtin_expect(__popcll(other_mask) >= other_min || !busy_elsewhere, 0)) {
                     w_prims += (unsigned long long)__popcll(__ballot(cur >= LEAF_KIND && cur != LINK_LEAVE));
-                    CENSUS(15, 1); CENSUS(16, __popcll(other_mask)); CENSUS(17, busy_elsewhere ? 0 : 1);
+                    CENSUS(15, 1); CENSUS(16, __popcll(other_mask)); CENSUS(17, busy_elsewhere ? 0 : 1); CENSUS(27, __popcll(other_mask) <= 8 ? 1 : 0);
                     since_other = 0u;
                     bool entered = false, root_tested = false;
                     if (cur == LINK_LEAVE) {
@@ -546,7 +547,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
 #endif
         for (int round = 0; round < (ANY ? 1 : K5_POP_ROUNDS); ++round) {  // (closest-hit: a culled entry costs no fetch; further rounds let its lane try the next one at once)
             if (__ballot(cur == CUR_POP) == 0ull) break;
-            CENSUS(8, 1); CENSUS(9, __popcll(__ballot(cur == CUR_POP)));
+            CENSUS(8, 1); CENSUS(9, __popcll(__ballot(cur == CUR_POP))); CENSUS(24, __popcll(__ballot(cur == CUR_POP)) <= 8 ? 1 : 0);
             if (cur == CUR_POP) {
                 if (ANY) { c_nodes += ph_top; ph_top = 0u; }  // the phantoms above the newest entry: popped, tested, dropped, one after the other
                 if (top == st_base) cur = CUR_DONE;
@@ -573,6 +574,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
             }
         }
         // ---- retire finished rays ----
+        CENSUS(26, __ballot(cur == CUR_DONE) != 0ull ? 1 : 0); CENSUS(25, (__ballot(cur == CUR_DONE) != 0ull && __popcll(__ballot(cur == CUR_DONE)) <= 8) ? 1 : 0);
         if (cur == CUR_DONE) {
             const bool found = (sgn & SGN_HIT) != 0u;
             if (ANY) {
@@ -600,7 +602,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     }
 #ifdef K5_CENSUS
     CENSUS(14, __builtin_readcyclecounter() - t_loop0);
-    if (ANY == (K5_CENSUS == 2) && lane == 0) for (int i = 0; i < 24; ++i) if (c_census[i]) atomicAdd(&g_census[i], c_census[i]);
+    if (ANY == (K5_CENSUS == 2) && lane == 0) for (int i = 0; i < 32; ++i) if (c_census[i]) atomicAdd(&g_census[i], c_census[i]);
 #endif
     if (ANY) {
         unsigned long long wn = c_nodes;
@@ -1023,7 +1025,7 @@ __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x;
 
 void wf_trace_census() {
 #ifdef K5_CENSUS
-    unsigned long long c[24];
+    unsigned long long c[32];
     if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_census), sizeof(c)) != hipSuccess || !c[0]) return;
     const double it = (double)c[0];
     fprintf(stderr, "[k5 census, %s] wave iterations %.3e | lanes per iteration: at a node %.1f, on a pending leaf %.1f, idle %.1f, pop pending %.1f | iterations with a node step %.3f\n"
@@ -1032,6 +1034,9 @@ void wf_trace_census() {
             (double)c[11], (double)c[12] / (double)c[11]);
     if (c[15]) fprintf(stderr, "  GEN: parked on a non-triangle test %.1f lanes per iteration | other phases %.3e (one per %.2f iterations) at %.1f lanes, %.1f %% of them because nothing else could run | instance entries %.3e | leave rounds %.3e at %.1f lanes\n",
                        c[21] / it, (double)c[15], it / (double)c[15], (double)c[16] / (double)c[15], 100.0 * (double)c[17] / (double)c[15], (double)c[18], (double)c[19], c[19] ? (double)c[20] / (double)c[19] : 0.0);
+    fprintf(stderr, "  with 8 or fewer lanes on: %.1f %% of the node steps, %.1f %% of the leaf phases, %.1f %% of the pop rounds, %.1f %% of the %.3e retire rounds, %.1f %% of the other phases\n",
+            100.0 * (double)c[22] / (double)(c[10] ? c[10] : 1), 100.0 * (double)c[23] / (double)(c[5] ? c[5] : 1), 100.0 * (double)c[24] / (double)(c[8] ? c[8] : 1), 100.0 * (double)c[25] / (double)(c[26] ? c[26] : 1), (double)c[26],
+            100.0 * (double)c[27] / (double)(c[15] ? c[15] : 1));
     fprintf(stderr, "  s_memtime ticks: in refills %.3e of %.3e wave-loop ticks = %.1f %% (%.0f ticks per refill)\n", (double)c[13], (double)c[14], 100.0 * (double)c[13] / (double)c[14], (double)c[13] / (double)c[11]);
 #endif
 }

@@ -530,6 +530,9 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
     if (const char* e = getenv("SHM_OTHER_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min = s->other_min_any = v2; }
+    if (const char* e = getenv("SHM_TAIL_FUSED_BOUNCE")) { const int v2 = atoi(e); s->tail_fused_bounce = v2 >= 0 ? v2 : 1 << 30; }
+    if (const char* e = getenv("SHM_FUSED_TEX")) s->fused_tex = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("SHM_TAIL_SORT")) s->tail_sort = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_OTHER_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min_any = v2; }
     if ((rc = wf_trace_prepare(s)) != SHM_OK) return fail(rc);
     DBG("scene: %u nodes, depth %u, trace blocks %d / %d, spill levels %d / %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->trace3_blocks[0], s->trace3_blocks[1],
@@ -729,11 +732,12 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 hipEventRecord(s0, s->stream);
                 const ShadeArgs sa{s->stream, cur, *params, sh, shade_blocks, first_lean ? 1 : 0, hit_kept ? 1 : 0};
                 const bool tri_only = !s->flat.has_spheres;
-                // the late bounces of a deep render in a triangle scene without textures or coated materials: ONE fused launch instead of the staged four or five
-                // (C4 frame, same box: 522-528 ms staged throughout; 510-512 from bounce 6, 511-513 from 8, 512-513 from 10, 514-517 from 14; 0 = off)
-                static const int tail_fused_bounce = [] { const char* e = getenv("SHM_TAIL_FUSED_BOUNCE"); const int v = e ? atoi(e) : 8; return v >= 1 ? v : 1 << 30; }();
-                if (staged && bounce >= tail_fused_bounce && tri_only && !s->flat.has_textures && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0) {
-                    rc = wf_launch_shade_tail(s, sa);
+                // a triangle scene with several BxDF classes but without textures or coated materials: ONE fused all-materials launch per bounce instead of the staged
+                // four or five, from bounce `tail_fused_bounce` on. Rounds 3-4, chunks unsorted: only the late bounces paid (C4 frame 522-528 ms staged throughout,
+                // 510-512 from bounce 6, 511-513 from 8). Round 5, chunks counting-sorted by material (k_shade_tail_sorted.hip): the earlier the better — C4 403.2 ms
+                // from bounce 8, 399 from 4, 388 from 2, 378 from 1, 365 from 0: the default (SHM_TAIL_FUSED_BOUNCE, negative = never; read at scene creation)
+                if (staged && bounce >= s->tail_fused_bounce && tri_only && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || s->fused_tex)) {
+                    rc = s->flat.has_textures ? wf_launch_shade_fused_tex(s, sa) : wf_launch_shade_tail(s, sa);
                 } else if (staged) {
                     // hit half (interaction, emission, get_bsdf -> parameter block, class queues), then one scattering kernel per BxDF
                     // class the scene holds, each over its own material-sorted queue

@@ -483,7 +483,7 @@ def test_ab_switches_change_no_result(env, monkeypatch, switch):
     the small scene tables staged in LDS, bounce 0 on known constants, the lean diversion (its fused kernel defers emitter hits),
     the LayeredBxDF class as dense per-wave stages (k_scatter_layered.inl; off: one pass per vertex, k_scatter<CLASS_LAYERED>), the fused kernel's vertex leaving its hit
     record instead of its LightSampleContext for the next vertex's emitter MIS weight (all-diffuse triangle scenes; k_emit_jobs rebuilds the context), the render's own
-    hit array as 16-byte records in triangle scenes, the tail kernel's material-sorted chunks (the glass Cornell box at depth 14 crosses into the tail at bounce 8)."""
+    hit array as 16-byte records in triangle scenes, the tail kernel's material-sorted chunks (the glass Cornell box at depth 14: the tail kernel from bounce 1 on)."""
     lib, oracle_py, render, scenes = env
     cases = [(scenes.ganesha_proxy(lib, 64, 64, n=32), 6, 5), (scenes.cornell_box(lib, 48, 48, coated=True, emitter_reflects=True), 6, 5),
              (scenes.cornell_box(lib, 40, 40, textured=True), 4, 6)]
@@ -502,6 +502,27 @@ def test_ab_switches_change_no_result(env, monkeypatch, switch):
         assert np.array_equal(f_on, f_off), (switch, sc.name)
         for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
             assert s_on[k] == s_off[k], (switch, sc.name, k)
+
+
+@pytest.mark.parametrize("first", ["-1", "0", "3"])
+def test_fused_all_materials_kernel_from_any_bounce(env, monkeypatch, first):
+    """Triangle scenes with several BxDF classes (no textures, no coated materials) shade with ONE fused all-materials launch per bounce from bounce
+    SHM_TAIL_FUSED_BOUNCE on (default 1; k_shade_tail*.hip) and with the staged kernels (k_vertex + one scatter kernel per class) before it: whichever bounce the switch
+    is made at — never (-1), from the camera ray's hit on (0), from bounce 3 — the films and the counters are the same bits. (The knob is read at scene creation.)"""
+    lib, oracle_py, render, scenes = env
+    for sc, spp, depth in [(scenes.cornell_box(lib, 48, 48, glass=True), 6, 14), (scenes.crown_proxy(lib, 40, 56, level=1, n_glass=6, n_gold=3), 4, 12)]:
+        p = render.make_params(seed=5, spp=spp, max_depth=depth)
+        monkeypatch.delenv("SHM_TAIL_FUSED_BOUNCE", raising=False)
+        g = render.Renderer(lib, sc.desc, 0)
+        f_def, s_def = g.render(p)
+        g.close()
+        monkeypatch.setenv("SHM_TAIL_FUSED_BOUNCE", first)
+        g = render.Renderer(lib, sc.desc, 0)
+        f_alt, s_alt = g.render(p)
+        g.close()
+        assert np.array_equal(f_def, f_alt), (first, sc.name)
+        for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+            assert s_def[k] == s_alt[k], (first, sc.name, k)
 
 
 def test_workspace_is_not_reallocated_between_equal_renders(env):
