@@ -531,6 +531,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
     if (const char* e = getenv("SHM_OTHER_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min = s->other_min_any = v2; }
     if (const char* e = getenv("SHM_TAIL_FUSED_BOUNCE")) { const int v2 = atoi(e); s->tail_fused_bounce = v2 >= 0 ? v2 : 1 << 30; }
+    if (const char* e = getenv("SHM_FUSED_GEN")) s->fused_gen = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_FUSED_TEX")) s->fused_tex = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_TAIL_SORT")) s->tail_sort = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_OTHER_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min_any = v2; }
@@ -736,8 +737,9 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 // four or five, from bounce `tail_fused_bounce` on. Rounds 3-4, chunks unsorted: only the late bounces paid (C4 frame 522-528 ms staged throughout,
                 // 510-512 from bounce 6, 511-513 from 8). Round 5, chunks counting-sorted by material (k_shade_tail_sorted.hip): the earlier the better — C4 403.2 ms
                 // from bounce 8, 399 from 4, 388 from 2, 378 from 1, 365 from 0: the default (SHM_TAIL_FUSED_BOUNCE, negative = never; read at scene creation)
-                if (staged && bounce >= s->tail_fused_bounce && tri_only && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || s->fused_tex)) {
-                    rc = s->flat.has_textures ? wf_launch_shade_fused_tex(s, sa) : wf_launch_shade_tail(s, sa);
+                if (staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || s->fused_tex) && (tri_only || s->fused_gen)) {
+                    rc = tri_only ? (s->flat.has_textures ? wf_launch_shade_fused_tex(s, sa) : wf_launch_shade_tail(s, sa))
+                                  : (s->flat.has_textures ? wf_launch_shade_fused_gen_tex(s, sa) : wf_launch_shade_fused_gen(s, sa));
                 } else if (staged) {
                     // hit half (interaction, emission, get_bsdf -> parameter block, class queues), then one scattering kernel per BxDF
                     // class the scene holds, each over its own material-sorted queue

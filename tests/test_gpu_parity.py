@@ -507,10 +507,15 @@ def test_ab_switches_change_no_result(env, monkeypatch, switch):
 @pytest.mark.parametrize("first", ["-1", "0", "3"])
 def test_fused_all_materials_kernel_from_any_bounce(env, monkeypatch, first):
     """Triangle scenes with several BxDF classes (no textures, no coated materials) shade with ONE fused all-materials launch per bounce from bounce
-    SHM_TAIL_FUSED_BOUNCE on (default 1; k_shade_tail*.hip) and with the staged kernels (k_vertex + one scatter kernel per class) before it: whichever bounce the switch
-    is made at — never (-1), from the camera ray's hit on (0), from bounce 3 — the films and the counters are the same bits. (The knob is read at scene creation.)"""
+    SHM_TAIL_FUSED_BOUNCE on (k_shade_tail*.hip, k_shade_fused_*.hip) and with the staged kernels (k_vertex + one scatter kernel per class) before it: whichever bounce the switch
+    is made at — never (-1), from the camera ray's hit on (0: the default), from bounce 3 — the films and the counters are the same bits. (The knob is read at scene creation.)"""
     lib, oracle_py, render, scenes = env
-    for sc, spp, depth in [(scenes.cornell_box(lib, 48, 48, glass=True), 6, 14), (scenes.crown_proxy(lib, 40, 56, level=1, n_glass=6, n_gold=3), 4, 12)]:
+    cases = [(scenes.cornell_box(lib, 48, 48, glass=True), 6, 14), (scenes.crown_proxy(lib, 40, 56, level=1, n_glass=6, n_gold=3), 4, 12),
+             # ... the same kernel's other instantiations: with textures (k_shade_fused_tex.hip), for scenes with spheres / patches / instances (k_shade_fused_gen.hip), both
+             # (k_shade_fused_gen_tex.hip: the environment map is an image)
+             (scenes.cornell_box(lib, 40, 40, textured=True, textured_coated_ceiling=False), 4, 6), (scenes.instanced_scene(lib, 48, 36), 4, 6),
+             (scenes.three_spheres(lib, 48, 36, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(32)), 4, 5)]
+    for sc, spp, depth in cases:
         p = render.make_params(seed=5, spp=spp, max_depth=depth)
         monkeypatch.delenv("SHM_TAIL_FUSED_BOUNCE", raising=False)
         g = render.Renderer(lib, sc.desc, 0)
