@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
               const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
               my_path[k] = 0u;
               if (i < n) {
-                  my_path[k] = q_cur[i];
+                  my_path[k] = first_bounce ? i : q_cur[i];  // (bounce 0 on known constants: the identity queue was not written)
                   const int prim = __float_as_int((TRI_ONLY && pa.hit16) ? reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + my_path[k])[0]
                                                                         : reinterpret_cast<const float*>(pa.hit + my_path[k])[0]);
                   uint32_t key = (uint32_t)SHADE_SORT_BINS;
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
         bool push_next = false, push_shadow = false, push_emit = false;
         uint32_t path = 0;
         if (active) {
-            // first_bounce (wave-uniform; the lean instantiation only): k_generate left the constants out — the queue is the identity, beta = 1, p_b = eta_scale = 1, flags = 0
+            // first_bounce (wave-uniform; the lean class and, since round 5, every class whose bounce 0 runs this kernel): k_generate left the constants out — the queue is the identity, beta = 1, p_b = eta_scale = 1, flags = 0
             path = SORT_CHUNK ? s_sorted[k * SHADE2_BLOCK + threadIdx.x] : (first_bounce ? i : q_cur[i]);
             Hit hit;
             if (TRI_ONLY) {

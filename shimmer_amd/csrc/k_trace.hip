@@ -545,6 +545,10 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
 #ifndef K5_POP_ROUNDS
 #define K5_POP_ROUNDS 1
 #endif
+#ifndef K5_LEAVE_INLINE
+#define K5_LEAVE_INLINE 1  // (0: a lane that popped an instance's marker parks as LINK_LEAVE and gets the outer ray back in the wave's next parked round — S3 instanced: K2 160 against 152.6 ms)
+#endif
+        bool left = false;  // GEN, K5_LEAVE_INLINE: this lane popped the marker of an instance
         for (int round = 0; round < (ANY ? 1 : K5_POP_ROUNDS); ++round) {  // (closest-hit: a culled entry costs no fetch; further rounds let its lane try the next one at once)
             if (__ballot(cur == CUR_POP) == 0ull) break;
             CENSUS(8, 1); CENSUS(9, __popcll(__ballot(cur == CUR_POP))); CENSUS(24, __popcll(__ballot(cur == CUR_POP)) <= 8 ? 1 : 0);
@@ -565,13 +569,24 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                         else if (sgn & SGN_HIT_INSIDE) reinterpret_cast<int32_t*>(hits + path)[6] = (int32_t)(e.x & LINK_INDEX_MASK) + 1;
                         else t_max = __uint_as_float(e.y);
                         sgn &= SGN_RAY | SGN_HIT;
+#if K5_LEAVE_INLINE
+                        left = true;  // the outer ray's state comes back behind the pop rounds (three loads from save area 0), the lane pops on in the next iteration
+#else
                         cur = LINK_LEAVE;  // parks: the outer ray's state comes back in the wave's next round of parked work (one ray leaves per three iterations: on its own, a round per leave)
+#endif
                     }
                     else if (ANY) { c_nodes += 1u; ph_top = e.y; cur = e.x; }
                     else if (__uint_as_float(e.y) < t_max) cur = e.x;  // the rest of the far child's test, against the t_max of now
                     // (else: culled without a fetch; the lane pops again in the next iteration)
                 }
             }
+        }
+        if (GEN && K5_LEAVE_INLINE && __builtin_expect(__ballot(left) != 0ull, 0)) {
+            if (left) restore_ray_state(0);
+            m_negx = __ballot((sgn & 1u) != 0u);
+            m_negy = __ballot((sgn & 2u) != 0u);
+            m_negz = __ballot((sgn & 4u) != 0u);
+            m_irregular = __ballot((sgn & 8u) != 0u);
         }
         // ---- retire finished rays ----
         CENSUS(26, __ballot(cur == CUR_DONE) != 0ull ? 1 : 0); CENSUS(25, (__ballot(cur == CUR_DONE) != 0ull && __popcll(__ballot(cur == CUR_DONE)) <= 8) ? 1 : 0);

@@ -201,6 +201,11 @@ static uint64_t max_batch_paths() {
 // crown-proxy C4 1 758 -> 1 735, Cornell with patches 2 840 -> 2 634: the staged pipeline replaced them everywhere.)
 // (round 5: whatever the shapes — a scene with spheres / patches / instances runs the kernel's general-geometry instantiation, k_shade_lean_gen.hip)
 static bool scene_is_lean(const ShmScene* s) { return s->flat.diffuse_only && !s->flat.has_textures; }
+// (round 5) scenes whose every bounce shades with ONE fused kernel that knows bounce 0's constants (ShadeArgs::first_bounce): the lean class, and — without textures or coated
+// materials — every class the material-sorted fused kernel takes from bounce 0 on (k_shade_tail*.hip, k_shade_fused_gen.hip)
+static bool first_bounce_candidate(const ShmScene* s) {
+    return scene_is_lean(s) || (!s->flat.has_textures && !s->flat.has_class[CLASS_LAYERED] && s->tail_fused_bounce == 0 && (!s->flat.has_spheres || s->fused_gen));
+}
 static bool use_staged(const ShmScene* s, const ShmRenderParams* params) {
     if (params->integrator != SHM_INTEGRATOR_PATH) return false;
     // (the lean class through the staged pipeline, measured: shade + generate + film 130 -> 165 ms per headline frame)
@@ -219,7 +224,7 @@ static uint64_t workspace_cap(const ShmScene* s, bool need_staged) {
     // path state + three queues (+ auxiliary rays) (+ the staging arrays whenever the upcoming render is staged: every scene class but the
     // lean one, and the lean one too under options.force_diffuse — the budget must count them BEFORE the first staged allocation)
     // (ray 32, hit 32, shadow_ray 32, shadow_contrib 16, L 16, the PathRec 64, lambda 16, lambda_pdf 16, the CtxRec 64 = 288)
-    const uint64_t BYTES_PER_PATH = 288 + (scene_is_lean(s) ? 12 : 0) + 3 * 4 + (s->flat.has_textures ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
+    const uint64_t BYTES_PER_PATH = 288 + (first_bounce_candidate(s) ? 12 : 0) + 3 * 4 + (s->flat.has_textures ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
     uint64_t cap = max_batch_paths();
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -283,7 +288,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
     WS(ray, ShmRay); WS(hit, ShmHit); WS(shadow_ray, ShmRay); WS(shadow_contrib, float4); WS(L, float4); WS(rec, PathRec);
     WS(lambda, float4); WS(lambda_pdf, float4); WS(ctx, CtxRec);
     s->pa.rng0 = nullptr; s->pa.pixel0 = nullptr;
-    if (scene_is_lean(s)) { WS(rng0, uint2); WS(pixel0, uint32_t); }
+    if (first_bounce_candidate(s)) { WS(rng0, uint2); WS(pixel0, uint32_t); }
     s->pa.e_ray = s->pa.e_beta = s->pa.e_ctx0 = s->pa.e_ctx1 = s->pa.e_ctx2 = nullptr;
     s->pa.e_flags = nullptr;
     s->d_q_emit = nullptr;
@@ -668,7 +673,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         // the fused kernel's own scene class under the path integrator: bounce 0 runs on known constants (k_generate<., LEAN>, ShadeArgs::first_bounce; SHM_LEAN_FIRST_BOUNCE=0: A/B)
         const bool layered_staged = [] { const char* e = getenv("SHM_LAYERED_STAGED"); return !(e && atoi(e) == 0); }();  // (the LayeredBxDF class as dense per-wave stages; read per render: the tests flip it)
         const bool lean_first_on = [] { const char* e = getenv("SHM_LEAN_FIRST_BOUNCE"); return !(e && atoi(e) == 0); }();  // (read per render: the tests flip it)
-        const bool lean_first = lean_first_on && !staged && !random_walk && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && !s->pa.aux0;
+        const bool lean_first = lean_first_on && (!staged || (first_bounce_candidate(s) && params->force_diffuse == 0)) && !random_walk && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && !s->pa.aux0 && s->pa.rng0;
         // triangle scenes without textures under the path integrator: every kernel that reads the render's hit array is a TRI_ONLY one, and none reads a triangle hit's t —
         // the closest-hit launches write {primitive, b0, b1, b2}, 16 bytes per path instead of the 32-byte ShmHit (SHM_HIT16=0: A/B)
         s->pa.hit16 = (!s->flat.has_spheres && !s->flat.has_textures && params->integrator == SHM_INTEGRATOR_PATH && !random_walk &&

@@ -486,7 +486,8 @@ def test_ab_switches_change_no_result(env, monkeypatch, switch):
     hit array as 16-byte records in triangle scenes, the tail kernel's material-sorted chunks (the glass Cornell box at depth 14: the tail kernel from bounce 1 on)."""
     lib, oracle_py, render, scenes = env
     cases = [(scenes.ganesha_proxy(lib, 64, 64, n=32), 6, 5), (scenes.cornell_box(lib, 48, 48, coated=True, emitter_reflects=True), 6, 5),
-             (scenes.cornell_box(lib, 40, 40, textured=True), 4, 6)]
+             (scenes.cornell_box(lib, 40, 40, textured=True), 4, 6),
+             (scenes.cornell_box(lib, 48, 48, glass=True), 6, 8)]  # (several BxDF classes, no coated one: the material-sorted fused kernel from bounce 0, on known constants there)
     if switch == "SHM_TAIL_SORT":
         cases = [(scenes.cornell_box(lib, 48, 48, glass=True), 6, 14)]
     for sc, spp, depth in cases:
