@@ -1,0 +1,6 @@
+cd /root/repo
+PMC=1 tools/profile_side.sh r05 C4 S3i > gpurun_out/r05_prof_side3.log 2>&1
+tools/profile_side.sh r05 C2u C2t > gpurun_out/r05_prof_side4.log 2>&1
+python3 tools/kernel_resources.py > gpurun_out/r05_kernel_resources.txt 2>&1
+python3 tools/c4_bounces.py > gpurun_out/r05_c4_per_bounce.txt 2>&1
+tail -32 gpurun_out/r05_prof_side3.log; tail -3 gpurun_out/r05_c4_per_bounce.txt
