@@ -142,6 +142,12 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     chunk = chunk < 64u ? 64u : (chunk > (uint32_t)K3_CHUNK_MAX ? (uint32_t)K3_CHUNK_MAX : chunk);
     chunk = (chunk + 63u) & ~63u;
     uint32_t path = 0;
+#ifndef K5_QUEUE_PREFETCH
+#define K5_QUEUE_PREFETCH 0
+#endif
+    // K5_QUEUE_PREFETCH: the queue entries [q_pre_base, q_pre_base + 64) of the wave's chunk, one per lane, fetched when the PREVIOUS refill ended: a refill's rank-r lane takes
+    // its path index from lane r (one ds_bpermute) instead of a load of its own — one round trip (the ray record) instead of two dependent ones, during which the wave stalls
+    uint32_t q_pre = 0u, q_pre_base = 0xffffffffu;
     V3 ro = v3s(0.0f), inv_dir = v3s(0.0f);
     // dir_is_neg (aggregate.rs:76-81) twice: as three wave-wide lane masks in scalar registers for the slab tests' selects (sel_mask), and as three bits of `sgn` for the near /
     // far child choice, where the axis varies per lane; and the lanes whose ray is not "regular" (bit 3 of sgn): a non-finite origin, or a direction component that is 0,
@@ -314,11 +320,14 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                     const unsigned long long t_refill0 = __builtin_readcyclecounter();
 #endif
                     const uint32_t take = min((uint32_t)n_idle, w_end - w_next);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    const bool pre_ok = K5_QUEUE_PREFETCH && queue && q_pre_base == w_next;  // (wave-uniform)
+                    uint32_t pre_path = 0u;
+                    if (pre_ok) pre_path = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank << 2), (int)q_pre);  // (every lane takes part: the source lanes need not be idle)
                     if (cur == CUR_IDLE) {
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                         if (rank < take) {
                             const uint32_t qi = w_next + rank;
-                            path = queue ? queue[qi] : qi;
+                            path = queue ? (pre_ok ? pre_path : queue[qi]) : qi;
                             const float4* rp = reinterpret_cast<const float4*>(rays + path);
                             const float4 r0 = rp[0], r1 = rp[1];
 #ifndef K5_L_AT_REFILL
@@ -341,6 +350,11 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                     w_next += take;
                     w_rays += take;
                     if (!ANY) w_nodes += take;
+                    if (K5_QUEUE_PREFETCH && queue) {  // the next refill's entries (it takes at most 64): in flight behind this refill's ray records, consumed ~30 iterations on
+                        q_pre_base = w_next;
+                        const uint32_t qj = w_next + lane;
+                        q_pre = qj < w_end ? queue[qj] : 0u;
+                    }
                     CENSUS(11, 1); CENSUS(12, take);
                     m_negx = __ballot((sgn & 1u) != 0u);
                     m_negy = __ballot((sgn & 2u) != 0u);
