@@ -252,7 +252,8 @@ def side_results(lib, args, render, scenes, headline_scene, log):
             C.memmove(C.byref(headline_scene.desc.materials[0]), C.byref(saved), C.sizeof(saved))
         # the headline frame with the shapes a real PBRT-v4 scene mixes into its triangles (round 5): the window emitter as ONE bilinear patch (what a quad PLY
         # face becomes, shape/shape.rs:119-134), a sphere beside the object, the object as a TransformedPrimitive (primitive.rs:136-176)
-        for variant, name in (("patch_emitter", "S3_patch_emitter"), ("one_sphere", "S3_with_one_sphere"), ("instanced", "S3_instanced")):
+        # ... and the object under an ImageInfinitelight (light.rs:805-981): escaped rays look the map up, next-event estimation samples its distribution
+        for variant, name in (("patch_emitter", "S3_patch_emitter"), ("one_sphere", "S3_with_one_sphere"), ("instanced", "S3_instanced"), ("environment", "S3_environment_map")):
             sc = scenes.ganesha_proxy(lib, 1024, 1024, n=args.n, variant=variant)
             timed(f"{name}_1024x1024_spp256", sc.desc, 256, args.max_depth, sc.info["n_primitives"])
             del sc
@@ -296,7 +297,7 @@ def parse_args(argv=None):
     ap.add_argument("--pmc-child", action="store_true", help="internal: the frame a live counter pass profiles (no baseline, no side runs, prints nothing)")
     ap.add_argument("--coated", action="store_true", help="S3 with a CoatedDiffuse object (LayeredBxDF, SURVEY 8f-1) instead of the "
                     "headline diffuse one: a side measurement, not the BASELINE config")
-    ap.add_argument("--variant", default=None, choices=["patch_emitter", "one_sphere", "instanced"],
+    ap.add_argument("--variant", default=None, choices=["patch_emitter", "one_sphere", "instanced", "environment"],
                     help="development: S3 with a bilinear-patch emitter / one sphere / the object instanced (the side results' scenes) instead of the headline scene")
     ap.add_argument("--shard-of", type=int, default=0, help="development: render only the tiles rank 0 of N would own (no gather), "
                     "to estimate the per-rank time of an N-GPU run on one GPU")

@@ -51,6 +51,7 @@ struct FlatScene {
     uint32_t rgb2spec_res = 0;
     bool has_textures = false;  // a material slot binds an image texture (the path carries ray differentials) or an image infinite
                                 // light exists (both read the colour-space tables): selects k_shade<.., HAS_TEX>
+    bool has_material_textures = false, has_image_light = false;  // ... which of the two (round 5: an image light alone needs no differentials — render.hip, env_lean)
     std::vector<ShmInstance> instances;
     bool has_instances = false;
     std::vector<ShmFloatTexture> float_textures;
@@ -434,7 +435,7 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
             rec.compensated = build_pc2d(dd, n, out.dist_data);
             out.image_lights.push_back(rec);
         }
-        out.has_textures = true;
+        out.has_image_light = true;  // (has_textures: set where flatten_scene returns)
     }
 
     // FloatTexture node table (texture.rs:88-305): children precede parents, nesting <= 4 (float_texture_evaluate's bound)
@@ -631,6 +632,8 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
     // The reference's traversal stack is [usize; 64] (aggregate.rs:90); deeper trees would index out of bounds there.
     if (getenv("SHM_DEBUG")) fprintf(stderr, "[shm] flatten: %u nodes, %u prims, max leaf depth %u\n", d->n_nodes, d->n_primitives, out.max_leaf_depth);
     if (out.max_leaf_depth >= 64) { err = "BVH deeper than the reference's 64-entry traversal stack"; return SHM_ERR_UNSUPPORTED; }
+    out.has_material_textures = out.has_textures;
+    out.has_textures = out.has_material_textures || out.has_image_light;
     return SHM_OK;
 }
 

@@ -30,6 +30,8 @@ namespace {
 // vertex: f and pdf for NEE, sample_f) are compiled out of it.
 //   TRI_ONLY = true is the instantiation for scenes made of triangles only: no quadric / bilinear-patch interaction and light
 //   sampling code (with it the kernel needs 264 VGPRs, one wave per SIMD; without it 243, two waves).
+//   ENV_LIGHT = true (round 5; with HAS_TEX = false): the scene's only image is an ImageInfinitelight — its look-up, sample and pdf (light.rs:805-981) are compiled in, and
+//   nothing else of the textured class: no ray differentials, no auxiliary rays (an image light reads the map at a direction; differentials only feed texture filtering).
 //   HAS_TEX = true is the instantiation for scenes that bind image textures: the path carries ray differentials (texture.h),
 //   get_bsdf filters the MIP pyramids. One general instantiation <true, false, true>.
 //   DIFFUSE_ONLY = true is the instantiation for scenes whose materials are all DiffuseMaterial (the headline scene class): the
@@ -41,7 +43,7 @@ namespace {
 //   — the queue is in image order, and a wave of the unsorted kernel ran at 11.5 of 64 lanes per instruction on C4's late bounces (profiles/r04_staged_C4.txt).
 //   Paths are independent and every later queue is order-agnostic: films and counters do not change.
 constexpr int SHADE_SORT_BINS = 64;
-template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ONLY = false, bool EMIT_INLINE = true, bool SORT_CHUNK = false>
+template <bool HAS_LAYERED, bool TRI_ONLY, bool HAS_TEX = false, bool DIFFUSE_ONLY = false, bool EMIT_INLINE = true, bool SORT_CHUNK = false, bool ENV_LIGHT = false>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneView sv_global, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_next,
                                                      uint32_t* __restrict__ q_shadow, QueueState* qs, int cur, ShmRenderParams params,
                                                      DeviceCounters* counters, int shadow_parity, const uint32_t* __restrict__ n_in, uint32_t* __restrict__ q_emit,
@@ -158,11 +160,11 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                     const ShmLight& light = sv.lights[sv.infinite_lights[k]];
                     // (flatten_scene lists only the infinite kinds here: light_pdf_li's area-light half — the inverted triangle sampling — folds away)
                     __builtin_assume(light.kind != SHM_LIGHT_DIFFUSE_AREA);
-                    Spec le = infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda);
+                    Spec le = infinite_light_le<HAS_TEX || ENV_LIGHT>(sv, light, ray_d, lambda);
                     if (depth == 0 || specular_bounce) {
                         add_l(load_beta() * le);
                     } else {
-                        Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
+                        Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX || ENV_LIGHT>(sv, light, load_prev_ctx(), ray_d);
                         Float w_b = power_heuristic(1, load_pb_eta().x, 1, p_l);
                         add_l(load_beta() * w_b * le);
                     }
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                         if (depth == 0 || specular_bounce) {
                             add_l(load_beta() * le);
                         } else {
-                            Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
+                            Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX || ENV_LIGHT>(sv, light, load_prev_ctx(), ray_d);
                             Float w_l = power_heuristic(1, load_pb_eta().x, 1, p_l);
                             add_l(load_beta() * w_l * le);
                         }
@@ -256,7 +258,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
                         if (li >= 0) {
                             const ShmLight& light = sv.lights[li];
                             LightLiSample ls;
-                            if (light_sample_li<TRI_ONLY, HAS_TEX>(sv, light, ctx, nee_u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
+                            if (light_sample_li<TRI_ONLY, HAS_TEX || ENV_LIGHT>(sv, light, ctx, nee_u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
                                 V3 wo = si.wo;
                                 V3 wi = ls.wi;
                                 Spec f = bsdf_f(bsdf, wo, wi) * abs_dot(wi, si.shading.n);

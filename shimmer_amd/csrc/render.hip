@@ -200,7 +200,13 @@ static uint64_t max_batch_paths() {
 // (Round-2 A/B against the fused general kernels of round 1, same box: coated S3 1 208 -> 1 724 Mray/s, textured Cornell 768 -> 906,
 // crown-proxy C4 1 758 -> 1 735, Cornell with patches 2 840 -> 2 634: the staged pipeline replaced them everywhere.)
 // (round 5: whatever the shapes — a scene with spheres / patches / instances runs the kernel's general-geometry instantiation, k_shade_lean_gen.hip)
-static bool scene_is_lean(const ShmScene* s) { return s->flat.diffuse_only && !s->flat.has_textures; }
+// (round 5: ... and an ImageInfinitelight alone does not make a scene "textured": the light's look-up, sample and pdf are compiled into the lean kernels' ENV_LIGHT
+// instantiations (k_shade_lean_env.hip); ray differentials and auxiliary rays only feed texture filtering, and nothing filters a texture there)
+static bool env_lean_scene(const ShmScene* s) { return s->env_lean && s->flat.diffuse_only && s->flat.has_image_light && !s->flat.has_material_textures; }
+static bool scene_is_lean(const ShmScene* s) { return s->flat.diffuse_only && (!s->flat.has_textures || env_lean_scene(s)); }
+// the textured class's machinery (auxiliary rays, differentials, the HAS_TEX kernels) in a render of this scene: a STAGED render of an env-lean scene (options.force_diffuse:
+// the staged kernels have no ENV_LIGHT instantiation) is a render of the textured class
+static bool tex_on(const ShmScene* s, bool staged_render) { return s->flat.has_textures && !(env_lean_scene(s) && !staged_render); }
 // (round 5) scenes whose every bounce shades with ONE fused kernel that knows bounce 0's constants (ShadeArgs::first_bounce): the lean class, and — without textures or coated
 // materials — every class the material-sorted fused kernel takes from bounce 0 on (k_shade_tail*.hip, k_shade_fused_gen.hip)
 static bool first_bounce_candidate(const ShmScene* s) {
@@ -224,7 +230,7 @@ static uint64_t workspace_cap(const ShmScene* s, bool need_staged) {
     // path state + three queues (+ auxiliary rays) (+ the staging arrays whenever the upcoming render is staged: every scene class but the
     // lean one, and the lean one too under options.force_diffuse — the budget must count them BEFORE the first staged allocation)
     // (ray 32, hit 32, shadow_ray 32, shadow_contrib 16, L 16, the PathRec 64, lambda 16, lambda_pdf 16, the CtxRec 64 = 288)
-    const uint64_t BYTES_PER_PATH = 288 + (first_bounce_candidate(s) ? 12 : 0) + 3 * 4 + (s->flat.has_textures ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
+    const uint64_t BYTES_PER_PATH = 288 + (first_bounce_candidate(s) ? 12 : 0) + 3 * 4 + (tex_on(s, need_staged || s->ws_staged) ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
     uint64_t cap = max_batch_paths();
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -297,7 +303,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
         if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_emit)) != SHM_OK) return rc;
     }
     s->pa.aux0 = s->pa.aux1 = s->pa.aux2 = nullptr;
-    if (s->flat.has_textures) { WS(aux0, float4); WS(aux1, float4); WS(aux2, float4); }
+    if (tex_on(s, need_staged)) { WS(aux0, float4); WS(aux1, float4); WS(aux2, float4); }
     s->pa.bx = nullptr;
     s->pa.has_layered = s->flat.has_class[CLASS_LAYERED] ? 1u : 0u;
     s->pa.dd0 = s->pa.dd1 = s->pa.dd2 = nullptr;
@@ -536,6 +542,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
     if (const char* e = getenv("SHM_OTHER_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min = s->other_min_any = v2; }
     if (const char* e = getenv("SHM_TAIL_FUSED_BOUNCE")) { const int v2 = atoi(e); s->tail_fused_bounce = v2 >= 0 ? v2 : 1 << 30; }
+    if (const char* e = getenv("SHM_ENV_LEAN")) s->env_lean = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_FUSED_GEN")) s->fused_gen = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_FUSED_TEX")) s->fused_tex = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_TAIL_SORT")) s->tail_sort = atoi(e) != 0 ? 1 : 0;
@@ -676,7 +683,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         const bool lean_first = lean_first_on && (!staged || (first_bounce_candidate(s) && params->force_diffuse == 0)) && !random_walk && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && !s->pa.aux0 && s->pa.rng0;
         // triangle scenes without textures under the path integrator: every kernel that reads the render's hit array is a TRI_ONLY one, and none reads a triangle hit's t —
         // the closest-hit launches write {primitive, b0, b1, b2}, 16 bytes per path instead of the 32-byte ShmHit (SHM_HIT16=0: A/B)
-        s->pa.hit16 = (!s->flat.has_spheres && !s->flat.has_textures && params->integrator == SHM_INTEGRATOR_PATH && !random_walk &&
+        s->pa.hit16 = (!s->flat.has_spheres && !tex_on(s, staged) && params->integrator == SHM_INTEGRATOR_PATH && !random_walk &&
                        [] { const char* e = getenv("SHM_HIT16"); return !(e && atoi(e) == 0); }()) ? 1u : 0u;
         if (s->pa.aux0)
             hipLaunchKernelGGL(k_generate<true>, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
@@ -738,11 +745,14 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 hipEventRecord(s0, s->stream);
                 const ShadeArgs sa{s->stream, cur, *params, sh, shade_blocks, first_lean ? 1 : 0, hit_kept ? 1 : 0};
                 const bool tri_only = !s->flat.has_spheres;
+                int n_classes_present = 0;  // (one BxDF class with textures: nothing to sort, and the textured fused kernel's 128 spilled VGPRs cost more than the staged pair's
+                                            //  parameter block — S3 under an environment map before it had its own kernel: shade 101 ms staged, 107 fused)
+                for (int c = 0; c < N_BXDF_CLASSES; ++c) n_classes_present += s->flat.has_class[c] ? 1 : 0;
                 // a triangle scene with several BxDF classes but without textures or coated materials: ONE fused all-materials launch per bounce instead of the staged
                 // four or five, from bounce `tail_fused_bounce` on. Rounds 3-4, chunks unsorted: only the late bounces paid (C4 frame 522-528 ms staged throughout,
                 // 510-512 from bounce 6, 511-513 from 8). Round 5, chunks counting-sorted by material (k_shade_tail_sorted.hip): the earlier the better — C4 403.2 ms
                 // from bounce 8, 399 from 4, 388 from 2, 378 from 1, 365 from 0: the default (SHM_TAIL_FUSED_BOUNCE, negative = never; read at scene creation)
-                if (staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || s->fused_tex) && (tri_only || s->fused_gen)) {
+                if (staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || (s->fused_tex && n_classes_present > 1)) && (tri_only || s->fused_gen)) {
                     rc = tri_only ? (s->flat.has_textures ? wf_launch_shade_fused_tex(s, sa) : wf_launch_shade_tail(s, sa))
                                   : (s->flat.has_textures ? wf_launch_shade_fused_gen_tex(s, sa) : wf_launch_shade_fused_gen(s, sa));
                 } else if (staged) {
@@ -796,6 +806,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 }
                 else if (random_walk) rc = wf_launch_shade_randomwalk(s, sa, cap_eff);
                 else if (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH) rc = wf_launch_shade_simple(s, sa);
+                else if (env_lean_scene(s)) rc = tri_only ? wf_launch_shade_lean_env(s, sa) : wf_launch_shade_lean_gen_env(s, sa);
                 else rc = tri_only ? wf_launch_shade_lean(s, sa) : wf_launch_shade_lean_gen(s, sa);
                 if (rc != SHM_OK) return rc;
                 hipEventRecord(s1, s->stream);

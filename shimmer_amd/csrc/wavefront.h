@@ -312,7 +312,10 @@ struct ShmScene {
     size_t rw_floats4 = 0;
     uint32_t* d_spill3_any = nullptr;  // the any-hit kernel may run concurrently with the closest-hit one (second stream)
     float4* d_gen_save[2] = {nullptr, nullptr};  // k_trace5<., GEN> (scenes with spheres / patches / instances): per resident lane two 48-byte areas for the ray state (closest, any)
-    int tail_fused_bounce = 0, tail_sort = 1, fused_tex = 1, fused_gen = 1;   // staged triangle scenes without textures or coated materials: ONE fused all-materials launch per bounce from this bounce on (SHM_TAIL_FUSED_BOUNCE, negative = never), its chunks sorted by material (SHM_TAIL_SORT)
+    // scenes without a coated material: ONE fused all-materials launch per bounce from this bounce on (SHM_TAIL_FUSED_BOUNCE, negative = never), its chunks sorted by
+    // material (SHM_TAIL_SORT); its instantiations with textures / for general geometry (SHM_FUSED_TEX, SHM_FUSED_GEN = 0: the staged pair there)
+    int tail_fused_bounce = 0, tail_sort = 1, fused_tex = 1, fused_gen = 1;
+    int env_lean = 1;              // an all-diffuse scene whose only image is an ImageInfinitelight runs the lean class's kernels (SHM_ENV_LEAN=0: the textured class's, as until round 5)
     int other_min = 16, other_min_any = 16;     // ... and the parked non-triangle tests a wave collects before it runs them (SHM_OTHER_MIN, SHM_OTHER_MIN_ANY)
     hipStream_t stream2 = nullptr;
     bool concurrent_scatter = true;  // SHM_CONCURRENT_SCATTER=0: everything on the render stream (A/B)
@@ -370,6 +373,8 @@ WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a);  // the f
 WF_INTERNAL int wf_launch_shade_lean_diverted(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_lean_gen(ShmScene* s, const ShadeArgs& a);           // the same kernel with the quadric / patch / instance code: scenes that hold such shapes (k_shade_lean_gen.hip)
 WF_INTERNAL int wf_launch_shade_lean_gen_diverted(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_shade_lean_env(ShmScene* s, const ShadeArgs& a);      // the lean fused kernel with an ImageInfinitelight compiled in (k_shade_lean_env.hip)
+WF_INTERNAL int wf_launch_shade_lean_gen_env(ShmScene* s, const ShadeArgs& a);  // ... for general geometry (k_shade_lean_gen_env.hip)
 WF_INTERNAL int wf_launch_shade_fused_gen(ShmScene* s, const ShadeArgs& a);    // ... for scenes with spheres / patches / instances (k_shade_fused_gen.hip)
 WF_INTERNAL int wf_launch_shade_fused_gen_tex(ShmScene* s, const ShadeArgs& a);  // ... and those with textures (k_shade_fused_gen_tex.hip)
 WF_INTERNAL int wf_launch_shade_fused_tex(ShmScene* s, const ShadeArgs& a);    // ... and for triangle scenes with textures, no coated material (k_shade_fused_tex.hip)

@@ -294,8 +294,10 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
     variant (round 5: the shapes a real PBRT-v4 scene mixes into its triangles; same camera, room and object):
       "patch_emitter"  the window emitter is ONE bilinear patch — what a quad face of a PLY file becomes (shape/shape.rs:119-134, shape/mesh.rs:233-256)
       "one_sphere"     a diffuse sphere stands on the floor beside the object (shape/sphere.rs)
-      "instanced"      the object is an object definition placed once through a TransformedPrimitive (primitive.rs:136-176)"""
-    assert variant in (None, "patch_emitter", "one_sphere", "instanced")
+      "instanced"      the object is an object definition placed once through a TransformedPrimitive (primitive.rs:136-176)
+      "environment"    no room and no window: the object on its ground plane under an ImageInfinitelight (light.rs:805-981) — escaped rays look the map up, next-event
+                       estimation samples its (compensated) piecewise-constant distribution"""
+    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment")
     b = SceneBuilder()
     b.set_film(width, height)
     rfw = b.set_camera_look_at(lib, (0.0, 0.6, 4.2), (0.0, 0.0, 0.0), (0, 1, 0), 38.0)
@@ -314,7 +316,12 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
         rfo = np.eye(4, dtype=np.float32)
         rfo[:3, 3] = _to_render(np.array([[0.7, -0.8, 1.7]], np.float32), rfw)[0]  # (in front of the object, to the right: in the camera's view)
         b.add_sphere(0.45, wall, render_from_object=rfo)
-    if with_room:
+    if variant == "environment":
+        p, vi = _quad((-4, -1.25, -4), (-4, -1.25, 6), (4, -1.25, 6), (4, -1.25, -4))
+        b.add_mesh(_to_render(p, rfw), vi, wall)
+        rot = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float32)  # +z of the map is the world's +y (as in three_spheres)
+        b.light_image_infinite(environment_image(64), scale=1.0, render_from_light=rot)
+    elif with_room:
         # ground (2) + open room (10: back, left, right, ceiling, front-top strip) + window emitter (2)
         p, vi = _quad((-4, -1.25, -4), (-4, -1.25, 6), (4, -1.25, 6), (4, -1.25, -4))
         b.add_mesh(_to_render(p, rfw), vi, wall)

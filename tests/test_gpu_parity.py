@@ -64,6 +64,7 @@ SCENES = {
     "S3_small_patch_emitter": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="patch_emitter"), 6, 5),
     "S3_small_one_sphere": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="one_sphere"), 6, 5),
     "S3_small_instanced": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="instanced"), 6, 5),
+    "S3_small_environment": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="environment"), 6, 5),
 }
 
 
@@ -389,10 +390,11 @@ def test_headline_frame_at_full_size(env):
     gpu.close()
 
 
-@pytest.mark.parametrize("variant,crop", [("patch_emitter", (504, 440, 520, 456)), ("one_sphere", (152, 920, 168, 936)), ("instanced", (504, 440, 520, 456))])
+@pytest.mark.parametrize("variant,crop", [("patch_emitter", (504, 440, 520, 456)), ("one_sphere", (152, 920, 168, 936)), ("instanced", (504, 440, 520, 456)),
+                                          ("environment", (504, 440, 520, 456))])
 def test_mixed_shape_frames_at_full_size(env, variant, crop):
     """The headline frame with the shapes a real PBRT-v4 scene mixes into its triangles (bench.py's round-5 side results: the emitter as ONE bilinear patch, a sphere
-    beside the object, the object as a TransformedPrimitive) at its own size — 4.3 M primitives, 1024 x 1024, 256 spp, one 268 M-path batch through k_trace5<., GEN> and the
+    beside the object, the object as a TransformedPrimitive; and the object under an ImageInfinitelight: the sorted fused kernel's textured instantiation) at its own size — 4.3 M primitives, 1024 x 1024, 256 spp, one 268 M-path batch through k_trace5<., GEN> and the
     general fused kernel: two renders identical in film and counters; every pixel 256 samples, finite; a 16 x 16 block at all 256 samples — on the object, on the sphere
     where there is one — equal to the oracle's film bit for bit, with the block's node / primitive visit counters."""
     lib, oracle_py, render, scenes = env
@@ -765,6 +767,46 @@ def test_force_diffuse_parity(env, integrator):
         assert np.array_equal(fg, fo) and np.isfinite(render.film_to_rgb(fg)).all()
         for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
             assert sg[k] == so[k], k
+        gpu.close(); orc.close()
+
+
+def test_environment_map_scenes_run_the_lean_class(env, monkeypatch):
+    """An all-diffuse scene whose only image is an ImageInfinitelight (light.rs:805-981) shades with the lean fused kernel's ENV_LIGHT instantiations (round 5:
+    k_shade_lean_env.hip, k_shade_lean_gen_env.hip — no ray differentials, no auxiliary rays, bounce 0 on known constants) instead of the textured class's kernels:
+    triangles (S3 under a map) and spheres, every integrator, against the oracle; with SHM_ENV_LEAN=0 (the textured class, as until round 5) the same bits; and
+    one Renderer through path -> force_diffuse (a STAGED render: the textured class's kernels and their workspace arrays) -> path again."""
+    lib, oracle_py, render, scenes = env
+    cases = [scenes.ganesha_proxy(lib, 48, 48, n=24, variant="environment"),
+             scenes.three_spheres(lib, 48, 36, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(32))]
+    for sc in cases:
+        orc = oracle_py.Oracle(sc.desc)
+        films = {}
+        for integrator in ("path", "simplepath", "randomwalk"):
+            p = render.make_params(seed=21, spp=6, max_depth=5, integrator=integrator)
+            fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
+            gpu = render.Renderer(lib, sc.desc, 0)
+            fg, sg = gpu.render(p)
+            gpu.close()
+            assert np.array_equal(fg, fo), (sc.name, integrator)
+            for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+                assert sg[k] == so[k], (sc.name, integrator, k)
+            films[integrator] = fo
+        assert render.film_to_rgb(films["path"]).max() > 0
+        # the textured class's kernels on the same scene
+        monkeypatch.setenv("SHM_ENV_LEAN", "0")
+        gpu = render.Renderer(lib, sc.desc, 0)
+        p = render.make_params(seed=21, spp=6, max_depth=5)
+        f_tex, _ = gpu.render(p)
+        gpu.close()
+        monkeypatch.delenv("SHM_ENV_LEAN")
+        assert np.array_equal(f_tex, films["path"]), sc.name
+        # one scene object through the class change and back
+        gpu = render.Renderer(lib, sc.desc, 0)
+        pf = render.make_params(seed=21, spp=6, max_depth=5, force_diffuse=True)
+        fo_f, so_f = orc.render(pf, n_threads=os.cpu_count() or 1)
+        for params, want in ((p, films["path"]), (pf, fo_f), (p, films["path"])):
+            fg, _ = gpu.render(params)
+            assert np.array_equal(fg, want), sc.name
         gpu.close(); orc.close()
 
 

@@ -17,6 +17,7 @@ CONFIGS = [
     ("S3p ganesha, patch emitter 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="patch_emitter"), 256, 5),
     ("S3s ganesha + one sphere 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="one_sphere"), 256, 5),
     ("S3i ganesha instanced 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="instanced"), 256, 5),
+    ("S3e ganesha under an environment map 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="environment"), 256, 5),
     ("C2t cornell textured 512x512x64", lambda: scenes.cornell_box(lib, 512, 512, textured=True), 64, 6),
     ("C2u cornell textured, no coated 512x512x64", lambda: scenes.cornell_box(lib, 512, 512, textured=True, textured_coated_ceiling=False), 64, 6),
     ("C2f-point cornell textured, every filter point", lambda: scenes.cornell_box(lib, 512, 512, textured=True, texture_filter="point"), 64, 6),
