@@ -266,6 +266,9 @@ def side_results(lib, args, render, scenes, headline_scene, log):
             c4.update(json.loads(r.stdout.strip().splitlines()[-1]))
         except Exception as e:  # reporting only
             c4["per_bounce_error"] = f"{type(e).__name__}: {e}"
+        # glass and metal under an ImageInfinitelight beside the emitter (round 5: the sorted fused kernel's ENV_LIGHT instantiation instead of the textured class)
+        sc = scenes.crown_proxy(lib, 1000, 1400, environment=scenes.environment_image(64))
+        timed("C4_crown_proxy_environment_map_1000x1400_spp256_depth32", sc.desc, 256, 32, sc.info["n_primitives"])
         sc = scenes.cornell_box(lib, 512, 512)
         timed("C2_cornell_512x512_spp64", sc.desc, 64, 5, sc.info["n_primitives"])
         sc = scenes.cornell_box(lib, 512, 512, textured=True)

@@ -202,15 +202,20 @@ static uint64_t max_batch_paths() {
 // (round 5: whatever the shapes — a scene with spheres / patches / instances runs the kernel's general-geometry instantiation, k_shade_lean_gen.hip)
 // (round 5: ... and an ImageInfinitelight alone does not make a scene "textured": the light's look-up, sample and pdf are compiled into the lean kernels' ENV_LIGHT
 // instantiations (k_shade_lean_env.hip); ray differentials and auxiliary rays only feed texture filtering, and nothing filters a texture there)
-static bool env_lean_scene(const ShmScene* s) { return s->env_lean && s->flat.diffuse_only && s->flat.has_image_light && !s->flat.has_material_textures; }
+static bool env_only_images(const ShmScene* s) { return s->env_lean && s->flat.has_image_light && !s->flat.has_material_textures; }
+// (the shapes and classes whose every bounce the material-sorted fused all-materials kernel takes: k_shade_tail*.hip, k_shade_fused_*.hip)
+static bool fused_all_from_0(const ShmScene* s) { return !s->flat.has_class[CLASS_LAYERED] && s->tail_fused_bounce == 0 && (!s->flat.has_spheres || s->fused_gen); }
+static bool env_lean_scene(const ShmScene* s) { return env_only_images(s) && s->flat.diffuse_only; }
+// ... and the same for scenes with other BxDF classes (glass, metal under a map): the sorted fused kernel's ENV_LIGHT instantiations. `env_plain`: no path-integrator render of
+// this scene reaches a HAS_TEX kernel unless options.force_diffuse sends it through the staged pair — and even there the differentials are dead values (no material binds
+// a texture), so the auxiliary-ray arrays are never allocated for it
+static bool env_plain_scene(const ShmScene* s) { return env_only_images(s) && (s->flat.diffuse_only || fused_all_from_0(s)); }
 static bool scene_is_lean(const ShmScene* s) { return s->flat.diffuse_only && (!s->flat.has_textures || env_lean_scene(s)); }
-// the textured class's machinery (auxiliary rays, differentials, the HAS_TEX kernels) in a render of this scene: a STAGED render of an env-lean scene (options.force_diffuse:
-// the staged kernels have no ENV_LIGHT instantiation) is a render of the textured class
-static bool tex_on(const ShmScene* s, bool staged_render) { return s->flat.has_textures && !(env_lean_scene(s) && !staged_render); }
+static bool tex_ws(const ShmScene* s) { return s->flat.has_textures && !env_plain_scene(s); }  // the auxiliary-ray arrays (and k_generate<true>)
 // (round 5) scenes whose every bounce shades with ONE fused kernel that knows bounce 0's constants (ShadeArgs::first_bounce): the lean class, and — without textures or coated
 // materials — every class the material-sorted fused kernel takes from bounce 0 on (k_shade_tail*.hip, k_shade_fused_gen.hip)
 static bool first_bounce_candidate(const ShmScene* s) {
-    return scene_is_lean(s) || (!s->flat.has_textures && !s->flat.has_class[CLASS_LAYERED] && s->tail_fused_bounce == 0 && (!s->flat.has_spheres || s->fused_gen));
+    return scene_is_lean(s) || ((!s->flat.has_textures || env_plain_scene(s)) && fused_all_from_0(s));
 }
 static bool use_staged(const ShmScene* s, const ShmRenderParams* params) {
     if (params->integrator != SHM_INTEGRATOR_PATH) return false;
@@ -230,7 +235,7 @@ static uint64_t workspace_cap(const ShmScene* s, bool need_staged) {
     // path state + three queues (+ auxiliary rays) (+ the staging arrays whenever the upcoming render is staged: every scene class but the
     // lean one, and the lean one too under options.force_diffuse — the budget must count them BEFORE the first staged allocation)
     // (ray 32, hit 32, shadow_ray 32, shadow_contrib 16, L 16, the PathRec 64, lambda 16, lambda_pdf 16, the CtxRec 64 = 288)
-    const uint64_t BYTES_PER_PATH = 288 + (first_bounce_candidate(s) ? 12 : 0) + 3 * 4 + (tex_on(s, need_staged || s->ws_staged) ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
+    const uint64_t BYTES_PER_PATH = 288 + (first_bounce_candidate(s) ? 12 : 0) + 3 * 4 + (tex_ws(s) ? 48 : 0) + (uses_fused_kernel(s) ? 88 : 0) + ((need_staged || s->ws_staged || !scene_is_lean(s)) ? staging_bytes_per_path(s) : 0);
     uint64_t cap = max_batch_paths();
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -303,7 +308,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
         if ((rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_emit)) != SHM_OK) return rc;
     }
     s->pa.aux0 = s->pa.aux1 = s->pa.aux2 = nullptr;
-    if (tex_on(s, need_staged)) { WS(aux0, float4); WS(aux1, float4); WS(aux2, float4); }
+    if (tex_ws(s)) { WS(aux0, float4); WS(aux1, float4); WS(aux2, float4); }
     s->pa.bx = nullptr;
     s->pa.has_layered = s->flat.has_class[CLASS_LAYERED] ? 1u : 0u;
     s->pa.dd0 = s->pa.dd1 = s->pa.dd2 = nullptr;
@@ -683,7 +688,10 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         const bool lean_first = lean_first_on && (!staged || (first_bounce_candidate(s) && params->force_diffuse == 0)) && !random_walk && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && !s->pa.aux0 && s->pa.rng0;
         // triangle scenes without textures under the path integrator: every kernel that reads the render's hit array is a TRI_ONLY one, and none reads a triangle hit's t —
         // the closest-hit launches write {primitive, b0, b1, b2}, 16 bytes per path instead of the 32-byte ShmHit (SHM_HIT16=0: A/B)
-        s->pa.hit16 = (!s->flat.has_spheres && !tex_on(s, staged) && params->integrator == SHM_INTEGRATOR_PATH && !random_walk &&
+        // (the kernels of THIS render that read hit records are HAS_TEX ones — compiled for general geometry only, 32-byte records — in a scene with textures, unless its only image
+        //  is an environment map and nothing sends the render through the staged pair)
+        const bool tex_kernels = s->flat.has_textures && !(env_plain_scene(s) && params->force_diffuse == 0);
+        s->pa.hit16 = (!s->flat.has_spheres && !tex_kernels && params->integrator == SHM_INTEGRATOR_PATH && !random_walk &&
                        [] { const char* e = getenv("SHM_HIT16"); return !(e && atoi(e) == 0); }()) ? 1u : 0u;
         if (s->pa.aux0)
             hipLaunchKernelGGL(k_generate<true>, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
@@ -752,9 +760,10 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 // four or five, from bounce `tail_fused_bounce` on. Rounds 3-4, chunks unsorted: only the late bounces paid (C4 frame 522-528 ms staged throughout,
                 // 510-512 from bounce 6, 511-513 from 8). Round 5, chunks counting-sorted by material (k_shade_tail_sorted.hip): the earlier the better — C4 403.2 ms
                 // from bounce 8, 399 from 4, 388 from 2, 378 from 1, 365 from 0: the default (SHM_TAIL_FUSED_BOUNCE, negative = never; read at scene creation)
-                if (staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || (s->fused_tex && n_classes_present > 1)) && (tri_only || s->fused_gen)) {
-                    rc = tri_only ? (s->flat.has_textures ? wf_launch_shade_fused_tex(s, sa) : wf_launch_shade_tail(s, sa))
-                                  : (s->flat.has_textures ? wf_launch_shade_fused_gen_tex(s, sa) : wf_launch_shade_fused_gen(s, sa));
+                if (staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || env_plain_scene(s) || (s->fused_tex && n_classes_present > 1)) && (tri_only || s->fused_gen)) {
+                    if (env_plain_scene(s)) rc = tri_only ? wf_launch_shade_tail_sorted_env(s, sa) : wf_launch_shade_fused_gen_env(s, sa);
+                    else rc = tri_only ? (s->flat.has_textures ? wf_launch_shade_fused_tex(s, sa) : wf_launch_shade_tail(s, sa))
+                                       : (s->flat.has_textures ? wf_launch_shade_fused_gen_tex(s, sa) : wf_launch_shade_fused_gen(s, sa));
                 } else if (staged) {
                     // hit half (interaction, emission, get_bsdf -> parameter block, class queues), then one scattering kernel per BxDF
                     // class the scene holds, each over its own material-sorted queue

@@ -375,6 +375,8 @@ WF_INTERNAL int wf_launch_shade_lean_gen(ShmScene* s, const ShadeArgs& a);      
 WF_INTERNAL int wf_launch_shade_lean_gen_diverted(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_lean_env(ShmScene* s, const ShadeArgs& a);      // the lean fused kernel with an ImageInfinitelight compiled in (k_shade_lean_env.hip)
 WF_INTERNAL int wf_launch_shade_lean_gen_env(ShmScene* s, const ShadeArgs& a);  // ... for general geometry (k_shade_lean_gen_env.hip)
+WF_INTERNAL int wf_launch_shade_tail_sorted_env(ShmScene* s, const ShadeArgs& a);  // the sorted fused all-materials kernel with an ImageInfinitelight compiled in (k_shade_tail_sorted_env.hip)
+WF_INTERNAL int wf_launch_shade_fused_gen_env(ShmScene* s, const ShadeArgs& a);    // ... for general geometry (k_shade_fused_gen_env.hip)
 WF_INTERNAL int wf_launch_shade_fused_gen(ShmScene* s, const ShadeArgs& a);    // ... for scenes with spheres / patches / instances (k_shade_fused_gen.hip)
 WF_INTERNAL int wf_launch_shade_fused_gen_tex(ShmScene* s, const ShadeArgs& a);  // ... and those with textures (k_shade_fused_gen_tex.hip)
 WF_INTERNAL int wf_launch_shade_fused_tex(ShmScene* s, const ShadeArgs& a);    // ... and for triangle scenes with textures, no coated material (k_shade_fused_tex.hip)

@@ -370,7 +370,7 @@ def icosphere(level):
     return v.astype(np.float32), f.astype(np.uint32)
 
 
-def crown_proxy(lib, width=1000, height=1400, level=4, n_glass=64, n_gold=16, seed=4242):
+def crown_proxy(lib, width=1000, height=1400, level=4, n_glass=64, n_gold=16, seed=4242, environment=None):
     """S4 (config C4): dispersive smooth dielectric icospheres (BK7 eta table -> terminate_secondary), rough gold
     conductors, diffuse floor, one quad emitter; render with max_depth=32."""
     b = SceneBuilder()
@@ -396,7 +396,10 @@ def crown_proxy(lib, width=1000, height=1400, level=4, n_glass=64, n_gold=16, se
     b.add_mesh(_to_render(p, rfw), vi, floor)
     p, vi = _quad((-2, 5, -2), (2, 5, -2), (2, 5, 2), (-2, 5, 2))
     b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=30.0)
-    return _finish(b, lib, name="S4 crown-proxy")
+    if environment is not None:  # glass and metal under an ImageInfinitelight as well (round 5: the sorted fused kernel's ENV_LIGHT instantiation)
+        rot = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float32)
+        b.light_image_infinite(environment, scale=1.0, render_from_light=rot)
+    return _finish(b, lib, name="S4 crown-proxy" + ("" if environment is None else " (environment map)"))
 
 
 def environment_image(n=32, sun=(0.3, 0.5, 0.81), sun_radiance=40.0):
@@ -443,7 +446,7 @@ def three_spheres(lib, width=32, height=32, offsets=(-3.5, 0.0, 5.0), camera=(0.
     return _finish(b, lib, name="three spheres" + ("" if environment is None else " (environment map)"))
 
 
-def instanced_scene(lib, width=64, height=48, n_instances=5, only_object=False, baked=False):
+def instanced_scene(lib, width=64, height=48, n_instances=5, only_object=False, baked=False, environment=None):
     """Object instancing: one object definition (an icosphere with per-vertex normals, a partial sphere and a curved
     bilinear patch, three materials) placed several times with rotated, non-uniformly scaled transforms over a floor lit by a quad
     light and a point light. `only_object`: just the object's shapes at top level, untransformed, no floor. `baked`: the same
@@ -500,7 +503,10 @@ def instanced_scene(lib, width=64, height=48, n_instances=5, only_object=False, 
     p, vi = _quad((-1.5, 5.0, -1.5), (1.5, 5.0, -1.5), (1.5, 5.0, 1.5), (-1.5, 5.0, 1.5))
     b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=12.0)
     b.light_point((rfw @ np.array([3.0, 4.0, 4.0, 1.0], np.float32))[:3], blackbody_dense(4000.0), scale=30.0)
-    sc = _finish(b, lib, name="instanced objects" + (" (baked)" if baked else ""))
+    if environment is not None:
+        rot = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float32)
+        b.light_image_infinite(environment, scale=0.5, render_from_light=rot)
+    sc = _finish(b, lib, name="instanced objects" + (" (baked)" if baked else "") + ("" if environment is None else " (environment map)"))
     sc.placements = placements
     return sc
 

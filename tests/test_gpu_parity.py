@@ -771,13 +771,17 @@ def test_force_diffuse_parity(env, integrator):
 
 
 def test_environment_map_scenes_run_the_lean_class(env, monkeypatch):
-    """An all-diffuse scene whose only image is an ImageInfinitelight (light.rs:805-981) shades with the lean fused kernel's ENV_LIGHT instantiations (round 5:
-    k_shade_lean_env.hip, k_shade_lean_gen_env.hip — no ray differentials, no auxiliary rays, bounce 0 on known constants) instead of the textured class's kernels:
-    triangles (S3 under a map) and spheres, every integrator, against the oracle; with SHM_ENV_LEAN=0 (the textured class, as until round 5) the same bits; and
+    """A scene without coated materials whose only image is an ImageInfinitelight (light.rs:805-981) shades with the ENV_LIGHT instantiations of the lean fused kernel
+    (all-diffuse: k_shade_lean_env.hip, k_shade_lean_gen_env.hip) or of the material-sorted fused kernel (glass, metal: k_shade_tail_sorted_env.hip,
+    k_shade_fused_gen_env.hip) — no ray differentials, no auxiliary rays, bounce 0 on known constants — instead of the textured class's kernels:
+    triangles and spheres / instances, every integrator, against the oracle; with SHM_ENV_LEAN=0 (the textured class, as until round 5) the same bits; and
     one Renderer through path -> force_diffuse (a STAGED render: the textured class's kernels and their workspace arrays) -> path again."""
     lib, oracle_py, render, scenes = env
     cases = [scenes.ganesha_proxy(lib, 48, 48, n=24, variant="environment"),
-             scenes.three_spheres(lib, 48, 36, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(32))]
+             scenes.three_spheres(lib, 48, 36, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(32)),
+             # ... and with other BxDF classes (glass and metal, the sorted fused kernel's ENV_LIGHT instantiations: k_shade_tail_sorted_env.hip, k_shade_fused_gen_env.hip)
+             scenes.crown_proxy(lib, 40, 56, level=1, n_glass=6, n_gold=3, environment=scenes.environment_image(32)),
+             scenes.instanced_scene(lib, 48, 36, environment=scenes.environment_image(32))]
     for sc in cases:
         orc = oracle_py.Oracle(sc.desc)
         films = {}
