@@ -257,6 +257,10 @@ def side_results(lib, args, render, scenes, headline_scene, log):
             sc = scenes.ganesha_proxy(lib, 1024, 1024, n=args.n, variant=variant)
             timed(f"{name}_1024x1024_spp256", sc.desc, 256, args.max_depth, sc.info["n_primitives"])
             del sc
+        # ... and the reference's showcase class: the coated object under the map (the staged kernels' K_ENV_LIGHT units)
+        sc = scenes.ganesha_proxy(lib, 1024, 1024, n=args.n, coated=True, variant="environment")
+        timed("coated_S3_environment_map_1024x1024_spp256", sc.desc, 256, args.max_depth, sc.info["n_primitives"])
+        del sc
         sc = scenes.crown_proxy(lib, 1000, 1400)
         timed("C4_crown_proxy_1000x1400_spp256_depth32", sc.desc, 256, 32, sc.info["n_primitives"])
         c4 = out["C4_crown_proxy_1000x1400_spp256_depth32"]

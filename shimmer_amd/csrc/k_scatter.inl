@@ -6,6 +6,11 @@
 #pragma once
 #include "wavefront.h"
 
+// K_ENV_LIGHT (a translation unit's switch, round 5): compile ImageInfinitelight's look-up / sample / pdf into a kernel of the class WITHOUT textures — a scene whose only
+// image is an environment map needs nothing else of the textured class (k_shade_lean_env.hip says why); the *_env.hip units define it
+#ifndef K_ENV_LIGHT
+#define K_ENV_LIGHT false
+#endif
 namespace {
 
 // Deferred next-event estimation of the LayeredBxDF class. In a CoatedDiffuse / CoatedConductor vertex the expensive part of NEE is LayeredBxDF::f
@@ -218,7 +223,7 @@ __device__ __forceinline__ void scatter_body(const SceneView& sv, const PathArra
                 if (li >= 0) {
                     const ShmLight& light = sv.lights[li];
                     LightLiSample ls;
-                    if (light_sample_li<TRI_ONLY, HAS_TEX>(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
+                    if (light_sample_li<TRI_ONLY, HAS_TEX || K_ENV_LIGHT>(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
                         V3 wi = ls.wi;
                         // (LayeredBxDF::f is zero when wo and wi lie on opposite sides of the shading plane — shm/bxdf.h, layered_f — or wo in it,
                         //  bsdf.rs:48: half of the usable light samples on the coated S3; nothing to evaluate, nothing to queue)

@@ -16,6 +16,11 @@
 #pragma once
 #include "wavefront.h"
 
+// K_ENV_LIGHT (a translation unit's switch, round 5): compile ImageInfinitelight's look-up / sample / pdf into a kernel of the class WITHOUT textures — a scene whose only
+// image is an environment map needs nothing else of the textured class (k_shade_lean_env.hip says why); the *_env.hip units define it
+#ifndef K_ENV_LIGHT
+#define K_ENV_LIGHT false
+#endif
 namespace {
 
 constexpr int LJ_CAP = 2 * WAVE;  // per buffer: at most 63 waiting + 64 new (a stage runs as soon as 64 wait, and before anything is added)
@@ -402,7 +407,7 @@ __device__ __forceinline__ void scatter_layered_staged(const SceneView& sv, cons
             if (li >= 0) {
                 const ShmLight& light = sv.lights[li];
                 LightLiSample ls;
-                if (light_sample_li<TRI_ONLY, HAS_TEX>(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
+                if (light_sample_li<TRI_ONLY, HAS_TEX || K_ENV_LIGHT>(sv, light, ctx, u_light, lambda, ls) && !(is_zero(ls.l) || ls.pdf == 0.0f)) {
                     // LayeredBxDF::f is zero when wo and wi lie on opposite sides of the shading plane (shm/bxdf.h, layered_f) or wo in it (bsdf.rs:48):
                     // nothing to evaluate, nothing to queue. (Only the z components of the local directions: Frame::to_local's third dot product.)
                     const Float wo_lz = dot(si_wo, ns), wi_lz = dot(ls.wi, ns);

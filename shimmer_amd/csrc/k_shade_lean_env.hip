@@ -13,3 +13,9 @@ int wf_launch_shade_lean_env(ShmScene* s, const ShadeArgs& a) {
     WF_EMIT_JOBS_LAUNCH(ctx_as_hit);
     return SHM_OK;
 }
+// ... over the queue k_vertex diverted plain-diffuse hits to (a scene under a map that also holds other materials: k_shade_lean.hip)
+int wf_launch_shade_lean_env_diverted(ShmScene* s, const ShadeArgs& a) {
+    WF_SHADE_LAUNCH_DIVERTED((k_shade<false, true, false, true, false, false, true>));
+    WF_EMIT_JOBS_LAUNCH(0);
+    return SHM_OK;
+}

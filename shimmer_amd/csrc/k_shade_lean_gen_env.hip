@@ -10,3 +10,9 @@ int wf_launch_shade_lean_gen_env(ShmScene* s, const ShadeArgs& a) {
     LAUNCH_TRY("k_emit_jobs");
     return SHM_OK;
 }
+int wf_launch_shade_lean_gen_env_diverted(ShmScene* s, const ShadeArgs& a) {
+    WF_SHADE_LAUNCH_DIVERTED((k_shade<false, false, false, true, false, false, true>));
+    hipLaunchKernelGGL((k_emit_jobs<false, false>), dim3(s->n_cu * 4), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_emit, s->d_qs, 0);
+    LAUNCH_TRY("k_emit_jobs");
+    return SHM_OK;
+}

@@ -8,6 +8,11 @@
 #pragma once
 #include "wavefront.h"
 
+// K_ENV_LIGHT (a translation unit's switch, round 5): compile ImageInfinitelight's look-up / sample / pdf into a kernel of the class WITHOUT textures — a scene whose only
+// image is an environment map needs nothing else of the textured class (k_shade_lean_env.hip says why); the *_env.hip units define it
+#ifndef K_ENV_LIGHT
+#define K_ENV_LIGHT false
+#endif
 namespace {
 
 // The queue K2 leaves is in image order: neighbouring lanes hit different materials, and this half of the vertex is where materials differ most
@@ -129,7 +134,7 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
                     add_l(beta * le);
                 } else {
                     Float p_b = pa.rec[path].pb_eta.x;
-                    Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX>(sv, light, load_prev_ctx(), ray_d);
+                    Float p_l = light_sampler_pmf(sv) * light_pdf_li<TRI_ONLY, HAS_TEX || K_ENV_LIGHT>(sv, light, load_prev_ctx(), ray_d);
                     Float w = power_heuristic(1, p_b, 1, p_l);
                     add_l(beta * w * le);
                 }
@@ -140,7 +145,7 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
                     const ShmLight& light = sv.lights[sv.infinite_lights[li]];
                     // (flatten_scene lists only the infinite kinds here: light_pdf_li's area-light half — the inverted triangle sampling — folds away)
                     __builtin_assume(light.kind != SHM_LIGHT_DIFFUSE_AREA);
-                    emit(infinite_light_le<HAS_TEX>(sv, light, ray_d, lambda), light);
+                    emit(infinite_light_le<HAS_TEX || K_ENV_LIGHT>(sv, light, ray_d, lambda), light);
                 }
             } else if (divert && sv.materials[sv.prim_recs[hit.prim].material].kind == SHM_MATERIAL_DIFFUSE) {
                 push_class = N_BXDF_CLASSES;  // the fused kernel takes this vertex from its start (emission included)

@@ -206,10 +206,10 @@ static bool env_only_images(const ShmScene* s) { return s->env_lean && s->flat.h
 // (the shapes and classes whose every bounce the material-sorted fused all-materials kernel takes: k_shade_tail*.hip, k_shade_fused_*.hip)
 static bool fused_all_from_0(const ShmScene* s) { return !s->flat.has_class[CLASS_LAYERED] && s->tail_fused_bounce == 0 && (!s->flat.has_spheres || s->fused_gen); }
 static bool env_lean_scene(const ShmScene* s) { return env_only_images(s) && s->flat.diffuse_only; }
-// ... and the same for scenes with other BxDF classes (glass, metal under a map): the sorted fused kernel's ENV_LIGHT instantiations. `env_plain`: no path-integrator render of
-// this scene reaches a HAS_TEX kernel unless options.force_diffuse sends it through the staged pair — and even there the differentials are dead values (no material binds
-// a texture), so the auxiliary-ray arrays are never allocated for it
-static bool env_plain_scene(const ShmScene* s) { return env_only_images(s) && (s->flat.diffuse_only || fused_all_from_0(s)); }
+// ... and the same for every other class (glass, metal, coated materials under a map): the ENV_LIGHT instantiations of the sorted fused kernel and the K_ENV_LIGHT units of
+// the staged kernels. `env_plain`: no path-integrator render of this scene reaches a HAS_TEX kernel unless options.force_diffuse asks for that code — and even there the
+// differentials are dead values (no material binds a texture), so the auxiliary-ray arrays are never allocated for it
+static bool env_plain_scene(const ShmScene* s) { return env_only_images(s); }
 static bool scene_is_lean(const ShmScene* s) { return s->flat.diffuse_only && (!s->flat.has_textures || env_lean_scene(s)); }
 static bool tex_ws(const ShmScene* s) { return s->flat.has_textures && !env_plain_scene(s); }  // the auxiliary-ray arrays (and k_generate<true>)
 // (round 5) scenes whose every bounce shades with ONE fused kernel that knows bounce 0's constants (ShadeArgs::first_bounce): the lean class, and — without textures or coated
@@ -531,7 +531,8 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_PIX_GROUP")) { long long v2 = atoll(e); if (v2 >= 1) s->pix_group = (uint32_t)std::min<long long>(v2, 0x7fffffffll); }
     if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
     // the lean diversion (k_vertex.inl): triangle-only scenes without textures that hold plain diffuse materials BESIDE other classes
-    s->lean_divert = !s->flat.has_textures && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s);
+    if (const char* e = getenv("SHM_ENV_LEAN")) s->env_lean = atoi(e) != 0 ? 1 : 0;
+    s->lean_divert = (!s->flat.has_textures || env_plain_scene(s)) && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s);
     if (const char* e = getenv("SHM_LEAN_DIVERT")) s->lean_divert = s->lean_divert && atoi(e) != 0;
     // a shallow tree means short rays, and short rays want fewer, fuller waves (C2's 63-node box: 15.5 -> 15.1 ms per frame at 8 rays per lane); a deep
     // tree means long dependent chains per ray, which want every wave the device has (C4: 8 costs 2 %) — profiles/r03_trace_rays_per_lane_sweep.txt
@@ -547,7 +548,6 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
     if (const char* e = getenv("SHM_OTHER_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min = s->other_min_any = v2; }
     if (const char* e = getenv("SHM_TAIL_FUSED_BOUNCE")) { const int v2 = atoi(e); s->tail_fused_bounce = v2 >= 0 ? v2 : 1 << 30; }
-    if (const char* e = getenv("SHM_ENV_LEAN")) s->env_lean = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_FUSED_GEN")) s->fused_gen = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_FUSED_TEX")) s->fused_tex = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_TAIL_SORT")) s->tail_sort = atoi(e) != 0 ? 1 : 0;
@@ -767,8 +767,10 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 } else if (staged) {
                     // hit half (interaction, emission, get_bsdf -> parameter block, class queues), then one scattering kernel per BxDF
                     // class the scene holds, each over its own material-sorted queue
-                    const bool has_tex = s->flat.has_textures;
-                    rc = has_tex ? wf_launch_vertex_tex(s, sa) : (tri_only ? wf_launch_vertex_tri(s, sa) : wf_launch_vertex_gen(s, sa));
+                    const bool env = env_plain_scene(s) && params->force_diffuse == 0;  // (the K_ENV_LIGHT units: the class without textures + the image light)
+                    const bool has_tex = s->flat.has_textures && !env;
+                    rc = has_tex ? wf_launch_vertex_tex(s, sa) : (env ? (tri_only ? wf_launch_vertex_tri_env(s, sa) : wf_launch_vertex_gen_env(s, sa))
+                                                                      : (tri_only ? wf_launch_vertex_tri(s, sa) : wf_launch_vertex_gen(s, sa)));
                     // the hits k_vertex diverted (plain diffuse materials): their whole vertex in the fused kernel — the first member of the group below
                     const bool lean_too = s->lean_divert && s->d_q_lean && params->force_diffuse == 0;
                     // The classes' scatter kernels are independent of each other (own queue each, disjoint paths, wave-aggregated atomics on the
@@ -802,14 +804,18 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                         }
                         ++k_cls;
                     };
-                    scatter_on(-1, [&](const ShadeArgs& x) { return tri_only ? wf_launch_shade_lean_diverted(s, x) : wf_launch_shade_lean_gen_diverted(s, x); });
-                    scatter_on(CLASS_DIFFUSE, [&](const ShadeArgs& x) { return wf_launch_scatter_diffuse(s, x, tri_only, has_tex); });
-                    scatter_on(CLASS_CONDUCTOR, [&](const ShadeArgs& x) { return wf_launch_scatter_conductor(s, x, tri_only, has_tex); });
-                    scatter_on(CLASS_DIELECTRIC, [&](const ShadeArgs& x) { return wf_launch_scatter_dielectric(s, x, tri_only, has_tex); });
+                    scatter_on(-1, [&](const ShadeArgs& x) { return env ? (tri_only ? wf_launch_shade_lean_env_diverted(s, x) : wf_launch_shade_lean_gen_env_diverted(s, x))
+                                                                        : (tri_only ? wf_launch_shade_lean_diverted(s, x) : wf_launch_shade_lean_gen_diverted(s, x)); });
+                    scatter_on(CLASS_DIFFUSE, [&](const ShadeArgs& x) { return env ? wf_launch_scatter_diffuse_env(s, x, tri_only) : wf_launch_scatter_diffuse(s, x, tri_only, has_tex); });
+                    scatter_on(CLASS_CONDUCTOR, [&](const ShadeArgs& x) { return env ? wf_launch_scatter_conductor_env(s, x, tri_only) : wf_launch_scatter_conductor(s, x, tri_only, has_tex); });
+                    scatter_on(CLASS_DIELECTRIC, [&](const ShadeArgs& x) { return env ? wf_launch_scatter_dielectric_env(s, x, tri_only) : wf_launch_scatter_dielectric(s, x, tri_only, has_tex); });
                     scatter_on(CLASS_LAYERED, [&](const ShadeArgs& x) {
                         // (options.force_diffuse replaces the BxDF inside this half: the one-pass kernel has that code)
-                        if (params->force_diffuse == 0 && layered_staged && s->capacity < (1u << 30))  // (its jobs carry two flag bits above the path index)
+                        if (params->force_diffuse == 0 && layered_staged && s->capacity < (1u << 30)) {  // (its jobs carry two flag bits above the path index)
+                            if (env) return tri_only ? wf_launch_scatter_layered_staged_tri_env(s, x) : wf_launch_scatter_layered_staged_gen_env(s, x);
                             return has_tex ? wf_launch_scatter_layered_staged_tex(s, x) : (tri_only ? wf_launch_scatter_layered_staged_tri(s, x) : wf_launch_scatter_layered_staged_gen(s, x));
+                        }
+                        if (env) return tri_only ? wf_launch_scatter_layered_tri_env(s, x) : wf_launch_scatter_layered_gen_env(s, x);
                         return has_tex ? wf_launch_scatter_layered_tex(s, x) : (tri_only ? wf_launch_scatter_layered_tri(s, x) : wf_launch_scatter_layered_gen(s, x)); });
                     for (hipEvent_t e : side_done) hipStreamWaitEvent(s->stream, e, 0);
                 }

@@ -375,6 +375,18 @@ WF_INTERNAL int wf_launch_shade_lean_gen(ShmScene* s, const ShadeArgs& a);      
 WF_INTERNAL int wf_launch_shade_lean_gen_diverted(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_lean_env(ShmScene* s, const ShadeArgs& a);      // the lean fused kernel with an ImageInfinitelight compiled in (k_shade_lean_env.hip)
 WF_INTERNAL int wf_launch_shade_lean_gen_env(ShmScene* s, const ShadeArgs& a);  // ... for general geometry (k_shade_lean_gen_env.hip)
+// the staged kernels of a scene whose only image is an ImageInfinitelight (K_ENV_LIGHT units: k_vertex_env.hip, k_scatter_*_env.hip, k_scatter_layered*_env.hip)
+WF_INTERNAL int wf_launch_vertex_tri_env(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_vertex_gen_env(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_scatter_diffuse_env(ShmScene* s, const ShadeArgs& a, bool tri_only);
+WF_INTERNAL int wf_launch_scatter_conductor_env(ShmScene* s, const ShadeArgs& a, bool tri_only);
+WF_INTERNAL int wf_launch_scatter_dielectric_env(ShmScene* s, const ShadeArgs& a, bool tri_only);
+WF_INTERNAL int wf_launch_scatter_layered_staged_tri_env(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_scatter_layered_staged_gen_env(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_scatter_layered_tri_env(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_scatter_layered_gen_env(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_shade_lean_env_diverted(ShmScene* s, const ShadeArgs& a);
+WF_INTERNAL int wf_launch_shade_lean_gen_env_diverted(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_tail_sorted_env(ShmScene* s, const ShadeArgs& a);  // the sorted fused all-materials kernel with an ImageInfinitelight compiled in (k_shade_tail_sorted_env.hip)
 WF_INTERNAL int wf_launch_shade_fused_gen_env(ShmScene* s, const ShadeArgs& a);    // ... for general geometry (k_shade_fused_gen_env.hip)
 WF_INTERNAL int wf_launch_shade_fused_gen(ShmScene* s, const ShadeArgs& a);    // ... for scenes with spheres / patches / instances (k_shade_fused_gen.hip)

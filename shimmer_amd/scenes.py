@@ -97,7 +97,7 @@ def test_image(size=64, channels=3, seed=7):
 
 
 def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=False, patch_skew=0.0, textured=False,
-                texture_filter=None, textured_coated_ceiling=True, glass=False, emitter_reflects=False):
+                texture_filter=None, textured_coated_ceiling=True, glass=False, emitter_reflects=False, environment=None):
     """S2 (config C2): 5 walls x 2 + 2 boxes x 5 faces x 2 + light 2 = 32 triangles.
     coated=True: the tall box becomes CoatedConductor (rough interface, Cu), the short one CoatedDiffuse with a scattering
     medium between the interfaces, the floor CoatedDiffuse with a smooth interface (SURVEY §8f-1 materials)."""
@@ -212,7 +212,10 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=Fal
         # emitter_reflects: the emitter's own material is white instead of black, so a path that hits it goes ON (emission at a vertex whose state the vertex
         # kernel overwrites: the deferred evaluation of k_emit_jobs reads its side copies), and it emits from both sides
         b.add_mesh(_to_render(p, rfw), vi, white if emitter_reflects else black, emission=blackbody_dense(6500.0), emission_scale=20.0, two_sided=bool(emitter_reflects))
-    return _finish(b, lib, name="S2 cornell box" + (" (coated)" if coated else "") + (" (mix)" if mix else "") + (" (patches)" if patches else "") + (" (textured)" if textured else "") + (" (glass)" if glass else ""))
+    if environment is not None:  # an ImageInfinitelight shines in through the open front (round 5: the K_ENV_LIGHT units of the staged kernels)
+        rot = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float32)
+        b.light_image_infinite(environment, scale=0.5, render_from_light=rot)
+    return _finish(b, lib, name="S2 cornell box" + (" (environment map)" if environment is not None else "") + (" (coated)" if coated else "") + (" (mix)" if mix else "") + (" (patches)" if patches else "") + (" (textured)" if textured else "") + (" (glass)" if glass else ""))
 
 
 def _hash3(ix, iy, iz, seed):

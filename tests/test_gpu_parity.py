@@ -781,7 +781,12 @@ def test_environment_map_scenes_run_the_lean_class(env, monkeypatch):
              scenes.three_spheres(lib, 48, 36, camera=(0.75, 0.5, 9.0), environment=scenes.environment_image(32)),
              # ... and with other BxDF classes (glass and metal, the sorted fused kernel's ENV_LIGHT instantiations: k_shade_tail_sorted_env.hip, k_shade_fused_gen_env.hip)
              scenes.crown_proxy(lib, 40, 56, level=1, n_glass=6, n_gold=3, environment=scenes.environment_image(32)),
-             scenes.instanced_scene(lib, 48, 36, environment=scenes.environment_image(32))]
+             scenes.instanced_scene(lib, 48, 36, environment=scenes.environment_image(32)),
+             # ... and with coated materials — the reference's showcase class, a coated object under a map —: the staged kernels' K_ENV_LIGHT units (k_vertex_env.hip,
+             # k_scatter_*_env.hip, k_scatter_layered*_env.hip), triangles / with bilinear patches / with glass beside the coated boxes
+             scenes.ganesha_proxy(lib, 48, 48, n=24, coated=True, variant="environment"),
+             scenes.cornell_box(lib, 40, 40, coated=True, patches=True, environment=scenes.environment_image(32)),
+             scenes.cornell_box(lib, 40, 40, coated=True, mix=True, environment=scenes.environment_image(32))]
     for sc in cases:
         orc = oracle_py.Oracle(sc.desc)
         films = {}
