@@ -532,6 +532,8 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
     // the lean diversion (k_vertex.inl): triangle-only scenes without textures that hold plain diffuse materials BESIDE other classes
     if (const char* e = getenv("SHM_ENV_LEAN")) s->env_lean = atoi(e) != 0 ? 1 : 0;
+    // (measured in round 5 and not kept: the diversion in scenes WITH material textures too — exact, a diffuse bounce ends the ray differentials — gave S3 with a textured floor
+    //  nothing: 3 131 against 3 169 Mray/s; what costs there is the textured vertices themselves, 0.7 ns each against 0.125)
     s->lean_divert = (!s->flat.has_textures || env_plain_scene(s)) && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s);
     if (const char* e = getenv("SHM_LEAN_DIVERT")) s->lean_divert = s->lean_divert && atoi(e) != 0;
     // a shallow tree means short rays, and short rays want fewer, fuller waves (C2's 63-node box: 15.5 -> 15.1 ms per frame at 8 rays per lane); a deep
@@ -804,8 +806,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                         }
                         ++k_cls;
                     };
-                    scatter_on(-1, [&](const ShadeArgs& x) { return env ? (tri_only ? wf_launch_shade_lean_env_diverted(s, x) : wf_launch_shade_lean_gen_env_diverted(s, x))
-                                                                        : (tri_only ? wf_launch_shade_lean_diverted(s, x) : wf_launch_shade_lean_gen_diverted(s, x)); });
+                    scatter_on(-1, [&](const ShadeArgs& x) { return s->flat.has_image_light ? (tri_only ? wf_launch_shade_lean_env_diverted(s, x) : wf_launch_shade_lean_gen_env_diverted(s, x))
+                                                                                              : (tri_only ? wf_launch_shade_lean_diverted(s, x) : wf_launch_shade_lean_gen_diverted(s, x)); });
                     scatter_on(CLASS_DIFFUSE, [&](const ShadeArgs& x) { return env ? wf_launch_scatter_diffuse_env(s, x, tri_only) : wf_launch_scatter_diffuse(s, x, tri_only, has_tex); });
                     scatter_on(CLASS_CONDUCTOR, [&](const ShadeArgs& x) { return env ? wf_launch_scatter_conductor_env(s, x, tri_only) : wf_launch_scatter_conductor(s, x, tri_only, has_tex); });
                     scatter_on(CLASS_DIELECTRIC, [&](const ShadeArgs& x) { return env ? wf_launch_scatter_dielectric_env(s, x, tri_only) : wf_launch_scatter_dielectric(s, x, tri_only, has_tex); });

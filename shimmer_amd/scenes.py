@@ -291,16 +291,17 @@ def cube_sphere(n, seed=1234, amplitude=0.15, shuffle_seed=99):
     return verts, tris
 
 
-def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=False, variant=None):
+def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=False, variant=None, floor_filter="ewa"):
     """S3 (configs C3/C5): n=599 gives 6*599^2*2 = 4 305 612 triangles and 2 152 808 vertices.
     coated=True: the object is CoatedDiffuse (the material of the reference's Ganesha render, images/shimmer-ganesha-1.png).
     variant (round 5: the shapes a real PBRT-v4 scene mixes into its triangles; same camera, room and object):
       "patch_emitter"  the window emitter is ONE bilinear patch — what a quad face of a PLY file becomes (shape/shape.rs:119-134, shape/mesh.rs:233-256)
       "one_sphere"     a diffuse sphere stands on the floor beside the object (shape/sphere.rs)
       "instanced"      the object is an object definition placed once through a TransformedPrimitive (primitive.rs:136-176)
+      "textured_floor" the ground plane's reflectance is an image texture (EWA-filtered, repeated): ONE textured material among plain ones
       "environment"    no room and no window: the object on its ground plane under an ImageInfinitelight (light.rs:805-981) — escaped rays look the map up, next-event
                        estimation samples its (compensated) piecewise-constant distribution"""
-    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment")
+    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment", "textured_floor")
     b = SceneBuilder()
     b.set_film(width, height)
     rfw = b.set_camera_look_at(lib, (0.0, 0.6, 4.2), (0.0, 0.0, 0.0), (0, 1, 0), 38.0)
@@ -327,7 +328,11 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
     elif with_room:
         # ground (2) + open room (10: back, left, right, ceiling, front-top strip) + window emitter (2)
         p, vi = _quad((-4, -1.25, -4), (-4, -1.25, 6), (4, -1.25, 6), (4, -1.25, -4))
-        b.add_mesh(_to_render(p, rfw), vi, wall)
+        if variant == "textured_floor":
+            floor_m = b.material_diffuse(b.add_image_texture(test_image(64, 3), filter=floor_filter, wrap="repeat", su=4.0, sv=4.0))
+            b.add_mesh(_to_render(p, rfw), vi, floor_m, uv=np.array([(0, 0), (1, 0), (1, 1), (0, 1)], np.float32))
+        else:
+            b.add_mesh(_to_render(p, rfw), vi, wall)
         room = _merge([
             _quad((-4, -1.25, -4), (4, -1.25, -4), (4, 4, -4), (-4, 4, -4)),      # back
             _quad((-4, -1.25, -4), (-4, 4, -4), (-4, 4, 6), (-4, -1.25, 6)),      # left

@@ -64,6 +64,7 @@ SCENES = {
     "S3_small_patch_emitter": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="patch_emitter"), 6, 5),
     "S3_small_one_sphere": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="one_sphere"), 6, 5),
     "S3_small_instanced": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="instanced"), 6, 5),
+    "S3_small_textured_floor": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="textured_floor"), 6, 5),
     "S3_small_environment": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="environment"), 6, 5),
 }
 
@@ -391,7 +392,7 @@ def test_headline_frame_at_full_size(env):
 
 
 @pytest.mark.parametrize("variant,crop", [("patch_emitter", (504, 440, 520, 456)), ("one_sphere", (152, 920, 168, 936)), ("instanced", (504, 440, 520, 456)),
-                                          ("environment", (504, 440, 520, 456))])
+                                          ("environment", (504, 440, 520, 456)), ("textured_floor", (504, 840, 520, 856))])
 def test_mixed_shape_frames_at_full_size(env, variant, crop):
     """The headline frame with the shapes a real PBRT-v4 scene mixes into its triangles (bench.py's round-5 side results: the emitter as ONE bilinear patch, a sphere
     beside the object, the object as a TransformedPrimitive; and the object under an ImageInfinitelight: the sorted fused kernel's textured instantiation) at its own size — 4.3 M primitives, 1024 x 1024, 256 spp, one 268 M-path batch through k_trace5<., GEN> and the
