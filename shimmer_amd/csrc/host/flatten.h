@@ -51,7 +51,8 @@ struct FlatScene {
     uint32_t rgb2spec_res = 0;
     bool has_textures = false;  // a material slot binds an image texture (the path carries ray differentials) or an image infinite
                                 // light exists (both read the colour-space tables): selects k_shade<.., HAS_TEX>
-    bool has_material_textures = false, has_image_light = false;  // ... which of the two (round 5: an image light alone needs no differentials — render.hip, env_lean)
+    bool has_material_textures = false, has_image_light = false;
+    uint64_t n_plain_diffuse_prims = 0;  // primitives whose material is a DiffuseMaterial that binds no texture (the split pass of textured scenes, render.hip)  // ... which of the two (round 5: an image light alone needs no differentials — render.hip, env_lean)
     std::vector<ShmInstance> instances;
     bool has_instances = false;
     std::vector<ShmFloatTexture> float_textures;
@@ -632,6 +633,17 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
     // The reference's traversal stack is [usize; 64] (aggregate.rs:90); deeper trees would index out of bounds there.
     if (getenv("SHM_DEBUG")) fprintf(stderr, "[shm] flatten: %u nodes, %u prims, max leaf depth %u\n", d->n_nodes, d->n_primitives, out.max_leaf_depth);
     if (out.max_leaf_depth >= 64) { err = "BVH deeper than the reference's 64-entry traversal stack"; return SHM_ERR_UNSUPPORTED; }
+    // ShmMaterial::pad[0] of the DEVICE copy, bit 0: a DiffuseMaterial that binds no texture — in a scene with textures what the split pass (k_split_plain, render.hip) sends to
+    // the lean fused kernel: a diffuse bounce ends the ray differentials (interaction.rs:430-514: only specular bounces carry them on), so nothing a later texture look-up reads
+    // depends on which kernel shaded such a vertex
+    for (ShmMaterial& m : out.materials) {
+        const bool tex_a = m.a.kind == SHM_SPECTRUM_IMAGE_TEXTURE || m.a.kind == SHM_SPECTRUM_TEXTURE_NODE;
+        bool any_float_tex = false;
+        for (int k = 0; k < 8; ++k) any_float_tex = any_float_tex || m.float_tex[k] != 0u;
+        m.pad[0] = (m.kind == SHM_MATERIAL_DIFFUSE && !tex_a && !any_float_tex && m.normal_map == 0u) ? 1u : 0u;
+    }
+    for (const shm::PrimRec& pr : out.prim_recs)
+        if (pr.material < out.materials.size() && (out.materials[pr.material].pad[0] & 1u)) out.n_plain_diffuse_prims += 1u;
     out.has_material_textures = out.has_textures;
     out.has_textures = out.has_material_textures || out.has_image_light;
     return SHM_OK;

@@ -28,8 +28,8 @@ constexpr int VERTEX_SORT_BINS = 64;
 constexpr int N_VERTEX_QUEUES = N_BXDF_CLASSES + 1;
 template <bool TRI_ONLY, bool HAS_TEX, bool SORT>
 __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArrays& pa, const uint32_t* __restrict__ q_cur, uint32_t* q_s0, uint32_t* q_s1,
-                                            uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, const ShmRenderParams& params, uint32_t* q_lean) {
-    const uint32_t n = qs->n_active[cur];
+                                            uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, const ShmRenderParams& params, uint32_t* q_lean, const uint32_t* n_in) {
+    const uint32_t n = n_in ? *n_in : qs->n_active[cur];  // (n_in: the split pass's queue, whose count is not n_active)
     const bool divert = !HAS_TEX && q_lean != nullptr;
     __shared__ uint32_t s_q[!HAS_TEX ? N_VERTEX_QUEUES : N_BXDF_CLASSES][SHADE_CHUNK];  // (the fifth queue only where the diversion can happen)
     __shared__ uint32_t s_cnt[N_VERTEX_QUEUES], s_base[N_VERTEX_QUEUES];
@@ -222,23 +222,23 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
 template <bool TRI_ONLY, bool HAS_TEX, bool SORT = false>
 __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_ATTR k_vertex(SceneView sv_global, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* q_s0, uint32_t* q_s1,
                                                                      uint32_t* q_s2, uint32_t* q_s3, QueueState* qs, int cur, ShmRenderParams params, uint32_t* q_lean,
-                                                                     LdsTables lds_tables) {
+                                                                     LdsTables lds_tables, const uint32_t* n_in) {
     __shared__ uint4 s_tables[LDS_TABLE_BUDGET / 16];  // the small scene tables, staged once per workgroup (wavefront.h, stage_scene_tables)
     __shared__ uint4 s_view[HAS_TEX ? SCENE_VIEW_UINT4S : 1];  // ... and, with textures, the view itself: what the texture evaluators that are real calls read the scene through
     const SceneView sv = stage_scene_tables_tex<HAS_TEX>(sv_global, lds_tables, s_tables, s_view);
-    vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params, q_lean);
+    vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params, q_lean, n_in);
 }
 // three waves per SIMD (<= 168 VGPRs): the triangle-only instantiation needs 159 and is bound by the latency of its gathers
 template <bool TRI_ONLY, bool HAS_TEX, bool SORT = false>
 __global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_vertex_w3(SceneView sv_global, PathArrays pa, const uint32_t* __restrict__ q_cur,
                                                                                                         uint32_t* q_s0, uint32_t* q_s1, uint32_t* q_s2, uint32_t* q_s3,
                                                                                                         QueueState* qs, int cur, ShmRenderParams params, uint32_t* q_lean,
-                                                                                                        LdsTables lds_tables) {
+                                                                                                        LdsTables lds_tables, const uint32_t* n_in) {
     // (three workgroups of this kernel share a CU's 160 KB with 41-51 KB each of sort bins and queues: 1.5 KB are left for tables — the material table of most scenes)
     __shared__ uint4 s_tables[LDS_TABLE_BUDGET_SMALL / 16];
     __shared__ uint4 s_view[HAS_TEX ? SCENE_VIEW_UINT4S : 1];
     const SceneView sv = stage_scene_tables_tex<HAS_TEX>(sv_global, lds_tables, s_tables, s_view);
-    vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params, q_lean);
+    vertex_body<TRI_ONLY, HAS_TEX, SORT>(sv, pa, q_cur, q_s0, q_s1, q_s2, q_s3, qs, cur, params, q_lean, n_in);
 }
 
 }  // namespace
@@ -252,15 +252,15 @@ static inline bool wf_vertex_sort(const ShmScene* s) {
 }
 #define WF_VERTEX_LAUNCH_W3(TRI, TEX, SORT)                                                                                                    \
     do {                                                                                                                                       \
-        hipLaunchKernelGGL((k_vertex_w3<TRI, TEX, SORT>), dim3(a.blocks * 3 / 2), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur], \
+        hipLaunchKernelGGL((k_vertex_w3<TRI, TEX, SORT>), dim3(a.blocks * 3 / 2), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, a.q_in ? a.q_in : s->d_q_active[a.cur], \
                            s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params,               \
-                           (a.params.force_diffuse == 0 && s->lean_divert) ? s->d_q_lean : (uint32_t*)nullptr, s->lds_tables_small);           \
+                           (a.params.force_diffuse == 0 && s->lean_divert) ? s->d_q_lean : (uint32_t*)nullptr, s->lds_tables_small, a.n_in);           \
         LAUNCH_TRY("k_vertex_w3");                                                                                                             \
     } while (0)
 #define WF_VERTEX_LAUNCH(TRI, TEX, SORT)                                                                                                       \
     do {                                                                                                                                       \
-        hipLaunchKernelGGL((k_vertex<TRI, TEX, SORT>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, s->d_q_active[a.cur],          \
+        hipLaunchKernelGGL((k_vertex<TRI, TEX, SORT>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, a.q_in ? a.q_in : s->d_q_active[a.cur],          \
                            s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params,               \
-                           (a.params.force_diffuse == 0 && s->lean_divert) ? s->d_q_lean : (uint32_t*)nullptr, s->lds_tables);                                 \
+                           (a.params.force_diffuse == 0 && s->lean_divert) ? s->d_q_lean : (uint32_t*)nullptr, s->lds_tables, a.n_in);                                 \
         LAUNCH_TRY("k_vertex");                                                                                                                \
     } while (0)

@@ -113,7 +113,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_generate(SceneView sv, PathArra
         qs->n_shadow[1] = 0;
         qs->n_scatter[0] = qs->n_scatter[1] = qs->n_scatter[2] = qs->n_scatter[3] = 0;
         qs->n_emit = 0;
-    qs->n_lean = 0;
+        qs->n_lean = 0;
+        qs->n_split = 0;
     }
 }
 
@@ -122,8 +123,50 @@ __global__ void k_next_bounce(QueueState* qs, int cur, int next_shadow_parity) {
     qs->n_active[cur] = 0;
     qs->n_scatter[0] = qs->n_scatter[1] = qs->n_scatter[2] = qs->n_scatter[3] = 0;
     qs->n_lean = 0;
+    qs->n_split = 0;
     qs->n_emit = 0;
     qs->n_shadow[next_shadow_parity] = 0;  // the one the NEXT shade launch fills; this bounce's count stays for its K3
+}
+// ---------------------------------------------------------------------------------------------
+// Scenes WITH textures (round 5): the split pass in front of the textured vertex kernel. Until then one textured material put every vertex of the scene through the textured
+// class's kernels — ray differentials, the 48-byte differential arrays, 256 VGPRs at two waves per SIMD —: the headline scene with a textured material OUT OF SIGHT shaded in
+// 207 ms per frame against 86. A vertex on a DiffuseMaterial that binds no texture (ShmMaterial::pad[0], flatten_scene) needs none of it, and a diffuse bounce ends the
+// ray differentials (interaction.rs:430-514: only specular bounces carry them on): nothing a later texture look-up reads depends on which kernel shaded it. This pass — a
+// few registers, full occupancy — sends such hits to q_lean (the lean fused kernel takes their whole vertex, as in the lean diversion of k_vertex.inl) and everything
+// else, escaped rays included, to q_split, which the textured kernels work through. Paths are independent and every later queue is order-agnostic: films and counters
+// do not change.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SHADE2_BLOCK) k_split_plain(SceneView sv, PathArrays pa, const uint32_t* __restrict__ q_cur, uint32_t* __restrict__ q_lean,
+                                                             uint32_t* __restrict__ q_split, QueueState* qs, int cur) {
+    const uint32_t n = qs->n_active[cur];
+    __shared__ uint32_t s_q[2][SHADE_CHUNK];
+    __shared__ uint32_t s_cnt[2], s_base[2];
+    for (uint32_t chunk0 = blockIdx.x * SHADE_CHUNK; chunk0 < n; chunk0 += gridDim.x * SHADE_CHUNK) {
+        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {
+            const uint32_t i = chunk0 + k * SHADE2_BLOCK + threadIdx.x;
+            bool plain = false, rest = false;
+            uint32_t path = 0;
+            if (i < n) {
+                path = q_cur[i];
+                const int prim = __float_as_int(reinterpret_cast<const float*>(pa.hit + path)[0]);  // (scenes with textures keep the 32-byte hit records)
+                plain = prim >= 0 && (sv.materials[sv.prim_recs[prim].material].pad[0] & 1u) != 0u;
+                rest = !plain;
+            }
+            const uint32_t a = queue_push_slot(&s_cnt[0], plain);
+            if (plain) s_q[0][a] = path;
+            const uint32_t b = queue_push_slot(&s_cnt[1], rest);
+            if (rest) s_q[1][b] = path;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base[0] = s_cnt[0] ? atomicAdd(&qs->n_lean, s_cnt[0]) : 0u;
+        if (threadIdx.x == 1) s_base[1] = s_cnt[1] ? atomicAdd(&qs->n_split, s_cnt[1]) : 0u;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < s_cnt[0]; j += SHADE2_BLOCK) q_lean[s_base[0] + j] = s_q[0][j];
+        for (uint32_t j = threadIdx.x; j < s_cnt[1]; j += SHADE2_BLOCK) q_split[s_base[1] + j] = s_q[1][j];
+        __syncthreads();
+    }
 }
 // ---------------------------------------------------------------------------------------------
 // K6: RgbFilm::add_sample for every sample of the batch, per pixel in sample order (f64 sums are
@@ -228,6 +271,7 @@ static uint64_t staging_bytes_per_path(const ShmScene* s) {
     if (f.has_textures) b += 48;                                               // dd0..2
     for (int c = 0; c < N_BXDF_CLASSES; ++c) if (f.has_class[c]) b += 4;       // class queues
     if (s->lean_divert) b += 4;                                                // the lean diversion's queue
+    if (s->tex_split) b += 4;                                                  // the split pass's queue
     return b;
 }
 static bool uses_fused_kernel(const ShmScene* s) { return scene_is_lean(s) || s->lean_divert; }  // k_shade<lean>: deferred emitter hits (PathArrays::e_*)
@@ -314,6 +358,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
     s->pa.dd0 = s->pa.dd1 = s->pa.dd2 = nullptr;
     for (int c = 0; c < N_BXDF_CLASSES; ++c) s->d_q_scatter[c] = nullptr;
     s->d_q_lean = nullptr;
+    s->d_q_split = nullptr;
     s->ws_staged = false;
     if (need_staged) {
         const shm_host::FlatScene& f = s->flat;
@@ -322,6 +367,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
         for (int c = 0; c < N_BXDF_CLASSES; ++c)
             if (f.has_class[c] && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_scatter[c])) != SHM_OK) return rc;
         if (s->lean_divert && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_lean)) != SHM_OK) return rc;
+        if (s->tex_split && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_split)) != SHM_OK) return rc;
         s->ws_staged = true;
     }
 #undef WS
@@ -532,9 +578,11 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
     // the lean diversion (k_vertex.inl): triangle-only scenes without textures that hold plain diffuse materials BESIDE other classes
     if (const char* e = getenv("SHM_ENV_LEAN")) s->env_lean = atoi(e) != 0 ? 1 : 0;
-    // (measured in round 5 and not kept: the diversion in scenes WITH material textures too — exact, a diffuse bounce ends the ray differentials — gave S3 with a textured floor
-    //  nothing: 3 131 against 3 169 Mray/s; what costs there is the textured vertices themselves, 0.7 ns each against 0.125)
-    s->lean_divert = (!s->flat.has_textures || env_plain_scene(s)) && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s);
+    // scenes with material textures: the split pass (k_split_plain) where a quarter of the primitives or more carry a plain DiffuseMaterial (the textured Cornell box, whose
+    // only plain material is its emitter's, would pay a pass per bounce for a handful of hits; SHM_TEX_SPLIT=0 / 1 overrides)
+    s->tex_split = s->flat.has_material_textures && s->flat.n_plain_diffuse_prims * 4ull >= (uint64_t)s->flat.prim_recs.size() ? 1 : 0;
+    if (const char* e = getenv("SHM_TEX_SPLIT")) s->tex_split = (atoi(e) != 0 && s->flat.has_material_textures && s->flat.n_plain_diffuse_prims > 0) ? 1 : 0;
+    s->lean_divert = ((!s->flat.has_textures || env_plain_scene(s)) && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s)) || s->tex_split;
     if (const char* e = getenv("SHM_LEAN_DIVERT")) s->lean_divert = s->lean_divert && atoi(e) != 0;
     // a shallow tree means short rays, and short rays want fewer, fuller waves (C2's 63-node box: 15.5 -> 15.1 ms per frame at 8 rays per lane); a deep
     // tree means long dependent chains per ray, which want every wave the device has (C4: 8 costs 2 %) — profiles/r03_trace_rays_per_lane_sweep.txt
@@ -551,7 +599,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_OTHER_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min = s->other_min_any = v2; }
     if (const char* e = getenv("SHM_TAIL_FUSED_BOUNCE")) { const int v2 = atoi(e); s->tail_fused_bounce = v2 >= 0 ? v2 : 1 << 30; }
     if (const char* e = getenv("SHM_FUSED_GEN")) s->fused_gen = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("SHM_FUSED_TEX")) s->fused_tex = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("SHM_FUSED_TEX")) s->fused_tex = atoi(e);  // (0: never; 1: where the scene holds more than one BxDF class; 2: development — always)
     if (const char* e = getenv("SHM_TAIL_SORT")) s->tail_sort = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_OTHER_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min_any = v2; }
     if ((rc = wf_trace_prepare(s)) != SHM_OK) return fail(rc);
@@ -762,7 +810,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 // four or five, from bounce `tail_fused_bounce` on. Rounds 3-4, chunks unsorted: only the late bounces paid (C4 frame 522-528 ms staged throughout,
                 // 510-512 from bounce 6, 511-513 from 8). Round 5, chunks counting-sorted by material (k_shade_tail_sorted.hip): the earlier the better — C4 403.2 ms
                 // from bounce 8, 399 from 4, 388 from 2, 378 from 1, 365 from 0: the default (SHM_TAIL_FUSED_BOUNCE, negative = never; read at scene creation)
-                if (staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || env_plain_scene(s) || (s->fused_tex && n_classes_present > 1)) && (tri_only || s->fused_gen)) {
+                if (staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || env_plain_scene(s) || (s->fused_tex && !s->tex_split && (n_classes_present > 1 || s->fused_tex == 2))) && (tri_only || s->fused_gen)) {
                     if (env_plain_scene(s)) rc = tri_only ? wf_launch_shade_tail_sorted_env(s, sa) : wf_launch_shade_fused_gen_env(s, sa);
                     else rc = tri_only ? (s->flat.has_textures ? wf_launch_shade_fused_tex(s, sa) : wf_launch_shade_tail(s, sa))
                                        : (s->flat.has_textures ? wf_launch_shade_fused_gen_tex(s, sa) : wf_launch_shade_fused_gen(s, sa));
@@ -771,10 +819,19 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     // class the scene holds, each over its own material-sorted queue
                     const bool env = env_plain_scene(s) && params->force_diffuse == 0;  // (the K_ENV_LIGHT units: the class without textures + the image light)
                     const bool has_tex = s->flat.has_textures && !env;
+                    const bool split = has_tex && s->tex_split && s->d_q_split && s->d_q_lean && params->force_diffuse == 0;
+                    if (split) {  // plain-diffuse hits -> q_lean (their whole vertex in the lean fused kernel, below), the rest -> q_split for the textured kernels
+                        hipLaunchKernelGGL(k_split_plain, dim3(s->n_cu * 8), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur], s->d_q_lean, s->d_q_split, s->d_qs, cur);
+                        LAUNCH_TRY("k_split_plain");
+                        ShadeArgs sv_ = sa;
+                        sv_.q_in = s->d_q_split;
+                        sv_.n_in = &s->d_qs->n_split;
+                        rc = wf_launch_vertex_tex(s, sv_);
+                    } else
                     rc = has_tex ? wf_launch_vertex_tex(s, sa) : (env ? (tri_only ? wf_launch_vertex_tri_env(s, sa) : wf_launch_vertex_gen_env(s, sa))
                                                                       : (tri_only ? wf_launch_vertex_tri(s, sa) : wf_launch_vertex_gen(s, sa)));
                     // the hits k_vertex diverted (plain diffuse materials): their whole vertex in the fused kernel — the first member of the group below
-                    const bool lean_too = s->lean_divert && s->d_q_lean && params->force_diffuse == 0;
+                    const bool lean_too = s->lean_divert && s->d_q_lean && params->force_diffuse == 0 && (!has_tex || split);
                     // The classes' scatter kernels are independent of each other (own queue each, disjoint paths, wave-aggregated atomics on the
                     // shared next / shadow queues): the first runs on the render stream, the others beside it on their own streams, and the render
                     // stream waits for them — for small batches only (the same threshold as the K3 / K2 overlap above), where the launches are

@@ -69,6 +69,7 @@ struct QueueState {
     uint32_t n_scatter[4];  // staged shading: entries in q_scatter[class], filled by k_vertex, drained by k_scatter<class>
     uint32_t n_lean;        // staged shading with the lean diversion: hits on plain DiffuseMaterial, which k_vertex hands to the fused kernel whole
     uint32_t n_emit;        // the fused kernel's deferred emitter hits (q_emit), worked off by k_emit_jobs after it
+    uint32_t n_split;       // scenes with textures: the hits the split pass left to the textured kernels (q_split; the plain-diffuse ones went to q_lean)
 };
 
 // The part of a path's state that EVERY vertex reads (and rewrites), as one 64-byte record. As six separate arrays (rounds 1-4) a vertex touched six cache lines for
@@ -284,6 +285,8 @@ struct ShmScene {
     uint32_t* d_q_active[2] = {nullptr, nullptr};
     uint32_t* d_q_shadow = nullptr;
     uint32_t* d_q_scatter[4] = {nullptr, nullptr, nullptr, nullptr};  // staged shading: one queue per BxDF class present in the scene
+    uint32_t* d_q_split = nullptr; // scenes with textures and plain diffuse materials: what the split pass leaves to the textured kernels
+    int tex_split = 0;             // ... that pass is on (SHM_TEX_SPLIT; a quarter of the primitives or more are plain diffuse)
     uint32_t* d_q_lean = nullptr;  // the lean diversion's queue (triangle-only scenes without textures that hold plain diffuse materials beside others)
     bool lean_divert = false;      // SHM_LEAN_DIVERT=0 switches it off (A/B)
     bool staged = false;           // the scene class runs k_vertex -> k_scatter<class> (everything but all-diffuse triangle scenes without textures)
@@ -368,6 +371,8 @@ struct ShadeArgs {
     int blocks;
     int first_bounce = 0;  // 1: bounce 0 of a render whose k_generate left the constants out (beta = 1, p_b = eta_scale = 1, flags = 0, the identity queue): the fused kernel knows them
     int hit_kept = 0;      // 1: the hit records are double-buffered by bounce parity (PathArrays::hit_prev is the previous bounce's): the fused kernel leaves nothing for the next vertex
+    const uint32_t* q_in = nullptr;  // k_vertex: the queue to work through instead of q_active[cur], and its count (the split pass's q_split)
+    const uint32_t* n_in = nullptr;
 };
 WF_INTERNAL int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a);  // the fused kernel: all-diffuse triangle scenes without textures
 WF_INTERNAL int wf_launch_shade_lean_diverted(ShmScene* s, const ShadeArgs& a);

@@ -301,7 +301,7 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
       "textured_floor" the ground plane's reflectance is an image texture (EWA-filtered, repeated): ONE textured material among plain ones
       "environment"    no room and no window: the object on its ground plane under an ImageInfinitelight (light.rs:805-981) — escaped rays look the map up, next-event
                        estimation samples its (compensated) piecewise-constant distribution"""
-    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment", "textured_floor")
+    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment", "textured_floor", "textured_hidden")
     b = SceneBuilder()
     b.set_film(width, height)
     rfw = b.set_camera_look_at(lib, (0.0, 0.6, 4.2), (0.0, 0.0, 0.0), (0, 1, 0), 38.0)
@@ -320,6 +320,10 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
         rfo = np.eye(4, dtype=np.float32)
         rfo[:3, 3] = _to_render(np.array([[0.7, -0.8, 1.7]], np.float32), rfw)[0]  # (in front of the object, to the right: in the camera's view)
         b.add_sphere(0.45, wall, render_from_object=rfo)
+    if variant == "textured_hidden":  # (development: a textured material nobody sees — the textured class's fixed cost)
+        tm = b.material_diffuse(b.add_image_texture(test_image(64, 3), filter="bilinear", wrap="repeat"))
+        p, vi = _quad((-0.1, -50.0, -0.1), (-0.1, -50.0, 0.1), (0.1, -50.0, 0.1), (0.1, -50.0, -0.1))
+        b.add_mesh(_to_render(p, rfw), vi, tm, uv=np.array([(0, 0), (1, 0), (1, 1), (0, 1)], np.float32))
     if variant == "environment":
         p, vi = _quad((-4, -1.25, -4), (-4, -1.25, 6), (4, -1.25, 6), (4, -1.25, -4))
         b.add_mesh(_to_render(p, rfw), vi, wall)

@@ -771,6 +771,32 @@ def test_force_diffuse_parity(env, integrator):
         gpu.close(); orc.close()
 
 
+def test_textured_scenes_split_their_plain_diffuse_hits(env, monkeypatch):
+    """A scene WITH material textures (round 5): the split pass (k_split_plain, render.hip) sends the hits on DiffuseMaterials that bind no texture to the lean fused kernel
+    — their whole vertex, without the textured class's differentials: a diffuse bounce ends them (interaction.rs:430-514) — and everything else to the textured kernels.
+    On by itself where a quarter of the primitives are plain diffuse (S3 with a textured floor); forced on (SHM_TEX_SPLIT=1) and off (0) on the textured Cornell boxes — with
+    and without the coated ceiling, with an environment map shining in as well — and on a random scene: the same bits, equal to the oracle's."""
+    lib, oracle_py, render, scenes = env
+    cases = [(scenes.ganesha_proxy(lib, 64, 64, n=24, variant="textured_floor"), 6, 5), (scenes.cornell_box(lib, 40, 40, textured=True), 4, 6),
+             (scenes.cornell_box(lib, 40, 40, textured=True, textured_coated_ceiling=False, environment=scenes.environment_image(32)), 4, 6),
+             (scenes.random_scene(lib, 13), 4, 5)]
+    for sc, spp, depth in cases:
+        p = render.make_params(seed=17, spp=spp, max_depth=depth)
+        orc = oracle_py.Oracle(sc.desc)
+        fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
+        orc.close()
+        for mode in ("1", "0", None):
+            if mode is None: monkeypatch.delenv("SHM_TEX_SPLIT", raising=False)
+            else: monkeypatch.setenv("SHM_TEX_SPLIT", mode)
+            gpu = render.Renderer(lib, sc.desc, 0)
+            fg, sg = gpu.render(p)
+            gpu.close()
+            assert np.array_equal(fg, fo), (sc.name, mode)
+            for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+                assert sg[k] == so[k], (sc.name, mode, k)
+        monkeypatch.delenv("SHM_TEX_SPLIT", raising=False)
+
+
 def test_environment_map_scenes_run_the_lean_class(env, monkeypatch):
     """A scene without coated materials whose only image is an ImageInfinitelight (light.rs:805-981) shades with the ENV_LIGHT instantiations of the lean fused kernel
     (all-diffuse: k_shade_lean_env.hip, k_shade_lean_gen_env.hip) or of the material-sorted fused kernel (glass, metal: k_shade_tail_sorted_env.hip,
