@@ -254,13 +254,13 @@ static inline bool wf_vertex_sort(const ShmScene* s) {
     do {                                                                                                                                       \
         hipLaunchKernelGGL((k_vertex_w3<TRI, TEX, SORT>), dim3(a.blocks * 3 / 2), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, a.q_in ? a.q_in : s->d_q_active[a.cur], \
                            s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params,               \
-                           (a.params.force_diffuse == 0 && s->lean_divert) ? s->d_q_lean : (uint32_t*)nullptr, s->lds_tables_small, a.n_in);           \
+                           (a.params.force_diffuse == 0 && s->lean_divert && !a.q_in) ? s->d_q_lean : (uint32_t*)nullptr, s->lds_tables_small, a.n_in);           \
         LAUNCH_TRY("k_vertex_w3");                                                                                                             \
     } while (0)
 #define WF_VERTEX_LAUNCH(TRI, TEX, SORT)                                                                                                       \
     do {                                                                                                                                       \
         hipLaunchKernelGGL((k_vertex<TRI, TEX, SORT>), dim3(a.blocks), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, a.q_in ? a.q_in : s->d_q_active[a.cur],          \
                            s->d_q_scatter[0], s->d_q_scatter[1], s->d_q_scatter[2], s->d_q_scatter[3], s->d_qs, a.cur, a.params,               \
-                           (a.params.force_diffuse == 0 && s->lean_divert) ? s->d_q_lean : (uint32_t*)nullptr, s->lds_tables, a.n_in);                                 \
+                           (a.params.force_diffuse == 0 && s->lean_divert && !a.q_in) ? s->d_q_lean : (uint32_t*)nullptr, s->lds_tables, a.n_in);                                 \
         LAUNCH_TRY("k_vertex");                                                                                                                \
     } while (0)

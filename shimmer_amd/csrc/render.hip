@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_split_plain(SceneView sv, Path
             uint32_t path = 0;
             if (i < n) {
                 path = q_cur[i];
-                const int prim = __float_as_int(reinterpret_cast<const float*>(pa.hit + path)[0]);  // (scenes with textures keep the 32-byte hit records)
+                const int prim = __float_as_int(pa.hit16 ? reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + path)[0] : reinterpret_cast<const float*>(pa.hit + path)[0]);
                 plain = prim >= 0 && (sv.materials[sv.prim_recs[prim].material].pad[0] & 1u) != 0u;
                 rest = !plain;
             }
@@ -271,7 +271,7 @@ static uint64_t staging_bytes_per_path(const ShmScene* s) {
     if (f.has_textures) b += 48;                                               // dd0..2
     for (int c = 0; c < N_BXDF_CLASSES; ++c) if (f.has_class[c]) b += 4;       // class queues
     if (s->lean_divert) b += 4;                                                // the lean diversion's queue
-    if (s->tex_split) b += 4;                                                  // the split pass's queue
+    if (s->split_pass) b += 4;                                                  // the split pass's queue
     return b;
 }
 static bool uses_fused_kernel(const ShmScene* s) { return scene_is_lean(s) || s->lean_divert; }  // k_shade<lean>: deferred emitter hits (PathArrays::e_*)
@@ -367,7 +367,7 @@ int ensure_workspace(ShmScene* s, uint64_t needed_paths, bool need_staged) {
         for (int c = 0; c < N_BXDF_CLASSES; ++c)
             if (f.has_class[c] && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_scatter[c])) != SHM_OK) return rc;
         if (s->lean_divert && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_lean)) != SHM_OK) return rc;
-        if (s->tex_split && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_split)) != SHM_OK) return rc;
+        if (s->split_pass && (rc = ws_alloc((size_t)cap * 4, (void**)&s->d_q_split)) != SHM_OK) return rc;
         s->ws_staged = true;
     }
 #undef WS
@@ -579,10 +579,12 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     // the lean diversion (k_vertex.inl): triangle-only scenes without textures that hold plain diffuse materials BESIDE other classes
     if (const char* e = getenv("SHM_ENV_LEAN")) s->env_lean = atoi(e) != 0 ? 1 : 0;
     // scenes with material textures: the split pass (k_split_plain) where a quarter of the primitives or more carry a plain DiffuseMaterial (the textured Cornell box, whose
-    // only plain material is its emitter's, would pay a pass per bounce for a handful of hits; SHM_TEX_SPLIT=0 / 1 overrides)
-    s->tex_split = s->flat.has_material_textures && s->flat.n_plain_diffuse_prims * 4ull >= (uint64_t)s->flat.prim_recs.size() ? 1 : 0;
-    if (const char* e = getenv("SHM_TEX_SPLIT")) s->tex_split = (atoi(e) != 0 && s->flat.has_material_textures && s->flat.n_plain_diffuse_prims > 0) ? 1 : 0;
-    s->lean_divert = ((!s->flat.has_textures || env_plain_scene(s)) && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s)) || s->tex_split;
+    // only plain material is its emitter's, would pay a pass per bounce for a handful of hits; SHM_SPLIT_PASS=0 / 1 overrides)
+    // (in scenes WITHOUT textures k_vertex diverts such hits itself, k_vertex.inl — its triangle instantiation runs three waves per SIMD; the pass as a kernel of its own in front of
+    //  it, forced with SHM_SPLIT_PASS=1, changes nothing there: coated S3 3 258-3 284 Mray/s either way)
+    s->split_pass = (s->flat.has_material_textures && !scene_is_lean(s) && s->flat.n_plain_diffuse_prims * 4ull >= (uint64_t)s->flat.prim_recs.size()) ? 1 : 0;
+    if (const char* e = getenv("SHM_SPLIT_PASS")) s->split_pass = (atoi(e) != 0 && !scene_is_lean(s) && s->flat.n_plain_diffuse_prims > 0) ? 1 : 0;
+    s->lean_divert = ((!s->flat.has_textures || env_plain_scene(s)) && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s)) || s->split_pass;
     if (const char* e = getenv("SHM_LEAN_DIVERT")) s->lean_divert = s->lean_divert && atoi(e) != 0;
     // a shallow tree means short rays, and short rays want fewer, fuller waves (C2's 63-node box: 15.5 -> 15.1 ms per frame at 8 rays per lane); a deep
     // tree means long dependent chains per ray, which want every wave the device has (C4: 8 costs 2 %) — profiles/r03_trace_rays_per_lane_sweep.txt
@@ -810,7 +812,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 // four or five, from bounce `tail_fused_bounce` on. Rounds 3-4, chunks unsorted: only the late bounces paid (C4 frame 522-528 ms staged throughout,
                 // 510-512 from bounce 6, 511-513 from 8). Round 5, chunks counting-sorted by material (k_shade_tail_sorted.hip): the earlier the better — C4 403.2 ms
                 // from bounce 8, 399 from 4, 388 from 2, 378 from 1, 365 from 0: the default (SHM_TAIL_FUSED_BOUNCE, negative = never; read at scene creation)
-                if (staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || env_plain_scene(s) || (s->fused_tex && !s->tex_split && (n_classes_present > 1 || s->fused_tex == 2))) && (tri_only || s->fused_gen)) {
+                if (staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || env_plain_scene(s) || (s->fused_tex && !s->split_pass && (n_classes_present > 1 || s->fused_tex == 2))) && (tri_only || s->fused_gen)) {
                     if (env_plain_scene(s)) rc = tri_only ? wf_launch_shade_tail_sorted_env(s, sa) : wf_launch_shade_fused_gen_env(s, sa);
                     else rc = tri_only ? (s->flat.has_textures ? wf_launch_shade_fused_tex(s, sa) : wf_launch_shade_tail(s, sa))
                                        : (s->flat.has_textures ? wf_launch_shade_fused_gen_tex(s, sa) : wf_launch_shade_fused_gen(s, sa));
@@ -819,14 +821,15 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     // class the scene holds, each over its own material-sorted queue
                     const bool env = env_plain_scene(s) && params->force_diffuse == 0;  // (the K_ENV_LIGHT units: the class without textures + the image light)
                     const bool has_tex = s->flat.has_textures && !env;
-                    const bool split = has_tex && s->tex_split && s->d_q_split && s->d_q_lean && params->force_diffuse == 0;
+                    const bool split = s->split_pass && s->d_q_split && s->d_q_lean && params->force_diffuse == 0;
                     if (split) {  // plain-diffuse hits -> q_lean (their whole vertex in the lean fused kernel, below), the rest -> q_split for the textured kernels
                         hipLaunchKernelGGL(k_split_plain, dim3(s->n_cu * 8), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur], s->d_q_lean, s->d_q_split, s->d_qs, cur);
                         LAUNCH_TRY("k_split_plain");
                         ShadeArgs sv_ = sa;
                         sv_.q_in = s->d_q_split;
                         sv_.n_in = &s->d_qs->n_split;
-                        rc = wf_launch_vertex_tex(s, sv_);
+                        rc = has_tex ? wf_launch_vertex_tex(s, sv_) : (env ? (tri_only ? wf_launch_vertex_tri_env(s, sv_) : wf_launch_vertex_gen_env(s, sv_))
+                                                                           : (tri_only ? wf_launch_vertex_tri(s, sv_) : wf_launch_vertex_gen(s, sv_)));
                     } else
                     rc = has_tex ? wf_launch_vertex_tex(s, sa) : (env ? (tri_only ? wf_launch_vertex_tri_env(s, sa) : wf_launch_vertex_gen_env(s, sa))
                                                                       : (tri_only ? wf_launch_vertex_tri(s, sa) : wf_launch_vertex_gen(s, sa)));

@@ -286,7 +286,7 @@ struct ShmScene {
     uint32_t* d_q_shadow = nullptr;
     uint32_t* d_q_scatter[4] = {nullptr, nullptr, nullptr, nullptr};  // staged shading: one queue per BxDF class present in the scene
     uint32_t* d_q_split = nullptr; // scenes with textures and plain diffuse materials: what the split pass leaves to the textured kernels
-    int tex_split = 0;             // ... that pass is on (SHM_TEX_SPLIT; a quarter of the primitives or more are plain diffuse)
+    int split_pass = 0;            // ... that pass is on (SHM_SPLIT_PASS; a quarter of the primitives or more are plain diffuse)
     uint32_t* d_q_lean = nullptr;  // the lean diversion's queue (triangle-only scenes without textures that hold plain diffuse materials beside others)
     bool lean_divert = false;      // SHM_LEAN_DIVERT=0 switches it off (A/B)
     bool staged = false;           // the scene class runs k_vertex -> k_scatter<class> (everything but all-diffuse triangle scenes without textures)

@@ -774,27 +774,30 @@ def test_force_diffuse_parity(env, integrator):
 def test_textured_scenes_split_their_plain_diffuse_hits(env, monkeypatch):
     """A scene WITH material textures (round 5): the split pass (k_split_plain, render.hip) sends the hits on DiffuseMaterials that bind no texture to the lean fused kernel
     — their whole vertex, without the textured class's differentials: a diffuse bounce ends them (interaction.rs:430-514) — and everything else to the textured kernels.
-    On by itself where a quarter of the primitives are plain diffuse (S3 with a textured floor); forced on (SHM_TEX_SPLIT=1) and off (0) on the textured Cornell boxes — with
+    On by itself where a quarter of the primitives are plain diffuse (S3 with a textured floor); forced on (SHM_SPLIT_PASS=1) and off (0) on the textured Cornell boxes — with
     and without the coated ceiling, with an environment map shining in as well — and on a random scene: the same bits, equal to the oracle's."""
     lib, oracle_py, render, scenes = env
     cases = [(scenes.ganesha_proxy(lib, 64, 64, n=24, variant="textured_floor"), 6, 5), (scenes.cornell_box(lib, 40, 40, textured=True), 4, 6),
              (scenes.cornell_box(lib, 40, 40, textured=True, textured_coated_ceiling=False, environment=scenes.environment_image(32)), 4, 6),
-             (scenes.random_scene(lib, 13), 4, 5)]
+             (scenes.random_scene(lib, 13), 4, 5),
+             # ... and without textures (the same pass in front of k_vertex, which then diverts nothing itself): coated + diffuse, with patches, with glass
+             (scenes.ganesha_proxy(lib, 64, 64, n=24, coated=True), 4, 5), (scenes.cornell_box(lib, 40, 40, coated=True, patches=True), 4, 5),
+             (scenes.cornell_box(lib, 40, 40, coated=True, mix=True, environment=scenes.environment_image(32)), 4, 5)]
     for sc, spp, depth in cases:
         p = render.make_params(seed=17, spp=spp, max_depth=depth)
         orc = oracle_py.Oracle(sc.desc)
         fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
         orc.close()
         for mode in ("1", "0", None):
-            if mode is None: monkeypatch.delenv("SHM_TEX_SPLIT", raising=False)
-            else: monkeypatch.setenv("SHM_TEX_SPLIT", mode)
+            if mode is None: monkeypatch.delenv("SHM_SPLIT_PASS", raising=False)
+            else: monkeypatch.setenv("SHM_SPLIT_PASS", mode)
             gpu = render.Renderer(lib, sc.desc, 0)
             fg, sg = gpu.render(p)
             gpu.close()
             assert np.array_equal(fg, fo), (sc.name, mode)
             for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
                 assert sg[k] == so[k], (sc.name, mode, k)
-        monkeypatch.delenv("SHM_TEX_SPLIT", raising=False)
+        monkeypatch.delenv("SHM_SPLIT_PASS", raising=False)
 
 
 def test_environment_map_scenes_run_the_lean_class(env, monkeypatch):

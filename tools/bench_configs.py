@@ -22,6 +22,7 @@ CONFIGS = [
     ("S3tb ganesha, textured floor (bilinear) 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_floor", floor_filter="bilinear"), 256, 5),
     ("S3tp ganesha, textured floor (point) 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_floor", floor_filter="point"), 256, 5),
     ("S3th ganesha, a textured material out of sight 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_hidden"), 256, 5),
+    ("S3c256 coated ganesha 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, coated=True), 256, 5),
     ("S3ce coated ganesha under an environment map 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, coated=True, variant="environment"), 256, 5),
     ("C4e crown-proxy under an environment map 1000x1400x256 d32", lambda: scenes.crown_proxy(lib, 1000, 1400, environment=scenes.environment_image(64)), 256, 32),
     ("C2t cornell textured 512x512x64", lambda: scenes.cornell_box(lib, 512, 512, textured=True), 64, 6),
