@@ -14,7 +14,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"k_(trace\d?|shade\w*|vertex|scatter\w*|generate|film|expand_tiles|next_bounce|reset_heads3|fold\w*|emit_jobs)", name)
+    m = re.search(r"k_(trace\d?|shade\w*|vertex|scatter\w*|generate|film|expand_tiles|next_bounce|reset_heads3|fold\w*|emit_jobs|split_plain)", name)
     if not m:
         return name[:48]
     k = m.group(0)
