@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
               my_path[k] = 0u;
               if (i < n) {
                   my_path[k] = first_bounce ? i : q_cur[i];  // (bounce 0 on known constants: the identity queue was not written)
-                  const int prim = __float_as_int((TRI_ONLY && pa.hit16) ? reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + my_path[k])[0]
+                  const int prim = __float_as_int(pa.hit16 ? reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + my_path[k])[0]
                                                                         : reinterpret_cast<const float*>(pa.hit + my_path[k])[0]);
                   uint32_t key = (uint32_t)SHADE_SORT_BINS;
                   if (prim >= 0) { const uint32_t m = sv.prim_recs[prim].material; key = m < (uint32_t)SHADE_SORT_BINS ? m : (uint32_t)SHADE_SORT_BINS - 1u; }
@@ -109,13 +109,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
             // first_bounce (wave-uniform; the lean class and, since round 5, every class whose bounce 0 runs this kernel): k_generate left the constants out — the queue is the identity, beta = 1, p_b = eta_scale = 1, flags = 0
             path = SORT_CHUNK ? s_sorted[k * SHADE2_BLOCK + threadIdx.x] : (first_bounce ? i : q_cur[i]);
             Hit hit;
-            if (TRI_ONLY) {
-                hit = load_hit_tri(pa, path);
-            } else {
-                const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
-                float4 h0 = hp[0], h1 = hp[1];
-                hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
-            }
+            hit = load_hit_tri(pa, path);  // (the 32-byte ShmHit, or — triangle scenes, whatever instantiation shades them: a textured triangle scene runs the general ones — the compact form)
             const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
             float4 r0 = rp[0], r1 = rp[1];
             V3 ray_d = v3(r0.w, r1.x, r1.y);
@@ -386,13 +380,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_emit_jobs(SceneView sv, PathAr
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t path = q_emit[i];
         Hit hit;
-        if (TRI_ONLY) {
-            hit = load_hit_tri(pa, path);
-        } else {
-            const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
-            const float4 h0 = hp[0], h1 = hp[1];
-            hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
-        }
+        hit = load_hit_tri(pa, path);
         const float4 er = pa.e_ray[path];
         const V3 ray_d = v3(er.x, er.y, er.z);
         Wavelengths lambda;

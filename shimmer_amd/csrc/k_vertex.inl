@@ -41,7 +41,7 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
       if (threadIdx.x < N_VERTEX_QUEUES) s_cnt[threadIdx.x] = 0;
       if (SORT) {
           auto key_of = [&](uint32_t path) -> uint32_t {
-              const int prim = __float_as_int((TRI_ONLY && pa.hit16) ? reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + path)[0] : reinterpret_cast<const float*>(pa.hit + path)[0]);
+              const int prim = __float_as_int(pa.hit16 ? reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + path)[0] : reinterpret_cast<const float*>(pa.hit + path)[0]);
               if (prim < 0) return (uint32_t)VERTEX_SORT_BINS;
               const uint32_t m = sv.prim_recs[prim].material;
               return m < (uint32_t)VERTEX_SORT_BINS ? m : (uint32_t)VERTEX_SORT_BINS - 1u;
@@ -95,13 +95,7 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
         if (i < n && !diverted_by_key) {
             path = SORT ? s_sorted[k * SHADE2_BLOCK + threadIdx.x] : q_cur[i];
             Hit hit;
-            if (TRI_ONLY) {
-                hit = load_hit_tri(pa, path);
-            } else {
-                const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
-                float4 h0 = hp[0], h1 = hp[1];
-                hit.prim = __float_as_int(h0.x); hit.t = h0.y; hit.b0 = h0.z; hit.b1 = h0.w; hit.b2 = h1.x; hit.phi = h1.y; hit.inst = __float_as_int(h1.z) - 1;
-            }
+            hit = load_hit_tri(pa, path);  // (the 32-byte ShmHit, or — triangle scenes, whatever instantiation shades them: a textured triangle scene runs the general ones — the compact form)
             const float4* rp = reinterpret_cast<const float4*>(pa.ray + path);
             float4 r0 = rp[0], r1 = rp[1];
             V3 ray_d = v3(r0.w, r1.x, r1.y);

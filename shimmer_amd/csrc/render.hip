@@ -740,10 +740,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         const bool lean_first = lean_first_on && (!staged || (first_bounce_candidate(s) && params->force_diffuse == 0)) && !random_walk && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && !s->pa.aux0 && s->pa.rng0;
         // triangle scenes without textures under the path integrator: every kernel that reads the render's hit array is a TRI_ONLY one, and none reads a triangle hit's t —
         // the closest-hit launches write {primitive, b0, b1, b2}, 16 bytes per path instead of the 32-byte ShmHit (SHM_HIT16=0: A/B)
-        // (the kernels of THIS render that read hit records are HAS_TEX ones — compiled for general geometry only, 32-byte records — in a scene with textures, unless its only image
-        //  is an environment map and nothing sends the render through the staged pair)
-        const bool tex_kernels = s->flat.has_textures && !(env_plain_scene(s) && params->force_diffuse == 0);
-        s->pa.hit16 = (!s->flat.has_spheres && !tex_kernels && params->integrator == SHM_INTEGRATOR_PATH && !random_walk &&
+        // (round 5: in scenes with textures too — their kernels, compiled for general geometry, read either record form: load_hit_tri)
+        s->pa.hit16 = (!s->flat.has_spheres && params->integrator == SHM_INTEGRATOR_PATH && !random_walk &&
                        [] { const char* e = getenv("SHM_HIT16"); return !(e && atoi(e) == 0); }()) ? 1u : 0u;
         if (s->pa.aux0)
             hipLaunchKernelGGL(k_generate<true>, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
