@@ -245,14 +245,13 @@ static uint64_t max_batch_paths() {
 // (round 5: whatever the shapes — a scene with spheres / patches / instances runs the kernel's general-geometry instantiation, k_shade_lean_gen.hip)
 // (round 5: ... and an ImageInfinitelight alone does not make a scene "textured": the light's look-up, sample and pdf are compiled into the lean kernels' ENV_LIGHT
 // instantiations (k_shade_lean_env.hip); ray differentials and auxiliary rays only feed texture filtering, and nothing filters a texture there)
-static bool env_only_images(const ShmScene* s) { return s->env_lean && s->flat.has_image_light && !s->flat.has_material_textures; }
+// `env_plain`: the scene's only image is an environment map. No path-integrator render of it reaches a HAS_TEX kernel unless options.force_diffuse asks for that code — and even
+// there the differentials are dead values (no material binds a texture), so the auxiliary-ray arrays are never allocated for it. Every class has its instantiation: the lean
+// kernel's and the sorted fused kernel's ENV_LIGHT ones (all-diffuse; glass, metal), the K_ENV_LIGHT units of the staged kernels (coated materials)
+static bool env_plain_scene(const ShmScene* s) { return s->env_lean && s->flat.has_image_light && !s->flat.has_material_textures; }
+static bool env_lean_scene(const ShmScene* s) { return env_plain_scene(s) && s->flat.diffuse_only; }
 // (the shapes and classes whose every bounce the material-sorted fused all-materials kernel takes: k_shade_tail*.hip, k_shade_fused_*.hip)
 static bool fused_all_from_0(const ShmScene* s) { return !s->flat.has_class[CLASS_LAYERED] && s->tail_fused_bounce == 0 && (!s->flat.has_spheres || s->fused_gen); }
-static bool env_lean_scene(const ShmScene* s) { return env_only_images(s) && s->flat.diffuse_only; }
-// ... and the same for every other class (glass, metal, coated materials under a map): the ENV_LIGHT instantiations of the sorted fused kernel and the K_ENV_LIGHT units of
-// the staged kernels. `env_plain`: no path-integrator render of this scene reaches a HAS_TEX kernel unless options.force_diffuse asks for that code — and even there the
-// differentials are dead values (no material binds a texture), so the auxiliary-ray arrays are never allocated for it
-static bool env_plain_scene(const ShmScene* s) { return env_only_images(s); }
 static bool scene_is_lean(const ShmScene* s) { return s->flat.diffuse_only && (!s->flat.has_textures || env_lean_scene(s)); }
 static bool tex_ws(const ShmScene* s) { return s->flat.has_textures && !env_plain_scene(s); }  // the auxiliary-ray arrays (and k_generate<true>)
 // (round 5) scenes whose every bounce shades with ONE fused kernel that knows bounce 0's constants (ShadeArgs::first_bounce): the lean class, and — without textures or coated
