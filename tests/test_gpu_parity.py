@@ -778,6 +778,7 @@ def test_textured_scenes_split_their_plain_diffuse_hits(env, monkeypatch):
     and without the coated ceiling, with an environment map shining in as well — and on a random scene: the same bits, equal to the oracle's."""
     lib, oracle_py, render, scenes = env
     cases = [(scenes.ganesha_proxy(lib, 64, 64, n=24, variant="textured_floor"), 6, 5), (scenes.cornell_box(lib, 40, 40, textured=True), 4, 6),
+             (scenes.ganesha_proxy(lib, 48, 48, n=16, variant="textured_hidden"), 4, 5),  # (the textured material out of sight: every hit is plain, q_split holds the escaped rays only)
              (scenes.cornell_box(lib, 40, 40, textured=True, textured_coated_ceiling=False, environment=scenes.environment_image(32)), 4, 6),
              (scenes.random_scene(lib, 13), 4, 5),
              # ... and without textures (the same pass in front of k_vertex, which then diverts nothing itself): coated + diffuse, with patches, with glass
