@@ -46,12 +46,12 @@ PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
 VALU_CLOCKS_BEST = 2.4     # v_add / v_mul / v_fma / v_add_u32 / v_mov
 VALU_CLOCKS_COUNTER = 4.0  # what SQ_ACTIVE_INST_VALU charges; v_cndmask (SGPR mask) / v_cmp -> SGPR / v_max3 measure 4.2
 N_SIMD, N_XCD = 256 * 4, 8
-K2_NAME = "k_trace<closest>"  # k_trace5<false> (triangle scenes: the both-children step) or k_trace3<false, *>
+K2_NAME = "k_trace<closest>"  # k_trace5<false, GEN> (the both-children step; GEN: scenes with spheres / patches / instances)
 
 
 def _counters_from_db(db, want):
     """Per-dispatch means of every counter of one kernel in a rocprofv3 rocpd database, and its mean duration there. `want`: "closest" — the
-    closest-hit traversal kernel (k_trace5<false> / k_trace3<false, *>) — or "shade" — the fused shading kernel of the headline scene class."""
+    closest-hit traversal kernel (k_trace5<false, *>) — or "shade" — the fused shading kernel of the headline scene class."""
     import re
     import sqlite3
     cur = sqlite3.connect(db).cursor()

@@ -29,7 +29,7 @@ def short(name):
             if k.startswith("k_trace5"):
                 k += "+gen" if t.group(2) == "true" else ""   # k_trace5<ANY, GEN>
             else:
-                k += "+sph" if t.group(2) == "false" else ""  # k_trace3<ANY, TRI_ONLY>
+                k += "+sph" if t.group(2) == "false" else ""  # (profiles of rounds 1-4: k_trace3<ANY, TRI_ONLY>)
     return k
 
 
