@@ -802,14 +802,18 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 hipEventRecord(s0, s->stream);
                 const ShadeArgs sa{s->stream, cur, *params, sh, shade_blocks, first_lean ? 1 : 0, hit_kept ? 1 : 0};
                 const bool tri_only = !s->flat.has_spheres;
-                int n_classes_present = 0;  // (one BxDF class with textures: nothing to sort, and the textured fused kernel's 128 spilled VGPRs cost more than the staged pair's
-                                            //  parameter block — S3 under an environment map before it had its own kernel: shade 101 ms staged, 107 fused)
+                int n_classes_present = 0;
                 for (int c = 0; c < N_BXDF_CLASSES; ++c) n_classes_present += s->flat.has_class[c] ? 1 : 0;
                 // a triangle scene with several BxDF classes but without textures or coated materials: ONE fused all-materials launch per bounce instead of the staged
                 // four or five, from bounce `tail_fused_bounce` on. Rounds 3-4, chunks unsorted: only the late bounces paid (C4 frame 522-528 ms staged throughout,
                 // 510-512 from bounce 6, 511-513 from 8). Round 5, chunks counting-sorted by material (k_shade_tail_sorted.hip): the earlier the better — C4 403.2 ms
                 // from bounce 8, 399 from 4, 388 from 2, 378 from 1, 365 from 0: the default (SHM_TAIL_FUSED_BOUNCE, negative = never; read at scene creation)
-                if (staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (!s->flat.has_textures || env_plain_scene(s) || (s->fused_tex && !s->split_pass && (n_classes_present > 1 || s->fused_tex == 2))) && (tri_only || s->fused_gen)) {
+                // (with textures: where there is more than one BxDF class to sort — one class: the fused textured kernel's 128 spilled VGPRs cost more than the staged pair's
+                //  parameter block — and no split pass takes most hits away from the textured kernels; an environment map alone is no texture)
+                const bool fused_tex_ok = s->fused_tex && !s->split_pass && (n_classes_present > 1 || s->fused_tex == 2);
+                const bool fused_all = staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (tri_only || s->fused_gen) &&
+                                       (!s->flat.has_textures || env_plain_scene(s) || fused_tex_ok);
+                if (fused_all) {
                     if (env_plain_scene(s)) rc = tri_only ? wf_launch_shade_tail_sorted_env(s, sa) : wf_launch_shade_fused_gen_env(s, sa);
                     else rc = tri_only ? (s->flat.has_textures ? wf_launch_shade_fused_tex(s, sa) : wf_launch_shade_tail(s, sa))
                                        : (s->flat.has_textures ? wf_launch_shade_fused_gen_tex(s, sa) : wf_launch_shade_fused_gen(s, sa));
@@ -819,17 +823,15 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     const bool env = env_plain_scene(s) && params->force_diffuse == 0;  // (the K_ENV_LIGHT units: the class without textures + the image light)
                     const bool has_tex = s->flat.has_textures && !env;
                     const bool split = s->split_pass && s->d_q_split && s->d_q_lean && params->force_diffuse == 0;
-                    if (split) {  // plain-diffuse hits -> q_lean (their whole vertex in the lean fused kernel, below), the rest -> q_split for the textured kernels
+                    ShadeArgs va = sa;  // (k_vertex's arguments: its queue is q_split behind the split pass)
+                    if (split) {  // plain-diffuse hits -> q_lean (their whole vertex in the lean fused kernel, below), the rest -> q_split for k_vertex
                         hipLaunchKernelGGL(k_split_plain, dim3(s->n_cu * 8), dim3(SHADE2_BLOCK), 0, s->stream, s->dsv, s->pa, s->d_q_active[cur], s->d_q_lean, s->d_q_split, s->d_qs, cur);
                         LAUNCH_TRY("k_split_plain");
-                        ShadeArgs sv_ = sa;
-                        sv_.q_in = s->d_q_split;
-                        sv_.n_in = &s->d_qs->n_split;
-                        rc = has_tex ? wf_launch_vertex_tex(s, sv_) : (env ? (tri_only ? wf_launch_vertex_tri_env(s, sv_) : wf_launch_vertex_gen_env(s, sv_))
-                                                                           : (tri_only ? wf_launch_vertex_tri(s, sv_) : wf_launch_vertex_gen(s, sv_)));
-                    } else
-                    rc = has_tex ? wf_launch_vertex_tex(s, sa) : (env ? (tri_only ? wf_launch_vertex_tri_env(s, sa) : wf_launch_vertex_gen_env(s, sa))
-                                                                      : (tri_only ? wf_launch_vertex_tri(s, sa) : wf_launch_vertex_gen(s, sa)));
+                        va.q_in = s->d_q_split;
+                        va.n_in = &s->d_qs->n_split;
+                    }
+                    rc = has_tex ? wf_launch_vertex_tex(s, va) : (env ? (tri_only ? wf_launch_vertex_tri_env(s, va) : wf_launch_vertex_gen_env(s, va))
+                                                                      : (tri_only ? wf_launch_vertex_tri(s, va) : wf_launch_vertex_gen(s, va)));
                     // the hits k_vertex diverted (plain diffuse materials): their whole vertex in the fused kernel — the first member of the group below
                     const bool lean_too = s->lean_divert && s->d_q_lean && params->force_diffuse == 0 && (!has_tex || split);
                     // The classes' scatter kernels are independent of each other (own queue each, disjoint paths, wave-aggregated atomics on the
