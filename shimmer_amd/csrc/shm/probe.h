@@ -16,7 +16,7 @@ enum : int {
     PROBE_TRIANGLE_PDF_WITH_CONTEXT, PROBE_TRIANGLE_INTERACTION, PROBE_SPHERE_SAMPLE_WITH_CONTEXT, PROBE_SPHERE_PDF_WITH_CONTEXT, PROBE_AREA_LIGHT_L, PROBE_FILM_ADD_SAMPLE,
     PROBE_CAMERA_RAY_DIFFERENTIAL, PROBE_INTERVAL_OP, PROBE_DET3, PROBE_ROTATE_FROM_TO, PROBE_SAMPLE_DISCRETE, PROBE_SAMPLER_STREAM, PROBE_SAMPLE_VISIBLE_WAVELENGTHS,
     PROBE_VISIBLE_WAVELENGTHS_PDF, PROBE_VECMATH, PROBE_TRANSFORM_APPLY, PROBE_BLP_INTERSECT, PROBE_BLP_SAMPLE_WITH_CONTEXT, PROBE_BLP_PDF_WITH_CONTEXT, PROBE_SPHERE_INTERSECT,
-    PROBE_UNARY, PROBE_N_OPS
+    PROBE_UNARY, PROBE_EQUAL_AREA_SQUARE_TO_SPHERE, PROBE_EQUAL_AREA_SPHERE_TO_SQUARE, PROBE_N_OPS
 };
 
 namespace probe_detail {
@@ -307,6 +307,10 @@ SHM_HD int leaf_probe(int op, const uint32_t* in, uint32_t* out) {
             put(out, 0, r);
             return 0;
         }
+        // the equal-area octahedral mapping of ImageInfinitelight (math.rs:456-525): the direction of a map texel and back — what the ENV_LIGHT instantiations' look-up, sample
+        // and pdf start from
+        case PROBE_EQUAL_AREA_SQUARE_TO_SPHERE: put3(out, 0, equal_area_square_to_sphere(v2(f(in, 0), f(in, 1)))); return 0;
+        case PROBE_EQUAL_AREA_SPHERE_TO_SQUARE: { const V2 p = equal_area_sphere_to_square(f3(in, 0)); put(out, 0, p.x); put(out, 1, p.y); return 0; }
         default: return -1;
     }
 }

@@ -14,7 +14,7 @@ OPS = ("next_float_up next_float_down gamma difference_of_products dot cross coo
        "tr_sample_wm fresnel_dielectric fresnel_complex bxdf_sample_f bxdf_f_pdf layered_f_pdf layered_sample_f offset_ray_origin triangle_sample_with_context "
        "triangle_pdf_with_context triangle_interaction sphere_sample_with_context sphere_pdf_with_context area_light_l film_add_sample camera_ray_differential interval_op det3 "
        "rotate_from_to sample_discrete sampler_stream sample_visible_wavelengths visible_wavelengths_pdf vecmath transform_apply blp_intersect blp_sample_with_context "
-       "blp_pdf_with_context sphere_intersect unary").split()
+       "blp_pdf_with_context sphere_intersect unary equal_area_square_to_sphere equal_area_sphere_to_square").split()
 OP = {name: i + 1 for i, name in enumerate(OPS)}  # (shm/probe.h: PROBE_* in this order, from 1)
 
 
@@ -73,6 +73,14 @@ class DeviceLeaves:
     def orc_fn_difference_of_products(self, a, b, c, d): return self._scalar("difference_of_products", [_f(a), _f(b), _f(c), _f(d)])
     def orc_fn_dot(self, a, b): return self._scalar("dot", _fl(a, 3) + _fl(b, 3))
     def orc_fn_hypot(self, x, y): return self._scalar("hypot", [_f(x), _f(y)])
+
+    def orc_fn_equal_area_square_to_sphere(self, uv, out3):
+        _, o = self._run("equal_area_square_to_sphere", _fl(uv, 2), 3)
+        out3[:] = list(o.view(np.float32))
+
+    def orc_fn_equal_area_sphere_to_square(self, d, out2):
+        _, o = self._run("equal_area_sphere_to_square", _fl(d, 3), 2)
+        out2[:] = list(o.view(np.float32))
     def orc_fn_round(self, x): return self._scalar("round", [_f(x)])
     def orc_fn_atan2(self, y, x): return self._scalar("atan2", [_f(y), _f(x)])
     def orc_fn_det3(self, m): return self._scalar("det3", _fl(m, 9))

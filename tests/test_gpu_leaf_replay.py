@@ -53,6 +53,13 @@ def test_reference_and_float32_vectors_on_device(dev, gpu_lib, golden_vectors, n
     _call(getattr(TO, name), dev, gpu_lib, golden_vectors)
 
 
+def test_equal_area_mappings_on_device(dev):
+    """ImageInfinitelight's equal-area octahedral mapping (math.rs:456-525) — where the ENV_LIGHT kernels' look-up, sample and pdf start — on the device against the float64
+    restatements of tests/test_image_light.py, the body of that file's CPU test."""
+    import test_image_light as TI
+    TI.test_equal_area_mappings(dev)
+
+
 @pytest.mark.parametrize("name,ref,lo,hi,tol", TO.test_transcendentals.pytestmark[0].args[1])
 def test_transcendentals_on_device(dev, name, ref, lo, hi, tol):
     TO.test_transcendentals(dev, name, ref, lo, hi, tol)
