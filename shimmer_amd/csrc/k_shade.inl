@@ -78,8 +78,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
               my_path[k] = 0u;
               if (i < n) {
                   my_path[k] = first_bounce ? i : q_cur[i];  // (bounce 0 on known constants: the identity queue was not written)
-                  const int prim = __float_as_int(pa.hit16 ? reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + my_path[k])[0]
-                                                                        : reinterpret_cast<const float*>(pa.hit + my_path[k])[0]);
+                  const int prim = pa.hit16 ? hit_prim_of(__float_as_int(reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + my_path[k])[0]))
+                                            : __float_as_int(reinterpret_cast<const float*>(pa.hit + my_path[k])[0]);
                   uint32_t key = (uint32_t)SHADE_SORT_BINS;
                   if (prim >= 0) { const uint32_t m = sv.prim_recs[prim].material; key = m < (uint32_t)SHADE_SORT_BINS ? m : (uint32_t)SHADE_SORT_BINS - 1u; }
                   if (k < 4) my_keys |= key << (8u * k); else my_keys_hi |= key << (8u * (k - 4u));

@@ -98,7 +98,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                                             float4* __restrict__ L, const float4* __restrict__ contrib,
                                             DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
                                             int refill_min, int leaf_min, int queue_parts, int rays_per_lane, int hit16, const uint32_t* __restrict__ big_leaf_n,
-                                            float4* gen_save, int other_min) {
+                                            float4* gen_save, int other_min, float4* __restrict__ hit2) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) u32x2 lds_u2;
     __shared__ u32x2 lds_stack5[(TRACE_BLOCK / WAVE) * LDS_N * WAVE];
@@ -431,7 +431,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                         sgn |= GEN ? (SGN_HIT | SGN_HIT_INSIDE) : SGN_HIT;
                         if (!ANY) {
                             t_max = ti.t;  // aggregate.rs:105-109 shrinks the ray to the hit
-                            if (!GEN && hit16) {
+                            if (hit16) {  // (GEN: the split form — a triangle hit is its 16-byte record; only a sphere / patch hit has a second one, below)
                                 reinterpret_cast<float4*>(hits)[path] = make_float4(__int_as_float((int32_t)slot), ti.b0, ti.b1, ti.b2);
                             } else {
                                 float4* hp = reinterpret_cast<float4*>(hits + path);
@@ -533,9 +533,14 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                                 sgn |= SGN_HIT | SGN_HIT_INSIDE;
                                 if (!ANY) {
                                     t_max = t_hit;
-                                    float4* hp = reinterpret_cast<float4*>(hits + path);
-                                    hp[0] = make_float4(__int_as_float((int32_t)slot), t_hit, h0, h1);
-                                    hp[1] = make_float4(h2, h_phi, 0.0f, 0.0f);
+                                    if (hit16) {  // the split form (scenes without instances): bit 30 of the primitive word says "read the second record" (t, phi)
+                                        reinterpret_cast<float4*>(hits)[path] = make_float4(__int_as_float((int32_t)(slot | HIT_HAS_SECOND)), h0, h1, h2);
+                                        hit2[path] = make_float4(t_hit, h_phi, 0.0f, 0.0f);
+                                    } else {
+                                        float4* hp = reinterpret_cast<float4*>(hits + path);
+                                        hp[0] = make_float4(__int_as_float((int32_t)slot), t_hit, h0, h1);
+                                        hp[1] = make_float4(h2, h_phi, 0.0f, 0.0f);
+                                    }
                                 }
                             }
                             leaf_n -= 1u;
@@ -618,7 +623,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                     }
                 }
             } else if (!found) {
-                if (!GEN && hit16) {
+                if (hit16) {
                     reinterpret_cast<float4*>(hits)[path] = make_float4(__int_as_float(-1), 0.0f, 0.0f, 0.0f);
                 } else {
                     float4* hp = reinterpret_cast<float4*>(hits + path);  // a miss is all zeros behind prim = -1
@@ -663,8 +668,8 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
 #define K5_LDS_AT_8 9
 #endif
 template <int WAVES> struct K5Shape { static constexpr int LDS = (WAVES >= 8 ? K5_LDS_AT_8 : (WAVES == 7 ? 11 : (WAVES == 6 ? 13 : 15))), PER_CU = WAVES; };
-#define K5_PARAMS K3_PARAMS, const uint32_t* __restrict__ big_leaf_n, float4* gen_save, int other_min
-#define K5_ARGS K3_ARGS, big_leaf_n, gen_save, other_min
+#define K5_PARAMS K3_PARAMS, const uint32_t* __restrict__ big_leaf_n, float4* gen_save, int other_min, float4* hit2
+#define K5_ARGS K3_ARGS, big_leaf_n, gen_save, other_min, hit2
 template <bool ANY, bool GEN = false>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace5(K5_PARAMS);
 template <>
@@ -1113,10 +1118,12 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
     hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, stream, heads);
     const int leaf_min = any ? s->leaf_min_any : s->leaf_min;
     const bool tri_only = !s->flat.has_spheres && !trace_force_gen();
+    // hit16 with the GEN kernels: the split record form (wavefront.h, load_hit_tri) — the second records follow the `capacity` first ones in the hit allocation
+    float4* const hit2 = (hit16 && !tri_only && hits) ? reinterpret_cast<float4*>(hits) + s->capacity : nullptr;
 #define TRACE5_LAUNCH(ANY, GEN)                                                                                                               \
     hipLaunchKernelGGL((k_trace5<ANY, GEN>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,  \
                        hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n, \
-                       s->d_gen_save[ANY ? 1 : 0], (ANY ? s->other_min_any : s->other_min))
+                       s->d_gen_save[ANY ? 1 : 0], (ANY ? s->other_min_any : s->other_min), hit2)
 #ifdef K6_EXPERIMENT
 #define TRACE6_LAUNCH(ANY)                                                                                                                    \
     hipLaunchKernelGGL((k_trace6<ANY>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,   \

@@ -41,7 +41,7 @@ __device__ __forceinline__ void vertex_body(const SceneView& sv, const PathArray
       if (threadIdx.x < N_VERTEX_QUEUES) s_cnt[threadIdx.x] = 0;
       if (SORT) {
           auto key_of = [&](uint32_t path) -> uint32_t {
-              const int prim = __float_as_int(pa.hit16 ? reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + path)[0] : reinterpret_cast<const float*>(pa.hit + path)[0]);
+              const int prim = pa.hit16 ? hit_prim_of(__float_as_int(reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + path)[0])) : __float_as_int(reinterpret_cast<const float*>(pa.hit + path)[0]);
               if (prim < 0) return (uint32_t)VERTEX_SORT_BINS;
               const uint32_t m = sv.prim_recs[prim].material;
               return m < (uint32_t)VERTEX_SORT_BINS ? m : (uint32_t)VERTEX_SORT_BINS - 1u;

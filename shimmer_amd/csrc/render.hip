@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) k_split_plain(SceneView sv, Path
             uint32_t path = 0;
             if (i < n) {
                 path = q_cur[i];
-                const int prim = __float_as_int(pa.hit16 ? reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + path)[0] : reinterpret_cast<const float*>(pa.hit + path)[0]);
+                const int prim = pa.hit16 ? hit_prim_of(__float_as_int(reinterpret_cast<const float*>(reinterpret_cast<const float4*>(pa.hit) + path)[0])) : __float_as_int(reinterpret_cast<const float*>(pa.hit + path)[0]);
                 plain = prim >= 0 && (sv.materials[sv.prim_recs[prim].material].pad[0] & 1u) != 0u;
                 rest = !plain;
             }
@@ -740,8 +740,11 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         // triangle scenes without textures under the path integrator: every kernel that reads the render's hit array is a TRI_ONLY one, and none reads a triangle hit's t —
         // the closest-hit launches write {primitive, b0, b1, b2}, 16 bytes per path instead of the 32-byte ShmHit (SHM_HIT16=0: A/B)
         // (round 5: in scenes with textures too — their kernels, compiled for general geometry, read either record form: load_hit_tri)
-        s->pa.hit16 = (!s->flat.has_spheres && params->integrator == SHM_INTEGRATOR_PATH && !random_walk &&
+        // (... and — the split form — in scenes with spheres / bilinear patches: a triangle hit is its 16-byte record, a sphere / patch hit flags a second one with t and phi
+        //  (HIT_HAS_SECOND, wavefront.h). Not with instances: a hit inside one names it in the 32-byte record, patched when the instance's marker is popped)
+        s->pa.hit16 = ((!s->flat.has_spheres || !s->flat.has_instances) && params->integrator == SHM_INTEGRATOR_PATH && !random_walk &&
                        [] { const char* e = getenv("SHM_HIT16"); return !(e && atoi(e) == 0); }()) ? 1u : 0u;
+        s->pa.hit2 = (s->pa.hit16 && s->flat.has_spheres) ? reinterpret_cast<const float4*>(s->pa.hit) + s->capacity : nullptr;
         if (s->pa.aux0)
             hipLaunchKernelGGL(k_generate<true>, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
                                sample_begin, n_samples, *params, s->d_q_active[0], s->d_qs, s->pix_group);
@@ -774,8 +777,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         ShmHit* const hit_base = s->pa.hit;
         // (s->pa is the scene's one PathArrays: the per-bounce overrides — hit, hit_prev — and the per-render record form, hit16, are taken back when the batch is through,
         //  so that whoever reads s->pa.hit outside a render — the public trace entry points, dist.hip — finds the allocation's base and 32-byte records)
-        struct HitRestore { ShmScene* sc; ShmHit* base; ~HitRestore() { sc->pa.hit = base; sc->pa.hit_prev = nullptr; sc->pa.hit16 = 0u; } } hit_restore{s, hit_base};
-        const bool hit_kept = s->pa.hit16 && scene_is_lean(s) && !staged && !random_walk;
+        struct HitRestore { ShmScene* sc; ShmHit* base; ~HitRestore() { sc->pa.hit = base; sc->pa.hit_prev = nullptr; sc->pa.hit16 = 0u; sc->pa.hit2 = nullptr; } } hit_restore{s, hit_base};
+        const bool hit_kept = s->pa.hit16 && !s->flat.has_spheres && scene_is_lean(s) && !staged && !random_walk;  // (the split form keeps its second records in the other half)
         for (int bounce = 0; bounce <= params->max_depth; ++bounce) {
             if (hit_kept) {
                 float4* const h16 = reinterpret_cast<float4*>(hit_base);

@@ -55,6 +55,7 @@ constexpr int SHADE_BLOCK = 128;
 //   leaf      1 << 31 | min(n_prims, 7) << 27 | offset of its first primitive record (a count of 7 means: read ShmScene::d_big_leaf_n[offset], the primitives left from that slot on);
 //             bit 30 is 0 in the array and set by a traversing lane (k_trace5<., GEN>): "the record at this slot is no triangle, its test is pending"
 // `n_prims` and `axis` stay where they were (no kernel reads them since the one-node-step kernels were retired: the link word holds everything).
+constexpr uint32_t HIT_HAS_SECOND = 0x40000000u;  // the compact hit records' primitive word, split form (scenes with spheres / patches, no instances): this hit has a second record
 constexpr uint32_t LINK_LEAF = 0x80000000u, LINK_OTHER = 0x40000000u, LINK_INDEX_MASK = 0x07ffffffu, LINK_COUNT_SHIFT = 27u, LINK_COUNT_MAX = 7u, LINK_AXIS_SHIFT = 29u;
 
 struct DeviceCounters {
@@ -129,6 +130,7 @@ struct PathArrays {
     BxRec* bx;              // 128 B: the parameter block as ONE record per path (above)
     uint32_t has_layered;   // the scene holds coated materials: k_vertex writes the record's third sector (bx3, bx4)
     // scenes with image textures only: what Igehy's specular differentials need beside the auxiliary rays (interaction.rs:430-514)
+    const float4* hit2;     // hit16 in a scene with spheres / patches: the second records (t, phi) of the hits that have one (HIT_HAS_SECOND), behind the first ones in the hit allocation
     float4* dd0;            // dpdx.xyz, dpdy.x
     float4* dd1;            // dpdy.yz, dndx.xy
     float4* dd2;            // dndx.z, dndy.xyz
@@ -224,12 +226,19 @@ __device__ __forceinline__ SceneView stage_scene_tables_tex(const SceneView& sv,
     return out;
 }
 
+// the primitive of a compact hit record's first word (a miss stays negative)
+__device__ __forceinline__ int hit_prim_of(int w) { return w < 0 ? w : (int)((uint32_t)w & ~HIT_HAS_SECOND); }
 // a path's hit record as the TRI_ONLY shading kernels read it: the 32-byte ShmHit, or the compact form the render's own traversal launches write (PathArrays::hit16)
 __device__ __forceinline__ Hit load_hit_tri(const PathArrays& pa, uint32_t path) {
     Hit hit;
     if (pa.hit16) {
         const float4 h = reinterpret_cast<const float4*>(pa.hit)[path];
-        hit.prim = __float_as_int(h.x); hit.t = 0.0f; hit.b0 = h.y; hit.b1 = h.z; hit.b2 = h.w; hit.phi = 0.0f; hit.inst = -1;
+        const int w = __float_as_int(h.x);
+        hit.prim = hit_prim_of(w); hit.t = 0.0f; hit.b0 = h.y; hit.b1 = h.z; hit.b2 = h.w; hit.phi = 0.0f; hit.inst = -1;
+        if (w >= 0 && ((uint32_t)w & HIT_HAS_SECOND)) {  // (the split form: a sphere / patch hit's t and phi — p_obj / (u, v) ride in b0..b2)
+            const float4 h2 = pa.hit2[path];
+            hit.t = h2.x; hit.phi = h2.y;
+        }
     } else {
         const float4* hp = reinterpret_cast<const float4*>(pa.hit + path);
         const float4 h0 = hp[0], h1 = hp[1];
