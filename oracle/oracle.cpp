@@ -43,6 +43,7 @@
 #include <thread>
 #include <vector>
 
+#define SHM_ORACLE_REFERENCE_STREAM 1  // shm/sampling.h: a sampler may carry the reference's own SmallRng stream (orc_render_reference_stream, below)
 #include "../shimmer_amd/csrc/host/flatten.h"
 #include "../shimmer_amd/csrc/shm/path.h"
 
@@ -573,6 +574,73 @@ int orc_render(OrcScene* s, const ShmRenderParams* params, const ShmTile* tiles,
     }
     return SHM_OK;
 }
+
+// ImageTileIntegrator::render as `RAYON_NUM_THREADS=1 shimmer scene.pbrt --seed S` draws it (ORACLE ONLY — the product keeps the defined per-pixel stream: a sequential
+// stream cannot be replayed by 268 M paths in flight). With one rayon worker the thread-local sampler of integrator.rs:252-253 is ONE clone of the prototype
+// (IndependentSampler::new: SmallRng::seed_from_u64(seed), sampler.rs:103-109) that lives across tiles AND across the spp-waves (sampler_tl is made outside the wave loop,
+// integrator.rs:238), start_pixel_sample is a no-op (sampler.rs:117-121), and the tiles come in index order (par_iter's halves are joined left first on one worker):
+// one Xoshiro256++ stream consumed by waves -> tiles -> x (OUTER, integrator.rs:257) -> y -> sample, every dimension in evaluate_pixel_sample's / li's call order.
+// Valid for scenes without LayeredBxDF / MixMaterial (those draw from SmallRng::from_entropy(), integrator.rs:255, bxdf.rs:1011: not reproducible by anybody).
+// UNVERIFIED HERE: no Rust toolchain in this image — the generator is checked against the published xoshiro256++ / SplitMix64 vectors and the mode for determinism
+// (tests/test_reference_stream.py); INTEGRATION.md holds the recipe for a maintainer with cargo.
+int orc_render_reference_stream(OrcScene* s, const ShmRenderParams* params, const ShmTile* tiles, uint32_t n_tiles, ShmFilmPixel* film, ShmStats* stats, uint64_t* draws_out) {
+    Oracle* o = reinterpret_cast<Oracle*>(s);
+    if (!params || !tiles || !film) { g_err = "invalid render arguments"; return SHM_ERR_INVALID_ARGUMENT; }
+    if (params->integrator != SHM_INTEGRATOR_PATH && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && params->integrator != SHM_INTEGRATOR_RANDOM_WALK) return SHM_ERR_INVALID_ARGUMENT;
+    bool entropy = o->flat.has_class[3];  // (class 3: the coated materials)
+    for (const ShmMaterial& m : o->flat.materials) entropy = entropy || m.kind == SHM_MATERIAL_MIX;
+    if (entropy) { g_err = "reference stream: the scene holds a LayeredBxDF or a MixMaterial (the reference seeds those from OS entropy)"; return SHM_ERR_UNSUPPORTED; }
+    SceneView sv = o->sv;
+    sv.quirks_off = params->disable_reference_quirks ? 1u : 0u;
+    const int width = sv.pixel_bounds[2] - sv.pixel_bounds[0];
+    const TexParams tp{o->flat.has_textures, params->samples_per_pixel, params->disable_pixel_jitter != 0, params->force_diffuse != 0, params->disable_texture_filtering != 0};
+    if (stats) memset(stats, 0, sizeof(*stats));
+    RefStream stream = ref_stream_seed_from_u64(params->seed);
+    const RefStream first = stream;
+    uint64_t draws = 0;
+    Counters c;
+    const int spp = params->samples_per_pixel;
+    int wave_start = 0, wave_end = 1, next_wave_size = 1;
+    while (wave_start < spp) {
+        for (uint32_t ti = 0; ti < n_tiles; ++ti) {
+            const ShmTile& tile = tiles[ti];
+            for (int x = tile.x0; x < tile.x1; ++x)
+                for (int y = tile.y0; y < tile.y1; ++y)
+                    for (int si = wave_start; si < wave_end; ++si) {
+                        Rng rng{0u, 1u, &stream};
+                        Wavelengths lambda;
+                        Float weight;
+                        AuxRays aux = aux_none();
+                        Ray ray = generate_camera_ray(sv, x, y, rng, params->disable_wavelength_jitter != 0, params->disable_pixel_jitter != 0, lambda, weight, tp.on ? &aux : nullptr, params->samples_per_pixel);
+                        Spec L = spec_const(1.0f) * ((params->integrator == SHM_INTEGRATOR_RANDOM_WALK) ? li_random_walk(sv, ray, aux, tp, lambda, rng, 0, params->max_depth, c)
+                                                     : (params->integrator == SHM_INTEGRATOR_SIMPLE_PATH) ? li_simple_path(sv, ray, aux, tp, lambda, rng, params->max_depth, params->sample_lights != 0, params->sample_bsdf != 0, c)
+                                                     : li(sv, ray, aux, tp, lambda, rng, params->max_depth, params->regularize != 0, c));
+                        c.paths++;
+                        if (sv.quirks_off && !spec_is_finite(L)) L = spec_const(0.0f);
+                        V3 rgb = film_sample_rgb(sv, L, lambda);
+                        ShmFilmPixel& px = film[(size_t)(y - sv.pixel_bounds[1]) * width + (x - sv.pixel_bounds[0])];
+                        px.rgb_sum[0] += (double)(weight * rgb.x);
+                        px.rgb_sum[1] += (double)(weight * rgb.y);
+                        px.rgb_sum[2] += (double)(weight * rgb.z);
+                        px.weight_sum += (double)weight;
+                    }
+        }
+        wave_start = wave_end;
+        wave_end = std::min(spp, wave_end + next_wave_size);
+        next_wave_size = std::min(2 * next_wave_size, 64);
+    }
+    if (draws_out) {  // how far the stream went: replayed from the seed until the state recurs (the period is 2^256 - 1: the first match is the end of this render)
+        RefStream r = first;
+        while (memcmp(&r, &stream, sizeof(r)) != 0) { ref_stream_next_u64(r); ++draws; }
+        *draws_out = draws;
+    }
+    if (stats) { stats->paths = c.paths; stats->rays_closest = c.rays_closest; stats->rays_any = c.rays_any; stats->nodes_closest = c.nodes_closest; stats->tris_closest = c.tris_closest; stats->nodes_any = c.nodes_any; stats->tris_any = c.tris_any; }
+    return SHM_OK;
+}
+// the generator alone (tests/test_reference_stream.py: published vectors)
+void orc_fn_xoshiro256pp(const uint64_t* state4, int n, uint64_t* out) { RefStream r; memcpy(r.s, state4, sizeof(r.s)); for (int i = 0; i < n; ++i) out[i] = ref_stream_next_u64(r); }
+void orc_fn_splitmix64(uint64_t seed, int n, uint64_t* out) { for (int i = 0; i < n; ++i) out[i] = ref_splitmix64_next(seed); }
+void orc_fn_reference_stream_f32(uint64_t seed, int n, float* out, uint64_t* state4_out) { RefStream r = ref_stream_seed_from_u64(seed); if (state4_out) memcpy(state4_out, r.s, sizeof(r.s)); for (int i = 0; i < n; ++i) out[i] = ref_stream_next_f32(r); }
 
 // ---- unit-function entry points for the golden-vector tests (tests/test_oracle_golden.py) ----
 float orc_fn_next_float_up(float v) { return next_float_up(v); }

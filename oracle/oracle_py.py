@@ -124,6 +124,11 @@ def load():
     lib.orc_fn_film_sample_rgb.restype, lib.orc_fn_film_sample_rgb.argtypes = None, [C.c_void_p, FP, FP, FP, FP]
     lib.orc_fn_spectrum_get.restype, lib.orc_fn_spectrum_get.argtypes = F, [C.c_void_p, C.POINTER(abi.ShmSpectrum), F]
     lib.orc_fn_spectrum_sample.restype, lib.orc_fn_spectrum_sample.argtypes = None, [C.c_void_p, C.POINTER(abi.ShmSpectrum), FP, FP]
+    lib.orc_render_reference_stream.argtypes = [C.c_void_p, C.POINTER(abi.ShmRenderParams), C.POINTER(abi.ShmTile), C.c_uint32, C.c_void_p, C.POINTER(abi.ShmStats),
+                                                C.POINTER(C.c_uint64)]
+    lib.orc_fn_xoshiro256pp.restype, lib.orc_fn_xoshiro256pp.argtypes = None, [C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
+    lib.orc_fn_splitmix64.restype, lib.orc_fn_splitmix64.argtypes = None, [C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    lib.orc_fn_reference_stream_f32.restype, lib.orc_fn_reference_stream_f32.argtypes = None, [C.c_uint64, C.c_int, FP, C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
 
@@ -168,6 +173,19 @@ class Oracle:
             if rc != 0:
                 raise RuntimeError(f"orc_render_wave failed ({rc}): {self.lib.orc_last_error().decode()}")
         return film, stats.as_dict()
+
+    def render_reference_stream(self, params, tiles=None, n_tiles=None):
+        """ImageTileIntegrator::render on the reference's OWN sampler stream, as `RAYON_NUM_THREADS=1 shimmer scene.pbrt --seed S` draws it (oracle.cpp,
+        orc_render_reference_stream; scenes without LayeredBxDF / MixMaterial). Returns (film, stats, number of u64 draws)."""
+        if tiles is None:
+            from shimmer_amd import abi as _abi
+            tiles, n_tiles = self.tiles(_abi.load_library())
+        film = np.zeros((self.height, self.width), dtype=FILM_DTYPE)
+        stats, draws = abi.ShmStats(), C.c_uint64()
+        rc = self.lib.orc_render_reference_stream(self.handle, C.byref(params), tiles, n_tiles, film.ctypes.data_as(C.c_void_p), C.byref(stats), C.byref(draws))
+        if rc != 0:
+            raise RuntimeError(f"orc_render_reference_stream failed ({rc}): {self.lib.orc_last_error().decode()}")
+        return film, stats.as_dict(), draws.value
 
     def trace(self, rays, any_hit=False):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)

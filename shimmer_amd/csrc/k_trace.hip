@@ -74,7 +74,7 @@ __device__ unsigned long long g_census[32];
 #else
 #define CENSUS(i, v) do { } while (0)
 #endif
-enum : uint32_t { CUR_IDLE = 0x7fffffffu, CUR_POP = 0x7ffffffeu, CUR_DONE = 0x7ffffffdu, CUR_FIRST_SPECIAL = 0x60000000u,
+enum : uint32_t { CUR_IDLE = 0x7fffffffu, CUR_POP = 0x7ffffffeu, CUR_DONE = 0x7ffffffdu, CUR_WAIT = 0x7ffffffcu /* FAST: stack exhausted, a deferred leaf still untested */, CUR_FIRST_SPECIAL = 0x60000000u,
                   CUR_MARKER = 0x60000000u };  // (GEN: CUR_MARKER | leaf slot of the instance — the stack entry that leads back out of it; never a lane's `cur`: slots are below 2^27)
 constexpr uint32_t SGN_RAY = 15u, SGN_HIT = 16u, SGN_HIT_INSIDE = 32u, SGN_INST_SHIFT = 6u;  // trace5_body's `sgn` word (see there)
 
@@ -91,7 +91,7 @@ constexpr uint32_t SGN_RAY = 15u, SGN_HIT = 16u, SGN_HIT_INSIDE = 32u, SGN_INST_
 // behind it, so that nothing but path, t_max, stack pointer and link word is live across ~1 000 instructions of interval arithmetic (inlined with the state live, they made
 // the loop itself spill; as real calls, the calling convention's caller-saved registers did the same). An instance's entry saves the OUTER ray state the same way: leaving is
 // three loads, not a second ray set-up. The hit record is the ABI's 32-byte ShmHit (t, phi and the instance ride along).
-template <bool ANY, bool GEN, int LDS_N>
+template <bool ANY, bool GEN, int LDS_N, bool FAST = false>
 __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
                                             uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
                                             ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
@@ -99,15 +99,18 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                                             DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
                                             int refill_min, int leaf_min, int queue_parts, int rays_per_lane, int hit16, const uint32_t* __restrict__ big_leaf_n,
                                             float4* gen_save, int other_min, float4* __restrict__ hit2) {
+    static_assert(!FAST || (ANY && !GEN), "FAST: the order-free occlusion kernel of triangle scenes");
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    typedef __attribute__((address_space(3))) u32x2 lds_u2;
-    __shared__ u32x2 lds_stack5[(TRACE_BLOCK / WAVE) * LDS_N * WAVE];
+    // a stack entry: {link word, t0 | phantom count}; FAST (no phantom accounting, t_max fixed): the link word alone
+    typedef typename std::conditional<FAST, uint32_t, u32x2>::type entry_t;
+    typedef __attribute__((address_space(3))) entry_t lds_u2;
+    __shared__ entry_t lds_stack5[(TRACE_BLOCK / WAVE) * LDS_N * WAVE];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave_in_block = threadIdx.x / WAVE;
     // the per-lane stack of {link word, t0 | phantom count} entries: levels [0, LDS_N) in LDS as [level][lane], deeper ones in the per-lane HBM spill
     lds_u2* const st_base = (lds_u2*)lds_stack5 + wave_in_block * LDS_N * WAVE + lane;
     lds_u2* top = st_base;
-    u32x2* const st_spill_wave = reinterpret_cast<u32x2*>(spill) + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE;
+    entry_t* const st_spill_wave = reinterpret_cast<entry_t*>(spill) + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE;
     // GEN: this wave's two save areas of 3 float4 per lane, [area][k][lane] (area 0: the outer ray's state while an instance is traversed; area 1: around a quadric / patch test)
     float4* const save_wave = GEN ? gen_save + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)(6 * WAVE) : nullptr;
     const uint32_t n = n_ptr ? *n_ptr : n_direct;
@@ -163,6 +166,11 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
     Float t_max = 0.0f;
     uint32_t cur = CUR_IDLE;
+    // FAST (the order-free occlusion kernel): the leaf a lane has reached and not yet tested — its link word (bit 31 set), 0 = none. intersect_predicate's verdict does not
+    // depend on the order the primitives are tested in (aggregate.rs:141-203: every test against the same t_max, `true` at the first hit), so a lane that reaches a leaf
+    // keeps it here and TRAVERSES ON; the wave's triangle tests run when `leaf_min` lanes hold one (or nothing else can run), several times denser than when every such lane
+    // has to wait (k_trace5<any>'s leaf phases run with 9.8 of 64 lanes on the headline frame, 42 % of them with 8 or fewer: profiles/r05_census_sparse_rounds.txt)
+    uint32_t def = 0u;
 
     // aggregate.rs:76-81 + the ray-constant part of the triangle test (the upper bits of sgn — what has been found so far, the instance — belong to the path, not to the ray)
     auto set_ray = [&](V3 o, V3 d) {
@@ -268,10 +276,14 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         t0_out = t0;
         return ok && (t1 > 0.0f);
     };
+    auto make_entry = [](uint32_t link, uint32_t word1) -> entry_t {
+        if constexpr (FAST) return link;
+        else return u32x2{link, word1};
+    };
     auto push = [&](uint32_t link, uint32_t word1) {
         // two different store flavours, so that the compiler cannot merge them into one flat_store of a selected pointer
-        if (top < st_base + LDS_N * WAVE) *top = u32x2{link, word1};
-        else st_spill_wave[(size_t)(top - (st_base + LDS_N * WAVE)) + lane] = u32x2{link, word1};
+        if (top < st_base + LDS_N * WAVE) *top = make_entry(link, word1);
+        else st_spill_wave[(size_t)(top - (st_base + LDS_N * WAVE)) + lane] = make_entry(link, word1);
         top += WAVE;
     };
 
@@ -341,15 +353,15 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                             set_ray(v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y));
                             t_max = r1.z;
                             top = st_base;
-                            if (ANY) ph_top = 0u;
+                            if (ANY && !FAST) ph_top = 0u;
                             // the root: tested where the ray is taken from the queue
                             cur = root_test(root_a, root_b) ? __float_as_uint(root_b.z) : (uint32_t)CUR_POP;  // (a miss pops the empty stack: done, retired below)
-                            if (ANY) c_nodes += 1u;
+                            if (ANY && !FAST) c_nodes += 1u;
                         }
                     }
                     w_next += take;
                     w_rays += take;
-                    if (!ANY) w_nodes += take;
+                    if (!ANY || FAST) w_nodes += take;
                     if (K5_QUEUE_PREFETCH && queue) {  // the next refill's entries (it takes at most 64): in flight behind this refill's ray records, consumed ~30 iterations on
                         q_pre_base = w_next;
                         const uint32_t qj = w_next + lane;
@@ -372,7 +384,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         }
         // ---- one uniform step: every lane that stands on an interior node fetches the block of its two children and tests both (aggregate.rs:92-135) ----
         const bool at_node = cur < (uint32_t)CUR_FIRST_SPECIAL;
-        if (!ANY) w_nodes += 2ull * (unsigned long long)__popcll(__ballot(at_node));
+        if (!ANY || FAST) w_nodes += 2ull * (unsigned long long)__popcll(__ballot(at_node));
         CENSUS(0, 1); CENSUS(1, __popcll(__ballot(at_node))); CENSUS(2, __popcll(__ballot((cur & 0xC0000000u) == 0x80000000u))); CENSUS(21, __popcll(__ballot(cur >= 0xC0000000u))); CENSUS(3, __popcll(__ballot(cur == CUR_IDLE)));
         CENSUS(4, __popcll(__ballot(cur == CUR_POP))); CENSUS(10, __ballot(at_node) != 0ull ? 1 : 0);
         CENSUS(22, (__ballot(at_node) != 0ull && __popcll(__ballot(at_node)) <= 8) ? 1 : 0);  // (a VALU instruction with 8 or fewer lanes on costs 4.5 x one with 9: profiles/r05_valu_exec.txt)
@@ -387,7 +399,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
             const bool pre_n = slab(na, nb, t0n), pre_f = slab(fa, fb, t0f);
             const bool hit_n = pre_n && (t0n < t_max), hit_f = pre_f && (t0f < t_max);
             const uint32_t link_n = __float_as_uint(nb.z), link_f = __float_as_uint(fb.z);
-            if (ANY) {
+            if (FAST) {
+                if (hit_n && hit_f) push(link_f, 0u);  // (both boxes tested, both visits counted at the step: what this kernel really does — no phantom accounting)
+            } else if (ANY) {
                 // t_max is fixed: the far child's verdict is final now. Visits: the near child now; the far child now if the traversal turns to it at
                 // once (the near child missed: the reference's very next pop), at its pop if it is pushed, and as a phantom otherwise
                 c_nodes += hit_n ? 1u : 2u;
@@ -402,7 +416,43 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         constexpr uint32_t NOT_A_TRIANGLE = PRIM_SPHERE_BIT | PRIM_PATCH_BIT | PRIM_INSTANCE_BIT;
         constexpr uint32_t LEAF_KIND = LINK_LEAF | LINK_OTHER;  // (GEN: a leaf link with bit 30 set is a parked non-triangle test, below)
         constexpr uint32_t LINK_LEAVE = LEAF_KIND | LINK_INDEX_MASK;  // (... and this one — no slot — a lane parked on its way back out of an instance)
-        const unsigned long long leaf_mask = GEN ? __ballot((cur & LEAF_KIND) == LINK_LEAF) : __ballot((int32_t)cur < 0);
+        if constexpr (FAST) {
+            // ---- FAST: deferred leaves. A lane that stands on a leaf with its slot free keeps the leaf and pops on (below, in this iteration); one whose slot is taken waits ----
+#ifndef K5_FAST_DEFER
+#define K5_FAST_DEFER 1  // (0: a lane that reaches a leaf waits on it, as in the reference-order kernel — what is left is "no phantom accounting, 4-byte stack entries": A/B)
+#endif
+            if (K5_FAST_DEFER) { if ((int32_t)cur < 0 && def == 0u) { def = cur; cur = (uint32_t)CUR_POP; } }
+            else if ((int32_t)cur < 0) { def = cur; cur = (uint32_t)CUR_WAIT; }  // (no deferral: the lane stands still until its leaf has been tested, then pops)
+            const unsigned long long def_mask = __ballot(def != 0u);
+            if (def_mask != 0ull) {
+                const unsigned long long busy = __ballot(cur < (uint32_t)CUR_FIRST_SPECIAL || cur == (uint32_t)CUR_POP);
+                if (__popcll(def_mask) >= leaf_min || busy == 0ull) {
+                    w_prims += (unsigned long long)__popcll(def_mask);
+                    CENSUS(5, 1); CENSUS(6, 1); CENSUS(7, __popcll(def_mask)); CENSUS(23, __popcll(def_mask) <= 8 ? 1 : 0);
+                    if (def != 0u) {
+                        const uint32_t slot = def & LINK_INDEX_MASK;
+                        uint32_t leaf_n = (def >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX;
+                        if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[slot];
+                        const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * sizeof(PrimRec));
+                        const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+                        TriangleIntersection ti;
+                        bool got = intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
+                        got = got && !(__float_as_uint(q2.y) & PRIM_DEGENERATE_BIT);
+                        leaf_n -= 1u;
+                        if (got) { sgn |= SGN_HIT; cur = (uint32_t)CUR_DONE; def = 0u; }  // occluded: whatever is left on the stack is never looked at (aggregate.rs:160-166)
+                        else {
+                            def = leaf_n == 0u ? 0u : (LINK_LEAF | ((leaf_n < LINK_COUNT_MAX ? leaf_n : LINK_COUNT_MAX) << LINK_COUNT_SHIFT) | (slot + 1u));
+                            if (def == 0u) {
+                                if (!K5_FAST_DEFER) cur = (uint32_t)CUR_POP;
+                                else if (cur == (uint32_t)CUR_WAIT) cur = (uint32_t)CUR_DONE;                           // the traversal had ended already: unoccluded
+                                else if ((int32_t)cur < 0) { def = cur; cur = (uint32_t)CUR_POP; }  // the leaf this lane was waiting on moves up
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned long long leaf_mask = FAST ? 0ull : (GEN ? __ballot((cur & LEAF_KIND) == LINK_LEAF) : __ballot((int32_t)cur < 0));
         if (leaf_mask != 0ull) {
             const unsigned long long node_mask = __ballot(cur < (uint32_t)CUR_FIRST_SPECIAL);
             if (__popcll(leaf_mask) >= leaf_min || node_mask == 0ull) {
@@ -571,6 +621,19 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         for (int round = 0; round < (ANY ? 1 : K5_POP_ROUNDS); ++round) {  // (closest-hit: a culled entry costs no fetch; further rounds let its lane try the next one at once)
             if (__ballot(cur == CUR_POP) == 0ull) break;
             CENSUS(8, 1); CENSUS(9, __popcll(__ballot(cur == CUR_POP))); CENSUS(24, __popcll(__ballot(cur == CUR_POP)) <= 8 ? 1 : 0);
+            if constexpr (FAST) {
+                if (cur == CUR_POP) {
+                    if (top == st_base) cur = def != 0u ? (uint32_t)CUR_WAIT : (uint32_t)CUR_DONE;
+                    else {
+                        top -= WAVE;
+                        uint32_t e;
+                        if (top < st_base + LDS_N * WAVE) e = *top;
+                        else e = __builtin_nontemporal_load(st_spill_wave + (size_t)(top - (st_base + LDS_N * WAVE)) + lane);
+                        cur = e;
+                        if (K5_FAST_DEFER && (int32_t)cur < 0 && def == 0u) { def = cur; cur = (uint32_t)CUR_POP; }  // a popped leaf is kept for later at once; the lane pops on in the next iteration
+                    }
+                }
+            } else
             if (cur == CUR_POP) {
                 if (ANY) { c_nodes += ph_top; ph_top = 0u; }  // the phantoms above the newest entry: popped, tested, dropped, one after the other
                 if (top == st_base) cur = CUR_DONE;
@@ -638,7 +701,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     CENSUS(14, __builtin_readcyclecounter() - t_loop0);
     if (ANY == (K5_CENSUS == 2) && lane == 0) for (int i = 0; i < 32; ++i) if (c_census[i]) atomicAdd(&g_census[i], c_census[i]);
 #endif
-    if (ANY) {
+    if (ANY && !FAST) {
         unsigned long long wn = c_nodes;
         for (int off = 32; off > 0; off >>= 1) wn += __shfl_down(wn, off);
         w_nodes = wn;
@@ -695,6 +758,19 @@ __global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_e
 template <>
 __global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_GEN_ANY_WAVES, K5_GEN_ANY_WAVES))) k_trace5<true, true>(K5_PARAMS) {
     trace5_body<true, true, K5Shape<K5_GEN_ANY_WAVES>::LDS>(K5_ARGS);
+}
+
+// The ORDER-FREE occlusion kernel (round 6; triangle scenes): intersect_predicate's verdict for a ray is a boolean that no visit order can change (aggregate.rs:141-203), and
+// the film takes nothing else from this kernel. So the kernel the RENDER launches keeps no phantom accounting (4-byte stack entries: twice the levels in the same LDS), counts
+// the box tests and triangle tests it really makes (scalar registers, as the closest-hit kernel), and defers leaves: see `def` in trace5_body. k_trace5<true, *> — the
+// reference's order, visit for visit — stays the kernel of shm_trace_any with statistics, of ShmRenderParams::reference_visit_order renders and of every visit-count test.
+#ifndef K5_FAST_WAVES
+#define K5_FAST_WAVES 8
+#endif
+// 256 lanes x 4 B = 1 KiB per level and workgroup
+template <int WAVES> struct K5FastShape { static constexpr int LDS = (WAVES >= 8 ? 18 : (WAVES == 7 ? 22 : (WAVES == 6 ? 26 : 30))), PER_CU = WAVES; };
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_FAST_WAVES, K5_FAST_WAVES))) k_trace5_occluded(K5_PARAMS) {
+    trace5_body<true, false, K5FastShape<K5_FAST_WAVES>::LDS, true>(K5_ARGS);
 }
 
 #ifdef K6_EXPERIMENT  // (a development build: tools/exp_variants.sh k_trace K6_EXPERIMENT 1, then SHM_TRACE_TWO=1 — NOT in the shipped library: measured and rejected, below)
@@ -1095,7 +1171,15 @@ int wf_trace_prepare(ShmScene* s) {
         if (s->trace3_per_cu_override > 0) per_cu = std::min(per_cu, s->trace3_per_cu_override);
         s->trace3_blocks[any] = s->n_cu * per_cu;
         s->spill3_levels[any] = std::max(0, (int)s->flat.max_leaf_depth + 1 - lds) + 1;
-        const size_t words = (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[any] * WAVE * 2u * (two ? 2u : 1u);  // (8-byte stack entries; k_trace6: two stacks per lane)
+        if (any && tri_only) {
+            // the order-free occlusion kernel shares the any-hit spill allocation: 4-byte entries, never more levels beyond its LDS window than the exact kernel has
+            int per_cu_f = K5FastShape<K5_FAST_WAVES>::PER_CU;
+            if (s->trace3_per_cu_override > 0) per_cu_f = std::min(per_cu_f, s->trace3_per_cu_override);
+            s->trace3_blocks[2] = s->n_cu * per_cu_f;
+            s->spill3_levels[2] = std::max(0, (int)s->flat.max_leaf_depth + 1 - K5FastShape<K5_FAST_WAVES>::LDS) + 1;
+        }
+        size_t words = (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[any] * WAVE * 2u * (two ? 2u : 1u);  // (8-byte stack entries; k_trace6: two stacks per lane)
+        if (any && tri_only) words = std::max(words, (size_t)s->trace3_blocks[2] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[2] * WAVE);
         void* d = nullptr;
         if (hipMalloc(&d, words * sizeof(uint32_t)) != hipSuccess) { shm_err() = "hipMalloc of the traversal stack spill failed"; return SHM_ERR_OUT_OF_MEMORY; }
         s->allocs.push_back(d);
@@ -1112,7 +1196,7 @@ int wf_trace_prepare(ShmScene* s) {
 }
 
 int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, const ShmRay* rays,
-                    ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib, int hit16) {
+                    ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib, int hit16, int order_free) {
     uint32_t* heads = s->d_heads3 + (any ? 8 * 32 : 0);
     uint32_t* spill = any ? s->d_spill3_any : s->d_spill3;
     hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, stream, heads);
@@ -1131,7 +1215,10 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
     if (tri_only && trace_two()) { if (any) TRACE6_LAUNCH(true); else TRACE6_LAUNCH(false); }
     else
 #endif
-    if (tri_only) { if (any) TRACE5_LAUNCH(true, false); else TRACE5_LAUNCH(false, false); }
+    if (tri_only && any && order_free) {
+        hipLaunchKernelGGL(k_trace5_occluded, dim3(s->trace3_blocks[2]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, hits, occluded, L, contrib, s->d_counters,
+                           spill, s->spill3_levels[2], s->refill_min_fast, s->leaf_min_fast, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n, (float4*)nullptr, 0, (float4*)nullptr);
+    } else if (tri_only) { if (any) TRACE5_LAUNCH(true, false); else TRACE5_LAUNCH(false, false); }
     else { if (any) TRACE5_LAUNCH(true, true); else TRACE5_LAUNCH(false, true); }
 #undef TRACE5_LAUNCH
     LAUNCH_TRY(any ? "k_trace<any>" : "k_trace<closest>");

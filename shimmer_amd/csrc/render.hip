@@ -597,6 +597,9 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) s->trace3_per_cu_override = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
+    if (const char* e = getenv("SHM_LEAF_MIN_FAST")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_fast = v2; }
+    if (const char* e = getenv("SHM_REFILL_MIN_FAST")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min_fast = v2; }
+    if (const char* e = getenv("SHM_ANY_ORDER_FREE")) s->any_order_free = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_OTHER_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min = s->other_min_any = v2; }
     if (const char* e = getenv("SHM_TAIL_FUSED_BOUNCE")) { const int v2 = atoi(e); s->tail_fused_bounce = v2 >= 0 ? v2 : 1 << 30; }
     if (const char* e = getenv("SHM_FUSED_GEN")) s->fused_gen = atoi(e) != 0 ? 1 : 0;
@@ -899,7 +902,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     hipStreamWaitEvent(any_stream, shaded, 0);
                 }
                 hipEventRecord(c, any_stream);
-                if ((rc = wf_launch_trace(s, true, any_stream, s->d_q_shadow, &s->d_qs->n_shadow[sh], 0, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib)) != SHM_OK) return rc;
+                if ((rc = wf_launch_trace(s, true, any_stream, s->d_q_shadow, &s->d_qs->n_shadow[sh], 0, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib, 0, s->any_order_free)) != SHM_OK) return rc;
                 hipEventRecord(d, any_stream);
                 ev_any.push_back({c, d});
                 k3_done = d;

@@ -22,9 +22,46 @@
 
 namespace shm {
 
+#ifdef SHM_ORACLE_REFERENCE_STREAM
+// oracle/oracle.cpp only (test infrastructure; the product is never compiled with this): the reference's OWN sampler stream — one SmallRng (rand 0.8.5: Xoshiro256++
+// seeded through SplitMix64) per worker thread, sampler.rs:103-131 — for orc_render_reference_stream. A sampler that carries one draws every dimension from it.
+struct RefStream {
+    uint64_t s[4];
+};
+inline uint64_t ref_splitmix64_next(uint64_t& state) {  // rand_core 0.6 / rand 0.8.5 xoshiro256plusplus.rs seed_from_u64: SplitMix64, the published constants
+    state += 0x9e3779b97f4a7c15ULL;
+    uint64_t z = state;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+inline RefStream ref_stream_seed_from_u64(uint64_t seed) {
+    RefStream r;
+    for (int i = 0; i < 4; ++i) r.s[i] = ref_splitmix64_next(seed);
+    return r;
+}
+inline uint64_t ref_rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+inline uint64_t ref_stream_next_u64(RefStream& r) {  // xoshiro256++ 1.0 (Blackman / Vigna, public domain)
+    const uint64_t result = ref_rotl(r.s[0] + r.s[3], 23) + r.s[0];
+    const uint64_t t = r.s[1] << 17;
+    r.s[2] ^= r.s[0];
+    r.s[3] ^= r.s[1];
+    r.s[1] ^= r.s[2];
+    r.s[0] ^= r.s[3];
+    r.s[2] ^= t;
+    r.s[3] = ref_rotl(r.s[3], 45);
+    return result;
+}
+// rng.gen::<f32>() of rand 0.8.5: Standard draws next_u32() (= next_u64() >> 32 for this generator) and keeps its upper 24 bits: (u32 >> 8) * 2^-24
+inline float ref_stream_next_f32(RefStream& r) { return (float)(uint32_t)(ref_stream_next_u64(r) >> 40) * 5.9604644775390625e-8f; }
+#endif
+
 struct Rng {
     uint64_t state;
     uint64_t inc;
+#ifdef SHM_ORACLE_REFERENCE_STREAM
+    RefStream* ref = nullptr;
+#endif
 };
 constexpr uint64_t PCG32_DEFAULT_STATE = 0x853c49e6748fea9bULL;
 constexpr uint64_t PCG32_MULT = 0x5851f42d4c957f2dULL;
@@ -90,7 +127,12 @@ SHM_HD Rng sampler_start_pixel_sample(int px, int py, int sample_index, uint64_t
     rng_advance_65536(r, (uint64_t)(uint32_t)sample_index);
     return r;
 }
-SHM_HD Float sampler_get_1d(Rng& r) { return (Float)(rng_next_u32(r) >> 8) * 5.9604644775390625e-8f; }
+SHM_HD Float sampler_get_1d(Rng& r) {
+#ifdef SHM_ORACLE_REFERENCE_STREAM
+    if (r.ref) return ref_stream_next_f32(*r.ref);
+#endif
+    return (Float)(rng_next_u32(r) >> 8) * 5.9604644775390625e-8f;
+}
 SHM_HD V2 sampler_get_2d(Rng& r) {  // sampler.rs:127-131: x drawn first
     Float x = sampler_get_1d(r);
     Float y = sampler_get_1d(r);

@@ -310,11 +310,14 @@ struct ShmScene {
     std::vector<uint64_t> tile_bitmap;  // host scratch of the disjointness check in shm_render_wave
     int n_cu = 256;
     // tuned traversal (k_trace5; the field names date from the retired one-node-step kernels)
-    int trace3_blocks[2] = {0, 0};   // persistent grid of the closest-hit [0] / any-hit [1] entry point this scene uses (k_trace.hip: K5Shape)
-    int spill3_levels[2] = {1, 1};   // stack levels beyond the entry point's LDS levels (HBM spill)
+    int trace3_blocks[3] = {0, 0, 0};   // persistent grid of the closest-hit [0] / any-hit [1] / order-free occlusion [2] entry point this scene uses (k_trace.hip: K5Shape)
+    int spill3_levels[3] = {1, 1, 1};   // stack levels beyond the entry point's LDS levels (HBM spill)
     int trace3_per_cu_override = 0;  // SHM_TRACE3_BLOCKS_PER_CU (development)
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
     int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
+    int leaf_min_fast = 24;        // the order-free occlusion kernel: lanes holding a deferred leaf before the triangle phase runs (SHM_LEAF_MIN_FAST)
+    int refill_min_fast = 40;      // ... and its refill threshold (SHM_REFILL_MIN_FAST)
+    int any_order_free = 1;        // development A/B: SHM_ANY_ORDER_FREE=0 renders with the reference-order any-hit kernel
     uint32_t* d_spill3 = nullptr;
     LdsTables lds_tables = {};        // the small tables the shading kernels stage in LDS within the full budget (render.hip: wf_lds_tables; SHM_LDS_TABLES=0: nothing)
     LdsTables lds_tables_small = {};  // ... within the 1.5 KB the material-sorted triangle vertex kernel has to spare
@@ -370,7 +373,7 @@ WF_INTERNAL void wf_trace_census();  // k_trace.hip: prints the per-phase lane c
 WF_INTERNAL void wf_layered_census();  // k_scatter_layered_staged_tri.hip: the same for a -DLJ_CENSUS build of the staged LayeredBxDF kernel
 WF_INTERNAL int wf_trace_prepare(ShmScene* s);  // grid sizes + stack spill buffers of the two traversal kernels (at scene creation)
 WF_INTERNAL int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct,
-                                const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib, int hit16 = 0);
+                                const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib, int hit16 = 0, int order_free = 0);
 // shading of one path vertex of PathIntegrator::li for every entry of q_active[cur]
 struct ShadeArgs {
     hipStream_t stream;

@@ -462,6 +462,31 @@ def test_c4_frame_at_full_size(env):
     gpu.close()
 
 
+def test_c2_frame_at_full_size(env):
+    """BASELINE.json configs[1] at its own size — the 32-triangle Cornell-style box, 512 x 512, 64 spp, maxdepth 5 (16.8 M paths) — WHOLE frame against the
+    oracle (it renders the frame in seconds on the test box's host cores): every f64 film sum and all seven counters bit for bit, through the entry point
+    bench.py times (shm_render_device, <= 64-spp launches) — and the same film once more through the reference's own spp-wave schedule (shm_render_wave)."""
+    lib, oracle_py, render, scenes = env
+    sc = scenes.cornell_box(lib, 512, 512)
+    assert sc.info["n_primitives"] == 32
+    p = render.make_params(seed=0, spp=64, max_depth=5)
+    gpu = render.Renderer(lib, sc.desc, 0)
+    gpu.clear()
+    sg = gpu.render_device(p)
+    fg = gpu.read_film()
+    orc = oracle_py.Oracle(sc.desc)
+    fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
+    orc.close()
+    assert sg["paths"] == 512 * 512 * 64 and (fg["weight_sum"] == 64.0).all() and np.isfinite(fg["rgb_sum"]).all()
+    assert np.array_equal(fg, fo)
+    assert float(np.max(np.abs(render.film_to_rgb(fg) - render.film_to_rgb(fo)))) < L_INF_TOL
+    for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+        assert sg[k] == so[k], k
+    fw, sw = gpu.render(p)  # clear, the waves 1, 1, 2, 4, 8, 16, 32 one by one (integrator.rs:226-322), read back
+    assert np.array_equal(fw, fo) and sw["rays_closest"] == so["rays_closest"] and sw["rays_any"] == so["rays_any"]
+    gpu.close()
+
+
 def test_instance_root_inside_another_tree_is_rejected(env):
     """An instance whose root node lies INSIDE the top-level tree (an instanced sub-tree) would get two device indices in the sibling-pair re-layout of the node array:
     scene creation names it instead of traversing something else (advisor, round 3). Whatever layer refuses it first, it is refused with a message, on the GPU path."""
