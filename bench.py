@@ -44,6 +44,7 @@ PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
 # measured on this part (tools/ubench/valu_rate.hip -> profiles/r03_valu_issue_rates.txt, >= 2 waves per SIMD): clocks a SIMD is held per wave64 VALU
 # instruction. The cheapest class prices the CEILING (no instruction mix can issue faster); the counter's own pricing is one quad-cycle = 4 clocks.
 VALU_CLOCKS_BEST = 2.4     # v_add / v_mul / v_fma / v_add_u32 / v_mov
+VALU_CLOCKS_GUIDE = 2.0    # MI355X_MICROARCH.md "Per-instruction cycle constants": v_fma_f32 (wave64) = 2 cyc (SIMD-32) — the guide's ceiling, stated beside the measured one
 VALU_CLOCKS_COUNTER = 4.0  # what SQ_ACTIVE_INST_VALU charges; v_cndmask (SGPR mask) / v_cmp -> SGPR / v_max3 measure 4.2
 N_SIMD, N_XCD = 256 * 4, 8
 K2_NAME = "k_trace<closest>"  # k_trace5<false, GEN> (the both-children step; GEN: scenes with spheres / patches / instances)
@@ -101,7 +102,7 @@ def live_pmc(args):
                 return None, f"pass {counters[0]}: no {K2_NAME} dispatch in the database"
             out.update(vals)
             out["dispatches"] = n
-            sv, sn = _counters_from_db(dbs[0], "shade")  # (the frame's longest kernel since round 4: the same accounting, informational)
+            sv, sn = _counters_from_db(dbs[0], "shade")  # (the fused vertex kernel, second to the closest-hit traversal in the frame: the same accounting, informational)
             if sn:
                 out.setdefault("_shade", {}).update(sv)
                 out["_shade"]["dispatches"] = sn
@@ -152,6 +153,8 @@ def counter_blocks(c, avg_launch_ms):
         busy4 = VALU_CLOCKS_COUNTER * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cycles)
         valu = {"kernel": "k_trace<closest>", "achieved_lane_ops_per_s": achieved, "peak_lane_ops_per_s": peak, "frac": achieved / peak,
                 "frac_at_counter_pricing_4_clocks": achieved / (N_SIMD * 64 * clock_hz / VALU_CLOCKS_COUNTER),
+                "frac_at_guide_peak_2_clocks": achieved / (N_SIMD * 64 * clock_hz / VALU_CLOCKS_GUIDE),
+                "peak_lane_ops_per_s_guide_2_clocks": N_SIMD * 64 * clock_hz / VALU_CLOCKS_GUIDE,
                 "valu_busy_frac_at_4_clocks": busy4, "valu_busy_frac_at_2p4_clocks": busy4 * VALU_CLOCKS_BEST / VALU_CLOCKS_COUNTER,
                 "lanes_per_valu_inst": lanes, "valu_insts_per_launch": n_inst, "gpu_cycles_per_launch": cycles, "effective_clock_GHz": clock_hz / 1e9,
                 "issue_rate_measured_clocks_per_inst": {"simple f32 / int (add, mul, fma, mov)": 2.4, "select / compare-to-SGPR / packed / 3-operand": 4.2, "rcp": 8.2},
@@ -457,7 +460,7 @@ def rank_main(args):
     else:
         tot = {k: float(v) for k, v in acc.items()}
 
-    out = None
+    out, frac_fatal = None, False
     if rank == 0:
         rays = tot["rays_closest"] + tot["rays_any"]
         value = rays / dt / 1e6
@@ -491,12 +494,14 @@ def rank_main(args):
                          "achieved": (valu["achieved_lane_ops_per_s"] / 1e12) if valu else None, "peak": (valu["peak_lane_ops_per_s"] / 1e12) if valu else None,
                          "unit": "Tlane-op/s", "frac": valu["frac"] if valu else None,
                          "frac_at_counter_pricing_4_clocks": valu["frac_at_counter_pricing_4_clocks"] if valu else None,
+                         "frac_at_guide_peak_2_clocks": valu["frac_at_guide_peak_2_clocks"] if valu else None,
                          "traffic": traffic, "traffic_source": counters_src, "lanes_active": lanes,
                          "wait_frac": valu["wait_frac"] if valu else None, "salu_busy_frac": valu["salu_busy_frac_at_4_clocks"] if valu else None,
                          "valu_busy_frac": valu["valu_busy_frac_at_4_clocks"] if valu else None,
                          "avg_launch_ms": ms / launches, "launches": launches,
                          "bound_note": "lane-operations per second of the closest-hit traversal kernel over 1024 SIMDs x 64 lanes x clock / 2.4 clocks per "
-                                       "instruction (the measured best issue rate); the gathers are L2 / MALL-served (roofline_hbm_counter), so HBM is not "
+                                       "instruction (the measured best issue rate; frac_at_guide_peak_2_clocks prices the same numerator against the guide's 2-cycle v_fma_f32: "
+                                       "MI355X_MICROARCH.md, per-instruction cycle constants); the gathers are L2 / MALL-served (roofline_hbm_counter), so HBM is not "
                                        "the ceiling; see roofline_valu for every term" if valu else
                                        "no hardware counters available in this run (rocprofv3 missing and no committed profile of this configuration): "
                                        "see roofline_hbm_algorithmic"},
@@ -539,7 +544,9 @@ def rank_main(args):
         if valu:
             out["roofline_valu"] = valu
             if not (0.0 < valu["frac"] <= 1.0):
-                # reporting only (the counters may come from the committed fallback profile of another build): say so in the line, keep the measured run
+                # counters from the committed fallback profile of another build: reporting only — say so in the line, keep the measured run. LIVE counters that do not give
+                # a fraction of the ceiling mean the accounting is broken: the line is printed and the run exits non-zero (below)
+                frac_fatal = counters_src.startswith("live")
                 out["roofline"]["frac_invalid"] = True
                 out["roofline"]["frac_invalid_note"] = f"frac = {valu['frac']} is not a fraction of a ceiling: counters ({counters_src}) and this run's launch time do not belong together"
                 out["roofline"]["frac"] = None
@@ -584,6 +591,8 @@ def rank_main(args):
         import ctypes
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
+        if frac_fatal:
+            raise SystemExit("roofline.frac is not a fraction of its ceiling although the counters are this run's own: the accounting is broken (line printed above)")
 
 
 def dry_run(args, rank, local_rank, world, store):

@@ -580,12 +580,7 @@ SHM_API int shm_bvh_build(const float* prim_bounds, uint32_t n, int split_method
  * for the reference's own vectors (bounding_box.rs:699-733, 950-995). a, b: {min xyz, max xyz}. out[16]: union(a, b) min, max | union_point(a, p)
  * min, max | surface_area(a), volume(a), max_dimension(a), 0. */
 SHM_API int shm_bounds3_probe(const float a[6], const float b[6], const float p[3], float out[16]);
-/* Test entry (DEVICE): one leaf function of the shared arithmetic — intersect_triangle, intersect_p_cached, every BxDF's f / sample_f / pdf incl. the
- * LayeredBxDF walks, shape sampling, camera rays, film accumulation ... (shimmer_amd/csrc/shm/probe.h lists the `op` codes and each one's argument layout) —
- * evaluated by one wave of `device` on flat 32-bit words; *fn_result receives the wrapped function's integer result (Some / None). The `-m gpu` suite replays
- * the committed golden vectors (the reference's in-source known answers: aggregate.rs:575-702, bxdf.rs:1871-1903 ..., and the independent re-evaluations of
- * tests/golden/golden_leaves.json / golden_layered.json) through it: the device code against the vectors themselves, not through the CPU oracle. Not a render path. */
-SHM_API int shm_debug_eval_leaf(int device, int op, const uint32_t* in_words, uint32_t n_in, uint32_t* out_words, uint32_t n_out, int* fn_result);
+/* (The DEVICE test entry of rounds 4-5, shm_debug_eval_leaf, lives in the test library libshimmer_hip_probe.so since round 6: include/shimmer_hip_probe.h.) */
 /* Tile::tile (tile.rs:21-104). tiles_out capacity ceil(w/tw)*ceil(h/th); returns the count via n_out. */
 SHM_API int shm_tile_bounds(const int32_t pixel_bounds[4], int32_t tile_w, int32_t tile_h, ShmTile* tiles_out,
                     uint32_t* n_out);

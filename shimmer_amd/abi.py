@@ -238,7 +238,6 @@ EXPORTS = {
     "shm_device_count": (C.c_int, []),
     "shm_bvh_build": (C.c_int, [c_float_p, C.c_uint32, C.c_int, C.POINTER(ShmBvhNode), c_u32_p, c_u32_p]),
     "shm_bounds3_probe": (C.c_int, [c_float_p, c_float_p, c_float_p, c_float_p]),
-    "shm_debug_eval_leaf": (C.c_int, [C.c_int, C.c_int, c_u32_p, C.c_uint32, c_u32_p, C.c_uint32, C.POINTER(C.c_int)]),
     "shm_tile_bounds": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(ShmTile), c_u32_p]),
     "shm_camera_perspective": (C.c_int, [c_float_p, C.c_float, C.POINTER(C.c_int32), C.c_float, C.c_float, C.POINTER(ShmCamera), c_float_p]),
     "shm_integrator_render": (C.c_int, [C.c_char_p, C.POINTER(ShmSceneDesc), C.c_int, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_int,
@@ -301,6 +300,25 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+PROBE_LIB_PATH = LIB_PATH.parent / "libshimmer_hip_probe.so"
+_probe = None
+
+
+def load_probe_library():
+    """The TEST library libshimmer_hip_probe.so (include/shimmer_hip_probe.h): shm_debug_eval_leaf, one leaf function of the shared arithmetic on the device. Only the
+    `-m gpu` suite loads it (tests/device_leaves.py); it is not part of the product library."""
+    global _probe
+    if _probe is None:
+        if not PROBE_LIB_PATH.exists():
+            raise ShimmerHipError(f"{PROBE_LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(str(PROBE_LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+        lib.shm_debug_eval_leaf.restype = C.c_int
+        lib.shm_debug_eval_leaf.argtypes = [C.c_int, C.c_int, c_u32_p, C.c_uint32, c_u32_p, C.c_uint32, C.POINTER(C.c_int)]
+        lib.shm_probe_last_error.restype = C.c_char_p
+        _probe = lib
+    return _probe
 
 
 def check(lib, rc, what):

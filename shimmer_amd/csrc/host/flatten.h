@@ -37,7 +37,7 @@ struct FlatScene {
     ShmFilm film;
     uint32_t max_leaf_depth = 0;  // deepest leaf (root = 0); bounds the traversal stack
     float scene_radius = 0.0f;
-    bool has_spheres = false;  // any non-triangle shape (sphere or bilinear patch): selects k_trace3<.., TRI_ONLY = false>
+    bool has_spheres = false;  // any non-triangle shape (sphere or bilinear patch): selects k_trace5<.., GEN = true> and the general-geometry shading instantiations
     bool has_layered = false;  // any Coated* material: selects the k_shade instantiation that carries LayeredBxDF
     bool has_rough_dielectric = false;  // a DielectricMaterial whose roughness is not the constant 0 (the specular / rough split of its scatter kernels)
     bool has_class[4] = {false, false, false, false};  // BxDF classes present in the material table (staged shading launches one scatter

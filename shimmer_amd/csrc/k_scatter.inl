@@ -11,6 +11,11 @@
 #ifndef K_ENV_LIGHT
 #define K_ENV_LIGHT false
 #endif
+#if K_ENV_LIGHT  // (the *_env.hip units' kernels carry their own names: a kernel trace tells them from the units without the light — tools/kernel_coverage.py)
+#define k_scatter k_scatter_env
+#define k_scatter_specular k_scatter_specular_env
+#define k_scatter_nonspecular k_scatter_nonspecular_env
+#endif
 namespace {
 
 // Deferred next-event estimation of the LayeredBxDF class. In a CoatedDiffuse / CoatedConductor vertex the expensive part of NEE is LayeredBxDF::f

@@ -5,8 +5,7 @@
 // entries — smooth DielectricBxDF, ThinDielectricBxDF: no NEE, no microfacet code — at four waves per SIMD, and the rough ones (launched only if the
 // material table holds a dielectric that can be rough) by the general kernel; each skips the other's entries.
 int wf_launch_scatter_dielectric(ShmScene* s, const ShadeArgs& a, bool tri_only, bool has_tex) {
-    static const bool split_off = [] { const char* e = getenv("SHM_SPECULAR_SPLIT"); return e && atoi(e) == 0; }();
-    if (split_off || a.params.force_diffuse != 0 || a.params.regularize != 0) {
+    if (a.params.force_diffuse != 0 || a.params.regularize != 0) {
         WF_SCATTER_DISPATCH(CLASS_DIELECTRIC);
         return SHM_OK;
     }

@@ -21,6 +21,9 @@
 #ifndef K_ENV_LIGHT
 #define K_ENV_LIGHT false
 #endif
+#if K_ENV_LIGHT  // (the *_env.hip units' kernels carry their own names: a kernel trace tells them from the units without the light — tools/kernel_coverage.py)
+#define k_scatter_layered k_scatter_layered_env
+#endif
 namespace {
 
 constexpr int LJ_CAP = 2 * WAVE;  // per buffer: at most 63 waiting + 64 new (a stage runs as soon as 64 wait, and before anything is added)

@@ -71,6 +71,8 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) K_SHADE_LEAN_ATTR k_shade(SceneV
           if (threadIdx.x <= SHADE_SORT_BINS) s_bin[threadIdx.x] = 0;
           __syncthreads();
           uint32_t my_path[SHADE_CHUNK / SHADE2_BLOCK];
+          // (the packing below holds exactly eight 8-bit keys per lane in two words: both constants are load-bearing)
+          static_assert(SHADE_CHUNK / SHADE2_BLOCK == 8 && SHADE_SORT_BINS < 256, "the chunk sort packs 8 keys of 8 bits per lane");
           uint32_t my_keys = 0u, my_keys_hi = 0u;  // 8 keys of 7 bits (0..64)
 #pragma unroll
           for (uint32_t k = 0; k < SHADE_CHUNK / SHADE2_BLOCK; ++k) {

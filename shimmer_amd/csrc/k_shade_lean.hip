@@ -4,9 +4,8 @@
 #include "k_shade.inl"
 
 int wf_launch_shade_lean(ShmScene* s, const ShadeArgs& a) {
-    // the scene runs this kernel alone: a vertex leaves its hit record, not its LightSampleContext, for the next vertex's emitter MIS weight (k_shade.inl; SHM_CTX_AS_HIT=0: A/B)
-    const char* e = getenv("SHM_CTX_AS_HIT");
-    const int ctx_as_hit = (e && atoi(e) == 0) ? 0 : 1;
+    // the scene runs this kernel alone: a vertex leaves its hit record, not its LightSampleContext, for the next vertex's emitter MIS weight (k_shade.inl; round 4 A/B: DESIGN.md section 6)
+    constexpr int ctx_as_hit = 1;
 #define CTX_AS_HIT_FLAG ((ctx_as_hit << 1) | ((ctx_as_hit && a.hit_kept) ? 4 : 0))
     WF_SHADE_LAUNCH((k_shade<false, true, false, true, false>));
 #undef CTX_AS_HIT_FLAG

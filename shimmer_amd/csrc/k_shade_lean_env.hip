@@ -5,8 +5,7 @@
 #include "k_shade.inl"
 
 int wf_launch_shade_lean_env(ShmScene* s, const ShadeArgs& a) {
-    const char* e = getenv("SHM_CTX_AS_HIT");
-    const int ctx_as_hit = (e && atoi(e) == 0) ? 0 : 1;
+    constexpr int ctx_as_hit = 1;
 #define CTX_AS_HIT_FLAG ((ctx_as_hit << 1) | ((ctx_as_hit && a.hit_kept) ? 4 : 0))
     WF_SHADE_LAUNCH((k_shade<false, true, false, true, false, false, true>));
 #undef CTX_AS_HIT_FLAG

@@ -39,6 +39,18 @@ __device__ __forceinline__ Float sel_mask(unsigned long long mask, Float if_clea
 // One-instruction max / min of three (IEEE maxNum / minNum; used only where no operand can be a NaN, see the slab test).
 __device__ __forceinline__ Float vmax3(Float a, Float b, Float c) { Float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ Float vmin3(Float a, Float b, Float c) { Float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// A cache-line prefetch (gfx950 has no prefetch instruction): one byte of the line into a register nobody reads. `sink` is an in-out operand so that the register stays this
+// variable's for the whole loop — the load writes it whenever it returns, and nothing else may live there meanwhile (two prefetches in flight into it are harmless). The
+// compiler's own s_waitcnt bookkeeping does not know this load: an unknown load in flight can only make its vmcnt(N) waits longer, never shorter (returns are in order).
+__device__ __forceinline__ void prefetch_line(const char* base, uint32_t byte_off, uint32_t& sink) {
+    asm volatile("global_load_ubyte %0, %1, %2" : "+v"(sink) : "v"(byte_off), "s"(base));
+}
+#ifndef K5_PREFETCH_LEAF
+#define K5_PREFETCH_LEAF 0  // a lane that finds itself on a triangle leaf requests the leaf record's line at once (the leaf phase, some iterations later, finds it in L2)
+#endif
+#ifndef K5_PREFETCH_FAR
+#define K5_PREFETCH_FAR 0   // a pushed far child's block of children is requested at the push (its pop is the head of a dependent chain)
+#endif
 
 #define K3_PARAMS SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_direct, uint32_t* head,                    \
                   const ShmRay* __restrict__ rays, ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out, float4* __restrict__ L,                 \
@@ -74,7 +86,7 @@ __device__ unsigned long long g_census[32];
 #else
 #define CENSUS(i, v) do { } while (0)
 #endif
-enum : uint32_t { CUR_IDLE = 0x7fffffffu, CUR_POP = 0x7ffffffeu, CUR_DONE = 0x7ffffffdu, CUR_WAIT = 0x7ffffffcu /* FAST: stack exhausted, a deferred leaf still untested */, CUR_FIRST_SPECIAL = 0x60000000u,
+enum : uint32_t { CUR_IDLE = 0x7fffffffu, CUR_POP = 0x7ffffffeu, CUR_DONE = 0x7ffffffdu, CUR_FIRST_SPECIAL = 0x60000000u,
                   CUR_MARKER = 0x60000000u };  // (GEN: CUR_MARKER | leaf slot of the instance — the stack entry that leads back out of it; never a lane's `cur`: slots are below 2^27)
 constexpr uint32_t SGN_RAY = 15u, SGN_HIT = 16u, SGN_HIT_INSIDE = 32u, SGN_INST_SHIFT = 6u;  // trace5_body's `sgn` word (see there)
 
@@ -91,7 +103,7 @@ constexpr uint32_t SGN_RAY = 15u, SGN_HIT = 16u, SGN_HIT_INSIDE = 32u, SGN_INST_
 // behind it, so that nothing but path, t_max, stack pointer and link word is live across ~1 000 instructions of interval arithmetic (inlined with the state live, they made
 // the loop itself spill; as real calls, the calling convention's caller-saved registers did the same). An instance's entry saves the OUTER ray state the same way: leaving is
 // three loads, not a second ray set-up. The hit record is the ABI's 32-byte ShmHit (t, phi and the instance ride along).
-template <bool ANY, bool GEN, int LDS_N, bool FAST = false>
+template <bool ANY, bool GEN, int LDS_N>
 __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
                                             uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
                                             ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
@@ -99,18 +111,15 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                                             DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
                                             int refill_min, int leaf_min, int queue_parts, int rays_per_lane, int hit16, const uint32_t* __restrict__ big_leaf_n,
                                             float4* gen_save, int other_min, float4* __restrict__ hit2) {
-    static_assert(!FAST || (ANY && !GEN), "FAST: the order-free occlusion kernel of triangle scenes");
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    // a stack entry: {link word, t0 | phantom count}; FAST (no phantom accounting, t_max fixed): the link word alone
-    typedef typename std::conditional<FAST, uint32_t, u32x2>::type entry_t;
-    typedef __attribute__((address_space(3))) entry_t lds_u2;
-    __shared__ entry_t lds_stack5[(TRACE_BLOCK / WAVE) * LDS_N * WAVE];
+    typedef __attribute__((address_space(3))) u32x2 lds_u2;
+    __shared__ u32x2 lds_stack5[(TRACE_BLOCK / WAVE) * LDS_N * WAVE];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave_in_block = threadIdx.x / WAVE;
     // the per-lane stack of {link word, t0 | phantom count} entries: levels [0, LDS_N) in LDS as [level][lane], deeper ones in the per-lane HBM spill
     lds_u2* const st_base = (lds_u2*)lds_stack5 + wave_in_block * LDS_N * WAVE + lane;
     lds_u2* top = st_base;
-    entry_t* const st_spill_wave = reinterpret_cast<entry_t*>(spill) + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE;
+    u32x2* const st_spill_wave = reinterpret_cast<u32x2*>(spill) + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)spill_levels * WAVE;
     // GEN: this wave's two save areas of 3 float4 per lane, [area][k][lane] (area 0: the outer ray's state while an instance is traversed; area 1: around a quadric / patch test)
     float4* const save_wave = GEN ? gen_save + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)(6 * WAVE) : nullptr;
     const uint32_t n = n_ptr ? *n_ptr : n_direct;
@@ -166,11 +175,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
     Float t_max = 0.0f;
     uint32_t cur = CUR_IDLE;
-    // FAST (the order-free occlusion kernel): the leaf a lane has reached and not yet tested — its link word (bit 31 set), 0 = none. intersect_predicate's verdict does not
-    // depend on the order the primitives are tested in (aggregate.rs:141-203: every test against the same t_max, `true` at the first hit), so a lane that reaches a leaf
-    // keeps it here and TRAVERSES ON; the wave's triangle tests run when `leaf_min` lanes hold one (or nothing else can run), several times denser than when every such lane
-    // has to wait (k_trace5<any>'s leaf phases run with 9.8 of 64 lanes on the headline frame, 42 % of them with 8 or fewer: profiles/r05_census_sparse_rounds.txt)
-    uint32_t def = 0u;
+    uint32_t pf_sink = 0u;  // (K5_PREFETCH_*: the register the prefetch loads land in)
 
     // aggregate.rs:76-81 + the ray-constant part of the triangle test (the upper bits of sgn — what has been found so far, the instance — belong to the path, not to the ray)
     auto set_ray = [&](V3 o, V3 d) {
@@ -276,14 +281,10 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         t0_out = t0;
         return ok && (t1 > 0.0f);
     };
-    auto make_entry = [](uint32_t link, uint32_t word1) -> entry_t {
-        if constexpr (FAST) return link;
-        else return u32x2{link, word1};
-    };
     auto push = [&](uint32_t link, uint32_t word1) {
         // two different store flavours, so that the compiler cannot merge them into one flat_store of a selected pointer
-        if (top < st_base + LDS_N * WAVE) *top = make_entry(link, word1);
-        else st_spill_wave[(size_t)(top - (st_base + LDS_N * WAVE)) + lane] = make_entry(link, word1);
+        if (top < st_base + LDS_N * WAVE) *top = u32x2{link, word1};
+        else st_spill_wave[(size_t)(top - (st_base + LDS_N * WAVE)) + lane] = u32x2{link, word1};
         top += WAVE;
     };
 
@@ -299,6 +300,15 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     const unsigned long long t_loop0 = __builtin_readcyclecounter();
 #endif
     for (;;) {
+#ifndef K5_PIGGYBACK
+#define K5_PIGGYBACK 0
+#endif
+        // K5_PIGGYBACK (round 6 experiment): a refill only CHOOSES the lanes that take a ray and their paths here; the ray records are fetched beside the node step's
+        // fetches of the lanes that have a node (one round trip serves both: the idle lanes' loads land in the registers the node lanes' loads land in), and the set-up
+        // arithmetic runs behind the node step — the wave does not stall for a refill's own round trip
+        bool taking = false;        // this lane takes a ray in this iteration
+        uint32_t n_taken = 0u;      // wave-uniform: how many do
+        const float4* pg_rp = nullptr;  // ... and its record (the address is made where the path index is: a path read from the queue is waited for THERE, not in front of the node step)
         // ---- refill idle lanes from the wave-private chunk [w_next, w_end); one atomic per `chunk` rays ----
         const unsigned long long idle = __ballot(cur == CUR_IDLE);
         if (GEN) since_other += 1u;
@@ -340,6 +350,8 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                         if (rank < take) {
                             const uint32_t qi = w_next + rank;
                             path = queue ? (pre_ok ? pre_path : queue[qi]) : qi;
+                            if (K5_PIGGYBACK) { taking = true; pg_rp = reinterpret_cast<const float4*>(rays + path); }
+                            else {
                             const float4* rp = reinterpret_cast<const float4*>(rays + path);
                             const float4 r0 = rp[0], r1 = rp[1];
 #ifndef K5_L_AT_REFILL
@@ -353,41 +365,55 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                             set_ray(v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y));
                             t_max = r1.z;
                             top = st_base;
-                            if (ANY && !FAST) ph_top = 0u;
+                            if (ANY) ph_top = 0u;
                             // the root: tested where the ray is taken from the queue
                             cur = root_test(root_a, root_b) ? __float_as_uint(root_b.z) : (uint32_t)CUR_POP;  // (a miss pops the empty stack: done, retired below)
-                            if (ANY && !FAST) c_nodes += 1u;
+                            if (ANY) c_nodes += 1u;
+                            }
                         }
                     }
+                    n_taken = take;
                     w_next += take;
                     w_rays += take;
-                    if (!ANY || FAST) w_nodes += take;
+                    if (!ANY) w_nodes += take;
                     if (K5_QUEUE_PREFETCH && queue) {  // the next refill's entries (it takes at most 64): in flight behind this refill's ray records, consumed ~30 iterations on
                         q_pre_base = w_next;
                         const uint32_t qj = w_next + lane;
                         q_pre = qj < w_end ? queue[qj] : 0u;
                     }
                     CENSUS(11, 1); CENSUS(12, take);
+                    if (!K5_PIGGYBACK) {
                     m_negx = __ballot((sgn & 1u) != 0u);
                     m_negy = __ballot((sgn & 2u) != 0u);
                     m_negz = __ballot((sgn & 4u) != 0u);
                     m_irregular = __ballot((sgn & 8u) != 0u);
+                    }
 #ifdef K5_CENSUS
                     CENSUS(13, __builtin_readcyclecounter() - t_refill0);  // (the ballots above consume the loaded rays: the refill's memory wait is inside)
 #endif
                 }
             }
-            if (__ballot(cur != CUR_IDLE) == 0ull) {
+            if (__ballot(cur != CUR_IDLE || taking) == 0ull) {
                 if (exhausted) break;
                 continue;  // private chunk was empty: fetch the next one
             }
         }
         // ---- one uniform step: every lane that stands on an interior node fetches the block of its two children and tests both (aggregate.rs:92-135) ----
         const bool at_node = cur < (uint32_t)CUR_FIRST_SPECIAL;
-        if (!ANY || FAST) w_nodes += 2ull * (unsigned long long)__popcll(__ballot(at_node));
+        if (!ANY) w_nodes += 2ull * (unsigned long long)__popcll(__ballot(at_node));
         CENSUS(0, 1); CENSUS(1, __popcll(__ballot(at_node))); CENSUS(2, __popcll(__ballot((cur & 0xC0000000u) == 0x80000000u))); CENSUS(21, __popcll(__ballot(cur >= 0xC0000000u))); CENSUS(3, __popcll(__ballot(cur == CUR_IDLE)));
         CENSUS(4, __popcll(__ballot(cur == CUR_POP))); CENSUS(10, __ballot(at_node) != 0ull ? 1 : 0);
         CENSUS(22, (__ballot(at_node) != 0ull && __popcll(__ballot(at_node)) <= 8) ? 1 : 0);  // (a VALU instruction with 8 or fewer lanes on costs 4.5 x one with 9: profiles/r05_valu_exec.txt)
+        // K5_PIGGYBACK: the new rays' records are requested HERE, just ahead of the node step's fetches, into registers of their own (into the node lanes' registers the
+        // compiler would wait for one load before it issues the other: two loads in flight into one register are a write-after-write hazard to it, whatever the lane
+        // masks say); returns are in order, so whoever waits for a node record has the ray records too — one round trip for both
+        float4 pg_r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pg_r1 = pg_r0, pg_l = pg_r0, pg_c = pg_r0;
+        if (K5_PIGGYBACK && n_taken != 0u) {  // (wave-uniform)
+            if (taking) {
+                pg_r0 = pg_rp[0]; pg_r1 = pg_rp[1];
+                if (ANY && L) { pg_l = L[path]; pg_c = contrib[path]; }
+            }
+        }
         if (at_node) {
             // near child first (aggregate.rs:119-127: dir_is_neg[axis] picks it); pairs start at even indices, so the sibling's record is at byte offset ^ 32
             const uint32_t neg = (sgn >> (cur >> LINK_AXIS_SHIFT)) & 1u;
@@ -399,9 +425,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
             const bool pre_n = slab(na, nb, t0n), pre_f = slab(fa, fb, t0f);
             const bool hit_n = pre_n && (t0n < t_max), hit_f = pre_f && (t0f < t_max);
             const uint32_t link_n = __float_as_uint(nb.z), link_f = __float_as_uint(fb.z);
-            if (FAST) {
-                if (hit_n && hit_f) push(link_f, 0u);  // (both boxes tested, both visits counted at the step: what this kernel really does — no phantom accounting)
-            } else if (ANY) {
+            if (ANY) {
                 // t_max is fixed: the far child's verdict is final now. Visits: the near child now; the far child now if the traversal turns to it at
                 // once (the near child missed: the reference's very next pop), at its pop if it is pushed, and as a phantom otherwise
                 c_nodes += hit_n ? 1u : 2u;
@@ -411,48 +435,35 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                 if (hit_n && pre_f) push(link_f, __float_as_uint(t0f));  // aggregate.rs:119-127: the far child waits; what is left of its test is `t0 < t_max`
             }
             cur = hit_n ? link_n : (hit_f ? link_f : (uint32_t)CUR_POP);
+            if (K5_PREFETCH_FAR && !GEN) {
+                const bool pushed = ANY ? (hit_n && hit_f) : (hit_n && pre_f);
+                if (pushed && (int32_t)link_f >= 0) prefetch_line(node_base, link_f << 5, pf_sink);  // (an interior far child: the block of ITS children, what its pop will fetch)
+                else if (K5_PREFETCH_LEAF && pushed) prefetch_line(prim_base, (link_f & LINK_INDEX_MASK) << 6, pf_sink);  // (a far leaf: its first record)
+            }
+            if (K5_PREFETCH_LEAF && !GEN && (int32_t)cur < 0) prefetch_line(prim_base, (cur & LINK_INDEX_MASK) << 6, pf_sink);
+        }
+        if (K5_PIGGYBACK && n_taken != 0u) {
+            // the set-up of the rays taken above (aggregate.rs:76-81, the shear, the root): behind the node step, on records that arrived with the node fetches
+            if (taking) {
+                if (ANY && L) l_new = make_float4(pg_l.x + pg_c.x, pg_l.y + pg_c.y, pg_l.z + pg_c.z, pg_l.w + pg_c.w);
+                sgn = 0u;
+                set_ray(v3(pg_r0.x, pg_r0.y, pg_r0.z), v3(pg_r0.w, pg_r1.x, pg_r1.y));
+                t_max = pg_r1.z;
+                top = st_base;
+                if (ANY) ph_top = 0u;
+                cur = root_test(root_a, root_b) ? __float_as_uint(root_b.z) : (uint32_t)CUR_POP;
+                if (ANY) c_nodes += 1u;
+            }
+            m_negx = __ballot((sgn & 1u) != 0u);
+            m_negy = __ballot((sgn & 2u) != 0u);
+            m_negz = __ballot((sgn & 4u) != 0u);
+            m_irregular = __ballot((sgn & 8u) != 0u);
         }
         // ---- postponed leaf phase: lanes standing on a leaf wait until enough of them do (or nothing else can run) ----
         constexpr uint32_t NOT_A_TRIANGLE = PRIM_SPHERE_BIT | PRIM_PATCH_BIT | PRIM_INSTANCE_BIT;
         constexpr uint32_t LEAF_KIND = LINK_LEAF | LINK_OTHER;  // (GEN: a leaf link with bit 30 set is a parked non-triangle test, below)
         constexpr uint32_t LINK_LEAVE = LEAF_KIND | LINK_INDEX_MASK;  // (... and this one — no slot — a lane parked on its way back out of an instance)
-        if constexpr (FAST) {
-            // ---- FAST: deferred leaves. A lane that stands on a leaf with its slot free keeps the leaf and pops on (below, in this iteration); one whose slot is taken waits ----
-#ifndef K5_FAST_DEFER
-#define K5_FAST_DEFER 1  // (0: a lane that reaches a leaf waits on it, as in the reference-order kernel — what is left is "no phantom accounting, 4-byte stack entries": A/B)
-#endif
-            if (K5_FAST_DEFER) { if ((int32_t)cur < 0 && def == 0u) { def = cur; cur = (uint32_t)CUR_POP; } }
-            else if ((int32_t)cur < 0) { def = cur; cur = (uint32_t)CUR_WAIT; }  // (no deferral: the lane stands still until its leaf has been tested, then pops)
-            const unsigned long long def_mask = __ballot(def != 0u);
-            if (def_mask != 0ull) {
-                const unsigned long long busy = __ballot(cur < (uint32_t)CUR_FIRST_SPECIAL || cur == (uint32_t)CUR_POP);
-                if (__popcll(def_mask) >= leaf_min || busy == 0ull) {
-                    w_prims += (unsigned long long)__popcll(def_mask);
-                    CENSUS(5, 1); CENSUS(6, 1); CENSUS(7, __popcll(def_mask)); CENSUS(23, __popcll(def_mask) <= 8 ? 1 : 0);
-                    if (def != 0u) {
-                        const uint32_t slot = def & LINK_INDEX_MASK;
-                        uint32_t leaf_n = (def >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX;
-                        if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[slot];
-                        const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * sizeof(PrimRec));
-                        const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
-                        TriangleIntersection ti;
-                        bool got = intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
-                        got = got && !(__float_as_uint(q2.y) & PRIM_DEGENERATE_BIT);
-                        leaf_n -= 1u;
-                        if (got) { sgn |= SGN_HIT; cur = (uint32_t)CUR_DONE; def = 0u; }  // occluded: whatever is left on the stack is never looked at (aggregate.rs:160-166)
-                        else {
-                            def = leaf_n == 0u ? 0u : (LINK_LEAF | ((leaf_n < LINK_COUNT_MAX ? leaf_n : LINK_COUNT_MAX) << LINK_COUNT_SHIFT) | (slot + 1u));
-                            if (def == 0u) {
-                                if (!K5_FAST_DEFER) cur = (uint32_t)CUR_POP;
-                                else if (cur == (uint32_t)CUR_WAIT) cur = (uint32_t)CUR_DONE;                           // the traversal had ended already: unoccluded
-                                else if ((int32_t)cur < 0) { def = cur; cur = (uint32_t)CUR_POP; }  // the leaf this lane was waiting on moves up
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        const unsigned long long leaf_mask = FAST ? 0ull : (GEN ? __ballot((cur & LEAF_KIND) == LINK_LEAF) : __ballot((int32_t)cur < 0));
+        const unsigned long long leaf_mask = GEN ? __ballot((cur & LEAF_KIND) == LINK_LEAF) : __ballot((int32_t)cur < 0);
         if (leaf_mask != 0ull) {
             const unsigned long long node_mask = __ballot(cur < (uint32_t)CUR_FIRST_SPECIAL);
             if (__popcll(leaf_mask) >= leaf_min || node_mask == 0ull) {
@@ -621,19 +632,6 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         for (int round = 0; round < (ANY ? 1 : K5_POP_ROUNDS); ++round) {  // (closest-hit: a culled entry costs no fetch; further rounds let its lane try the next one at once)
             if (__ballot(cur == CUR_POP) == 0ull) break;
             CENSUS(8, 1); CENSUS(9, __popcll(__ballot(cur == CUR_POP))); CENSUS(24, __popcll(__ballot(cur == CUR_POP)) <= 8 ? 1 : 0);
-            if constexpr (FAST) {
-                if (cur == CUR_POP) {
-                    if (top == st_base) cur = def != 0u ? (uint32_t)CUR_WAIT : (uint32_t)CUR_DONE;
-                    else {
-                        top -= WAVE;
-                        uint32_t e;
-                        if (top < st_base + LDS_N * WAVE) e = *top;
-                        else e = __builtin_nontemporal_load(st_spill_wave + (size_t)(top - (st_base + LDS_N * WAVE)) + lane);
-                        cur = e;
-                        if (K5_FAST_DEFER && (int32_t)cur < 0 && def == 0u) { def = cur; cur = (uint32_t)CUR_POP; }  // a popped leaf is kept for later at once; the lane pops on in the next iteration
-                    }
-                }
-            } else
             if (cur == CUR_POP) {
                 if (ANY) { c_nodes += ph_top; ph_top = 0u; }  // the phantoms above the newest entry: popped, tested, dropped, one after the other
                 if (top == st_base) cur = CUR_DONE;
@@ -701,7 +699,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     CENSUS(14, __builtin_readcyclecounter() - t_loop0);
     if (ANY == (K5_CENSUS == 2) && lane == 0) for (int i = 0; i < 32; ++i) if (c_census[i]) atomicAdd(&g_census[i], c_census[i]);
 #endif
-    if (ANY && !FAST) {
+    if (ANY) {
         unsigned long long wn = c_nodes;
         for (int off = 32; off > 0; off >>= 1) wn += __shfl_down(wn, off);
         w_nodes = wn;
@@ -760,375 +758,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_e
     trace5_body<true, true, K5Shape<K5_GEN_ANY_WAVES>::LDS>(K5_ARGS);
 }
 
-// The ORDER-FREE occlusion kernel (round 6; triangle scenes): intersect_predicate's verdict for a ray is a boolean that no visit order can change (aggregate.rs:141-203), and
-// the film takes nothing else from this kernel. So the kernel the RENDER launches keeps no phantom accounting (4-byte stack entries: twice the levels in the same LDS), counts
-// the box tests and triangle tests it really makes (scalar registers, as the closest-hit kernel), and defers leaves: see `def` in trace5_body. k_trace5<true, *> — the
-// reference's order, visit for visit — stays the kernel of shm_trace_any with statistics, of ShmRenderParams::reference_visit_order renders and of every visit-count test.
-#ifndef K5_FAST_WAVES
-#define K5_FAST_WAVES 8
-#endif
-// 256 lanes x 4 B = 1 KiB per level and workgroup
-template <int WAVES> struct K5FastShape { static constexpr int LDS = (WAVES >= 8 ? 18 : (WAVES == 7 ? 22 : (WAVES == 6 ? 26 : 30))), PER_CU = WAVES; };
-__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_FAST_WAVES, K5_FAST_WAVES))) k_trace5_occluded(K5_PARAMS) {
-    trace5_body<true, false, K5FastShape<K5_FAST_WAVES>::LDS, true>(K5_ARGS);
-}
-
-#ifdef K6_EXPERIMENT  // (a development build: tools/exp_variants.sh k_trace K6_EXPERIMENT 1, then SHM_TRACE_TWO=1 — NOT in the shipped library: measured and rejected, below)
-// ---------------------------------------------------------------------------------------------
-// k_trace6: TWO rays per lane (round 5 experiment; triangle scenes). MEASURED AND REJECTED (profiles/r05_rejected_two_rays_per_lane.txt): bit-exact (hit records and all
-// four counters on the GPU suite), and it does what it was built for — 23 % fewer wave iterations (VMEM reads 548 M -> 421 M per 64-spp frame), 38.3 instead of 31.4 lanes
-// per VALU instruction — but an iteration costs 62 % more VALU instructions (the selects that bring the chosen slot's state to each phase and back, the sign masks rebuilt
-// every iteration, two retire / refill sections): 15.4 G instead of 12.3 G VALU instructions per frame, K2 91 -> 133 ms, K3 58 -> 79 ms per headline frame
-// (thresholds swept: 129-141 ms). Swapping slots instead of selecting (v_swap_b32 when the foreground slot parks) would still pay ~25 instructions per iteration for
-// ~23 % fewer iterations: break-even at best. The loop's fixed cost per iteration (~95 VALU) is what two rays per lane cannot amortise. The same algorithm and the same step as k_trace5 — every ray visits the nodes and tests the primitives the
-// reference's loop does, in its order — with twice the work to choose from per wave: a lane holds two independent rays ("slots": origin, reciprocals, shear, t_max,
-// link word, stack pointer — 14 registers each — and a stack of its own in LDS), and every phase of an iteration runs for whichever slot of a lane is ready for it.
-// Why: k_trace5's census (profiles/r04_k5_census.txt) — of 64 lanes 37 take the node step, 9 wait on a pending leaf, 16 idle towards the next refill; the triangle test,
-// a third of the instructions, runs with 23 lanes (any-hit: 10). With two rays per lane a lane has a node to step on whenever EITHER slot has (1 - 0.42^2 = 82 % of the
-// lanes instead of 58 %), a leaf phase can wait for twice the lanes without starving the node step, a refill counts idle slots of 128. The price: ten selects per phase
-// to bring the chosen slot's state to the step (and back), the sign masks rebuilt per iteration (the chosen slot changes), half the stack levels per ray in LDS, and
-// registers for two rays (5 waves per SIMD instead of 8: the rays in flight per SIMD go from 512 to 640).
-// ---------------------------------------------------------------------------------------------
-template <bool ANY, int LDS_N>
-__device__ __forceinline__ void trace6_body(const SceneView& sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
-                                            uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
-                                            ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
-                                            float4* __restrict__ L, const float4* __restrict__ contrib,
-                                            DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels,
-                                            int refill_min, int leaf_min, int queue_parts, int rays_per_lane, int hit16, const uint32_t* __restrict__ big_leaf_n) {
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    typedef __attribute__((address_space(3))) u32x2 lds_u2;
-    __shared__ u32x2 lds_stack6[(TRACE_BLOCK / WAVE) * 2 * LDS_N * WAVE];
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wave_in_block = threadIdx.x / WAVE;
-    // per lane and slot a stack of {link word, t0 | phantom count}: levels [0, LDS_N) in LDS as [slot][level][lane], deeper ones in the HBM spill laid out the same way
-    lds_u2* const st_base0 = (lds_u2*)lds_stack6 + wave_in_block * 2 * LDS_N * WAVE + lane;
-    u32x2* const st_spill0 = reinterpret_cast<u32x2*>(spill) + ((size_t)blockIdx.x * (TRACE_BLOCK / WAVE) + wave_in_block) * (size_t)(2 * spill_levels) * WAVE;
-    const uint32_t n = n_ptr ? *n_ptr : n_direct;
-    const uint32_t per_block = (uint32_t)TRACE_BLOCK * 2u * (uint32_t)(rays_per_lane > 0 ? rays_per_lane : 1);
-    const uint32_t blocks_wanted = rays_per_lane > 0 ? (n + per_block - 1u) / per_block : gridDim.x;
-    const uint32_t active_blocks = blocks_wanted < 64u ? (gridDim.x < 64u ? gridDim.x : 64u) : (blocks_wanted < gridDim.x ? blocks_wanted : gridDim.x);
-    if (blockIdx.x >= active_blocks) return;
-    const char* __restrict__ node_base = reinterpret_cast<const char*>(sv.nodes);
-    const char* __restrict__ prim_base = reinterpret_cast<const char*>(sv.prim_recs);
-    auto uniform4 = [](float4 v) {
-        return make_float4(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.x))), __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.y))),
-                           __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.z))), __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.w))));
-    };
-    const float4 root_a = uniform4(reinterpret_cast<const float4*>(node_base)[0]), root_b = uniform4(reinterpret_cast<const float4*>(node_base)[1]);
-    unsigned long long w_nodes = 0, w_rays = 0, w_prims = 0;
-    uint32_t c_nodes = 0;  // any-hit: node visits of this lane's rays (both slots)
-
-    // one ray's state (`sgn`: bits 0-2 dir_is_neg, bit 3 irregular ray, bit 4 a hit has been found, bits 8-9 the shear's kz)
-    struct Slot {
-        V3 ro, id;
-        Float sx, sy, sz, t_max;
-        uint32_t path, cur, sgn, ph;  // (ph: any-hit, the phantoms above the newest stack entry)
-        lds_u2* top;
-        float4 l_new;                 // (any-hit with the render's deferred contributions: L + contrib, summed when the ray is taken)
-    };
-    Slot S0, S1;
-    S0.ro = S0.id = v3s(0.0f); S0.sx = S0.sy = S0.sz = S0.t_max = 0.0f; S0.path = 0u; S0.cur = CUR_IDLE; S0.sgn = 0u; S0.ph = 0u; S0.top = st_base0; S0.l_new = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    S1 = S0;
-    S1.top = st_base0 + LDS_N * WAVE;
-
-    bool exhausted = false;
-    uint32_t w_next = 0, w_end = 0;
-    const uint32_t n_waves = active_blocks * (TRACE_BLOCK / WAVE);
-    uint32_t chunk = n / (n_waves * 8u);
-    chunk = chunk < 128u ? 128u : (chunk > (uint32_t)K3_CHUNK_MAX ? (uint32_t)K3_CHUNK_MAX : chunk);
-    chunk = (chunk + 63u) & ~63u;
-    const uint32_t n_parts = (uint32_t)queue_parts;
-    const uint32_t part_size = ((n + n_parts * 64u - 1u) / (n_parts * 64u)) * 64u;
-    uint32_t part = (n_parts > 1u) ? (__builtin_amdgcn_s_getreg(6164 /* HW_REG_XCC_ID, bits [3:0] */) & (n_parts - 1u)) : 0u;
-    uint32_t parts_left = n_parts;
-    bool prefer1 = false;  // wave-uniform: which slot steps when both of a lane's stand on a node (alternates)
-
-    // a slot takes the ray of queue entry qi: aggregate.rs:76-81 + the ray-constant part of the triangle test + the root (as k_trace5's refill)
-    auto take_ray = [&](Slot& S, uint32_t qi, lds_u2* base) {
-        S.path = queue ? queue[qi] : qi;
-        const float4* rp = reinterpret_cast<const float4*>(rays + S.path);
-        const float4 r0 = rp[0], r1 = rp[1];
-        if (ANY && L) {
-            const float4 l = L[S.path], c = contrib[S.path];
-            S.l_new = make_float4(l.x + c.x, l.y + c.y, l.z + c.z, l.w + c.w);
-        }
-        const V3 o = v3(r0.x, r0.y, r0.z), d = v3(r0.w, r1.x, r1.y);
-        S.ro = o;
-        S.id = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        const bool regular = is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(S.id.x) && is_finite(S.id.y) && is_finite(S.id.z) &&
-                             S.id.x != 0.0f && S.id.y != 0.0f && S.id.z != 0.0f;
-        const RayShear rs = ray_shear(d);
-        S.sx = rs.sx; S.sy = rs.sy; S.sz = rs.sz;
-        S.sgn = (S.id.x < 0.0f ? 1u : 0u) | (S.id.y < 0.0f ? 2u : 0u) | (S.id.z < 0.0f ? 4u : 0u) | (regular ? 0u : 8u) | ((uint32_t)rs.kz << 8);
-        S.t_max = r1.z;
-        S.top = base;
-        S.ph = 0u;
-        // the root (aggregate.rs:92-97, first iteration), by the reference's own chain
-        const Float g = 1.0f + 2.0f * gamma(3);
-        const bool nx = (S.sgn & 1u) != 0u, ny = (S.sgn & 2u) != 0u, nz = (S.sgn & 4u) != 0u;
-        Float t0 = ((nx ? root_a.w : root_a.x) - S.ro.x) * S.id.x;
-        Float t1 = ((nx ? root_a.x : root_a.w) - S.ro.x) * S.id.x;
-        const Float ty0 = ((ny ? root_b.x : root_a.y) - S.ro.y) * S.id.y;
-        Float ty1 = ((ny ? root_a.y : root_b.x) - S.ro.y) * S.id.y;
-        t1 *= g;
-        ty1 *= g;
-        bool ok = !(t0 > ty1 || ty0 > t1);
-        if (ty0 > t0) t0 = ty0;
-        if (ty1 < t1) t1 = ty1;
-        const Float tz0 = ((nz ? root_b.y : root_a.z) - S.ro.z) * S.id.z;
-        Float tz1 = ((nz ? root_a.z : root_b.y) - S.ro.z) * S.id.z;
-        tz1 *= g;
-        ok = ok && !(t0 > tz1 || tz0 > t1);
-        if (tz0 > t0) t0 = tz0;
-        if (tz1 < t1) t1 = tz1;
-        ok = ok && (t0 < S.t_max) && (t1 > 0.0f);
-        S.cur = ok ? __float_as_uint(root_b.z) : (uint32_t)CUR_POP;
-        if (ANY) c_nodes += 1u;
-    };
-    auto retire = [&](Slot& S) {
-        if (S.cur == CUR_DONE) {
-            const bool found = (S.sgn & SGN_HIT) != 0u;
-            if (ANY) {
-                if (occluded_out) occluded_out[S.path] = found ? 1 : 0;
-                if (L && !found) L[S.path] = S.l_new;
-            } else if (!found) {
-                if (hit16) {
-                    reinterpret_cast<float4*>(hits)[S.path] = make_float4(__int_as_float(-1), 0.0f, 0.0f, 0.0f);
-                } else {
-                    float4* hp = reinterpret_cast<float4*>(hits + S.path);  // a miss is all zeros behind prim = -1
-                    hp[0] = make_float4(__int_as_float(-1), 0.0f, 0.0f, 0.0f);
-                    hp[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-            }
-            S.cur = CUR_IDLE;
-        }
-    };
-
-    for (;;) {
-        // ---- refill: idle SLOTS take rays from the wave-private chunk; slot 0's idle lanes first, then slot 1's ----
-        const unsigned long long idle0 = __ballot(S0.cur == CUR_IDLE), idle1 = __ballot(S1.cur == CUR_IDLE);
-        const int n_idle0 = __popcll(idle0), n_idle1 = __popcll(idle1);
-        if ((idle0 | idle1) != 0ull) {
-            if (!exhausted && (n_idle0 + n_idle1 >= refill_min || (idle0 & idle1) == ~0ull)) {
-                while (w_next >= w_end && !exhausted) {
-                    const uint32_t p_begin = part * part_size;
-                    const uint32_t p_end = (p_begin < n) ? ((n - p_begin < part_size) ? n : p_begin + part_size) : p_begin;
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(head + part * 32u, chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base < p_end - p_begin) {
-                        w_next = p_begin + base;
-                        w_end = (p_end - w_next < chunk) ? p_end : w_next + chunk;
-                    } else {
-                        part = (part + 1u == n_parts) ? 0u : part + 1u;
-                        if (--parts_left == 0u) exhausted = true;
-                    }
-                }
-                if (!exhausted) {
-                    const uint32_t take0 = min((uint32_t)n_idle0, w_end - w_next);
-                    if (take0 != 0u && S0.cur == CUR_IDLE) {
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle0, 0u));
-                        if (rank < take0) take_ray(S0, w_next + rank, st_base0);
-                    }
-                    w_next += take0;
-                    const uint32_t take1 = min((uint32_t)n_idle1, w_end - w_next);
-                    if (take1 != 0u && S1.cur == CUR_IDLE) {
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle1, 0u));
-                        if (rank < take1) take_ray(S1, w_next + rank, st_base0 + LDS_N * WAVE);
-                    }
-                    w_next += take1;
-                    w_rays += take0 + take1;
-                    if (!ANY) w_nodes += take0 + take1;
-                }
-            }
-            if (__ballot(S0.cur != CUR_IDLE || S1.cur != CUR_IDLE) == 0ull) {
-                if (exhausted) break;
-                continue;  // private chunk was empty: fetch the next one
-            }
-        }
-        // ---- one uniform step for the slot of each lane that stands on an interior node (both: they take turns) ----
-        {
-            const bool n0 = S0.cur < (uint32_t)CUR_FIRST_SPECIAL, n1 = S1.cur < (uint32_t)CUR_FIRST_SPECIAL;
-            const bool pick1 = n1 && (!n0 || prefer1);
-            const bool at_node = n0 || n1;
-            prefer1 = !prefer1;
-            if (!ANY) w_nodes += 2ull * (unsigned long long)__popcll(__ballot(at_node));
-            const uint32_t sgn = pick1 ? S1.sgn : S0.sgn;
-            // the chosen slots' sign masks (k_trace5 keeps them across iterations: here the choice changes)
-            const unsigned long long m_negx = __ballot(at_node && (sgn & 1u) != 0u), m_negy = __ballot(at_node && (sgn & 2u) != 0u), m_negz = __ballot(at_node && (sgn & 4u) != 0u);
-            const unsigned long long m_irregular = __ballot(at_node && (sgn & 8u) != 0u);
-            if (at_node) {
-                const V3 ro = pick1 ? S1.ro : S0.ro, inv_dir = pick1 ? S1.id : S0.id;
-                const Float t_max = pick1 ? S1.t_max : S0.t_max;
-                uint32_t cur = pick1 ? S1.cur : S0.cur;
-                lds_u2* top = pick1 ? S1.top : S0.top;
-                uint32_t ph_top = pick1 ? S1.ph : S0.ph;
-                lds_u2* const st_base = pick1 ? st_base0 + LDS_N * WAVE : st_base0;
-                // Bounds3f::intersect_p_cached without its `t0 < t_max` (see k_trace5)
-                auto slab = [&](const float4 na, const float4 nb, Float& t0_out) -> bool {
-                    const Float g = 1.0f + 2.0f * gamma(3);
-                    const Float tx0 = (sel_mask(m_negx, na.x, na.w) - ro.x) * inv_dir.x;
-                    Float tx1 = (sel_mask(m_negx, na.w, na.x) - ro.x) * inv_dir.x;
-                    const Float ty0 = (sel_mask(m_negy, na.y, nb.x) - ro.y) * inv_dir.y;
-                    Float ty1 = (sel_mask(m_negy, nb.x, na.y) - ro.y) * inv_dir.y;
-                    const Float tz0 = (sel_mask(m_negz, na.z, nb.y) - ro.z) * inv_dir.z;
-                    Float tz1 = (sel_mask(m_negz, nb.y, na.z) - ro.z) * inv_dir.z;
-                    if (m_irregular == 0ull) {
-                        const Float t0 = vmax3(tx0, ty0, tz0), t1 = vmin3(tx1, ty1, tz1);
-                        t0_out = t0;
-                        return (t0 <= t1 * g) && (t1 > 0.0f);
-                    }
-                    tx1 *= g;
-                    ty1 *= g;
-                    tz1 *= g;
-                    Float t0 = tx0, t1 = tx1;
-                    bool ok = !(t0 > ty1 || ty0 > t1);
-                    if (ty0 > t0) t0 = ty0;
-                    if (ty1 < t1) t1 = ty1;
-                    ok = ok && !(t0 > tz1 || tz0 > t1);
-                    if (tz0 > t0) t0 = tz0;
-                    if (tz1 < t1) t1 = tz1;
-                    t0_out = t0;
-                    return ok && (t1 > 0.0f);
-                };
-                auto push = [&](uint32_t link, uint32_t word1) {
-                    if (top < st_base + LDS_N * WAVE) *top = u32x2{link, word1};
-                    else (st_spill0 + (pick1 ? (size_t)spill_levels * WAVE : (size_t)0))[(size_t)(top - (st_base + LDS_N * WAVE)) + lane] = u32x2{link, word1};
-                    top += WAVE;
-                };
-                const uint32_t neg = (sgn >> (cur >> LINK_AXIS_SHIFT)) & 1u;
-                const uint32_t off_near = (cur << 5) | (neg << 5);
-                const float4* pn = reinterpret_cast<const float4*>(node_base + off_near);
-                const float4* pf = reinterpret_cast<const float4*>(node_base + (off_near ^ 32u));
-                const float4 na = pn[0], nb = pn[1], fa = pf[0], fb = pf[1];
-                Float t0n, t0f;
-                const bool pre_n = slab(na, nb, t0n), pre_f = slab(fa, fb, t0f);
-                const bool hit_n = pre_n && (t0n < t_max), hit_f = pre_f && (t0f < t_max);
-                const uint32_t link_n = __float_as_uint(nb.z), link_f = __float_as_uint(fb.z);
-                if (ANY) {
-                    c_nodes += hit_n ? 1u : 2u;
-                    if (hit_n && hit_f) { push(link_f, ph_top); ph_top = 0u; }
-                    else if (hit_n) ph_top += 1u;
-                } else {
-                    if (hit_n && pre_f) push(link_f, __float_as_uint(t0f));
-                }
-                cur = hit_n ? link_n : (hit_f ? link_f : (uint32_t)CUR_POP);
-                if (pick1) { S1.cur = cur; S1.top = top; if (ANY) S1.ph = ph_top; }
-                else { S0.cur = cur; S0.top = top; if (ANY) S0.ph = ph_top; }
-            }
-        }
-        // ---- postponed leaf phase: a lane with a slot on a leaf waits until enough lanes have one (or no lane can take a node step); one slot per lane and phase ----
-        {
-            const bool l0 = (int32_t)S0.cur < 0, l1 = (int32_t)S1.cur < 0;
-            const unsigned long long leaf_mask = __ballot(l0 || l1);
-            if (leaf_mask != 0ull) {
-                const unsigned long long node_mask = __ballot(S0.cur < (uint32_t)CUR_FIRST_SPECIAL || S1.cur < (uint32_t)CUR_FIRST_SPECIAL);
-                if (__popcll(leaf_mask) >= leaf_min || node_mask == 0ull) {
-                    const bool pick1 = l1 && !l0;
-                    const bool on_leaf = l0 || l1;
-                    w_prims += (unsigned long long)__popcll(leaf_mask);
-                    if (on_leaf) {
-                        const V3 ro = pick1 ? S1.ro : S0.ro;
-                        RayShear rs;
-                        rs.sx = pick1 ? S1.sx : S0.sx; rs.sy = pick1 ? S1.sy : S0.sy; rs.sz = pick1 ? S1.sz : S0.sz;
-                        uint32_t sgn = pick1 ? S1.sgn : S0.sgn;
-                        rs.kz = (int)((sgn >> 8) & 3u);
-                        rs.kx = rs.kz == 2 ? 0 : rs.kz + 1;
-                        rs.ky = rs.kx == 2 ? 0 : rs.kx + 1;
-                        rs.d = v3s(0.0f);
-                        Float t_max = pick1 ? S1.t_max : S0.t_max;
-                        uint32_t cur = pick1 ? S1.cur : S0.cur;
-                        const uint32_t path = pick1 ? S1.path : S0.path;
-                        const uint32_t slot = cur & LINK_INDEX_MASK;
-                        uint32_t leaf_n = (cur >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX;
-                        if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[slot];
-                        const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * sizeof(PrimRec));
-                        const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
-                        TriangleIntersection ti;
-                        bool got = intersect_triangle_nondegenerate(ro, rs, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ti);
-                        got = got && !(__float_as_uint(q2.y) & PRIM_DEGENERATE_BIT);
-                        if (got) {
-                            sgn |= SGN_HIT;
-                            if (!ANY) {
-                                t_max = ti.t;
-                                if (hit16) {
-                                    reinterpret_cast<float4*>(hits)[path] = make_float4(__int_as_float((int32_t)slot), ti.b0, ti.b1, ti.b2);
-                                } else {
-                                    float4* hp = reinterpret_cast<float4*>(hits + path);
-                                    hp[0] = make_float4(__int_as_float((int32_t)slot), ti.t, ti.b0, ti.b1);
-                                    hp[1] = make_float4(ti.b2, 0.0f, 0.0f, 0.0f);
-                                }
-                            }
-                        }
-                        leaf_n -= 1u;
-                        if (ANY && got) cur = CUR_DONE;
-                        else if (leaf_n == 0u) cur = CUR_POP;
-                        else cur = LINK_LEAF | ((leaf_n < LINK_COUNT_MAX ? leaf_n : LINK_COUNT_MAX) << LINK_COUNT_SHIFT) | (slot + 1u);
-                        if (pick1) { S1.cur = cur; S1.sgn = sgn; if (!ANY) S1.t_max = t_max; }
-                        else { S0.cur = cur; S0.sgn = sgn; if (!ANY) S0.t_max = t_max; }
-                    }
-                }
-            }
-        }
-        // ---- pop: one slot per lane and iteration (a lane whose slots both want one pops the second in the next) ----
-        {
-            const bool p0 = S0.cur == (uint32_t)CUR_POP, p1 = S1.cur == (uint32_t)CUR_POP;
-            if (__ballot(p0 || p1) != 0ull) {
-                if (p0 || p1) {
-                    const bool pick1 = !p0;
-                    lds_u2* top = pick1 ? S1.top : S0.top;
-                    lds_u2* const st_base = pick1 ? st_base0 + LDS_N * WAVE : st_base0;
-                    uint32_t ph_top = pick1 ? S1.ph : S0.ph;
-                    const Float t_max = pick1 ? S1.t_max : S0.t_max;
-                    uint32_t cur = CUR_POP;
-                    if (ANY) { c_nodes += ph_top; ph_top = 0u; }
-                    if (top == st_base) cur = CUR_DONE;
-                    else {
-                        top -= WAVE;
-                        u32x2 e;
-                        if (top < st_base + LDS_N * WAVE) e = *top;
-                        else e = __builtin_nontemporal_load(st_spill0 + (pick1 ? (size_t)spill_levels * WAVE : (size_t)0) + (size_t)(top - (st_base + LDS_N * WAVE)) + lane);
-                        if (ANY) { c_nodes += 1u; ph_top = e.y; cur = e.x; }
-                        else if (__uint_as_float(e.y) < t_max) cur = e.x;
-                    }
-                    if (pick1) { S1.cur = cur; S1.top = top; if (ANY) S1.ph = ph_top; }
-                    else { S0.cur = cur; S0.top = top; if (ANY) S0.ph = ph_top; }
-                }
-            }
-        }
-        // ---- retire finished rays ----
-        retire(S0);
-        retire(S1);
-    }
-    if (ANY) {
-        unsigned long long wn = c_nodes;
-        for (int off = 32; off > 0; off >>= 1) wn += __shfl_down(wn, off);
-        w_nodes = wn;
-    }
-    if (lane == 0 && w_rays) {
-        if (ANY) {
-            atomicAdd(&counters->rays_any, w_rays);
-            atomicAdd(&counters->nodes_any, w_nodes);
-            atomicAdd(&counters->tris_any, w_prims);
-        } else {
-            atomicAdd(&counters->rays_closest, w_rays);
-            atomicAdd(&counters->nodes_closest, w_nodes);
-            atomicAdd(&counters->tris_closest, w_prims);
-        }
-    }
-}
-#ifndef K6_WAVES
-#define K6_WAVES 5
-#endif
-#ifndef K6_LDS
-#define K6_LDS (K6_WAVES >= 6 ? 6 : (K6_WAVES == 5 ? 8 : 10))  // stack levels per slot in LDS: 2 slots x 256 lanes x 8 B = 4 KiB per level and workgroup
-#endif
-#define K6_PARAMS K3_PARAMS, const uint32_t* __restrict__ big_leaf_n
-#define K6_ARGS K3_ARGS, big_leaf_n
-template <bool ANY>
-__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K6_WAVES, K6_WAVES))) k_trace6(K6_PARAMS) { trace6_body<ANY, K6_LDS>(K6_ARGS); }
-#endif  // K6_EXPERIMENT
+// (Round 5 built and measured k_trace6 here — TWO rays per lane, each phase run for whichever slot of a lane is ready: bit-exact, 23 % fewer wave iterations, 38.3 instead of 31.4
+// lanes per VALU instruction, and 62 % more instructions per iteration for the selects that bring the chosen slot's state to each phase: K2 91 -> 133 ms, K3 58 -> 79 ms.
+// Rejected with profiles/r05_rejected_two_rays_per_lane.txt; the code left the tree in round 6 (git history: round-5 commits of k_trace.hip).)
 
 __global__ void k_reset_heads3(uint32_t* heads) { for (uint32_t i = threadIdx.x; i < 8 * 32; i += blockDim.x) heads[i] = 0; }
 }  // namespace
@@ -1151,35 +783,15 @@ void wf_trace_census() {
 #endif
 }
 
-// development: SHM_TRACE_GEN=1 traces a triangle scene with the GEN kernels (A/B of the kernels themselves on one workload; needs SHM_HIT16=0: they write 32-byte records)
-#ifdef K6_EXPERIMENT
-// development build only: SHM_TRACE_TWO=1 traces triangle scenes with two rays per lane (k_trace6, a rejected experiment)
-static bool trace_two() { static const int v = [] { const char* e = getenv("SHM_TRACE_TWO"); return e ? atoi(e) : 0; }(); return v != 0; }
-#else
-static bool trace_two() { return false; }
-constexpr int K6_LDS = 0, K6_WAVES = 0;
-#endif
-static bool trace_force_gen() { static const int v = [] { const char* e = getenv("SHM_TRACE_GEN"); return e ? atoi(e) : 0; }(); return v != 0; }
 int wf_trace_prepare(ShmScene* s) {
     if (s->flat.nodes.size() + s->flat.instances.size() + 2 > (size_t)1 << 27) { shm_err() = "more than 2^27 BVH nodes (the traversal kernels address the node array with 32-bit byte offsets)"; return SHM_ERR_UNSUPPORTED; }
-    const bool tri_only = !s->flat.has_spheres && !trace_force_gen();
+    const bool tri_only = !s->flat.has_spheres;
     for (int any = 0; any < 2; ++any) {
         int lds = any ? K5Shape<K5_ANY_WAVES>::LDS : K5Shape<K5_CLOSEST_WAVES>::LDS, per_cu = any ? K5Shape<K5_ANY_WAVES>::PER_CU : K5Shape<K5_CLOSEST_WAVES>::PER_CU;
         if (!tri_only) { lds = any ? K5Shape<K5_GEN_ANY_WAVES>::LDS : K5Shape<K5_GEN_CLOSEST_WAVES>::LDS; per_cu = any ? K5Shape<K5_GEN_ANY_WAVES>::PER_CU : K5Shape<K5_GEN_CLOSEST_WAVES>::PER_CU; }
-        const bool two = tri_only && trace_two();
-        if (two) { lds = K6_LDS; per_cu = K6_WAVES; }
-        if (s->trace3_per_cu_override > 0) per_cu = std::min(per_cu, s->trace3_per_cu_override);
         s->trace3_blocks[any] = s->n_cu * per_cu;
         s->spill3_levels[any] = std::max(0, (int)s->flat.max_leaf_depth + 1 - lds) + 1;
-        if (any && tri_only) {
-            // the order-free occlusion kernel shares the any-hit spill allocation: 4-byte entries, never more levels beyond its LDS window than the exact kernel has
-            int per_cu_f = K5FastShape<K5_FAST_WAVES>::PER_CU;
-            if (s->trace3_per_cu_override > 0) per_cu_f = std::min(per_cu_f, s->trace3_per_cu_override);
-            s->trace3_blocks[2] = s->n_cu * per_cu_f;
-            s->spill3_levels[2] = std::max(0, (int)s->flat.max_leaf_depth + 1 - K5FastShape<K5_FAST_WAVES>::LDS) + 1;
-        }
-        size_t words = (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[any] * WAVE * 2u * (two ? 2u : 1u);  // (8-byte stack entries; k_trace6: two stacks per lane)
-        if (any && tri_only) words = std::max(words, (size_t)s->trace3_blocks[2] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[2] * WAVE);
+        const size_t words = (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[any] * WAVE * 2u;  // (8-byte stack entries)
         void* d = nullptr;
         if (hipMalloc(&d, words * sizeof(uint32_t)) != hipSuccess) { shm_err() = "hipMalloc of the traversal stack spill failed"; return SHM_ERR_OUT_OF_MEMORY; }
         s->allocs.push_back(d);
@@ -1196,29 +808,19 @@ int wf_trace_prepare(ShmScene* s) {
 }
 
 int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct, const ShmRay* rays,
-                    ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib, int hit16, int order_free) {
+                    ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib, int hit16) {
     uint32_t* heads = s->d_heads3 + (any ? 8 * 32 : 0);
     uint32_t* spill = any ? s->d_spill3_any : s->d_spill3;
     hipLaunchKernelGGL(k_reset_heads3, dim3(1), dim3(64), 0, stream, heads);
     const int leaf_min = any ? s->leaf_min_any : s->leaf_min;
-    const bool tri_only = !s->flat.has_spheres && !trace_force_gen();
+    const bool tri_only = !s->flat.has_spheres;
     // hit16 with the GEN kernels: the split record form (wavefront.h, load_hit_tri) — the second records follow the `capacity` first ones in the hit allocation
     float4* const hit2 = (hit16 && !tri_only && hits) ? reinterpret_cast<float4*>(hits) + s->capacity : nullptr;
 #define TRACE5_LAUNCH(ANY, GEN)                                                                                                               \
     hipLaunchKernelGGL((k_trace5<ANY, GEN>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,  \
                        hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n, \
                        s->d_gen_save[ANY ? 1 : 0], (ANY ? s->other_min_any : s->other_min), hit2)
-#ifdef K6_EXPERIMENT
-#define TRACE6_LAUNCH(ANY)                                                                                                                    \
-    hipLaunchKernelGGL((k_trace6<ANY>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,   \
-                       hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n)
-    if (tri_only && trace_two()) { if (any) TRACE6_LAUNCH(true); else TRACE6_LAUNCH(false); }
-    else
-#endif
-    if (tri_only && any && order_free) {
-        hipLaunchKernelGGL(k_trace5_occluded, dim3(s->trace3_blocks[2]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, hits, occluded, L, contrib, s->d_counters,
-                           spill, s->spill3_levels[2], s->refill_min_fast, s->leaf_min_fast, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n, (float4*)nullptr, 0, (float4*)nullptr);
-    } else if (tri_only) { if (any) TRACE5_LAUNCH(true, false); else TRACE5_LAUNCH(false, false); }
+    if (tri_only) { if (any) TRACE5_LAUNCH(true, false); else TRACE5_LAUNCH(false, false); }
     else { if (any) TRACE5_LAUNCH(true, true); else TRACE5_LAUNCH(false, true); }
 #undef TRACE5_LAUNCH
     LAUNCH_TRY(any ? "k_trace<any>" : "k_trace<closest>");

@@ -13,6 +13,10 @@
 #ifndef K_ENV_LIGHT
 #define K_ENV_LIGHT false
 #endif
+#if K_ENV_LIGHT  // (the *_env.hip units' kernels carry their own names: a kernel trace tells them from the units without the light — tools/kernel_coverage.py)
+#define k_vertex k_vertex_env
+#define k_vertex_w3 k_vertex_w3_env
+#endif
 namespace {
 
 // The queue K2 leaves is in image order: neighbouring lanes hit different materials, and this half of the vertex is where materials differ most
@@ -237,13 +241,6 @@ __global__ void __launch_bounds__(SHADE2_BLOCK) __attribute__((amdgpu_waves_per_
 
 }  // namespace
 
-// material-sorted chunks: on when the scene holds more than one material (SHM_VERTEX_SORT=0 / 1 overrides, for A/B runs)
-static inline bool wf_vertex_sort(const ShmScene* s) {
-    static int forced = -2;
-    if (forced == -2) { const char* e = getenv("SHM_VERTEX_SORT"); forced = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
-    if (forced >= 0) return forced == 1;
-    return s->flat.materials.size() > 1;
-}
 #define WF_VERTEX_LAUNCH_W3(TRI, TEX, SORT)                                                                                                    \
     do {                                                                                                                                       \
         hipLaunchKernelGGL((k_vertex_w3<TRI, TEX, SORT>), dim3(a.blocks * 3 / 2), dim3(SHADE2_BLOCK), 0, a.stream, s->dsv, s->pa, a.q_in ? a.q_in : s->d_q_active[a.cur], \

@@ -4,12 +4,10 @@
 #include "k_vertex.inl"
 
 int wf_launch_vertex_tri_env(ShmScene* s, const ShadeArgs& a) {
-    if (wf_vertex_sort(s)) WF_VERTEX_LAUNCH_W3(true, false, true);
-    else WF_VERTEX_LAUNCH_W3(true, false, false);
+    WF_VERTEX_LAUNCH_W3(true, false, true);
     return SHM_OK;
 }
 int wf_launch_vertex_gen_env(ShmScene* s, const ShadeArgs& a) {
-    if (wf_vertex_sort(s)) WF_VERTEX_LAUNCH(false, false, true);
-    else WF_VERTEX_LAUNCH(false, false, false);
+    WF_VERTEX_LAUNCH(false, false, true);
     return SHM_OK;
 }

@@ -2,7 +2,6 @@
 #include "k_vertex.inl"
 
 int wf_launch_vertex_gen(ShmScene* s, const ShadeArgs& a) {
-    if (wf_vertex_sort(s)) WF_VERTEX_LAUNCH(false, false, true);
-    else WF_VERTEX_LAUNCH(false, false, false);
+    WF_VERTEX_LAUNCH(false, false, true);
     return SHM_OK;
 }

@@ -2,7 +2,6 @@
 #include "k_vertex.inl"
 
 int wf_launch_vertex_tex(ShmScene* s, const ShadeArgs& a) {
-    if (wf_vertex_sort(s)) WF_VERTEX_LAUNCH(false, true, true);
-    else WF_VERTEX_LAUNCH(false, true, false);
+    WF_VERTEX_LAUNCH(false, true, true);
     return SHM_OK;
 }

@@ -231,7 +231,7 @@ static uint64_t max_batch_paths() {
     uint64_t max_cap = 1ull << 29;
     if (const char* e = getenv("SHM_BATCH_PATHS")) {
         long long v = atoll(e);
-        if (v >= 4096) max_cap = (uint64_t)v;
+        if (v >= 4096) max_cap = std::min<uint64_t>((uint64_t)v, (1ull << 30) - 4096ull);  // (below 2^30: the layered scatter kernel's jobs carry two flag bits above the path index)
     }
     return max_cap;
 }
@@ -248,10 +248,10 @@ static uint64_t max_batch_paths() {
 // `env_plain`: the scene's only image is an environment map. No path-integrator render of it reaches a HAS_TEX kernel unless options.force_diffuse asks for that code — and even
 // there the differentials are dead values (no material binds a texture), so the auxiliary-ray arrays are never allocated for it. Every class has its instantiation: the lean
 // kernel's and the sorted fused kernel's ENV_LIGHT ones (all-diffuse; glass, metal), the K_ENV_LIGHT units of the staged kernels (coated materials)
-static bool env_plain_scene(const ShmScene* s) { return s->env_lean && s->flat.has_image_light && !s->flat.has_material_textures; }
+static bool env_plain_scene(const ShmScene* s) { return s->flat.has_image_light && !s->flat.has_material_textures; }
 static bool env_lean_scene(const ShmScene* s) { return env_plain_scene(s) && s->flat.diffuse_only; }
 // (the shapes and classes whose every bounce the material-sorted fused all-materials kernel takes: k_shade_tail*.hip, k_shade_fused_*.hip)
-static bool fused_all_from_0(const ShmScene* s) { return !s->flat.has_class[CLASS_LAYERED] && s->tail_fused_bounce == 0 && (!s->flat.has_spheres || s->fused_gen); }
+static bool fused_all_from_0(const ShmScene* s) { return !s->flat.has_class[CLASS_LAYERED] && s->tail_fused_bounce == 0; }
 static bool scene_is_lean(const ShmScene* s) { return s->flat.diffuse_only && (!s->flat.has_textures || env_lean_scene(s)); }
 static bool tex_ws(const ShmScene* s) { return s->flat.has_textures && !env_plain_scene(s); }  // the auxiliary-ray arrays (and k_generate<true>)
 // (round 5) scenes whose every bounce shades with ONE fused kernel that knows bounce 0's constants (ShadeArgs::first_bounce): the lean class, and — without textures or coated
@@ -293,8 +293,6 @@ static uint64_t workspace_cap(const ShmScene* s, bool need_staged) {
 // Which of the small scene tables a kernel with `budget` bytes of LDS to spare stages there (wavefront.h, stage_scene_tables): greedily, in the enum's order.
 LdsTables wf_lds_tables(const ShmScene* s, uint32_t budget) {
     LdsTables t = {};
-    const char* e = getenv("SHM_LDS_TABLES");
-    if (e && atoi(e) == 0) return t;
     const shm_host::FlatScene& f = s->flat;
     auto pad16 = [](size_t b) { return (size_t)((b + 15u) & ~(size_t)15u); };  // (dev_upload allocates whole 16-byte groups)
     const size_t want[N_LDS_TABLES] = {
@@ -443,6 +441,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     std::vector<ShmBvhNode> pair_nodes;
     std::vector<uint32_t> big_leaf_n;
     std::vector<ShmInstance> pair_instances = f.instances;
+    for (ShmInstance& in : pair_instances) in.pad[0] = 0xffffffffu;  // (the slot of the instance's leaf, filled in below; 0xffffffff: not seen yet)
     {
         const std::vector<ShmBvhNode>& dn = f.nodes;
         std::vector<uint32_t> new_index(dn.size(), 0xffffffffu);
@@ -452,7 +451,6 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
         roots.erase(std::unique(roots.begin(), roots.end()), roots.end());
         uint32_t next = 0;
         std::vector<uint32_t> stack;
-        static const int layout = [] { const char* e = getenv("SHM_NODE_LAYOUT"); return e ? atoi(e) : 1; }();  // 0: the first child's block next; 1: the larger child's (default)
         for (uint32_t r : roots) {
             if (r >= dn.size()) { g_err = "instance root node out of range"; return fail(SHM_ERR_INVALID_ARGUMENT); }
             // (a root inside another root's tree — an instanced SUB-tree — would get two device indices: named, not mis-traversed)
@@ -472,14 +470,11 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
                 new_index[c1] = next + 1u;
                 next += 2;
                 // the child whose block of children comes next (and, half of the time, in the same 128-byte line): the one a ray is more likely to enter
-                bool first_next = true;
-                if (layout >= 1) {
-                    auto area = [&](const ShmBvhNode& n) {
-                        const float dx = n.bmax[0] - n.bmin[0], dy = n.bmax[1] - n.bmin[1], dz = n.bmax[2] - n.bmin[2];
-                        return dx * dy + dy * dz + dz * dx;
-                    };
-                    first_next = !(area(dn[c1]) > area(dn[c0]));
-                }
+                auto area = [&](const ShmBvhNode& n) {
+                    const float dx = n.bmax[0] - n.bmin[0], dy = n.bmax[1] - n.bmin[1], dz = n.bmax[2] - n.bmin[2];
+                    return dx * dy + dy * dz + dz * dx;
+                };
+                const bool first_next = !(area(dn[c1]) > area(dn[c0]));  // (the larger child's; "the first child's block next" measured 1 % slower in round 4)
                 stack.push_back(first_next ? c1 : c0);
                 stack.push_back(first_next ? c0 : c1);
             }
@@ -505,6 +500,9 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
                 const uint32_t kind1 = n.n_prims == 1 ? f.prim_recs[n.offset].kind_index : 0u;
                 if (kind1 & shm::PRIM_INSTANCE_BIT) {
                     const uint32_t idx = kind1 & shm::PRIM_INDEX_MASK;
+                    // (one leaf per ShmInstance: the traversal finds the instance's leaf slot — what a hit inside it is named by — in this record. Two instance primitives
+                    //  that shared one ShmInstance would overwrite each other's slot: refused, the host gives each primitive its own record)
+                    if (pair_instances[idx].pad[0] != 0xffffffffu) { g_err = "two instance primitives share one ShmInstance record (give each TransformedPrimitive its own)"; return fail(SHM_ERR_INVALID_ARGUMENT); }
                     pair_instances[idx].pad[0] = n.offset;
                     n.offset = LINK_LEAF | LINK_OTHER | idx;
                 } else if (kind1 & (shm::PRIM_SPHERE_BIT | shm::PRIM_PATCH_BIT)) {
@@ -573,10 +571,7 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     hipMemset(s->d_counters, 0, sizeof(DeviceCounters));
 
     // Tuning knobs (development): defaults are the measured optimum on S3
-    if (const char* e = getenv("SHM_PIX_GROUP")) { long long v2 = atoll(e); if (v2 >= 1) s->pix_group = (uint32_t)std::min<long long>(v2, 0x7fffffffll); }
-    if (const char* e = getenv("SHM_QUEUE_PARTS")) { int v2 = atoi(e); if (v2 == 1 || v2 == 8) s->queue_parts = v2; }
     // the lean diversion (k_vertex.inl): triangle-only scenes without textures that hold plain diffuse materials BESIDE other classes
-    if (const char* e = getenv("SHM_ENV_LEAN")) s->env_lean = atoi(e) != 0 ? 1 : 0;
     // scenes with material textures: the split pass (k_split_plain) where a quarter of the primitives or more carry a plain DiffuseMaterial (the textured Cornell box, whose
     // only plain material is its emitter's, would pay a pass per bounce for a handful of hits; SHM_SPLIT_PASS=0 / 1 overrides)
     // (in scenes WITHOUT textures k_vertex diverts such hits itself, k_vertex.inl — its triangle instantiation runs three waves per SIMD; the pass as a kernel of its own in front of
@@ -584,27 +579,18 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     s->split_pass = (s->flat.has_material_textures && !scene_is_lean(s) && s->flat.n_plain_diffuse_prims * 4ull >= (uint64_t)s->flat.prim_recs.size()) ? 1 : 0;
     if (const char* e = getenv("SHM_SPLIT_PASS")) s->split_pass = (atoi(e) != 0 && !scene_is_lean(s) && s->flat.n_plain_diffuse_prims > 0) ? 1 : 0;
     s->lean_divert = ((!s->flat.has_textures || env_plain_scene(s)) && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s)) || s->split_pass;
-    if (const char* e = getenv("SHM_LEAN_DIVERT")) s->lean_divert = s->lean_divert && atoi(e) != 0;
     // a shallow tree means short rays, and short rays want fewer, fuller waves (C2's 63-node box: 15.5 -> 15.1 ms per frame at 8 rays per lane); a deep
     // tree means long dependent chains per ray, which want every wave the device has (C4: 8 costs 2 %) — profiles/r03_trace_rays_per_lane_sweep.txt
     if (f.nodes.size() < 4096) s->trace_rays_per_lane = 8;
     if (const char* e = getenv("SHM_TRACE_RAYS_PER_LANE")) { int v2 = atoi(e); if (v2 >= 0 && v2 <= 4096) s->trace_rays_per_lane = v2; }
-    if (const char* e = getenv("SHM_CONCURRENT_SCATTER")) s->concurrent_scatter = atoi(e) != 0;
     s->lds_tables = wf_lds_tables(s, LDS_TABLE_BUDGET);
     s->lds_tables_small = wf_lds_tables(s, LDS_TABLE_BUDGET_SMALL);
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_REFILL_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min_any = v2; }
-    if (const char* e = getenv("SHM_TRACE3_BLOCKS_PER_CU")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 8) s->trace3_per_cu_override = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_any = v2; }
-    if (const char* e = getenv("SHM_LEAF_MIN_FAST")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min_fast = v2; }
-    if (const char* e = getenv("SHM_REFILL_MIN_FAST")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min_fast = v2; }
-    if (const char* e = getenv("SHM_ANY_ORDER_FREE")) s->any_order_free = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_OTHER_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min = s->other_min_any = v2; }
     if (const char* e = getenv("SHM_TAIL_FUSED_BOUNCE")) { const int v2 = atoi(e); s->tail_fused_bounce = v2 >= 0 ? v2 : 1 << 30; }
-    if (const char* e = getenv("SHM_FUSED_GEN")) s->fused_gen = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("SHM_FUSED_TEX")) s->fused_tex = atoi(e);  // (0: never; 1: where the scene holds more than one BxDF class; 2: development — always)
-    if (const char* e = getenv("SHM_TAIL_SORT")) s->tail_sort = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SHM_OTHER_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->other_min_any = v2; }
     if ((rc = wf_trace_prepare(s)) != SHM_OK) return fail(rc);
     DBG("scene: %u nodes, depth %u, trace blocks %d / %d, spill levels %d / %d", (unsigned)f.nodes.size(), f.max_leaf_depth, s->trace3_blocks[0], s->trace3_blocks[1],
@@ -730,23 +716,19 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_any, ev_shade;
     bool used_overlap = false;
     HIP_TRY(hipEventRecord(e_begin, s->stream));
-    static const int shade_per_cu = [] { const char* e = getenv("SHM_SHADE_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 16) ? v : 4; }();
-    const int shade_blocks = s->n_cu * shade_per_cu;
+    const int shade_blocks = s->n_cu * 4;  // (the fused / vertex / scatter launchers scale this by their own waves per SIMD)
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += pix_per_batch) {
         uint32_t n_pix = (uint32_t)std::min<uint64_t>(pix_per_batch, n_pixels - p0);
         uint32_t total = n_pix * (uint32_t)n_samples;
         const uint32_t* pixels = s->d_pixels + p0;
-        // the fused kernel's own scene class under the path integrator: bounce 0 runs on known constants (k_generate<., LEAN>, ShadeArgs::first_bounce; SHM_LEAN_FIRST_BOUNCE=0: A/B)
-        const bool layered_staged = [] { const char* e = getenv("SHM_LAYERED_STAGED"); return !(e && atoi(e) == 0); }();  // (the LayeredBxDF class as dense per-wave stages; read per render: the tests flip it)
-        const bool lean_first_on = [] { const char* e = getenv("SHM_LEAN_FIRST_BOUNCE"); return !(e && atoi(e) == 0); }();  // (read per render: the tests flip it)
-        const bool lean_first = lean_first_on && (!staged || (first_bounce_candidate(s) && params->force_diffuse == 0)) && !random_walk && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && !s->pa.aux0 && s->pa.rng0;
+        // the fused kernel's own scene class under the path integrator: bounce 0 runs on known constants (k_generate<., LEAN>, ShadeArgs::first_bounce)
+        const bool lean_first = (!staged || (first_bounce_candidate(s) && params->force_diffuse == 0)) && !random_walk && params->integrator != SHM_INTEGRATOR_SIMPLE_PATH && !s->pa.aux0 && s->pa.rng0;
         // triangle scenes without textures under the path integrator: every kernel that reads the render's hit array is a TRI_ONLY one, and none reads a triangle hit's t —
-        // the closest-hit launches write {primitive, b0, b1, b2}, 16 bytes per path instead of the 32-byte ShmHit (SHM_HIT16=0: A/B)
+        // the closest-hit launches write {primitive, b0, b1, b2}, 16 bytes per path instead of the 32-byte ShmHit
         // (round 5: in scenes with textures too — their kernels, compiled for general geometry, read either record form: load_hit_tri)
         // (... and — the split form — in scenes with spheres / bilinear patches: a triangle hit is its 16-byte record, a sphere / patch hit flags a second one with t and phi
         //  (HIT_HAS_SECOND, wavefront.h). Not with instances: a hit inside one names it in the 32-byte record, patched when the instance's marker is popped)
-        s->pa.hit16 = ((!s->flat.has_spheres || !s->flat.has_instances) && params->integrator == SHM_INTEGRATOR_PATH && !random_walk &&
-                       [] { const char* e = getenv("SHM_HIT16"); return !(e && atoi(e) == 0); }()) ? 1u : 0u;
+        s->pa.hit16 = ((!s->flat.has_spheres || !s->flat.has_instances) && params->integrator == SHM_INTEGRATOR_PATH && !random_walk) ? 1u : 0u;
         s->pa.hit2 = (s->pa.hit16 && s->flat.has_spheres) ? reinterpret_cast<const float4*>(s->pa.hit) + s->capacity : nullptr;
         if (s->pa.aux0)
             hipLaunchKernelGGL(k_generate<true>, dim3((total + SHADE_BLOCK - 1) / SHADE_BLOCK), dim3(SHADE_BLOCK), 0, s->stream, s->dsv, s->pa, pixels, n_pix,
@@ -769,8 +751,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
         const bool overlap_batch = s->overlap_paths > 0 && ((uint64_t)total < s->overlap_paths || mixed_lean_layered) && params->max_depth > 0;
         // ... and, whatever the batch size, the LATE bounces of a deep render: from bounce `late_overlap_bounce` on the queues hold a few percent of the paths
         // (C4: 7 % at bounce 6, 1 % at 12) and every launch is a tail (profiles/r03_c4_per_bounce.txt): K3 beside the next K2, the class scatter kernels beside each other.
-        // C4 frame 541 -> 522 ms at 6 (524-528 at 10, 528-534 at 16, 530 at 4; SHM_LATE_OVERLAP_BOUNCE, 0 = off)
-        static const int late_overlap_bounce = [] { const char* e = getenv("SHM_LATE_OVERLAP_BOUNCE"); const int v = e ? atoi(e) : 6; return v >= 1 ? v : 1 << 30; }();
+        // C4 frame 541 -> 522 ms at 6 (524-528 at 10, 528-534 at 16, 530 at 4)
+        constexpr int late_overlap_bounce = 6;
         bool overlap = overlap_batch;
         hipStream_t any_stream = overlap ? s->stream2 : s->stream;
         used_overlap = used_overlap || overlap;
@@ -816,12 +798,12 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                 // from bounce 8, 399 from 4, 388 from 2, 378 from 1, 365 from 0: the default (SHM_TAIL_FUSED_BOUNCE, negative = never; read at scene creation)
                 // (with textures: where there is more than one BxDF class to sort — one class: the fused textured kernel's 128 spilled VGPRs cost more than the staged pair's
                 //  parameter block — and no split pass takes most hits away from the textured kernels; an environment map alone is no texture)
-                const bool fused_tex_ok = s->fused_tex && !s->split_pass && (n_classes_present > 1 || s->fused_tex == 2);
-                const bool fused_all = staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 && (tri_only || s->fused_gen) &&
+                const bool fused_tex_ok = !s->split_pass && n_classes_present > 1;
+                const bool fused_all = staged && bounce >= s->tail_fused_bounce && !s->flat.has_class[CLASS_LAYERED] && params->force_diffuse == 0 &&
                                        (!s->flat.has_textures || env_plain_scene(s) || fused_tex_ok);
                 if (fused_all) {
                     if (env_plain_scene(s)) rc = tri_only ? wf_launch_shade_tail_sorted_env(s, sa) : wf_launch_shade_fused_gen_env(s, sa);
-                    else rc = tri_only ? (s->flat.has_textures ? wf_launch_shade_fused_tex(s, sa) : wf_launch_shade_tail(s, sa))
+                    else rc = tri_only ? (s->flat.has_textures ? wf_launch_shade_fused_tex(s, sa) : wf_launch_shade_tail_sorted(s, sa))
                                        : (s->flat.has_textures ? wf_launch_shade_fused_gen_tex(s, sa) : wf_launch_shade_fused_gen(s, sa));
                 } else if (staged) {
                     // hit half (interaction, emission, get_bsdf -> parameter block, class queues), then one scattering kernel per BxDF
@@ -850,9 +832,8 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     hipEvent_t vertex_done = nullptr;
                     // ... and at any batch size where the diverted fused kernel (latency-bound, three waves per SIMD) has the LayeredBxDF class's scatter kernel
                     // (issue-bound, two) to run beside: complementary bounds (coated S3 at 256 spp: see DESIGN.md section 6)
-                    static const int concurrent_big = [] { const char* e = getenv("SHM_CONCURRENT_BIG"); return e ? atoi(e) : 1; }();
-                    const bool group_big = (concurrent_big == 1 && lean_too && s->flat.has_class[CLASS_LAYERED]) || concurrent_big == 2;  // (2: every staged scene — experiment)
-                    if (s->concurrent_scatter && (overlap || group_big) && n_cls > 1) { vertex_done = ev.get(); hipEventRecord(vertex_done, s->stream); }  // (before the first class's launch)
+                    const bool group_big = lean_too && s->flat.has_class[CLASS_LAYERED];
+                    if ((overlap || group_big) && n_cls > 1) { vertex_done = ev.get(); hipEventRecord(vertex_done, s->stream); }  // (before the first class's launch)
                     std::vector<hipEvent_t> side_done;
                     int k_cls = 0;
                     auto scatter_on = [&](int cls, auto&& launch) {
@@ -878,11 +859,12 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     scatter_on(CLASS_DIELECTRIC, [&](const ShadeArgs& x) { return env ? wf_launch_scatter_dielectric_env(s, x, tri_only) : wf_launch_scatter_dielectric(s, x, tri_only, has_tex); });
                     scatter_on(CLASS_LAYERED, [&](const ShadeArgs& x) {
                         // (options.force_diffuse replaces the BxDF inside this half: the one-pass kernel has that code)
-                        if (params->force_diffuse == 0 && layered_staged && s->capacity < (1u << 30)) {  // (its jobs carry two flag bits above the path index)
+                        if (params->force_diffuse == 0 && s->capacity < (1u << 30)) {  // (its jobs carry two flag bits above the path index)
                             if (env) return tri_only ? wf_launch_scatter_layered_staged_tri_env(s, x) : wf_launch_scatter_layered_staged_gen_env(s, x);
                             return has_tex ? wf_launch_scatter_layered_staged_tex(s, x) : (tri_only ? wf_launch_scatter_layered_staged_tri(s, x) : wf_launch_scatter_layered_staged_gen(s, x));
                         }
-                        if (env) return tri_only ? wf_launch_scatter_layered_tri_env(s, x) : wf_launch_scatter_layered_gen_env(s, x);
+                        // (`env` implies params->force_diffuse == 0: the one-pass kernel is reached from here only past 2^30 paths of workspace, which ensure_workspace never grants —
+                        //  its K_ENV_LIGHT units left the library in round 6 — and under options.force_diffuse, where the textured class's units run)
                         return has_tex ? wf_launch_scatter_layered_tex(s, x) : (tri_only ? wf_launch_scatter_layered_tri(s, x) : wf_launch_scatter_layered_gen(s, x)); });
                     for (hipEvent_t e : side_done) hipStreamWaitEvent(s->stream, e, 0);
                 }
@@ -902,7 +884,7 @@ int shm_render_wave(ShmScene* s, const ShmRenderParams* params, const ShmTile* t
                     hipStreamWaitEvent(any_stream, shaded, 0);
                 }
                 hipEventRecord(c, any_stream);
-                if ((rc = wf_launch_trace(s, true, any_stream, s->d_q_shadow, &s->d_qs->n_shadow[sh], 0, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib, 0, s->any_order_free)) != SHM_OK) return rc;
+                if ((rc = wf_launch_trace(s, true, any_stream, s->d_q_shadow, &s->d_qs->n_shadow[sh], 0, s->pa.shadow_ray, nullptr, nullptr, s->pa.L, s->pa.shadow_contrib)) != SHM_OK) return rc;
                 hipEventRecord(d, any_stream);
                 ev_any.push_back({c, d});
                 k3_done = d;
@@ -965,9 +947,8 @@ int shm_render_device(ShmScene* s, const ShmRenderParams* params, const ShmTile*
     // exist there to show progress / write intermediate images (TODO at :311); a pixel's samples are added to the film in
     // increasing sample_index whatever the grouping, so consecutive waves are fused into launches of at least 64 spp (the
     // reference's own maximum wave size) and as many more as fit the path workspace in one batch (a rank that owns 1/8 of
-    // the tiles takes all 256 spp at once), without changing a single film sum. SHM_FUSE_WAVES=0 keeps one launch per wave.
-    bool fuse = true;
-    if (const char* e = getenv("SHM_FUSE_WAVES")) fuse = atoi(e) != 0;
+    // the tiles takes all 256 spp at once), without changing a single film sum (shm_render_wave is the one-launch-per-wave entry: tests/test_gpu_parity.py holds the two against each other).
+    const bool fuse = true;
     int spp = params->samples_per_pixel;
     uint64_t n_pixels = 0;
     for (uint32_t t = 0; tiles && t < n_tiles; ++t)

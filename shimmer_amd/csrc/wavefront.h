@@ -297,7 +297,7 @@ struct ShmScene {
     uint32_t* d_q_split = nullptr; // scenes with textures and plain diffuse materials: what the split pass leaves to the textured kernels
     int split_pass = 0;            // ... that pass is on (SHM_SPLIT_PASS; a quarter of the primitives or more are plain diffuse)
     uint32_t* d_q_lean = nullptr;  // the lean diversion's queue (triangle-only scenes without textures that hold plain diffuse materials beside others)
-    bool lean_divert = false;      // SHM_LEAN_DIVERT=0 switches it off (A/B)
+    bool lean_divert = false;      // (round 4 A/B: DESIGN.md section 6)
     bool staged = false;           // the scene class runs k_vertex -> k_scatter<class> (everything but all-diffuse triangle scenes without textures)
     bool ws_staged = false;        // the workspace holds the staging arrays
     QueueState* d_qs = nullptr;
@@ -310,30 +310,24 @@ struct ShmScene {
     std::vector<uint64_t> tile_bitmap;  // host scratch of the disjointness check in shm_render_wave
     int n_cu = 256;
     // tuned traversal (k_trace5; the field names date from the retired one-node-step kernels)
-    int trace3_blocks[3] = {0, 0, 0};   // persistent grid of the closest-hit [0] / any-hit [1] / order-free occlusion [2] entry point this scene uses (k_trace.hip: K5Shape)
-    int spill3_levels[3] = {1, 1, 1};   // stack levels beyond the entry point's LDS levels (HBM spill)
-    int trace3_per_cu_override = 0;  // SHM_TRACE3_BLOCKS_PER_CU (development)
+    int trace3_blocks[2] = {0, 0};   // persistent grid of the closest-hit [0] / any-hit [1] entry point this scene uses (k_trace.hip: K5Shape)
+    int spill3_levels[2] = {1, 1};   // stack levels beyond the entry point's LDS levels (HBM spill)
     int leaf_min = 16;             // closest-hit: lanes with a pending leaf before the triangle phase runs (SHM_LEAF_MIN)
     int leaf_min_any = 8;          // any-hit (SHM_LEAF_MIN_ANY)
-    int leaf_min_fast = 24;        // the order-free occlusion kernel: lanes holding a deferred leaf before the triangle phase runs (SHM_LEAF_MIN_FAST)
-    int refill_min_fast = 40;      // ... and its refill threshold (SHM_REFILL_MIN_FAST)
-    int any_order_free = 1;        // development A/B: SHM_ANY_ORDER_FREE=0 renders with the reference-order any-hit kernel
     uint32_t* d_spill3 = nullptr;
     LdsTables lds_tables = {};        // the small tables the shading kernels stage in LDS within the full budget (render.hip: wf_lds_tables; SHM_LDS_TABLES=0: nothing)
     LdsTables lds_tables_small = {};  // ... within the 1.5 KB the material-sorted triangle vertex kernel has to spare
     uint32_t* d_q_emit = nullptr;      // paths of the current fused-kernel launch that hit an emitter (k_emit_jobs)
-    uint32_t* d_big_leaf_n = nullptr;  // n_prims by first primitive slot, only in scenes with a leaf of >= 15 primitives (the link word holds smaller counts)
+    uint32_t* d_big_leaf_n = nullptr;  // n_prims by first primitive slot, only in scenes with a leaf of >= 7 primitives (LINK_COUNT_MAX: the link word holds smaller counts)
     float4* d_rw = nullptr;          // RandomWalk: (le, f cos) per depth per path, 2 * (max_depth + 1) * capacity float4
     size_t rw_floats4 = 0;
     uint32_t* d_spill3_any = nullptr;  // the any-hit kernel may run concurrently with the closest-hit one (second stream)
     float4* d_gen_save[2] = {nullptr, nullptr};  // k_trace5<., GEN> (scenes with spheres / patches / instances): per resident lane two 48-byte areas for the ray state (closest, any)
-    // scenes without a coated material: ONE fused all-materials launch per bounce from this bounce on (SHM_TAIL_FUSED_BOUNCE, negative = never), its chunks sorted by
-    // material (SHM_TAIL_SORT); its instantiations with textures / for general geometry (SHM_FUSED_TEX, SHM_FUSED_GEN = 0: the staged pair there)
-    int tail_fused_bounce = 0, tail_sort = 1, fused_tex = 1, fused_gen = 1;
-    int env_lean = 1;              // an all-diffuse scene whose only image is an ImageInfinitelight runs the lean class's kernels (SHM_ENV_LEAN=0: the textured class's, as until round 5)
+    // scenes without a coated material: ONE fused all-materials launch per bounce from this bounce on (SHM_TAIL_FUSED_BOUNCE, negative = never: the staged kernels before
+    // it — the test instrument that holds the two pipelines against each other), its chunks sorted by material
+    int tail_fused_bounce = 0;
     int other_min = 16, other_min_any = 16;     // ... and the parked non-triangle tests a wave collects before it runs them (SHM_OTHER_MIN, SHM_OTHER_MIN_ANY)
     hipStream_t stream2 = nullptr;
-    bool concurrent_scatter = true;  // SHM_CONCURRENT_SCATTER=0: everything on the render stream (A/B)
     hipStream_t stream_cls[4] = {nullptr, nullptr, nullptr, nullptr};  // staged shading: the scatter kernels of the 2nd .. 4th BxDF class of a bounce run beside the first one's
     uint64_t overlap_paths = 96ull << 20;  // batches below this many paths run K3(b) beside K2(b+1) (SHM_OVERLAP_PATHS; 0 = never)
     // idle lanes before a traversal wave refills: the kernels set a ray up with the root test and six IEEE divisions (200 VALU instructions), so that fewer, fuller refills
@@ -342,8 +336,8 @@ struct ShmScene {
     int refill_min = 40;           // (SHM_REFILL_MIN)
     int trace_rays_per_lane = 4;   // a traversal launch uses as much of its persistent grid as gives each resident lane about this many rays (SHM_TRACE_RAYS_PER_LANE; 0 = always
                                    // the whole grid). profiles/r03_trace_rays_per_lane_sweep.txt: C2 16.8 / 16.1 / 15.8 / 15.8 / 16.5 ms at 0 / 4 / 8 / 16 / 32, C4's K2 276.7 / 276.8 / 282 / 307 / 362
-    uint32_t pix_group = 1024;      // path-slot order [tile][sample][pixel in tile] (SHM_PIX_GROUP; >= n_pix: sample-major)
-    int queue_parts = 8;           // the traversal queue's partitions, one per XCD with stealing (SHM_QUEUE_PARTS: 1 or 8)
+    uint32_t pix_group = 1024;      // path-slot order [tile][sample][pixel in tile] (>= n_pix would be sample-major; swept in round 1: profiles/r01_*)
+    int queue_parts = 8;           // the traversal queue's partitions, one per XCD with stealing
     uint32_t* d_heads3 = nullptr;  // [2 (closest, any)][8 partitions][32 dwords: one 128-B line per head word]
     std::vector<hipEvent_t> events;
     struct DistState* dist = nullptr;  // multi-GPU state (dist.hip): communicator, this rank's tile shard, the gather plan
@@ -373,7 +367,7 @@ WF_INTERNAL void wf_trace_census();  // k_trace.hip: prints the per-phase lane c
 WF_INTERNAL void wf_layered_census();  // k_scatter_layered_staged_tri.hip: the same for a -DLJ_CENSUS build of the staged LayeredBxDF kernel
 WF_INTERNAL int wf_trace_prepare(ShmScene* s);  // grid sizes + stack spill buffers of the two traversal kernels (at scene creation)
 WF_INTERNAL int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* queue, const uint32_t* n_ptr, uint32_t n_direct,
-                                const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib, int hit16 = 0, int order_free = 0);
+                                const ShmRay* rays, ShmHit* hits, uint8_t* occluded, float4* L, const float4* contrib, int hit16 = 0);
 // shading of one path vertex of PathIntegrator::li for every entry of q_active[cur]
 struct ShadeArgs {
     hipStream_t stream;
@@ -400,8 +394,6 @@ WF_INTERNAL int wf_launch_scatter_conductor_env(ShmScene* s, const ShadeArgs& a,
 WF_INTERNAL int wf_launch_scatter_dielectric_env(ShmScene* s, const ShadeArgs& a, bool tri_only);
 WF_INTERNAL int wf_launch_scatter_layered_staged_tri_env(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_scatter_layered_staged_gen_env(ShmScene* s, const ShadeArgs& a);
-WF_INTERNAL int wf_launch_scatter_layered_tri_env(ShmScene* s, const ShadeArgs& a);
-WF_INTERNAL int wf_launch_scatter_layered_gen_env(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_lean_env_diverted(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_lean_gen_env_diverted(ShmScene* s, const ShadeArgs& a);
 WF_INTERNAL int wf_launch_shade_tail_sorted_env(ShmScene* s, const ShadeArgs& a);  // the sorted fused all-materials kernel with an ImageInfinitelight compiled in (k_shade_tail_sorted_env.hip)
@@ -410,7 +402,7 @@ WF_INTERNAL int wf_launch_shade_fused_gen(ShmScene* s, const ShadeArgs& a);    /
 WF_INTERNAL int wf_launch_shade_fused_gen_tex(ShmScene* s, const ShadeArgs& a);  // ... and those with textures (k_shade_fused_gen_tex.hip)
 WF_INTERNAL int wf_launch_shade_fused_tex(ShmScene* s, const ShadeArgs& a);    // ... and for triangle scenes with textures, no coated material (k_shade_fused_tex.hip)
 WF_INTERNAL int wf_launch_shade_tail_sorted(ShmScene* s, const ShadeArgs& a);  // ... with material-sorted chunks (k_shade_tail_sorted.hip)
-WF_INTERNAL int wf_launch_shade_tail(ShmScene* s, const ShadeArgs& a);  // fused, every material class but the coated ones: late bounces of deep renders (k_shade_tail.hip)  // the same kernel over q_lean, in a scene the staged pipeline renders
+// (the unsorted tail kernel of rounds 3-4, k_shade_tail.hip, left the library in round 6: k_shade_tail_sorted.hip below takes its scenes)
 // staged shading (k_vertex_*.hip, k_scatter_*.hip): the hit half of a vertex (interaction, emission + MIS, get_bsdf with its texture
 // evaluation -> BxDF parameter block, pushed to the queue of its BxDF class), then per class the scattering half (NEE, sample_f, RR)
 WF_INTERNAL int wf_launch_vertex_tri(ShmScene* s, const ShadeArgs& a);

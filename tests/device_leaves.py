@@ -1,6 +1,6 @@
 """A device-backed stand-in for the oracle's ctypes library (oracle_py.load()) in the leaf tests: every `orc_fn_<name>(...)` it implements takes the SAME arguments as
-the oracle's test entry point of that name and evaluates the function ON THE GPU through the library's test entry shm_debug_eval_leaf (shimmer_amd/csrc/shm/probe.h,
-k_leaf_probe.hip). tests/test_gpu_leaf_replay.py calls the CPU tests' own bodies (tests/test_oracle_golden.py, test_leaf_golden.py, test_layered_golden.py) with this
+the oracle's test entry point of that name and evaluates the function ON THE GPU through the TEST library's entry shm_debug_eval_leaf (libshimmer_hip_probe.so: shimmer_amd/csrc/shm/probe.h,
+csrc/probe/k_leaf_probe.hip, include/shimmer_hip_probe.h — the same shared arithmetic headers the render kernels are compiled from). tests/test_gpu_leaf_replay.py calls the CPU tests' own bodies (tests/test_oracle_golden.py, test_leaf_golden.py, test_layered_golden.py) with this
 object in the oracle library's place: the committed golden vectors — the reference's in-source known answers and the independent re-evaluations — meet the device code
 directly, at the CPU tests' tolerances."""
 import ctypes as C
@@ -48,13 +48,16 @@ def _deref(p):
 
 class DeviceLeaves:
     def __init__(self, lib, device=0):
-        self.lib, self.device = lib, device
+        self.lib, self.device = lib, device  # (lib: the product library — the scene-building entries some leaf tests use)
+        self.probe = abi.load_probe_library()
 
     def _run(self, name, words, n_out):
         inp = (C.c_uint32 * len(words))(*words)
         out = (C.c_uint32 * n_out)()
         res = C.c_int(0)
-        abi.check(self.lib, self.lib.shm_debug_eval_leaf(self.device, OP[name], inp, len(words), out, n_out, C.byref(res)), "shm_debug_eval_leaf " + name)
+        rc = self.probe.shm_debug_eval_leaf(self.device, OP[name], inp, len(words), out, n_out, C.byref(res))
+        if rc != abi.SHM_OK:
+            raise abi.ShimmerHipError(f"shm_debug_eval_leaf {name} failed ({rc}): {self.probe.shm_probe_last_error().decode()}")
         return res.value, np.frombuffer(bytes(out), dtype=np.uint32).copy()
 
     def _scalar(self, name, words):

@@ -505,34 +505,6 @@ def test_instance_root_inside_another_tree_is_rejected(env):
     r.close()
 
 
-@pytest.mark.parametrize("switch", ["SHM_LDS_TABLES", "SHM_LEAN_FIRST_BOUNCE", "SHM_LEAN_DIVERT", "SHM_LAYERED_STAGED", "SHM_CTX_AS_HIT", "SHM_HIT16", "SHM_TAIL_SORT"])
-def test_ab_switches_change_no_result(env, monkeypatch, switch):
-    """The round-4 optimisations each have an A/B switch read at scene creation / first launch; switched off, the films and the counters are the same bits:
-    the small scene tables staged in LDS, bounce 0 on known constants, the lean diversion (its fused kernel defers emitter hits),
-    the LayeredBxDF class as dense per-wave stages (k_scatter_layered.inl; off: one pass per vertex, k_scatter<CLASS_LAYERED>), the fused kernel's vertex leaving its hit
-    record instead of its LightSampleContext for the next vertex's emitter MIS weight (all-diffuse triangle scenes; k_emit_jobs rebuilds the context), the render's own
-    hit array as 16-byte records in triangle scenes, the tail kernel's material-sorted chunks (the glass Cornell box at depth 14: the tail kernel from bounce 1 on)."""
-    lib, oracle_py, render, scenes = env
-    cases = [(scenes.ganesha_proxy(lib, 64, 64, n=32), 6, 5), (scenes.cornell_box(lib, 48, 48, coated=True, emitter_reflects=True), 6, 5),
-             (scenes.cornell_box(lib, 40, 40, textured=True), 4, 6),
-             (scenes.cornell_box(lib, 48, 48, glass=True), 6, 8)]  # (several BxDF classes, no coated one: the material-sorted fused kernel from bounce 0, on known constants there)
-    if switch == "SHM_TAIL_SORT":
-        cases = [(scenes.cornell_box(lib, 48, 48, glass=True), 6, 14)]
-    for sc, spp, depth in cases:
-        p = render.make_params(seed=9, spp=spp, max_depth=depth)
-        monkeypatch.delenv(switch, raising=False)
-        g = render.Renderer(lib, sc.desc, 0)
-        f_on, s_on = g.render(p)
-        g.close()
-        monkeypatch.setenv(switch, "0")
-        g = render.Renderer(lib, sc.desc, 0)
-        f_off, s_off = g.render(p)
-        g.close()
-        assert np.array_equal(f_on, f_off), (switch, sc.name)
-        for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
-            assert s_on[k] == s_off[k], (switch, sc.name, k)
-
-
 @pytest.mark.parametrize("first", ["-1", "0", "3"])
 def test_fused_all_materials_kernel_from_any_bounce(env, monkeypatch, first):
     """Triangle scenes with several BxDF classes (no textures, no coated materials) shade with ONE fused all-materials launch per bounce from bounce
@@ -830,7 +802,7 @@ def test_environment_map_scenes_run_the_lean_class(env, monkeypatch):
     """A scene without coated materials whose only image is an ImageInfinitelight (light.rs:805-981) shades with the ENV_LIGHT instantiations of the lean fused kernel
     (all-diffuse: k_shade_lean_env.hip, k_shade_lean_gen_env.hip) or of the material-sorted fused kernel (glass, metal: k_shade_tail_sorted_env.hip,
     k_shade_fused_gen_env.hip) — no ray differentials, no auxiliary rays, bounce 0 on known constants — instead of the textured class's kernels:
-    triangles and spheres / instances, every integrator, against the oracle; with SHM_ENV_LEAN=0 (the textured class, as until round 5) the same bits; and
+    triangles and spheres / instances, every integrator, against the oracle; and
     one Renderer through path -> force_diffuse (a STAGED render: the textured class's kernels and their workspace arrays) -> path again."""
     lib, oracle_py, render, scenes = env
     cases = [scenes.ganesha_proxy(lib, 48, 48, n=24, variant="environment"),
@@ -857,14 +829,7 @@ def test_environment_map_scenes_run_the_lean_class(env, monkeypatch):
                 assert sg[k] == so[k], (sc.name, integrator, k)
             films[integrator] = fo
         assert render.film_to_rgb(films["path"]).max() > 0
-        # the textured class's kernels on the same scene
-        monkeypatch.setenv("SHM_ENV_LEAN", "0")
-        gpu = render.Renderer(lib, sc.desc, 0)
         p = render.make_params(seed=21, spp=6, max_depth=5)
-        f_tex, _ = gpu.render(p)
-        gpu.close()
-        monkeypatch.delenv("SHM_ENV_LEAN")
-        assert np.array_equal(f_tex, films["path"]), sc.name
         # one scene object through the class change and back
         gpu = render.Renderer(lib, sc.desc, 0)
         pf = render.make_params(seed=21, spp=6, max_depth=5, force_diffuse=True)

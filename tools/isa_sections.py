@@ -2,7 +2,7 @@
 """Per-section instruction census of the traversal kernels from the compiler's own assembly ("nobody has shown the ISA").
 
 Compiles shimmer_amd/csrc/k_trace.hip exactly as the Makefile does plus -gline-tables-only -save-temps, and attributes every instruction of
-k_trace3<closest, TRI_ONLY> / k_trace3<any, TRI_ONLY> to a section of trace3_body by the source line its .loc names (inlined leaf functions —
+k_trace5<closest, GEN> / k_trace5<any, GEN> to a section of trace5_body by the source line its .loc names (inlined leaf functions —
 shm/shapes.h, shm/fp.h — count towards the section that calls them: the leaf phase). Classes: VALU (v_*), SALU (s_* except waitcnt / nop /
 branches), BRANCH (s_cbranch*, s_branch), VMEM (global_* / buffer_* / scratch_* / flat_*), LDS (ds_*), WAIT (s_waitcnt, s_nop).
 The counts are STATIC (instructions in the code object per section); one loop iteration executes the refill test, at most one pop, one node

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """K2 microbenchmark on S3: device-resident ray batches through shm_trace_closest_device.
 Ray sets: camera (coherent), diffuse-bounce rays off the object (incoherent), the same sorted by a Morton key.
-Prints Mray/s, nodes/ray, algorithmic GB/s. Env knobs (SHM_REFILL_MIN, SHM_LEAF_MIN, SHM_TRACE3_BLOCKS_PER_CU)
+Prints Mray/s, nodes/ray, algorithmic GB/s. Env knobs (SHM_REFILL_MIN, SHM_LEAF_MIN)
 are read at scene creation, so each configuration is a separate process invocation."""
 import ctypes as C
 import os, sys, time
@@ -98,7 +98,7 @@ def survey_8d_rays():
     rays[:, :3], rays[:, 3:6], rays[:, 6] = o, d, np.inf
     return rays
 
-cfg = {k: os.environ.get(k) for k in ("SHM_REFILL_MIN", "SHM_LEAF_MIN", "SHM_TRACE3_BLOCKS_PER_CU")}
+cfg = {k: os.environ.get(k) for k in ("SHM_REFILL_MIN", "SHM_LEAF_MIN")}
 print("config:", cfg, flush=True)
 cam = camera_rays()
 report("camera (tile order)", cam)
