@@ -39,19 +39,6 @@ __device__ __forceinline__ Float sel_mask(unsigned long long mask, Float if_clea
 // One-instruction max / min of three (IEEE maxNum / minNum; used only where no operand can be a NaN, see the slab test).
 __device__ __forceinline__ Float vmax3(Float a, Float b, Float c) { Float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ Float vmin3(Float a, Float b, Float c) { Float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// A cache-line prefetch (gfx950 has no prefetch instruction): one byte of the line into a register nobody reads. `sink` is an in-out operand so that the register stays this
-// variable's for the whole loop — the load writes it whenever it returns, and nothing else may live there meanwhile (two prefetches in flight into it are harmless). The
-// compiler's own s_waitcnt bookkeeping does not know this load: an unknown load in flight can only make its vmcnt(N) waits longer, never shorter (returns are in order).
-__device__ __forceinline__ void prefetch_line(const char* base, uint32_t byte_off, uint32_t& sink) {
-    asm volatile("global_load_ubyte %0, %1, %2" : "+v"(sink) : "v"(byte_off), "s"(base));
-}
-#ifndef K5_PREFETCH_LEAF
-#define K5_PREFETCH_LEAF 0  // a lane that finds itself on a triangle leaf requests the leaf record's line at once (the leaf phase, some iterations later, finds it in L2)
-#endif
-#ifndef K5_PREFETCH_FAR
-#define K5_PREFETCH_FAR 0   // a pushed far child's block of children is requested at the push (its pop is the head of a dependent chain)
-#endif
-
 #define K3_PARAMS SceneView sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr, uint32_t n_direct, uint32_t* head,                    \
                   const ShmRay* __restrict__ rays, ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out, float4* __restrict__ L,                 \
                   const float4* __restrict__ contrib, DeviceCounters* counters, uint32_t* __restrict__ spill, int spill_levels, int refill_min, int leaf_min, \
@@ -154,12 +141,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     chunk = chunk < 64u ? 64u : (chunk > (uint32_t)K3_CHUNK_MAX ? (uint32_t)K3_CHUNK_MAX : chunk);
     chunk = (chunk + 63u) & ~63u;
     uint32_t path = 0;
-#ifndef K5_QUEUE_PREFETCH
-#define K5_QUEUE_PREFETCH 0
-#endif
-    // K5_QUEUE_PREFETCH: the queue entries [q_pre_base, q_pre_base + 64) of the wave's chunk, one per lane, fetched when the PREVIOUS refill ended: a refill's rank-r lane takes
-    // its path index from lane r (one ds_bpermute) instead of a load of its own — one round trip (the ray record) instead of two dependent ones, during which the wave stalls
-    uint32_t q_pre = 0u, q_pre_base = 0xffffffffu;
+    // (Measured and rejected on the refill — round 5: the next refill's queue entries fetched a refill ahead, K2 -0.8 ms, profiles/r05_refill_queue_prefetch.txt; round 6:
+    //  the ray records requested beside the node step's fetches with the set-up behind it, and cache-line prefetches of leaf records / pushed far children: K2 +7-13 % /
+    //  +4-12 %, profiles/r06_rejected_refill_and_prefetch.txt. The kernel is short of issue slots, not of loads in flight.)
     V3 ro = v3s(0.0f), inv_dir = v3s(0.0f);
     // dir_is_neg (aggregate.rs:76-81) twice: as three wave-wide lane masks in scalar registers for the slab tests' selects (sel_mask), and as three bits of `sgn` for the near /
     // far child choice, where the axis varies per lane; and the lanes whose ray is not "regular" (bit 3 of sgn): a non-finite origin, or a direction component that is 0,
@@ -175,7 +159,6 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     rs.kx = 0; rs.ky = 1; rs.kz = 2; rs.d = v3s(0.0f); rs.sx = rs.sy = rs.sz = 0.0f;
     Float t_max = 0.0f;
     uint32_t cur = CUR_IDLE;
-    uint32_t pf_sink = 0u;  // (K5_PREFETCH_*: the register the prefetch loads land in)
 
     // aggregate.rs:76-81 + the ray-constant part of the triangle test (the upper bits of sgn — what has been found so far, the instance — belong to the path, not to the ray)
     auto set_ray = [&](V3 o, V3 d) {
@@ -300,15 +283,6 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     const unsigned long long t_loop0 = __builtin_readcyclecounter();
 #endif
     for (;;) {
-#ifndef K5_PIGGYBACK
-#define K5_PIGGYBACK 0
-#endif
-        // K5_PIGGYBACK (round 6 experiment): a refill only CHOOSES the lanes that take a ray and their paths here; the ray records are fetched beside the node step's
-        // fetches of the lanes that have a node (one round trip serves both: the idle lanes' loads land in the registers the node lanes' loads land in), and the set-up
-        // arithmetic runs behind the node step — the wave does not stall for a refill's own round trip
-        bool taking = false;        // this lane takes a ray in this iteration
-        uint32_t n_taken = 0u;      // wave-uniform: how many do
-        const float4* pg_rp = nullptr;  // ... and its record (the address is made where the path index is: a path read from the queue is waited for THERE, not in front of the node step)
         // ---- refill idle lanes from the wave-private chunk [w_next, w_end); one atomic per `chunk` rays ----
         const unsigned long long idle = __ballot(cur == CUR_IDLE);
         if (GEN) since_other += 1u;
@@ -343,15 +317,10 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
 #endif
                     const uint32_t take = min((uint32_t)n_idle, w_end - w_next);
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                    const bool pre_ok = K5_QUEUE_PREFETCH && queue && q_pre_base == w_next;  // (wave-uniform)
-                    uint32_t pre_path = 0u;
-                    if (pre_ok) pre_path = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank << 2), (int)q_pre);  // (every lane takes part: the source lanes need not be idle)
                     if (cur == CUR_IDLE) {
                         if (rank < take) {
                             const uint32_t qi = w_next + rank;
-                            path = queue ? (pre_ok ? pre_path : queue[qi]) : qi;
-                            if (K5_PIGGYBACK) { taking = true; pg_rp = reinterpret_cast<const float4*>(rays + path); }
-                            else {
+                            path = queue ? queue[qi] : qi;
                             const float4* rp = reinterpret_cast<const float4*>(rays + path);
                             const float4 r0 = rp[0], r1 = rp[1];
 #ifndef K5_L_AT_REFILL
@@ -369,31 +338,22 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                             // the root: tested where the ray is taken from the queue
                             cur = root_test(root_a, root_b) ? __float_as_uint(root_b.z) : (uint32_t)CUR_POP;  // (a miss pops the empty stack: done, retired below)
                             if (ANY) c_nodes += 1u;
-                            }
                         }
                     }
-                    n_taken = take;
                     w_next += take;
                     w_rays += take;
                     if (!ANY) w_nodes += take;
-                    if (K5_QUEUE_PREFETCH && queue) {  // the next refill's entries (it takes at most 64): in flight behind this refill's ray records, consumed ~30 iterations on
-                        q_pre_base = w_next;
-                        const uint32_t qj = w_next + lane;
-                        q_pre = qj < w_end ? queue[qj] : 0u;
-                    }
                     CENSUS(11, 1); CENSUS(12, take);
-                    if (!K5_PIGGYBACK) {
                     m_negx = __ballot((sgn & 1u) != 0u);
                     m_negy = __ballot((sgn & 2u) != 0u);
                     m_negz = __ballot((sgn & 4u) != 0u);
                     m_irregular = __ballot((sgn & 8u) != 0u);
-                    }
 #ifdef K5_CENSUS
                     CENSUS(13, __builtin_readcyclecounter() - t_refill0);  // (the ballots above consume the loaded rays: the refill's memory wait is inside)
 #endif
                 }
             }
-            if (__ballot(cur != CUR_IDLE || taking) == 0ull) {
+            if (__ballot(cur != CUR_IDLE) == 0ull) {
                 if (exhausted) break;
                 continue;  // private chunk was empty: fetch the next one
             }
@@ -404,16 +364,6 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         CENSUS(0, 1); CENSUS(1, __popcll(__ballot(at_node))); CENSUS(2, __popcll(__ballot((cur & 0xC0000000u) == 0x80000000u))); CENSUS(21, __popcll(__ballot(cur >= 0xC0000000u))); CENSUS(3, __popcll(__ballot(cur == CUR_IDLE)));
         CENSUS(4, __popcll(__ballot(cur == CUR_POP))); CENSUS(10, __ballot(at_node) != 0ull ? 1 : 0);
         CENSUS(22, (__ballot(at_node) != 0ull && __popcll(__ballot(at_node)) <= 8) ? 1 : 0);  // (a VALU instruction with 8 or fewer lanes on costs 4.5 x one with 9: profiles/r05_valu_exec.txt)
-        // K5_PIGGYBACK: the new rays' records are requested HERE, just ahead of the node step's fetches, into registers of their own (into the node lanes' registers the
-        // compiler would wait for one load before it issues the other: two loads in flight into one register are a write-after-write hazard to it, whatever the lane
-        // masks say); returns are in order, so whoever waits for a node record has the ray records too — one round trip for both
-        float4 pg_r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pg_r1 = pg_r0, pg_l = pg_r0, pg_c = pg_r0;
-        if (K5_PIGGYBACK && n_taken != 0u) {  // (wave-uniform)
-            if (taking) {
-                pg_r0 = pg_rp[0]; pg_r1 = pg_rp[1];
-                if (ANY && L) { pg_l = L[path]; pg_c = contrib[path]; }
-            }
-        }
         if (at_node) {
             // near child first (aggregate.rs:119-127: dir_is_neg[axis] picks it); pairs start at even indices, so the sibling's record is at byte offset ^ 32
             const uint32_t neg = (sgn >> (cur >> LINK_AXIS_SHIFT)) & 1u;
@@ -435,29 +385,6 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                 if (hit_n && pre_f) push(link_f, __float_as_uint(t0f));  // aggregate.rs:119-127: the far child waits; what is left of its test is `t0 < t_max`
             }
             cur = hit_n ? link_n : (hit_f ? link_f : (uint32_t)CUR_POP);
-            if (K5_PREFETCH_FAR && !GEN) {
-                const bool pushed = ANY ? (hit_n && hit_f) : (hit_n && pre_f);
-                if (pushed && (int32_t)link_f >= 0) prefetch_line(node_base, link_f << 5, pf_sink);  // (an interior far child: the block of ITS children, what its pop will fetch)
-                else if (K5_PREFETCH_LEAF && pushed) prefetch_line(prim_base, (link_f & LINK_INDEX_MASK) << 6, pf_sink);  // (a far leaf: its first record)
-            }
-            if (K5_PREFETCH_LEAF && !GEN && (int32_t)cur < 0) prefetch_line(prim_base, (cur & LINK_INDEX_MASK) << 6, pf_sink);
-        }
-        if (K5_PIGGYBACK && n_taken != 0u) {
-            // the set-up of the rays taken above (aggregate.rs:76-81, the shear, the root): behind the node step, on records that arrived with the node fetches
-            if (taking) {
-                if (ANY && L) l_new = make_float4(pg_l.x + pg_c.x, pg_l.y + pg_c.y, pg_l.z + pg_c.z, pg_l.w + pg_c.w);
-                sgn = 0u;
-                set_ray(v3(pg_r0.x, pg_r0.y, pg_r0.z), v3(pg_r0.w, pg_r1.x, pg_r1.y));
-                t_max = pg_r1.z;
-                top = st_base;
-                if (ANY) ph_top = 0u;
-                cur = root_test(root_a, root_b) ? __float_as_uint(root_b.z) : (uint32_t)CUR_POP;
-                if (ANY) c_nodes += 1u;
-            }
-            m_negx = __ballot((sgn & 1u) != 0u);
-            m_negy = __ballot((sgn & 2u) != 0u);
-            m_negz = __ballot((sgn & 4u) != 0u);
-            m_irregular = __ballot((sgn & 8u) != 0u);
         }
         // ---- postponed leaf phase: lanes standing on a leaf wait until enough of them do (or nothing else can run) ----
         constexpr uint32_t NOT_A_TRIANGLE = PRIM_SPHERE_BIT | PRIM_PATCH_BIT | PRIM_INSTANCE_BIT;
