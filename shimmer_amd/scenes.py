@@ -97,7 +97,7 @@ def test_image(size=64, channels=3, seed=7):
 
 
 def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=False, patch_skew=0.0, textured=False,
-                texture_filter=None, textured_coated_ceiling=True, glass=False, emitter_reflects=False, environment=None):
+                texture_filter=None, textured_coated_ceiling=True, glass=False, emitter_reflects=False, environment=None, glass_too=False):
     """S2 (config C2): 5 walls x 2 + 2 boxes x 5 faces x 2 + light 2 = 32 triangles.
     coated=True: the tall box becomes CoatedConductor (rough interface, Cu), the short one CoatedDiffuse with a scattering
     medium between the interfaces, the floor CoatedDiffuse with a smooth interface (SURVEY §8f-1 materials)."""
@@ -123,6 +123,9 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=Fal
         tall_m = b.material_mix(b.material_mix(red, green, 0.3), b.material_coated_diffuse(reflectance=0.7, roughness=0.1), 0.6)
         floor_m = b.material_mix(white, black, 0.0)  # amount <= 0: always the first
     ceil_m, back_m, left_m, right_m = white, white, red, green
+    if glass_too:  # beside whatever else the scene holds (coated boxes, ...): a smooth glass short box and a rough dielectric left wall — the dielectric class's specular AND general kernels
+        short_m = b.material_dielectric(1.5)
+        left_m = b.material_dielectric(1.5, roughness=0.3)
     if glass:
         left_m = b.material_mix(red, b.material_dielectric(1.33, thin=True), 0.5)
     if textured:
@@ -215,7 +218,7 @@ def cornell_box(lib, width=512, height=512, coated=False, mix=False, patches=Fal
     if environment is not None:  # an ImageInfinitelight shines in through the open front (round 5: the K_ENV_LIGHT units of the staged kernels)
         rot = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float32)
         b.light_image_infinite(environment, scale=0.5, render_from_light=rot)
-    return _finish(b, lib, name="S2 cornell box" + (" (environment map)" if environment is not None else "") + (" (coated)" if coated else "") + (" (mix)" if mix else "") + (" (patches)" if patches else "") + (" (textured)" if textured else "") + (" (glass)" if glass else ""))
+    return _finish(b, lib, name="S2 cornell box" + (" (environment map)" if environment is not None else "") + (" (coated)" if coated else "") + (" (mix)" if mix else "") + (" (patches)" if patches else "") + (" (textured)" if textured else "") + (" (glass)" if glass else "") + (" (+ glass)" if glass_too else ""))
 
 
 def _hash3(ix, iy, iz, seed):

@@ -52,6 +52,14 @@ SCENES = {
     # diverted kernel of a scene with coated materials
     "S2_cornell_reflecting_emitter": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, emitter_reflects=True), 8, 5),
     "S2_cornell_coated_reflecting_emitter": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, coated=True, emitter_reflects=True), 6, 5),
+    # (round 6, found by the kernel-coverage run — profiles/r06_kernel_coverage.txt: until then no test reached these instantiations)
+    # the material-sorted fused all-materials kernel for GENERAL geometry: patches + glass (k_shade_fused_gen.hip), under a map (k_shade_fused_gen_env.hip), with textures (k_shade_fused_gen_tex.hip)
+    "S2_cornell_patches_glass": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, patches=True, glass=True), 6, 8),
+    "S2_cornell_patches_glass_env": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, patches=True, glass=True, environment=scenes.environment_image(32)), 6, 8),
+    "S2_cornell_textured_nocoat_patches": lambda scenes, lib: (scenes.cornell_box(lib, 40, 40, textured=True, textured_coated_ceiling=False, patches=True), 4, 6),
+    # coated + smooth and rough glass under a map: the dielectric class's K_ENV_LIGHT units (k_scatter_specular_env / k_scatter_nonspecular_env), triangles and with patches
+    "S2_cornell_coated_glass_env": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, coated=True, glass_too=True, environment=scenes.environment_image(32)), 6, 8),
+    "S2_cornell_coated_glass_env_patches": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, coated=True, glass_too=True, patches=True, environment=scenes.environment_image(32)), 6, 8),
     "S2_cornell_mix": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, mix=True), 8, 5),  # MixMaterial, nested, with a coated leaf
     # image textures (every mapping / filter / wrap / spectrum type), ray differentials through a mirror and glass
     "S2_cornell_textured": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, textured=True), 8, 6),
@@ -765,6 +773,26 @@ def test_force_diffuse_parity(env, integrator):
         assert np.array_equal(fg, fo) and np.isfinite(render.film_to_rgb(fg)).all()
         for k in ("rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
             assert sg[k] == so[k], k
+        gpu.close(); orc.close()
+
+
+@pytest.mark.parametrize("option", ["force_diffuse", "regularize"])
+def test_rare_options_reach_the_one_pass_kernels(env, option):
+    """options.force_diffuse / regularize change the BxDF INSIDE the scatter half: those renders run the one-pass kernels of each class — k_scatter<CLASS_LAYERED, *, *> for the
+    coated materials (the staged stages have no such code), k_scatter<CLASS_DIELECTRIC, *, *> instead of the specular / general pair, and under a map with regularize their
+    K_ENV_LIGHT units — on scenes WITHOUT textures, triangles and with patches (round 6: the kernel-coverage run found them unreached, profiles/r06_kernel_coverage.txt)."""
+    lib, oracle_py, render, scenes = env
+    cases = [scenes.cornell_box(lib, 40, 40, coated=True, glass_too=True), scenes.cornell_box(lib, 40, 40, coated=True, glass_too=True, patches=True),
+             scenes.cornell_box(lib, 40, 40, coated=True, glass_too=True, environment=scenes.environment_image(32)),
+             scenes.cornell_box(lib, 40, 40, coated=True, glass_too=True, patches=True, environment=scenes.environment_image(32))]
+    for sc in cases:
+        gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+        p = render.make_params(seed=4, spp=4, max_depth=8, force_diffuse=option == "force_diffuse", regularize=option == "regularize")
+        fg, sg = gpu.render(p)
+        fo, so = orc.render(p, n_threads=os.cpu_count() or 1)
+        assert np.array_equal(fg, fo), (sc.name, option)
+        for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+            assert sg[k] == so[k], (sc.name, option, k)
         gpu.close(); orc.close()
 
 

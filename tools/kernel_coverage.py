@@ -48,7 +48,16 @@ def library_kernels(path):
 
 
 def traced_calls(d):
+    """{kernel: launches} of a rocprofv3 --kernel-trace run: its rocpd SQLite database (ROCm 7: the default output; the `top_kernels` view), else the CSV forms."""
     calls = {}
+    files = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    if files:
+        import sqlite3
+        for f in files:
+            for name, n in sqlite3.connect(f).cursor().execute("select name, total_calls from top_kernels"):
+                k = norm(name)
+                calls[k] = calls.get(k, 0) + int(n)
+        return calls, files
     files = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
     if files:
         for f in files:
