@@ -220,7 +220,7 @@ def cpu_baseline(sc, params_full, host_lib, budget_s=15.0):
 
 def side_results(lib, args, render, scenes, headline_scene, log):
     """Other BASELINE.json configurations and the material the real Ganesha uses, timed on this GPU in the same run (one warm-up +
-    one timed frame each; informational, outside `value`)."""
+    two timed frames each, their mean reported; informational, outside `value`)."""
     import ctypes as C
     out = {}
 
@@ -229,13 +229,16 @@ def side_results(lib, args, render, scenes, headline_scene, log):
         p = render.make_params(seed=0, spp=spp, max_depth=depth)
         r.clear()
         r.render_device(p)
-        r.clear()
-        t0 = time.perf_counter()
-        st = r.render_device(p)
-        dt = time.perf_counter() - t0
+        frames = []
+        for _ in range(2):  # one warm-up + TWO timed frames (round 6: single frames differ by +-2 % run to run; both are in the line, the mean is the figure)
+            r.clear()
+            t0 = time.perf_counter()
+            st = r.render_device(p)
+            frames.append(time.perf_counter() - t0)
+        dt = sum(frames) / len(frames)
         r.close()
         rays = st["rays_closest"] + st["rays_any"]
-        out[name] = {"Mray_s": rays / dt / 1e6, "ms": dt * 1e3, "rays": rays, "prims": prims, "spp": spp, "max_depth": depth,
+        out[name] = {"Mray_s": rays / dt / 1e6, "ms": dt * 1e3, "ms_frames": [f * 1e3 for f in frames], "rays": rays, "prims": prims, "spp": spp, "max_depth": depth,
                      "ms_closest": st["ms_trace_closest"], "ms_any": st["ms_trace_any"], "ms_shade": st["ms_shade"]}
         log(f"[bench] side {name}: {rays / dt / 1e6:.0f} Mray/s ({dt * 1e3:.1f} ms)")
 

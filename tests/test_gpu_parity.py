@@ -513,6 +513,25 @@ def test_instance_root_inside_another_tree_is_rejected(env):
     r.close()
 
 
+def test_two_primitives_sharing_one_instance_record_are_rejected(env):
+    """The traversal finds an instance's leaf slot — what a hit inside it is named by — in the ShmInstance record itself: two instance primitives that name ONE record would
+    overwrite each other's slot (advisor, round 5). Scene creation refuses the description with a message instead of reporting the other primitive's slot."""
+    from shimmer_amd import abi
+    lib, oracle_py, render, scenes = env
+    sc = scenes.instanced_scene(lib, 16, 16, n_instances=2)
+    prims = [i for i in range(sc.desc.n_primitives) if sc.desc.primitives[i].shape_kind == abi.SHM_SHAPE_INSTANCE]
+    assert len(prims) >= 2 and sc.desc.primitives[prims[0]].shape_index != sc.desc.primitives[prims[1]].shape_index
+    saved = sc.desc.primitives[prims[1]].shape_index
+    try:
+        sc.desc.primitives[prims[1]].shape_index = sc.desc.primitives[prims[0]].shape_index
+        with pytest.raises(Exception) as ei:
+            render.Renderer(lib, sc.desc, 0).close()
+        assert "instance" in str(ei.value).lower(), str(ei.value)
+    finally:
+        sc.desc.primitives[prims[1]].shape_index = saved
+    render.Renderer(lib, sc.desc, 0).close()  # (the untouched description still loads)
+
+
 @pytest.mark.parametrize("first", ["-1", "0", "3"])
 def test_fused_all_materials_kernel_from_any_bounce(env, monkeypatch, first):
     """Triangle scenes with several BxDF classes (no textures, no coated materials) shade with ONE fused all-materials launch per bounce from bounce
