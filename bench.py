@@ -126,7 +126,7 @@ def committed_pmc(args):
     c = {"FETCH_SIZE": t.get("FETCH_SIZE_bytes_per_dispatch_raw", 0.0) / 1024.0, "WRITE_SIZE": t.get("WRITE_SIZE_bytes_per_dispatch_raw", 0.0) / 1024.0}
     if t.get("valu_lanes_active"):
         c["lanes"] = t["valu_lanes_active"]
-    for k in ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):
+    for k in ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SALU"):
         if k in t:
             c[k] = t[k]
     return c

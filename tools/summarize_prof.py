@@ -71,6 +71,8 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
                 if c in ("FETCH_SIZE", "WRITE_SIZE"):
                     traffic.setdefault(k, {})[c + "_bytes_per_dispatch_raw"] = v * 1024 / n
                     traffic[k]["dispatches"] = n
+                elif c in ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SALU"):
+                    traffic.setdefault(k, {})[c] = v / n  # per dispatch: what bench.py's committed-profile fallback prices the VALU-issue roofline with (committed_pmc)
             # mean active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) when that pass was collected
             if "SQ_THREAD_CYCLES_VALU" in acc[k] and acc[k].get("SQ_ACTIVE_INST_VALU", 0) > 0:
                 lanes = acc[k]["SQ_THREAD_CYCLES_VALU"] / acc[k]["SQ_ACTIVE_INST_VALU"]
