@@ -23,6 +23,19 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.shm_last_error() is not None
 
 
+def test_probe_library_exports_its_header_and_the_product_does_not(lib):
+    """include/shimmer_hip_probe.h is the TEST library's ABI (libshimmer_hip_probe.so: the device leaf probe, round 6): it exports every function that header declares,
+    and the product library exports none of them (no compute call here: loading a HIP library needs no device)."""
+    header = (ROOT / "include" / "shimmer_hip_probe.h").read_text()
+    declared = set(re.findall(r"SHM_API\s+[\w\s\*]+?\b(shm_[a-z_0-9]+)\s*\(", header))
+    assert declared == {"shm_debug_eval_leaf", "shm_probe_last_error"}, declared
+    probe = abi.load_probe_library()
+    for name in declared:
+        assert getattr(probe, name) is not None
+        assert not hasattr(lib, name), name
+    assert not (declared & set(abi.EXPORTS))
+
+
 def test_struct_layouts_match_header(tmp_path):
     assert C.sizeof(abi.ShmBvhNode) == 32 and C.sizeof(abi.ShmPrimitive) == 16 and C.sizeof(abi.ShmSpectrum) == 32
     assert C.sizeof(abi.ShmRay) == 32 and C.sizeof(abi.ShmHit) == 32 and C.sizeof(abi.ShmFilmPixel) == 32 and C.sizeof(abi.ShmTile) == 16
