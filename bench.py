@@ -59,7 +59,7 @@ def _counters_from_db(db, want):
     acc, disp = {}, {}
     for name, counter, value, d, dur in cur.execute("select kernel_name, counter_name, value, dispatch_id, duration from counters_collection"):
         if want == "closest":
-            m = re.search(r"k_trace\d<(\w+)(?:, (\w+))?>", name)
+            m = re.search(r"k_trace\d<(\w+)", name)  # (k_trace5<ANY, GEN, HEAVY>: the first argument decides)
             if not m or m.group(1) != "false":  # first template argument: ANY
                 continue
         elif not re.search(r"k_shade<false, true, false, true\b", name):
@@ -259,11 +259,18 @@ def side_results(lib, args, render, scenes, headline_scene, log):
         # the headline frame with the shapes a real PBRT-v4 scene mixes into its triangles (round 5): the window emitter as ONE bilinear patch (what a quad PLY
         # face becomes, shape/shape.rs:119-134), a sphere beside the object, the object as a TransformedPrimitive (primitive.rs:136-176)
         # ... and the object under an ImageInfinitelight (light.rs:805-981): escaped rays look the map up, next-event estimation samples its distribution
+        # (round 6: "quads" — the object's cells as 2.15 M bilinear patches instead of 4.3 M triangles: what a quad PLY file, the reference's showcase Ganesha, becomes there
+        #  (shape/mesh.rs:233-256): every leaf of the object a non-triangle test — the traversal kernels' five-wave instantiations)
         for variant, name in (("patch_emitter", "S3_patch_emitter"), ("one_sphere", "S3_with_one_sphere"), ("instanced", "S3_instanced"), ("environment", "S3_environment_map"),
-                              ("textured_floor", "S3_textured_floor")):  # (ONE textured material among plain ones: the split pass in front of the textured kernels)
+                              ("textured_floor", "S3_textured_floor"),  # (ONE textured material among plain ones: the split pass in front of the textured kernels)
+                              ("quads", "S3_as_bilinear_patches")):
             sc = scenes.ganesha_proxy(lib, 1024, 1024, n=args.n, variant=variant)
             timed(f"{name}_1024x1024_spp256", sc.desc, 256, args.max_depth, sc.info["n_primitives"])
             del sc
+        # ... the showcase's own class: a CoatedDiffuse object made of bilinear patches
+        sc = scenes.ganesha_proxy(lib, 1024, 1024, n=args.n, coated=True, variant="quads")
+        timed("coated_S3_as_bilinear_patches_1024x1024_spp256", sc.desc, 256, args.max_depth, sc.info["n_primitives"])
+        del sc
         # ... and the reference's showcase class: the coated object under the map (the staged kernels' K_ENV_LIGHT units)
         sc = scenes.ganesha_proxy(lib, 1024, 1024, n=args.n, coated=True, variant="environment")
         timed("coated_S3_environment_map_1024x1024_spp256", sc.desc, 256, args.max_depth, sc.info["n_primitives"])
@@ -311,7 +318,7 @@ def parse_args(argv=None):
     ap.add_argument("--pmc-child", action="store_true", help="internal: the frame a live counter pass profiles (no baseline, no side runs, prints nothing)")
     ap.add_argument("--coated", action="store_true", help="S3 with a CoatedDiffuse object (LayeredBxDF, SURVEY 8f-1) instead of the "
                     "headline diffuse one: a side measurement, not the BASELINE config")
-    ap.add_argument("--variant", default=None, choices=["patch_emitter", "one_sphere", "instanced", "environment", "textured_floor"],
+    ap.add_argument("--variant", default=None, choices=["patch_emitter", "one_sphere", "instanced", "environment", "textured_floor", "quads"],
                     help="development: S3 with a bilinear-patch emitter / one sphere / the object instanced (the side results' scenes) instead of the headline scene")
     ap.add_argument("--shard-of", type=int, default=0, help="development: render only the tiles rank 0 of N would own (no gather), "
                     "to estimate the per-rank time of an N-GPU run on one GPU")

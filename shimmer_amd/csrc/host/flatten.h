@@ -37,6 +37,8 @@ struct FlatScene {
     ShmFilm film;
     uint32_t max_leaf_depth = 0;  // deepest leaf (root = 0); bounds the traversal stack
     float scene_radius = 0.0f;
+    uint64_t n_quadric_patch_prims = 0;  // primitive records that are spheres or bilinear patches (instances not counted): a scene where they are MANY runs the traversal
+                                         // kernels' five-wave instantiations (k_trace.hip, K5_GEN_HEAVY_WAVES: the parked round's registers instead of its spill code)
     bool has_spheres = false;  // any non-triangle shape (sphere or bilinear patch): selects k_trace5<.., GEN = true> and the general-geometry shading instantiations
     bool has_layered = false;  // any Coated* material: selects the k_shade instantiation that carries LayeredBxDF
     bool has_rough_dielectric = false;  // a DielectricMaterial whose roughness is not the constant 0 (the specular / rough split of its scatter kernels)
@@ -288,6 +290,7 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         rec.area_light = pr.area_light;
         if (pr.shape_kind == SHM_SHAPE_SPHERE) {
             if (pr.shape_index >= d->n_spheres) { err = "sphere index out of range"; return SHM_ERR_INVALID_ARGUMENT; }
+            out.n_quadric_patch_prims += 1u;
             rec.kind_index = shm::PRIM_SPHERE_BIT | pr.shape_index;
             out.has_spheres = true;
         } else if (pr.shape_kind == SHM_SHAPE_TRIANGLE) {
@@ -322,12 +325,16 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
             rec.p2[0] = c[2].x; rec.p2[1] = c[2].y; rec.p2[2] = c[2].z;  // p01
             shm::PatchExtra& px = out.patches[pr.shape_index];
             px.p11[0] = c[3].x; px.p11[1] = c[3].y; px.p11[2] = c[3].z;
+            // ... and in the record's own 64 bytes, in the words a patch does not use (mesh, tri, pad[0]): the traversal's patch test reads the fourth corner from the line it
+            // already fetched instead of through a dependent gather from `patches` (k_trace.hip, the parked round; round 6)
+            memcpy(&rec.mesh, &c[3].x, 4); memcpy(&rec.tri, &c[3].y, 4); memcpy(&rec.pad[0], &c[3].z, 4);
             // BilinearPatch::new / is_rectangle (bilinear_patch.rs:40-69, 108-142), evaluated once, with the shared arithmetic
             bool is_rect = shm::blp_is_rectangle(c[0], c[1], c[2], c[3]);
             px.area = shm::blp_area(c[0], c[1], c[2], c[3], is_rect);
             px.flags = (is_rect ? 1u : 0u) | ((((mesh.reverse_orientation != 0) ^ (mesh.transform_swaps_handedness != 0)) ? 2u : 0u)) |
                        (mesh.n ? 4u : 0u) | (mesh.uv ? 8u : 0u);
             rec.kind_index = shm::PRIM_PATCH_BIT | pr.shape_index;
+            out.n_quadric_patch_prims += 1u;
             out.has_spheres = true;
         } else if (pr.shape_kind == SHM_SHAPE_INSTANCE) {
             if (!d->instances || pr.shape_index >= d->n_instances) { err = "instance index out of range"; return SHM_ERR_INVALID_ARGUMENT; }

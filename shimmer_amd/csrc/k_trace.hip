@@ -487,7 +487,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                         uint32_t leaf_n = (cur >> LINK_COUNT_SHIFT) & LINK_COUNT_MAX;
                         if (leaf_n == LINK_COUNT_MAX) leaf_n = big_leaf_n[slot];
                         const float4* pr = reinterpret_cast<const float4*>(prim_base + (size_t)slot * sizeof(PrimRec));
-                        const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+                        const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2], q3 = pr[3];  // (q3: a patch's p11.z in its third word — the whole 64-byte line in one round trip)
                         const uint32_t kind = __float_as_uint(q2.y);
                         // the ray's direction, read back from the ray array (the loop keeps the origin, the reciprocals and the shear); inside an instance it goes through that
                         // instance's matrix again — the product apply_ray_inverse / apply_ray made when the instance was entered, bit for bit
@@ -500,7 +500,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                         }
                         {
                             // (a sphere or a bilinear patch: an instance never parks here — it is alone in its leaf, and such a leaf's link word names it, above)
-                            save_ray_state(1);  // (... and nothing of it is live across the test)
+                            save_ray_state(1);  // (... and nothing of it is live across the test; the five-wave build WITHOUT this save / restore: 40 / 14 spilled VGPRs instead of 10 / 0, S3 as patches 3 736 -> 3 572 Mray/s)
                             bool got;
                             Float t_hit, h0, h1, h2, h_phi;
                             if (kind & PRIM_SPHERE_BIT) {
@@ -513,7 +513,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                                 // BilinearPatch::intersect (bilinear_patch.rs:144-236): the record holds p00, p10, p01; (u, v) go in b0, b1
                                 BilinearIntersection bi;
                                 bi.t = 0.0f; bi.u = 0.0f; bi.v = 0.0f;
-                                got = blp_intersect(ro, rd, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), ld3(sv.patches[kind & PRIM_INDEX_MASK].p11), bi);
+                                got = blp_intersect(ro, rd, t_max, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), v3(q2.z, q2.w, q3.z), bi);  // (p11: in the record's spare words, flatten.h)
                                 t_hit = bi.t; h0 = bi.u; h1 = bi.v; h2 = 0.0f; h_phi = 0.0f;
                             }
                             restore_ray_state(1);
@@ -658,7 +658,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
 template <int WAVES> struct K5Shape { static constexpr int LDS = (WAVES >= 8 ? K5_LDS_AT_8 : (WAVES == 7 ? 11 : (WAVES == 6 ? 13 : 15))), PER_CU = WAVES; };
 #define K5_PARAMS K3_PARAMS, const uint32_t* __restrict__ big_leaf_n, float4* gen_save, int other_min, float4* hit2
 #define K5_ARGS K3_ARGS, big_leaf_n, gen_save, other_min, hit2
-template <bool ANY, bool GEN = false>
+template <bool ANY, bool GEN = false, bool HEAVY = false>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace5(K5_PARAMS);
 template <>
 __global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_CLOSEST_WAVES, K5_CLOSEST_WAVES))) k_trace5<false, false>(K5_PARAMS) {
@@ -683,6 +683,23 @@ __global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_e
 template <>
 __global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_GEN_ANY_WAVES, K5_GEN_ANY_WAVES))) k_trace5<true, true>(K5_PARAMS) {
     trace5_body<true, true, K5Shape<K5_GEN_ANY_WAVES>::LDS>(K5_ARGS);
+}
+// HEAVY (round 6): scenes where the non-triangle tests are the RULE — a quad PLY file becomes one BilinearPatch per face in the reference (shape/mesh.rs:233-256), so a real
+// scene's object is patches, not triangles. At seven waves (72 VGPRs) the parked round's arithmetic lives in spill code: 124 / 94 spilled VGPRs, 164 / 148 B of scratch per
+// lane — harmless where a round runs every 270 iterations (one sphere among 4.3 M triangles), and 0.7 TB of scratch traffic per frame where one runs every 17 (S3 as 2.15 M
+// patches: K2 263 ms, K3 171 ms against 92 / 59 for the same object as triangles). The SAME body at five waves per SIMD holds it in registers (96 VGPRs + 10 spilled / 93 + 0):
+// K2 158, K3 87 ms, 2 261 -> 3 496 Mray/s; with the refill at 24 idle lanes and the patch's fourth corner in its own record (flatten.h) K2 147, K3 77 ms, 3 736 Mray/s
+// (profiles/r06_patch_heavy_scenes.txt); with few non-triangles the seven-wave build stays ahead by 3-10 % (occupancy for the node step): chosen per scene, render.hip.
+#ifndef K5_GEN_HEAVY_WAVES
+#define K5_GEN_HEAVY_WAVES 5
+#endif
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_GEN_HEAVY_WAVES, K5_GEN_HEAVY_WAVES))) k_trace5<false, true, true>(K5_PARAMS) {
+    trace5_body<false, true, K5Shape<K5_GEN_HEAVY_WAVES>::LDS>(K5_ARGS);
+}
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_GEN_HEAVY_WAVES, K5_GEN_HEAVY_WAVES))) k_trace5<true, true, true>(K5_PARAMS) {
+    trace5_body<true, true, K5Shape<K5_GEN_HEAVY_WAVES>::LDS>(K5_ARGS);
 }
 
 // (Round 5 built and measured k_trace6 here — TWO rays per lane, each phase run for whichever slot of a lane is ready: bit-exact, 23 % fewer wave iterations, 38.3 instead of 31.4
@@ -716,6 +733,7 @@ int wf_trace_prepare(ShmScene* s) {
     for (int any = 0; any < 2; ++any) {
         int lds = any ? K5Shape<K5_ANY_WAVES>::LDS : K5Shape<K5_CLOSEST_WAVES>::LDS, per_cu = any ? K5Shape<K5_ANY_WAVES>::PER_CU : K5Shape<K5_CLOSEST_WAVES>::PER_CU;
         if (!tri_only) { lds = any ? K5Shape<K5_GEN_ANY_WAVES>::LDS : K5Shape<K5_GEN_CLOSEST_WAVES>::LDS; per_cu = any ? K5Shape<K5_GEN_ANY_WAVES>::PER_CU : K5Shape<K5_GEN_CLOSEST_WAVES>::PER_CU; }
+        if (!tri_only && s->gen_heavy) { lds = K5Shape<K5_GEN_HEAVY_WAVES>::LDS; per_cu = K5Shape<K5_GEN_HEAVY_WAVES>::PER_CU; }
         s->trace3_blocks[any] = s->n_cu * per_cu;
         s->spill3_levels[any] = std::max(0, (int)s->flat.max_leaf_depth + 1 - lds) + 1;
         const size_t words = (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[any] * WAVE * 2u;  // (8-byte stack entries)
@@ -743,11 +761,12 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
     const bool tri_only = !s->flat.has_spheres;
     // hit16 with the GEN kernels: the split record form (wavefront.h, load_hit_tri) — the second records follow the `capacity` first ones in the hit allocation
     float4* const hit2 = (hit16 && !tri_only && hits) ? reinterpret_cast<float4*>(hits) + s->capacity : nullptr;
-#define TRACE5_LAUNCH(ANY, GEN)                                                                                                               \
-    hipLaunchKernelGGL((k_trace5<ANY, GEN>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,  \
+#define TRACE5_LAUNCH(ANY, ...)                                                                                                               \
+    hipLaunchKernelGGL((k_trace5<ANY, __VA_ARGS__>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,  \
                        hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n, \
                        s->d_gen_save[ANY ? 1 : 0], (ANY ? s->other_min_any : s->other_min), hit2)
     if (tri_only) { if (any) TRACE5_LAUNCH(true, false); else TRACE5_LAUNCH(false, false); }
+    else if (s->gen_heavy) { if (any) TRACE5_LAUNCH(true, true, true); else TRACE5_LAUNCH(false, true, true); }
     else { if (any) TRACE5_LAUNCH(true, true); else TRACE5_LAUNCH(false, true); }
 #undef TRACE5_LAUNCH
     LAUNCH_TRY(any ? "k_trace<any>" : "k_trace<closest>");

@@ -585,6 +585,12 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_TRACE_RAYS_PER_LANE")) { int v2 = atoi(e); if (v2 >= 0 && v2 <= 4096) s->trace_rays_per_lane = v2; }
     s->lds_tables = wf_lds_tables(s, LDS_TABLE_BUDGET);
     s->lds_tables_small = wf_lds_tables(s, LDS_TABLE_BUDGET_SMALL);
+    // the traversal kernels' instantiation for scenes with spheres / patches: five waves per SIMD where those shapes are a sixth of the primitive records or more (k_trace.hip,
+    // K5_GEN_HEAVY_WAVES; S3 with 100 / 50 / 25 / 10 / 3 % of the object's cells as patches, five against seven waves: +53 / +24 / +7 / -3 / -7 %). At five waves a refill is
+    // cheaper to make early (24 idle lanes: S3 as patches 3 506 -> 3 685 Mray/s, a quarter of it as patches +1.4 %; profiles/r06_patch_heavy_scenes.txt)
+    s->gen_heavy = f.has_spheres && f.n_quadric_patch_prims * 6ull >= (uint64_t)f.prim_recs.size();
+    if (const char* e = getenv("SHM_GEN_HEAVY")) s->gen_heavy = f.has_spheres && atoi(e) != 0;
+    if (s->gen_heavy) s->refill_min = s->refill_min_any = 24;
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_REFILL_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }

@@ -23,13 +23,13 @@ namespace shm {
 struct PrimRec {
     Float p0[3], p1[3], p2[3];
     uint32_t kind_index;  // bit 31: sphere, bit 30: bilinear patch; low bits: sphere / patch index (0 for a triangle)
-    uint32_t mesh;        // triangle: mesh id
-    uint32_t tri;         // triangle: global triangle index
+    uint32_t mesh;        // triangle: mesh id                 | bilinear patch: p11.x (bits)
+    uint32_t tri;         // triangle: global triangle index   | bilinear patch: p11.y
     // ... and, filling the record to 64 bytes, the ShmPrimitive fields the shading kernels read of a hit: one aligned 64-byte fetch gives a triangle test its three vertices
     // (48-byte records straddled a 64-byte boundary every other time) and a vertex its material and emitter as well (a second gather from `primitives` before)
     uint32_t material;
     int32_t area_light;
-    uint32_t pad[2];
+    uint32_t pad[2];      // bilinear patch: pad[0] = p11.z — the fourth corner travels with the record (PatchExtra keeps its own copy for the shading kernels)
 };
 static_assert(sizeof(PrimRec) == 64, "PrimRec is one aligned 64-byte record");
 // A bilinear patch keeps p00, p10, p01 in {p0, p1, p2}; its fourth corner and the per-patch constants live here.

@@ -326,6 +326,8 @@ struct ShmScene {
     // scenes without a coated material: ONE fused all-materials launch per bounce from this bounce on (SHM_TAIL_FUSED_BOUNCE, negative = never: the staged kernels before
     // it — the test instrument that holds the two pipelines against each other), its chunks sorted by material
     int tail_fused_bounce = 0;
+    bool gen_heavy = false;        // a quarter or more of the primitive records are spheres / bilinear patches (a quad PLY file: every face a patch): the traversal kernels'
+                                   // five-wave instantiations (k_trace.hip, K5_GEN_HEAVY_WAVES; SHM_GEN_HEAVY=0 / 1 overrides: the suite runs both)
     int other_min = 16, other_min_any = 16;     // ... and the parked non-triangle tests a wave collects before it runs them (SHM_OTHER_MIN, SHM_OTHER_MIN_ANY)
     hipStream_t stream2 = nullptr;
     hipStream_t stream_cls[4] = {nullptr, nullptr, nullptr, nullptr};  // staged shading: the scatter kernels of the 2nd .. 4th BxDF class of a bounce run beside the first one's

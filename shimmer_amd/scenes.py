@@ -254,7 +254,7 @@ def _value_noise(p, seed, octaves=3):
 
 
 @functools.lru_cache(maxsize=2)
-def cube_sphere(n, seed=1234, amplitude=0.15, shuffle_seed=99):
+def cube_sphere(n, seed=1234, amplitude=0.15, shuffle_seed=99, as_quads=False, quad_fraction=None):
     """Closed genus-0 cube-sphere: 6 faces x n x n quads x 2 triangles with shared vertices (6 n^2 + 2), unit radius,
     radially displaced by value noise; triangle order randomised (seeded Fisher-Yates / permutation)."""
     m = n + 1
@@ -280,7 +280,7 @@ def cube_sphere(n, seed=1234, amplitude=0.15, shuffle_seed=99):
     sph = cube / np.linalg.norm(cube, axis=1, keepdims=True)
     r = 1.0 + amplitude * _value_noise(sph, seed) * 2.0
     verts = (sph * r[:, None]).astype(np.float32)
-    tris = []
+    tris, quads = [], []
     cell_i, cell_j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
     cell_i, cell_j = cell_i.ravel(), cell_j.ravel()
     for fi in range(6):
@@ -288,13 +288,26 @@ def cube_sphere(n, seed=1234, amplitude=0.15, shuffle_seed=99):
         a, b_, c, d = idx[cell_i, cell_j], idx[cell_i + 1, cell_j], idx[cell_i + 1, cell_j + 1], idx[cell_i, cell_j + 1]
         tris.append(np.stack([a, b_, c], 1))
         tris.append(np.stack([a, c, d], 1))
-    tris = np.concatenate(tris).astype(np.uint32)
+        quads.append(np.stack([a, b_, d, c], 1))  # p00, p10, p01, p11 (bilinear_patch.rs:87-98): the same cell as ONE bilinear patch
     rng = np.random.Generator(np.random.PCG64(shuffle_seed))
+    if quad_fraction is not None:  # (development: a MIXED object — this share of the cells as patches, the others as triangle pairs; returns verts, tris, quads)
+        quads = np.concatenate(quads).astype(np.uint32)
+        perm = rng.permutation(quads.shape[0])
+        nq = int(round(quad_fraction * quads.shape[0]))
+        q_cells, t_cells = perm[:nq], perm[nq:]
+        qq = quads[q_cells]
+        cells = quads[t_cells]  # a, b, d, c
+        tt = np.concatenate([np.stack([cells[:, 0], cells[:, 1], cells[:, 3]], 1), np.stack([cells[:, 0], cells[:, 3], cells[:, 2]], 1)]).astype(np.uint32)
+        return verts, tt[rng.permutation(tt.shape[0])], qq
+    if as_quads:  # what the reference makes of a PLY file's quad faces (shape/mesh.rs:233-256): 6 n^2 bilinear patches over the same vertices, order randomised alike
+        quads = np.concatenate(quads).astype(np.uint32)
+        return verts, quads[rng.permutation(quads.shape[0])]
+    tris = np.concatenate(tris).astype(np.uint32)
     tris = tris[rng.permutation(tris.shape[0])]
     return verts, tris
 
 
-def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=False, variant=None, floor_filter="ewa"):
+def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=False, variant=None, floor_filter="ewa", quad_fraction=None):
     """S3 (configs C3/C5): n=599 gives 6*599^2*2 = 4 305 612 triangles and 2 152 808 vertices.
     coated=True: the object is CoatedDiffuse (the material of the reference's Ganesha render, images/shimmer-ganesha-1.png).
     variant (round 5: the shapes a real PBRT-v4 scene mixes into its triangles; same camera, room and object):
@@ -302,17 +315,30 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
       "one_sphere"     a diffuse sphere stands on the floor beside the object (shape/sphere.rs)
       "instanced"      the object is an object definition placed once through a TransformedPrimitive (primitive.rs:136-176)
       "textured_floor" the ground plane's reflectance is an image texture (EWA-filtered, repeated): ONE textured material among plain ones
+      "quads"          (round 6) the object's 6 n^2 cells as bilinear patches instead of 12 n^2 triangles: what a quad PLY file becomes in the reference
       "environment"    no room and no window: the object on its ground plane under an ImageInfinitelight (light.rs:805-981) — escaped rays look the map up, next-event
                        estimation samples its (compensated) piecewise-constant distribution"""
-    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment", "textured_floor", "textured_hidden")
+    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment", "textured_floor", "textured_hidden", "quads")
     b = SceneBuilder()
     b.set_film(width, height)
     rfw = b.set_camera_look_at(lib, (0.0, 0.6, 4.2), (0.0, 0.0, 0.0), (0, 1, 0), 38.0)
     obj = b.material_coated_diffuse(reflectance=0.4, roughness=0.05, thickness=0.01) if coated else b.material_diffuse(0.4)
     wall = b.material_diffuse(0.6)
     black = b.material_diffuse(0.0)
-    verts, tris = cube_sphere(n)
-    if variant == "instanced":
+    if quad_fraction is not None:  # (development: where the five-wave traversal kernels start to pay — a share of the object's cells as patches, the rest as triangles)
+        verts, tris, quads = cube_sphere(n, quad_fraction=quad_fraction)
+        b.add_mesh(_to_render(verts, rfw), tris, obj)
+        if quads.shape[0]:
+            b.add_patch_mesh(_to_render(verts, rfw), quads, obj)
+    else:
+        verts, tris = cube_sphere(n, as_quads=variant == "quads")
+    if quad_fraction is not None:
+        pass
+    elif variant == "quads":
+        # (round 6) the object as 6 n^2 BILINEAR PATCHES — the reference turns every quad face of a PLY file into one (shape/shape.rs:97-137), and the showcase Ganesha is
+        # a quad PLY: the class a real scene's traversal runs in, every leaf a parked non-triangle test
+        b.add_patch_mesh(_to_render(verts, rfw), tris, obj)
+    elif variant == "instanced":
         b.begin_object("object")
         b.add_mesh(verts, tris, obj)  # object space
         b.end_object()

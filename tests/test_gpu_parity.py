@@ -52,6 +52,9 @@ SCENES = {
     # diverted kernel of a scene with coated materials
     "S2_cornell_reflecting_emitter": lambda scenes, lib: (scenes.cornell_box(lib, 64, 64, emitter_reflects=True), 8, 5),
     "S2_cornell_coated_reflecting_emitter": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, coated=True, emitter_reflects=True), 6, 5),
+    # (round 6) the object as bilinear patches — what a quad PLY file becomes in the reference: every leaf of the object a parked non-triangle test
+    "S3_small_quads": lambda scenes, lib: (scenes.ganesha_proxy(lib, 96, 96, n=48, variant="quads"), 8, 5),
+    "S3_small_quads_coated": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="quads", coated=True), 4, 5),
     # (round 6, found by the kernel-coverage run — profiles/r06_kernel_coverage.txt: until then no test reached these instantiations)
     # the material-sorted fused all-materials kernel for GENERAL geometry: patches + glass (k_shade_fused_gen.hip), under a map (k_shade_fused_gen_env.hip), with textures (k_shade_fused_gen_tex.hip)
     "S2_cornell_patches_glass": lambda scenes, lib: (scenes.cornell_box(lib, 48, 48, patches=True, glass=True), 6, 8),
@@ -200,6 +203,35 @@ def test_trace_tree_shapes_and_parked_tests(env, monkeypatch, other_min):
             assert st[k] == so[k], (sc.name, k)
         gpu.close()
         orc.close()
+
+
+@pytest.mark.parametrize("heavy", ["0", "1"])
+def test_both_occupancies_of_the_general_traversal_kernels(env, monkeypatch, heavy):
+    """Scenes with spheres / bilinear patches trace with k_trace5<., GEN> at seven waves per SIMD, or — where those shapes are a sixth of the primitive records or more (a quad
+    PLY file: every face a patch) — at five (k_trace5<., GEN, HEAVY>: the parked round's arithmetic in registers instead of spill code; round 6). The same body: whichever the
+    scene would choose, forced either way (SHM_GEN_HEAVY), hit records, films and all seven counters equal the oracle's."""
+    lib, oracle_py, render, scenes = env
+    monkeypatch.setenv("SHM_GEN_HEAVY", heavy)
+    cases = [(scenes.ganesha_proxy(lib, 64, 64, n=32, variant="quads"), 6, 5), (scenes.ganesha_proxy(lib, 48, 48, n=24, quad_fraction=0.3, coated=True), 4, 5),
+             (scenes.cornell_box(lib, 48, 48, patches=True), 6, 5), (scenes.three_spheres(lib, 48, 32, camera=(0.75, 0.5, 9.0)), 4, 5), (scenes.instanced_scene(lib, 48, 36), 4, 6)]
+    for sc, spp, depth in cases:
+        gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)
+        rays = _rays(sc, 20000, 5)
+        hg, sg = gpu.trace(rays)
+        ho, so = orc.trace(rays)
+        assert all(np.array_equal(hg[k], ho[k]) for k in ("prim", "t", "b0", "b1", "b2", "phi")), sc.name
+        assert sg["nodes_closest"] == so["nodes_closest"] and sg["tris_closest"] == so["tris_closest"], sc.name
+        rays[:, 6] = 2.5
+        ag, s2 = gpu.trace(rays, any_hit=True)
+        ao, s3 = orc.trace(rays, any_hit=True)
+        assert np.array_equal(ag, ao) and s2["nodes_any"] == s3["nodes_any"] and s2["tris_any"] == s3["tris_any"], sc.name
+        p = render.make_params(seed=11, spp=spp, max_depth=depth)
+        fg, stg = gpu.render(p)
+        fo, sto = orc.render(p, n_threads=os.cpu_count() or 1)
+        assert np.array_equal(fg, fo), sc.name
+        for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+            assert stg[k] == sto[k], (sc.name, k)
+        gpu.close(); orc.close()
 
 
 def test_trace_edge_cases(env):
@@ -400,7 +432,8 @@ def test_headline_frame_at_full_size(env):
 
 
 @pytest.mark.parametrize("variant,crop", [("patch_emitter", (504, 440, 520, 456)), ("one_sphere", (152, 920, 168, 936)), ("instanced", (504, 440, 520, 456)),
-                                          ("environment", (504, 440, 520, 456)), ("textured_floor", (504, 840, 520, 856))])
+                                          ("environment", (504, 440, 520, 456)), ("textured_floor", (504, 840, 520, 856)),
+                                          ("quads", (504, 440, 520, 456))])  # (round 6: the object as 2.15 M bilinear patches — the five-wave traversal kernels)
 def test_mixed_shape_frames_at_full_size(env, variant, crop):
     """The headline frame with the shapes a real PBRT-v4 scene mixes into its triangles (bench.py's round-5 side results: the emitter as ONE bilinear patch, a sphere
     beside the object, the object as a TransformedPrimitive; and the object under an ImageInfinitelight: the sorted fused kernel's textured instantiation) at its own size — 4.3 M primitives, 1024 x 1024, 256 spp, one 268 M-path batch through k_trace5<., GEN> and the

@@ -25,6 +25,12 @@ SC = {
     "S3s": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="one_sphere"), 256, 5),
     "S3i": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="instanced"), 256, 5),
     "S3t": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_floor"), 256, 5),
+    "S3q": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="quads"), 256, 5),
+    "S3q50": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, quad_fraction=0.5), 256, 5),
+    "S3q25": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, quad_fraction=0.25), 256, 5),
+    "S3q10": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, quad_fraction=0.10), 256, 5),
+    "S3q03": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, quad_fraction=0.03), 256, 5),
+    "S3qc": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="quads", coated=True), 256, 5),
     "C4": (lambda: scenes.crown_proxy(lib, 1000, 1400), 256, 32),
     "C2": (lambda: scenes.cornell_box(lib, 512, 512), 64, 5),
     "C2t": (lambda: scenes.cornell_box(lib, 512, 512, textured=True), 64, 6),

@@ -23,11 +23,12 @@ def short(name):
         if t:
             k += "<" + t.group(1).replace("true", "1").replace("false", "0").replace(" ", "") + ">"
     if k.startswith("k_trace"):
-        t = re.search(r"k_trace\d?<(\w+)(?:, (\w+))?>", name)
+        t = re.search(r"k_trace\d?<(\w+)(?:, (\w+))?(?:, (\w+))?>", name)
         if t:
             k += "<any>" if t.group(1) == "true" else "<closest>"
             if k.startswith("k_trace5"):
-                k += "+gen" if t.group(2) == "true" else ""   # k_trace5<ANY, GEN>
+                k += "+gen" if t.group(2) == "true" else ""   # k_trace5<ANY, GEN, HEAVY>
+                k += "+heavy" if t.group(3) == "true" else ""
             else:
                 k += "+sph" if t.group(2) == "false" else ""  # (profiles of rounds 1-4: k_trace3<ANY, TRI_ONLY>)
     return k
