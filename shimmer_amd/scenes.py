@@ -315,10 +315,12 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
       "one_sphere"     a diffuse sphere stands on the floor beside the object (shape/sphere.rs)
       "instanced"      the object is an object definition placed once through a TransformedPrimitive (primitive.rs:136-176)
       "textured_floor" the ground plane's reflectance is an image texture (EWA-filtered, repeated): ONE textured material among plain ones
+      "smooth"         (round 6) the object's mesh carries per-vertex normals and uv coordinates, as every production mesh does (triangle.rs:380-504: the shading frame from
+                       interpolated normals, dndu / dndv): the headline scene's object has neither
       "quads"          (round 6) the object's 6 n^2 cells as bilinear patches instead of 12 n^2 triangles: what a quad PLY file becomes in the reference
       "environment"    no room and no window: the object on its ground plane under an ImageInfinitelight (light.rs:805-981) — escaped rays look the map up, next-event
                        estimation samples its (compensated) piecewise-constant distribution"""
-    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment", "textured_floor", "textured_hidden", "quads")
+    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment", "textured_floor", "textured_hidden", "quads", "smooth")
     b = SceneBuilder()
     b.set_film(width, height)
     rfw = b.set_camera_look_at(lib, (0.0, 0.6, 4.2), (0.0, 0.0, 0.0), (0, 1, 0), 38.0)
@@ -343,6 +345,14 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
         b.add_mesh(verts, tris, obj)  # object space
         b.end_object()
         b.add_instance("object", rfw)  # render_from_instance = render_from_world x identity (loading/scene.rs:855-866)
+    elif variant == "smooth":
+        vr = _to_render(verts, rfw)
+        centre = _to_render(np.zeros((1, 3), np.float32), rfw)[0]
+        nrm = vr - centre  # (radial: a smoothed version of the displaced sphere's normals — any unit field serves the arithmetic)
+        nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+        d = verts / np.linalg.norm(verts, axis=1, keepdims=True)
+        uv = np.stack([0.5 + np.arctan2(d[:, 2], d[:, 0]) / (2 * np.pi), 0.5 - np.arcsin(np.clip(d[:, 1], -1, 1)) / np.pi], 1).astype(np.float32)
+        b.add_mesh(vr, tris, obj, n=nrm, uv=uv)
     else:
         b.add_mesh(_to_render(verts, rfw), tris, obj)
     if variant == "one_sphere":
