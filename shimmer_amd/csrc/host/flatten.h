@@ -54,6 +54,7 @@ struct FlatScene {
     bool has_textures = false;  // a material slot binds an image texture (the path carries ray differentials) or an image infinite
                                 // light exists (both read the colour-space tables): selects k_shade<.., HAS_TEX>
     bool has_material_textures = false, has_image_light = false;
+    double area_plain_diffuse = 0.0, area_total = 0.0;  // surface area of those primitives / of all (instances' placements not counted): the split pass's second criterion
     uint64_t n_plain_diffuse_prims = 0;  // primitives whose material is a DiffuseMaterial that binds no texture (the split pass of textured scenes, render.hip)  // ... which of the two (round 5: an image light alone needs no differentials — render.hip, env_lean)
     std::vector<ShmInstance> instances;
     bool has_instances = false;
@@ -649,8 +650,21 @@ inline int flatten_scene(const ShmSceneDesc* d, FlatScene& out, std::string& err
         for (int k = 0; k < 8; ++k) any_float_tex = any_float_tex || m.float_tex[k] != 0u;
         m.pad[0] = (m.kind == SHM_MATERIAL_DIFFUSE && !tex_a && !any_float_tex && m.normal_map == 0u) ? 1u : 0u;
     }
-    for (const shm::PrimRec& pr : out.prim_recs)
-        if (pr.material < out.materials.size() && (out.materials[pr.material].pad[0] & 1u)) out.n_plain_diffuse_prims += 1u;
+    for (const shm::PrimRec& pr : out.prim_recs) {
+        const bool plain = pr.material < out.materials.size() && (out.materials[pr.material].pad[0] & 1u);
+        if (plain) out.n_plain_diffuse_prims += 1u;
+        // ... and by SURFACE AREA (round 6): where the hits fall. A textured 4.3 M-triangle object in a plain room of 14 triangles is 3 ppm plain by count and half plain by hits
+        double area = 0.0;
+        if (pr.kind_index & shm::PRIM_SPHERE_BIT) { const double r = d->spheres[pr.kind_index & shm::PRIM_INDEX_MASK].radius; area = 4.0 * 3.14159265358979 * r * r; }
+        else if (pr.kind_index & shm::PRIM_PATCH_BIT) area = out.patches[pr.kind_index & shm::PRIM_INDEX_MASK].area;
+        else if (!(pr.kind_index & shm::PRIM_INSTANCE_BIT)) {
+            const double ax = (double)pr.p1[0] - pr.p0[0], ay = (double)pr.p1[1] - pr.p0[1], az = (double)pr.p1[2] - pr.p0[2];
+            const double bx = (double)pr.p2[0] - pr.p0[0], by = (double)pr.p2[1] - pr.p0[1], bz = (double)pr.p2[2] - pr.p0[2];
+            const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+            area = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+        }
+        if (area == area && area < 1e300) { out.area_total += area; if (plain) out.area_plain_diffuse += area; }
+    }
     out.has_material_textures = out.has_textures;
     out.has_textures = out.has_material_textures || out.has_image_light;
     return SHM_OK;

@@ -576,7 +576,11 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     // only plain material is its emitter's, would pay a pass per bounce for a handful of hits; SHM_SPLIT_PASS=0 / 1 overrides)
     // (in scenes WITHOUT textures k_vertex diverts such hits itself, k_vertex.inl — its triangle instantiation runs three waves per SIMD; the pass as a kernel of its own in front of
     //  it, forced with SHM_SPLIT_PASS=1, changes nothing there: coated S3 3 258-3 284 Mray/s either way)
-    s->split_pass = (s->flat.has_material_textures && !scene_is_lean(s) && s->flat.n_plain_diffuse_prims * 4ull >= (uint64_t)s->flat.prim_recs.size()) ? 1 : 0;
+    // (round 6: ... or a quarter of the SURFACE AREA — hits fall by area, not by count: a textured 4.3 M-triangle object in a plain room of 14 triangles sent every wall and
+    //  floor hit through the textured class: 2 796 -> 3 127 Mray/s with the pass, profiles/r06_textured_object.txt)
+    s->split_pass = (s->flat.has_material_textures && !scene_is_lean(s) &&
+                     (s->flat.n_plain_diffuse_prims * 4ull >= (uint64_t)s->flat.prim_recs.size() ||
+                      (s->flat.n_plain_diffuse_prims > 0 && s->flat.area_plain_diffuse * 4.0 >= s->flat.area_total))) ? 1 : 0;
     if (const char* e = getenv("SHM_SPLIT_PASS")) s->split_pass = (atoi(e) != 0 && !scene_is_lean(s) && s->flat.n_plain_diffuse_prims > 0) ? 1 : 0;
     s->lean_divert = ((!s->flat.has_textures || env_plain_scene(s)) && s->flat.has_class[CLASS_DIFFUSE] && !scene_is_lean(s)) || s->split_pass;
     // a shallow tree means short rays, and short rays want fewer, fuller waves (C2's 63-node box: 15.5 -> 15.1 ms per frame at 8 rays per lane); a deep

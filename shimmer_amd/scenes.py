@@ -315,12 +315,14 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
       "one_sphere"     a diffuse sphere stands on the floor beside the object (shape/sphere.rs)
       "instanced"      the object is an object definition placed once through a TransformedPrimitive (primitive.rs:136-176)
       "textured_floor" the ground plane's reflectance is an image texture (EWA-filtered, repeated): ONE textured material among plain ones
+      "mesh_emitter"   (round 6) the window emitter tessellated into 64 x 64 x 2 = 8 192 emissive triangles: one DiffuseAreaLight per triangle (light.rs:632-684), the uniform
+                       light sampler picks among 8 192 lights — the light table, the emitters' records and the per-light data no longer fit the kernels' LDS tables
       "smooth"         (round 6) the object's mesh carries per-vertex normals and uv coordinates, as every production mesh does (triangle.rs:380-504: the shading frame from
                        interpolated normals, dndu / dndv): the headline scene's object has neither
       "quads"          (round 6) the object's 6 n^2 cells as bilinear patches instead of 12 n^2 triangles: what a quad PLY file becomes in the reference
       "environment"    no room and no window: the object on its ground plane under an ImageInfinitelight (light.rs:805-981) — escaped rays look the map up, next-event
                        estimation samples its (compensated) piecewise-constant distribution"""
-    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment", "textured_floor", "textured_hidden", "quads", "smooth")
+    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment", "textured_floor", "textured_hidden", "quads", "smooth", "mesh_emitter", "textured_object")
     b = SceneBuilder()
     b.set_film(width, height)
     rfw = b.set_camera_look_at(lib, (0.0, 0.6, 4.2), (0.0, 0.0, 0.0), (0, 1, 0), 38.0)
@@ -345,7 +347,9 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
         b.add_mesh(verts, tris, obj)  # object space
         b.end_object()
         b.add_instance("object", rfw)  # render_from_instance = render_from_world x identity (loading/scene.rs:855-866)
-    elif variant == "smooth":
+    elif variant in ("smooth", "textured_object"):
+        if variant == "textured_object":  # (round 6) ... and its reflectance is an image texture (trilinear, repeated) over that uv: EVERY hit on the object is a textured vertex
+            obj = b.material_diffuse(b.add_image_texture(test_image(256, 3), filter="trilinear", wrap="repeat", su=8.0, sv=8.0))
         vr = _to_render(verts, rfw)
         centre = _to_render(np.zeros((1, 3), np.float32), rfw)[0]
         nrm = vr - centre  # (radial: a smoothed version of the displaced sphere's normals — any unit field serves the arithmetic)
@@ -386,7 +390,19 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
         b.add_mesh(_to_render(room[0], rfw), room[1], wall)
         # window emitter high on the left, facing +x/-y into the room (one-sided)
         p, vi = _quad((-3.9, 1.0, -1.5), (-3.9, 3.0, -1.5), (-3.9, 3.0, 1.5), (-3.9, 1.0, 1.5))
-        if variant == "patch_emitter":  # p00, p10, p01, p11 (bilinear_patch.rs:87-98): the same quad, the same side emitting
+        if variant == "mesh_emitter":
+            m = 64
+            g = np.linspace(0.0, 1.0, m + 1)
+            yy, zz = np.meshgrid(1.0 + 2.0 * g, -1.5 + 3.0 * g, indexing="ij")
+            pv = np.stack([np.full(yy.size, -3.9), yy.ravel(), zz.ravel()], 1).astype(np.float32)
+            ii, jj = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+            a, b_, c, d = (ii * (m + 1) + jj).ravel(), ((ii + 1) * (m + 1) + jj).ravel(), ((ii + 1) * (m + 1) + jj + 1).ravel(), (ii * (m + 1) + jj + 1).ravel()
+            tv = np.concatenate([np.stack([a, b_, c], 1), np.stack([a, c, d], 1)]).astype(np.uint32)  # the same winding as the two-triangle quad: (p0, p1, p2), (p0, p2, p3)
+            # per-vertex normals (+x, into the room): without them the reference's Triangle::sample FLIPS the area-sampled normal (triangle.rs:558-560: `n * -1.0` whenever
+            # the mesh has no normals) and a one-sided emitter of small triangles — solid angle below 3e-4 sr: sampled by area — sends its light samples the wrong way
+            nv = (_to_render(np.array([[1.0, 0.0, 0.0]], np.float32), rfw) - _to_render(np.zeros((1, 3), np.float32), rfw))[0]
+            b.add_mesh(_to_render(pv, rfw), tv, black, n=np.tile(nv / np.linalg.norm(nv), (pv.shape[0], 1)).astype(np.float32), emission=blackbody_dense(6500.0), emission_scale=40.0)
+        elif variant == "patch_emitter":  # p00, p10, p01, p11 (bilinear_patch.rs:87-98): the same quad, the same side emitting
             b.add_patch_mesh(_to_render(p, rfw), [[0, 1, 3, 2]], black, emission=blackbody_dense(6500.0), emission_scale=40.0)
         else:
             b.add_mesh(_to_render(p, rfw), vi, black, emission=blackbody_dense(6500.0), emission_scale=40.0)

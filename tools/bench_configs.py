@@ -19,6 +19,9 @@ CONFIGS = [
     ("S3i ganesha instanced 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="instanced"), 256, 5),
     ("S3q ganesha as 2.15 M bilinear patches (a quad PLY) 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="quads"), 256, 5),
     ("S3e ganesha under an environment map 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="environment"), 256, 5),
+    ("S3to ganesha, textured OBJECT (image texture over its uv) 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_object"), 256, 5),
+    ("S3n ganesha, per-vertex normals + uv 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="smooth"), 256, 5),
+    ("S3m ganesha, 8192-triangle emitter 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="mesh_emitter"), 256, 5),
     ("S3t ganesha, textured floor 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_floor"), 256, 5),
     ("S3tb ganesha, textured floor (bilinear) 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_floor", floor_filter="bilinear"), 256, 5),
     ("S3tp ganesha, textured floor (point) 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_floor", floor_filter="point"), 256, 5),

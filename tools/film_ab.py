@@ -26,6 +26,8 @@ SC = {
     "S3i": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="instanced"), 256, 5),
     "S3t": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_floor"), 256, 5),
     "S3q": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="quads"), 256, 5),
+    "S3to": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_object"), 256, 5),
+    "S3m": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="mesh_emitter"), 256, 5),
     "S3n": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="smooth"), 256, 5),
     "S3nc": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="smooth", coated=True), 256, 5),
     "S3q50": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, quad_fraction=0.5), 256, 5),
