@@ -307,7 +307,7 @@ def cube_sphere(n, seed=1234, amplitude=0.15, shuffle_seed=99, as_quads=False, q
     return verts, tris
 
 
-def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=False, variant=None, floor_filter="ewa", quad_fraction=None):
+def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=False, variant=None, floor_filter="ewa", quad_fraction=None, object_material=None):
     """S3 (configs C3/C5): n=599 gives 6*599^2*2 = 4 305 612 triangles and 2 152 808 vertices.
     coated=True: the object is CoatedDiffuse (the material of the reference's Ganesha render, images/shimmer-ganesha-1.png).
     variant (round 5: the shapes a real PBRT-v4 scene mixes into its triangles; same camera, room and object):
@@ -327,6 +327,12 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
     b.set_film(width, height)
     rfw = b.set_camera_look_at(lib, (0.0, 0.6, 4.2), (0.0, 0.0, 0.0), (0, 1, 0), 38.0)
     obj = b.material_coated_diffuse(reflectance=0.4, roughness=0.05, thickness=0.01) if coated else b.material_diffuse(0.4)
+    if object_material == "gold":  # (round 6 class probes) a rough conductor / a dispersive glass / a coated conductor object
+        obj = b.material_conductor(b.spectrum_named("metal-Au-eta"), b.spectrum_named("metal-Au-k"), roughness=0.2)
+    elif object_material == "glass":
+        obj = b.material_dielectric(b.spectrum_named("glass-BK7"))
+    elif object_material == "coated_conductor":
+        obj = b.material_coated_conductor(interface_roughness=0.05, conductor_roughness=0.2, thickness=0.02)
     wall = b.material_diffuse(0.6)
     black = b.material_diffuse(0.0)
     if quad_fraction is not None:  # (development: where the five-wave traversal kernels start to pay — a share of the object's cells as patches, the rest as triangles)

@@ -26,6 +26,10 @@ SC = {
     "S3i": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="instanced"), 256, 5),
     "S3t": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_floor"), 256, 5),
     "S3q": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="quads"), 256, 5),
+    "S3au": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, object_material="gold"), 256, 5),
+    "S3gl": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, object_material="glass"), 256, 5),
+    "S3gl16": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, object_material="glass"), 256, 16),
+    "S3cc": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, object_material="coated_conductor"), 256, 5),
     "S3to": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_object"), 256, 5),
     "S3m": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="mesh_emitter"), 256, 5),
     "S3n": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="smooth"), 256, 5),
