@@ -263,7 +263,8 @@ def side_results(lib, args, render, scenes, headline_scene, log):
         #  (shape/mesh.rs:233-256): every leaf of the object a non-triangle test — the traversal kernels' five-wave instantiations)
         for variant, name in (("patch_emitter", "S3_patch_emitter"), ("one_sphere", "S3_with_one_sphere"), ("instanced", "S3_instanced"), ("environment", "S3_environment_map"),
                               ("textured_floor", "S3_textured_floor"),  # (ONE textured material among plain ones: the split pass in front of the textured kernels)
-                              ("quads", "S3_as_bilinear_patches")):
+                              ("quads", "S3_as_bilinear_patches"),
+                              ("instance_grid", "S3_as_64_instances")):  # (one small definition placed 4 x 4 x 4 times: rays cross several instance boxes, more node visits per ray)
             sc = scenes.ganesha_proxy(lib, 1024, 1024, n=args.n, variant=variant)
             timed(f"{name}_1024x1024_spp256", sc.desc, 256, args.max_depth, sc.info["n_primitives"])
             del sc

@@ -90,7 +90,7 @@ constexpr uint32_t SGN_RAY = 15u, SGN_HIT = 16u, SGN_HIT_INSIDE = 32u, SGN_INST_
 // behind it, so that nothing but path, t_max, stack pointer and link word is live across ~1 000 instructions of interval arithmetic (inlined with the state live, they made
 // the loop itself spill; as real calls, the calling convention's caller-saved registers did the same). An instance's entry saves the OUTER ray state the same way: leaving is
 // three loads, not a second ray set-up. The hit record is the ABI's 32-byte ShmHit (t, phi and the instance ride along).
-template <bool ANY, bool GEN, int LDS_N>
+template <bool ANY, bool GEN, int LDS_N, bool SAVE_LDS = false>
 __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
                                             uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
                                             ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
@@ -101,6 +101,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) u32x2 lds_u2;
     __shared__ u32x2 lds_stack5[(TRACE_BLOCK / WAVE) * LDS_N * WAVE];
+    // SAVE_LDS (the five-wave builds): the save area around a quadric / patch test in LDS ([k][thread], 12 KB per workgroup: six stack levels' worth) instead of
+    // the wave's HBM area — in a patch-heavy scene every other round is such a test (S3 as patches 3 740 -> 3 909 Mray/s, profiles/r06_patch_heavy_scenes.txt)
+    __shared__ float4 lds_save1[SAVE_LDS ? 3 * TRACE_BLOCK : 1];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave_in_block = threadIdx.x / WAVE;
     // the per-lane stack of {link word, t0 | phantom count} entries: levels [0, LDS_N) in LDS as [level][lane], deeper ones in the per-lane HBM spill
@@ -204,6 +207,12 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
             o_ro = ro; o_inv = inv_dir; o_sx = rs.sx; o_sy = rs.sy; o_sz = rs.sz; o_kz_sgn = (uint32_t)rs.kz | ((sgn & SGN_RAY) << 2);
             return;
         }
+        if (SAVE_LDS && area == 1) {
+            lds_save1[threadIdx.x] = make_float4(ro.x, ro.y, ro.z, inv_dir.x);
+            lds_save1[TRACE_BLOCK + threadIdx.x] = make_float4(inv_dir.y, inv_dir.z, rs.sx, rs.sy);
+            lds_save1[2 * TRACE_BLOCK + threadIdx.x] = make_float4(rs.sz, __int_as_float(rs.kz), __uint_as_float(sgn & SGN_RAY), 0.0f);
+            return;
+        }
         float4* a = save_wave + (size_t)area * (3 * WAVE) + lane;
         a[0] = make_float4(ro.x, ro.y, ro.z, inv_dir.x);
         a[WAVE] = make_float4(inv_dir.y, inv_dir.z, rs.sx, rs.sy);
@@ -220,7 +229,9 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         }
         asm volatile("" ::: "memory");  // (the loads below must be loads: with the stored values forwarded, the state would be live across what lies in between)
         const float4* a = save_wave + (size_t)area * (3 * WAVE) + lane;
-        const float4 s0 = a[0], s1 = a[WAVE], s2 = a[2 * WAVE];
+        float4 s0, s1, s2;
+        if (SAVE_LDS && area == 1) { s0 = lds_save1[threadIdx.x]; s1 = lds_save1[TRACE_BLOCK + threadIdx.x]; s2 = lds_save1[2 * TRACE_BLOCK + threadIdx.x]; }
+        else { s0 = a[0]; s1 = a[WAVE]; s2 = a[2 * WAVE]; }
         ro = v3(s0.x, s0.y, s0.z);
         inv_dir = v3(s0.w, s1.x, s1.y);
         rs.sx = s1.z; rs.sy = s1.w; rs.sz = s2.x;
@@ -689,17 +700,20 @@ __global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_e
 // lane — harmless where a round runs every 270 iterations (one sphere among 4.3 M triangles), and 0.7 TB of scratch traffic per frame where one runs every 17 (S3 as 2.15 M
 // patches: K2 263 ms, K3 171 ms against 92 / 59 for the same object as triangles). The SAME body at five waves per SIMD holds it in registers (96 VGPRs + 10 spilled / 93 + 0):
 // K2 158, K3 87 ms, 2 261 -> 3 496 Mray/s; with the refill at 24 idle lanes and the patch's fourth corner in its own record (flatten.h) K2 147, K3 77 ms, 3 736 Mray/s
-// (profiles/r06_patch_heavy_scenes.txt); with few non-triangles the seven-wave build stays ahead by 3-10 % (occupancy for the node step): chosen per scene, render.hip.
+// (profiles/r06_patch_heavy_scenes.txt), with the save area around the test in LDS K2 138, K3 72 ms, 3 909 Mray/s; with few non-triangles the seven-wave build stays ahead by 3-10 % (occupancy for the node step): chosen per scene, render.hip.
 #ifndef K5_GEN_HEAVY_WAVES
 #define K5_GEN_HEAVY_WAVES 5
 #endif
+#ifndef K5_GEN_HEAVY_LDS
+#define K5_GEN_HEAVY_LDS (K5Shape<K5_GEN_HEAVY_WAVES>::LDS - 6)  // stack levels in LDS: the five-wave share (15 x 2 KB) less the 12 KB save area of trace5_body<SAVE_LDS>
+#endif
 template <>
 __global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_GEN_HEAVY_WAVES, K5_GEN_HEAVY_WAVES))) k_trace5<false, true, true>(K5_PARAMS) {
-    trace5_body<false, true, K5Shape<K5_GEN_HEAVY_WAVES>::LDS>(K5_ARGS);
+    trace5_body<false, true, K5_GEN_HEAVY_LDS, true>(K5_ARGS);
 }
 template <>
 __global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_GEN_HEAVY_WAVES, K5_GEN_HEAVY_WAVES))) k_trace5<true, true, true>(K5_PARAMS) {
-    trace5_body<true, true, K5Shape<K5_GEN_HEAVY_WAVES>::LDS>(K5_ARGS);
+    trace5_body<true, true, K5_GEN_HEAVY_LDS, true>(K5_ARGS);
 }
 
 // (Round 5 built and measured k_trace6 here — TWO rays per lane, each phase run for whichever slot of a lane is ready: bit-exact, 23 % fewer wave iterations, 38.3 instead of 31.4
@@ -733,7 +747,7 @@ int wf_trace_prepare(ShmScene* s) {
     for (int any = 0; any < 2; ++any) {
         int lds = any ? K5Shape<K5_ANY_WAVES>::LDS : K5Shape<K5_CLOSEST_WAVES>::LDS, per_cu = any ? K5Shape<K5_ANY_WAVES>::PER_CU : K5Shape<K5_CLOSEST_WAVES>::PER_CU;
         if (!tri_only) { lds = any ? K5Shape<K5_GEN_ANY_WAVES>::LDS : K5Shape<K5_GEN_CLOSEST_WAVES>::LDS; per_cu = any ? K5Shape<K5_GEN_ANY_WAVES>::PER_CU : K5Shape<K5_GEN_CLOSEST_WAVES>::PER_CU; }
-        if (!tri_only && s->gen_heavy) { lds = K5Shape<K5_GEN_HEAVY_WAVES>::LDS; per_cu = K5Shape<K5_GEN_HEAVY_WAVES>::PER_CU; }
+        if (!tri_only && s->gen_heavy) { lds = K5_GEN_HEAVY_LDS; per_cu = K5Shape<K5_GEN_HEAVY_WAVES>::PER_CU; }
         s->trace3_blocks[any] = s->n_cu * per_cu;
         s->spill3_levels[any] = std::max(0, (int)s->flat.max_leaf_depth + 1 - lds) + 1;
         const size_t words = (size_t)s->trace3_blocks[any] * (TRACE_BLOCK / WAVE) * (size_t)s->spill3_levels[any] * WAVE * 2u;  // (8-byte stack entries)

@@ -589,12 +589,15 @@ int shm_scene_create(const ShmSceneDesc* desc, int device, ShmScene** out) {
     if (const char* e = getenv("SHM_TRACE_RAYS_PER_LANE")) { int v2 = atoi(e); if (v2 >= 0 && v2 <= 4096) s->trace_rays_per_lane = v2; }
     s->lds_tables = wf_lds_tables(s, LDS_TABLE_BUDGET);
     s->lds_tables_small = wf_lds_tables(s, LDS_TABLE_BUDGET_SMALL);
-    // the traversal kernels' instantiation for scenes with spheres / patches: five waves per SIMD where those shapes are a sixth of the primitive records or more (k_trace.hip,
-    // K5_GEN_HEAVY_WAVES; S3 with 100 / 50 / 25 / 10 / 3 % of the object's cells as patches, five against seven waves: +53 / +24 / +7 / -3 / -7 %). At five waves a refill is
-    // cheaper to make early (24 idle lanes: S3 as patches 3 506 -> 3 685 Mray/s, a quarter of it as patches +1.4 %; profiles/r06_patch_heavy_scenes.txt)
-    s->gen_heavy = f.has_spheres && f.n_quadric_patch_prims * 6ull >= (uint64_t)f.prim_recs.size();
+    // the traversal kernels' instantiation for scenes with spheres / patches: five waves per SIMD where those shapes are a twelfth of the primitive records or more (k_trace.hip,
+    // K5_GEN_HEAVY_WAVES; S3 with 100 / 50 / 25 / 10 % of the object's cells as patches — 100 / 33 / 14 / 5 % of the records —, five against seven waves: +73 / +38 / +13 / 0 %,
+    // with ONE patch in 4.3 M triangles -7 %). At five waves a refill is cheaper to make early (24 idle lanes: S3 as patches 3 506 -> 3 685 Mray/s; profiles/r06_patch_heavy_scenes.txt)
+    s->gen_heavy = f.has_spheres && f.n_quadric_patch_prims * 12ull >= (uint64_t)f.prim_recs.size();
     if (const char* e = getenv("SHM_GEN_HEAVY")) s->gen_heavy = f.has_spheres && atoi(e) != 0;
     if (s->gen_heavy) s->refill_min = s->refill_min_any = 24;
+    // parked rounds of a scene whose only non-triangles are instances are ray set-ups in another space (~450 instructions): worth waiting for 32 lanes (S3 instanced
+    // 4 263 -> 4 354, its object as 4 x 4 x 4 instances 2 703 -> 2 839 Mray/s; with spheres / patches 16 stays ahead: profiles/r06_instance_grid.txt)
+    if (f.has_instances && f.n_quadric_patch_prims == 0) s->other_min = s->other_min_any = 32;
     if (const char* e = getenv("SHM_REFILL_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min = s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_REFILL_MIN_ANY")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->refill_min_any = v2; }
     if (const char* e = getenv("SHM_LEAF_MIN")) { int v2 = atoi(e); if (v2 >= 1 && v2 <= 64) s->leaf_min = v2; }

@@ -319,10 +319,12 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
                        light sampler picks among 8 192 lights — the light table, the emitters' records and the per-light data no longer fit the kernels' LDS tables
       "smooth"         (round 6) the object's mesh carries per-vertex normals and uv coordinates, as every production mesh does (triangle.rs:380-504: the shading frame from
                        interpolated normals, dndu / dndv): the headline scene's object has neither
+      "instance_grid"  (round 6) the object is ONE small object definition (the same displaced sphere at n // 4: a sixteenth of the triangles) placed 4 x 4 x 4 times through
+                       TransformedPrimitives in the object's place — the class instancing exists for: most rays cross several instance boxes, each a transformed sub-traversal
       "quads"          (round 6) the object's 6 n^2 cells as bilinear patches instead of 12 n^2 triangles: what a quad PLY file becomes in the reference
       "environment"    no room and no window: the object on its ground plane under an ImageInfinitelight (light.rs:805-981) — escaped rays look the map up, next-event
                        estimation samples its (compensated) piecewise-constant distribution"""
-    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment", "textured_floor", "textured_hidden", "quads", "smooth", "mesh_emitter", "textured_object")
+    assert variant in (None, "patch_emitter", "one_sphere", "instanced", "environment", "textured_floor", "textured_hidden", "quads", "smooth", "mesh_emitter", "textured_object", "instance_grid")
     b = SceneBuilder()
     b.set_film(width, height)
     rfw = b.set_camera_look_at(lib, (0.0, 0.6, 4.2), (0.0, 0.0, 0.0), (0, 1, 0), 38.0)
@@ -353,6 +355,18 @@ def ganesha_proxy(lib, width=1024, height=1024, n=599, with_room=True, coated=Fa
         b.add_mesh(verts, tris, obj)  # object space
         b.end_object()
         b.add_instance("object", rfw)  # render_from_instance = render_from_world x identity (loading/scene.rs:855-866)
+    elif variant == "instance_grid":
+        sv, st = cube_sphere(max(2, n // 4))
+        b.begin_object("cell")
+        b.add_mesh(sv, st, obj)
+        b.end_object()
+        for ix in range(4):
+            for iy in range(4):
+                for iz in range(4):
+                    m = np.eye(4, dtype=np.float32)
+                    m[0, 0] = m[1, 1] = m[2, 2] = 0.27  # (cells of 0.5: neighbouring spheres' boxes overlap a little, as a scattered placement's do)
+                    m[:3, 3] = (-0.75 + 0.5 * ix, -0.75 + 0.5 * iy, -0.75 + 0.5 * iz)
+                    b.add_instance("cell", (np.asarray(rfw, np.float32).reshape(4, 4) @ m).astype(np.float32))
     elif variant in ("smooth", "textured_object"):
         if variant == "textured_object":  # (round 6) ... and its reflectance is an image texture (trilinear, repeated) over that uv: EVERY hit on the object is a textured vertex
             obj = b.material_diffuse(b.add_image_texture(test_image(256, 3), filter="trilinear", wrap="repeat", su=8.0, sv=8.0))

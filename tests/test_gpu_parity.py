@@ -56,6 +56,7 @@ SCENES = {
     "S3_small_smooth": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="smooth"), 6, 5),  # per-vertex normals + uv on the object (shading frames, dndu / dndv)
     "S3_small_mesh_emitter": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="mesh_emitter"), 6, 5),  # 8 192 area lights: the light tables beyond the LDS budget
     "S3_small_textured_object": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="textured_object"), 6, 5),  # an image texture over the object's uv: every object hit a textured vertex
+    "S3_small_instance_grid": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="instance_grid"), 6, 5),  # 64 placements of one definition: rays cross several instance boxes
     "S3_small_quads": lambda scenes, lib: (scenes.ganesha_proxy(lib, 96, 96, n=48, variant="quads"), 8, 5),
     "S3_small_quads_coated": lambda scenes, lib: (scenes.ganesha_proxy(lib, 64, 64, n=32, variant="quads", coated=True), 4, 5),
     # (round 6, found by the kernel-coverage run — profiles/r06_kernel_coverage.txt: until then no test reached these instantiations)

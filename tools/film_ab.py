@@ -25,6 +25,8 @@ SC = {
     "S3s": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="one_sphere"), 256, 5),
     "S3i": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="instanced"), 256, 5),
     "S3t": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_floor"), 256, 5),
+    "S3ig": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="instance_grid"), 256, 5),
+    "S3igsmall": (lambda: scenes.ganesha_proxy(lib, 256, 256, n=120, variant="instance_grid"), 16, 5),
     "S3q": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="quads"), 256, 5),
     "S3au": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, object_material="gold"), 256, 5),
     "S3gl": (lambda: scenes.ganesha_proxy(lib, 1024, 1024, object_material="glass"), 256, 5),
@@ -77,7 +79,7 @@ for name in args.scenes.split(","):
                 if ref is None:
                     ref = (h, cnt)
                 ok = (h, cnt) == ref
-                line = f" film {h} {'== first' if ok else '!= FIRST  <<<<<<<< MISMATCH'} nodes_any/ray {st['nodes_any'] / max(1, st['rays_any']):.2f} tris_any/ray {st['tris_any'] / max(1, st['rays_any']):.2f}"
+                line = f" film {h} {'== first' if ok else '!= FIRST  <<<<<<<< MISMATCH'} nodes_closest/ray {st['nodes_closest'] / max(1, st['rays_closest']):.2f} nodes_any/ray {st['nodes_any'] / max(1, st['rays_any']):.2f} tris_any/ray {st['tris_any'] / max(1, st['rays_any']):.2f}"
             rays = st["rays_closest"] + st["rays_any"]
             print(f"{name:8s} [{cfg or 'defaults':40s}] {rays / dt / 1e6:8.1f} Mray/s {dt * 1e3:8.1f} ms | closest {st['ms_trace_closest']:7.1f} any {st['ms_trace_any']:7.1f} shade {st['ms_shade']:7.1f}{line}", flush=True)
             r.close()
