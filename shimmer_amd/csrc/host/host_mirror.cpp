@@ -19,10 +19,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/shimmer_hip.h"
@@ -78,12 +80,26 @@ struct BuildNode {  // aggregate.rs:498-510
     uint32_t n_primitives = 0;
 };
 
+// build_recursive is serial in the reference (aggregate.rs:389-394: "This can be done in parallel, but let's do it sequentially for now"). Here the SAME recursion runs
+// over disjoint sub-ranges on host threads: a builder that is given `tasks` stops at ranges of `grain` primitives or fewer and records them (a placeholder node each);
+// every recorded range is then built by the same code into its own node vector, and shm_bvh_build splices the vectors in at the placeholders. A range's primitives end
+// up in ordered[begin, end) whoever builds it (the leaves of a pre-order walk cover the primitives in order: the reference's running offset IS `begin`), every node runs
+// the same partition over the same elements in the same order, and the pre-order numbering is restored by the splice: nodes and primitive order are bit-identical to the
+// serial build's (tests/test_host_mirror.py builds both ways).
+struct BuildTask {
+    size_t begin, end;
+    int top_index;  // the placeholder in the top builder's nodes
+    std::vector<BuildNode> nodes;
+};
+constexpr uint32_t TASK_PLACEHOLDER = 0xffffffffu;  // BuildNode::n_primitives of a placeholder (first_prim_offset: the task)
+
 struct Builder {
-    std::vector<BvhPrimitive> prims;
+    BvhPrimitive* prims;
     std::vector<BuildNode> build_nodes;
     uint32_t* ordered;
-    uint32_t ordered_offset = 0;
     int split_method;
+    std::vector<BuildTask>* tasks = nullptr;
+    size_t grain = 0;
 
     // itertools::partition: elements for which pred is true are moved to the front (unstable, two-ended).
     template <typename Pred>
@@ -109,11 +125,42 @@ struct Builder {
         return split_index;
     }
 
+    // the two folds of aggregate.rs:309-313 / 340-346 over one range: the union of the primitives' bounds and of their centroids. Above the sub-range tasks (`fold_threads`
+    // > 1, a large range) the range is folded in consecutive pieces on host threads and the pieces are united in order: fmin_rs / fmax_rs keep the LATER operand of two
+    // equal ones, in a piece and between pieces alike, so the result — the sign of a zero included — is the serial fold's
+    unsigned fold_threads = 1;
+    void range_bounds(size_t begin, size_t end, B3& bounds, B3& cb) const {
+        auto fold = [this](size_t b0, size_t e0, B3& bo, B3& co) {
+            bo = b3_default();
+            co = b3_default();
+            for (size_t i = b0; i < e0; ++i) {
+                bo = b3_union(bo, prims[i].bounds);
+                float c[3] = {prims[i].centroid(0), prims[i].centroid(1), prims[i].centroid(2)};
+                co = b3_union_point(co, c);
+            }
+        };
+        const size_t n = end - begin;
+        if (fold_threads <= 1 || n < ((size_t)1 << 17)) { fold(begin, end, bounds, cb); return; }
+        const size_t pieces = std::min<size_t>(fold_threads, n >> 15);
+        std::vector<B3> pb(pieces), pc(pieces);
+        std::vector<std::thread> pool;
+        auto piece = [&](size_t k) { fold(begin + n * k / pieces, begin + n * (k + 1) / pieces, pb[k], pc[k]); };
+        size_t started = 1;
+        try {
+            for (; started < pieces; ++started) pool.emplace_back(piece, started);
+        } catch (...) {}
+        piece(0);
+        for (std::thread& t : pool) t.join();
+        for (size_t k = started; k < pieces; ++k) piece(k);  // (pieces no thread could be had for)
+        bounds = b3_default();
+        cb = b3_default();
+        for (size_t k = 0; k < pieces; ++k) { bounds = b3_union(bounds, pb[k]); cb = b3_union(cb, pc[k]); }
+    }
+
     int make_leaf(int node_idx, size_t begin, size_t end, const B3& bounds) {  // aggregate.rs:326-337, 348-358
         BuildNode& node = build_nodes[node_idx];
-        uint32_t first = ordered_offset;
-        ordered_offset += (uint32_t)(end - begin);
-        for (size_t i = begin; i < end; ++i) ordered[first + (i - begin)] = prims[i].primitive_index;
+        const uint32_t first = (uint32_t)begin;  // (aggregate.rs:327-331's ordered_prims_offset: every primitive before `begin` is in an earlier leaf)
+        for (size_t i = begin; i < end; ++i) ordered[i] = prims[i].primitive_index;
         node.bounds = bounds;
         node.first_prim_offset = first;
         node.n_primitives = (uint32_t)(end - begin);
@@ -124,27 +171,28 @@ struct Builder {
     int build(size_t begin, size_t end) {
         int node_idx = (int)build_nodes.size();
         build_nodes.emplace_back();
-        B3 bounds = b3_default();
-        for (size_t i = begin; i < end; ++i) bounds = b3_union(bounds, prims[i].bounds);
-        if (b3_surface_area(bounds) == 0.0f || end - begin == 1) return make_leaf(node_idx, begin, end, bounds);
-        B3 cb = b3_default();
-        for (size_t i = begin; i < end; ++i) {
-            float c[3] = {prims[i].centroid(0), prims[i].centroid(1), prims[i].centroid(2)};
-            cb = b3_union_point(cb, c);
+        if (tasks && end - begin <= grain) {  // a sub-range for another thread: the same call on a builder of its own
+            build_nodes[node_idx].n_primitives = TASK_PLACEHOLDER;
+            build_nodes[node_idx].first_prim_offset = (uint32_t)tasks->size();
+            tasks->push_back(BuildTask{begin, end, node_idx, {}});
+            return node_idx;
         }
+        B3 bounds, cb;
+        range_bounds(begin, end, bounds, cb);
+        if (b3_surface_area(bounds) == 0.0f || end - begin == 1) return make_leaf(node_idx, begin, end, bounds);
         int dim = b3_max_dimension(cb);
         if (cb.mx[dim] == cb.mn[dim]) return make_leaf(node_idx, begin, end, bounds);
         size_t n = end - begin;
         size_t split_index;
         auto median_split = [&]() {
             size_t mid = n / 2;
-            std::nth_element(prims.begin() + begin, prims.begin() + begin + mid, prims.begin() + end,
+            std::nth_element(prims + begin, prims + begin + mid, prims + end,
                              [dim](const BvhPrimitive& a, const BvhPrimitive& b) { return a.centroid(dim) < b.centroid(dim); });
             return mid;
         };
         if (split_method == 0) {
             float pmid = (cb.mn[dim] + cb.mx[dim]) / 2.0f;
-            split_index = partition(prims.data() + begin, n, [dim, pmid](const BvhPrimitive& p) { return p.centroid(dim) < pmid; });
+            split_index = partition(prims + begin, n, [dim, pmid](const BvhPrimitive& p) { return p.centroid(dim) < pmid; });
             if (split_index == 0 || split_index == n) split_index = median_split();
         } else {
             split_index = median_split();
@@ -152,7 +200,7 @@ struct Builder {
         int left = build(begin, begin + split_index);
         int right = build(begin + split_index, end);
         BuildNode& node = build_nodes[node_idx];
-        node.bounds = b3_union(build_nodes[left].bounds, build_nodes[right].bounds);  // init_interior, aggregate.rs:540-557
+        node.bounds = b3_union(build_nodes[left].bounds, build_nodes[right].bounds);  // init_interior, aggregate.rs:540-557 (above placeholders: made again once they are built)
         node.left = left;
         node.right = right;
         node.split_axis = (uint8_t)dim;
@@ -235,42 +283,109 @@ int shm_bvh_build(const float* prim_bounds, uint32_t n, int split_method, ShmBvh
                   uint32_t* n_nodes_out, uint32_t* prim_order_out) {
     if (!prim_bounds || n == 0 || !nodes_out || !n_nodes_out || !prim_order_out || split_method < 0 || split_method > 1)
         return SHM_ERR_INVALID_ARGUMENT;
-    Builder b;
-    b.prims.resize(n);
+    std::vector<BvhPrimitive> prims(n);
     for (uint32_t i = 0; i < n; ++i) {
-        b.prims[i].primitive_index = i;
+        prims[i].primitive_index = i;
         for (int k = 0; k < 3; ++k) {
-            b.prims[i].bounds.mn[k] = prim_bounds[6ull * i + k];
-            b.prims[i].bounds.mx[k] = prim_bounds[6ull * i + 3 + k];
+            prims[i].bounds.mn[k] = prim_bounds[6ull * i + k];
+            prims[i].bounds.mx[k] = prim_bounds[6ull * i + 3 + k];
             if (prim_bounds[6ull * i + k] != prim_bounds[6ull * i + k]) return SHM_ERR_INVALID_ARGUMENT;  // "Unexpected NaN"
         }
     }
-    b.build_nodes.reserve(2ull * n);
+    // host threads for the sub-ranges (SHM_BVH_THREADS; 1 = the serial build): the ranges of n / 64 primitives or fewer below the first levels
+    unsigned n_threads = std::min(std::max(std::thread::hardware_concurrency(), 1u), 64u);
+    if (const char* e = getenv("SHM_BVH_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) n_threads = (unsigned)v; }
+    if (n < 65536u) n_threads = 1;
+    std::vector<BuildTask> tasks;
+    Builder b;
+    b.prims = prims.data();
+    b.build_nodes.reserve(n_threads > 1 ? 1024 : 2ull * n);
     b.ordered = prim_order_out;
     b.split_method = split_method;
-    int root = b.build(0, n);
-    if (b.ordered_offset != n) return SHM_ERR_INTERNAL;
+    if (n_threads > 1) { b.tasks = &tasks; b.grain = n / 64u; b.fold_threads = std::min(n_threads, 16u); }
+    b.build(0, n);
+    if (!tasks.empty()) {
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t t = next.fetch_add(1); t < tasks.size(); t = next.fetch_add(1)) {
+                Builder sub;
+                sub.prims = prims.data();
+                sub.ordered = prim_order_out;
+                sub.split_method = split_method;
+                sub.build_nodes.reserve(2 * (tasks[t].end - tasks[t].begin));
+                sub.build(tasks[t].begin, tasks[t].end);
+                tasks[t].nodes.swap(sub.build_nodes);
+            }
+        };
+        std::vector<std::thread> pool;
+        try {
+            for (unsigned t = 1; t < std::min<size_t>(n_threads, tasks.size()); ++t) pool.emplace_back(worker);
+        } catch (...) {}  // (no more threads: this one builds what is left)
+        worker();
+        for (std::thread& t : pool) t.join();
+        // the interior nodes above the placeholders: bounds from their children, innermost first (pre-order: children have the larger indices)
+        auto bounds_of = [&](int i) -> const B3& { const BuildNode& c = b.build_nodes[i]; return c.n_primitives == TASK_PLACEHOLDER ? tasks[c.first_prim_offset].nodes[0].bounds : c.bounds; };
+        for (size_t i = b.build_nodes.size(); i-- > 0;) {
+            BuildNode& node = b.build_nodes[i];
+            if (node.n_primitives == 0) node.bounds = b3_union(bounds_of(node.left), bounds_of(node.right));
+        }
+    }
     // flatten_bvh, aggregate.rs:425-467: DFS, first child right after the parent. Our build order IS DFS
-    // pre-order (node created before its left subtree, right subtree after it), so indices carry over.
-    uint32_t total = (uint32_t)b.build_nodes.size();
-    (void)root;
-    for (uint32_t i = 0; i < total; ++i) {
-        const BuildNode& bn = b.build_nodes[i];
-        ShmBvhNode ln;
+    // pre-order (node created before its left subtree, right subtree after it), so indices carry over — with every placeholder replaced by its sub-range's nodes.
+    std::vector<uint32_t> final_index(b.build_nodes.size());
+    uint64_t total64 = 0;
+    for (size_t i = 0; i < b.build_nodes.size(); ++i) {
+        final_index[i] = (uint32_t)total64;
+        total64 += b.build_nodes[i].n_primitives == TASK_PLACEHOLDER ? tasks[b.build_nodes[i].first_prim_offset].nodes.size() : 1u;
+    }
+    if (total64 > 0xffffffffull) return SHM_ERR_UNSUPPORTED;
+    const uint32_t total = (uint32_t)total64;
+    std::atomic<int> rc_emit{SHM_OK};
+    std::atomic<uint64_t> n_in_leaves{0};
+    auto emit = [&](const BuildNode& bn, uint32_t base, ShmBvhNode& ln, uint64_t& leaf_prims) {
         memset(&ln, 0, sizeof(ln));
         for (int k = 0; k < 3; ++k) { ln.bmin[k] = bn.bounds.mn[k]; ln.bmax[k] = bn.bounds.mx[k]; }
         if (bn.n_primitives > 0) {
-            if (bn.n_primitives >= 65536) return SHM_ERR_UNSUPPORTED;  // aggregate.rs:441 debug_assert
+            if (bn.n_primitives >= 65536) rc_emit = SHM_ERR_UNSUPPORTED;  // aggregate.rs:441 debug_assert
             ln.offset = bn.first_prim_offset;
             ln.n_prims = (uint16_t)bn.n_primitives;
             ln.axis = 0;
+            leaf_prims += bn.n_primitives;
         } else {
-            ln.offset = (uint32_t)bn.right;  // second_child_offset
+            ln.offset = base;  // second_child_offset (the caller's numbering)
             ln.n_prims = 0;
             ln.axis = bn.split_axis;
         }
-        nodes_out[i] = ln;
+    };
+    {
+        uint64_t leaf_prims = 0;
+        for (size_t i = 0; i < b.build_nodes.size(); ++i) {
+            const BuildNode& bn = b.build_nodes[i];
+            if (bn.n_primitives == TASK_PLACEHOLDER) continue;
+            emit(bn, bn.n_primitives == 0 ? final_index[bn.right] : 0u, nodes_out[final_index[i]], leaf_prims);
+        }
+        n_in_leaves += leaf_prims;
     }
+    if (!tasks.empty()) {
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            uint64_t leaf_prims = 0;
+            for (size_t t = next.fetch_add(1); t < tasks.size(); t = next.fetch_add(1)) {
+                const uint32_t base = final_index[tasks[t].top_index];
+                const std::vector<BuildNode>& nodes = tasks[t].nodes;
+                for (size_t i = 0; i < nodes.size(); ++i) emit(nodes[i], nodes[i].n_primitives == 0 ? base + (uint32_t)nodes[i].right : 0u, nodes_out[base + i], leaf_prims);
+            }
+            n_in_leaves += leaf_prims;
+        };
+        std::vector<std::thread> pool;
+        try {
+            for (unsigned t = 1; t < std::min<size_t>(n_threads, tasks.size()); ++t) pool.emplace_back(worker);
+        } catch (...) {}
+        worker();
+        for (std::thread& t : pool) t.join();
+    }
+    if (rc_emit != SHM_OK) return rc_emit;
+    if (n_in_leaves != n) return SHM_ERR_INTERNAL;
     *n_nodes_out = total;
     return SHM_OK;
 }

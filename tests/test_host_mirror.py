@@ -181,6 +181,39 @@ def test_bvh_equal_counts_and_errors(lib):
     assert lib.shm_bvh_build(bad.ctypes.data_as(abi.c_float_p), 257, 0, nodes, C.byref(nn), order.ctypes.data_as(abi.c_u32_p)) == -1
 
 
+@pytest.mark.parametrize("method", [0, 1])
+def test_bvh_build_on_host_threads_equals_the_serial_build(lib, method, monkeypatch):
+    """aggregate.rs:389-394 leaves build_recursive serial ("This can be done in parallel ..."); shm_bvh_build runs the same recursion over disjoint sub-ranges on host
+    threads from 65 536 primitives on (host_mirror.cpp, BuildTask). Nodes and primitive order must be the serial build's byte for byte — with coincident centroids
+    (leaves of several primitives: the order inside them is the partition's), flat boxes and signed zeros in the bounds (the piecewise folds keep a zero's sign)."""
+    rng = np.random.default_rng(11)
+    n = 150_000
+    lo = (rng.random((n, 3)) * 2.0 - 1.0).astype(np.float32)
+    ext = (rng.random((n, 3)) * 0.01).astype(np.float32)
+    lo[:3000] = lo[3000:6000]  # coincident boxes: the degenerate-centroid-bounds exit (aggregate.rs:345)
+    ext[:3000] = ext[3000:6000]
+    ext[6000:9000, 1] = 0.0  # flat boxes
+    lo[9000:9400, 0] = 0.0   # +0 / -0 among the minima of one axis
+    lo[9400:9800, 0] = -0.0
+    bounds = np.ascontiguousarray(np.concatenate([lo, lo + ext], axis=1).astype(np.float32))
+
+    def build():
+        nodes = (abi.ShmBvhNode * (2 * n))()
+        order = np.zeros(n, np.uint32)
+        nn = C.c_uint32()
+        assert lib.shm_bvh_build(bounds.ctypes.data_as(abi.c_float_p), n, method, nodes, C.byref(nn), order.ctypes.data_as(abi.c_u32_p)) == 0
+        return nn.value, bytes(memoryview(nodes))[:nn.value * C.sizeof(abi.ShmBvhNode)], order.tobytes()
+
+    monkeypatch.setenv("SHM_BVH_THREADS", "1")
+    serial = build()
+    for threads in ("2", "5", "16"):
+        monkeypatch.setenv("SHM_BVH_THREADS", threads)
+        got = build()
+        assert got[0] == serial[0] and got[2] == serial[2], threads
+        assert got[1] == serial[1], threads
+    assert sorted(np.frombuffer(serial[2], np.uint32).tolist()) == list(range(n))
+
+
 def test_camera_perspective(lib):
     """PerspectiveCamera::new: the centre of the raster maps to the optical axis, corners to +-tan(fov/2) on the short
     side (camera.rs:848-963), camera-world rendering space (camera.rs:507-523)."""
