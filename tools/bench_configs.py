@@ -17,6 +17,7 @@ CONFIGS = [
     ("S3p ganesha, patch emitter 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="patch_emitter"), 256, 5),
     ("S3s ganesha + one sphere 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="one_sphere"), 256, 5),
     ("S3i ganesha instanced 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="instanced"), 256, 5),
+    ("S3ig ganesha as 4 x 4 x 4 instances of one small definition 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="instance_grid"), 256, 5),
     ("S3q ganesha as 2.15 M bilinear patches (a quad PLY) 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="quads"), 256, 5),
     ("S3e ganesha under an environment map 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="environment"), 256, 5),
     ("S3to ganesha, textured OBJECT (image texture over its uv) 1024x1024x256", lambda: scenes.ganesha_proxy(lib, 1024, 1024, variant="textured_object"), 256, 5),
