@@ -1,0 +1,154 @@
+"""Area-light sampling as a measure (light.rs:632-684 through Triangle / Sphere / BilinearPatch::sample_with_context and pdf_with_context: triangle.rs:540-745,
+sphere.rs:339-457, bilinear_patch.rs:521-782), checked through properties that need no reading of the Rust text:
+
+  * every sampled direction points at the emitter (a float64 ray test of this file against the shape);
+  * 1 / pdf averages to the SOLID ANGLE the emitter subtends from the reference point — computed here in float64 from the geometry alone (the spherical excess of a
+    triangle, the cone of a sphere) — whichever strategy the shape picks (spherical triangle / rectangle / cone sampling: a constant density; area sampling for very
+    small emitters: d^2 / (|cos| A));
+  * pdf_li evaluated at a sampled direction is the density the sample reported.
+
+Two of the reference's own deviations from these properties surface here, as they must (both reproduced on purpose and listed in DESIGN.md): the sphere's pdf
+constant (sphere.rs:456) and the area sampling of a non-rectangular patch (bilinear_patch.rs:549-553).
+
+tests/test_leaf_golden.py and tests/test_bilinear_patch.py pin the same leaves bit for bit against independent numpy evaluations; the device replays them
+(tests/test_gpu_leaf_replay.py)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_py
+from shimmer_amd import abi
+from shimmer_amd.scene import SceneBuilder
+from shimmer_amd.scenes import blackbody_dense
+
+F, FP = C.c_float, C.POINTER(C.c_float)
+LAMS = (450.0, 520.0, 600.0, 680.0)
+
+
+def fa(v):
+    v = np.asarray(v, np.float32).ravel()
+    return (F * len(v))(*[float(x) for x in v])
+
+
+def tri_solid_angle(p):
+    a, b, c = [q / np.linalg.norm(q) for q in np.asarray(p, np.float64)]
+    return abs(2.0 * math.atan2(np.dot(a, np.cross(b, c)), 1.0 + np.dot(a, b) + np.dot(a, c) + np.dot(b, c)))  # van Oosterom & Strackee
+
+
+def ray_hits_triangle(d, p, eps=1e-4):
+    p0, p1, p2 = np.asarray(p, np.float64)
+    e1, e2 = p1 - p0, p2 - p0
+    h = np.cross(d, e2)
+    det = np.dot(e1, h)
+    if abs(det) < 1e-300:
+        return False
+    s = -p0
+    u = np.dot(s, h) / det
+    q = np.cross(s, e1)
+    v = np.dot(d, q) / det
+    t = np.dot(e2, q) / det
+    return t > 0 and u >= -eps and v >= -eps and u + v <= 1 + eps
+
+
+# emitters seen from the ORIGIN of render space (the camera sits there: render space = world space for these scenes)
+TRI_CASES = {
+    "triangle_wide": [(-1.0, 2.0, -1.2), (1.3, 2.0, -0.8), (0.2, 2.2, 1.5)],          # spherical-triangle sampling (3e-4 < solid angle < 6.22, triangle.rs:588-600)
+    "triangle_oblique": [(0.5, 0.2, -3.0), (2.5, 0.1, -3.5), (1.0, 1.8, -2.0)],
+    "triangle_tiny": [(0.0, 30.0, 0.0), (0.3, 30.0, 0.0), (0.0, 30.0, 0.3)],           # below 3e-4 sr: area sampling, d^2 / (|cos| A)
+}
+
+
+def build(lib, shape):
+    b = SceneBuilder()
+    b.set_film(8, 8)
+    rfw = b.set_camera_look_at(lib, (0, 0, 0), (0, 0, -1), (0, 1, 0), 40.0)
+    assert np.allclose(rfw, np.eye(4))
+    black = b.material_diffuse(0.0)
+    em = blackbody_dense(6500.0)
+    if shape in TRI_CASES:
+        b.add_mesh(np.array(TRI_CASES[shape], np.float32), [[0, 1, 2]], black, emission=em, emission_scale=2.0, two_sided=True)
+    elif shape == "sphere":
+        rfo = np.eye(4, dtype=np.float32)
+        rfo[:3, 3] = (1.0, 2.0, -2.0)
+        b.add_sphere(0.8, black, render_from_object=rfo, emission=em, emission_scale=2.0)
+    elif shape == "rectangle_patch":  # a planar rectangle: spherical-rectangle sampling (bilinear_patch.rs:620-668)
+        q = np.array([(-1.0, 2.5, -1.0), (1.0, 2.5, -1.0), (-1.0, 2.5, 0.5), (1.0, 2.5, 0.5)], np.float32)
+        b.add_patch_mesh(q, [[0, 1, 2, 3]], black, emission=em, emission_scale=2.0, two_sided=True)
+    elif shape == "skew_patch":  # planar, not a rectangle: area sampling with the bilinear warp
+        q = np.array([(-1.0, 2.5, -1.0), (1.2, 2.5, -0.7), (-0.6, 2.5, 0.8), (0.7, 2.5, 0.4)], np.float32)
+        b.add_patch_mesh(q, [[0, 1, 2, 3]], black, emission=em, emission_scale=2.0, two_sided=True)
+    desc, _ = b.build(lib)
+    return b, desc
+
+
+def solid_angle_and_hit(shape):
+    if shape in TRI_CASES:
+        p = TRI_CASES[shape]
+        return tri_solid_angle(p), lambda d: ray_hits_triangle(d, p)
+    if shape == "sphere":
+        c, r = np.array([1.0, 2.0, -2.0]), 0.8
+        dc = np.linalg.norm(c)
+        cos_max = math.sqrt(1.0 - (r / dc) ** 2)
+        return 2.0 * math.pi * (1.0 - cos_max), lambda d: np.dot(d, c / dc) >= cos_max - 1e-5
+    q = {"rectangle_patch": [(-1.0, 2.5, -1.0), (1.0, 2.5, -1.0), (-1.0, 2.5, 0.5), (1.0, 2.5, 0.5)],
+         "skew_patch": [(-1.0, 2.5, -1.0), (1.2, 2.5, -0.7), (-0.6, 2.5, 0.8), (0.7, 2.5, 0.4)]}[shape]
+    t1, t2 = [q[0], q[1], q[3]], [q[0], q[3], q[2]]  # p00 p10 p11 | p00 p11 p01: a planar patch is these two triangles
+    return tri_solid_angle(t1) + tri_solid_angle(t2), lambda d: ray_hits_triangle(d, t1) or ray_hits_triangle(d, t2)
+
+
+@pytest.mark.parametrize("shape", list(TRI_CASES) + ["sphere", "rectangle_patch", "skew_patch"])
+def test_inverse_pdf_averages_to_the_solid_angle(lib, shape):
+    olib = oracle_py.load()
+    olib.orc_fn_light_pdf_li.restype, olib.orc_fn_light_pdf_li.argtypes = F, [C.c_void_p, C.c_uint32, FP, FP, FP, FP]
+    b, desc = build(lib, shape)
+    o = oracle_py.Oracle(desc)
+    lights = [li for li in range(desc.n_lights) if desc.lights[li].kind == abi.SHM_LIGHT_DIFFUSE_AREA]
+    assert len(lights) == 1
+    li = lights[0]
+    omega, hits = solid_angle_and_hit(shape)
+    rng = np.random.default_rng(13)
+    n, acc, acc2, n_some = 4000, 0.0, 0.0, 0
+    zero = fa([0.0, 0.0, 0.0])
+    pdfs = []
+    for k in range(n):
+        out = (F * 8)()
+        if not o.lib.orc_fn_light_sample_li(o.handle, li, fa(rng.random(2)), 0, fa(LAMS), out):
+            continue
+        n_some += 1
+        wi, pdf = np.array(out[:3], np.float64), float(out[3])
+        assert abs(np.linalg.norm(wi) - 1.0) < 1e-5 and pdf > 0 and np.isfinite(pdf)
+        assert hits(wi), (shape, wi)
+        assert all(x > 0 for x in out[4:8])  # two-sided (or facing) emitter: radiance arrives
+        acc += 1.0 / pdf
+        acc2 += 1.0 / (pdf * pdf)
+        pdfs.append(pdf)
+        if k % 16 == 0:
+            again = olib.orc_fn_light_pdf_li(o.handle, li, zero, zero, zero, fa(wi))
+            # (the reference's Sphere::pdf_with_context divides by 2.90 pi where sample_with_context divides by 2 pi — sphere.rs:456 against :404, reproduced on purpose:
+            #  DESIGN.md "reference quirks" 1, tests/test_quirks_switch.py; this test met it on its own, which is what it is for)
+            want = pdf * (2.0 / 2.90) if shape == "sphere" else pdf
+            if shape != "skew_patch":  # (below)
+                assert abs(again - want) <= 2e-3 * want, (shape, pdf, again)
+    assert n_some >= 0.98 * n
+    mean = acc / n_some
+    sigma = math.sqrt(max(acc2 / n_some - mean * mean, 0.0) / n_some)
+    if shape == "skew_patch":
+        # the second reference behaviour this test met on its own: BilinearPatch::sample interpolates its two edge points along DIFFERENT parameters
+        # (bilinear_patch.rs:549-553: lerp(u, p00, p10) and lerp(v, p10, p11) where PBRT-v4 has lerp(v, p00, p01) and lerp(v, p10, p11)), so an area-sampled
+        # non-rectangular patch is neither sampled uniformly nor given the density of its samples: 1 / pdf averages to about HALF the solid angle here, and pdf() —
+        # which has its own form, :627-628 — disagrees with it. Reproduced on purpose (DESIGN.md "ABI v3" paragraph, shm/patch.h "(sic)"; tests/test_bilinear_patch.py holds the
+        # formulas bit for bit); what this test keeps for the class is that every sample lies on the emitter.
+        assert mean < 0.75 * omega, (mean, omega)
+        o.close()
+        return
+    assert abs(mean - omega) <= 5.0 * sigma + 2e-3 * omega, (shape, mean, omega, sigma)
+    if shape in ("triangle_wide", "triangle_oblique", "sphere", "rectangle_patch"):
+        # solid-angle strategies: the density is the constant 1 / solid angle
+        assert np.allclose(pdfs, 1.0 / omega, rtol=2e-3), (shape, min(pdfs), max(pdfs), 1.0 / omega)
+    else:
+        assert max(pdfs) > min(pdfs)  # area sampling: the density varies over the emitter
+    if shape == "triangle_tiny":
+        assert omega < 3e-4
+    o.close()
