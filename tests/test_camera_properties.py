@@ -1,0 +1,83 @@
+"""PerspectiveCamera (camera.rs:893-1079) through optics instead of through a second reading of the Rust text (tests/test_leaf_golden.py holds the float64
+construction): a pinhole camera's directions are a projective image of the raster — tan of the half field of view at the edges of the SHORTER axis, affine in between,
+square pixels —, a thin lens sends every lens sample of one film point through one point of the plane of focus, which lies on the pinhole ray, and the auxiliary rays
+are the rays of the neighbouring pixels."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_py
+from shimmer_amd import abi
+
+F, FP = C.c_float, C.POINTER(C.c_float)
+IDENTITY = np.eye(4, dtype=np.float32)
+
+
+def fa(v):
+    v = np.asarray(v, np.float32).ravel()
+    return (F * len(v))(*[float(x) for x in v])
+
+
+@pytest.fixture(scope="module")
+def olib():
+    lib = oracle_py.load()
+    lib.orc_fn_camera_ray_differential.restype, lib.orc_fn_camera_ray_differential.argtypes = None, [C.POINTER(abi.ShmCamera), FP, FP, FP]
+    return lib
+
+
+def camera(lib, fov, res, lens_radius=0.0, focal_distance=1e6):
+    cam = abi.ShmCamera()
+    rfw = (F * 16)()
+    abi.check(lib, lib.shm_camera_perspective(fa(IDENTITY), fov, (C.c_int32 * 2)(*res), lens_radius, focal_distance, C.byref(cam), rfw), "shm_camera_perspective")
+    assert np.allclose(np.array(rfw[:]).reshape(4, 4), IDENTITY)  # the camera at the world's origin, unrotated: render space = camera space
+    return cam
+
+
+def ray(olib, cam, p_film, p_lens=(0.5, 0.5)):
+    out = (F * 18)()
+    olib.orc_fn_camera_ray_differential(C.byref(cam), fa(p_film), fa(p_lens), out)
+    v = np.array(out[:], np.float64)
+    return {k: v[3 * i:3 * i + 3] for i, k in enumerate(["o", "d", "rx_o", "rx_d", "ry_o", "ry_d"])}
+
+
+@pytest.mark.parametrize("res", [(640, 480), (300, 700), (512, 512)])
+@pytest.mark.parametrize("fov", [25.0, 60.0, 110.0])
+def test_pinhole_is_a_projective_image_of_the_raster(lib, olib, fov, res):
+    cam = camera(lib, fov, res)
+    w, h = res
+    t = math.tan(math.radians(fov) / 2.0)
+    k = 2.0 * t / min(w, h)  # tangent per pixel: the field of view spans the shorter axis (camera.rs:905-920: the screen window is [-1, 1] there)
+    for x, y in [(0.0, 0.0), (w, h), (w / 2, h / 2), (w, 0.0), (0.3 * w, 0.9 * h), (17.25, 3.5)]:
+        r = ray(olib, cam, (x, y))
+        assert np.allclose(r["o"], 0.0) and abs(np.linalg.norm(r["d"]) - 1.0) < 1e-6
+        assert r["d"][2] > 0  # looks down +z (transform.rs:305-316: a left-handed perspective projection)
+        assert r["d"][0] / r["d"][2] == pytest.approx((x - w / 2) * k, abs=2e-5 * (1 + t))
+        assert r["d"][1] / r["d"][2] == pytest.approx(-(y - h / 2) * k, abs=2e-5 * (1 + t))  # raster y runs down
+    # the auxiliary rays are the rays one pixel to the right / below (camera.rs:1046-1076)
+    r = ray(olib, cam, (100.5, 77.25))
+    rx, ry = ray(olib, cam, (101.5, 77.25)), ray(olib, cam, (100.5, 78.25))
+    assert np.allclose(r["rx_d"], rx["d"], atol=2e-6) and np.allclose(r["ry_d"], ry["d"], atol=2e-6)
+
+
+@pytest.mark.parametrize("focal", [2.5, 40.0])
+def test_thin_lens_focuses_every_lens_sample_on_the_plane_of_focus(lib, olib, focal):
+    lens_radius = 0.2
+    cam = camera(lib, 45.0, (400, 300), lens_radius=lens_radius, focal_distance=focal)
+    pin = camera(lib, 45.0, (400, 300))
+    rng = np.random.default_rng(2)
+    for p_film in [(200.0, 150.0), (10.5, 280.25), (390.0, 5.0)]:
+        d_pin = ray(olib, pin, p_film)["d"]
+        focus = d_pin * (focal / d_pin[2])  # where the pinhole ray meets z = focal
+        origins = []
+        for _ in range(40):
+            r = ray(olib, cam, p_film, rng.random(2))
+            assert abs(r["o"][2]) < 1e-7 and math.hypot(r["o"][0], r["o"][1]) <= lens_radius * (1 + 1e-5)  # on the lens disk
+            hit = r["o"] + r["d"] * ((focal - r["o"][2]) / r["d"][2])
+            assert np.allclose(hit, focus, atol=3e-5 * focal), (p_film, hit, focus)
+            origins.append(r["o"][:2])
+        origins = np.array(origins)
+        assert origins.std(axis=0).min() > 0.2 * lens_radius / 2  # ... and the lens samples do spread over the disk
+    # the centre of the concentric mapping is the centre of the lens
+    assert np.allclose(ray(olib, cam, (123.0, 45.0), (0.5, 0.5))["o"], 0.0, atol=1e-7)
