@@ -9,7 +9,7 @@ the film is in the ratio: the light sampler's pmf (two triangle lights), spheric
 ray that finds the emitter by itself, f = R / pi, the film's weights.
 
 The emitter as ONE rectangular bilinear patch is sampled uniformly in solid angle: there the estimate must be the integral. As two triangles it carries the reference's
-own skew of sample_spherical_triangle (second test)."""
+own mismatch between the sample and its density in Triangle::sample_with_context (second test)."""
 import ctypes as C
 import math
 
@@ -122,9 +122,10 @@ def test_direct_lighting_by_a_rectangular_patch_is_the_radiometric_integral(lib)
 
 def test_direct_lighting_by_two_triangles_is_the_integral_up_to_the_reference_s_sampling_skew(lib):
     """The same emitter as two triangle lights: the level is right — pmf 1/2 per light, the density 1 / solid angle, the power heuristic — while the blocks scatter by a
-    few percent around it that more samples do not remove: sample_spherical_triangle's `b1 / b1 + b2` (sampling.rs, the reference's precedence; DESIGN.md "reference
-    quirks preserved", not behind the switch) skews the samples over each triangle under a constant density, so every block is off by the integrand's variation over the
-    emitter as seen from there. Kept as the reference computes it; this test bounds it."""
+    few percent around it that more samples do not remove: Triangle::sample_with_context computes the cosine-warped sample in a block whose `u` shadows the outer one
+    (triangle.rs:639-641), so the direction is drawn from the UNWARPED u while the density carries the warp's factor, evaluated at a point the sample is not at. Every
+    block is off by what the cosine varies over the emitter as seen from there. A listed reference behaviour (DESIGN.md "reference quirks preserved": "the warped u
+    shadowed"), not behind the switch, kept as the reference computes it; this test bounds what it does to an image."""
     few, many = compare(lib, "triangles", quirks=True, spp=192), compare(lib, "triangles", quirks=True, spp=768)
     for ratios in (few, many):
         assert abs(float(ratios.mean()) - 1.0) < 0.015, float(ratios.mean())
