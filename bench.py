@@ -587,13 +587,15 @@ def rank_main(args):
         r.dist_barrier()   # nobody tears its communicator down while a peer still checks the film
     r.close()
     if rank == 0 and world == 1:
+        # the side results BEFORE the CPU baseline (round 6): after the oracle's run on every host thread the box's host side stays unsettled for a minute or more and
+        # launch-bound frames pay for it — C4's second timed frame 373-381 ms instead of 347, every other side result 0.5-1.5 % slower (profiles/r06_bench_order.txt)
+        if not args.no_side and not args.coated and not args.variant and not args.shard_of and (width, height) == (1024, 1024):
+            out["side_results"] = side_results(lib, args, render, scenes, sc, log)
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sc, params, lib)
             except Exception as e:  # the baseline is reporting only; never let it hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        if not args.no_side and not args.coated and not args.variant and not args.shard_of and (width, height) == (1024, 1024):
-            out["side_results"] = side_results(lib, args, render, scenes, sc, log)
     if store is not None:
         store.finish()
     if rank == 0:
