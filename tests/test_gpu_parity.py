@@ -362,6 +362,35 @@ def test_render_decomposition_invariance(env, monkeypatch):
     assert np.array_equal(f4, f1) and s4["rays_any"] == s1["rays_any"] and s4["nodes_any"] == s1["nodes_any"]
 
 
+@pytest.mark.parametrize("kind", ["quads", "instance_grid", "coated_quads", "one_sphere"])
+def test_batch_and_overlap_invariance_of_the_general_scene_classes(env, monkeypatch, kind):
+    """The decomposition properties of the test above on the classes round 6 gave their own traversal instantiations or thresholds: an object of bilinear patches (five
+    waves per SIMD, the LDS save area), the same coated (the staged LayeredBxDF pipeline beside it), a grid of instances (32 parked lanes), one sphere among triangles
+    (seven waves): 8192-path batches and serialised streams render the same film and counters as the defaults, and the defaults equal the oracle."""
+    lib, oracle_py, render, scenes = env
+    sc = {"quads": lambda: scenes.ganesha_proxy(lib, 96, 72, n=40, variant="quads"),
+          "coated_quads": lambda: scenes.ganesha_proxy(lib, 96, 72, n=40, variant="quads", coated=True),
+          "instance_grid": lambda: scenes.ganesha_proxy(lib, 96, 72, n=40, variant="instance_grid"),
+          "one_sphere": lambda: scenes.ganesha_proxy(lib, 96, 72, n=40, variant="one_sphere")}[kind]()
+    p = render.make_params(seed=8, spp=6, max_depth=5)
+    keys = ("paths", "rays_closest", "rays_any", "nodes_closest", "nodes_any", "tris_closest", "tris_any")
+    gpu = render.Renderer(lib, sc.desc, 0)
+    f1, s1 = gpu.render(p)
+    gpu.close()
+    orc = oracle_py.Oracle(sc.desc)
+    fo, so = orc.render(p, n_threads=8)
+    orc.close()
+    assert f1.tobytes() == fo.tobytes() and all(s1[k] == so[k] for k in keys)
+    for env_kv in (("SHM_BATCH_PATHS", "8192"), ("SHM_OVERLAP_PATHS", "0")):
+        monkeypatch.setenv(*env_kv)
+        g = render.Renderer(lib, sc.desc, 0)
+        f, st = g.render(p)
+        g.close()
+        monkeypatch.delenv(env_kv[0])
+        assert f.tobytes() == f1.tobytes(), env_kv
+        assert all(st[k] == s1[k] for k in keys), env_kv
+
+
 def test_full_size_properties_and_crop_parity(env):
     """BASELINE-scale geometry (S3: 4.3 M triangles, 8.5 M nodes) at a reduced frame: the oracle renders a 64x64 crop
     of tiles and the GPU must match it bit for bit; whole-frame invariants hold (weights, finiteness)."""
