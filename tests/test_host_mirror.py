@@ -36,6 +36,20 @@ def test_probe_library_exports_its_header_and_the_product_does_not(lib):
     assert not (declared & set(abi.EXPORTS))
 
 
+def test_documents_name_only_entry_points_the_headers_declare():
+    """INTEGRATION.md (the binding a maintainer of the reference would write), README.md and DESIGN.md may only name `shm_*` entry points that include/*.h declares:
+    the documents cannot drift from the boundary."""
+    import re
+    root = Path(__file__).resolve().parent.parent
+    declared = set()
+    for h in ("shimmer_hip.h", "shimmer_hip_probe.h"):
+        declared |= set(re.findall(r"\bshm_[a-z0-9_]+\b", (root / "include" / h).read_text()))
+    for doc in ("INTEGRATION.md", "README.md", "DESIGN.md"):
+        named = set(re.findall(r"\bshm_[a-z0-9_]+\b", (root / doc).read_text()))
+        unknown = sorted(n for n in named - declared if not n.endswith("_"))  # ("shm_dist_*": a family, written with the star)
+        assert not unknown, (doc, unknown)
+
+
 def test_struct_layouts_match_header(tmp_path):
     assert C.sizeof(abi.ShmBvhNode) == 32 and C.sizeof(abi.ShmPrimitive) == 16 and C.sizeof(abi.ShmSpectrum) == 32
     assert C.sizeof(abi.ShmRay) == 32 and C.sizeof(abi.ShmHit) == 32 and C.sizeof(abi.ShmFilmPixel) == 32 and C.sizeof(abi.ShmTile) == 16
