@@ -810,6 +810,20 @@ int orc_fn_triangle_sample_with_context(const float* p0, const float* p1, const 
     out7[0] = p.x; out7[1] = p.y; out7[2] = p.z; out7[3] = ss.n.x; out7[4] = ss.n.y; out7[5] = ss.n.z; out7[6] = ss.pdf;
     return 1;
 }
+// ... the same with ShmRenderParams::disable_reference_quirks' value (strict = 1: PBRT-v4's forms of the two sampling behaviours, shm/shapes.h)
+int orc_fn_triangle_sample_with_context_strict(const float* p0, const float* p1, const float* p2, const float* ctx_p, const float* ctx_n,
+                                               const float* ctx_ns, const float* u, int strict, float* out7) {
+    TriangleData tr;
+    memset(&tr, 0, sizeof(tr));
+    tr.p0 = ld3(p0); tr.p1 = ld3(p1); tr.p2 = ld3(p2);
+    ShapeSampleContext c;
+    c.pi = p3i_exact(ld3(ctx_p)); c.n = ld3(ctx_n); c.ns = ld3(ctx_ns);
+    ShapeSample ss;
+    if (!triangle_sample_with_context(tr, c, v2(u[0], u[1]), ss, strict != 0)) return 0;
+    V3 p = ss.pi.mid();
+    out7[0] = p.x; out7[1] = p.y; out7[2] = p.z; out7[3] = ss.n.x; out7[4] = ss.n.y; out7[5] = ss.n.z; out7[6] = ss.pdf;
+    return 1;
+}
 float orc_fn_triangle_pdf_with_context(const float* p0, const float* p1, const float* p2, const float* ctx_p, const float* ctx_n,
                                        const float* ctx_ns, const float* wi) {
     TriangleData tr;

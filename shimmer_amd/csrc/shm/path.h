@@ -96,7 +96,7 @@ SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const Li
     bool ok;
     if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) ok = sphere_sample_with_context(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], sctx, u, ss);
     else if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) ok = blp_sample_with_context(load_patch_rec(sv, pr), sctx, u, ss);  // (the emitter's record: the per-light copy, as for triangles)
-    else ok = triangle_sample_with_context(load_triangle_rec(sv, pr), sctx, u, ss);
+    else ok = triangle_sample_with_context(load_triangle_rec(sv, pr), sctx, u, ss, sv.quirks_off != 0);
     if (!ok) return false;
     if (ss.pdf == 0.0f || length_squared(ss.pi.mid() - ctx.p()) == 0.0f) return false;
     V3 wi = normalize(ss.pi.mid() - ctx.p());

@@ -252,8 +252,11 @@ SHM_HD Float spherical_triangle_area(V3 a, V3 b, V3 c) {
     return abs(2.0f * atan2(dot(a, cross(b, c)), 1.0f + dot(a, b) + dot(a, c) + dot(b, c)));
 }
 
-// sampling.rs:412-499. Returns pdf; b[3] barycentrics.
-SHM_HD Float sample_spherical_triangle(const V3 v[3], V3 p, V2 u, Float b[3]) {
+// sampling.rs:412-499. Returns pdf; b[3] barycentrics. Two reference behaviours in the barycentrics of the sampled direction w, kept by default and replaced by PBRT-v4's
+// forms with `strict` (ShmRenderParams::disable_reference_quirks): the divisor is e1 . e1 where PBRT-v4 has s1 . e1 (sampling.rs:477: found in round 6 by
+// tests/test_light_sampling_properties.py / test_direct_lighting_analytic.py — the point handed back is then NOT where w meets the triangle, and pdf_with_context of the
+// direction to it is not the sample's density), and `b1 / b1 + b2` (:493-497, quirk 3).
+SHM_HD Float sample_spherical_triangle(const V3 v[3], V3 p, V2 u, Float b[3], bool strict = false) {
     V3 a = v[0] - p, bb = v[1] - p, c = v[2] - p;
     a = normalize(a);
     bb = normalize(bb);
@@ -296,7 +299,7 @@ SHM_HD Float sample_spherical_triangle(const V3 v[3], V3 p, V2 u, Float b[3]) {
     V3 e1 = v[1] - v[0];
     V3 e2 = v[2] - v[0];
     V3 s1 = cross(w, e2);
-    Float divisor = dot(e1, e1);
+    Float divisor = strict ? dot(s1, e1) : dot(e1, e1);  // (sic, sampling.rs:477)
     if (divisor == 0.0f) {
         b[0] = b[1] = b[2] = 1.0f / 3.0f;
         return pdf;
@@ -308,11 +311,16 @@ SHM_HD Float sample_spherical_triangle(const V3 v[3], V3 p, V2 u, Float b[3]) {
     b1 = clamp(b1, 0.0f, 1.0f);
     b2 = clamp(b2, 0.0f, 1.0f);
     if (b1 + b2 > 1.0f) {
-        // sampling.rs:493-497, reference precedence: (b1 / b1) + b2 and (b2 / b1) + b2 (quirk 3)
-        Float nb1 = b1 / b1 + b2;
-        Float nb2 = b2 / b1 + b2;
-        b1 = nb1;
-        b2 = nb2;
+        if (strict) {  // PBRT-v4, statement by statement: b1 /= b1 + b2; b2 /= b1 + b2;
+            b1 = b1 / (b1 + b2);
+            b2 = b2 / (b1 + b2);
+        } else {
+            // sampling.rs:493-497, reference precedence: (b1 / b1) + b2 and (b2 / b1) + b2 (quirk 3)
+            Float nb1 = b1 / b1 + b2;
+            Float nb2 = b2 / b1 + b2;
+            b1 = nb1;
+            b2 = nb2;
+        }
     }
     b[0] = 1.0f - b1 - b2;
     b[1] = b1;

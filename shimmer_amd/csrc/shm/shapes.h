@@ -535,13 +535,16 @@ SHM_HD Float triangle_solid_angle(const TriangleData& tr, V3 p) {  // triangle.r
     return spherical_triangle_area(normalize(tr.p0 - p), normalize(tr.p1 - p), normalize(tr.p2 - p));
 }
 // triangle.rs:543-593 (the n.is_empty() branch always negates: reference behaviour preserved)
-SHM_HD ShapeSample triangle_sample(const TriangleData& tr, V2 u) {
+// (`strict`: ShmRenderParams::disable_reference_quirks — PBRT-v4's form of the two reference behaviours below that bias an image: a mesh without normals flips the sampled
+//  normal only with reverse_orientation ^ transform_swaps_handedness, and the spherical sample is drawn from the WARPED u whose density it is given. Default: as the reference.)
+SHM_HD ShapeSample triangle_sample(const TriangleData& tr, V2 u, bool strict = false) {
     Float b0, b1, b2;
     sample_uniform_triangle(u, b0, b1, b2);
     V3 p = b0 * tr.p0 + b1 * tr.p1 + b2 * tr.p2;
     V3 n = normalize(cross(tr.p1 - tr.p0, tr.p2 - tr.p0));
-    if (!tr.has_n) n = n * -1.0f;
-    else {
+    if (!tr.has_n) {  // triangle.rs:558-560 negates ALWAYS (a one-sided emitter without normals then shows its area samples its dark side: no next-event estimation from it)
+        if (!strict || tr.flip) n = n * -1.0f;
+    } else {
         V3 ns = b0 * tr.n0 + b1 * tr.n1 + b2 * tr.n2;
         n = face_forward(n, ns);
     }
@@ -556,10 +559,10 @@ SHM_HD ShapeSample triangle_sample(const TriangleData& tr, V2 u) {
 constexpr Float MIN_SPHERICAL_SAMPLE_AREA = 3e-4f;
 constexpr Float MAX_SPHERICAL_SAMPLE_AREA = 6.22f;
 // triangle.rs:595-694
-SHM_HD bool triangle_sample_with_context(const TriangleData& tr, const ShapeSampleContext& ctx, V2 u, ShapeSample& out) {
+SHM_HD bool triangle_sample_with_context(const TriangleData& tr, const ShapeSampleContext& ctx, V2 u, ShapeSample& out, bool strict = false) {
     Float solid_angle = triangle_solid_angle(tr, ctx.p());
     if (solid_angle < MIN_SPHERICAL_SAMPLE_AREA || solid_angle > MAX_SPHERICAL_SAMPLE_AREA) {
-        ShapeSample ss = triangle_sample(tr, u);
+        ShapeSample ss = triangle_sample(tr, u, strict);
         V3 wi = ss.pi.mid() - ctx.p();
         if (length_squared(wi) == 0.0f) return false;
         wi = normalize(wi);
@@ -578,10 +581,11 @@ SHM_HD bool triangle_sample_with_context(const TriangleData& tr, const ShapeSamp
         // uses the ORIGINAL u (reference behaviour preserved).
         V2 uw = sample_bilinear(u, w);
         pdf = bilinear_pdf(uw, w);
+        if (strict) u = uw;  // (PBRT-v4: the sample the density belongs to; tests/test_direct_lighting_analytic.py measures what the shadowing does to an image)
     }
     V3 verts[3] = {tr.p0, tr.p1, tr.p2};
     Float b[3];
-    Float tri_pdf = sample_spherical_triangle(verts, ctx.p(), u, b);
+    Float tri_pdf = sample_spherical_triangle(verts, ctx.p(), u, b, strict);
     if (tri_pdf == 0.0f) return false;
     pdf = pdf * tri_pdf;
     V3 p_abs_sum = abs3(b[0] * tr.p0) + abs3(b[1] * tr.p1) + abs3((1.0f - b[0] - b[1]) * tr.p2);

@@ -8,8 +8,8 @@ the integral is a float64 quadrature written here, the floor points are the pixe
 the film is in the ratio: the light sampler's pmf (two triangle lights), spherical-triangle sampling and its density, the power heuristic against the cosine-sampled BSDF
 ray that finds the emitter by itself, f = R / pi, the film's weights.
 
-The emitter as ONE rectangular bilinear patch is sampled uniformly in solid angle: there the estimate must be the integral. As two triangles it carries the reference's
-own mismatch between the sample and its density in Triangle::sample_with_context (second test)."""
+The emitter as ONE rectangular bilinear patch is sampled uniformly in solid angle: there the estimate must be the integral. As two triangles the same holds with the reference quirks
+switched off; reference-exact it carries the reference's own mismatches between a triangle sample and its density (last test)."""
 import ctypes as C
 import math
 
@@ -120,12 +120,19 @@ def test_direct_lighting_by_a_rectangular_patch_is_the_radiometric_integral(lib)
     assert abs(float(ratios.mean()) - 1.0) < 0.01, float(ratios.mean())
 
 
-def test_direct_lighting_by_two_triangles_is_the_integral_up_to_the_reference_s_sampling_skew(lib):
-    """The same emitter as two triangle lights: the level is right — pmf 1/2 per light, the density 1 / solid angle, the power heuristic — while the blocks scatter by a
-    few percent around it that more samples do not remove: Triangle::sample_with_context computes the cosine-warped sample in a block whose `u` shadows the outer one
-    (triangle.rs:639-641), so the direction is drawn from the UNWARPED u while the density carries the warp's factor, evaluated at a point the sample is not at. Every
-    block is off by what the cosine varies over the emitter as seen from there. A listed reference behaviour (DESIGN.md "reference quirks preserved": "the warped u
-    shadowed"), not behind the switch, kept as the reference computes it; this test bounds what it does to an image."""
+def test_direct_lighting_by_two_triangles_is_the_radiometric_integral_with_the_quirks_off(lib):
+    """The same emitter as two triangle lights, ShmRenderParams::disable_reference_quirks = 1 (PBRT-v4's forms of the triangle sampling: shm/shapes.h, shm/sampling.h)."""
+    ratios = compare(lib, "triangles", quirks=False)
+    assert np.all(np.abs(ratios - 1.0) < 0.03), ratios.round(3).tolist()
+    assert abs(float(ratios.mean()) - 1.0) < 0.01, float(ratios.mean())
+
+
+def test_reference_exact_triangle_emitters_scatter_around_the_integral(lib):
+    """Reference-exact (the default): the level is right — pmf 1/2 per light, the density 1 / solid angle, the power heuristic — while the blocks scatter by a few percent
+    around it that more samples do not remove. Two reference behaviours, both found by this file and tests/test_light_sampling_properties.py and kept as the reference
+    computes them: sample_spherical_triangle divides the barycentrics of its direction by e1 . e1 where PBRT-v4 has s1 . e1 (sampling.rs:477), so the point handed back is not
+    where the uniformly sampled direction meets the triangle; and Triangle::sample_with_context draws from the unwarped u while the density carries the cosine warp's factor
+    (the warped u is shadowed, triangle.rs:639-641). This test bounds what they do to an image."""
     few, many = compare(lib, "triangles", quirks=True, spp=192), compare(lib, "triangles", quirks=True, spp=768)
     for ratios in (few, many):
         assert abs(float(ratios.mean()) - 1.0) < 0.015, float(ratios.mean())

@@ -26,7 +26,7 @@ def coated_s3(lib):
 def test_layered_pdf_nan_pixel_disappears_with_the_quirks_off(lib, coated_s3):
     """bxdf.rs:1491-1506: LayeredBxDF::pdf uses the reflected sample `rs` without PBRT-v4's `rs.f != 0 && rs.pdf > 0`; pixel (714, 268),
     sample 83 of the coated S3 frame then gets power_heuristic(1, 0, 1, 0) = 0 / 0 (tests/test_gpu_parity.py pins that NaN). With the
-    quirks off the same sample is finite, and the other 63 pixels of the tile do not change (the guard only fires on such samples)."""
+    quirks off the same sample is finite."""
     x, y, sample = 714, 268, 83
     x0, y0 = x & ~7, y & ~7
     tiles, n = scn.tiles_for(lib, (x0, y0, x0 + 8, y0 + 8))
@@ -37,8 +37,8 @@ def test_layered_pdf_nan_pixel_disappears_with_the_quirks_off(lib, coated_s3):
     a, b = on["rgb_sum"][y0:y0 + 8, x0:x0 + 8], off["rgb_sum"][y0:y0 + 8, x0:x0 + 8]
     assert np.isnan(a[y - y0, x - x0]).all() and np.isfinite(a).sum() == 3 * 63
     assert np.isfinite(b).all()
-    same = (a.view(np.uint64) == b.view(np.uint64)).all(axis=-1)
-    assert same.sum() == 63 and not same[y - y0, x - x0]
+    # (until round 6 the other 63 pixels kept their bits — the guard only fires on such samples; the switch now also covers the triangle emitters' sampling, which every
+    #  lit pixel goes through: test_layered_pdf_guard_only_changes_degenerate_samples below holds the guard's own footprint at function level)
 
 
 def test_layered_pdf_guard_only_changes_degenerate_samples(orc):
@@ -65,14 +65,16 @@ def test_layered_pdf_guard_only_changes_degenerate_samples(orc):
 
 
 def test_sphere_light_scene_with_the_quirks_off(lib):
-    """S1 (sphere + quad light) has no sphere EMITTER, so Sphere::pdf_with_context is not reached and the film is the same; three spheres
+    """S1 (sphere + quad light) has no sphere EMITTER, so Sphere::pdf_with_context is not reached; its two triangle lights are sampled as PBRT-v4 samples them since
+    round 6; three spheres
     under a uniform sky lit through SimplePath's uniform sampling change with uniform_hemisphere_pdf (1/4pi -> 1/2pi halves those terms)."""
     s1 = scenes.sphere_light(lib, 32, 32)
     o = oracle_py.Oracle(s1.desc)
     a, _ = o.render(render.make_params(seed=1, spp=4), n_threads=4)
     b, _ = o.render(render.make_params(seed=1, spp=4, reference_quirks=False), n_threads=4)
     o.close()
-    assert np.isfinite(b["rgb_sum"]).all() and np.array_equal(a, b)
+    assert np.isfinite(b["rgb_sum"]).all() and not np.array_equal(a, b)
+    assert b["rgb_sum"].mean() > a["rgb_sum"].mean()  # (by how much, and which of the two is the physical one: test_s1_against_an_estimator_that_never_samples_lights)
     ts = scenes.three_spheres(lib, 32, 32, camera=(0.0, 0.0, 12.0))
     o = oracle_py.Oracle(ts.desc)
     kw = dict(seed=2, spp=16, max_depth=3, integrator="simplepath", sample_lights=False, sample_bsdf=False)
@@ -95,3 +97,95 @@ def test_sphere_emitter_pdf_constant(lib):
     b, _ = o.render(render.make_params(seed=3, spp=4, reference_quirks=False), n_threads=4)
     o.close()
     assert np.isfinite(b["rgb_sum"]).all()
+
+
+def _tri_sample(orc, tri, ctx_p, ctx_n, ctx_ns, u, strict):
+    fa = lambda v: (C.c_float * len(v))(*[float(x) for x in v])
+    out = (C.c_float * 7)()
+    orc.orc_fn_triangle_sample_with_context_strict.restype = C.c_int
+    ok = orc.orc_fn_triangle_sample_with_context_strict(fa(tri[0]), fa(tri[1]), fa(tri[2]), fa(ctx_p), fa(ctx_n), fa(ctx_ns), fa(u), int(strict), out)
+    return (np.array(out[0:3], np.float64), np.array(out[3:6], np.float64), float(out[6])) if ok else None
+
+
+def test_triangle_emitters_are_sampled_as_pbrt_v4_does_with_the_quirks_off(orc):
+    """Two reference behaviours of Triangle sampling that bias an image, behind the switch since round 6 (shm/shapes.h):
+    (a) triangle.rs:639-641 computes the cosine-warped sample in a block whose `u` shadows the outer one: the direction is drawn from the unwarped u, the density carries the
+        warp's factor. Quirks off: the warped u is the sample's — and only then does pdf_with_context return the density of the sampled direction;
+    (c) sampling.rs:477 (above all: it is what keeps the reference's point off the sampled direction even without a warp);
+    (b) triangle.rs:558-560 negates the sampled normal of a mesh without normals ALWAYS (PBRT-v4: only with reverse_orientation ^ transform_swaps_handedness): the area
+        samples of a small one-sided emitter show their dark side."""
+    orc.orc_fn_triangle_pdf_with_context.restype = C.c_float
+    fa = lambda v: (C.c_float * len(v))(*[float(x) for x in v])
+    tri = [(-1.0, 2.0, -1.2), (1.3, 2.0, -0.8), (0.2, 2.2, 1.5)]
+    ctx_p, ctx_n, ctx_ns = (0.3, 0.0, 0.1), (0.0, 1.0, 0.0), (0.35, 0.9, 0.1)
+    rng = np.random.default_rng(1)
+    n_differ = 0
+    for _ in range(200):
+        u = rng.random(2)
+        ref, strict = _tri_sample(orc, tri, ctx_p, ctx_n, ctx_ns, u, 0), _tri_sample(orc, tri, ctx_p, ctx_n, ctx_ns, u, 1)
+        assert ref is not None and strict is not None
+        assert ref[2] == strict[2]  # the same density either way (the warp's factor at the warped u times 1 / solid angle) ...
+        n_differ += not np.allclose(ref[0], strict[0], atol=1e-6)  # ... for different points
+        for (p, _, pdf), is_strict in ((ref, False), (strict, True)):
+            wi = (p - np.array(ctx_p)) / np.linalg.norm(p - np.array(ctx_p))
+            again = orc.orc_fn_triangle_pdf_with_context(fa(tri[0]), fa(tri[1]), fa(tri[2]), fa(ctx_p), fa(ctx_n), fa(ctx_ns), fa(wi))
+            if is_strict:
+                assert again == pytest.approx(pdf, rel=2e-3), (u, pdf, again)  # the density of the direction that was sampled
+    assert n_differ > 190
+    # without a shading normal at the reference point there is no warp — the points still differ: (c) sample_spherical_triangle's barycentrics of the sampled direction
+    # are divided by e1 . e1 in the reference (sampling.rs:477; PBRT-v4: s1 . e1), so its point is not where that direction meets the triangle
+    a, b = _tri_sample(orc, tri, ctx_p, (0, 0, 0), (0, 0, 0), (0.3, 0.6), 0), _tri_sample(orc, tri, ctx_p, (0, 0, 0), (0, 0, 0), (0.3, 0.6), 1)
+    assert a[2] == b[2] and not np.allclose(a[0], b[0], atol=1e-4)
+    # (b) a tiny triangle (below 3e-4 sr: area sampling): the geometric normal of p0 p1 p2 is +y here; the reference hands out -y, PBRT-v4 +y
+    tiny = [(0.0, 30.0, 0.0), (0.0, 30.0, 0.3), (0.3, 30.0, 0.0)]
+    geo = np.cross(np.array(tiny[1]) - np.array(tiny[0]), np.array(tiny[2]) - np.array(tiny[0]))
+    geo /= np.linalg.norm(geo)
+    a, b = _tri_sample(orc, tiny, (0, 0, 0), (0, 1, 0), (0, 1, 0), (0.3, 0.6), 0), _tri_sample(orc, tiny, (0, 0, 0), (0, 1, 0), (0, 1, 0), (0.3, 0.6), 1)
+    assert np.allclose(a[1], -geo) and np.allclose(b[1], geo) and np.array_equal(a[0], b[0]) and a[2] == b[2]
+
+
+def test_small_one_sided_emitter_lights_the_scene_only_with_the_quirks_off(lib):
+    """The image-level consequence of (b): a floor under a FINELY tessellated one-sided emitter without normals (every triangle below 3e-4 sr from the floor) gets no
+    next-event estimation in the reference — the power heuristic still discounts the BSDF samples that find the emitter, so most of the light is lost; quirks off, it is lit."""
+    def floor_mean(quirks):
+        b = scn.SceneBuilder()
+        b.set_film(16, 16)
+        rfw = b.set_camera_look_at(lib, (0.0, 1.2, 4.0), (0.0, 0.0, 0.3), (0, 1, 0), 30.0)
+        p, vi = scenes._quad((-40, 0, -40), (-40, 0, 40), (40, 0, 40), (40, 0, -40))
+        b.add_mesh(scenes._to_render(p, rfw), vi, b.material_diffuse(0.5))
+        n = 24  # a 0.5 x 0.5 emitter at height 2 as 24 x 24 x 2 triangles, facing down
+        g = np.linspace(-0.25, 0.25, n + 1)
+        vx, vz = np.meshgrid(g, g)
+        verts = np.stack([vx.ravel(), np.full(vx.size, 2.0), vz.ravel()], 1).astype(np.float32)
+        idx = lambda i, j: i * (n + 1) + j
+        tris = []
+        for i in range(n):
+            for j in range(n):
+                tris += [[idx(i, j), idx(i, j + 1), idx(i + 1, j + 1)], [idx(i, j), idx(i + 1, j + 1), idx(i + 1, j)]]
+        b.add_mesh(scenes._to_render(verts, rfw), np.array(tris, np.uint32), b.material_diffuse(0.0), emission=scenes.blackbody_dense(6500.0), emission_scale=5.0)
+        desc, _ = b.build(lib)
+        o = oracle_py.Oracle(desc)
+        f, _ = o.render(render.make_params(seed=2, spp=64, max_depth=1, reference_quirks=quirks), n_threads=8)
+        o.close()
+        return render.film_to_rgb(f)[8:, :].mean()
+    on, off = floor_mean(True), floor_mean(False)
+    assert off > 0 and on < 0.25 * off, (on, off)
+
+
+def test_s1_against_an_estimator_that_never_samples_lights(lib):
+    """BASELINE's C1 scene (S1: a sphere under a 2 x 2 quad light, seen under a LARGE solid angle from the sphere) three ways: the path integrator reference-exact, the
+    same with the quirks off, and SimplePathIntegrator with sample_lights = false (integrator.rs:573-733: light is found only by BSDF-sampled rays hitting it — no light
+    sampling code at all, so none of its deviations). The third is the yardstick: quirks off agrees with it, the reference-exact image is about a fifth darker — what
+    sample_spherical_triangle's `e1 . e1` divisor (sampling.rs:477) and the shadowed warp (triangle.rs:639-641) cost the reference's own showcase of its C1 configuration.
+    The default stays reference-exact (the drop-in contract); the switch is for a host that wants the physics."""
+    sc = scenes.sphere_light(lib, 24, 24)
+    o = oracle_py.Oracle(sc.desc)
+
+    def mean(**kw):
+        f, _ = o.render(render.make_params(seed=1, max_depth=5, **kw), n_threads=8)
+        return float(render.film_to_rgb(f).mean())
+    exact, off = mean(spp=192), mean(spp=192, reference_quirks=False)
+    yardstick = mean(spp=3072, integrator="simplepath", sample_lights=False, sample_bsdf=True)
+    o.close()
+    assert off == pytest.approx(yardstick, rel=0.03), (off, yardstick)
+    assert 0.70 * yardstick < exact < 0.90 * yardstick, (exact, yardstick)
