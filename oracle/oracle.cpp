@@ -1145,6 +1145,8 @@ void orc_fn_equal_area_sphere_to_square(const float* d, float* out2) {
     V2 p = equal_area_sphere_to_square(ld3(d));
     out2[0] = p.x; out2[1] = p.y;
 }
+// the value of ShmRenderParams::disable_reference_quirks for the scene-level leaf entries below (a render sets it from its own parameters)
+void orc_set_quirks_off(OrcScene* s, int off) { reinterpret_cast<Oracle*>(s)->sv.quirks_off = off ? 1u : 0u; }
 // Light::sample_li of light `li` from a point at the origin: out = wi[3], pdf, L[4]; returns 1 if Some
 int orc_fn_light_sample_li(OrcScene* s, uint32_t li, const float* u, int allow_incomplete_pdf, const float* lambda4, float* out8) {
     Oracle* o = reinterpret_cast<Oracle*>(s);

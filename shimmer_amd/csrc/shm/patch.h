@@ -340,8 +340,10 @@ SHM_HD V2 invert_spherical_rectangle_sample(V3 p_ref, V3 s, V3 ex, V3 ey, V3 p_r
     return v2(clamp(u0, 0.0f, 1.0f), u1b);
 }
 
-// bilinear_patch.rs:521-600 (the sample's st is not produced: see the header)
-SHM_HD bool blp_sample(const PatchData& pd, V2 u, ShapeSample& out) {
+// bilinear_patch.rs:521-600 (the sample's st is not produced: see the header). `strict` (ShmRenderParams::disable_reference_quirks, round 6): PBRT-v4's edge points
+// lerp(v, p00, p01) and lerp(v, p10, p11) here and in blp_pdf — with the reference's (sic, below) the point is not uniformly distributed and the density is not the point's:
+// a non-rectangular patch emitter renders at 40-50 % of its light (tests/test_quirks_switch.py, against an estimator that samples no lights)
+SHM_HD bool blp_sample(const PatchData& pd, V2 u, ShapeSample& out, bool strict = false) {
     V2 uv;
     Float pdf;
     if (pd.is_rect) {
@@ -353,8 +355,8 @@ SHM_HD bool blp_sample(const PatchData& pd, V2 u, ShapeSample& out) {
         uv = sample_bilinear(u, w);
         pdf = bilinear_pdf(uv, w);
     }
-    V3 pu0 = lerp3(uv.x, pd.p00, pd.p10);  // (sic, :549)
-    V3 pu1 = lerp3(uv.y, pd.p10, pd.p11);  // (sic, :550)
+    V3 pu0 = strict ? lerp3(uv.y, pd.p00, pd.p01) : lerp3(uv.x, pd.p00, pd.p10);  // (sic, :549)
+    V3 pu1 = lerp3(uv.y, pd.p10, pd.p11);  // (sic, :550: right only beside PBRT-v4's pu0)
     V3 p = lerp3(uv.x, pu0, pu1);
     V3 dpdu = pu1 - pu0;
     V3 dpdv = lerp3(uv.x, pd.p01, pd.p11) - lerp3(uv.x, pd.p00, pd.p10);
@@ -370,7 +372,7 @@ SHM_HD bool blp_sample(const PatchData& pd, V2 u, ShapeSample& out) {
     return true;
 }
 // bilinear_patch.rs:602-636: `uv` is Interaction::uv, i.e. (s, t) when the mesh has a uv array (inverted first, :607-614)
-SHM_HD Float blp_pdf(const PatchData& pd, V2 uv) {
+SHM_HD Float blp_pdf(const PatchData& pd, V2 uv, bool strict = false) {
     if (pd.has_uv) uv = invert_bilinear(uv, pd.uv00, pd.uv10, pd.uv01, pd.uv11);
     Float pdf = 1.0f;
     if (!pd.is_rect) {
@@ -378,7 +380,7 @@ SHM_HD Float blp_pdf(const PatchData& pd, V2 uv) {
                       length(cross(pd.p01 - pd.p00, pd.p11 - pd.p01)), length(cross(pd.p11 - pd.p10, pd.p11 - pd.p01))};
         pdf = bilinear_pdf(uv, w);
     }
-    V3 pu0 = lerp3(uv.y, pd.p00, pd.p10);  // (sic, :627)
+    V3 pu0 = strict ? lerp3(uv.y, pd.p00, pd.p01) : lerp3(uv.y, pd.p00, pd.p10);  // (sic, :627)
     V3 pu1 = lerp3(uv.y, pd.p10, pd.p11);
     V3 dpdu = pu1 - pu0;
     V3 dpdv = lerp3(uv.x, pd.p01, pd.p11) - lerp3(uv.x, pd.p00, pd.p10);
@@ -388,12 +390,12 @@ SHM_HD Float blp_pdf(const PatchData& pd, V2 uv) {
 constexpr Float BLP_MIN_SPHERICAL_SAMPLE_AREA = 1e-4f;
 
 // bilinear_patch.rs:638-737
-SHM_HD bool blp_sample_with_context(const PatchData& pd, const ShapeSampleContext& ctx, V2 u, ShapeSample& out) {
+SHM_HD bool blp_sample_with_context(const PatchData& pd, const ShapeSampleContext& ctx, V2 u, ShapeSample& out, bool strict = false) {
     V3 rp = ctx.p();
     V3 v00 = normalize(pd.p00 - rp), v10 = normalize(pd.p10 - rp), v01 = normalize(pd.p01 - rp), v11 = normalize(pd.p11 - rp);
     if (!pd.is_rect || spherical_quad_area(v00, v10, v11, v01) <= BLP_MIN_SPHERICAL_SAMPLE_AREA) {
         ShapeSample ss;
-        if (!blp_sample(pd, u, ss)) return false;  // (the reference unwraps: a degenerate patch would panic there)
+        if (!blp_sample(pd, u, ss, strict)) return false;  // (the reference unwraps: a degenerate patch would panic there)
         V3 wi = ss.pi.mid() - rp;
         if (length_squared(wi) == 0.0f) return false;
         wi = normalize(wi);
@@ -423,7 +425,7 @@ SHM_HD bool blp_sample_with_context(const PatchData& pd, const ShapeSampleContex
 }
 
 // bilinear_patch.rs:739-783
-SHM_HD Float blp_pdf_with_context(const PatchData& pd, const ShapeSampleContext& ctx, V3 wi) {
+SHM_HD Float blp_pdf_with_context(const PatchData& pd, const ShapeSampleContext& ctx, V3 wi, bool strict = false) {
     V3 o = offset_ray_origin(ctx.pi, ctx.n, wi);  // ctx.spawn_ray(wi)
     BilinearIntersection bi;
     if (!blp_intersect(o, wi, infinity(), pd.p00, pd.p10, pd.p01, pd.p11, bi)) return 0.0f;
@@ -431,7 +433,7 @@ SHM_HD Float blp_pdf_with_context(const PatchData& pd, const ShapeSampleContext&
     V3 rp = ctx.p();
     V3 v00 = normalize(pd.p00 - rp), v10 = normalize(pd.p10 - rp), v01 = normalize(pd.p01 - rp), v11 = normalize(pd.p11 - rp);
     if (!pd.is_rect || spherical_quad_area(v00, v10, v11, v01) <= BLP_MIN_SPHERICAL_SAMPLE_AREA) {
-        Float pdf = blp_pdf(pd, isect.uv) * distance_squared(rp, isect.p()) / abs_dot(isect.n, -wi);
+        Float pdf = blp_pdf(pd, isect.uv, strict) * distance_squared(rp, isect.p()) / abs_dot(isect.n, -wi);
         return is_inf(pdf) ? 0.0f : pdf;
     }
     Float pdf = 1.0f / spherical_quad_area(v00, v10, v11, v01);

@@ -95,7 +95,7 @@ SHM_HD bool light_sample_li(const SceneView& sv, const ShmLight& light, const Li
     const PrimRec& pr = light_prim_rec(sv, light);
     bool ok;
     if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) ok = sphere_sample_with_context(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], sctx, u, ss);
-    else if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) ok = blp_sample_with_context(load_patch_rec(sv, pr), sctx, u, ss);  // (the emitter's record: the per-light copy, as for triangles)
+    else if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) ok = blp_sample_with_context(load_patch_rec(sv, pr), sctx, u, ss, sv.quirks_off != 0);  // (the emitter's record: the per-light copy, as for triangles)
     else ok = triangle_sample_with_context(load_triangle_rec(sv, pr), sctx, u, ss, sv.quirks_off != 0);
     if (!ok) return false;
     if (ss.pdf == 0.0f || length_squared(ss.pi.mid() - ctx.p()) == 0.0f) return false;
@@ -121,7 +121,7 @@ SHM_HD Float light_pdf_li(const SceneView& sv, const ShmLight& light, const Ligh
     sctx.pi = ctx.pi; sctx.n = ctx.n; sctx.ns = ctx.ns;
     const PrimRec& pr = light_prim_rec(sv, light);
     if (!TRI_ONLY && (pr.kind_index & PRIM_SPHERE_BIT)) return sphere_pdf_with_context(sv.spheres[pr.kind_index & PRIM_INDEX_MASK], sctx, wi, sv.quirks_off != 0);
-    if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) return blp_pdf_with_context(load_patch_rec(sv, pr), sctx, wi);
+    if (!TRI_ONLY && (pr.kind_index & PRIM_PATCH_BIT)) return blp_pdf_with_context(load_patch_rec(sv, pr), sctx, wi, sv.quirks_off != 0);
     return triangle_pdf_with_context(load_triangle_rec(sv, pr), sctx, wi);
 }
 // Light::le of an infinite light for an escaped ray: UniformInfiniteLight (light.rs:795-797) or ImageInfinitelight (:900-904)

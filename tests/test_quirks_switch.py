@@ -189,3 +189,43 @@ def test_s1_against_an_estimator_that_never_samples_lights(lib):
     o.close()
     assert off == pytest.approx(yardstick, rel=0.03), (off, yardstick)
     assert 0.70 * yardstick < exact < 0.90 * yardstick, (exact, yardstick)
+
+
+@pytest.mark.parametrize("kind", ["skew_patch", "curved_patch", "rect_patch", "sphere"])
+def test_emitter_kinds_against_an_estimator_that_never_samples_lights(lib, kind):
+    """Every area-light shape over a floor and a sphere, the path integrator against SimplePathIntegrator with sample_lights = false (no light-sampling code in it). A
+    rectangular patch and a sphere agree reference-exact already (the sphere's 2.90 pi only moves MIS weights). A NON-rectangular patch — planar or curved — is area-sampled
+    through BilinearPatch::sample, whose edge points are interpolated along the wrong parameters (bilinear_patch.rs:549-553; pdf(): :627-628): reference-exact such an
+    emitter delivers 40-50 % of its light; with the quirks off (PBRT-v4's lerp(v, p00, p01), lerp(v, p10, p11): shm/patch.h) it agrees with the yardstick."""
+    b = scn.SceneBuilder()
+    b.set_film(16, 16)
+    rfw = b.set_camera_look_at(lib, (0.0, 1.5, 4.5), (0.0, 0.3, 0.0), (0, 1, 0), 35.0)
+    p, vi = scenes._quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6))
+    b.add_mesh(scenes._to_render(p, rfw), vi, b.material_diffuse(0.6))
+    rfo = np.eye(4, dtype=np.float32)
+    rfo[:3, 3] = scenes._to_render(np.array([[0.8, 0.5, 0.0]], np.float32), rfw)[0]
+    b.add_sphere(0.5, b.material_diffuse(0.7), render_from_object=rfo)
+    black, em = b.material_diffuse(0.0), dict(emission=scenes.blackbody_dense(6500.0), emission_scale=4.0)
+    if kind == "sphere":
+        r2 = np.eye(4, dtype=np.float32)
+        r2[:3, 3] = scenes._to_render(np.array([[-0.8, 1.6, 0.3]], np.float32), rfw)[0]
+        b.add_sphere(0.4, black, render_from_object=r2, **em)
+    else:
+        q = {"rect_patch": [(-1.2, 1.8, -0.5), (-0.2, 1.8, -0.5), (-1.2, 1.8, 0.5), (-0.2, 1.8, 0.5)],
+             "skew_patch": [(-1.2, 1.8, -0.5), (-0.1, 1.8, -0.3), (-1.0, 1.8, 0.6), (-0.4, 1.8, 0.4)],
+             "curved_patch": [(-1.2, 1.8, -0.5), (-0.2, 1.6, -0.5), (-1.2, 1.5, 0.5), (-0.2, 1.9, 0.5)]}[kind]
+        b.add_patch_mesh(scenes._to_render(np.array(q, np.float32), rfw), [[0, 1, 2, 3]], black, two_sided=(kind == "curved_patch"), **em)
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+
+    def mean(**kw):
+        f, _ = o.render(render.make_params(seed=1, max_depth=3, **kw), n_threads=8)
+        return float(render.film_to_rgb(f).mean())
+    yardstick = mean(spp=4096, integrator="simplepath", sample_lights=False, sample_bsdf=True)
+    exact, off = mean(spp=256), mean(spp=256, reference_quirks=False)
+    o.close()
+    assert off == pytest.approx(yardstick, rel=0.03), (kind, off, yardstick)
+    if kind in ("skew_patch", "curved_patch"):
+        assert 0.3 * yardstick < exact < 0.6 * yardstick, (kind, exact, yardstick)
+    else:
+        assert exact == pytest.approx(yardstick, rel=0.03), (kind, exact, yardstick)
