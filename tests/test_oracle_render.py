@@ -167,3 +167,32 @@ def test_force_diffuse(lib):
     finally:
         o.close()
     assert np.isfinite(render.film_to_rgb(d)).all() and sd["rays_any"] > sc_["rays_any"]  # every vertex is non-specular now: NEE everywhere
+
+
+@pytest.mark.parametrize("kind", ["glass", "thin_glass", "dispersive_glass", "coated_white_smooth", "rough_glass"])
+def test_lossless_objects_vanish_in_the_furnace(lib, kind):
+    """Under a uniform sky a body that absorbs nothing shows the sky's radiance in every pixel — whatever it refracts, however often light bounces inside (the 1 / eta^2
+    of radiance transport through an interface cancels on the way out): a smooth glass sphere, a thin-dielectric one, BK7 with its dispersion (secondary wavelengths
+    terminated, material.rs:609-619), a white CoatedDiffuse with a smooth coat of negligible thickness at maxdepth 100. A rough-glass sphere (alpha 0.3) keeps 92-93 %:
+    what single-scattering microfacet interfaces lose over the inner bounces — bounded here, not exact."""
+    b = scn.SceneBuilder()
+    b.set_film(16, 16)
+    rfw = b.set_camera_look_at(lib, (0, 0, 4), (0, 0, 0), (0, 1, 0), 32.0)
+    m = {"glass": lambda: b.material_dielectric(1.5), "thin_glass": lambda: b.material_dielectric(1.5, thin=True),
+         "dispersive_glass": lambda: b.material_dielectric(b.spectrum_named("glass-BK7")),
+         "coated_white_smooth": lambda: b.material_coated_diffuse(reflectance=1.0, roughness=0.0, thickness=1e-6, max_depth=100),
+         "rough_glass": lambda: b.material_dielectric(1.5, roughness=0.3, remap=False)}[kind]()
+    rfo = np.eye(4, dtype=np.float32)
+    rfo[:3, 3] = rfw[:3, 3]
+    b.add_sphere(1.0, m, render_from_object=rfo)
+    b.light_uniform_infinite(np.ones(471, np.float32), scale=1.0)
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    f, _ = o.render(render.make_params(seed=2, spp=512, max_depth=100), n_threads=8)
+    o.close()
+    rgb = render.film_to_rgb(f)
+    bg, centre = rgb[:2, :].reshape(-1, 3).mean(axis=0), rgb[5:11, 5:11].reshape(-1, 3).mean(axis=0)
+    if kind == "rough_glass":
+        assert np.all(centre / bg > 0.88) and np.all(centre / bg < 0.97), centre / bg
+    else:
+        assert np.allclose(centre / bg, 1.0, atol=0.012 if kind == "dispersive_glass" else 0.005), (kind, centre / bg)
