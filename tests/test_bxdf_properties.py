@@ -185,3 +185,30 @@ def test_albedo_is_bounded_and_the_estimator_agrees(quad, name):
         if s is not None:
             acc += s[0] * abs(float(s[1][2])) / s[2]
     assert np.allclose(acc / n, albedo, rtol=0.05, atol=5e-3), (acc / n, albedo)
+
+
+def test_fresnel_terms_against_their_closed_forms(olib):
+    """scattering.rs:32-104 at the points where optics gives the answer without the formula: normal incidence R = ((eta - 1) / (eta + 1))^2 from either side and
+    ((n - 1)^2 + k^2) / ((n + 1)^2 + k^2) for a conductor, grazing incidence R = 1, total internal reflection beyond the critical angle, Brewster's angle (the p-polarised
+    term vanishes: R = r_s^2 / 2), and R + T = 1 is what DielectricBxDF::sample_f's choice between the two lobes assumes (pr + pt, bxdf.rs:594-600)."""
+    olib.orc_fn_fresnel_dielectric.restype, olib.orc_fn_fresnel_dielectric.argtypes = F, [F, F]
+    olib.orc_fn_fresnel_complex.restype, olib.orc_fn_fresnel_complex.argtypes = F, [F, F, F]
+    for eta in (1.33, 1.5, 2.4):
+        r0 = ((eta - 1.0) / (eta + 1.0)) ** 2
+        assert olib.orc_fn_fresnel_dielectric(1.0, eta) == pytest.approx(r0, rel=1e-5)
+        assert olib.orc_fn_fresnel_dielectric(-1.0, eta) == pytest.approx(r0, rel=1e-5)  # from inside (cos < 0 flips the interface: scattering.rs:36-41)
+        assert olib.orc_fn_fresnel_dielectric(1e-6, eta) == pytest.approx(1.0, abs=1e-4)
+        cos_crit = math.sqrt(1.0 - 1.0 / (eta * eta))
+        assert olib.orc_fn_fresnel_dielectric(-(cos_crit - 1e-3), eta) == 1.0            # beyond the critical angle, from inside
+        assert olib.orc_fn_fresnel_dielectric(-(cos_crit + 1e-2), eta) < 1.0
+        cb = math.cos(math.atan(eta))                                                     # Brewster
+        ct = math.sqrt(1.0 - (1.0 - cb * cb) / (eta * eta))
+        rs = (cb - eta * ct) / (cb + eta * ct)
+        assert olib.orc_fn_fresnel_dielectric(cb, eta) == pytest.approx(0.5 * rs * rs, rel=1e-4)
+    for n, k in ((0.2, 3.9), (1.4, 1.6), (2.0, 0.0)):
+        r0 = ((n - 1.0) ** 2 + k * k) / ((n + 1.0) ** 2 + k * k)
+        assert olib.orc_fn_fresnel_complex(1.0, n, k) == pytest.approx(r0, rel=1e-5)
+        assert olib.orc_fn_fresnel_complex(1e-6, n, k) == pytest.approx(1.0, abs=1e-4)
+    # a conductor without absorption is a dielectric
+    for c in (1.0, 0.7, 0.2):
+        assert olib.orc_fn_fresnel_complex(c, 1.5, 0.0) == pytest.approx(olib.orc_fn_fresnel_dielectric(c, 1.5), rel=1e-5)
