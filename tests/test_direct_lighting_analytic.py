@@ -138,3 +138,36 @@ def test_reference_exact_triangle_emitters_scatter_around_the_integral(lib):
         assert abs(float(ratios.mean()) - 1.0) < 0.015, float(ratios.mean())
         assert np.all(np.abs(ratios - 1.0) < 0.08), ratios.round(3).tolist()
     assert many.std() > 0.6 * few.std() and many.std() > 0.015  # systematic, not noise: four times the samples leave the scatter where it was
+
+
+def test_point_light_falls_off_as_the_cosine_over_the_square_of_the_distance(lib):
+    """PointLight::sample_li (light.rs:560-600): a floor under a point light at height H shows L(x) proportional to cos(theta) / d^2 = H / d^3 — the ratio between two floor
+    points needs no unit. Pixel blocks against the block directly under the light."""
+    b = scn.SceneBuilder()
+    b.set_film(W, W)
+    rfw = b.set_camera_look_at(lib, (0.0, 1.2, 4.0), (0.0, 0.0, 0.3), (0, 1, 0), 30.0)
+    p, vi = _quad((-40, 0, -40), (-40, 0, 40), (40, 0, 40), (40, 0, -40))
+    b.add_mesh(_to_render(p, rfw), vi, b.material_diffuse(R))
+    b.light_point(_to_render(np.array([[0.0, H, 0.0]], np.float32), rfw)[0], blackbody_dense(5000.0), scale=10.0)
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    film, _ = o.render(render.make_params(seed=6, spp=64, max_depth=1), n_threads=8)
+    rgb = render.film_to_rgb(film)[..., 1]
+    o.lib.orc_fn_camera_ray_differential.restype, o.lib.orc_fn_camera_ray_differential.argtypes = None, [C.c_void_p, FP, FP, FP]
+    cam_pos = -np.asarray(rfw, np.float64).reshape(4, 4)[:3, 3]
+    want = np.full((W, W), np.nan)
+    for y in range(W):
+        for x in range(W):
+            out = (F * 18)()
+            o.lib.orc_fn_camera_ray_differential(C.byref(desc.camera), fa((x + 0.5, y + 0.5)), fa((0.5, 0.5)), out)
+            org, d = np.array(out[0:3], np.float64) + cam_pos, np.array(out[3:6], np.float64)
+            if d[1] < -1e-6:
+                hit = org + (-org[1] / d[1]) * d
+                want[y, x] = H / (hit[0] ** 2 + H ** 2 + hit[2] ** 2) ** 1.5
+    o.close()
+    ok = np.isfinite(want) & (want > 0.02 * np.nanmax(want))
+    ratio = rgb[ok] / want[ok]
+    assert ok.sum() > 200
+    # one constant of proportionality for every pixel: a delta light has no sampling noise, what is left is the pixel-centre approximation of the box filter (and the
+    # wavelength estimator's, which a single channel of a smooth spectrum keeps below a percent at 64 spp)
+    assert ratio.std() / ratio.mean() < 0.02, (ratio.std() / ratio.mean())

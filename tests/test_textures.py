@@ -641,3 +641,38 @@ def test_disable_texture_filtering(lib):
     ra, rb = a["rgb_sum"] / a["weight_sum"][..., None], b["rgb_sum"] / b["weight_sum"][..., None]
     assert np.isfinite(rb).all() and not np.array_equal(a, b)
     assert abs(rb.mean() / ra.mean() - 1) < 0.2  # same scene, sharper textures
+
+
+@pytest.mark.parametrize("flt", ["bilinear", "trilinear", "ewa"])
+def test_filters_reproduce_a_linear_ramp(lib, flt):
+    """A property no reading of mipmap.rs is needed for: every filter here is a normalised kernel that is symmetric about the lookup point — bilinear interpolation, its
+    blend across two box-filtered levels, the EWA Gaussian over its ellipse — and the box pyramid of a linear image is linear; so filtering the ramp a + b x + c y gives
+    the ramp's value AT the lookup point, for any footprint that stays inside the image (clamp wrap, centre region)."""
+    n = 64
+    yy, xx = np.mgrid[0:n, 0:n].astype(np.float64)
+    a, bx, cy = 0.2, 0.5 / n, 0.25 / n
+    img = (a + bx * (xx + 0.5) + cy * (yy + 0.5)).astype(np.float32)  # texel centres at (x + 0.5, y + 0.5) / n
+    sc = scenes.cornell_box(lib, 8, 8)
+    b = sc.builder
+    b.add_image_texture(np.stack([img] * 3, axis=-1), filter=flt, wrap="clamp", max_anisotropy=8.0)
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    out = (C.c_float * 3)()
+    rng = np.random.default_rng(12)
+    errs = []
+    try:
+        for _ in range(200):
+            s, t = rng.uniform(0.35, 0.65, 2)
+            mag = 2.0 ** -rng.uniform(2.5, 7.0)  # footprints of ~0.5 to 11 texels
+            ang, ratio = rng.uniform(0, 2 * np.pi), rng.choice([1.0, 0.5, 0.2])
+            d0 = (mag * math.cos(ang), mag * math.sin(ang))
+            d1 = (-ratio * mag * math.sin(ang), ratio * mag * math.cos(ang))
+            o.lib.orc_fn_texture_filter(o.handle, desc.n_image_textures - 1, fa(float(s), float(t)), fa(*map(float, d0)), fa(*map(float, d1)), out)
+            want = a + bx * s * n + cy * t * n
+            errs.append(out[0] / want - 1.0)
+            # (bilinear / trilinear are exact on a ramp; EWA sums a truncated Gaussian over the LATTICE points inside its ellipse, which are not symmetric about the lookup
+            #  point: each lookup is off by a fraction of a texel of its level — bounded here —, with no systematic shift — the mean below)
+            assert out[0] == pytest.approx(want, rel=1.5e-2 if flt == "ewa" else 2e-5), (flt, s, t, mag, ratio, out[0], want)
+        assert abs(np.mean(errs)) < (1.5e-3 if flt == "ewa" else 1e-6), np.mean(errs)
+    finally:
+        o.close()
