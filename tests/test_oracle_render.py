@@ -196,3 +196,25 @@ def test_lossless_objects_vanish_in_the_furnace(lib, kind):
         assert np.all(centre / bg > 0.88) and np.all(centre / bg < 0.97), centre / bg
     else:
         assert np.allclose(centre / bg, 1.0, atol=0.012 if kind == "dispersive_glass" else 0.005), (kind, centre / bg)
+
+
+@pytest.mark.parametrize("amount", [0.25, 0.7])
+def test_mix_material_in_the_furnace_is_the_weighted_reflectance(lib, amount):
+    """A convex diffuse body under a uniform sky shows R times the sky (no inter-reflection); MixMaterial chooses its second material with probability `amount`
+    (material.rs:1308-1330), so the mix of R = 0.2 and R = 0.8 shows (1 - amount) 0.2 + amount 0.8 — the only test of WHICH way the amount leans that needs no text."""
+    b = scn.SceneBuilder()
+    b.set_film(16, 16)
+    rfw = b.set_camera_look_at(lib, (0, 0, 4), (0, 0, 0), (0, 1, 0), 32.0)
+    m = b.material_mix(b.material_diffuse(0.2), b.material_diffuse(0.8), amount=amount)
+    rfo = np.eye(4, dtype=np.float32)
+    rfo[:3, 3] = rfw[:3, 3]
+    b.add_sphere(1.0, m, render_from_object=rfo)
+    b.light_uniform_infinite(np.ones(471, np.float32), scale=1.0)
+    desc, _ = b.build(lib)
+    o = oracle_py.Oracle(desc)
+    f, _ = o.render(render.make_params(seed=2, spp=256, max_depth=5), n_threads=8)
+    o.close()
+    rgb = render.film_to_rgb(f)
+    bg = np.mean([rgb[0, 0], rgb[0, -1], rgb[-1, 0], rgb[-1, -1]], axis=0)  # (the corners: the sphere's disk reaches into the border rows of this frame)
+    centre = rgb[5:11, 5:11].reshape(-1, 3).mean(axis=0)
+    assert np.allclose(centre / bg, (1 - amount) * 0.2 + amount * 0.8, rtol=0.03), (centre / bg)
