@@ -575,7 +575,14 @@ def rank_main(args):
             r.dist_selftest()  # film rows through the RCCL send / recv group, looped back to this rank
     if rank == 0 and world == 1 and not use_dist and not args.shard_of:
         # self-check outside the timed region: every pixel received all its samples, all sums finite
+        t0 = time.perf_counter()
         host = r.read_film()
+        t_readback = time.perf_counter() - t0
+        # what the boundary moves over PCIe, never part of `value`: the scene goes up once at shm_scene_create, the film (32 B per pixel) comes back once per frame
+        film_bytes = int(host.nbytes)
+        out["host_transfers"] = {"scene_create_s": t_upload, "film_readback_ms": t_readback * 1e3, "film_bytes": film_bytes,
+                                 "value_with_film_readback": out["value"] * (out["ms_per_step"] / (out["ms_per_step"] + t_readback * 1e3)),
+                                 "note": "value counts the render with the scene resident in HBM; shm_scene_create (flatten + pair layout + H2D) is paid once per scene, the film read-back once per frame"}
         if not (host["weight_sum"] == float(args.spp)).all():
             raise SystemExit("film is incomplete")
         # LayeredBxDF::pdf of the reference can return 0 / 0 ("Reference quirks preserved"): counted, and fatal only where no
