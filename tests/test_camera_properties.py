@@ -81,3 +81,21 @@ def test_thin_lens_focuses_every_lens_sample_on_the_plane_of_focus(lib, olib, fo
         assert origins.std(axis=0).min() > 0.2 * lens_radius / 2  # ... and the lens samples do spread over the disk
     # the centre of the concentric mapping is the centre of the lens
     assert np.allclose(ray(olib, cam, (123.0, 45.0), (0.5, 0.5))["o"], 0.0, atol=1e-7)
+
+
+@pytest.mark.parametrize("res", [(640, 480), (300, 700)])
+def test_orthographic_rays_are_parallel_and_their_origins_a_scaled_raster(lib, olib, res):
+    """OrthographicCamera (camera.rs:658-840): every ray runs along +z of camera space; its origin is the raster point mapped onto the screen window — [-1, 1] along the
+    shorter axis, the aspect ratio along the other —, so origins are affine in the raster with square pixels of size 2 / min(w, h), and the auxiliary rays start one pixel
+    to the right / below with the same direction."""
+    cam = abi.ShmCamera()
+    rfw = (F * 16)()
+    abi.check(lib, lib.shm_camera_orthographic(fa(IDENTITY), (C.c_int32 * 2)(*res), 0.0, 1e6, C.byref(cam), rfw), "shm_camera_orthographic")
+    w, h = res
+    px = 2.0 / min(w, h)
+    for x, y in [(0.0, 0.0), (w, h), (w / 2, h / 2), (0.3 * w, 0.9 * h), (17.25, 3.5)]:
+        r = ray(olib, cam, (x, y))
+        assert np.allclose(r["d"], (0.0, 0.0, 1.0), atol=1e-6)
+        assert r["o"][0] == pytest.approx((x - w / 2) * px, abs=2e-5) and r["o"][1] == pytest.approx(-(y - h / 2) * px, abs=2e-5)
+        assert np.allclose(r["rx_d"], r["d"], atol=1e-6) and np.allclose(r["ry_d"], r["d"], atol=1e-6)
+        assert np.allclose(r["rx_o"] - r["o"], (px, 0.0, 0.0), atol=2e-5) and np.allclose(r["ry_o"] - r["o"], (0.0, -px, 0.0), atol=2e-5)
