@@ -407,7 +407,9 @@ typedef struct ShmRenderParams {
      * (round 6): sample_spherical_triangle's barycentrics divided by s1 . e1 (sampling.rs:477: e1 . e1) and renormalised as in PBRT-v4 (:493-497),
      * Triangle::sample_with_context drawing from the warped u whose density it reports (triangle.rs:639-641 shadows it), Triangle::sample negating
      * the normal of a mesh without normals only with reverse_orientation ^ transform_swaps_handedness (triangle.rs:558-560: always); a non-rectangular
-     * bilinear patch is area-sampled with PBRT-v4's edge points in sample() and pdf() (bilinear_patch.rs:549-553, 627-628). Reference-exact,
+     * bilinear patch is area-sampled with PBRT-v4's edge points in sample() and pdf() (bilinear_patch.rs:549-553, 627-628); a shadow ray enters an instance
+     * through apply_ray_inverse with its t_max (primitive.rs:173-176 maps it forward) and an instanced hit's interaction is mapped back by PBRT-v4's
+     * Transform::operator() (transform.rs:573-608 uses the inverse for everything but the point): instances render as their baked copies. Reference-exact,
      * BASELINE's C1 scene is 19 % darker than an estimator that samples no lights; with 1 it agrees with it (tests/test_quirks_switch.py). */
     uint8_t disable_reference_quirks;
     uint8_t pad[7];

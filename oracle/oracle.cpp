@@ -150,6 +150,12 @@ bool bvh_intersect_predicate_from(const SceneView& sv, uint32_t root, V3 ro, V3 
                     if (sv.prim_recs[slot].kind_index & PRIM_INSTANCE_BIT) {
                         // TransformedPrimitive::intersect_predicate, primitive.rs:173-176: the FORWARD apply_ray, as written there
                         const ShmInstance& in = sv.instances[sv.prim_recs[slot].kind_index & PRIM_INDEX_MASK];
+                        if (sv.quirks_off) {  // PBRT-v4: TransformedPrimitive::IntersectP maps the ray as Intersect does (ApplyInverse, t_max with it)
+                            Float t_inst = t_max;
+                            Ray ri = xf_ray_inverse(in.primitive_from_render, ro, rd, t_inst);
+                            if (bvh_intersect_predicate_from(sv, in.root_node, ri.o, ri.d, t_inst, c)) return true;
+                            continue;
+                        }
                         Ray w;
                         w.o = ro; w.d = rd;
                         Ray r = xf_ray(in.render_from_primitive, w);  // the origin is exact: no error step, t_max unchanged

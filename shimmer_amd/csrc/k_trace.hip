@@ -90,7 +90,11 @@ constexpr uint32_t SGN_RAY = 15u, SGN_HIT = 16u, SGN_HIT_INSIDE = 32u, SGN_INST_
 // behind it, so that nothing but path, t_max, stack pointer and link word is live across ~1 000 instructions of interval arithmetic (inlined with the state live, they made
 // the loop itself spill; as real calls, the calling convention's caller-saved registers did the same). An instance's entry saves the OUTER ray state the same way: leaving is
 // three loads, not a second ray set-up. The hit record is the ABI's 32-byte ShmHit (t, phi and the instance ride along).
-template <bool ANY, bool GEN, int LDS_N, bool SAVE_LDS = false>
+// STRICT (any-hit, scenes with instances, ShmRenderParams::disable_reference_quirks; round 6): TransformedPrimitive::intersect_predicate maps the ray as intersect does —
+// apply_ray_inverse, t_max shrinking with the origin's error step — where the reference writes the FORWARD apply_ray (primitive.rs:173-176: instanced objects cast their
+// shadows from somewhere else; tests/test_instancing.py). The outer t_max rides in the spare word of save area 0. Own instantiations (k_trace5_any_strict): the
+// reference-exact kernels are compiled without a trace of it.
+template <bool ANY, bool GEN, int LDS_N, bool SAVE_LDS = false, bool STRICT = false>
 __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_ptr,
                                             uint32_t n_direct, uint32_t* head, const ShmRay* __restrict__ rays,
                                             ShmHit* __restrict__ hits, uint8_t* __restrict__ occluded_out,
@@ -216,7 +220,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         float4* a = save_wave + (size_t)area * (3 * WAVE) + lane;
         a[0] = make_float4(ro.x, ro.y, ro.z, inv_dir.x);
         a[WAVE] = make_float4(inv_dir.y, inv_dir.z, rs.sx, rs.sy);
-        a[2 * WAVE] = make_float4(rs.sz, __int_as_float(rs.kz), __uint_as_float(sgn & SGN_RAY), 0.0f);
+        a[2 * WAVE] = make_float4(rs.sz, __int_as_float(rs.kz), __uint_as_float(sgn & SGN_RAY), (ANY && STRICT && area == 0) ? t_max : 0.0f);
     };
     auto restore_ray_state = [&](int area) {
         if (K5_OUTER_IN_REGS && area == 0) {
@@ -239,6 +243,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
         rs.kx = rs.kz == 2 ? 0 : rs.kz + 1;
         rs.ky = rs.kx == 2 ? 0 : rs.kx + 1;
         sgn = (sgn & ~SGN_RAY) | __float_as_uint(s2.z);
+        if (ANY && STRICT && area == 0) t_max = s2.w;  // (the outer ray's extent: apply_ray_inverse shortened the inner one)
     };
 
     // Bounds3f::intersect_p_cached (bounding_box.rs:520-563) without its `t0 < t_max`: the t_max-independent part of the verdict, and t0
@@ -482,7 +487,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                         else push((uint32_t)CUR_MARKER | slot, __float_as_uint(t_max));
                         sgn = (sgn & (SGN_RAY | SGN_HIT)) | ((idx + 1u) << SGN_INST_SHIFT);
                         Ray r;
-                        if (ANY) { Ray w; w.o = ro; w.d = rd; r = xf_ray(in.render_from_primitive, w); }
+                        if (ANY && !STRICT) { Ray w; w.o = ro; w.d = rd; r = xf_ray(in.render_from_primitive, w); }
                         else r = xf_ray_inverse(in.primitive_from_render, ro, rd, t_max);
                         set_ray(r.o, r.d);
                         cur = root_test(ra, rb) ? __float_as_uint(rb.z) : (uint32_t)CUR_POP;  // (a miss pops the marker: back out)
@@ -507,7 +512,7 @@ __device__ __forceinline__ void trace5_body(const SceneView& sv, const uint32_t*
                         V3 rd = v3(r0.w, r1.x, r1.y);
                         if (sgn >> SGN_INST_SHIFT) {
                             const ShmInstance& in = sv.instances[(sgn >> SGN_INST_SHIFT) - 1u];
-                            rd = xf_vector(ANY ? in.render_from_primitive : in.primitive_from_render, rd);
+                            rd = xf_vector((ANY && !STRICT) ? in.render_from_primitive : in.primitive_from_render, rd);
                         }
                         {
                             // (a sphere or a bilinear patch: an instance never parks here — it is alone in its leaf, and such a leaf's link word names it, above)
@@ -715,6 +720,17 @@ template <>
 __global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_GEN_HEAVY_WAVES, K5_GEN_HEAVY_WAVES))) k_trace5<true, true, true>(K5_PARAMS) {
     trace5_body<true, true, K5_GEN_HEAVY_LDS, true>(K5_ARGS);
 }
+// the any-hit kernels of scenes with instances under ShmRenderParams::disable_reference_quirks (trace5_body, STRICT): seven waves, and the five-wave build for patch-heavy scenes
+template <bool HEAVY>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace5_any_strict(K5_PARAMS);
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_GEN_ANY_WAVES, K5_GEN_ANY_WAVES))) k_trace5_any_strict<false>(K5_PARAMS) {
+    trace5_body<true, true, K5Shape<K5_GEN_ANY_WAVES>::LDS, false, true>(K5_ARGS);
+}
+template <>
+__global__ void __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(K5_GEN_HEAVY_WAVES, K5_GEN_HEAVY_WAVES))) k_trace5_any_strict<true>(K5_PARAMS) {
+    trace5_body<true, true, K5_GEN_HEAVY_LDS, true, true>(K5_ARGS);
+}
 
 // (Round 5 built and measured k_trace6 here — TWO rays per lane, each phase run for whichever slot of a lane is ready: bit-exact, 23 % fewer wave iterations, 38.3 instead of 31.4
 // lanes per VALU instruction, and 62 % more instructions per iteration for the selects that bring the chosen slot's state to each phase: K2 91 -> 133 ms, K3 58 -> 79 ms.
@@ -779,7 +795,13 @@ int wf_launch_trace(ShmScene* s, bool any, hipStream_t stream, const uint32_t* q
     hipLaunchKernelGGL((k_trace5<ANY, __VA_ARGS__>), dim3(s->trace3_blocks[ANY]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays,  \
                        hits, occluded, L, contrib, s->d_counters, spill, s->spill3_levels[ANY], (ANY ? s->refill_min_any : s->refill_min), leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n, \
                        s->d_gen_save[ANY ? 1 : 0], (ANY ? s->other_min_any : s->other_min), hit2)
-    if (tri_only) { if (any) TRACE5_LAUNCH(true, false); else TRACE5_LAUNCH(false, false); }
+    if (any && s->flat.has_instances && s->dsv.quirks_off) {  // (the PBRT-v4 form of the shadow ray's way into an instance: its own instantiations)
+        if (s->gen_heavy) hipLaunchKernelGGL((k_trace5_any_strict<true>), dim3(s->trace3_blocks[1]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, hits, occluded, L, contrib,
+                                             s->d_counters, spill, s->spill3_levels[1], s->refill_min_any, leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n, s->d_gen_save[1], s->other_min_any, hit2);
+        else hipLaunchKernelGGL((k_trace5_any_strict<false>), dim3(s->trace3_blocks[1]), dim3(TRACE_BLOCK), 0, stream, s->dsv, queue, n_ptr, n_direct, heads, rays, hits, occluded, L, contrib,
+                                s->d_counters, spill, s->spill3_levels[1], s->refill_min_any, leaf_min, s->queue_parts, s->trace_rays_per_lane, hit16, s->d_big_leaf_n, s->d_gen_save[1], s->other_min_any, hit2);
+    }
+    else if (tri_only) { if (any) TRACE5_LAUNCH(true, false); else TRACE5_LAUNCH(false, false); }
     else if (s->gen_heavy) { if (any) TRACE5_LAUNCH(true, true, true); else TRACE5_LAUNCH(false, true, true); }
     else { if (any) TRACE5_LAUNCH(true, true); else TRACE5_LAUNCH(false, true); }
 #undef TRACE5_LAUNCH

@@ -248,7 +248,7 @@ SHM_HD SurfaceInteraction hit_interaction(const SceneView& sv, const Hit& h, V3 
     if (!TRI_ONLY && h.inst >= 0) {
         const ShmInstance& in = sv.instances[sv.prim_recs[h.inst].kind_index & PRIM_INDEX_MASK];
         V3 wo_local = xf_vector(in.primitive_from_render, wo);  // -(m_inv d) == m_inv (-d) exactly
-        return xf_surface_interaction(in.render_from_primitive, in.primitive_from_render, hit_interaction_local<false>(sv, h, wo_local));
+        return xf_surface_interaction(in.render_from_primitive, in.primitive_from_render, hit_interaction_local<false>(sv, h, wo_local), sv.quirks_off != 0);
     }
     return hit_interaction_local<TRI_ONLY>(sv, h, wo);
 }

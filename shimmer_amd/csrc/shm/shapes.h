@@ -402,8 +402,30 @@ SHM_HD Ray xf_ray(const Float* m, const Ray& val) {
     return r;
 }
 // transform.rs:556-608 TransformI<SurfaceInteraction> (quirk 6: t = self.inverse() is used for everything
-// but the point). m = self.m, minv = self.m_inv; t.m = minv, t.m_inv = m.
-SHM_HD SurfaceInteraction xf_surface_interaction(const Float* m, const Float* minv, const SurfaceInteraction& v) {
+// but the point). m = self.m, minv = self.m_inv; t.m = minv, t.m_inv = m. `strict` (ShmRenderParams::disable_reference_quirks, round 6): PBRT-v4's Transform::operator()
+// (SurfaceInteraction) — vectors through m, normals through the transpose of m_inv.
+SHM_HD SurfaceInteraction xf_surface_interaction(const Float* m, const Float* minv, const SurfaceInteraction& v, bool strict = false) {
+    if (strict) {
+        const Float* t = m;
+        m = minv;     // (below, "minv" maps vectors and "m" maps normals: swapped, they are the forward maps)
+        minv = t;
+        SurfaceInteraction r;
+        V3 n = normalize(xf_normal(m, v.n));
+        r.pi = xf_point_i(minv, v.pi);
+        r.wo = normalize(xf_vector(minv, v.wo));
+        r.n = n;
+        r.uv = v.uv;
+        r.dpdu = xf_vector(minv, v.dpdu);
+        r.dpdv = xf_vector(minv, v.dpdv);
+        r.dndu = xf_normal(m, v.dndu);
+        r.dndv = xf_normal(m, v.dndv);
+        r.shading.n = face_forward(normalize(xf_normal(m, v.shading.n)), n);
+        r.shading.dpdu = xf_vector(minv, v.shading.dpdu);
+        r.shading.dpdv = xf_vector(minv, v.shading.dpdv);
+        r.shading.dndu = xf_normal(m, v.shading.dndu);
+        r.shading.dndv = xf_normal(m, v.shading.dndv);
+        return r;
+    }
     SurfaceInteraction r;
     V3 n = normalize(xf_normal(m, v.n));            // t.apply(Normal) uses t.m_inv = m
     r.pi = xf_point_i(m, v.pi);
@@ -513,7 +535,7 @@ SHM_HD SurfaceInteraction sphere_interaction(const ShmSphere& s, const QuadricIn
     V3 wo_object = xf_vector(s.object_from_render, wo);
     SurfaceInteraction si = surface_interaction_new(p3i_from_value_and_error(p_hit, p_error), v2(u, v), wo_object,
                                                     dpdu, dpdv, dndu, dndv, flip_normal);
-    return xf_surface_interaction(s.render_from_object, s.object_from_render, si);
+    return xf_surface_interaction(s.render_from_object, s.object_from_render, si, strict);
 }
 
 // ---------------------------------------------------------------------------------------------

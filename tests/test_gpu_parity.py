@@ -235,6 +235,13 @@ def test_both_occupancies_of_the_general_traversal_kernels(env, monkeypatch, hea
         assert np.array_equal(fg, fo), sc.name
         for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
             assert stg[k] == sto[k], (sc.name, k)
+        if sc.desc.n_instances:  # ... and with the reference quirks off: the any-hit kernels' STRICT instantiations (k_trace5_any_strict<heavy>), at this occupancy
+            p = render.make_params(seed=11, spp=spp, max_depth=depth, reference_quirks=False)
+            fg, stg = gpu.render(p)
+            fo, sto = orc.render(p, n_threads=os.cpu_count() or 1)
+            assert np.array_equal(fg, fo), sc.name
+            for k in ("paths", "rays_closest", "rays_any", "nodes_closest", "tris_closest", "nodes_any", "tris_any"):
+                assert stg[k] == sto[k], (sc.name, k)
         gpu.close(); orc.close()
 
 
@@ -695,10 +702,12 @@ def test_reference_quirks_off_no_nan_and_still_bit_exact(env):
     gpu.close(); orc.close()
 
 
-@pytest.mark.parametrize("name", ["S1_sphere_light", "three_spheres_environment", "S2_cornell_textured", "S2_cornell_coated", "instanced"])
+@pytest.mark.parametrize("name", ["S1_sphere_light", "three_spheres_environment", "S2_cornell_textured", "S2_cornell_coated", "instanced", "S3_small_instance_grid",
+                                  "S3_small_instanced", "S2_cornell_patches_skewed", "S3_small_mesh_emitter", "S3_small_quads", "S3_small_one_sphere"])
 def test_render_parity_with_reference_quirks_off(env, name):
     """Every site the switch touches (sphere (u, v) through acos, SphericalMapping, LayeredBxDF::pdf's guard, the dropped non-finite
-    samples) through the wavefront pipeline == the scalar oracle, bit for bit, with the quirks off as with them on."""
+    samples; round 6: triangle and patch emitters sampled as PBRT-v4 samples them, the shadow ray's way into an instance — the any-hit kernels' STRICT instantiations, at
+    both occupancies — and the instanced hit's interaction) through the wavefront pipeline == the scalar oracle, bit for bit, with the quirks off as with them on."""
     lib, oracle_py, render, scenes = env
     sc, spp, depth = SCENES[name](scenes, lib)
     gpu, orc = render.Renderer(lib, sc.desc, 0), oracle_py.Oracle(sc.desc)

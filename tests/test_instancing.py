@@ -174,3 +174,49 @@ def test_what_the_reference_s_instance_mappings_do_to_an_image(lib):
     baked, inst = build(True), build(False)
     assert 1.15 < inst.mean() / baked.mean() < 1.45, inst.mean() / baked.mean()
     assert (np.abs(inst - baked) > 0.1 * np.maximum(baked, 1e-3)).mean() > 0.2
+
+
+def test_with_the_quirks_off_instances_render_as_their_baked_copies(lib):
+    """ShmRenderParams::disable_reference_quirks (round 6): intersect_predicate maps the shadow ray with apply_ray_inverse as intersect does, and the instanced hit's
+    interaction goes through PBRT-v4's Transform::operator()(SurfaceInteraction) — the two images of the test above are then the same image (the same sample streams meet
+    the same geometry: equal to rounding, not merely in the mean)."""
+    import math
+
+    def build(baked):
+        rng = np.random.Generator(np.random.PCG64(77))
+        b = scn.SceneBuilder()
+        b.set_film(48, 36)
+        rfw = b.set_camera_look_at(lib, (0.0, 2.2, 7.0), (0.0, 0.8, 0.0), (0, 1, 0), 40.0)
+        mat = b.material_diffuse(0.7)
+        sv, sf = scenes.icosphere(2)
+        p0 = (sv * np.float32(0.6)).astype(np.float32)
+        placements = []
+        for _ in range(5):
+            ang, axis = rng.uniform(0, 2 * np.pi), rng.normal(size=3)
+            axis /= np.linalg.norm(axis)
+            k = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+            m = np.eye(4)
+            m[:3, :3] = (np.eye(3) + math.sin(ang) * k + (1 - math.cos(ang)) * (k @ k)) @ np.diag(rng.uniform(0.6, 1.4, 3))
+            m[:3, 3] = (rng.uniform(-2.5, 2.5), rng.uniform(0.8, 1.6), rng.uniform(-1.5, 1.5))
+            placements.append(np.asarray(rfw, np.float64).reshape(4, 4) @ m)
+        if baked:
+            for m in placements:
+                b.add_mesh((np.c_[p0.astype(np.float64), np.ones(len(p0))] @ m.T)[:, :3].astype(np.float32), sf, mat)
+        else:
+            b.begin_object("blob")
+            b.add_mesh(p0, sf, mat)
+            b.end_object()
+            for m in placements:
+                b.add_instance("blob", m.astype(np.float32))
+        p, vi = scenes._quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6))
+        b.add_mesh(scenes._to_render(p, rfw), vi, b.material_diffuse(0.6))
+        q = np.array([(-1.5, 5.0, -1.5), (1.5, 5.0, -1.5), (-1.5, 5.0, 1.5), (1.5, 5.0, 1.5)], np.float32)
+        b.add_patch_mesh(scenes._to_render(q, rfw), [[0, 1, 2, 3]], b.material_diffuse(0.0), emission=scenes.blackbody_dense(6500.0), emission_scale=12.0)
+        desc, _ = b.build(lib)
+        o = oracle_py.Oracle(desc)
+        f, _ = o.render(render.make_params(seed=1, spp=96, max_depth=4, reference_quirks=False), n_threads=8)
+        o.close()
+        return render.film_to_rgb(f).mean(axis=2)
+    baked, inst = build(True), build(False)
+    assert inst.mean() == pytest.approx(baked.mean(), rel=2e-3)
+    assert (np.abs(inst - baked) > 0.1 * np.maximum(baked, 1e-3)).mean() < 0.01
