@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--integrator", default="path", choices=["path", "simplepath", "randomwalk"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--exposure", type=float, default=1.0)
+    ap.add_argument("--quirks-off", action="store_true",
+                    help="ShmRenderParams::disable_reference_quirks: PBRT-v4's forms of the reference's deviations (emitter sampling, instancing, ...: DESIGN.md section 2) "
+                         "instead of the reference-exact default")
     ap.add_argument("-o", "--output", default="")
     args = ap.parse_args()
     lib = abi.load_library()
@@ -72,7 +75,7 @@ def main():
     w, h = args.res, args.height or args.res
     sc = make_scene(lib, args.scene, w, h)
     r = render.Renderer(lib, sc.desc, 0)
-    p = render.make_params(seed=args.seed, spp=args.spp, max_depth=args.max_depth, integrator=args.integrator)
+    p = render.make_params(seed=args.seed, spp=args.spp, max_depth=args.max_depth, integrator=args.integrator, reference_quirks=not args.quirks_off)
     r.clear()
     t0 = time.perf_counter()
     st = r.render_device(p)
