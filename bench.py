@@ -224,9 +224,9 @@ def side_results(lib, args, render, scenes, headline_scene, log):
     import ctypes as C
     out = {}
 
-    def timed(name, desc, spp, depth, prims):
+    def timed(name, desc, spp, depth, prims, **params):
         r = render.Renderer(lib, desc, device=0)
-        p = render.make_params(seed=0, spp=spp, max_depth=depth)
+        p = render.make_params(seed=0, spp=spp, max_depth=depth, **params)
         r.clear()
         r.render_device(p)
         frames = []
@@ -244,6 +244,9 @@ def side_results(lib, args, render, scenes, headline_scene, log):
 
     try:
         # S3 with the object's material switched to CoatedDiffuse in place (the reference's Ganesha render uses it): same geometry, BVH
+        # the headline frame with ShmRenderParams::disable_reference_quirks (PBRT-v4's forms of the reference's deviations): the same kernels, the
+        # same speed — the switch costs a host nothing
+        timed("S3_reference_quirks_off_1024x1024_spp256", headline_scene.desc, 256, args.max_depth, headline_scene.info["n_primitives"], reference_quirks=False)
         b = headline_scene.builder
         tmp = type(b)()
         tmp.material_coated_diffuse(reflectance=0.4, roughness=0.05, thickness=0.01)
